@@ -1,0 +1,118 @@
+"""ctypes binding of libdfvo_hip.so -- one Python function table, no compute here.
+
+The product path has NO CPU fallback: if the shared library is missing or a call fails, a
+``DfvoError`` is raised (the -m gpu tests and the driver rely on that).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import LIB_PATH
+
+
+class DfvoError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in (
+        "N", "H", "W", "kh", "kw", "stride", "pad_h", "pad_w", "pad_mode",
+        "c0", "cs0", "co0", "up0", "c1", "cs1", "co1", "cout", "act")] + [
+        ("act_param", C.c_float)] + [(n, C.c_int) for n in ("res_cs", "res_co", "dst_cs", "dst_co")]
+
+
+_vp, _i, _f, _d, _sz = C.c_void_p, C.c_int, C.c_float, C.c_double, C.c_size_t
+_ip = C.POINTER(C.c_int)
+
+# name -> (restype, argtypes); every symbol declared in include/dfvo_hip.h must be listed here
+SIGNATURES = {
+    "dfvo_last_error": (C.c_char_p, []),
+    "dfvo_device_count": (_i, []),
+    "dfvo_set_device": (_i, [_i]),
+    "dfvo_sync_device": (_i, []),
+    "dfvo_malloc": (_i, [C.POINTER(_vp), _sz]),
+    "dfvo_free": (_i, [_vp]),
+    "dfvo_memcpy_h2d": (_i, [_vp, _vp, _sz]),
+    "dfvo_memcpy_d2h": (_i, [_vp, _vp, _sz]),
+    "dfvo_conv2d": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dfvo_correlation": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
+    "dfvo_backward_warp": (_i, [_vp, _vp, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "dfvo_deconv_dw4x4s2": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "dfvo_resize_bilinear": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
+    "dfvo_flownet_create": (_i, [_i, _i, _vp, C.POINTER(_vp)]),
+    "dfvo_flownet_destroy": (None, [_vp]),
+    "dfvo_flownet_set_param": (_i, [_vp, C.c_char_p, _vp, _i, _ip]),
+    "dfvo_flownet_finalize": (_i, [_vp]),
+    "dfvo_flownet_net_size": (_i, [_vp, _ip, _ip]),
+    "dfvo_flownet_set_graph": (_i, [_vp, _i]),
+    "dfvo_flownet_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "dfvo_flownet_forward_host": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "dfvo_flownet_last_flops": (_d, [_vp]),
+    "dfvo_flownet_get_level_flow": (_i, [_vp, _i, _vp, _ip, _ip]),
+    "dfvo_flownet_sync": (_i, [_vp]),
+    "dfvo_depthnet_create": (_i, [_i, _i, _f, _f, _f, _vp, C.POINTER(_vp)]),
+    "dfvo_depthnet_destroy": (None, [_vp]),
+    "dfvo_depthnet_set_param": (_i, [_vp, C.c_char_p, _vp, _i, _ip]),
+    "dfvo_depthnet_finalize": (_i, [_vp]),
+    "dfvo_depthnet_set_graph": (_i, [_vp, _i]),
+    "dfvo_depthnet_forward": (_i, [_vp, _vp, _vp]),
+    "dfvo_depthnet_forward_host": (_i, [_vp, _vp, _vp]),
+    "dfvo_depthnet_last_flops": (_d, [_vp]),
+    "dfvo_depthnet_sync": (_i, [_vp]),
+    "dfvo_depth_postprocess": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
+}
+
+
+def lib():
+    """Load (once) and return the ctypes library; raises DfvoError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DfvoError(
+            "libdfvo_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'`. "
+            "There is no CPU fallback." % LIB_PATH)
+    try:
+        l = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise DfvoError("cannot load %s: %s" % (LIB_PATH, e))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(l, name)
+        except AttributeError:
+            raise DfvoError("libdfvo_hip.so does not export %s (stale build?)" % name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().dfvo_last_error()
+        raise DfvoError("libdfvo_hip call failed (%d): %s" % (rc, msg.decode() if msg else "?"))
+
+
+def require_gpu():
+    if lib().dfvo_device_count() < 1:
+        raise DfvoError("no HIP device visible: the DF-VO hot path has no CPU fallback")
+
+
+def as_ptr(a):
+    """host pointer of a C-contiguous numpy array (or None)"""
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def set_params(setter, handle, tensors):
+    """push a {name: array-like} dict through dfvo_*_set_param"""
+    for name, t in tensors.items():
+        a = np.ascontiguousarray(np.asarray(t, dtype=np.float32))
+        shape = (C.c_int * max(a.ndim, 1))(*a.shape)
+        check(setter(handle, name.encode(), as_ptr(a), a.ndim, shape))

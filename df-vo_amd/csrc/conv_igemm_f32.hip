@@ -1,0 +1,308 @@
+// Implicit-GEMM convolution on the gfx950 matrix cores, exact fp32 numerics.
+//
+// Replaces the torch.nn.Conv2d (+bias, +LeakyReLU/ReLU/ELU/sigmoid, +residual, +BatchNorm(eval),
+// +ReflectionPad2d, +nearest x2 upsample, +channel concat) call sites of the reference's nets:
+//   LiteFlowNet  /root/reference/libs/deep_models/flow/lite_flow_net/lite_flow_net.py:39-75,98-101,
+//                121-129,164-179,204-240
+//   monodepth2   /root/reference/libs/deep_models/depth/monodepth2/resnet_encoder.py:87-98,
+//                depth_decoder.py:29-65, layers.py:106-136,347-350
+//
+// GEMM view: M = N*Ho*Wo output pixels, N = cout, K = kh*kw*(c0+c1) walked in "k-groups" of 4
+// channels (one 16-byte NHWC load) and K-steps of 4 groups.  The contraction runs on
+// v_mfma_f32_16x16x4_f32 (f32 in / f32 accumulate: bit-for-bit an fmaf chain, 157 TF peak).
+// A lane (i = lane&15, kq = lane>>4) holds 4 consecutive channels of k-group kq for pixel i in one
+// float4; MFMA #r of a K-step consumes component r of the A and of the B fragment, so the four
+// MFMAs together cover the 16 k-values of the step (the k permutation is the same on both sides).
+//
+// Tiles: a 256-thread block (4 wave64) computes BM x BN = (WM*TM*16) x (WN*TN*16); A (pixels x 16 k)
+// and B (16 k x couts) tiles are staged global -> registers -> LDS with the next step's loads in
+// flight under the current step's MFMAs.  The LDS A image is XOR-swizzled on the k-group so the four
+// 16-lane service groups of ds_read_b128 each hit 16 distinct 16-byte slots.
+#include "dfvo_common.h"
+
+#include <algorithm>
+#include <vector>
+
+namespace dfvo {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float apply_act(float v, int act, float a) {
+    switch (act) {
+        case ACT_LEAKY: return v > 0.f ? v : v * a;
+        case ACT_RELU: return v > 0.f ? v : 0.f;
+        case ACT_ELU: return v > 0.f ? v : a * expm1f(v);
+        case ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        default: return v;
+    }
+}
+
+__device__ __forceinline__ int reflect_idx(int i, int n) {
+    i = i < 0 ? -i : i;
+    return i >= n ? 2 * n - 2 - i : i;
+}
+
+__device__ __forceinline__ f32x4 conv_load_a(const ConvParams& p, int n, int iy0, int ix0, bool vm, int g,
+                                             int G, int taps) {
+    const int tap = g / G;
+    const int cg = g - tap * G;
+    const int ky = tap / p.kw;
+    const int kx = tap - ky * p.kw;
+    int iy = iy0 + ky, ix = ix0 + kx;
+    bool v = vm && (tap < taps);
+    if (p.pad_mode == PAD_REFLECT) {
+        iy = reflect_idx(iy, p.H);
+        ix = reflect_idx(ix, p.W);
+    } else {
+        v = v && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+    }
+    f32x4 r = {0.f, 0.f, 0.f, 0.f};
+    if (v) {
+        if (cg < p.G0) {
+            int yy = iy, xx = ix, HH = p.H, WW = p.W;
+            if (p.up0) {
+                yy >>= 1;
+                xx >>= 1;
+                HH >>= 1;
+                WW >>= 1;
+            }
+            r = *reinterpret_cast<const f32x4*>(p.src0 + ((size_t)(n * HH + yy) * WW + xx) * p.cs0 + p.co0 +
+                                                cg * 4);
+        } else {
+            r = *reinterpret_cast<const f32x4*>(p.src1 + ((size_t)(n * p.H + iy) * p.W + ix) * p.cs1 + p.co1 +
+                                                (cg - p.G0) * 4);
+        }
+    }
+    return r;
+}
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p) {
+    constexpr int BM = WM * TM * 16;
+    constexpr int BN = WN * TN * 16;
+    constexpr int A_CNT = (BM * 4 + 255) / 256;
+    constexpr int B_CNT = (BN * 4 + 255) / 256;
+    static_assert(WM * WN == 4, "4 waves per block");
+    __shared__ __attribute__((aligned(16))) float lds[BM * 16 + BN * 16];
+    float* As = lds;
+    float* Bs = lds + BM * 16;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = t >> 6;
+    const int wm = wave / WN;
+    const int wn = wave % WN;
+
+    // XCD-aware tile order: consecutive block ids land on different XCDs (id % 8), so give each XCD
+    // a contiguous run of M-tiles (neighbouring tiles share conv halo rows in that XCD's L2).
+    const int nb = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = nb >> 3, r = nb & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int m0 = bid * BM;
+    const int n0 = blockIdx.y * BN;
+    const int M = p.N * p.Ho * p.Wo;
+    const int G = p.G0 + p.G1;
+    const int taps = p.kh * p.kw;
+
+    // per-thread A staging slots
+    int a_n[A_CNT], a_iy0[A_CNT], a_ix0[A_CNT];
+    bool a_vm[A_CNT];
+#pragma unroll
+    for (int r = 0; r < A_CNT; ++r) {
+        const int id = t + 256 * r;
+        const int m = m0 + (id >> 2);
+        const bool vm = (id < BM * 4) && (m < M);
+        const int mm = vm ? m : 0;
+        const int n = mm / (p.Ho * p.Wo);
+        const int rem = mm - n * (p.Ho * p.Wo);
+        const int oy = rem / p.Wo;
+        const int ox = rem - oy * p.Wo;
+        a_n[r] = n;
+        a_iy0[r] = oy * p.stride - p.pad_h;
+        a_ix0[r] = ox * p.stride - p.pad_w;
+        a_vm[r] = vm;
+    }
+
+    f32x4 ra[A_CNT], rb[B_CNT];
+    auto load_step = [&](int s) {
+#pragma unroll
+        for (int r = 0; r < A_CNT; ++r) {
+            const int id = t + 256 * r;
+            ra[r] = conv_load_a(p, a_n[r], a_iy0[r], a_ix0[r], a_vm[r], 4 * s + (id & 3), G, taps);
+        }
+#pragma unroll
+        for (int r = 0; r < B_CNT; ++r) {
+            const int id = t + 256 * r;
+            if (id < BN * 4) {
+                const int gi = id / BN, j = id - gi * BN;
+                rb[r] = *reinterpret_cast<const f32x4*>(p.wp + ((size_t)(4 * s + gi) * p.cout_pad + n0 + j) * 4);
+            }
+        }
+    };
+    auto store_step = [&]() {
+#pragma unroll
+        for (int r = 0; r < A_CNT; ++r) {
+            const int id = t + 256 * r;
+            if (id < BM * 4) {
+                const int m = id >> 2, gi = id & 3;
+                const int gs = gi ^ (((m >> 3) & 1) << 1);
+                *reinterpret_cast<f32x4*>(As + m * 16 + gs * 4) = ra[r];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < B_CNT; ++r) {
+            const int id = t + 256 * r;
+            if (id < BN * 4) *reinterpret_cast<f32x4*>(Bs + id * 4) = rb[r];
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int li = lane & 15, kq = lane >> 4;
+    load_step(0);
+    store_step();
+    __syncthreads();
+    for (int s = 0; s < p.ksteps; ++s) {
+        const bool more = (s + 1 < p.ksteps);
+        if (more) load_step(s + 1);
+        f32x4 fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = wm * TM * 16 + i * 16 + li;
+            const int gs = kq ^ (((m >> 3) & 1) << 1);
+            fa[i] = *reinterpret_cast<const f32x4*>(As + m * 16 + gs * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int c = wn * TN * 16 + j * 16 + li;
+            fb[j] = *reinterpret_cast<const f32x4*>(Bs + (kq * BN + c) * 4);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][r], fb[j][r], acc[i][j], 0, 0, 0);
+        __syncthreads();
+        if (more) store_step();
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout col = lane&15, row = (lane>>4)*4 + reg
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * TN * 16 + j * 16 + li;
+        const bool vcol = col < p.cout;
+        const bool zcol = !vcol && col < p.dst_zero_to;
+        const float b = vcol ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + wm * TM * 16 + i * 16 + kq * 4 + r;
+                if (m < M) {
+                    if (vcol) {
+                        float v = acc[i][j][r] + b;
+                        if (p.res) v += p.res[(size_t)m * p.res_cs + p.res_co + col];
+                        v = apply_act(v, p.act, p.act_param);
+                        p.dst[(size_t)m * p.dst_cs + p.dst_co + col] = v;
+                    } else if (zcol) {
+                        p.dst[(size_t)m * p.dst_cs + p.dst_co + col] = 0.f;
+                    }
+                }
+            }
+        }
+    }
+}
+
+int conv_pick_bn(int cout, long long M) {
+    (void)M;
+    if (cout <= 16) return 16;
+    if (cout <= 32) return 32;
+    if (cout % 128 == 0) return 128;
+    if (cout % 64 == 0) return 64;
+    if (cout % 32 == 0) return 32;  // 96 -> 3 x 32
+    return 64;                      // 49 -> 64
+}
+
+void conv_pack_weights(const float* w, const float* bias, int cout, int c0, int c1, int kh, int kw, int cout_pad,
+                       const float* fold_scale, const float* fold_shift, float* out_w, float* out_b) {
+    const int G0 = cdiv(c0, 4), G1 = cdiv(c1, 4), G = G0 + G1;
+    const int taps = kh * kw;
+    const int ksteps = cdiv(taps * G, 4);
+    const int cin = c0 + c1;
+    std::fill(out_w, out_w + (size_t)ksteps * 4 * cout_pad * 4, 0.f);
+    for (int tap = 0; tap < taps; ++tap) {
+        const int ky = tap / kw, kx = tap % kw;
+        for (int cg = 0; cg < G; ++cg) {
+            const int g = tap * G + cg;
+            for (int q = 0; q < 4; ++q) {
+                int ci;
+                if (cg < G0) {
+                    ci = cg * 4 + q;
+                    if (ci >= c0) continue;
+                } else {
+                    ci = (cg - G0) * 4 + q;
+                    if (ci >= c1) continue;
+                    ci += c0;
+                }
+                for (int o = 0; o < cout; ++o) {
+                    float v = w[(((size_t)o * cin + ci) * kh + ky) * kw + kx];
+                    if (fold_scale) v *= fold_scale[o];
+                    out_w[((size_t)g * cout_pad + o) * 4 + q] = v;
+                }
+            }
+        }
+    }
+    for (int o = 0; o < cout_pad; ++o) {
+        float b = 0.f;
+        if (o < cout) {
+            b = bias ? bias[o] : 0.f;
+            if (fold_scale) b *= fold_scale[o];
+            if (fold_shift) b += fold_shift[o];
+        }
+        out_b[o] = b;
+    }
+}
+
+template <int WM, int WN, int TM, int TN>
+static int launch_cfg(const ConvParams& p, hipStream_t stream) {
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+    const long long M = (long long)p.N * p.Ho * p.Wo;
+    dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(p.cout_pad / BN), 1);
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<WM, WN, TM, TN>), grid, dim3(256), 0, stream, p);
+    DFVO_HIP_CHECK(hipGetLastError());
+    return DFVO_OK;
+}
+
+int launch_conv(const ConvParams& p, hipStream_t stream) {
+    const long long M = (long long)p.N * p.Ho * p.Wo;
+    const int bn = conv_pick_bn(p.cout, M);
+    DFVO_ARG_CHECK(p.cout_pad % bn == 0, "launch_conv: cout_pad not a multiple of the N tile");
+    DFVO_ARG_CHECK((p.cs0 % 4) == 0 && (p.co0 % 4) == 0, "launch_conv: src0 stride/offset must be multiples of 4");
+    DFVO_ARG_CHECK(p.G1 == 0 || ((p.cs1 % 4) == 0 && (p.co1 % 4) == 0), "launch_conv: src1 stride/offset");
+    if (bn == 128) {
+        if (M <= 4096) return launch_cfg<1, 4, 2, 2>(p, stream);  // 32 x 128: more blocks for small maps
+        return launch_cfg<2, 2, 4, 4>(p, stream);                 // 128 x 128
+    }
+    if (bn == 64) {
+        if (M <= 8192) return launch_cfg<2, 2, 2, 2>(p, stream);  // 64 x 64
+        return launch_cfg<4, 1, 4, 4>(p, stream);                 // 256 x 64
+    }
+    if (bn == 32) {
+        if (M <= 8192) return launch_cfg<2, 2, 2, 1>(p, stream);  // 64 x 32
+        return launch_cfg<4, 1, 4, 2>(p, stream);                 // 256 x 32
+    }
+    if (M <= 8192) return launch_cfg<4, 1, 1, 1>(p, stream);      // 64 x 16
+    return launch_cfg<4, 1, 4, 1>(p, stream);                     // 256 x 16
+}
+
+}  // namespace dfvo

@@ -1,0 +1,87 @@
+// Shared internal declarations for libdfvo_hip.so (gfx950 only).
+// Activations are NHWC float32; "cs" = floats per pixel of the underlying
+// buffer, "co" = channel offset of the view inside the pixel.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/dfvo_hip.h"
+
+namespace dfvo {
+
+void set_last_error(const std::string& s);
+const char* last_error();
+
+#define DFVO_HIP_CHECK(expr)                                                        \
+    do {                                                                            \
+        hipError_t _e = (expr);                                                     \
+        if (_e != hipSuccess) {                                                     \
+            dfvo::set_last_error(std::string(#expr) + ": " + hipGetErrorString(_e)); \
+            return DFVO_ERR_HIP;                                                    \
+        }                                                                           \
+    } while (0)
+
+#define DFVO_ARG_CHECK(cond, msg)                   \
+    do {                                            \
+        if (!(cond)) {                              \
+            dfvo::set_last_error(std::string(msg)); \
+            return DFVO_ERR_ARG;                    \
+        }                                           \
+    } while (0)
+
+enum Act { ACT_NONE = 0, ACT_LEAKY = 1, ACT_RELU = 2, ACT_ELU = 3, ACT_SIGMOID = 4 };
+enum PadMode { PAD_ZERO = 0, PAD_REFLECT = 1 };
+
+// Implicit-GEMM convolution parameters (device-visible, passed by value).
+struct ConvParams {
+    // logical input spatial dims the taps index into (after optional x2 nearest upsample of src0)
+    int N, H, W;
+    int Ho, Wo;
+    int kh, kw, stride, pad_h, pad_w;
+    int pad_mode;
+    // source 0: c0 logical channels, G0 = ceil(c0/4) k-groups per tap
+    const float* src0;
+    int G0, cs0, co0, up0;
+    // source 1 (optional; G1 == 0 when absent)
+    const float* src1;
+    int G1, cs1, co1;
+    // packed weights [ksteps*4][cout_pad][4], bias[cout_pad]
+    const float* wp;
+    const float* bias;
+    int cout, cout_pad, ksteps;
+    // optional residual (added before activation)
+    const float* res;
+    int res_cs, res_co;
+    int act;
+    float act_param;
+    float* dst;
+    int dst_cs, dst_co;
+    // when != 0 the epilogue also zero-fills channels [cout, dst_zero_to) of dst
+    int dst_zero_to;
+};
+
+static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// number of K-steps (16 k-values = 4 groups of 4 channels) for a conv
+static inline int conv_ksteps(int kh, int kw, int c0, int c1) {
+    int G = cdiv(c0, 4) + cdiv(c1, 4);
+    return cdiv(kh * kw * G, 4);
+}
+// N-tile (BN) the launcher will use for a given cout; cout_pad is a multiple of it
+int conv_pick_bn(int cout, long long M);
+static inline int conv_cout_pad(int cout, long long M) {
+    int bn = conv_pick_bn(cout, M);
+    return round_up(cout, bn);
+}
+// Pack OIHW weights (cin = c0 + c1) into the kernel layout. `out` must hold
+// conv_ksteps*4*cout_pad*4 floats. fold_scale/fold_shift (per-cout, may be null)
+// implement eval-mode BatchNorm folding: w' = w*scale, b' = b*scale + shift.
+void conv_pack_weights(const float* w_oihw, const float* bias, int cout, int c0, int c1, int kh, int kw,
+                       int cout_pad, const float* fold_scale, const float* fold_shift, float* out_w,
+                       float* out_b);
+
+int launch_conv(const ConvParams& p, hipStream_t stream);
+
+}  // namespace dfvo

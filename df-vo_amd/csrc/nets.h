@@ -1,0 +1,122 @@
+// Host-side executors of the two CNNs: own every device buffer, pack weights once, replay a fixed
+// launch sequence on one HIP stream (captured into a hipGraph after the first run).
+#pragma once
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "dfvo_common.h"
+
+namespace dfvo {
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int> shape;
+};
+
+struct DevBuf {
+    float* p = nullptr;
+    size_t n = 0;
+    int alloc(size_t floats);  // zero-filled
+    void release();
+};
+
+struct ConvLayer {
+    float* wp = nullptr;
+    float* bias = nullptr;
+    int cout = 0, cout_pad = 0, c0 = 0, c1 = 0, kh = 0, kw = 0, ksteps = 0;
+    int stride = 1, pad_h = 0, pad_w = 0, pad_mode = PAD_ZERO, act = ACT_NONE;
+    float act_param = 0.f;
+    double macs_per_pixel() const { return (double)cout * (c0 + c1) * kh * kw; }
+};
+
+struct ParamStore {
+    std::map<std::string, HostTensor> t;
+    const HostTensor* get(const std::string& name) const;
+};
+
+// builds + uploads a conv layer from OIHW weights; scale/shift fold an eval BatchNorm
+int make_conv(const ParamStore& ps, const std::string& wname, const std::string& bname, int c0, int c1,
+              long long M_hint, const float* scale, const float* shift, ConvLayer* out);
+void free_conv(ConvLayer* l);
+
+struct View {
+    const float* p;
+    int cs, co;
+};
+
+int run_conv(const ConvLayer& L, int N, int H, int W, View s0, int up0, View s1, const float* res, int res_cs,
+             int res_co, float* dst, int dst_cs, int dst_co, int dst_zero_to, hipStream_t s, double* flops);
+
+// ------------------------------------------------------------------------------------------------
+struct FlowNet {
+    int imgH = 0, imgW = 0;  // cfg image size
+    int H = 0, W = 0;        // net size (multiple of 32), deep_flow.py:89-105
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    ParamStore params;
+    bool finalized = false;
+
+    // per level l = 1..6 (index l)
+    int lh[7], lw[7], lc[7];
+    DevBuf img[7], feat[7];
+    DevBuf lin_x[7], lin_y[7];
+    std::vector<ConvLayer> feat_convs;  // 12 convs of Features
+    struct Level {
+        ConvLayer m_feat, m_main[4], s_feat, s_main[4], r_feat, r_main[6], r_dist[2];
+        bool has_mfeat = false, has_upflow = false, has_upcorr = false, has_rfeat = false, dist_sep = false;
+        DevBuf upflow_w, upcorr_w, scale_wx, scale_wy;
+        float scale_bx = 0.f, scale_by = 0.f;
+        // activations
+        DevBuf mfeat, sfeat, rfeat, flow_up, warped, corr, corr_up, x128, x64, x32, x128b, x64b, x32b, flowM, b1,
+            flowS, r0, dist_a, dist_b, flow, mean;
+    } lv[7];
+    DevBuf u8_ref, u8_cur;  // staging for the host-pointer entry point
+    DevBuf out_fwd, out_bwd, out_diff;
+    double flops_last = 0.0;  // useful conv+corr FLOPs of the last forward (2*MAC)
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    const uint8_t* graph_ref = nullptr;
+    const uint8_t* graph_cur = nullptr;
+    float *graph_fwd = nullptr, *graph_bwd = nullptr, *graph_diff = nullptr;
+    bool use_graph = true;
+
+    int init(int imgH, int imgW, hipStream_t s);
+    int finalize();
+    int forward(const uint8_t* d_ref, const uint8_t* d_cur, float* d_fwd, float* d_bwd, float* d_diff);
+    int enqueue(const uint8_t* d_ref, const uint8_t* d_cur, float* d_fwd, float* d_bwd, float* d_diff);
+    void destroy();
+};
+
+struct DepthNet {
+    int H = 0, W = 0;  // feed size
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    ParamStore params;
+    bool finalized = false;
+    float min_depth = 0.1f, max_depth = 100.f, baseline_mult = 5.4f;
+
+    ConvLayer conv1;
+    struct Block {
+        ConvLayer c1, c2, ds;
+        bool has_ds = false;
+    } blocks[8];
+    ConvLayer up[5][2], dispconv;
+    DevBuf x0, f0, pool, tmp[4], feat[5], blk_t, blk_ds, blk_o[2], du[5], dx[5], disp, depth;
+    DevBuf u8_in;
+    double flops_last = 0.0;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    const uint8_t* graph_in = nullptr;
+    float* graph_out = nullptr;
+    bool use_graph = true;
+
+    int init(int feedH, int feedW, hipStream_t s);
+    int finalize();
+    int forward(const uint8_t* d_img, float* d_depth);
+    int enqueue(const uint8_t* d_img, float* d_depth);
+    void destroy();
+};
+
+}  // namespace dfvo

@@ -1,0 +1,786 @@
+// LiteFlowNet and monodepth2 (ResNet18 + skip decoder) forward executors.
+// Structure restated from /root/reference/libs/deep_models/flow/lite_flow_net/lite_flow_net.py:31-325,
+// flow/lite_flow_net/lite_flow.py:55-148, flow/deep_flow.py:89-196,
+// depth/monodepth2/{resnet_encoder.py:87-98, depth_decoder.py:17-65, monodepth2.py:91-139}.
+#include "nets.h"
+
+#include <cmath>
+#include <cstring>
+
+#include "ops.h"
+
+namespace dfvo {
+
+int DevBuf::alloc(size_t floats) {
+    release();
+    n = floats;
+    DFVO_HIP_CHECK(hipMalloc((void**)&p, floats * sizeof(float)));
+    DFVO_HIP_CHECK(hipMemset(p, 0, floats * sizeof(float)));
+    return DFVO_OK;
+}
+void DevBuf::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    n = 0;
+}
+
+const HostTensor* ParamStore::get(const std::string& name) const {
+    auto it = t.find(name);
+    return it == t.end() ? nullptr : &it->second;
+}
+
+#define DFVO_TRY(expr)                   \
+    do {                                 \
+        int _rc = (expr);                \
+        if (_rc != DFVO_OK) return _rc;  \
+    } while (0)
+
+static int upload(const std::vector<float>& h, DevBuf* d) {
+    DFVO_TRY(d->alloc(h.size()));
+    DFVO_HIP_CHECK(hipMemcpy(d->p, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    return DFVO_OK;
+}
+
+int make_conv(const ParamStore& ps, const std::string& wname, const std::string& bname, int c0, int c1,
+              long long M_hint, const float* scale, const float* shift, ConvLayer* L) {
+    const HostTensor* w = ps.get(wname);
+    if (!w) {
+        set_last_error("missing parameter " + wname);
+        return DFVO_ERR_STATE;
+    }
+    DFVO_ARG_CHECK(w->shape.size() == 4, "conv weight must be 4-D: " + wname);
+    const HostTensor* b = bname.empty() ? nullptr : ps.get(bname);
+    if (!bname.empty() && !b) {
+        set_last_error("missing parameter " + bname);
+        return DFVO_ERR_STATE;
+    }
+    L->cout = w->shape[0];
+    DFVO_ARG_CHECK(w->shape[1] == c0 + c1, "conv weight cin mismatch: " + wname);
+    L->c0 = c0;
+    L->c1 = c1;
+    L->kh = w->shape[2];
+    L->kw = w->shape[3];
+    L->cout_pad = conv_cout_pad(L->cout, M_hint);
+    L->ksteps = conv_ksteps(L->kh, L->kw, c0, c1);
+    std::vector<float> pw((size_t)L->ksteps * 4 * L->cout_pad * 4), pb(L->cout_pad);
+    conv_pack_weights(w->data.data(), b ? b->data.data() : nullptr, L->cout, c0, c1, L->kh, L->kw, L->cout_pad,
+                      scale, shift, pw.data(), pb.data());
+    DFVO_HIP_CHECK(hipMalloc((void**)&L->wp, pw.size() * sizeof(float)));
+    DFVO_HIP_CHECK(hipMalloc((void**)&L->bias, pb.size() * sizeof(float)));
+    DFVO_HIP_CHECK(hipMemcpy(L->wp, pw.data(), pw.size() * sizeof(float), hipMemcpyHostToDevice));
+    DFVO_HIP_CHECK(hipMemcpy(L->bias, pb.data(), pb.size() * sizeof(float), hipMemcpyHostToDevice));
+    return DFVO_OK;
+}
+
+void free_conv(ConvLayer* l) {
+    if (l->wp) (void)hipFree(l->wp);
+    if (l->bias) (void)hipFree(l->bias);
+    l->wp = l->bias = nullptr;
+}
+
+int run_conv(const ConvLayer& L, int N, int H, int W, View s0, int up0, View s1, const float* res, int res_cs,
+             int res_co, float* dst, int dst_cs, int dst_co, int dst_zero_to, hipStream_t s, double* flops) {
+    ConvParams p;
+    memset(&p, 0, sizeof(p));
+    p.N = N;
+    p.H = H;
+    p.W = W;
+    p.kh = L.kh;
+    p.kw = L.kw;
+    p.stride = L.stride;
+    p.pad_h = L.pad_h;
+    p.pad_w = L.pad_w;
+    p.pad_mode = L.pad_mode;
+    p.Ho = (H + 2 * L.pad_h - L.kh) / L.stride + 1;
+    p.Wo = (W + 2 * L.pad_w - L.kw) / L.stride + 1;
+    p.src0 = s0.p;
+    p.G0 = cdiv(L.c0, 4);
+    p.cs0 = s0.cs;
+    p.co0 = s0.co;
+    p.up0 = up0;
+    p.src1 = s1.p;
+    p.G1 = cdiv(L.c1, 4);
+    p.cs1 = s1.cs;
+    p.co1 = s1.co;
+    p.wp = L.wp;
+    p.bias = L.bias;
+    p.cout = L.cout;
+    p.cout_pad = L.cout_pad;
+    p.ksteps = L.ksteps;
+    p.res = res;
+    p.res_cs = res_cs;
+    p.res_co = res_co;
+    p.act = L.act;
+    p.act_param = L.act_param;
+    p.dst = dst;
+    p.dst_cs = dst_cs;
+    p.dst_co = dst_co;
+    p.dst_zero_to = dst_zero_to;
+    if (flops) *flops += 2.0 * (double)N * p.Ho * p.Wo * L.macs_per_pixel();
+    return launch_conv(p, s);
+}
+
+// torch.linspace(-1, 1, n) fallback (the Python host normally uploads torch's own table, see capi)
+static std::vector<float> linspace_pm1(int n) {
+    std::vector<float> v(n);
+    if (n == 1) {
+        v[0] = -1.f;
+        return v;
+    }
+    const float start = -1.f, end = 1.f;
+    const float step = (end - start) / (float)(n - 1);
+    const int half = n / 2;
+    for (int i = 0; i < n; ++i) v[i] = i < half ? start + step * (float)i : end - step * (float)(n - i - 1);
+    return v;
+}
+
+// ================================================================================================
+// LiteFlowNet
+// ================================================================================================
+static const float kDbl[7] = {0.f, 0.f, 10.f, 5.f, 2.5f, 1.25f, 0.625f};
+static const int kKer[7] = {0, 0, 7, 5, 5, 3, 3};
+static const int kFeatC[7] = {0, 32, 32, 64, 96, 128, 192};
+
+static void target_size(int h, int w, int* th, int* tw) {
+    // deep_flow.py:89-105
+    const int hs[2] = {32 * (h / 32), 32 * (h / 32 + 1)};
+    const int ws[2] = {32 * (w / 32), 32 * (w / 32 + 1)};
+    double best = 1e300;
+    int bi = 0;
+    for (int i = 0; i < 4; ++i) {
+        const double r = std::fabs((double)hs[i / 2] * (1.0 / (double)ws[i % 2]) - (double)h / (double)w);
+        if (r < best) {
+            best = r;
+            bi = i;
+        }
+    }
+    *th = hs[bi / 2];
+    *tw = ws[bi % 2];
+}
+
+int FlowNet::init(int imgH_, int imgW_, hipStream_t s) {
+    imgH = imgH_;
+    imgW = imgW_;
+    target_size(imgH, imgW, &H, &W);
+    DFVO_ARG_CHECK(H >= 64 && W >= 64, "FlowNet: image too small");
+    if (s) {
+        stream = s;
+    } else {
+        DFVO_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        own_stream = true;
+    }
+    for (int l = 1; l <= 6; ++l) {
+        lh[l] = H >> (l - 1);
+        lw[l] = W >> (l - 1);
+        lc[l] = kFeatC[l];
+    }
+    return DFVO_OK;
+}
+
+static std::string lvl_name(const char* mod, int l, const std::string& rest) {
+    return std::string(mod) + "." + std::to_string(l - 2) + "." + rest;
+}
+
+int FlowNet::finalize() {
+    if (finalized) return DFVO_OK;
+    const int N = 2;
+    // ---- Features
+    struct FC { const char* name; int cin, stride, pad, level_in; };
+    const FC fcs[12] = {
+        {"moduleOne.0", 3, 1, 3, 1},   {"moduleTwo.0", 32, 2, 1, 1},  {"moduleTwo.2", 32, 1, 1, 2},
+        {"moduleTwo.4", 32, 1, 1, 2},  {"moduleThr.0", 32, 2, 1, 2},  {"moduleThr.2", 64, 1, 1, 3},
+        {"moduleFou.0", 64, 2, 1, 3},  {"moduleFou.2", 96, 1, 1, 4},  {"moduleFiv.0", 96, 2, 1, 4},
+        {"moduleSix.0", 128, 2, 1, 5},
+    };
+    feat_convs.resize(10);
+    for (int i = 0; i < 10; ++i) {
+        const std::string base = std::string("moduleFeatures.") + fcs[i].name;
+        const long long M = (long long)N * lh[fcs[i].level_in] * lw[fcs[i].level_in];
+        DFVO_TRY(make_conv(params, base + ".weight", base + ".bias", fcs[i].cin, 0, M, nullptr, nullptr,
+                           &feat_convs[i]));
+        feat_convs[i].stride = fcs[i].stride;
+        feat_convs[i].pad_h = feat_convs[i].pad_w = fcs[i].pad;
+        feat_convs[i].act = ACT_LEAKY;
+        feat_convs[i].act_param = 0.1f;
+    }
+    for (int l = 1; l <= 6; ++l) {
+        const size_t px = (size_t)N * lh[l] * lw[l];
+        DFVO_TRY(img[l].alloc(px * 4));
+        DFVO_TRY(feat[l].alloc(px * lc[l]));
+        const HostTensor* ox = params.get("aux.linspace_x." + std::to_string(l));
+        const HostTensor* oy = params.get("aux.linspace_y." + std::to_string(l));
+        DFVO_TRY(upload(ox && (int)ox->data.size() == lw[l] ? ox->data : linspace_pm1(lw[l]), &lin_x[l]));
+        DFVO_TRY(upload(oy && (int)oy->data.size() == lh[l] ? oy->data : linspace_pm1(lh[l]), &lin_y[l]));
+    }
+    // scratch for the Features chain (reuse level buffers): needs two temporaries per level
+    // ---- per level modules
+    for (int l = 6; l >= 2; --l) {
+        Level& L = lv[l];
+        const int h = lh[l], w = lw[l], C = lc[l], k = kKer[l], r = (k - 1) / 2;
+        const size_t px = (size_t)N * h * w;
+        const long long M = (long long)px;
+        auto leaky = [](ConvLayer& c, int pad_h, int pad_w) {
+            c.stride = 1;
+            c.pad_h = pad_h;
+            c.pad_w = pad_w;
+            c.act = ACT_LEAKY;
+            c.act_param = 0.1f;
+        };
+        auto linear = [](ConvLayer& c, int pad_h, int pad_w) {
+            c.stride = 1;
+            c.pad_h = pad_h;
+            c.pad_w = pad_w;
+            c.act = ACT_NONE;
+        };
+        L.has_mfeat = (l == 2);
+        L.has_upflow = (l != 6);
+        L.has_upcorr = (l < 4);
+        L.has_rfeat = (l < 5);
+        L.dist_sep = (l < 5);
+        const int Cm = L.has_mfeat ? 64 : C;
+        const int Cr = L.has_rfeat ? 128 : C;
+        // Matching
+        if (L.has_mfeat) {
+            DFVO_TRY(make_conv(params, lvl_name("moduleMatching", l, "moduleFeat.0.weight"),
+                               lvl_name("moduleMatching", l, "moduleFeat.0.bias"), C, 0, M, nullptr, nullptr,
+                               &L.m_feat));
+            leaky(L.m_feat, 0, 0);
+            DFVO_TRY(L.mfeat.alloc(px * 64));
+            DFVO_TRY(make_conv(params, lvl_name("moduleSubpixel", l, "moduleFeat.0.weight"),
+                               lvl_name("moduleSubpixel", l, "moduleFeat.0.bias"), C, 0, M, nullptr, nullptr,
+                               &L.s_feat));
+            leaky(L.s_feat, 0, 0);
+            DFVO_TRY(L.sfeat.alloc(px * 64));
+        }
+        if (L.has_upflow) {
+            const HostTensor* t = params.get(lvl_name("moduleMatching", l, "moduleUpflow.weight"));
+            if (!t || t->data.size() != 2 * 16) {
+                set_last_error("missing/invalid " + lvl_name("moduleMatching", l, "moduleUpflow.weight"));
+                return DFVO_ERR_STATE;
+            }
+            DFVO_TRY(upload(t->data, &L.upflow_w));
+            DFVO_TRY(L.flow_up.alloc(px * 4));
+            DFVO_TRY(L.warped.alloc(px * Cm));
+        }
+        if (L.has_upcorr) {
+            const HostTensor* t = params.get(lvl_name("moduleMatching", l, "moduleUpcorr.weight"));
+            if (!t || t->data.size() != 49 * 16) {
+                set_last_error("missing/invalid " + lvl_name("moduleMatching", l, "moduleUpcorr.weight"));
+                return DFVO_ERR_STATE;
+            }
+            DFVO_TRY(upload(t->data, &L.upcorr_w));
+            DFVO_TRY(L.corr.alloc((size_t)N * (h / 2) * (w / 2) * 52));
+            DFVO_TRY(L.corr_up.alloc(px * 52));
+        } else {
+            DFVO_TRY(L.corr.alloc(px * 52));
+        }
+        const int mcin[4] = {49, 128, 64, 32}, scin0[4] = {Cm, 128, 64, 32};
+        for (int i = 0; i < 4; ++i) {
+            const std::string idx = std::to_string(2 * i);
+            const int kk = (i == 3) ? k : 3, pp = (i == 3) ? r : 1;
+            DFVO_TRY(make_conv(params, lvl_name("moduleMatching", l, "moduleMain." + idx + ".weight"),
+                               lvl_name("moduleMatching", l, "moduleMain." + idx + ".bias"), mcin[i], 0, M, nullptr,
+                               nullptr, &L.m_main[i]));
+            DFVO_ARG_CHECK(L.m_main[i].kh == kk, "Matching main kernel size mismatch");
+            if (i < 3) leaky(L.m_main[i], pp, pp); else linear(L.m_main[i], pp, pp);
+            DFVO_TRY(make_conv(params, lvl_name("moduleSubpixel", l, "moduleMain." + idx + ".weight"),
+                               lvl_name("moduleSubpixel", l, "moduleMain." + idx + ".bias"), scin0[i],
+                               i == 0 ? Cm + 2 : 0, M, nullptr, nullptr, &L.s_main[i]));
+            if (i < 3) leaky(L.s_main[i], pp, pp); else linear(L.s_main[i], pp, pp);
+        }
+        DFVO_TRY(L.x128.alloc(px * 128));
+        DFVO_TRY(L.x64.alloc(px * 64));
+        DFVO_TRY(L.x32.alloc(px * 32));
+        DFVO_TRY(L.x128b.alloc(px * 128));
+        DFVO_TRY(L.x64b.alloc(px * 64));
+        DFVO_TRY(L.x32b.alloc(px * 32));
+        DFVO_TRY(L.flowM.alloc(px * 4));
+        DFVO_TRY(L.b1.alloc(px * (Cm + 4)));
+        DFVO_TRY(L.flowS.alloc(px * 4));
+        // Regularization
+        if (L.has_rfeat) {
+            DFVO_TRY(make_conv(params, lvl_name("moduleRegularization", l, "moduleFeat.0.weight"),
+                               lvl_name("moduleRegularization", l, "moduleFeat.0.bias"), C, 0, M, nullptr, nullptr,
+                               &L.r_feat));
+            leaky(L.r_feat, 0, 0);
+            DFVO_TRY(L.rfeat.alloc(px * 128));
+        }
+        const int rc0[6] = {3, 128, 128, 64, 64, 32}, rc1[6] = {Cr, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 6; ++i) {
+            const std::string idx = std::to_string(2 * i);
+            DFVO_TRY(make_conv(params, lvl_name("moduleRegularization", l, "moduleMain." + idx + ".weight"),
+                               lvl_name("moduleRegularization", l, "moduleMain." + idx + ".bias"), rc0[i], rc1[i], M,
+                               nullptr, nullptr, &L.r_main[i]));
+            leaky(L.r_main[i], 1, 1);
+        }
+        DFVO_TRY(make_conv(params, lvl_name("moduleRegularization", l, "moduleDist.0.weight"),
+                           lvl_name("moduleRegularization", l, "moduleDist.0.bias"), 32, 0, M, nullptr, nullptr,
+                           &L.r_dist[0]));
+        if (L.dist_sep) {
+            linear(L.r_dist[0], r, 0);
+            DFVO_TRY(make_conv(params, lvl_name("moduleRegularization", l, "moduleDist.1.weight"),
+                               lvl_name("moduleRegularization", l, "moduleDist.1.bias"), k * k, 0, M, nullptr,
+                               nullptr, &L.r_dist[1]));
+            linear(L.r_dist[1], 0, r);
+        } else {
+            linear(L.r_dist[0], r, r);
+        }
+        const HostTensor* sx = params.get(lvl_name("moduleRegularization", l, "moduleScaleX.weight"));
+        const HostTensor* sy = params.get(lvl_name("moduleRegularization", l, "moduleScaleY.weight"));
+        const HostTensor* bx = params.get(lvl_name("moduleRegularization", l, "moduleScaleX.bias"));
+        const HostTensor* by = params.get(lvl_name("moduleRegularization", l, "moduleScaleY.bias"));
+        if (!sx || !sy || !bx || !by || (int)sx->data.size() != k * k || (int)sy->data.size() != k * k) {
+            set_last_error("missing/invalid moduleScaleX/Y for level " + std::to_string(l));
+            return DFVO_ERR_STATE;
+        }
+        DFVO_TRY(upload(sx->data, &L.scale_wx));
+        DFVO_TRY(upload(sy->data, &L.scale_wy));
+        L.scale_bx = bx->data[0];
+        L.scale_by = by->data[0];
+        DFVO_TRY(L.r0.alloc(px * 4));
+        const int kkp = round_up(k * k, 4);
+        DFVO_TRY(L.dist_a.alloc(px * kkp));
+        DFVO_TRY(L.dist_b.alloc(px * kkp));
+        DFVO_TRY(L.flow.alloc(px * 4));
+        DFVO_TRY(L.mean.alloc(N * 2));
+    }
+    DFVO_TRY(out_fwd.alloc((size_t)2 * imgH * imgW));
+    DFVO_TRY(out_bwd.alloc((size_t)2 * imgH * imgW));
+    DFVO_TRY(out_diff.alloc((size_t)imgH * imgW));
+    DFVO_TRY(u8_ref.alloc(((size_t)imgH * imgW * 3 + 3) / 4 + 1));
+    DFVO_TRY(u8_cur.alloc(((size_t)imgH * imgW * 3 + 3) / 4 + 1));
+    finalized = true;
+    return DFVO_OK;
+}
+
+int FlowNet::enqueue(const uint8_t* d_ref, const uint8_t* d_cur, float* d_fwd, float* d_bwd, float* d_diff) {
+    const int N = 2;
+    hipStream_t s = stream;
+    double fl = 0.0;
+    const View none{nullptr, 0, 0};
+    // batch sample 0 = ref, sample 1 = cur: "first" = X[n], "second" = X[1-n]  (lite_flow.py:108-110)
+    const size_t img_px = (size_t)H * W;
+    DFVO_TRY(launch_img_u8_to_flow_input(d_ref, imgH, imgW, img[1].p, H, W, s));
+    DFVO_TRY(launch_img_u8_to_flow_input(d_cur, imgH, imgW, img[1].p + img_px * 4, H, W, s));
+    // image pyramid (lite_flow_net.py:307-309)
+    for (int l = 2; l <= 6; ++l)
+        DFVO_TRY(launch_resize_bilinear(img[l - 1].p, N, lh[l - 1], lw[l - 1], 4, img[l].p, lh[l], lw[l], 0, s));
+    // Features (lite_flow_net.py:78-86); temporaries borrowed from level-2/3/4 scratch
+    {
+        Level& L2 = lv[2];
+        Level& L3 = lv[3];
+        Level& L4 = lv[4];
+        DFVO_TRY(run_conv(feat_convs[0], N, lh[1], lw[1], View{img[1].p, 4, 0}, 0, none, nullptr, 0, 0, feat[1].p, 32, 0,
+                          0, s, &fl));
+        DFVO_TRY(run_conv(feat_convs[1], N, lh[1], lw[1], View{feat[1].p, 32, 0}, 0, none, nullptr, 0, 0, L2.x32.p, 32,
+                          0, 0, s, &fl));
+        DFVO_TRY(run_conv(feat_convs[2], N, lh[2], lw[2], View{L2.x32.p, 32, 0}, 0, none, nullptr, 0, 0, L2.x32b.p, 32,
+                          0, 0, s, &fl));
+        DFVO_TRY(run_conv(feat_convs[3], N, lh[2], lw[2], View{L2.x32b.p, 32, 0}, 0, none, nullptr, 0, 0, feat[2].p, 32,
+                          0, 0, s, &fl));
+        DFVO_TRY(run_conv(feat_convs[4], N, lh[2], lw[2], View{feat[2].p, 32, 0}, 0, none, nullptr, 0, 0, L3.x64.p, 64,
+                          0, 0, s, &fl));
+        DFVO_TRY(run_conv(feat_convs[5], N, lh[3], lw[3], View{L3.x64.p, 64, 0}, 0, none, nullptr, 0, 0, feat[3].p, 64,
+                          0, 0, s, &fl));
+        DFVO_TRY(run_conv(feat_convs[6], N, lh[3], lw[3], View{feat[3].p, 64, 0}, 0, none, nullptr, 0, 0, L4.x128.p, 96,
+                          0, 0, s, &fl));
+        DFVO_TRY(run_conv(feat_convs[7], N, lh[4], lw[4], View{L4.x128.p, 96, 0}, 0, none, nullptr, 0, 0, feat[4].p, 96,
+                          0, 0, s, &fl));
+        DFVO_TRY(run_conv(feat_convs[8], N, lh[4], lw[4], View{feat[4].p, 96, 0}, 0, none, nullptr, 0, 0, feat[5].p,
+                          128, 0, 0, s, &fl));
+        DFVO_TRY(run_conv(feat_convs[9], N, lh[5], lw[5], View{feat[5].p, 128, 0}, 0, none, nullptr, 0, 0, feat[6].p,
+                          192, 0, 0, s, &fl));
+    }
+    const float* flow_prev = nullptr;
+    for (int l = 6; l >= 2; --l) {
+        Level& L = lv[l];
+        const int h = lh[l], w = lw[l], C = lc[l], k = kKer[l];
+        const float dbl = kDbl[l];
+        const int Cm = L.has_mfeat ? 64 : C;
+        const int Cr = L.has_rfeat ? 128 : C;
+        const int kkp = round_up(k * k, 4);
+        // ------------------------------ Matching (lite_flow_net.py:132-152)
+        const float* mf = feat[l].p;
+        const float* sf = feat[l].p;
+        if (L.has_mfeat) {
+            DFVO_TRY(run_conv(L.m_feat, N, h, w, View{feat[l].p, C, 0}, 0, none, nullptr, 0, 0, L.mfeat.p, 64, 0, 0, s,
+                              &fl));
+            DFVO_TRY(run_conv(L.s_feat, N, h, w, View{feat[l].p, C, 0}, 0, none, nullptr, 0, 0, L.sfeat.p, 64, 0, 0, s,
+                              &fl));
+            mf = L.mfeat.p;
+            sf = L.sfeat.p;
+        }
+        const int stride = L.has_upcorr ? 2 : 1;
+        if (flow_prev) {
+            DFVO_TRY(launch_deconv_dw(flow_prev, 4, 0, N, h / 2, w / 2, 2, L.upflow_w.p, L.flow_up.p, 4, 0, s));
+            DFVO_TRY(launch_warp(mf, Cm, 0, 1, L.flow_up.p, 4, 0, dbl, N, h, w, Cm, lin_x[l].p, lin_y[l].p, L.warped.p,
+                                 Cm, 0, 0, s));
+            DFVO_TRY(launch_correlation(mf, Cm, 0, L.warped.p, Cm, 0, 0, N, h, w, Cm, stride, L.corr.p, 52, 0.1f, s));
+        } else {
+            DFVO_TRY(launch_correlation(mf, Cm, 0, mf, Cm, 0, 1, N, h, w, Cm, stride, L.corr.p, 52, 0.1f, s));
+        }
+        fl += 2.0 * N * cdiv(h, stride) * cdiv(w, stride) * 49.0 * Cm;
+        const float* corr = L.corr.p;
+        if (L.has_upcorr) {
+            DFVO_TRY(launch_deconv_dw(L.corr.p, 52, 0, N, h / 2, w / 2, 49, L.upcorr_w.p, L.corr_up.p, 52, 0, s));
+            corr = L.corr_up.p;
+        }
+        DFVO_TRY(run_conv(L.m_main[0], N, h, w, View{corr, 52, 0}, 0, none, nullptr, 0, 0, L.x128.p, 128, 0, 0, s, &fl));
+        DFVO_TRY(run_conv(L.m_main[1], N, h, w, View{L.x128.p, 128, 0}, 0, none, nullptr, 0, 0, L.x64.p, 64, 0, 0, s,
+                          &fl));
+        DFVO_TRY(run_conv(L.m_main[2], N, h, w, View{L.x64.p, 64, 0}, 0, none, nullptr, 0, 0, L.x32.p, 32, 0, 0, s, &fl));
+        DFVO_TRY(run_conv(L.m_main[3], N, h, w, View{L.x32.p, 32, 0}, 0, none, flow_prev ? L.flow_up.p : nullptr, 4, 0,
+                          L.flowM.p, 4, 0, 0, s, &fl));
+        // ------------------------------ Subpixel (lite_flow_net.py:182-190)
+        DFVO_TRY(launch_warp(sf, Cm, 0, 1, L.flowM.p, 4, 0, dbl, N, h, w, Cm, lin_x[l].p, lin_y[l].p, L.b1.p, Cm + 4, 0,
+                             1, s));
+        DFVO_TRY(run_conv(L.s_main[0], N, h, w, View{sf, Cm, 0}, 0, View{L.b1.p, Cm + 4, 0}, nullptr, 0, 0, L.x128b.p,
+                          128, 0, 0, s, &fl));
+        DFVO_TRY(run_conv(L.s_main[1], N, h, w, View{L.x128b.p, 128, 0}, 0, none, nullptr, 0, 0, L.x64b.p, 64, 0, 0, s,
+                          &fl));
+        DFVO_TRY(run_conv(L.s_main[2], N, h, w, View{L.x64b.p, 64, 0}, 0, none, nullptr, 0, 0, L.x32b.p, 32, 0, 0, s,
+                          &fl));
+        DFVO_TRY(run_conv(L.s_main[3], N, h, w, View{L.x32b.p, 32, 0}, 0, none, L.flowM.p, 4, 0, L.flowS.p, 4, 0, 0, s,
+                          &fl));
+        // ------------------------------ Regularization (lite_flow_net.py:243-264)
+        DFVO_TRY(launch_flow_mean(L.flowS.p, 4, 0, N, h * w, nullptr, L.mean.p, s));
+        DFVO_TRY(launch_reg_prep(img[l].p, L.flowS.p, 4, 0, dbl, L.mean.p, N, h, w, lin_x[l].p, lin_y[l].p, L.r0.p, s));
+        const float* rf = feat[l].p;
+        if (L.has_rfeat) {
+            DFVO_TRY(run_conv(L.r_feat, N, h, w, View{feat[l].p, C, 0}, 0, none, nullptr, 0, 0, L.rfeat.p, 128, 0, 0, s,
+                              &fl));
+            rf = L.rfeat.p;
+        }
+        DFVO_TRY(run_conv(L.r_main[0], N, h, w, View{L.r0.p, 4, 0}, 0, View{rf, Cr, 0}, nullptr, 0, 0, L.x128.p, 128, 0,
+                          0, s, &fl));
+        DFVO_TRY(run_conv(L.r_main[1], N, h, w, View{L.x128.p, 128, 0}, 0, none, nullptr, 0, 0, L.x128b.p, 128, 0, 0, s,
+                          &fl));
+        DFVO_TRY(run_conv(L.r_main[2], N, h, w, View{L.x128b.p, 128, 0}, 0, none, nullptr, 0, 0, L.x64.p, 64, 0, 0, s,
+                          &fl));
+        DFVO_TRY(run_conv(L.r_main[3], N, h, w, View{L.x64.p, 64, 0}, 0, none, nullptr, 0, 0, L.x64b.p, 64, 0, 0, s,
+                          &fl));
+        DFVO_TRY(run_conv(L.r_main[4], N, h, w, View{L.x64b.p, 64, 0}, 0, none, nullptr, 0, 0, L.x32.p, 32, 0, 0, s,
+                          &fl));
+        DFVO_TRY(run_conv(L.r_main[5], N, h, w, View{L.x32.p, 32, 0}, 0, none, nullptr, 0, 0, L.x32b.p, 32, 0, 0, s,
+                          &fl));
+        const float* dist = L.dist_a.p;
+        DFVO_TRY(run_conv(L.r_dist[0], N, h, w, View{L.x32b.p, 32, 0}, 0, none, nullptr, 0, 0, L.dist_a.p, kkp, 0, kkp,
+                          s, &fl));
+        if (L.dist_sep) {
+            DFVO_TRY(run_conv(L.r_dist[1], N, h, w, View{L.dist_a.p, kkp, 0}, 0, none, nullptr, 0, 0, L.dist_b.p, kkp, 0,
+                              kkp, s, &fl));
+            dist = L.dist_b.p;
+        }
+        DFVO_TRY(launch_reg_head(dist, kkp, k, L.flowS.p, 4, 0, L.scale_wx.p, L.scale_bx, L.scale_wy.p, L.scale_by, N,
+                                 h, w, L.flow.p, 4, 0, s));
+        fl += 2.0 * N * h * w * 2.0 * k * k;
+        flow_prev = L.flow.p;
+    }
+    // lite_flow_net.py:322-324 (x 20*0.5^1 for the level-2 map) + resize + consistency
+    DFVO_TRY(launch_flow_post(lv[2].flow.p, 4, 0, lh[2], lw[2], 10.0f, imgH, imgW, d_fwd, d_bwd, d_diff, s));
+    flops_last = fl;
+    return DFVO_OK;
+}
+
+int FlowNet::forward(const uint8_t* d_ref, const uint8_t* d_cur, float* d_fwd, float* d_bwd, float* d_diff) {
+    if (!finalized) {
+        set_last_error("FlowNet::forward before finalize");
+        return DFVO_ERR_STATE;
+    }
+    if (!use_graph) return enqueue(d_ref, d_cur, d_fwd, d_bwd, d_diff);
+    if (graph_exec && (graph_ref != d_ref || graph_cur != d_cur || graph_fwd != d_fwd || graph_bwd != d_bwd ||
+                       graph_diff != d_diff)) {
+        (void)hipGraphExecDestroy(graph_exec);
+        (void)hipGraphDestroy(graph);
+        graph_exec = nullptr;
+        graph = nullptr;
+    }
+    if (!graph_exec) {
+        // run once eagerly (configures function attributes), then capture
+        DFVO_TRY(enqueue(d_ref, d_cur, d_fwd, d_bwd, d_diff));
+        DFVO_HIP_CHECK(hipStreamSynchronize(stream));
+        DFVO_HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        int rc = enqueue(d_ref, d_cur, d_fwd, d_bwd, d_diff);
+        hipError_t e = hipStreamEndCapture(stream, &graph);
+        if (rc != DFVO_OK) return rc;
+        DFVO_HIP_CHECK(e);
+        DFVO_HIP_CHECK(hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0));
+        graph_ref = d_ref;
+        graph_cur = d_cur;
+        graph_fwd = d_fwd;
+        graph_bwd = d_bwd;
+        graph_diff = d_diff;
+        return DFVO_OK;  // results of the eager run are already in place
+    }
+    DFVO_HIP_CHECK(hipGraphLaunch(graph_exec, stream));
+    return DFVO_OK;
+}
+
+void FlowNet::destroy() {
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    for (auto& c : feat_convs) free_conv(&c);
+    for (int l = 1; l <= 6; ++l) {
+        img[l].release();
+        feat[l].release();
+        lin_x[l].release();
+        lin_y[l].release();
+    }
+    for (int l = 2; l <= 6; ++l) {
+        Level& L = lv[l];
+        free_conv(&L.m_feat);
+        free_conv(&L.s_feat);
+        free_conv(&L.r_feat);
+        for (auto& c : L.m_main) free_conv(&c);
+        for (auto& c : L.s_main) free_conv(&c);
+        for (auto& c : L.r_main) free_conv(&c);
+        for (auto& c : L.r_dist) free_conv(&c);
+        DevBuf* bufs[] = {&L.upflow_w, &L.upcorr_w, &L.scale_wx, &L.scale_wy, &L.mfeat, &L.sfeat, &L.rfeat, &L.flow_up,
+                          &L.warped,   &L.corr,     &L.corr_up,  &L.x128,     &L.x64,   &L.x32,   &L.x128b, &L.x64b,
+                          &L.x32b,     &L.flowM,    &L.b1,       &L.flowS,    &L.r0,    &L.dist_a, &L.dist_b, &L.flow,
+                          &L.mean};
+        for (DevBuf* b : bufs) b->release();
+    }
+    out_fwd.release();
+    out_bwd.release();
+    out_diff.release();
+    u8_ref.release();
+    u8_cur.release();
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+    stream = nullptr;
+}
+
+// ================================================================================================
+// monodepth2
+// ================================================================================================
+int DepthNet::init(int feedH, int feedW, hipStream_t s) {
+    H = feedH;
+    W = feedW;
+    DFVO_ARG_CHECK(H % 32 == 0 && W % 32 == 0, "DepthNet: feed size must be a multiple of 32");
+    if (s) {
+        stream = s;
+    } else {
+        DFVO_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        own_stream = true;
+    }
+    return DFVO_OK;
+}
+
+static int bn_fold(const ParamStore& ps, const std::string& bn, int c, std::vector<float>* scale,
+                   std::vector<float>* shift) {
+    const HostTensor* g = ps.get(bn + ".weight");
+    const HostTensor* b = ps.get(bn + ".bias");
+    const HostTensor* m = ps.get(bn + ".running_mean");
+    const HostTensor* v = ps.get(bn + ".running_var");
+    if (!g || !b || !m || !v || (int)g->data.size() != c) {
+        set_last_error("missing/invalid batch-norm parameters " + bn);
+        return DFVO_ERR_STATE;
+    }
+    scale->resize(c);
+    shift->resize(c);
+    for (int i = 0; i < c; ++i) {
+        const float inv = 1.0f / std::sqrt(v->data[i] + 1e-5f);
+        (*scale)[i] = g->data[i] * inv;
+        (*shift)[i] = b->data[i] - m->data[i] * (*scale)[i];
+    }
+    return DFVO_OK;
+}
+
+int DepthNet::finalize() {
+    if (finalized) return DFVO_OK;
+    std::vector<float> sc, sh;
+    const int N = 1;
+    const int ch[5] = {64, 64, 128, 256, 512};
+    // encoder
+    DFVO_TRY(bn_fold(params, "encoder.bn1", 64, &sc, &sh));
+    DFVO_TRY(make_conv(params, "encoder.conv1.weight", "", 3, 0, (long long)(H / 2) * (W / 2), sc.data(), sh.data(),
+                       &conv1));
+    conv1.stride = 2;
+    conv1.pad_h = conv1.pad_w = 3;
+    conv1.act = ACT_RELU;
+    int hh = H / 4, ww = W / 4;
+    for (int li = 0; li < 4; ++li) {
+        const int cin = li == 0 ? 64 : ch[li], cout = ch[li + 1];
+        for (int b = 0; b < 2; ++b) {
+            Block& B = blocks[li * 2 + b];
+            const std::string base = "encoder.layer" + std::to_string(li + 1) + "." + std::to_string(b);
+            const int s = (li > 0 && b == 0) ? 2 : 1;
+            const int c_in = b == 0 ? cin : cout;
+            if (s == 2) {
+                hh /= 2;
+                ww /= 2;
+            }
+            const long long M = (long long)hh * ww;
+            DFVO_TRY(bn_fold(params, base + ".bn1", cout, &sc, &sh));
+            DFVO_TRY(make_conv(params, base + ".conv1.weight", "", c_in, 0, M, sc.data(), sh.data(), &B.c1));
+            B.c1.stride = s;
+            B.c1.pad_h = B.c1.pad_w = 1;
+            B.c1.act = ACT_RELU;
+            DFVO_TRY(bn_fold(params, base + ".bn2", cout, &sc, &sh));
+            DFVO_TRY(make_conv(params, base + ".conv2.weight", "", cout, 0, M, sc.data(), sh.data(), &B.c2));
+            B.c2.stride = 1;
+            B.c2.pad_h = B.c2.pad_w = 1;
+            B.c2.act = ACT_RELU;  // applied after the residual add
+            B.has_ds = (s == 2);
+            if (B.has_ds) {
+                DFVO_TRY(bn_fold(params, base + ".downsample.1", cout, &sc, &sh));
+                DFVO_TRY(make_conv(params, base + ".downsample.0.weight", "", c_in, 0, M, sc.data(), sh.data(), &B.ds));
+                B.ds.stride = 2;
+                B.ds.pad_h = B.ds.pad_w = 0;
+                B.ds.act = ACT_NONE;
+            }
+        }
+    }
+    // decoder (depth_decoder.py:29-47): ModuleList order (4,0),(4,1),(3,0),...,(0,1), dispconv 0..3
+    const int dec[5] = {16, 32, 64, 128, 256};
+    for (int i = 4; i >= 0; --i) {
+        const int idx0 = (4 - i) * 2, idx1 = idx0 + 1;
+        const int cin0 = i == 4 ? 512 : dec[i + 1];
+        const int skip = i > 0 ? ch[i - 1] : 0;
+        const long long M0 = (long long)(H >> (i + 1)) * (W >> (i + 1)), M1 = (long long)(H >> i) * (W >> i);
+        const std::string b0 = "decoder." + std::to_string(idx0) + ".conv.conv";
+        const std::string b1 = "decoder." + std::to_string(idx1) + ".conv.conv";
+        DFVO_TRY(make_conv(params, b0 + ".weight", b0 + ".bias", cin0, 0, M0, nullptr, nullptr, &up[i][0]));
+        DFVO_TRY(make_conv(params, b1 + ".weight", b1 + ".bias", dec[i], skip, M1, nullptr, nullptr, &up[i][1]));
+        for (int j = 0; j < 2; ++j) {
+            up[i][j].stride = 1;
+            up[i][j].pad_h = up[i][j].pad_w = 1;
+            up[i][j].pad_mode = PAD_REFLECT;
+            up[i][j].act = ACT_ELU;
+            up[i][j].act_param = 1.0f;
+        }
+    }
+    DFVO_TRY(make_conv(params, "decoder.10.conv.weight", "decoder.10.conv.bias", 16, 0, (long long)H * W, nullptr,
+                       nullptr, &dispconv));
+    dispconv.stride = 1;
+    dispconv.pad_h = dispconv.pad_w = 1;
+    dispconv.pad_mode = PAD_REFLECT;
+    dispconv.act = ACT_SIGMOID;
+    // buffers
+    DFVO_TRY(x0.alloc((size_t)N * H * W * 4));
+    DFVO_TRY(feat[0].alloc((size_t)N * (H / 2) * (W / 2) * 64));
+    DFVO_TRY(pool.alloc((size_t)N * (H / 4) * (W / 4) * 64));
+    for (int i = 1; i < 5; ++i) DFVO_TRY(feat[i].alloc((size_t)N * (H >> (i + 1)) * (W >> (i + 1)) * ch[i]));
+    const size_t big = (size_t)N * (H / 4) * (W / 4) * 64;  // every block tensor is <= this many floats
+    DFVO_TRY(blk_t.alloc(big));
+    DFVO_TRY(blk_ds.alloc(big));
+    DFVO_TRY(blk_o[0].alloc(big));
+    DFVO_TRY(blk_o[1].alloc(big));
+    for (int i = 4; i >= 0; --i) {
+        DFVO_TRY(du[i].alloc((size_t)N * (H >> (i + 1)) * (W >> (i + 1)) * dec[i]));
+        DFVO_TRY(dx[i].alloc((size_t)N * (H >> i) * (W >> i) * dec[i]));
+    }
+    DFVO_TRY(disp.alloc((size_t)N * H * W * 4));
+    DFVO_TRY(depth.alloc((size_t)N * H * W));
+    DFVO_TRY(u8_in.alloc(((size_t)H * W * 3 + 3) / 4 + 1));
+    finalized = true;
+    return DFVO_OK;
+}
+
+int DepthNet::enqueue(const uint8_t* d_img, float* d_depth) {
+    const int N = 1;
+    hipStream_t s = stream;
+    double fl = 0.0;
+    const View none{nullptr, 0, 0};
+    const int ch[5] = {64, 64, 128, 256, 512};
+    const int dec[5] = {16, 32, 64, 128, 256};
+    DFVO_TRY(launch_img_u8_to_depth_input(d_img, H, W, x0.p, s));
+    DFVO_TRY(run_conv(conv1, N, H, W, View{x0.p, 4, 0}, 0, none, nullptr, 0, 0, feat[0].p, 64, 0, 0, s, &fl));
+    DFVO_TRY(launch_maxpool3x3s2(feat[0].p, N, H / 2, W / 2, 64, pool.p, s));
+    const float* x = pool.p;
+    int hh = H / 4, ww = W / 4, c = 64;
+    for (int li = 0; li < 4; ++li) {
+        for (int b = 0; b < 2; ++b) {
+            const Block& B = blocks[li * 2 + b];
+            const int cout = ch[li + 1];
+            const int ho = B.has_ds ? hh / 2 : hh, wo = B.has_ds ? ww / 2 : ww;
+            float* out = (b == 1) ? feat[li + 1].p : blk_o[0].p;
+            DFVO_TRY(run_conv(B.c1, N, hh, ww, View{x, c, 0}, 0, none, nullptr, 0, 0, blk_t.p, cout, 0, 0, s, &fl));
+            const float* idn = x;
+            int idn_cs = c;
+            if (B.has_ds) {
+                DFVO_TRY(run_conv(B.ds, N, hh, ww, View{x, c, 0}, 0, none, nullptr, 0, 0, blk_ds.p, cout, 0, 0, s, &fl));
+                idn = blk_ds.p;
+                idn_cs = cout;
+            }
+            DFVO_TRY(run_conv(B.c2, N, ho, wo, View{blk_t.p, cout, 0}, 0, none, idn, idn_cs, 0, out, cout, 0, 0, s, &fl));
+            x = out;
+            hh = ho;
+            ww = wo;
+            c = cout;
+        }
+    }
+    // decoder
+    const float* cur = feat[4].p;
+    int cc = 512;
+    for (int i = 4; i >= 0; --i) {
+        const int h0 = H >> (i + 1), w0 = W >> (i + 1);
+        DFVO_TRY(run_conv(up[i][0], N, h0, w0, View{cur, cc, 0}, 0, none, nullptr, 0, 0, du[i].p, dec[i], 0, 0, s, &fl));
+        View skip = none;
+        if (i > 0) skip = View{feat[i - 1].p, ch[i - 1], 0};
+        DFVO_TRY(run_conv(up[i][1], N, 2 * h0, 2 * w0, View{du[i].p, dec[i], 0}, 1, skip, nullptr, 0, 0, dx[i].p, dec[i],
+                          0, 0, s, &fl));
+        cur = dx[i].p;
+        cc = dec[i];
+    }
+    DFVO_TRY(run_conv(dispconv, N, H, W, View{dx[0].p, 16, 0}, 0, none, nullptr, 0, 0, disp.p, 4, 0, 0, s, &fl));
+    const float min_disp = 1.0f / max_depth, max_disp = 1.0f / min_depth;
+    DFVO_TRY(launch_disp_to_depth(disp.p, 4, 0, H * W, min_disp, (float)((double)max_disp - (double)min_disp),
+                                  baseline_mult, d_depth, s));
+    flops_last = fl;
+    return DFVO_OK;
+}
+
+int DepthNet::forward(const uint8_t* d_img, float* d_depth) {
+    if (!finalized) {
+        set_last_error("DepthNet::forward before finalize");
+        return DFVO_ERR_STATE;
+    }
+    if (!use_graph) return enqueue(d_img, d_depth);
+    if (graph_exec && (graph_in != d_img || graph_out != d_depth)) {
+        (void)hipGraphExecDestroy(graph_exec);
+        (void)hipGraphDestroy(graph);
+        graph_exec = nullptr;
+        graph = nullptr;
+    }
+    if (!graph_exec) {
+        DFVO_TRY(enqueue(d_img, d_depth));
+        DFVO_HIP_CHECK(hipStreamSynchronize(stream));
+        DFVO_HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        int rc = enqueue(d_img, d_depth);
+        hipError_t e = hipStreamEndCapture(stream, &graph);
+        if (rc != DFVO_OK) return rc;
+        DFVO_HIP_CHECK(e);
+        DFVO_HIP_CHECK(hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0));
+        graph_in = d_img;
+        graph_out = d_depth;
+        return DFVO_OK;
+    }
+    DFVO_HIP_CHECK(hipGraphLaunch(graph_exec, stream));
+    return DFVO_OK;
+}
+
+void DepthNet::destroy() {
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    if (graph) (void)hipGraphDestroy(graph);
+    free_conv(&conv1);
+    for (auto& b : blocks) {
+        free_conv(&b.c1);
+        free_conv(&b.c2);
+        free_conv(&b.ds);
+    }
+    for (int i = 0; i < 5; ++i) {
+        free_conv(&up[i][0]);
+        free_conv(&up[i][1]);
+        feat[i].release();
+        du[i].release();
+        dx[i].release();
+    }
+    free_conv(&dispconv);
+    DevBuf* bufs[] = {&x0, &pool, &blk_t, &blk_ds, &blk_o[0], &blk_o[1], &disp, &depth, &u8_in};
+    for (DevBuf* b : bufs) b->release();
+    if (own_stream && stream) (void)hipStreamDestroy(stream);
+    stream = nullptr;
+}
+
+}  // namespace dfvo

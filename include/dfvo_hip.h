@@ -1,0 +1,136 @@
+/* libdfvo_hip.so -- C ABI of the MI355X (gfx950) DF-VO tracking hot path.
+ *
+ * The reference (Huangying-Zhan/DF-VO) has no FFI: its boundary is the Python class surface that
+ * libs/dfvo.py consumes.  This header is the C ABI placed underneath that
+ * surface; each entry point names the reference call site it replaces (paths relative to
+ * /root/reference).  The Python mirror classes in df-vo_amd/libs bind these symbols with ctypes.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative DFVO_ERR_* code otherwise;
+ *     dfvo_last_error() returns a thread-local human readable message for the last failure.
+ *   - "d_" arguments are DEVICE pointers (HBM), "h_" arguments are HOST pointers.  Nothing is
+ *     retained after the call returns unless stated.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the object's own stream).
+ *   - images are uint8 HWC RGB; activations are NHWC float32; dense maps are row-major.
+ *   - handles are opaque, not re-entrant per handle, independent across handles.
+ */
+#ifndef DFVO_HIP_H
+#define DFVO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DFVO_OK 0
+#define DFVO_ERR_HIP (-1)
+#define DFVO_ERR_ARG (-2)
+#define DFVO_ERR_STATE (-3)
+
+const char* dfvo_last_error(void);
+/* number of visible HIP devices (0 when there is none); never fails */
+int dfvo_device_count(void);
+int dfvo_set_device(int ordinal);
+int dfvo_sync_device(void);
+
+/* ---- raw device memory helpers (plumbing for hosts without torch) ---- */
+int dfvo_malloc(void** d_ptr, size_t bytes);
+int dfvo_free(void* d_ptr);
+int dfvo_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
+int dfvo_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);
+
+/* =====================================================================================
+ * Unit-testable operators (each is one kernel launch; used by the nets below)
+ * ===================================================================================== */
+
+/* torch.nn.Conv2d + bias + activation (+ residual, + reflection pad, + x2 nearest upsample of
+ * source 0, + channel concat of two sources) as an fp32 MFMA implicit GEMM.
+ *   lite_flow_net.py:39-75,121-129,171-179,211-240; depth_decoder.py:50-65; layers.py:106-136
+ * Weights are given in torch OIHW layout on the HOST (cin = c0 + c1) and packed internally. */
+typedef struct dfvo_conv_desc {
+    int N, H, W;              /* input batch / spatial size the taps index (after upsample) */
+    int kh, kw, stride, pad_h, pad_w;
+    int pad_mode;             /* 0 zeros, 1 reflect */
+    int c0, cs0, co0, up0;    /* source 0: logical channels, floats per pixel, channel offset, x2 nearest */
+    int c1, cs1, co1;         /* source 1 (c1 = 0: absent) */
+    int cout;
+    int act;                  /* 0 none, 1 leaky(act_param), 2 relu, 3 elu(act_param), 4 sigmoid */
+    float act_param;
+    int res_cs, res_co;       /* residual view (used when d_res != NULL) */
+    int dst_cs, dst_co;
+} dfvo_conv_desc;
+int dfvo_conv2d(const dfvo_conv_desc* desc, const float* d_src0, const float* d_src1, const float* h_weight_oihw,
+                const float* h_bias, const float* d_res, float* d_dst, void* stream);
+
+/* correlation.py:38-106,281-340 (_FunctionCorrelation.forward) followed by leaky_relu(slope)
+ * (lite_flow_net.py:145,148).  NHWC inputs [N,H,W,C]; output [N,ceil(H/s),ceil(W/s),52], 49 used.
+ * slope = 1 gives the bare correlation. */
+int dfvo_correlation(const float* d_first, const float* d_second, int N, int H, int W, int C, int stride,
+                     float slope, float* d_out, void* stream);
+
+/* Backward() bilinear warp, lite_flow_net.py:10-28.  h_lin_x/h_lin_y: torch.linspace(-1,1,W/H)
+ * tables (HOST; NULL = library formula). */
+int dfvo_backward_warp(const float* d_src, const float* d_flow, float flow_mult, int N, int H, int W, int C,
+                       const float* h_lin_x, const float* h_lin_y, float* d_dst, void* stream);
+
+/* depthwise ConvTranspose2d(k=4, s=2, p=1, bias=False), lite_flow_net.py:109,117. h_weight [C,1,4,4] */
+int dfvo_deconv_dw4x4s2(const float* d_src, int N, int H, int W, int C, int cs, const float* h_weight,
+                        float* d_dst, void* stream);
+
+/* F.interpolate(mode='bilinear') on dense NHWC, C % 4 == 0 */
+int dfvo_resize_bilinear(const float* d_src, int N, int H, int W, int C, float* d_dst, int Ho, int Wo,
+                         int align_corners, void* stream);
+
+/* =====================================================================================
+ * LiteFlowNet forward/backward flow + consistency   (replaces LiteFlow.inference_flow,
+ * lite_flow.py:89-148, behind DeepModel.forward_flow, deep_models.py:144-182)
+ * ===================================================================================== */
+typedef struct dfvo_flownet dfvo_flownet;
+int dfvo_flownet_create(int img_h, int img_w, void* stream, dfvo_flownet** out);
+void dfvo_flownet_destroy(dfvo_flownet* net);
+/* state_dict entry by its key (lite_flow.py:45-46), float32 HOST data; also accepts the optional
+ * "aux.linspace_x.<level>" / "aux.linspace_y.<level>" tables (level 2..6). */
+int dfvo_flownet_set_param(dfvo_flownet* net, const char* name, const float* h_data, int ndim, const int* shape);
+int dfvo_flownet_finalize(dfvo_flownet* net);
+int dfvo_flownet_net_size(const dfvo_flownet* net, int* net_h, int* net_w);
+int dfvo_flownet_set_graph(dfvo_flownet* net, int enable);
+/* device in, device out: ref/cur uint8 [H,W,3]; fwd,bwd float [2,H,W]; diff float [H,W] */
+int dfvo_flownet_forward(dfvo_flownet* net, const uint8_t* d_ref, const uint8_t* d_cur, float* d_fwd, float* d_bwd,
+                         float* d_diff);
+/* host in, host out (synchronous) */
+int dfvo_flownet_forward_host(dfvo_flownet* net, const uint8_t* h_ref, const uint8_t* h_cur, float* h_fwd,
+                              float* h_bwd, float* h_diff);
+/* conv + correlation FLOPs (2 x MAC, unpadded) enqueued by the last forward */
+double dfvo_flownet_last_flops(const dfvo_flownet* net);
+/* debugging / parity: copy the final flow of pyramid level 2..6 ([2,h,w,2] float, HOST) */
+int dfvo_flownet_get_level_flow(dfvo_flownet* net, int level, float* h_out, int* h, int* w);
+int dfvo_flownet_sync(dfvo_flownet* net);
+
+/* =====================================================================================
+ * monodepth2 depth  (replaces Monodepth2DepthNet.inference_depth, monodepth2.py:91-139,
+ * behind DeepModel.forward_depth, deep_models.py:184-206)
+ * ===================================================================================== */
+typedef struct dfvo_depthnet dfvo_depthnet;
+int dfvo_depthnet_create(int feed_h, int feed_w, float min_depth, float max_depth, float baseline_mult,
+                         void* stream, dfvo_depthnet** out);
+void dfvo_depthnet_destroy(dfvo_depthnet* net);
+/* keys of encoder.pth ("encoder.conv1.weight", ...) and depth.pth ("decoder.0.conv.conv.weight", ...) */
+int dfvo_depthnet_set_param(dfvo_depthnet* net, const char* name, const float* h_data, int ndim, const int* shape);
+int dfvo_depthnet_finalize(dfvo_depthnet* net);
+int dfvo_depthnet_set_graph(dfvo_depthnet* net, int enable);
+/* img uint8 [feed_h, feed_w, 3] -> depth float [feed_h, feed_w] (metres, x baseline multiplier) */
+int dfvo_depthnet_forward(dfvo_depthnet* net, const uint8_t* d_img, float* d_depth);
+int dfvo_depthnet_forward_host(dfvo_depthnet* net, const uint8_t* h_img, float* h_depth);
+double dfvo_depthnet_last_flops(const dfvo_depthnet* net);
+int dfvo_depthnet_sync(dfvo_depthnet* net);
+/* dfvo.py:314-319 + utils.py:89-114: nearest resize to (H,W), crop rows/cols, range mask.
+ * d_depth float [h,w] -> d_raw float [H,W], d_proc double [H,W] */
+int dfvo_depth_postprocess(const float* d_depth, int h, int w, int H, int W, int y0, int y1, int x0, int x1,
+                           float min_depth, float max_depth, float* d_raw, double* d_proc, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DFVO_HIP_H */

@@ -1,0 +1,449 @@
+"""ORACLE (test infrastructure only -- never imported by the product path).
+
+CPU restatement, in plain torch fp32 ops, of the two CNNs on DF-VO's tracking hot path.  Only
+tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
+
+Follows (paths relative to /root/reference):
+    LiteFlowNet.forward            libs/deep_models/flow/lite_flow_net/lite_flow_net.py:285-325
+      Features / Matching / Subpixel / Regularization          lite_flow_net.py:35-264
+      Backward (bilinear warp)                                  lite_flow_net.py:10-28
+      FunctionCorrelation (CUDA string, semantics restated)     correlation.py:38-106,281-340
+    LiteFlow.inference / inference_flow                         lite_flow.py:55-148
+    DeepFlow.get_target_size / resize_dense_flow / forward_backward_consistency
+                                                                deep_flow.py:89-129,171-196
+    FlowToPix                                                   depth/monodepth2/layers.py:193-229
+    ResnetEncoder.forward                                       depth/monodepth2/resnet_encoder.py:87-98
+      torchvision 0.3 resnet18 BasicBlock topology [2,2,2,2]    (third party, not vendored; restated)
+    DepthDecoder.forward                                        depth/monodepth2/depth_decoder.py:50-65
+    Monodepth2DepthNet.inference / inference_depth              depth/monodepth2/monodepth2.py:91-139
+    DeepModel.forward_flow / forward_depth pre-processing       deep_models.py:144-206
+
+Pinning: tests/golden/make_golden.py imports the reference's own LiteFlowNet / DepthDecoder /
+ResnetEncoder classes (with third-party shims) in the build container and stores their outputs on
+seeded inputs; tests/test_oracle_nets.py checks this restatement against those fixtures.
+torch >= 1.3 changed grid_sample's default corner alignment; the reference is pinned to torch 1.1,
+so every grid_sample here states align_corners=True.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+DBL = [0.0, 0.0, 10.0, 5.0, 2.5, 1.25, 0.625]
+KER = [0, 0, 7, 5, 5, 3, 3]
+
+
+# ----------------------------------------------------------------------------------------------
+# correlation
+# ----------------------------------------------------------------------------------------------
+def correlation(first, second, stride):
+    """correlation.py:38-106,294: out[n, tc, y, x] = mean_c F1[n,c,y*s,x*s] * F2[n,c,(y+dy)*s,(x+dx)*s],
+    dy = tc//7 - 3, dx = tc%7 - 3, zero outside."""
+    n, c, h, w = first.shape
+    s = stride
+    p = 3 * s
+    f2 = F.pad(second, (p, p, p, p))
+    ho, wo = int(math.ceil(h / s)), int(math.ceil(w / s))
+    f1 = first[:, :, ::s, ::s]
+    out = []
+    for tc in range(49):
+        dy, dx = (tc // 7 - 3) * s, (tc % 7 - 3) * s
+        sl = f2[:, :, p + dy:p + dy + h:s, p + dx:p + dx + w:s]
+        out.append((f1 * sl).sum(1, keepdim=True) / float(c))
+    out = torch.cat(out, 1)
+    assert out.shape[2] == ho and out.shape[3] == wo
+    return out
+
+
+def correlation_cuda_order(first, second, stride):
+    """Same values, reproducing the CUDA kernel's fp32 summation order (32 strided partial sums with
+    fused multiply-add, then a sequential total, then / C): numpy float32, for small inputs only."""
+    f1 = first.numpy().astype(np.float32)
+    f2 = second.numpy().astype(np.float32)
+    n, c, h, w = f1.shape
+    s = stride
+    ho, wo = int(math.ceil(h / s)), int(math.ceil(w / s))
+    out = np.zeros((n, 49, ho, wo), np.float32)
+    for tc in range(49):
+        dy, dx = (tc // 7 - 3) * s, (tc % 7 - 3) * s
+        b = np.zeros((n, c, ho, wo), np.float32)
+        ys = np.arange(ho) * s + dy
+        xs = np.arange(wo) * s + dx
+        vy = (ys >= 0) & (ys < h)
+        vx = (xs >= 0) & (xs < w)
+        b[:, :, np.ix_(vy, vx)[0], np.ix_(vy, vx)[1]] = f2[:, :, ys[vy]][:, :, :, xs[vx]]
+        a = f1[:, :, ::s, ::s]
+        total = np.zeros((n, ho, wo), np.float32)
+        for j in range(32):
+            part = np.zeros((n, ho, wo), np.float64)
+            partf = np.zeros((n, ho, wo), np.float32)
+            for ch in range(j, c, 32):
+                # fmaf(a, b, part): exact product + one rounding
+                part = a[:, ch].astype(np.float64) * b[:, ch].astype(np.float64) + partf.astype(np.float64)
+                partf = part.astype(np.float32)
+            total = (total + partf).astype(np.float32)
+        out[:, tc] = total / np.float32(c)
+    return torch.from_numpy(out)
+
+
+# ----------------------------------------------------------------------------------------------
+# LiteFlowNet
+# ----------------------------------------------------------------------------------------------
+_grid_cache = {}
+
+
+def backward_warp(inp, flow):
+    """lite_flow_net.py:10-28 (torch 1.1 grid_sample semantics = align_corners=True)"""
+    key = str(flow.size())
+    if key not in _grid_cache:
+        hor = torch.linspace(-1.0, 1.0, flow.size(3)).view(1, 1, 1, flow.size(3)).expand(flow.size(0), -1, flow.size(2), -1)
+        ver = torch.linspace(-1.0, 1.0, flow.size(2)).view(1, 1, flow.size(2), 1).expand(flow.size(0), -1, -1, flow.size(3))
+        _grid_cache[key] = torch.cat([hor, ver], 1)
+    flow = torch.cat([flow[:, 0:1] / ((inp.size(3) - 1.0) / 2.0), flow[:, 1:2] / ((inp.size(2) - 1.0) / 2.0)], 1)
+    return F.grid_sample(input=inp, grid=(_grid_cache[key] + flow).permute(0, 2, 3, 1), mode='bilinear',
+                         padding_mode='zeros', align_corners=True)
+
+
+def _conv(sd, name, x, stride=1, padding=0):
+    return F.conv2d(x, sd[name + '.weight'], sd.get(name + '.bias'), stride=stride, padding=padding)
+
+
+def _lrelu(x):
+    return F.leaky_relu(x, 0.1)
+
+
+def features(sd, x):
+    p = 'moduleFeatures.'
+    one = _lrelu(_conv(sd, p + 'moduleOne.0', x, 1, 3))
+    two = _lrelu(_conv(sd, p + 'moduleTwo.0', one, 2, 1))
+    two = _lrelu(_conv(sd, p + 'moduleTwo.2', two, 1, 1))
+    two = _lrelu(_conv(sd, p + 'moduleTwo.4', two, 1, 1))
+    thr = _lrelu(_conv(sd, p + 'moduleThr.0', two, 2, 1))
+    thr = _lrelu(_conv(sd, p + 'moduleThr.2', thr, 1, 1))
+    fou = _lrelu(_conv(sd, p + 'moduleFou.0', thr, 2, 1))
+    fou = _lrelu(_conv(sd, p + 'moduleFou.2', fou, 1, 1))
+    fiv = _lrelu(_conv(sd, p + 'moduleFiv.0', fou, 2, 1))
+    six = _lrelu(_conv(sd, p + 'moduleSix.0', fiv, 2, 1))
+    return [one, two, thr, fou, fiv, six]
+
+
+def matching(sd, lvl, feat1, feat2, flow):
+    p = 'moduleMatching.%d.' % (lvl - 2)
+    if lvl == 2:
+        feat1 = _lrelu(_conv(sd, p + 'moduleFeat.0', feat1))
+        feat2 = _lrelu(_conv(sd, p + 'moduleFeat.0', feat2))
+    if flow is not None:
+        flow = F.conv_transpose2d(flow, sd[p + 'moduleUpflow.weight'], None, stride=2, padding=1, groups=2)
+        feat2 = backward_warp(feat2, flow * DBL[lvl])
+    if lvl >= 4:
+        corr = _lrelu(correlation(feat1, feat2, 1))
+    else:
+        corr = _lrelu(correlation(feat1, feat2, 2))
+        corr = F.conv_transpose2d(corr, sd[p + 'moduleUpcorr.weight'], None, stride=2, padding=1, groups=49)
+    k = KER[lvl]
+    x = _lrelu(_conv(sd, p + 'moduleMain.0', corr, 1, 1))
+    x = _lrelu(_conv(sd, p + 'moduleMain.2', x, 1, 1))
+    x = _lrelu(_conv(sd, p + 'moduleMain.4', x, 1, 1))
+    x = _conv(sd, p + 'moduleMain.6', x, 1, (k - 1) // 2)
+    return (flow if flow is not None else 0.0) + x
+
+
+def subpixel(sd, lvl, feat1, feat2, flow):
+    p = 'moduleSubpixel.%d.' % (lvl - 2)
+    if lvl == 2:
+        feat1 = _lrelu(_conv(sd, p + 'moduleFeat.0', feat1))
+        feat2 = _lrelu(_conv(sd, p + 'moduleFeat.0', feat2))
+    feat2 = backward_warp(feat2, flow * DBL[lvl])
+    k = KER[lvl]
+    x = _lrelu(_conv(sd, p + 'moduleMain.0', torch.cat([feat1, feat2, flow], 1), 1, 1))
+    x = _lrelu(_conv(sd, p + 'moduleMain.2', x, 1, 1))
+    x = _lrelu(_conv(sd, p + 'moduleMain.4', x, 1, 1))
+    x = _conv(sd, p + 'moduleMain.6', x, 1, (k - 1) // 2)
+    return flow + x
+
+
+def regularization(sd, lvl, img1, img2, feat1, flow):
+    p = 'moduleRegularization.%d.' % (lvl - 2)
+    k = KER[lvl]
+    r = (k - 1) // 2
+    diff = img1 - backward_warp(img2, flow * DBL[lvl])
+    diff = (diff.pow(2.0).sum(1, True) + 1e-6).sqrt()
+    f = feat1
+    if lvl < 5:
+        f = _lrelu(_conv(sd, p + 'moduleFeat.0', feat1))
+    x = torch.cat([diff, flow - flow.view(flow.size(0), 2, -1).mean(2, True).view(flow.size(0), 2, 1, 1), f], 1)
+    for i in range(6):
+        x = _lrelu(_conv(sd, p + 'moduleMain.%d' % (2 * i), x, 1, 1))
+    if lvl >= 5:
+        dist = _conv(sd, p + 'moduleDist.0', x, 1, r)
+    else:
+        dist = F.conv2d(x, sd[p + 'moduleDist.0.weight'], sd[p + 'moduleDist.0.bias'], padding=(r, 0))
+        dist = F.conv2d(dist, sd[p + 'moduleDist.1.weight'], sd[p + 'moduleDist.1.bias'], padding=(0, r))
+    dist = dist.pow(2.0).neg()
+    dist = (dist - dist.max(1, True)[0]).exp()
+    div = dist.sum(1, True).reciprocal()
+    sx = _conv(sd, p + 'moduleScaleX', dist * F.unfold(flow[:, 0:1], k, stride=1, padding=r).view_as(dist)) * div
+    sy = _conv(sd, p + 'moduleScaleY', dist * F.unfold(flow[:, 1:2], k, stride=1, padding=r).view_as(dist)) * div
+    return torch.cat([sx, sy], 1)
+
+
+def liteflownet_forward(sd, first, second, return_levels=False):
+    """lite_flow_net.py:285-325: returns {1..5: flow} scaled by 20*0.5^i (and the raw per-level flows)."""
+    f1 = features(sd, first)
+    f2 = features(sd, second)
+    im1, im2 = [first], [second]
+    for lv in range(1, 6):
+        size = (f1[lv].size(2), f1[lv].size(3))
+        im1.append(F.interpolate(im1[-1], size=size, mode='bilinear', align_corners=False))
+        im2.append(F.interpolate(im2[-1], size=size, mode='bilinear', align_corners=False))
+    flow = None
+    flows, raw = {}, {}
+    for cnt, lvl in enumerate([6, 5, 4, 3, 2]):
+        i = lvl - 1
+        flow = matching(sd, lvl, f1[i], f2[i], flow)
+        flow = subpixel(sd, lvl, f1[i], f2[i], flow)
+        flow = regularization(sd, lvl, im1[i], im2[i], f1[i], flow)
+        raw[lvl] = flow
+        flows[5 - cnt] = flow
+    for i in flows:
+        flows[i] = flows[i] * (20.0 * (0.5 ** i))
+    return (flows, raw) if return_levels else flows
+
+
+def get_target_size(h, w):
+    """deep_flow.py:89-105"""
+    hh = 32 * np.array([[math.floor(h / 32), math.floor(h / 32) + 1]])
+    ww = 32 * np.array([[math.floor(w / 32), math.floor(w / 32) + 1]])
+    ratio = np.abs(np.matmul(np.transpose(hh), 1 / ww) - h / w)
+    index = np.argmin(ratio)
+    return int(hh[0, index // 2]), int(ww[0, index % 2])
+
+
+def resize_dense_flow(flow, des_h, des_w):
+    """deep_flow.py:107-129"""
+    rh = float(des_h / flow.size(2))
+    rw = float(des_w / flow.size(3))
+    flow = F.interpolate(flow, (des_h, des_w), mode='bilinear', align_corners=True)
+    return torch.stack([flow[:, 0] * rw, flow[:, 1] * rh], dim=1)
+
+
+def flow_to_pix(flow):
+    """layers.py:193-229 (normalized=True)"""
+    _, _, h, w = flow.shape
+    mesh = np.meshgrid(range(w), range(h), indexing='xy')
+    ids = torch.from_numpy(np.stack(mesh, axis=0).astype(np.float32)).unsqueeze(0)
+    pix = (ids + flow).permute(0, 2, 3, 1).clone()
+    pix[..., 0] /= w - 1
+    pix[..., 1] /= h - 1
+    return (pix - 0.5) * 2
+
+
+def forward_backward_consistency(flow1, flow2, px1on2):
+    """deep_flow.py:171-196 (torch 1.1 grid_sample default: bilinear, zeros, corners aligned)"""
+    warp = F.grid_sample(-flow2, px1on2, mode='bilinear', padding_mode='zeros', align_corners=True)
+    return (flow1 - warp).norm(dim=1, keepdim=True).permute(0, 2, 3, 1)
+
+
+@torch.no_grad()
+def flow_inference(sd, ref_img_u8, cur_img_u8, return_levels=False):
+    """DeepModel.forward_flow (deep_models.py:144-182) + LiteFlow.inference_flow (lite_flow.py:89-148),
+    forward_backward=True.  Images uint8 [H,W,3].  Returns numpy fwd [2,H,W], bwd [2,H,W], diff [H,W,1]."""
+    cur = torch.from_numpy(np.transpose(cur_img_u8 / 255, (2, 0, 1))).unsqueeze(0).float()
+    ref = torch.from_numpy(np.transpose(ref_img_u8 / 255, (2, 0, 1))).unsqueeze(0).float()
+    img1 = torch.cat((ref, cur), 0)
+    img2 = torch.cat((cur, ref), 0)
+    _, _, h, w = img1.shape
+    th, tw = get_target_size(h, w)
+    r1 = F.interpolate(img1, (th, tw), mode='bilinear', align_corners=True)
+    r2 = F.interpolate(img2, (th, tw), mode='bilinear', align_corners=True)
+    out = liteflownet_forward(sd, r1, r2, return_levels=return_levels)
+    raw = None
+    if return_levels:
+        out, raw = out
+    flow = resize_dense_flow(out[1], h, w)
+    fwd, bwd = flow[0:1], flow[1:2]
+    diff = forward_backward_consistency(fwd, bwd, flow_to_pix(fwd))
+    res = (fwd[0].numpy(), bwd[0].numpy(), diff[0].numpy())
+    return res + (raw,) if return_levels else res
+
+
+# ----------------------------------------------------------------------------------------------
+# monodepth2
+# ----------------------------------------------------------------------------------------------
+def _bn(sd, name, x):
+    return F.batch_norm(x, sd[name + '.running_mean'], sd[name + '.running_var'], sd[name + '.weight'],
+                        sd[name + '.bias'], training=False, eps=1e-5)
+
+
+def _basic_block(sd, p, x, stride):
+    out = F.conv2d(x, sd[p + 'conv1.weight'], None, stride=stride, padding=1)
+    out = F.relu(_bn(sd, p + 'bn1', out))
+    out = _bn(sd, p + 'bn2', F.conv2d(out, sd[p + 'conv2.weight'], None, stride=1, padding=1))
+    idn = x
+    if (p + 'downsample.0.weight') in sd:
+        idn = _bn(sd, p + 'downsample.1', F.conv2d(x, sd[p + 'downsample.0.weight'], None, stride=stride))
+    return F.relu(out + idn)
+
+
+def resnet18_encoder(sd, img):
+    """resnet_encoder.py:87-98 over torchvision's resnet18 (keys 'encoder.*' as in encoder.pth)"""
+    feats = []
+    x = (img - 0.45) / 0.225
+    x = F.conv2d(x, sd['encoder.conv1.weight'], None, stride=2, padding=3)
+    x = F.relu(_bn(sd, 'encoder.bn1', x))
+    feats.append(x)
+    x = F.max_pool2d(x, 3, 2, 1)
+    for li in range(1, 5):
+        for b in range(2):
+            x = _basic_block(sd, 'encoder.layer%d.%d.' % (li, b), x, 2 if (li > 1 and b == 0) else 1)
+        feats.append(x)
+    return feats
+
+
+def _conv3x3_refl(sd, name, x):
+    return F.conv2d(F.pad(x, (1, 1, 1, 1), mode='reflect'), sd[name + '.weight'], sd[name + '.bias'])
+
+
+def depth_decoder(sd, feats):
+    """depth_decoder.py:50-65 (keys 'decoder.<idx>...' as in depth.pth); returns {scale: sigmoid disp}"""
+    out = {}
+    x = feats[-1]
+    for i in range(4, -1, -1):
+        idx0 = (4 - i) * 2
+        x = F.elu(_conv3x3_refl(sd, 'decoder.%d.conv.conv' % idx0, x))
+        x = [F.interpolate(x, scale_factor=2, mode='nearest')]
+        if i > 0:
+            x += [feats[i - 1]]
+        x = torch.cat(x, 1)
+        x = F.elu(_conv3x3_refl(sd, 'decoder.%d.conv.conv' % (idx0 + 1), x))
+        if i in range(4):
+            out[i] = torch.sigmoid(_conv3x3_refl(sd, 'decoder.%d.conv' % (10 + i), x))
+    return out
+
+
+@torch.no_grad()
+def depth_inference(sd, img_u8_feed, min_depth=0.1, max_depth=100, mult=5.4):
+    """DeepModel.forward_depth (deep_models.py:184-206) after the PIL resize, +
+    Monodepth2DepthNet.inference_depth (monodepth2.py:91-139).  img uint8 [feedH, feedW, 3]."""
+    x = torch.from_numpy(img_u8_feed).permute(2, 0, 1).contiguous().float().div(255).unsqueeze(0)
+    disp = depth_decoder(sd, resnet18_encoder(sd, x))[0]
+    disp = F.interpolate(disp, (x.shape[2], x.shape[3]), mode='bilinear', align_corners=False)
+    min_disp = 1 / max_depth
+    max_disp = 1 / min_depth
+    scaled = min_disp + (max_disp - min_disp) * disp
+    depth = (1. / scaled) * mult
+    return depth[0, 0].numpy()
+
+
+# ----------------------------------------------------------------------------------------------
+# seeded synthetic weights: the reference's own initialisation
+# ----------------------------------------------------------------------------------------------
+def liteflownet_state_dict(seed=4869, gain=1.0):
+    """Kaiming-normal conv weights, zero bias (lite_flow_net.py:273-282); `gain` < 1 tames activations."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+
+    def conv(name, cout, cin, kh, kw, bias=True):
+        fan_in = cin * kh * kw
+        std = math.sqrt(2.0) / math.sqrt(fan_in)
+        sd[name + '.weight'] = torch.randn(cout, cin, kh, kw, generator=g) * std * gain
+        if bias:
+            sd[name + '.bias'] = torch.randn(cout, generator=g) * 0.01
+
+    p = 'moduleFeatures.'
+    conv(p + 'moduleOne.0', 32, 3, 7, 7)
+    conv(p + 'moduleTwo.0', 32, 32, 3, 3)
+    conv(p + 'moduleTwo.2', 32, 32, 3, 3)
+    conv(p + 'moduleTwo.4', 32, 32, 3, 3)
+    conv(p + 'moduleThr.0', 64, 32, 3, 3)
+    conv(p + 'moduleThr.2', 64, 64, 3, 3)
+    conv(p + 'moduleFou.0', 96, 64, 3, 3)
+    conv(p + 'moduleFou.2', 96, 96, 3, 3)
+    conv(p + 'moduleFiv.0', 128, 96, 3, 3)
+    conv(p + 'moduleSix.0', 192, 128, 3, 3)
+    featc = [0, 32, 32, 64, 96, 128, 192]
+    for lvl in [2, 3, 4, 5, 6]:
+        k = KER[lvl]
+        cm = 64 if lvl == 2 else featc[lvl]
+        pm = 'moduleMatching.%d.' % (lvl - 2)
+        ps = 'moduleSubpixel.%d.' % (lvl - 2)
+        pr = 'moduleRegularization.%d.' % (lvl - 2)
+        if lvl == 2:
+            conv(pm + 'moduleFeat.0', 64, 32, 1, 1)
+            conv(ps + 'moduleFeat.0', 64, 32, 1, 1)
+        if lvl != 6:
+            # ConvTranspose2d(2, 2, 4, groups=2): weight [2, 1, 4, 4]; near-bilinear init keeps flows sane
+            sd[pm + 'moduleUpflow.weight'] = (torch.randn(2, 1, 4, 4, generator=g) * 0.05 + 0.25) * gain
+        if lvl < 4:
+            sd[pm + 'moduleUpcorr.weight'] = (torch.randn(49, 1, 4, 4, generator=g) * 0.05 + 0.25)
+        conv(pm + 'moduleMain.0', 128, 49, 3, 3)
+        conv(pm + 'moduleMain.2', 64, 128, 3, 3)
+        conv(pm + 'moduleMain.4', 32, 64, 3, 3)
+        conv(pm + 'moduleMain.6', 2, 32, k, k)
+        conv(ps + 'moduleMain.0', 128, 2 * cm + 2, 3, 3)
+        conv(ps + 'moduleMain.2', 64, 128, 3, 3)
+        conv(ps + 'moduleMain.4', 32, 64, 3, 3)
+        conv(ps + 'moduleMain.6', 2, 32, k, k)
+        if lvl < 5:
+            conv(pr + 'moduleFeat.0', 128, featc[lvl], 1, 1)
+        conv(pr + 'moduleMain.0', 128, 131 if lvl < 6 else 195, 3, 3)
+        conv(pr + 'moduleMain.2', 128, 128, 3, 3)
+        conv(pr + 'moduleMain.4', 64, 128, 3, 3)
+        conv(pr + 'moduleMain.6', 64, 64, 3, 3)
+        conv(pr + 'moduleMain.8', 32, 64, 3, 3)
+        conv(pr + 'moduleMain.10', 32, 32, 3, 3)
+        if lvl >= 5:
+            conv(pr + 'moduleDist.0', k * k, 32, k, k)
+        else:
+            conv(pr + 'moduleDist.0', k * k, 32, k, 1)
+            conv(pr + 'moduleDist.1', k * k, k * k, 1, k)
+        conv(pr + 'moduleScaleX', 1, k * k, 1, 1)
+        conv(pr + 'moduleScaleY', 1, k * k, 1, 1)
+    # flow heads: scale so that per-level flows are of the order of a pixel (warps get exercised)
+    for key in list(sd.keys()):
+        if key.endswith('moduleMain.6.weight'):
+            sd[key] = sd[key] * 3.0
+    return sd
+
+
+def monodepth2_state_dict(seed=4869):
+    """ResNet18 encoder (kaiming fan_out, BN identity-ish with seeded statistics) + decoder."""
+    g = torch.Generator().manual_seed(seed + 1)
+    sd = {}
+
+    def conv(name, cout, cin, k, bias):
+        std = math.sqrt(2.0 / (cin * k * k))
+        sd[name + '.weight'] = torch.randn(cout, cin, k, k, generator=g) * std
+        if bias:
+            sd[name + '.bias'] = torch.randn(cout, generator=g) * 0.01
+
+    def bn(name, c):
+        sd[name + '.weight'] = 1.0 + 0.1 * torch.randn(c, generator=g)
+        sd[name + '.bias'] = 0.05 * torch.randn(c, generator=g)
+        sd[name + '.running_mean'] = 0.05 * torch.randn(c, generator=g)
+        sd[name + '.running_var'] = 1.0 + 0.1 * torch.rand(c, generator=g)
+
+    conv('encoder.conv1', 64, 3, 7, False)
+    bn('encoder.bn1', 64)
+    ch = [64, 64, 128, 256, 512]
+    for li in range(1, 5):
+        cin, cout = ch[li - 1], ch[li]
+        for b in range(2):
+            p = 'encoder.layer%d.%d.' % (li, b)
+            conv(p + 'conv1', cout, cin if b == 0 else cout, 3, False)
+            bn(p + 'bn1', cout)
+            conv(p + 'conv2', cout, cout, 3, False)
+            bn(p + 'bn2', cout)
+            if li > 1 and b == 0:
+                conv(p + 'downsample.0', cout, cin, 1, False)
+                bn(p + 'downsample.1', cout)
+    dec = [16, 32, 64, 128, 256]
+    for i in range(4, -1, -1):
+        idx0 = (4 - i) * 2
+        cin0 = 512 if i == 4 else dec[i + 1]
+        conv('decoder.%d.conv.conv' % idx0, dec[i], cin0, 3, True)
+        conv('decoder.%d.conv.conv' % (idx0 + 1), dec[i], dec[i] + (ch[i - 1] if i > 0 else 0), 3, True)
+    for s in range(4):
+        conv('decoder.%d.conv' % (10 + s), 1, dec[s], 3, True)
+    return sd

@@ -1,0 +1,183 @@
+"""Generate golden fixtures by running the REFERENCE's own Python (read from /root/reference) in
+the build container.  The reference cannot travel to the GPU box, so the outputs are committed
+under tests/golden/*.npz together with this script.
+
+    python tests/golden/make_golden.py            # (re)writes the fixtures
+
+What runs here is reference code verbatim; only third-party imports are shimmed
+(oracle/ref_shims/README.md) and three documented compat patches are applied:
+  * correlation.FunctionCorrelation (cupy CUDA string)  -> oracle.nets_torch.correlation
+  * F.grid_sample default                              -> align_corners=True (torch 1.1 semantics)
+  * Tensor.cuda / Module.cuda / torch.cuda.current_stream -> CPU no-ops; np.int -> int
+np.argpartition order is CPU-dispatch dependent (SURVEY.md hard part 3): run with
+NPY_DISABLE_CPU_FEATURES set (done below by re-exec) so that the scalar introselect order is the
+canonical one.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+_SIMD_OFF = "AVX512F AVX512CD AVX512_SKX AVX512_CLX AVX512_CNL AVX512_ICL AVX512_SPR AVX2 FMA3"
+if os.environ.get("NPY_DISABLE_CPU_FEATURES") is None and "--no-reexec" not in sys.argv:
+    env = dict(os.environ, NPY_DISABLE_CPU_FEATURES=_SIMD_OFF)
+    os.execve(sys.executable, [sys.executable] + sys.argv + ["--no-reexec"], env)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.nn.functional as F  # noqa: E402
+
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle", "ref_shims"))
+sys.path.insert(0, REF)
+
+from oracle import nets_torch as O  # noqa: E402
+
+
+def apply_compat():
+    if not hasattr(np, "int"):
+        np.int = int
+    if not hasattr(np, "float"):
+        np.float = float
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    torch.cuda.current_stream = lambda *a, **k: types.SimpleNamespace(cuda_stream=0)
+    _gs = F.grid_sample
+
+    def grid_sample(input, grid, mode='bilinear', padding_mode='zeros', align_corners=None):
+        return _gs(input, grid, mode=mode, padding_mode=padding_mode,
+                   align_corners=True if align_corners is None else align_corners)
+    F.grid_sample = grid_sample
+    torch.nn.functional.grid_sample = grid_sample
+
+
+def load_by_path(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def golden_liteflownet():
+    from libs.deep_models.flow.lite_flow_net import correlation as ref_corr
+    ref_corr.FunctionCorrelation = lambda tensorFirst, tensorSecond, intStride: O.correlation(
+        tensorFirst, tensorSecond, intStride)
+    from libs.deep_models.flow.lite_flow_net import lite_flow_net as ref_lfn
+    net = ref_lfn.LiteFlowNet()
+    sd = O.liteflownet_state_dict(seed=4869)
+    missing = net.load_state_dict(sd, strict=True)
+    print("LiteFlowNet load_state_dict:", missing)
+    net.eval()
+    g = torch.Generator().manual_seed(1001)
+    h, w = 64, 96
+    base = torch.rand(2, 3, h + 8, w + 8, generator=g)
+    base = F.avg_pool2d(base, 5, 1, 2)  # smooth texture
+    first = base[:, :, 4:4 + h, 4:4 + w].contiguous()
+    second = base[:, :, 3:3 + h, 6:6 + w].contiguous()  # shifted copy
+    with torch.no_grad():
+        flows = net([first, second])
+    out = {"first": first.numpy(), "second": second.numpy()}
+    for k, v in flows.items():
+        out["flow%d" % k] = v.numpy()
+        print("  flow", k, tuple(v.shape), float(v.abs().max()))
+    np.savez_compressed(os.path.join(HERE, "liteflownet_64x96.npz"), **out)
+
+
+def golden_monodepth2():
+    from libs.deep_models.depth.monodepth2.resnet_encoder import ResnetEncoder
+    from libs.deep_models.depth.monodepth2.depth_decoder import DepthDecoder
+    enc = ResnetEncoder(18, False)
+    dec = DepthDecoder(num_ch_enc=enc.num_ch_enc, scales=range(4))
+    sd = O.monodepth2_state_dict(seed=4869)
+    enc_sd = {k: v for k, v in sd.items() if k.startswith("encoder.")}
+    # torchvision's resnet carries an unused fc layer + num_batches_tracked buffers: keep the module's own
+    full = enc.state_dict()
+    for k, v in enc_sd.items():
+        assert k in full and full[k].shape == v.shape, k
+        full[k] = v
+    enc.load_state_dict(full)
+    dec_sd = {k: v for k, v in sd.items() if k.startswith("decoder.")}
+    print("DepthDecoder load_state_dict:", dec.load_state_dict(dec_sd, strict=True))
+    enc.eval()
+    dec.eval()
+    g = torch.Generator().manual_seed(1002)
+    img = F.avg_pool2d(torch.rand(1, 3, 64, 96, generator=g), 3, 1, 1)
+    with torch.no_grad():
+        feats = enc(img)
+        outs = dec(feats)
+    out = {"img": img.numpy()}
+    for i, f in enumerate(feats):
+        out["feat%d" % i] = f.numpy()
+    for s in range(4):
+        out["disp%d" % s] = outs[("disp", s)].numpy()
+        print("  disp", s, tuple(outs[("disp", s)].shape))
+    np.savez_compressed(os.path.join(HERE, "monodepth2_64x96.npz"), **out)
+
+
+def kp_case(h, w, seed, frac):
+    """seeded flow / flow_diff maps for the keypoint-selection fixtures (also imported by the tests)"""
+    rng = np.random.Generator(np.random.PCG64(int(seed)))
+    diff = rng.random((int(h), int(w), 1), dtype=np.float32) * np.float32(0.1 / frac)
+    diff[rng.random((int(h), int(w), 1)) < 0.01] = np.float32(0.05)  # ties
+    flow = (rng.standard_normal((2, int(h), int(w))) * 3).astype(np.float32)
+    return diff, flow
+
+
+def golden_kp_selection():
+    kps = load_by_path("ref_kp_selection", os.path.join(REF, "libs/matching/kp_selection.py"))
+    from easydict import EasyDict
+    cfg = EasyDict({"kp_selection": {
+        "local_bestN": {"enable": True, "num_bestN": 2000, "num_row": 10, "num_col": 10, "score_method": "flow",
+                        "thre": 0.1},
+        "depth_consistency": {"enable": False, "thre": 0.05}}})
+    out = {}
+    for tag, (h, w, seed, frac) in {"a": (192, 640, 11, 0.6), "b": (376, 1241, 12, 0.35), "c": (100, 130, 13, 0.02),
+                                    "d": (120, 160, 14, 0.004)}.items():
+        diff, flow = kp_case(h, w, seed, frac)
+        x = np.linspace(0, w - 1, w)
+        y = np.linspace(0, h - 1, h)
+        xv, yv = np.meshgrid(x, y)
+        kp1 = np.expand_dims(np.transpose(np.stack([xv, yv]), (1, 2, 0)), 0)
+        kp2 = kp1 + np.transpose(np.expand_dims(flow, 0), (0, 2, 3, 1))
+        res = kps.local_bestN(kp1=kp1, kp2=kp2, ref_data={"flow_diff": diff, "flow": flow}, cfg=cfg,
+                              outputs={"good_kp_found": True})
+        out[tag + "_spec"] = np.array([h, w, seed, frac])  # inputs are regenerated from the seed by kp_case()
+        out[tag + "_good"] = np.array(res["good_kp_found"])
+        if res["good_kp_found"]:
+            out[tag + "_kp1"] = res["kp1_best"]
+            out[tag + "_kp2"] = res["kp2_best"]
+            print("  kp", tag, res["kp1_best"].shape)
+        else:
+            print("  kp", tag, "not enough keypoints")
+    np.savez_compressed(os.path.join(HERE, "local_bestN.npz"), **out)
+
+
+def golden_gric():
+    gric = load_by_path("ref_gric", os.path.join(REF, "libs/tracker/gric.py"))
+    rng = np.random.Generator(np.random.PCG64(21))
+    n = 500
+    kp1 = rng.random((n, 2)) * np.array([1241.0, 376.0])
+    kp2 = kp1 + rng.standard_normal((n, 2)) * 2 + np.array([3.0, 0.5])
+    Fm = rng.standard_normal((3, 3)) * np.array([[1e-6, 1e-5, 1e-3], [1e-5, 1e-6, 1e-2], [1e-3, 1e-2, 1.0]])
+    Hm = np.eye(3) + rng.standard_normal((3, 3)) * np.array([[1e-3, 1e-3, 1.0], [1e-3, 1e-3, 1.0], [1e-6, 1e-6, 0]])
+    f_res = gric.compute_fundamental_residual(Fm, kp1, kp2)
+    h_res = gric.compute_homography_residual(Hm, kp1, kp2)
+    np.savez_compressed(os.path.join(HERE, "gric.npz"), kp1=kp1, kp2=kp2, F=Fm, H=Hm, f_res=f_res, h_res=h_res,
+                        f_gric=gric.calc_GRIC(f_res, 0.8, n, "EMat"), h_gric=gric.calc_GRIC(h_res, 0.8, n, "HMat"))
+    print("  gric E", gric.calc_GRIC(f_res, 0.8, n, "EMat"), "H", gric.calc_GRIC(h_res, 0.8, n, "HMat"))
+
+
+if __name__ == "__main__":
+    apply_compat()
+    torch.set_num_threads(8)
+    which = [a for a in sys.argv[1:] if not a.startswith("--")]
+    todo = {"liteflownet": golden_liteflownet, "monodepth2": golden_monodepth2, "kp": golden_kp_selection,
+            "gric": golden_gric}
+    for name, fn in todo.items():
+        if not which or name in which:
+            print("==", name)
+            fn()

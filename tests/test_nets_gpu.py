@@ -1,0 +1,106 @@
+"""GPU parity of the two CNN executors (C ABI: dfvo_flownet_*, dfvo_depthnet_*) against the torch-CPU
+oracle (oracle/nets_torch.py, itself pinned to the reference by tests/golden).
+
+Tolerance: the nets are ~60 fp32 convolutions deep with data-dependent warps; the HIP path differs
+from torch-CPU only in fp32 summation order (MFMA fmaf chains vs oneDNN), so errors are reported
+relative to the flow magnitude.  Stated bound: max|dflow| <= 2e-3 px on the final maps with the
+seeded random weights (which amplify noise far more than trained weights do)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets_torch as O
+from synth import image_pair
+from util import report
+
+pytestmark = pytest.mark.gpu
+
+
+def make_flownet(capi, h, w, sd, graph=0):
+    lib = capi.lib()
+    net = C.c_void_p()
+    capi.check(lib.dfvo_flownet_create(h, w, None, C.byref(net)))
+    nh, nw = C.c_int(), C.c_int()
+    capi.check(lib.dfvo_flownet_net_size(net, C.byref(nh), C.byref(nw)))
+    params = {k: v.numpy() for k, v in sd.items()}
+    for l in range(1, 7):
+        params["aux.linspace_x.%d" % l] = torch.linspace(-1.0, 1.0, nw.value >> (l - 1)).numpy()
+        params["aux.linspace_y.%d" % l] = torch.linspace(-1.0, 1.0, nh.value >> (l - 1)).numpy()
+    capi.set_params(lib.dfvo_flownet_set_param, net, params)
+    capi.check(lib.dfvo_flownet_finalize(net))
+    capi.check(lib.dfvo_flownet_set_graph(net, graph))
+    return net, nh.value, nw.value
+
+
+@pytest.mark.parametrize("h,w", [(70, 100), (192, 640), (376, 1241)])
+def test_flownet_vs_oracle(gpu, h, w):
+    lib = gpu.lib()
+    sd = O.liteflownet_state_dict(4869)
+    ref_img, cur_img = image_pair(h, w, seed=1001 + h)
+    net, nh, nw = make_flownet(gpu, h, w, sd)
+    assert (nh, nw) == O.get_target_size(h, w)
+    fwd = np.zeros((2, h, w), np.float32)
+    bwd = np.zeros((2, h, w), np.float32)
+    diff = np.zeros((h, w), np.float32)
+    gpu.check(lib.dfvo_flownet_forward_host(net, gpu.as_ptr(ref_img), gpu.as_ptr(cur_img), gpu.as_ptr(fwd),
+                                            gpu.as_ptr(bwd), gpu.as_ptr(diff)))
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    O._grid_cache.clear()
+    ofwd, obwd, odiff, raw = O.flow_inference(sd, ref_img, cur_img, return_levels=True)
+    worst = 0.0
+    for lvl in (6, 5, 4, 3, 2):
+        lh, lw = nh >> (lvl - 1), nw >> (lvl - 1)
+        buf = np.zeros((2, lh, lw, 2), np.float32)
+        gpu.check(lib.dfvo_flownet_get_level_flow(net, lvl, gpu.as_ptr(buf), None, None))
+        e, s = report("flow level %d (%dx%d)" % (lvl, h, w), np.transpose(buf, (0, 3, 1, 2)), raw[lvl].numpy())
+        worst = max(worst, e / max(1.0, s))
+    e1, s1 = report("fwd flow", fwd, ofwd)
+    e2, s2 = report("bwd flow", bwd, obwd)
+    e3, s3 = report("flow diff", diff, odiff[..., 0])
+    print("   useful GFLOP per forward: %.1f" % (lib.dfvo_flownet_last_flops(net) / 1e9))
+    lib.dfvo_flownet_destroy(net)
+    assert np.isfinite(fwd).all() and np.isfinite(bwd).all() and np.isfinite(diff).all()
+    assert e1 <= 2e-3 * max(1.0, s1 / 10) and e2 <= 2e-3 * max(1.0, s2 / 10) and e3 <= 4e-3 * max(1.0, s3 / 10)
+
+
+def test_flownet_graph_replay_is_identical(gpu):
+    lib = gpu.lib()
+    h, w = 128, 224
+    sd = O.liteflownet_state_dict(4869)
+    ref_img, cur_img = image_pair(h, w, seed=7)
+    outs = []
+    for graph in (0, 1):
+        net, _, _ = make_flownet(gpu, h, w, sd, graph=graph)
+        for _ in range(3):  # eager+capture, replay, replay
+            fwd = np.zeros((2, h, w), np.float32)
+            bwd = np.zeros((2, h, w), np.float32)
+            diff = np.zeros((h, w), np.float32)
+            gpu.check(lib.dfvo_flownet_forward_host(net, gpu.as_ptr(ref_img), gpu.as_ptr(cur_img), gpu.as_ptr(fwd),
+                                                    gpu.as_ptr(bwd), gpu.as_ptr(diff)))
+            outs.append((fwd, bwd, diff))
+        lib.dfvo_flownet_destroy(net)
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("h,w", [(64, 96), (192, 640)])
+def test_depthnet_vs_oracle(gpu, h, w):
+    lib = gpu.lib()
+    sd = O.monodepth2_state_dict(4869)
+    img, _ = image_pair(h, w, seed=55)
+    net = C.c_void_p()
+    gpu.check(lib.dfvo_depthnet_create(h, w, 0.1, 100.0, 5.4, None, C.byref(net)))
+    gpu.set_params(lib.dfvo_depthnet_set_param, net, {k: v.numpy() for k, v in sd.items()})
+    gpu.check(lib.dfvo_depthnet_finalize(net))
+    depth = np.zeros((h, w), np.float32)
+    for _ in range(2):
+        gpu.check(lib.dfvo_depthnet_forward_host(net, gpu.as_ptr(img), gpu.as_ptr(depth)))
+    ref = O.depth_inference(sd, img)
+    e, s = report("depth %dx%d" % (h, w), depth, ref)
+    print("   useful GFLOP per forward: %.2f" % (lib.dfvo_depthnet_last_flops(net) / 1e9))
+    lib.dfvo_depthnet_destroy(net)
+    assert np.isfinite(depth).all()
+    assert e <= 1e-3 * max(1.0, s)

@@ -1,0 +1,170 @@
+"""GPU parity of the individual HIP operators against torch-CPU fp32 references of the same op
+(each a one-line restatement of the reference call site named in include/dfvo_hip.h).
+Tolerances are stated per test; fp32 MFMA is an exact fmaf chain, so conv errors are pure
+summation-order noise."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import nets_torch as O
+from util import nhwc_dev, nchw_host, ptr, report
+
+pytestmark = pytest.mark.gpu
+
+
+def run_conv(capi, x0, w, b, stride=1, pad=(0, 0), pad_mode=0, act=0, act_param=0.0, x1=None, up0=0, res=None,
+             cs0=None, cs1=None):
+    lib = capi.lib()
+    n, c0 = x0.shape[0], x0.shape[1]
+    c1 = x1.shape[1] if x1 is not None else 0
+    cout, cin, kh, kw = w.shape
+    assert cin == c0 + c1
+    H, W = (x0.shape[2] * 2, x0.shape[3] * 2) if up0 else (x0.shape[2], x0.shape[3])
+    Ho = (H + 2 * pad[0] - kh) // stride + 1
+    Wo = (W + 2 * pad[1] - kw) // stride + 1
+    d0 = nhwc_dev(x0, cs0)
+    d1 = nhwc_dev(x1, cs1) if x1 is not None else None
+    dcs = (cout + 3) // 4 * 4
+    dst = torch.zeros(n, Ho, Wo, dcs, device="cuda")
+    dres = nhwc_dev(res) if res is not None else None
+    desc = capi.ConvDesc(N=n, H=H, W=W, kh=kh, kw=kw, stride=stride, pad_h=pad[0], pad_w=pad[1], pad_mode=pad_mode,
+                         c0=c0, cs0=d0.shape[3], co0=0, up0=up0, c1=c1, cs1=d1.shape[3] if d1 is not None else 0, co1=0,
+                         cout=cout, act=act, act_param=act_param, res_cs=dres.shape[3] if dres is not None else 0,
+                         res_co=0, dst_cs=dcs, dst_co=0)
+    wn = np.ascontiguousarray(w.numpy())
+    bn = np.ascontiguousarray(b.numpy()) if b is not None else None
+    capi.check(lib.dfvo_conv2d(C.byref(desc), ptr(d0), ptr(d1), capi.as_ptr(wn), capi.as_ptr(bn), ptr(dres), ptr(dst),
+                               None))
+    torch.cuda.synchronize()
+    return nchw_host(dst, cout)
+
+
+def ref_act(y, act, a):
+    return {0: lambda t: t, 1: lambda t: F.leaky_relu(t, a), 2: F.relu, 3: lambda t: F.elu(t, a), 4: torch.sigmoid}[act](y)
+
+
+CASES = [
+    # name, N, H, W, c0, c1, cout, kh, kw, stride, pad, pad_mode, act, up0, res
+    ("3x3_64_128_leaky", 2, 24, 40, 64, 0, 128, 3, 3, 1, (1, 1), 0, 1, 0, False),
+    ("7x7_3_32", 2, 40, 56, 3, 0, 32, 7, 7, 1, (3, 3), 0, 1, 0, False),
+    ("3x3s2_32_64", 2, 48, 64, 32, 0, 64, 3, 3, 2, (1, 1), 0, 1, 0, False),
+    ("1x1_32_64", 2, 33, 47, 32, 0, 64, 1, 1, 1, (0, 0), 0, 1, 0, False),
+    ("cat_64+66_128", 2, 20, 30, 64, 66, 128, 3, 3, 1, (1, 1), 0, 1, 0, False),
+    ("cat_3+128_128", 2, 20, 30, 3, 128, 128, 3, 3, 1, (1, 1), 0, 1, 0, False),
+    ("head7x7_32_2_res", 2, 30, 44, 32, 0, 2, 7, 7, 1, (3, 3), 0, 0, 0, True),
+    ("dist7x1_32_49", 2, 30, 44, 32, 0, 49, 7, 1, 1, (3, 0), 0, 0, 0, False),
+    ("dist1x7_49_49", 2, 30, 44, 49, 0, 49, 1, 7, 1, (0, 3), 0, 0, 0, False),
+    ("96_96", 2, 16, 24, 96, 0, 96, 3, 3, 1, (1, 1), 0, 1, 0, False),
+    ("192_out", 2, 8, 12, 128, 0, 192, 3, 3, 2, (1, 1), 0, 1, 0, False),
+    ("dec_refl_up_cat_elu", 1, 12, 20, 128, 128, 128, 3, 3, 1, (1, 1), 1, 3, 1, False),
+    ("dec_refl_sigmoid_16_1", 1, 32, 48, 16, 0, 1, 3, 3, 1, (1, 1), 1, 4, 0, False),
+    ("resnet_512_small", 1, 6, 20, 512, 0, 512, 3, 3, 1, (1, 1), 0, 2, 0, True),
+    ("big_M_128_128", 2, 96, 160, 128, 0, 128, 3, 3, 1, (1, 1), 0, 1, 0, False),
+    ("big_M_64_32", 2, 96, 160, 64, 0, 32, 3, 3, 1, (1, 1), 0, 1, 0, False),
+    ("big_M_32_2_5x5", 2, 96, 160, 32, 0, 2, 5, 5, 1, (2, 2), 0, 0, 0, True),
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv(gpu, case):
+    name, n, h, w, c0, c1, cout, kh, kw, stride, pad, pad_mode, act, up0, use_res = case
+    g = torch.Generator().manual_seed(hash(name) % 10000)
+    x0 = torch.randn(n, c0, h, w, generator=g)
+    H, W = (2 * h, 2 * w) if up0 else (h, w)
+    x1 = torch.randn(n, c1, H, W, generator=g) if c1 else None
+    wt = torch.randn(cout, c0 + c1, kh, kw, generator=g) / np.sqrt((c0 + c1) * kh * kw)
+    b = torch.randn(cout, generator=g) * 0.1
+    xin = F.interpolate(x0, scale_factor=2, mode="nearest") if up0 else x0
+    if x1 is not None:
+        xin = torch.cat([xin, x1], 1)
+    if pad_mode == 1:
+        ref = F.conv2d(F.pad(xin, (pad[1], pad[1], pad[0], pad[0]), mode="reflect"), wt, b, stride=stride)
+    else:
+        ref = F.conv2d(xin, wt, b, stride=stride, padding=pad)
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    if res is not None:
+        ref = ref + res
+    ref = ref_act(ref, act, 0.1 if act == 1 else 1.0)
+    got = run_conv(gpu, x0, wt, b, stride, pad, pad_mode, act, 0.1 if act == 1 else 1.0, x1, up0, res)
+    err, scale = report("conv " + name, got, ref)
+    assert err <= 2e-5 * max(1.0, scale)
+
+
+@pytest.mark.parametrize("C,stride,h,w", [(64, 1, 12, 20), (64, 2, 24, 39), (96, 1, 12, 13), (128, 1, 9, 11),
+                                           (192, 1, 6, 10), (32, 2, 17, 23)])
+def test_correlation(gpu, C, stride, h, w):
+    lib = gpu.lib()
+    g = torch.Generator().manual_seed(C + stride)
+    a = torch.randn(2, C, h, w, generator=g)
+    b = torch.randn(2, C, h, w, generator=g)
+    ho, wo = -(-h // stride), -(-w // stride)
+    out = torch.zeros(2, ho, wo, 52, device="cuda")
+    da, db = nhwc_dev(a), nhwc_dev(b)
+    gpu.check(lib.dfvo_correlation(ptr(da), ptr(db), 2, h, w, C, stride, 1.0, ptr(out), None))
+    torch.cuda.synchronize()
+    got = nchw_host(out, 49)
+    ref = O.correlation(a, b, stride)
+    err, scale = report("correlation C=%d s=%d" % (C, stride), got, ref)
+    assert err <= 1e-5 * max(1.0, scale)
+    exact = O.correlation_cuda_order(a, b, stride)
+    nbad = int((got != exact).sum())
+    print("   bit-exact vs CUDA-order restatement: %d / %d differ" % (nbad, exact.numel()))
+    assert nbad <= exact.numel() // 1000  # fmaf emulation via float64 can double-round on rare elements
+    # leaky relu fused
+    gpu.check(lib.dfvo_correlation(ptr(da), ptr(db), 2, h, w, C, stride, 0.1, ptr(out), None))
+    torch.cuda.synchronize()
+    assert (nchw_host(out, 49) - F.leaky_relu(got, 0.1)).abs().max() <= 1e-7
+
+
+@pytest.mark.parametrize("C,h,w,mult", [(64, 24, 40, 2.5), (4, 48, 64, 10.0), (96, 7, 9, 0.625)])
+def test_backward_warp(gpu, C, h, w, mult):
+    lib = gpu.lib()
+    g = torch.Generator().manual_seed(C)
+    src = torch.randn(2, C, h, w, generator=g)
+    flow = torch.randn(2, 2, h, w, generator=g) * 1.5
+    flow[0, :, 0, 0] = torch.tensor([-30.0, 4.0])  # far out of range -> zeros
+    O._grid_cache.clear()
+    ref = O.backward_warp(src, flow * mult)
+    lx = torch.linspace(-1.0, 1.0, w).numpy()
+    ly = torch.linspace(-1.0, 1.0, h).numpy()
+    dsrc = nhwc_dev(src)
+    dflow = flow.permute(0, 2, 3, 1).contiguous().cuda()
+    dst = torch.zeros(2, h, w, C, device="cuda")
+    gpu.check(lib.dfvo_backward_warp(ptr(dsrc), ptr(dflow), mult, 2, h, w, C, gpu.as_ptr(lx), gpu.as_ptr(ly), ptr(dst),
+                                     None))
+    torch.cuda.synchronize()
+    err, scale = report("warp C=%d" % C, nchw_host(dst, C), ref)
+    assert err <= 2e-5 * max(1.0, scale)
+
+
+@pytest.mark.parametrize("C,cs,h,w", [(2, 4, 12, 20), (49, 52, 9, 14)])
+def test_deconv_dw(gpu, C, cs, h, w):
+    lib = gpu.lib()
+    g = torch.Generator().manual_seed(C)
+    x = torch.randn(2, C, h, w, generator=g)
+    wt = torch.randn(C, 1, 4, 4, generator=g)
+    ref = F.conv_transpose2d(x, wt, None, stride=2, padding=1, groups=C)
+    dx = nhwc_dev(x, cs)
+    dst = torch.zeros(2, 2 * h, 2 * w, cs, device="cuda")
+    wn = np.ascontiguousarray(wt.numpy())
+    gpu.check(lib.dfvo_deconv_dw4x4s2(ptr(dx), 2, h, w, C, cs, gpu.as_ptr(wn), ptr(dst), None))
+    torch.cuda.synchronize()
+    err, scale = report("deconv C=%d" % C, nchw_host(dst, C), ref)
+    assert err <= 1e-5 * max(1.0, scale)
+
+
+@pytest.mark.parametrize("ac,h,w,ho,wo", [(0, 48, 64, 24, 32), (1, 37, 53, 48, 64), (0, 24, 39, 12, 20), (1, 48, 64, 37, 53)])
+def test_resize_bilinear(gpu, ac, h, w, ho, wo):
+    lib = gpu.lib()
+    g = torch.Generator().manual_seed(h)
+    x = torch.randn(2, 4, h, w, generator=g)
+    ref = F.interpolate(x, (ho, wo), mode="bilinear", align_corners=bool(ac))
+    dx = nhwc_dev(x)
+    dst = torch.zeros(2, ho, wo, 4, device="cuda")
+    gpu.check(lib.dfvo_resize_bilinear(ptr(dx), 2, h, w, 4, ptr(dst), ho, wo, ac, None))
+    torch.cuda.synchronize()
+    err, scale = report("resize ac=%d" % ac, nchw_host(dst, 4), ref)
+    assert err <= 1e-5 * max(1.0, scale)

@@ -1,0 +1,52 @@
+"""CPU: the torch restatement of the nets (oracle/nets_torch.py) against fixtures produced by the
+reference's own classes (tests/golden/make_golden.py)."""
+import os
+
+import numpy as np
+import torch
+
+from oracle import nets_torch as O
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_liteflownet_matches_reference_fixture():
+    g = np.load(os.path.join(G, "liteflownet_64x96.npz"))
+    sd = O.liteflownet_state_dict(4869)
+    with torch.no_grad():
+        flows = O.liteflownet_forward(sd, torch.from_numpy(g["first"]), torch.from_numpy(g["second"]))
+    for k in range(1, 6):
+        want = g["flow%d" % k]
+        got = flows[k].numpy()
+        assert got.shape == want.shape
+        # same torch build on the same ISA reproduces bit-for-bit; allow fp32 noise across CPUs
+        assert np.abs(got - want).max() <= 2e-4 * max(1.0, np.abs(want).max()), k
+
+
+def test_monodepth2_matches_reference_fixture():
+    g = np.load(os.path.join(G, "monodepth2_64x96.npz"))
+    sd = O.monodepth2_state_dict(4869)
+    with torch.no_grad():
+        feats = O.resnet18_encoder(sd, torch.from_numpy(g["img"]))
+        disps = O.depth_decoder(sd, feats)
+    for i in range(5):
+        assert np.abs(feats[i].numpy() - g["feat%d" % i]).max() <= 1e-4 * max(1.0, np.abs(g["feat%d" % i]).max())
+    for s in range(4):
+        assert np.abs(disps[s].numpy() - g["disp%d" % s]).max() <= 1e-5
+
+
+def test_correlation_orders_agree():
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(1, 64, 6, 9, generator=g)
+    b = torch.randn(1, 64, 6, 9, generator=g)
+    for s in (1, 2):
+        x = O.correlation(a, b, s)
+        y = O.correlation_cuda_order(a, b, s)
+        assert x.shape == y.shape
+        assert (x - y).abs().max() < 1e-5
+
+
+def test_target_size():
+    assert O.get_target_size(376, 1241) == (384, 1248)
+    assert O.get_target_size(370, 1226) == (384, 1248)
+    assert O.get_target_size(192, 640) == (192, 640)
