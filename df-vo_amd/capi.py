@@ -64,6 +64,12 @@ SIGNATURES = {
     "dfvo_depthnet_last_flops": (_d, [_vp]),
     "dfvo_depthnet_sync": (_i, [_vp]),
     "dfvo_depth_postprocess": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
+    "dfvo_tracker_create": (_i, [_vp, C.POINTER(_vp)]),
+    "dfvo_tracker_destroy": (None, [_vp]),
+    "dfvo_find_essential_mat": (_i, [_vp, _vp, _vp, _i, _d, _d, _d, _d, _d, _i, _vp, _vp, _vp]),
+    "dfvo_find_homography": (_i, [_vp, _vp, _vp, _i, _d, _i, _d, _vp, _vp, _vp]),
+    "dfvo_recover_pose": (_i, [_vp, _vp, _vp, _vp, _i, _d, _d, _d, _vp, _vp, _vp, _ip]),
+    "dfvo_triangulate_points": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
 }
 
 

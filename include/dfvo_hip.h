@@ -130,6 +130,33 @@ int dfvo_depthnet_sync(dfvo_depthnet* net);
 int dfvo_depth_postprocess(const float* d_depth, int h, int w, int H, int W, int y0, int y1, int x0, int x1,
                            float min_depth, float max_depth, float* d_raw, double* d_proc, void* stream);
 
+/* =====================================================================================
+ * Pose solvers (wavefront-parallel RANSAC, f64).  Host arrays in / out, synchronous: these are the
+ * calls the Python mirror classes make where the reference calls OpenCV.
+ * ===================================================================================== */
+typedef struct dfvo_tracker dfvo_tracker;
+int dfvo_tracker_create(void* stream, dfvo_tracker** out);
+void dfvo_tracker_destroy(dfvo_tracker* trk);
+
+/* cv2.findEssentialMat(points1, points2, focal, pp, RANSAC, prob, threshold)
+ * (E_tracker.py:59-67,231-239).  h_pts [n][2] doubles.  h_E[9], h_mask[n] (0/1).
+ * h_info[5] = {found, iterations replayed, winning iteration, winning model, inlier count}.
+ * max_iters: 1000 reproduces OpenCV 3.4.3 (not a Python parameter there). */
+int dfvo_find_essential_mat(dfvo_tracker* trk, const double* h_pts1, const double* h_pts2, int n, double focal,
+                            double ppx, double ppy, double prob, double threshold, int max_iters, double* h_E,
+                            uint8_t* h_mask, int* h_info);
+/* cv2.findHomography(src, dst, RANSAC, ransacReprojThreshold, maxIters=2000, confidence)
+ * (E_tracker.py:188-194,199-205) including the least-squares refit and the LM refinement. */
+int dfvo_find_homography(dfvo_tracker* trk, const double* h_pts1, const double* h_pts2, int n, double thr,
+                         int max_iters, double confidence, double* h_H, uint8_t* h_mask, int* h_info);
+/* cv2.recoverPose(E, points1, points2, focal, pp) (E_tracker.py:73-75,251-253,292-295).
+ * h_R[9], h_t[3], h_mask[n] (0/255), *h_good = cheirality count. */
+int dfvo_recover_pose(dfvo_tracker* trk, const double* h_E, const double* h_pts1, const double* h_pts2, int n,
+                      double focal, double ppx, double ppy, double* h_R, double* h_t, uint8_t* h_mask, int* h_good);
+/* cv2.triangulatePoints(P1, P2, x1, x2) (ops_3d.py:63): P 3x4, x [2][n], X4 [4][n] */
+int dfvo_triangulate_points(dfvo_tracker* trk, const double* h_P1, const double* h_P2, const double* h_x1,
+                            const double* h_x2, int n, double* h_X4);
+
 #ifdef __cplusplus
 }
 #endif

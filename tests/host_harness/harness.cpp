@@ -1,0 +1,33 @@
+// TEST-ONLY host build of df-vo_amd/csrc/solver_math.h (the per-lane device functions of the HIP
+// solvers) so that their arithmetic can be checked bit-for-bit against the C oracle on a machine
+// without a GPU.  Never linked into libdfvo_hip.so; the product has no CPU path.
+#include "../../df-vo_amd/csrc/solver_math.h"
+
+extern "C" {
+
+int hh_five_point(const double* q1, const double* q2, double* E_out) {
+    double EE[36], b[39], c[11], rre[10], rim[10];
+    if (!sm::five_point_stage1(q1, q2, EE, b, c)) return 0;
+    sm::solve_poly10(c, rre, rim);
+    return sm::five_point_stage3(EE, b, rre, rim, E_out);
+}
+float hh_essential_error(const double* E, double a, double b, double c, double d) {
+    return sm::essential_error(E, a, b, c, d);
+}
+int hh_homography_kernel(const float* M, const float* m, int count, double* H) {
+    return sm::homography_kernel(M, m, count, H) ? 1 : 0;
+}
+int hh_homography_check_subset(const float* M, const float* m) { return sm::homography_check_subset(M, m) ? 1 : 0; }
+float hh_homography_error(const double* H, float Mx, float My, float mx, float my) {
+    float Hf[8];
+    for (int i = 0; i < 8; i++) Hf[i] = (float)H[i];
+    return sm::homography_error(Hf, Mx, My, mx, my);
+}
+void hh_decompose_essential(const double* E, double* R1, double* R2, double* t) { sm::decompose_essential(E, R1, R2, t); }
+void hh_triangulate_point(const double* P1, const double* P2, double x1, double y1, double x2, double y2, double* X) {
+    sm::triangulate_point(P1, P2, x1, y1, x2, y2, X);
+}
+int hh_ransac_update_num_iters(double p, double ep, int mp, int mi) { return sm::ransac_update_num_iters(p, ep, mp, mi); }
+void hh_solve_eig8(const double* A, const double* b, double* x) { sm::solve_eig<8>(A, b, x); }
+void hh_invert_eig8(const double* A, double* d) { sm::invert_eig<8>(A, d); }
+}

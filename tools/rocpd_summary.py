@@ -1,0 +1,31 @@
+"""Summarise a rocprofv3 (rocpd sqlite) kernel trace: per-kernel calls / total / average / share,
+optionally split by grid size.  Usage: python tools/rocpd_summary.py <results.db> [--by-grid] [--top N]"""
+import sqlite3
+import sys
+
+
+def main():
+    db = sqlite3.connect(sys.argv[1])
+    by_grid = "--by-grid" in sys.argv
+    top = 40
+    if "--top" in sys.argv:
+        top = int(sys.argv[sys.argv.index("--top") + 1])
+    cur = db.cursor()
+    key = "name, grid_x, grid_y, grid_z" if by_grid else "name"
+    rows = list(cur.execute(
+        "select %s, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by %s "
+        "order by sum(duration) desc" % (key, key)))
+    total = sum(r[-4] for r in rows)
+    print("total kernel time %.3f ms over %d dispatches" % (total / 1e6, sum(r[-5] for r in rows)))
+    print("%-72s %7s %11s %10s %10s %10s %6s" % ("kernel", "calls", "total_us", "avg_us", "min_us", "max_us", "%"))
+    for r in rows[:top]:
+        name = r[0]
+        if by_grid:
+            name = "%s [%dx%dx%d]" % (r[0][:48], r[1], r[2], r[3])
+        n, tot, avg, mn, mx = r[-5:]
+        print("%-72s %7d %11.1f %10.2f %10.2f %10.2f %6.2f" % (name[:72], n, tot / 1e3, avg / 1e3, mn / 1e3, mx / 1e3,
+                                                               100.0 * tot / total))
+
+
+if __name__ == "__main__":
+    main()
