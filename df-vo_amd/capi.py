@@ -83,6 +83,12 @@ def lib():
             "libdfvo_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'`. "
             "There is no CPU fallback." % LIB_PATH)
     try:
+        # torch bundles its own libamdhip64; import it FIRST so that one HIP runtime serves both
+        # (loading ours first made torch.cuda unavailable on the GPU box)
+        import torch  # noqa: F401
+    except ImportError:  # pragma: no cover
+        pass
+    try:
         l = C.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover
         raise DfvoError("cannot load %s: %s" % (LIB_PATH, e))

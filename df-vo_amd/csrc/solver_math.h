@@ -38,6 +38,20 @@ SM_HD unsigned cvrng_next(CvRng& r) {
 }
 SM_HD int cvrng_uniform(CvRng& r, int a, int b) { return a == b ? a : (int)(cvrng_next(r) % (unsigned)(b - a) + a); }
 
+// hypot from IEEE-exact operations only (+ * / sqrt): libm's hypot differs between glibc and the
+// device library in the last bit, which would break bit-reproducibility of the Jacobi rotations.
+SM_HD double hypot_p(double x, double y) {
+    double a = fabs(x), b = fabs(y);
+    if (a < b) {
+        const double t = a;
+        a = b;
+        b = t;
+    }
+    if (a == 0) return 0;
+    const double r = b / a;
+    return a * sqrt(1 + r * r);
+}
+
 SM_HD double det3(const double* m) {
     return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
 }
@@ -82,7 +96,7 @@ SM_HD_NOINLINE void jacobi_svd(double* At, int astep, double* W, double* Vt, int
                 for (k = 0; k < m; k++) p += Ai[k] * Aj[k];
                 if (fabs(p) <= eps * sqrt(a * b)) continue;
                 p *= 2;
-                const double beta = a - b, gamma = hypot(p, beta);
+                const double beta = a - b, gamma = hypot_p(p, beta);
                 if (beta < 0) {
                     const double delta = (gamma - beta) * 0.5;
                     s = sqrt(delta / gamma);
@@ -237,8 +251,8 @@ SM_HD_NOINLINE void jacobi_eigen(double* A, double* W, double* V) {
             const double p = A[astep * k + l];
             if (fabs(p) <= eps) break;
             const double y = (W[l] - W[k]) * 0.5;
-            double t = fabs(y) + hypot(p, y);
-            double s = hypot(p, t);
+            double t = fabs(y) + hypot_p(p, y);
+            double s = hypot_p(p, t);
             const double c = t / s;
             s = p / s;
             t = (p / t) * p;

@@ -17,6 +17,20 @@ int cv3_rng_uniform_int(cv3_rng* r, int a, int b) { return a == b ? a : (int)(cv
 
 int cv3_round(double v) { return (int)lrint(v); }
 
+/* std::hypot in OpenCV; restated with IEEE-exact operations only so that the oracle and the GPU
+ * solvers agree bit for bit (glibc's and the device library's hypot differ in the last bit) */
+static double cv3_hypot(double x, double y) {
+    double a = fabs(x), b = fabs(y);
+    if (a < b) {
+        const double t = a;
+        a = b;
+        b = t;
+    }
+    if (a == 0) return 0;
+    const double r = b / a;
+    return a * sqrt(1 + r * r);
+}
+
 double cv3_det3(const double* m) {
     return m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
 }
@@ -55,7 +69,7 @@ void cv3_jacobi_svd(double* At, int astep, double* _W, double* Vt, int vstep, in
                 for (k = 0; k < m; k++) p += Ai[k] * Aj[k];
                 if (fabs(p) <= eps * sqrt(a * b)) continue;
                 p *= 2;
-                double beta = a - b, gamma = hypot(p, beta);
+                double beta = a - b, gamma = cv3_hypot(p, beta);
                 if (beta < 0) {
                     double delta = (gamma - beta) * 0.5;
                     s = sqrt(delta / gamma);
@@ -241,8 +255,8 @@ void cv3_jacobi_eigen(double* A, int n, double* W, double* V) {
             double p = A[astep * k + l];
             if (fabs(p) <= eps) break;
             double y = (W[l] - W[k]) * 0.5;
-            double t = fabs(y) + hypot(p, y);
-            double s = hypot(p, t);
+            double t = fabs(y) + cv3_hypot(p, y);
+            double s = cv3_hypot(p, t);
             double c = t / s;
             s = p / s;
             t = (p / t) * p;

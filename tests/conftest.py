@@ -24,7 +24,7 @@ def capi():
 @pytest.fixture(scope="session")
 def gpu(capi):
     """loaded library + a visible device; GPU tests FAIL (not skip) when the HIP path is unavailable"""
-    capi.require_gpu()
     import torch
+    capi.require_gpu()
     assert torch.cuda.is_available(), "torch sees no GPU"
     return capi

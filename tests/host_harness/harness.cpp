@@ -31,3 +31,33 @@ int hh_ransac_update_num_iters(double p, double ep, int mp, int mi) { return sm:
 void hh_solve_eig8(const double* A, const double* b, double* x) { sm::solve_eig<8>(A, b, x); }
 void hh_invert_eig8(const double* A, double* d) { sm::invert_eig<8>(A, d); }
 }
+
+// ---- numpy legacy RandomState + argpartition emulation
+#include "../../df-vo_amd/csrc/kp_select.h"
+#include "../../df-vo_amd/csrc/np_legacy.h"
+extern "C" {
+// state: key[624] + pos (as uint32[625]); functions update it in place
+void hh_mt_shuffle(uint32_t* state, int n, int* perm) {
+    sm::Mt19937 s;
+    for (int i = 0; i < 624; i++) s.key[i] = state[i];
+    s.pos = (int)state[624];
+    sm::mt_shuffle_arange(s, n, perm);
+    for (int i = 0; i < 624; i++) state[i] = s.key[i];
+    state[624] = (uint32_t)s.pos;
+}
+void hh_mt_sample(uint32_t* state, int n_population, int n_samples, int* out) {
+    sm::Mt19937 s;
+    for (int i = 0; i < 624; i++) s.key[i] = state[i];
+    s.pos = (int)state[624];
+    sm::mt_sample_without_replacement(s, n_population, n_samples, out);
+    for (int i = 0; i < 624; i++) state[i] = s.key[i];
+    state[624] = (uint32_t)s.pos;
+}
+void hh_argpartition(const float* v, int num, int kth, int* tosort) {
+    for (int i = 0; i < num; i++) tosort[i] = i;
+    if (num > 0) sm::kp_introselect<int>(v, tosort, num, kth, 0);
+}
+void hh_cell_bounds(int h, int w, int nr, int nc, int row, int col, int* out) {
+    sm::kp_cell_bounds(h, w, nr, nc, row, col, out, out + 1, out + 2, out + 3);
+}
+}
