@@ -18,6 +18,23 @@ class DfvoError(RuntimeError):
 _lib = None
 
 
+class Pose2d2dCfg(C.Structure):
+    _fields_ = [("fx", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("reproj_thre", C.c_double),
+                ("repeat", C.c_int), ("max_iters", C.c_int), ("KinvT", C.c_double * 9), ("Kinv", C.c_double * 9)]
+
+
+class Pose2d2dOut(C.Structure):
+    _fields_ = [("R", C.c_double * 9), ("t", C.c_double * 3), ("n", C.c_int), ("best_inlier_cnt", C.c_int),
+                ("num_valid", C.c_int), ("major_valid", C.c_int), ("cheirality", C.c_int), ("h_found", C.c_int),
+                ("h_gric", C.c_double), ("rep_inliers", C.c_int * 8), ("rep_valid", C.c_int * 8),
+                ("rep_gric", C.c_double * 8)]
+
+
+class ScaleCfg(C.Structure):
+    _fields_ = [("cx", C.c_double), ("cy", C.c_double), ("fx", C.c_double), ("fy", C.c_double),
+                ("min_samples", C.c_int), ("max_trials", C.c_int), ("stop_prob", C.c_double), ("thre", C.c_double)]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "N", "H", "W", "kh", "kw", "stride", "pad_h", "pad_w", "pad_mode",
@@ -70,6 +87,12 @@ SIGNATURES = {
     "dfvo_find_homography": (_i, [_vp, _vp, _vp, _i, _d, _i, _d, _vp, _vp, _vp]),
     "dfvo_recover_pose": (_i, [_vp, _vp, _vp, _vp, _i, _d, _d, _d, _vp, _vp, _vp, _ip]),
     "dfvo_triangulate_points": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "dfvo_tracker_seed": (_i, [_vp, C.c_uint32]),
+    "dfvo_tracker_set_rng_state": (_i, [_vp, _vp]),
+    "dfvo_tracker_get_rng_state": (_i, [_vp, _vp]),
+    "dfvo_kp_local_bestn": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _ip, _ip]),
+    "dfvo_compute_pose_2d2d": (_i, [_vp, _vp, _vp, _i, C.POINTER(Pose2d2dCfg), C.POINTER(Pose2d2dOut), _vp]),
+    "dfvo_find_scale_from_depth": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, C.POINTER(ScaleCfg), C.POINTER(_d), _ip]),
 }
 
 

@@ -2,13 +2,19 @@
 #include <vector>
 
 #include "solver.h"
+#include "tracker.h"
+#include "../../include/dfvo_hip.h"
 
 using namespace dfvo;
 
 struct dfvo_tracker {
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    RansacWorkspace ws;
+    TrackerBuffers tb;
+    RansacWorkspace& ws = tb.ws_e;
+    float *d_flow = nullptr, *d_diff = nullptr;
+    double* d_depth = nullptr;
+    size_t flow_cap = 0, depth_cap = 0;
     double* d_small = nullptr;  // 64 doubles
     double *d_x1 = nullptr, *d_x2 = nullptr, *d_X4 = nullptr;
     int tri_cap = 0;
@@ -29,18 +35,22 @@ int dfvo_tracker_create(void* stream, dfvo_tracker** out) {
         }
         t->own_stream = true;
     }
-    if (hipMalloc((void**)&t->d_small, 64 * sizeof(double)) != hipSuccess) {
+    if (hipMalloc((void**)&t->d_small, 64 * sizeof(double)) != hipSuccess || t->tb.init() != DFVO_OK) {
         delete t;
         dfvo::set_last_error("hipMalloc failed");
         return DFVO_ERR_HIP;
     }
+    enqueue_mt_seed(t->tb, 5489u, t->stream);
     *out = t;
     return DFVO_OK;
 }
 
 void dfvo_tracker_destroy(dfvo_tracker* t) {
     if (!t) return;
-    t->ws.release();
+    t->tb.release();
+    if (t->d_flow) (void)hipFree(t->d_flow);
+    if (t->d_diff) (void)hipFree(t->d_diff);
+    if (t->d_depth) (void)hipFree(t->d_depth);
     if (t->d_small) (void)hipFree(t->d_small);
     if (t->d_x1) (void)hipFree(t->d_x1);
     if (t->d_x2) (void)hipFree(t->d_x2);
@@ -139,6 +149,145 @@ int dfvo_triangulate_points(dfvo_tracker* t, const double* h_P1, const double* h
     if (rc != DFVO_OK) return rc;
     DFVO_HIP_CHECK(hipMemcpyAsync(h_X4, t->d_X4, sizeof(double) * 4 * n, hipMemcpyDeviceToHost, t->stream));
     DFVO_HIP_CHECK(hipStreamSynchronize(t->stream));
+    return DFVO_OK;
+}
+
+
+int dfvo_tracker_seed(dfvo_tracker* t, uint32_t seed) {
+    DFVO_ARG_CHECK(t, "null tracker");
+    return enqueue_mt_seed(t->tb, seed, t->stream);
+}
+int dfvo_tracker_set_rng_state(dfvo_tracker* t, const uint32_t* h) {
+    DFVO_ARG_CHECK(t && h, "dfvo_tracker_set_rng_state: null argument");
+    DFVO_HIP_CHECK(hipMemcpyAsync(t->tb.mt_state, h, 625 * sizeof(uint32_t), hipMemcpyHostToDevice, t->stream));
+    DFVO_HIP_CHECK(hipStreamSynchronize(t->stream));
+    return DFVO_OK;
+}
+int dfvo_tracker_get_rng_state(dfvo_tracker* t, uint32_t* h) {
+    DFVO_ARG_CHECK(t && h, "dfvo_tracker_get_rng_state: null argument");
+    DFVO_HIP_CHECK(hipMemcpyAsync(h, t->tb.mt_state, 625 * sizeof(uint32_t), hipMemcpyDeviceToHost, t->stream));
+    DFVO_HIP_CHECK(hipStreamSynchronize(t->stream));
+    return DFVO_OK;
+}
+
+int dfvo_kp_local_bestn(dfvo_tracker* t, const float* h_flow, const float* h_diff, int H, int W, int num_row,
+                        int num_col, int num_bestN, float thre, double* h_kp1, double* h_kp2, int* n_out,
+                        int* good_kp_found) {
+    DFVO_ARG_CHECK(t && h_flow && h_diff && h_kp1 && h_kp2 && n_out && good_kp_found && H > 0 && W > 0,
+                   "dfvo_kp_local_bestn: bad argument");
+    const size_t px = (size_t)H * W;
+    if (px > t->flow_cap) {
+        if (t->d_flow) (void)hipFree(t->d_flow);
+        if (t->d_diff) (void)hipFree(t->d_diff);
+        t->flow_cap = px;
+        DFVO_HIP_CHECK(hipMalloc((void**)&t->d_flow, sizeof(float) * 2 * px));
+        DFVO_HIP_CHECK(hipMalloc((void**)&t->d_diff, sizeof(float) * px));
+    }
+    DFVO_HIP_CHECK(hipMemcpyAsync(t->d_flow, h_flow, sizeof(float) * 2 * px, hipMemcpyHostToDevice, t->stream));
+    DFVO_HIP_CHECK(hipMemcpyAsync(t->d_diff, h_diff, sizeof(float) * px, hipMemcpyHostToDevice, t->stream));
+    int rc = enqueue_local_bestn(t->tb, t->d_flow, t->d_diff, H, W, num_row, num_col, num_bestN, thre, t->stream);
+    if (rc != DFVO_OK) return rc;
+    int info[3];
+    DFVO_HIP_CHECK(hipMemcpyAsync(info, t->tb.kp_info, sizeof(info), hipMemcpyDeviceToHost, t->stream));
+    DFVO_HIP_CHECK(hipStreamSynchronize(t->stream));
+    *n_out = info[0];
+    *good_kp_found = info[1];
+    if (info[1] && info[0] > 0) {
+        DFVO_HIP_CHECK(hipMemcpy(h_kp1, t->tb.kp_ref, sizeof(double) * 2 * info[0], hipMemcpyDeviceToHost));
+        DFVO_HIP_CHECK(hipMemcpy(h_kp2, t->tb.kp_cur, sizeof(double) * 2 * info[0], hipMemcpyDeviceToHost));
+    }
+    return DFVO_OK;
+}
+
+static int stage_kp(dfvo_tracker* t, const double* h_a, const double* h_b, int n) {
+    int rc = t->tb.ensure_kp(n > 16 ? n : 16, 1, 1);
+    if (rc != DFVO_OK) return rc;
+    if (n > 0) {
+        DFVO_HIP_CHECK(hipMemcpyAsync(t->tb.kp_ref, h_a, sizeof(double) * 2 * n, hipMemcpyHostToDevice, t->stream));
+        DFVO_HIP_CHECK(hipMemcpyAsync(t->tb.kp_cur, h_b, sizeof(double) * 2 * n, hipMemcpyHostToDevice, t->stream));
+    }
+    int info[3] = {n, 1, 0};
+    DFVO_HIP_CHECK(hipMemcpyAsync(t->tb.kp_info, info, sizeof(info), hipMemcpyHostToDevice, t->stream));
+    DFVO_HIP_CHECK(hipStreamSynchronize(t->stream));  // `info` is a stack buffer
+    return DFVO_OK;
+}
+
+int dfvo_compute_pose_2d2d(dfvo_tracker* t, const double* h_kp_ref, const double* h_kp_cur, int n,
+                           const dfvo_pose2d2d_cfg* cfg, dfvo_pose2d2d_out* out, uint8_t* h_inliers) {
+    DFVO_ARG_CHECK(t && h_kp_ref && h_kp_cur && cfg && out && h_inliers && n >= 0, "dfvo_compute_pose_2d2d: bad argument");
+    int rc = stage_kp(t, h_kp_ref, h_kp_cur, n);
+    if (rc != DFVO_OK) return rc;
+    PoseConfig pc;
+    pc.fx = cfg->fx;
+    pc.cx = cfg->cx;
+    pc.cy = cfg->cy;
+    pc.reproj_thre = cfg->reproj_thre;
+    pc.repeat = cfg->repeat;
+    pc.max_iters = cfg->max_iters;
+    for (int i = 0; i < 9; i++) {
+        pc.KinvT[i] = cfg->KinvT[i];
+        pc.Kinv[i] = cfg->Kinv[i];
+    }
+    rc = enqueue_compute_pose_2d2d(t->tb, n, pc, t->stream);
+    if (rc != DFVO_OK) return rc;
+    PoseState ps;
+    DFVO_HIP_CHECK(hipMemcpyAsync(&ps, t->tb.pose, sizeof(ps), hipMemcpyDeviceToHost, t->stream));
+    if (n > 0) DFVO_HIP_CHECK(hipMemcpyAsync(h_inliers, t->tb.best_inliers, n, hipMemcpyDeviceToHost, t->stream));
+    DFVO_HIP_CHECK(hipStreamSynchronize(t->stream));
+    for (int i = 0; i < 9; i++) out->R[i] = ps.R[i];
+    for (int i = 0; i < 3; i++) out->t[i] = ps.t[i];
+    out->n = ps.n;
+    out->best_inlier_cnt = ps.best_cnt;
+    out->num_valid = ps.num_valid;
+    out->major_valid = n > 10 ? ps.major_valid : 0;
+    out->cheirality = ps.cheirality;
+    out->h_found = ps.h_found;
+    out->h_gric = ps.h_gric;
+    for (int i = 0; i < 8; i++) {
+        out->rep_inliers[i] = ps.rep_cnt[i];
+        out->rep_valid[i] = ps.rep_valid[i];
+        out->rep_gric[i] = ps.rep_gric[i];
+    }
+    return DFVO_OK;
+}
+
+int dfvo_find_scale_from_depth(dfvo_tracker* t, const double* h_kp1, const double* h_kp2, int n, const double* h_T21,
+                               const double* h_depth, int H, int W, const dfvo_scale_cfg* cfg, double* scale,
+                               int* h_info) {
+    DFVO_ARG_CHECK(t && h_kp1 && h_kp2 && h_T21 && h_depth && cfg && scale && n >= 0 && H > 0 && W > 0,
+                   "dfvo_find_scale_from_depth: bad argument");
+    DFVO_ARG_CHECK(cfg->min_samples >= 1 && cfg->min_samples <= 8, "dfvo_find_scale_from_depth: min_samples in [1,8]");
+    int rc = stage_kp(t, h_kp1, h_kp2, n);
+    if (rc != DFVO_OK) return rc;
+    const size_t px = (size_t)H * W;
+    if (px > t->depth_cap) {
+        if (t->d_depth) (void)hipFree(t->d_depth);
+        t->depth_cap = px;
+        DFVO_HIP_CHECK(hipMalloc((void**)&t->d_depth, sizeof(double) * px));
+    }
+    DFVO_HIP_CHECK(hipMemcpyAsync(t->d_depth, h_depth, sizeof(double) * px, hipMemcpyHostToDevice, t->stream));
+    DFVO_HIP_CHECK(hipMemcpyAsync(t->d_small, h_T21, 16 * sizeof(double), hipMemcpyHostToDevice, t->stream));
+    ScaleConfig sc;
+    sc.cx = cfg->cx;
+    sc.cy = cfg->cy;
+    sc.fx = cfg->fx;
+    sc.fy = cfg->fy;
+    sc.min_samples = cfg->min_samples;
+    sc.max_trials = cfg->max_trials;
+    sc.stop_prob = cfg->stop_prob;
+    sc.thre = cfg->thre;
+    rc = enqueue_find_scale(t->tb, n, t->d_small, t->d_depth, H, W, sc, t->stream);
+    if (rc != DFVO_OK) return rc;
+    ScaleResult sr;
+    DFVO_HIP_CHECK(hipMemcpyAsync(&sr, t->tb.scale_out, sizeof(sr), hipMemcpyDeviceToHost, t->stream));
+    DFVO_HIP_CHECK(hipStreamSynchronize(t->stream));
+    *scale = sr.scale;
+    if (h_info) {
+        h_info[0] = sr.n_valid;
+        h_info[1] = sr.n_trials;
+        h_info[2] = sr.n_inliers;
+        h_info[3] = sr.status;
+    }
     return DFVO_OK;
 }
 

@@ -77,10 +77,16 @@ SM_HD void mt_shuffle_arange(Mt19937& s, int n, int* perm) {
     }
 }
 
-// sklearn.utils.random.sample_without_replacement(n_population, n_samples, method="auto"), n_samples <= 8
-SM_HD void mt_sample_without_replacement(Mt19937& s, int n_population, int n_samples, int* out) {
-    const double ratio = (double)n_samples / (double)n_population;
-    if (ratio < 0.01) {  // tracking selection
+// sklearn.utils.random.sample_without_replacement(n_population, n_samples, method="auto"), n_samples <= 8:
+//   0.01 < ratio < 0.99 -> RandomState.permutation(n_population)[:n_samples]
+//   otherwise ratio < 0.2 -> tracking selection, else reservoir sampling.
+// `scratch` must hold n_population ints when the permutation branch can be taken (n_population < 100 * n_samples).
+SM_HD void mt_sample_without_replacement(Mt19937& s, int n_population, int n_samples, int* out, int* scratch) {
+    const double ratio = n_population != 0 ? (double)n_samples / (double)n_population : 1.0;
+    if (ratio > 0.01 && ratio < 0.99) {
+        mt_shuffle_arange(s, n_population, scratch);
+        for (int i = 0; i < n_samples; i++) out[i] = scratch[i];
+    } else if (ratio < 0.2) {  // tracking selection
         for (int i = 0; i < n_samples; i++) {
             int j;
             bool dup;
@@ -91,21 +97,11 @@ SM_HD void mt_sample_without_replacement(Mt19937& s, int n_population, int n_sam
             } while (dup);
             out[i] = j;
         }
-    } else if (ratio < 0.99) {  // reservoir sampling
+    } else {  // reservoir sampling
         for (int i = 0; i < n_samples; i++) out[i] = i;
         for (int i = n_samples; i < n_population; i++) {
             const int j = (int)mt_randint(s, (uint32_t)(i + 1));
             if (j < n_samples) out[j] = i;
-        }
-    } else {  // pool
-        int pool[16];
-        for (int i = 0; i < n_population; i++) pool[i] = i;
-        int np_ = n_population;
-        for (int i = 0; i < n_samples; i++) {
-            const int j = (int)mt_randint(s, (uint32_t)np_);
-            out[i] = pool[j];
-            pool[j] = pool[np_ - 1];
-            np_--;
         }
     }
 }

@@ -16,11 +16,12 @@
 #include <stdint.h>
 
 #ifdef __HIPCC__
+#include <hip/hip_runtime.h>
 #define SM_HD __host__ __device__ __forceinline__
-#define SM_HD_NOINLINE __host__ __device__ __noinline__
+#define SM_HD_NOINLINE __host__ __device__ __noinline__ inline
 #else
 #define SM_HD inline
-#define SM_HD_NOINLINE
+#define SM_HD_NOINLINE inline
 #endif
 
 namespace sm {

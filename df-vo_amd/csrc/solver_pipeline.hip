@@ -1,0 +1,660 @@
+// Device-side tracker stages around the RANSAC solvers: keypoint selection (local_bestN), GRIC model
+// selection, the repeated shuffled five-point RANSAC of EssTracker.compute_pose_2d2d, and depth-ratio
+// scale recovery.  Reference call sites (paths relative to /root/reference):
+//   libs/matching/kp_selection.py:74-200          local_bestN
+//   libs/matching/keypoint_sampler.py:76-163      kp1 = pixel grid, kp2 = kp1 + flow
+//   libs/tracker/gric.py:14-132                   Sampson / homography residuals + GRIC
+//   libs/tracker/E_tracker.py:154-307             compute_pose_2d2d
+//   libs/tracker/E_tracker.py:571-643             find_scale_from_depth (+ ops_3d.py:15-67)
+//   sklearn RANSACRegressor.fit (third party)     subset draws from the global numpy RandomState
+// Sequential semantics that leak into the results (argpartition order, python-loop summation order,
+// the global np.random stream, last-writer-wins scatter) are kept by giving each sequential chain to one
+// lane and spreading independent chains over lanes / workgroups.  Built with -ffp-contract=off.
+#include "kp_select.h"
+#include "np_legacy.h"
+#include "solver.h"
+#include "solver_math.h"
+#include "tracker.h"
+
+namespace dfvo {
+
+__device__ __forceinline__ int wave_sum_i(int v) {
+    v += __builtin_amdgcn_ds_swizzle(v, 0x041F);
+    v += __builtin_amdgcn_ds_swizzle(v, 0x081F);
+    v += __builtin_amdgcn_ds_swizzle(v, 0x101F);
+    v += __builtin_amdgcn_ds_swizzle(v, 0x201F);
+    v += __builtin_amdgcn_ds_swizzle(v, 0x401F);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// ================================================================================================
+// keypoint selection
+// ================================================================================================
+__global__ void k_kp_count(const float* __restrict__ diff, int n, float thre, int* __restrict__ total) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = (i < n && diff[i] < thre) ? 1 : 0;
+    const int s = wave_sum_i(f);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(total, s);
+}
+
+// one 256-thread block per grid cell: ordered (row-major) compaction of the candidates into LDS, then
+// lane 0 runs numpy's introselect on them; writes the picked local indices in argpartition order.
+__global__ __launch_bounds__(256) void k_kp_cell(const float* __restrict__ diff, int H, int W, int num_row, int num_col,
+                                                  float thre, int n_best, int cap, int* __restrict__ cell_count,
+                                                  int* __restrict__ cell_sel /*[cells][n_best] (y<<16|x)*/) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* vals = reinterpret_cast<float*>(smem_raw);
+    unsigned short* tosort = reinterpret_cast<unsigned short*>(vals + cap);
+    unsigned short* lidx = tosort + cap;
+    __shared__ int s_base, s_wave[4];
+    const int cell = blockIdx.x;
+    const int row = cell / num_col, col = cell - row * num_col;
+    int y0, y1, x0, x1;
+    sm::kp_cell_bounds(H, W, num_row, num_col, row, col, &y0, &y1, &x0, &x1);
+    const int th = y1 - y0 > 0 ? y1 - y0 : 0, tw = x1 - x0 > 0 ? x1 - x0 : 0;
+    const int total = th * tw;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) s_base = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < total; c0 += 256) {
+        const int e = c0 + t;
+        bool f = false;
+        float v = 0.f;
+        if (e < total) {
+            const int ly = e / tw, lx = e - ly * tw;
+            v = diff[(size_t)(y0 + ly) * W + x0 + lx];
+            f = v < thre;
+        }
+        const unsigned long long b = __ballot(f);
+        const int before = __popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[wave] = __popcll(b);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wave; w++) off += s_wave[w];
+        if (f) {
+            const int pos = off + before;
+            vals[pos] = v;
+            tosort[pos] = (unsigned short)pos;
+            lidx[pos] = (unsigned short)e;
+        }
+        __syncthreads();
+        if (t == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+    const int cnt = s_base;
+    const int pick = cnt < n_best ? cnt : n_best;
+    if (t == 0) {
+        if (pick > 0) sm::kp_introselect<unsigned short>(vals, tosort, cnt, pick - 1, 0);
+        cell_count[cell] = pick;
+    }
+    __syncthreads();
+    if (t < pick) {
+        const int e = lidx[tosort[t]];
+        const int ly = e / tw, lx = e - ly * tw;
+        cell_sel[cell * n_best + t] = ((y0 + ly) << 16) | (x0 + lx);
+    }
+}
+
+// concatenate the cells (row-major cell order), build kp1 (pixel grid) and kp2 = kp1 + flow
+__global__ __launch_bounds__(256) void k_kp_gather(const int* __restrict__ cell_count, const int* __restrict__ cell_sel,
+                                                    int cells, int n_best, const float* __restrict__ flow, int H, int W,
+                                                    const int* __restrict__ total_good, int min_total, int min_regions,
+                                                    double* __restrict__ kp1, double* __restrict__ kp2,
+                                                    int* __restrict__ info /*[n, good_kp_found, regions]*/) {
+    __shared__ int s_off[1025];
+    const int t = threadIdx.x;
+    if (t == 0) {
+        int acc = 0, regions = 0;
+        for (int c = 0; c < cells; c++) {
+            s_off[c] = acc;
+            acc += cell_count[c];
+            regions += cell_count[c] != 0;
+        }
+        s_off[cells] = acc;
+        const bool enough = !(*total_good < min_total);     // (mask.sum() < N*0.1) -> fail
+        const bool diverse = !(regions < min_regions);      // good_region_cnt < rows*cols*0.1 -> fail
+        info[0] = (enough && diverse) ? acc : 0;
+        info[1] = (enough && diverse) ? 1 : 0;
+        info[2] = regions;
+    }
+    __syncthreads();
+    if (!info[1]) return;
+    for (int c = 0; c < cells; c++) {
+        const int cnt = cell_count[c];
+        if (t < cnt) {
+            const int code = cell_sel[c * n_best + t];
+            const int y = code >> 16, x = code & 0xffff;
+            const int o = s_off[c] + t;
+            kp1[o * 2] = (double)x;
+            kp1[o * 2 + 1] = (double)y;
+            kp2[o * 2] = (double)x + (double)flow[(size_t)y * W + x];
+            kp2[o * 2 + 1] = (double)y + (double)flow[(size_t)H * W + (size_t)y * W + x];
+        }
+    }
+}
+
+int enqueue_local_bestn(TrackerBuffers& tb, const float* d_flow, const float* d_diff, int H, int W, int num_row,
+                        int num_col, int num_bestN, float thre, hipStream_t s) {
+    const int cells = num_row * num_col;
+    DFVO_ARG_CHECK(cells > 0 && cells <= 1024 && H < 65536 && W < 65536, "local_bestN: grid too large");
+    const int n_best = num_bestN / cells;  // math.floor(N / (rows*cols))
+    DFVO_ARG_CHECK(n_best >= 1 && n_best <= 256, "local_bestN: n_best out of range");
+    const int cap = (H / num_row + 2) * (W / num_col + 2);
+    DFVO_ARG_CHECK(cap < 65536, "local_bestN: cell larger than 65535 pixels");
+    const size_t lds = (size_t)cap * (4 + 2 + 2);
+    DFVO_ARG_CHECK(lds <= 150 * 1024, "local_bestN: cell does not fit in LDS");
+    int rc = tb.ensure_kp(cells * n_best, cells, n_best);
+    if (rc != DFVO_OK) return rc;
+    static size_t configured = 0;
+    if (lds > configured) {
+        DFVO_HIP_CHECK(hipFuncSetAttribute((const void*)k_kp_cell, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    DFVO_HIP_CHECK(hipMemsetAsync(tb.kp_total, 0, sizeof(int), s));
+    hipLaunchKernelGGL(k_kp_count, dim3(cdiv(H * W, 256)), dim3(256), 0, s, d_diff, H * W, thre, tb.kp_total);
+    hipLaunchKernelGGL(k_kp_cell, dim3(cells), dim3(256), lds, s, d_diff, H, W, num_row, num_col, thre, n_best, cap,
+                       tb.cell_count, tb.cell_sel);
+    // thresholds exactly as the python float comparisons: count < N*0.1 ; regions < rows*cols*0.1
+    const int min_total = (int)ceil((double)num_bestN * 0.1);
+    const int min_regions = (int)ceil((double)cells * 0.1);
+    hipLaunchKernelGGL(k_kp_gather, dim3(1), dim3(256), 0, s, tb.cell_count, tb.cell_sel, cells, n_best, d_flow, H, W,
+                       tb.kp_total, min_total, min_regions, tb.kp_ref, tb.kp_cur, tb.kp_info);
+    DFVO_HIP_CHECK(hipGetLastError());
+    return DFVO_OK;
+}
+
+// ================================================================================================
+// numpy RNG on the device
+// ================================================================================================
+__global__ void k_mt_seed(uint32_t* __restrict__ st, uint32_t seed) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (int pos = 0; pos < 624; pos++) {
+        st[pos] = seed;
+        seed = 1812433253u * (seed ^ (seed >> 30)) + (uint32_t)pos + 1u;
+    }
+    st[624] = 624;
+}
+
+// perm = np.arange(n); np.random.shuffle(perm)   (n read from device: info[0])
+__global__ __launch_bounds__(64) void k_mt_shuffle(uint32_t* __restrict__ st, const int* __restrict__ n_ptr,
+                                                    int* __restrict__ perm) {
+    __shared__ sm::Mt19937 s;
+    const int t = threadIdx.x;
+    for (int i = t; i < 624; i += 64) s.key[i] = st[i];
+    if (t == 0) s.pos = (int)st[624];
+    __syncthreads();
+    if (t == 0) sm::mt_shuffle_arange(s, *n_ptr, perm);
+    __syncthreads();
+    for (int i = t; i < 624; i += 64) st[i] = s.key[i];
+    if (t == 0) st[624] = (uint32_t)s.pos;
+}
+
+__global__ void k_permute_points(const int* __restrict__ n_ptr, const int* __restrict__ perm,
+                                 const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ pa,
+                                 double* __restrict__ pb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *n_ptr) return;
+    const int p = perm[i];
+    pa[i * 2] = a[p * 2];
+    pa[i * 2 + 1] = a[p * 2 + 1];
+    pb[i * 2] = b[p * 2];
+    pb[i * 2 + 1] = b[p * 2 + 1];
+}
+
+// ================================================================================================
+// GRIC
+// ================================================================================================
+// res = compute_fundamental_residual(F, kp1, kp2), F = KinvT @ E @ Kinv (gric.py:14-37)
+__global__ void k_gric_f_residual(const double* __restrict__ E, const double* __restrict__ KinvT,
+                                  const double* __restrict__ Kinv, const int* __restrict__ n_ptr,
+                                  const double* __restrict__ kp1, const double* __restrict__ kp2,
+                                  double* __restrict__ res) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *n_ptr) return;
+    double T[9], F[9];
+    sm::mul33(KinvT, E, T);
+    sm::mul33(T, Kinv, F);
+    const double m0[3] = {kp1[i * 2], kp1[i * 2 + 1], 1.0}, m1[3] = {kp2[i * 2], kp2[i * 2 + 1], 1.0};
+    double Fm0[3], Ftm1[3];
+    for (int r = 0; r < 3; r++) {
+        Fm0[r] = F[r * 3] * m0[0] + F[r * 3 + 1] * m0[1] + F[r * 3 + 2] * m0[2];
+        Ftm1[r] = F[r] * m1[0] + F[3 + r] * m1[1] + F[6 + r] * m1[2];
+    }
+    const double m1Fm0 = Fm0[0] * m1[0] + Fm0[1] * m1[1] + Fm0[2] * m1[2];
+    res[i] = m1Fm0 * m1Fm0 / ((Fm0[0] * Fm0[0] + Fm0[1] * Fm0[1]) + (Ftm1[0] * Ftm1[0] + Ftm1[1] * Ftm1[1]));
+}
+
+// res = compute_homography_residual(H, kp1, kp2) (gric.py:40-92)
+__global__ void k_gric_h_residual(const double* __restrict__ Hm, const int* __restrict__ n_ptr,
+                                  const double* __restrict__ kp1, const double* __restrict__ kp2,
+                                  double* __restrict__ res) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *n_ptr) return;
+    const double* H = Hm;
+    const double m0x = kp1[i * 2], m0y = kp1[i * 2 + 1], m1x = kp2[i * 2], m1y = kp2[i * 2 + 1];
+    const double G00 = H[0] - m1x * H[6], G01 = H[1] - m1x * H[7], G02 = -m0x * H[6] - m0y * H[7] - H[8];
+    const double G10 = H[3] - m1y * H[6], G11 = H[4] - m1y * H[7], G12 = -m0x * H[6] - m0y * H[7] - H[8];
+    const double magG0 = sqrt(G00 * G00 + G01 * G01 + G02 * G02);
+    const double magG1 = sqrt(G10 * G10 + G11 * G11 + G12 * G12);
+    const double magG0G1 = G00 * G10 + G01 * G11;
+    const double alpha = acos(magG0G1 / (magG0 * magG1));
+    const double alg0 = m0x * H[0] + m0y * H[1] + H[2] - m1x * (m0x * H[6] + m0y * H[7] + H[8]);
+    const double alg1 = m0x * H[3] + m0y * H[4] + H[5] - m1y * (m0x * H[6] + m0y * H[7] + H[8]);
+    const double D1 = alg0 / magG0, D2 = alg1 / magG1;
+    res[i] = (D1 * D1 + D2 * D2 - 2.0 * D1 * D2 * cos(alpha)) / sin(alpha);
+}
+
+// calc_GRIC (gric.py:95-132): the python loop's sequential sum, one lane
+__global__ void k_gric_sum(const double* __restrict__ res, const int* __restrict__ n_ptr, double sigma, int Kp, int D,
+                           double* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int n = *n_ptr;
+    const double R = 4, sigmasq1 = 1. / (sigma * sigma);
+    const double lam3RD = 2.0 * (R - D);
+    double sum = 0;
+    for (int i = 0; i < n; i++) {
+        const double tmp = res[i] * sigmasq1;
+        sum += tmp <= lam3RD ? tmp : lam3RD;
+    }
+    sum += n * D * log(R) + Kp * log(R * n);
+    *out = sum;
+}
+
+// ================================================================================================
+// compute_pose_2d2d bookkeeping
+// ================================================================================================
+__global__ void k_pose_state_init(PoseState* ps, const int* __restrict__ n_ptr, uint8_t* __restrict__ best_inliers,
+                                  int cap) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cap) best_inliers[i] = 1;  // np.ones((N,1)) == 1
+    if (i == 0) {
+        ps->best_cnt = 0;
+        ps->num_valid = 0;
+        ps->have_best = 0;
+        ps->h_gric = 0;
+        ps->n = *n_ptr;
+        for (int k = 0; k < 9; k++) ps->best_E[k] = 0;
+        for (int k = 0; k < 9; k++) ps->R[k] = (k % 4 == 0) ? 1.0 : 0.0;
+        ps->t[0] = ps->t[1] = ps->t[2] = 0;
+        ps->cheirality = 0;
+        ps->valid_case = 1;
+    }
+}
+
+__global__ void k_set_h_gric(PoseState* ps, const RansacState* hst, const double* __restrict__ gric) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    ps->h_found = hst->found;
+    ps->h_gric = hst->found ? *gric : INFINITY;
+}
+
+// after one findEssentialMat repeat: valid_case, inlier_check, un-permuted mask (E_tracker.py:258-285)
+__global__ __launch_bounds__(256) void k_rep_update(PoseState* ps, const RansacState* est, const double* __restrict__ E,
+                                                     const double* __restrict__ e_gric,
+                                                     const uint8_t* __restrict__ mask, const int* __restrict__ perm,
+                                                     uint8_t* __restrict__ best_inliers, int rep) {
+    __shared__ int s_take;
+    const int n = ps->n;
+    if (threadIdx.x == 0) {
+        const int found = est->found;
+        const int cnt = found ? est->max_good : 0;
+        const bool valid = found && (ps->h_gric > *e_gric);
+        ps->rep_cnt[rep] = cnt;
+        ps->rep_valid[rep] = valid ? 1 : 0;
+        ps->rep_gric[rep] = found ? *e_gric : INFINITY;
+        ps->num_valid += valid ? 1 : 0;
+        s_take = (found && cnt > ps->best_cnt) ? 1 : 0;
+        if (s_take) {
+            ps->best_cnt = cnt;
+            ps->have_best = 1;
+            for (int k = 0; k < 9; k++) ps->best_E[k] = E[k];
+        }
+    }
+    __syncthreads();
+    if (!s_take) return;
+    for (int c = threadIdx.x; c < n; c += blockDim.x) best_inliers[perm[c]] = mask[c];
+}
+
+__global__ void k_pose_finish(PoseState* ps, const double* __restrict__ rp_out, int repeat, int stage) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (stage == 0) {
+        // major_valid = num_valid_case > (max_ransac_iter / 2)
+        ps->major_valid = ((double)ps->num_valid > (double)repeat / 2.0 && ps->have_best) ? 1 : 0;
+        return;
+    }
+    if (!ps->major_valid) return;
+    const int good = (int)rp_out[12];
+    ps->cheirality = good;
+    if ((double)good > (double)ps->n * 0.1) {
+        for (int k = 0; k < 9; k++) ps->R[k] = rp_out[k];
+        for (int k = 0; k < 3; k++) ps->t[k] = rp_out[9 + k];
+    }
+}
+
+// ================================================================================================
+// scale recovery (find_scale_from_depth)
+// ================================================================================================
+// per keypoint: normalise, triangulate with [I|0] / T_21, X2 = T_21[:3] @ (X / X[3]); target pixel of kp2
+__global__ void k_scale_triangulate(const int* __restrict__ n_ptr, const double* __restrict__ kp1,
+                                    const double* __restrict__ kp2, const double* __restrict__ T21, double cx, double cy,
+                                    double fx, double fy, int H, int W, double* __restrict__ z2,
+                                    int* __restrict__ pix, int* __restrict__ winner) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *n_ptr) return;
+    const double P1[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    double P2[12];
+    for (int k = 0; k < 12; k++) P2[k] = T21[k];
+    const double x1 = (kp1[i * 2] - cx) / fx, y1 = (kp1[i * 2 + 1] - cy) / fy;
+    const double x2 = (kp2[i * 2] - cx) / fx, y2 = (kp2[i * 2 + 1] - cy) / fy;
+    double X[4];
+    sm::triangulate_point(P1, P2, x1, y1, x2, y2, X);
+    const double w = X[3];
+    const double Xn[4] = {X[0] / w, X[1] / w, X[2] / w, X[3] / w};
+    double z = 0;
+    z = P2[8] * Xn[0] + P2[9] * Xn[1] + P2[10] * Xn[2] + P2[11] * Xn[3];
+    z2[i] = z;
+    // kp.astype(np.int): truncation toward zero
+    const double kx = kp2[i * 2], ky = kp2[i * 2 + 1];
+    const int ix = (int)kx, iy = (int)ky;
+    int p = -1;
+    if (ix >= 0 && ix < W && iy >= 0 && iy < H && kx == kx && ky == ky) p = iy * W + ix;
+    pix[i] = p;
+    if (p >= 0) atomicMax(&winner[p], i);  // numpy fancy assignment: the last index wins
+}
+
+// ordered list of depth ratios: pixels (row-major) whose winning keypoint has tri > 0 and CNN depth > 0
+__global__ __launch_bounds__(256) void k_scale_ratios(const int* __restrict__ n_ptr, const double* __restrict__ z2,
+                                                       const int* __restrict__ pix, const int* __restrict__ winner,
+                                                       const double* __restrict__ depth, double* __restrict__ ratios,
+                                                       int* __restrict__ n_valid) {
+    // single block: n <= a few thousand.  rank = number of valid entries with a smaller pixel index.
+    extern __shared__ int s_pix[];
+    const int n = *n_ptr;
+    const int t = threadIdx.x;
+    for (int i = t; i < n; i += blockDim.x) {
+        const int p = pix[i];
+        bool ok = p >= 0 && winner[p] == i;
+        if (ok) {
+            double tri = z2[i];
+            if (tri < 0) tri = 0;  // depth2_tri[depth2_tri < 0] = 0 (NaN stays NaN and fails > 0)
+            ok = (tri > 0) && (depth[p] > 0);
+        }
+        s_pix[i] = ok ? p : -1;
+    }
+    __syncthreads();
+    int local = 0;
+    for (int i = t; i < n; i += blockDim.x) {
+        const int p = s_pix[i];
+        if (p < 0) continue;
+        int rank = 0;
+        for (int j = 0; j < n; j++) rank += (s_pix[j] >= 0 && s_pix[j] < p) ? 1 : 0;
+        ratios[rank] = z2[i] / depth[p];
+        local++;
+    }
+    const int s = wave_sum_i(local);
+    if ((t & 63) == 0 && s) atomicAdd(n_valid, s);
+}
+
+// sklearn RANSACRegressor(LinearRegression(fit_intercept=False), min_samples, max_trials, stop_probability,
+// residual_threshold).fit(ratio.reshape(-1,1), ones) -> estimator_.coef_[0,0]; one 256-thread block.
+__global__ __launch_bounds__(256) void k_scale_ransac(uint32_t* __restrict__ mt_state, const double* __restrict__ x,
+                                                       const int* __restrict__ n_valid, int min_valid, int min_samples,
+                                                       int max_trials, double stop_prob, double thr,
+                                                       uint8_t* __restrict__ inl_a, uint8_t* __restrict__ inl_b,
+                                                       int* __restrict__ scratch, ScaleResult* __restrict__ out) {
+    __shared__ sm::Mt19937 s;
+    __shared__ double s_coef;
+    __shared__ int s_cnt[4], s_nz[4];
+    __shared__ int s_ctl;  // 0 continue, 1 stop
+    __shared__ int s_best_is_a;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n = *n_valid;
+    if (!(n > min_valid)) {  // valid_mask2.sum() > 10
+        if (t == 0) {
+            out->scale = -1.0;
+            out->n_valid = n;
+            out->n_trials = 0;
+            out->n_inliers = 0;
+            out->status = 0;
+        }
+        return;
+    }
+    for (int i = t; i < 624; i += 256) s.key[i] = mt_state[i];
+    if (t == 0) s.pos = (int)mt_state[624];
+    __syncthreads();
+    int n_inliers_best = 1, n_trials = 0, trials_cap = max_trials;
+    double score_best = -INFINITY;
+    bool have_best = false;
+    int best_is_a = 0;
+    for (;;) {
+        if (!(n_trials < trials_cap)) break;
+        n_trials++;
+        if (t == 0) {
+            int idx[8];
+            sm::mt_sample_without_replacement(s, n, min_samples, idx, scratch);
+            // LinearRegression(fit_intercept=False) on (x_subset, ones): least squares through the origin
+            double sx = 0, sxx = 0;
+            for (int k = 0; k < min_samples; k++) {
+                sx += x[idx[k]];
+                sxx += x[idx[k]] * x[idx[k]];
+            }
+            s_coef = sx / sxx;
+        }
+        __syncthreads();
+        const double coef = s_coef;
+        uint8_t* cur = best_is_a ? inl_b : inl_a;  // write the candidate mask into the non-best buffer
+        int c = 0, nz = 0;
+        for (int i = t; i < n; i += 256) {
+            const double pred = x[i] * coef;
+            const double r = fabs(1.0 - pred);
+            const int f = r <= thr ? 1 : 0;
+            cur[i] = (uint8_t)f;
+            c += f;
+            nz += (f && (1.0 - pred) != 0.0) ? 1 : 0;  // r2_score numerator != 0 on the inlier set
+        }
+        c = wave_sum_i(c);
+        nz = wave_sum_i(nz);
+        if (lane == 0) {
+            s_cnt[wave] = c;
+            s_nz[wave] = nz;
+        }
+        __syncthreads();
+        const int n_in = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        const int nzs = s_nz[0] + s_nz[1] + s_nz[2] + s_nz[3];
+        __syncthreads();
+        if (n_in < n_inliers_best) continue;  // n_skips_no_inliers_
+        // r2_score with constant y_true: 1.0 when the residual sum is zero, else 0.0
+        const double score = nzs == 0 ? 1.0 : 0.0;
+        if (n_in == n_inliers_best && score < score_best) continue;
+        n_inliers_best = n_in;
+        score_best = score;
+        have_best = true;
+        best_is_a = best_is_a ? 0 : 1;  // the buffer just written becomes the best
+        // _dynamic_max_trials
+        {
+            const double eps = 2.220446049250313e-16;
+            const double ratio = (double)n_in / (double)n;
+            double nom = 1 - stop_prob;
+            nom = nom > eps ? nom : eps;
+            double denom = 1 - pow(ratio, (double)min_samples);
+            denom = denom > eps ? denom : eps;
+            double dyn;
+            if (nom == 1)
+                dyn = 0;
+            else if (denom == 1)
+                dyn = INFINITY;
+            else
+                dyn = fabs(ceil(log(nom) / log(denom)));
+            if (dyn < (double)trials_cap) trials_cap = (int)dyn;
+        }
+    }
+    // final fit on the best inliers (in index order)
+    if (t == 0) {
+        double scale = -1.0;
+        int status = 0;
+        if (have_best) {
+            const uint8_t* best = best_is_a ? inl_a : inl_b;
+            double sx = 0, sxx = 0;
+            for (int i = 0; i < n; i++)
+                if (best[i]) {
+                    sx += x[i];
+                    sxx += x[i] * x[i];
+                }
+            scale = sx / sxx;
+            status = 1;
+        } else {
+            status = -1;  // sklearn raises ValueError: no valid consensus set
+        }
+        out->scale = scale;
+        out->n_valid = n;
+        out->n_trials = n_trials;
+        out->n_inliers = have_best ? n_inliers_best : 0;
+        out->status = status;
+        out->best_is_a = best_is_a;
+    }
+    __syncthreads();
+    for (int i = t; i < 624; i += 256) mt_state[i] = s.key[i];
+    if (t == 0) mt_state[624] = (uint32_t)s.pos;
+    (void)s_ctl;
+    (void)s_best_is_a;
+}
+
+// ================================================================================================
+// host-side enqueue helpers
+// ================================================================================================
+int TrackerBuffers::ensure_kp(int cap, int cells, int n_best) {
+    if (cap <= kp_cap && cells * n_best <= sel_cap) return DFVO_OK;
+    release_kp();
+    kp_cap = cap > kp_cap ? cap : kp_cap;
+    sel_cap = cells * n_best > sel_cap ? cells * n_best : sel_cap;
+    DFVO_HIP_CHECK(hipMalloc((void**)&kp_ref, sizeof(double) * 2 * kp_cap));
+    DFVO_HIP_CHECK(hipMalloc((void**)&kp_cur, sizeof(double) * 2 * kp_cap));
+    DFVO_HIP_CHECK(hipMalloc((void**)&pa, sizeof(double) * 2 * kp_cap));
+    DFVO_HIP_CHECK(hipMalloc((void**)&pb, sizeof(double) * 2 * kp_cap));
+    DFVO_HIP_CHECK(hipMalloc((void**)&perm, sizeof(int) * (kp_cap + 8)));
+    DFVO_HIP_CHECK(hipMalloc((void**)&res, sizeof(double) * kp_cap));
+    DFVO_HIP_CHECK(hipMalloc((void**)&best_inliers, kp_cap + 8));
+    DFVO_HIP_CHECK(hipMalloc((void**)&cell_count, sizeof(int) * 1024));
+    DFVO_HIP_CHECK(hipMalloc((void**)&cell_sel, sizeof(int) * sel_cap));
+    DFVO_HIP_CHECK(hipMalloc((void**)&z2, sizeof(double) * kp_cap));
+    DFVO_HIP_CHECK(hipMalloc((void**)&pix, sizeof(int) * kp_cap));
+    DFVO_HIP_CHECK(hipMalloc((void**)&ratios, sizeof(double) * kp_cap));
+    DFVO_HIP_CHECK(hipMalloc((void**)&inl_a, kp_cap + 8));
+    DFVO_HIP_CHECK(hipMalloc((void**)&inl_b, kp_cap + 8));
+    DFVO_HIP_CHECK(hipMalloc((void**)&scratch, sizeof(int) * (kp_cap + 8)));
+    return DFVO_OK;
+}
+
+void TrackerBuffers::release_kp() {
+    void* ptrs[] = {kp_ref, kp_cur, pa, pb, perm, res, best_inliers, cell_count, cell_sel, z2, pix, ratios, inl_a, inl_b, scratch};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    kp_ref = kp_cur = pa = pb = res = z2 = ratios = nullptr;
+    perm = cell_count = cell_sel = pix = scratch = nullptr;
+    best_inliers = inl_a = inl_b = nullptr;
+    kp_cap = sel_cap = 0;
+}
+
+int TrackerBuffers::init() {
+    DFVO_HIP_CHECK(hipMalloc((void**)&mt_state, sizeof(uint32_t) * 640));
+    DFVO_HIP_CHECK(hipMalloc((void**)&kp_info, sizeof(int) * 8));
+    DFVO_HIP_CHECK(hipMalloc((void**)&kp_total, sizeof(int) * 8));
+    DFVO_HIP_CHECK(hipMalloc((void**)&pose, sizeof(PoseState)));
+    DFVO_HIP_CHECK(hipMalloc((void**)&small, sizeof(double) * 128));
+    DFVO_HIP_CHECK(hipMalloc((void**)&scale_out, sizeof(ScaleResult)));
+    DFVO_HIP_CHECK(hipMemset(kp_info, 0, sizeof(int) * 8));
+    return DFVO_OK;
+}
+
+void TrackerBuffers::release() {
+    release_kp();
+    ws_h.release();
+    ws_e.release();
+    void* ptrs[] = {mt_state, kp_info, kp_total, pose, small, scale_out, winner};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    mt_state = nullptr;
+    kp_info = kp_total = winner = nullptr;
+    pose = nullptr;
+    small = nullptr;
+    scale_out = nullptr;
+    winner_cap = 0;
+}
+
+int enqueue_mt_seed(TrackerBuffers& tb, uint32_t seed, hipStream_t s) {
+    hipLaunchKernelGGL(k_mt_seed, dim3(1), dim3(1), 0, s, tb.mt_state, seed);
+    DFVO_HIP_CHECK(hipGetLastError());
+    return DFVO_OK;
+}
+
+// EssTracker.compute_pose_2d2d with validity.method == "GRIC" on tb.kp_ref / tb.kp_cur (n = kp_info[0] on the
+// device, n_host = upper bound known to the host for launch sizing).
+// small[] layout: [0..8] KinvT, [9..17] Kinv, [18] H_gric, [19] E_gric
+int enqueue_compute_pose_2d2d(TrackerBuffers& tb, int n_host, const PoseConfig& cfg, hipStream_t s) {
+    DFVO_ARG_CHECK(n_host >= 0 && n_host <= tb.kp_cap, "compute_pose_2d2d: keypoint capacity");
+    DFVO_ARG_CHECK(cfg.repeat >= 1 && cfg.repeat <= 8, "compute_pose_2d2d: repeat out of range");
+    const int nb = cdiv(n_host > 0 ? n_host : 1, 256);
+    double hk[18];
+    for (int i = 0; i < 9; i++) {
+        hk[i] = cfg.KinvT[i];
+        hk[9 + i] = cfg.Kinv[i];
+    }
+    DFVO_HIP_CHECK(hipMemcpyAsync(tb.small, hk, sizeof(hk), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_pose_state_init, dim3(cdiv(tb.kp_cap, 256)), dim3(256), 0, s, tb.pose, tb.kp_info,
+                       tb.best_inliers, tb.kp_cap);
+    // ---- homography + GRIC-H (kp_cur -> kp_ref), only when more than 10 keypoints (E_tracker.py:196)
+    if (n_host > 10) {
+        int rc = enqueue_find_homography(tb.ws_h, tb.kp_cur, tb.kp_ref, n_host, 1.0, 2000, 0.99, s);
+        if (rc != DFVO_OK) return rc;
+        hipLaunchKernelGGL(k_gric_h_residual, dim3(nb), dim3(256), 0, s, tb.ws_h.out, tb.kp_info, tb.kp_cur, tb.kp_ref,
+                           tb.res);
+        hipLaunchKernelGGL(k_gric_sum, dim3(1), dim3(1), 0, s, tb.res, tb.kp_info, 0.8, 8, 2, tb.small + 18);
+        hipLaunchKernelGGL(k_set_h_gric, dim3(1), dim3(1), 0, s, tb.pose, tb.ws_h.state, tb.small + 18);
+        for (int rep = 0; rep < cfg.repeat; ++rep) {
+            hipLaunchKernelGGL(k_mt_shuffle, dim3(1), dim3(64), 0, s, tb.mt_state, tb.kp_info, tb.perm);
+            hipLaunchKernelGGL(k_permute_points, dim3(nb), dim3(256), 0, s, tb.kp_info, tb.perm, tb.kp_cur, tb.kp_ref,
+                               tb.pa, tb.pb);
+            rc = enqueue_find_essential(tb.ws_e, tb.pa, tb.pb, n_host, cfg.fx, cfg.cx, cfg.cy, 0.99, cfg.reproj_thre,
+                                        cfg.max_iters, s);
+            if (rc != DFVO_OK) return rc;
+            hipLaunchKernelGGL(k_gric_f_residual, dim3(nb), dim3(256), 0, s, tb.ws_e.out, tb.small, tb.small + 9,
+                               tb.kp_info, tb.pa, tb.pb, tb.res);
+            hipLaunchKernelGGL(k_gric_sum, dim3(1), dim3(1), 0, s, tb.res, tb.kp_info, 0.8, 5, 3, tb.small + 19);
+            hipLaunchKernelGGL(k_rep_update, dim3(1), dim3(256), 0, s, tb.pose, tb.ws_e.state, tb.ws_e.out,
+                               tb.small + 19, tb.ws_e.mask, tb.perm, tb.best_inliers, rep);
+        }
+        hipLaunchKernelGGL(k_pose_finish, dim3(1), dim3(1), 0, s, tb.pose, tb.ws_e.out + 16, cfg.repeat, 0);
+        // recoverPose(best_E, kp_cur, kp_ref): always enqueued, consumed only when major_valid
+        rc = enqueue_recover_pose(tb.ws_e, (const double*)((const char*)tb.pose + offsetof(PoseState, best_E)), tb.kp_cur,
+                                  tb.kp_ref, n_host, cfg.fx, cfg.cx, cfg.cy, s);
+        if (rc != DFVO_OK) return rc;
+        hipLaunchKernelGGL(k_pose_finish, dim3(1), dim3(1), 0, s, tb.pose, tb.ws_e.out + 16, cfg.repeat, 1);
+    }
+    DFVO_HIP_CHECK(hipGetLastError());
+    return DFVO_OK;
+}
+
+// find_scale_from_depth on tb.kp_ref (kp1) / tb.kp_cur (kp2); d_T21: 16 doubles; d_depth: H x W doubles
+int enqueue_find_scale(TrackerBuffers& tb, int n_host, const double* d_T21, const double* d_depth, int H, int W,
+                       const ScaleConfig& cfg, hipStream_t s) {
+    DFVO_ARG_CHECK(n_host >= 0 && n_host <= tb.kp_cap, "find_scale: keypoint capacity");
+    if ((size_t)H * W > tb.winner_cap) {
+        if (tb.winner) (void)hipFree(tb.winner);
+        tb.winner_cap = (size_t)H * W;
+        DFVO_HIP_CHECK(hipMalloc((void**)&tb.winner, sizeof(int) * tb.winner_cap));
+    }
+    DFVO_HIP_CHECK(hipMemsetAsync(tb.winner, 0xff, sizeof(int) * (size_t)H * W, s));
+    DFVO_HIP_CHECK(hipMemsetAsync(tb.kp_total, 0, sizeof(int), s));
+    const int nb = cdiv(n_host > 0 ? n_host : 1, 256);
+    hipLaunchKernelGGL(k_scale_triangulate, dim3(nb), dim3(256), 0, s, tb.kp_info, tb.kp_ref, tb.kp_cur, d_T21, cfg.cx,
+                       cfg.cy, cfg.fx, cfg.fy, H, W, tb.z2, tb.pix, tb.winner);
+    hipLaunchKernelGGL(k_scale_ratios, dim3(1), dim3(256), sizeof(int) * (size_t)(n_host > 0 ? n_host : 1), s, tb.kp_info,
+                       tb.z2, tb.pix, tb.winner, d_depth, tb.ratios, tb.kp_total);
+    hipLaunchKernelGGL(k_scale_ransac, dim3(1), dim3(256), 0, s, tb.mt_state, tb.ratios, tb.kp_total, 10,
+                       cfg.min_samples, cfg.max_trials, cfg.stop_prob, cfg.thre, tb.inl_a, tb.inl_b, tb.scratch,
+                       tb.scale_out);
+    DFVO_HIP_CHECK(hipGetLastError());
+    return DFVO_OK;
+}
+
+}  // namespace dfvo

@@ -1,0 +1,79 @@
+// Device buffers and small state blocks of the tracker pipeline (solver_pipeline.hip).
+#pragma once
+#include <stddef.h>
+
+#include "solver.h"
+
+namespace dfvo {
+
+struct PoseState {
+    int n;
+    int best_cnt;
+    int num_valid;
+    int have_best;
+    int major_valid;
+    int cheirality;
+    int valid_case;
+    int h_found;
+    double h_gric;
+    double best_E[9];
+    double R[9];
+    double t[3];
+    int rep_cnt[8];
+    int rep_valid[8];
+    double rep_gric[8];
+};
+
+struct ScaleResult {
+    double scale;
+    int n_valid;
+    int n_trials;
+    int n_inliers;
+    int status;  // 1 ok, 0 too few valid points (scale -1), -1 no consensus set (sklearn raises)
+    int best_is_a;
+};
+
+struct PoseConfig {
+    double fx, cx, cy;
+    double reproj_thre;
+    int repeat;
+    int max_iters;
+    double KinvT[9], Kinv[9];
+};
+
+struct ScaleConfig {
+    double cx, cy, fx, fy;
+    int min_samples, max_trials;
+    double stop_prob, thre;
+};
+
+struct TrackerBuffers {
+    RansacWorkspace ws_h, ws_e;
+    uint32_t* mt_state = nullptr;  // numpy RandomState: key[624], pos
+    int* kp_info = nullptr;        // [n, good_kp_found, regions]
+    int* kp_total = nullptr;
+    PoseState* pose = nullptr;
+    double* small = nullptr;
+    ScaleResult* scale_out = nullptr;
+    int* winner = nullptr;
+    size_t winner_cap = 0;
+    // keypoint-sized buffers
+    double *kp_ref = nullptr, *kp_cur = nullptr, *pa = nullptr, *pb = nullptr, *res = nullptr, *z2 = nullptr,
+           *ratios = nullptr;
+    int *perm = nullptr, *cell_count = nullptr, *cell_sel = nullptr, *pix = nullptr, *scratch = nullptr;
+    uint8_t *best_inliers = nullptr, *inl_a = nullptr, *inl_b = nullptr;
+    int kp_cap = 0, sel_cap = 0;
+    int init();
+    int ensure_kp(int cap, int cells, int n_best);
+    void release_kp();
+    void release();
+};
+
+int enqueue_local_bestn(TrackerBuffers& tb, const float* d_flow, const float* d_diff, int H, int W, int num_row,
+                        int num_col, int num_bestN, float thre, hipStream_t s);
+int enqueue_mt_seed(TrackerBuffers& tb, uint32_t seed, hipStream_t s);
+int enqueue_compute_pose_2d2d(TrackerBuffers& tb, int n_host, const PoseConfig& cfg, hipStream_t s);
+int enqueue_find_scale(TrackerBuffers& tb, int n_host, const double* d_T21, const double* d_depth, int H, int W,
+                       const ScaleConfig& cfg, hipStream_t s);
+
+}  // namespace dfvo

@@ -157,6 +157,56 @@ int dfvo_recover_pose(dfvo_tracker* trk, const double* h_E, const double* h_pts1
 int dfvo_triangulate_points(dfvo_tracker* trk, const double* h_P1, const double* h_P2, const double* h_x1,
                             const double* h_x2, int n, double* h_X4);
 
+/* ---- the global numpy RandomState threaded through the device (np.random.shuffle at
+ * E_tracker.py:225-228 / pnp_tracker.py:91-92; sklearn RANSACRegressor's random_state=None at
+ * E_tracker.py:618-636).  State layout = np.random.get_state(): key[624] then pos, as uint32[625]. */
+int dfvo_tracker_seed(dfvo_tracker* trk, uint32_t seed);                 /* np.random.seed(seed) */
+int dfvo_tracker_set_rng_state(dfvo_tracker* trk, const uint32_t* h_state625);
+int dfvo_tracker_get_rng_state(dfvo_tracker* trk, uint32_t* h_state625);
+
+/* local_bestN keypoint selection (kp_selection.py:74-200 behind KeypointSampler.kp_selection,
+ * keypoint_sampler.py:76-143), score_method "flow", depth consistency off.
+ * h_flow float [2,H,W], h_diff float [H,W]; h_kp1/h_kp2 double [num_bestN][2] (x,y), *n_out rows valid;
+ * *good_kp_found 0 when either "insufficient keypoint" rule fires.  The order of the keypoints is
+ * numpy's scalar-introselect argpartition order, cell by cell. */
+int dfvo_kp_local_bestn(dfvo_tracker* trk, const float* h_flow, const float* h_diff, int H, int W, int num_row,
+                        int num_col, int num_bestN, float thre, double* h_kp1, double* h_kp2, int* n_out,
+                        int* good_kp_found);
+
+/* EssTracker.compute_pose_2d2d with validity.method == "GRIC" (E_tracker.py:154-307): homography +
+ * GRIC-H, `repeat` x (shuffle, findEssentialMat, GRIC-E), best-of by inlier count, recoverPose,
+ * cheirality > 10 %.  Consumes the tracker's RandomState for the shuffles. */
+typedef struct dfvo_pose2d2d_cfg {
+    double fx, cx, cy;       /* focal = fx, principal point (E_tracker.py:231-239) */
+    double reproj_thre;      /* e_tracker.ransac.reproj_thre */
+    int repeat;              /* e_tracker.ransac.repeat (or 3) */
+    int max_iters;           /* 1000 = OpenCV 3.4.3 */
+    double KinvT[9];         /* np.linalg.inv(K.T) */
+    double Kinv[9];          /* np.linalg.inv(K)   */
+} dfvo_pose2d2d_cfg;
+typedef struct dfvo_pose2d2d_out {
+    double R[9], t[3];       /* pose cur -> ref (identity / zero when rejected) */
+    int n, best_inlier_cnt, num_valid, major_valid, cheirality, h_found;
+    double h_gric;
+    int rep_inliers[8], rep_valid[8];
+    double rep_gric[8];
+} dfvo_pose2d2d_out;
+int dfvo_compute_pose_2d2d(dfvo_tracker* trk, const double* h_kp_ref, const double* h_kp_cur, int n,
+                           const dfvo_pose2d2d_cfg* cfg, dfvo_pose2d2d_out* out, uint8_t* h_inliers);
+
+/* EssTracker.find_scale_from_depth (E_tracker.py:571-643): triangulate (ops_3d.py:44-67), scatter to a
+ * sparse depth map (ops_3d.py:15-41), depth ratios on valid pixels, sklearn RANSACRegressor on them.
+ * h_T21 4x4; h_depth double [H,W].  *scale = -1 when fewer than 11 valid ratios.
+ * h_info[4] = {n_valid, n_trials, n_inliers, status}.  Consumes the tracker's RandomState. */
+typedef struct dfvo_scale_cfg {
+    double cx, cy, fx, fy;
+    int min_samples, max_trials;
+    double stop_prob, thre;
+} dfvo_scale_cfg;
+int dfvo_find_scale_from_depth(dfvo_tracker* trk, const double* h_kp1, const double* h_kp2, int n,
+                               const double* h_T21, const double* h_depth, int H, int W, const dfvo_scale_cfg* cfg,
+                               double* scale, int* h_info);
+
 #ifdef __cplusplus
 }
 #endif

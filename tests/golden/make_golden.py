@@ -23,7 +23,7 @@ REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 _SIMD_OFF = "AVX512F AVX512CD AVX512_SKX AVX512_CLX AVX512_CNL AVX512_ICL AVX512_SPR AVX2 FMA3"
-if os.environ.get("NPY_DISABLE_CPU_FEATURES") is None and "--no-reexec" not in sys.argv:
+if __name__ == "__main__" and os.environ.get("NPY_DISABLE_CPU_FEATURES") is None and "--no-reexec" not in sys.argv:
     env = dict(os.environ, NPY_DISABLE_CPU_FEATURES=_SIMD_OFF)
     os.execve(sys.executable, [sys.executable] + sys.argv + ["--no-reexec"], env)
 
@@ -171,12 +171,83 @@ def golden_gric():
     print("  gric E", gric.calc_GRIC(f_res, 0.8, n, "EMat"), "H", gric.calc_GRIC(h_res, 0.8, n, "HMat"))
 
 
+def tracker_case(seed, n=2000, out_frac=0.3, noise=0.15, h=376, w=1241):
+    """seeded inputs for the E-tracker fixtures (also imported by the tests)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from synth import two_view
+    x1, x2, R, t, K, o = two_view(n, out_frac, noise, seed, w=w, h=h)
+    # view 1 = reference frame, view 2 = current frame; CNN depth of the current view at int(kp_cur):
+    rng = np.random.Generator(np.random.PCG64(seed + 77))
+    Kinv = np.linalg.inv(K)
+    depth = np.zeros((h, w))
+    zs = rng.uniform(5, 60, n)
+    ix, iy = x2[:, 0].astype(int), x2[:, 1].astype(int)
+    ok = (ix >= 0) & (ix < w) & (iy >= 0) & (iy < h)
+    depth[iy[ok], ix[ok]] = zs[ok]
+    return dict(kp_ref=x1, kp_cur=x2, K=K, depth_cur=depth, R=R, t=t, outliers=o)
+
+
+def golden_tracker():
+    """the reference's own EssTracker (libs/tracker/E_tracker.py) over the oracle cv2 shim"""
+    from oracle import cv2_shim
+    sys.modules["cv2"] = cv2_shim
+    import sklearn.linear_model as lm
+    _RR = lm.RANSACRegressor
+
+    def ransac_regressor_compat(base_estimator=None, **kw):  # sklearn 0.20 spelling: base_estimator=
+        return _RR(estimator=base_estimator, **kw)
+    lm.RANSACRegressor = ransac_regressor_compat
+    try:
+        import matplotlib.pyplot  # noqa: F401
+    except Exception:
+        mpl = types.ModuleType("matplotlib")
+        mpl.pyplot = types.ModuleType("matplotlib.pyplot")
+        sys.modules["matplotlib"] = mpl
+        sys.modules["matplotlib.pyplot"] = mpl.pyplot
+    from easydict import EasyDict
+    E_tracker = load_by_path("ref_E_tracker_pkg", os.path.join(REF, "libs/tracker/gric.py"))  # warm import path
+    from libs.tracker.E_tracker import EssTracker
+    from libs.general.timer import Timer
+    from libs.geometry.camera_modules import Intrinsics, SE3
+    cfg = EasyDict({
+        "kp_selection": {"rigid_flow_kp": {"enable": False}},
+        "e_tracker": {"ransac": {"reproj_thre": 0.2, "repeat": 5}, "validity": {"method": "GRIC", "thre": None},
+                      "kp_src": "kp_best", "iterative_kp": {"enable": False}},
+        "scale_recovery": {"method": "simple", "kp_src": "kp_best", "iterative_kp": {"enable": False, "kp_src": "kp_depth"},
+                           "ransac": {"method": "depth_ratio", "min_samples": 3, "max_trials": 100, "stop_prob": 0.99,
+                                      "thre": 0.1}},
+        "image": {"height": 376, "width": 1241}})
+    out = {}
+    for tag, (seed, n, of, noise) in {"a": (31, 2000, 0.3, 0.15), "b": (32, 2000, 0.6, 0.3), "c": (33, 600, 0.2, 0.1),
+                                      "d": (34, 2000, 0.97, 0.2)}.items():
+        c = tracker_case(seed, n, of, noise)
+        K = c["K"]
+        cam = Intrinsics([K[0, 2], K[1, 2], K[0, 0], K[1, 1]])
+        trk = EssTracker(cfg, cam, Timer())
+        np.random.seed(4869 + seed)
+        res = trk.compute_pose_2d2d(c["kp_ref"], c["kp_cur"], True)
+        pose = res["pose"]
+        out[tag + "_spec"] = np.array([seed, n, of, noise])
+        out[tag + "_pose"] = pose.pose.copy()
+        out[tag + "_inliers"] = res["inliers"].copy()
+        scale = -2.0
+        if np.linalg.norm(pose.t) != 0:
+            cur = {"kp_best": c["kp_cur"], "depth": c["depth_cur"]}
+            ref = {"kp_best": c["kp_ref"]}
+            scale = trk.scale_recovery(cur, ref, pose, False)["scale"]
+        out[tag + "_scale"] = np.array(float(scale))
+        st = np.random.get_state()
+        out[tag + "_rng_after"] = np.r_[st[1].astype(np.uint32), np.uint32(st[2])]
+        print("  tracker", tag, "inliers", int(res["inliers"].sum()), "t", pose.t.ravel(), "scale", scale)
+    np.savez_compressed(os.path.join(HERE, "e_tracker.npz"), **out)
+
+
 if __name__ == "__main__":
     apply_compat()
     torch.set_num_threads(8)
     which = [a for a in sys.argv[1:] if not a.startswith("--")]
     todo = {"liteflownet": golden_liteflownet, "monodepth2": golden_monodepth2, "kp": golden_kp_selection,
-            "gric": golden_gric}
+            "gric": golden_gric, "tracker": golden_tracker}
     for name, fn in todo.items():
         if not which or name in which:
             print("==", name)

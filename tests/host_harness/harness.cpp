@@ -49,7 +49,8 @@ void hh_mt_sample(uint32_t* state, int n_population, int n_samples, int* out) {
     sm::Mt19937 s;
     for (int i = 0; i < 624; i++) s.key[i] = state[i];
     s.pos = (int)state[624];
-    sm::mt_sample_without_replacement(s, n_population, n_samples, out);
+    int scratch[4096];
+    sm::mt_sample_without_replacement(s, n_population, n_samples, out, scratch);
     for (int i = 0; i < 624; i++) state[i] = s.key[i];
     state[624] = (uint32_t)s.pos;
 }

@@ -1,0 +1,85 @@
+"""CPU: the oracle's host-side tracker restatement (oracle/tracker_np.py + oracle/cv3_*.c + np_select.c)
+against fixtures produced by the reference's own kp_selection.py / gric.py / E_tracker.py
+(tests/golden/make_golden.py), plus real numpy / scikit-learn where those ARE the third-party reference."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from golden.make_golden import kp_case, tracker_case
+from oracle import tracker_np as T
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SIMD_OFF = "AVX512F AVX512CD AVX512_SKX AVX512_CLX AVX512_CNL AVX512_ICL AVX512_SPR AVX2 FMA3"
+
+
+def test_argpartition_restatements_match_scalar_numpy():
+    """pure-python and C restatements vs numpy itself with its SIMD sort dispatch disabled"""
+    code = r"""
+import numpy as np, sys
+rng = np.random.default_rng(3)
+out = []
+for trial in range(60):
+    n = int(rng.integers(1, 5000)); v = rng.random(n).astype(np.float32)
+    if trial % 3 == 0: v = np.round(v * 50) / 50
+    k = min(20, n)
+    out.append(np.argpartition(v, k - 1)[:k])
+np.save(sys.argv[1], np.concatenate(out))
+"""
+    path = "/tmp/_np_scalar_order.npy"
+    env = dict(os.environ, NPY_DISABLE_CPU_FEATURES=SIMD_OFF)
+    subprocess.check_call([sys.executable, "-c", code, path], env=env)
+    want = np.load(path)
+    rng = np.random.default_rng(3)
+    got_c, got_py = [], []
+    for trial in range(60):
+        n = int(rng.integers(1, 5000))
+        v = rng.random(n).astype(np.float32)
+        if trial % 3 == 0:
+            v = np.round(v * 50) / 50
+        k = min(20, n)
+        got_c.append(T.argpartition_c(v, k - 1)[:k])
+        if n < 1500:
+            assert np.array_equal(T.argpartition_scalar(v, k - 1)[:k], got_c[-1])
+    assert np.array_equal(np.concatenate(got_c), want)
+
+
+def test_local_bestN_matches_reference_fixture():
+    g = np.load(os.path.join(G, "local_bestN.npz"))
+    for tag in "abcd":
+        h, w, seed, frac = g[tag + "_spec"]
+        diff, flow = kp_case(h, w, seed, frac)
+        res = T.local_bestN(flow, diff)
+        assert bool(res["good_kp_found"]) == bool(g[tag + "_good"])
+        if res["good_kp_found"]:
+            assert np.array_equal(res["kp1_best"], g[tag + "_kp1"]), tag
+            assert np.array_equal(res["kp2_best"], g[tag + "_kp2"]), tag
+
+
+def test_gric_matches_reference_fixture():
+    g = np.load(os.path.join(G, "gric.npz"))
+    f = T.fundamental_residual(g["F"], g["kp1"], g["kp2"])
+    h = T.homography_residual(g["H"], g["kp1"], g["kp2"])
+    assert np.allclose(f, g["f_res"], rtol=1e-12, atol=0)
+    assert np.allclose(h, g["h_res"], rtol=1e-9, atol=1e-12)
+    assert abs(T.calc_GRIC(f, 0.8, len(f), "EMat") - float(g["f_gric"])) < 1e-8
+    assert abs(T.calc_GRIC(h, 0.8, len(h), "HMat") - float(g["h_gric"])) < 1e-8
+
+
+def test_e_tracker_matches_reference_fixture():
+    g = np.load(os.path.join(G, "e_tracker.npz"))
+    for tag in "abcd":
+        seed, n, of, noise = g[tag + "_spec"]
+        c = tracker_case(int(seed), int(n), float(of), float(noise))
+        np.random.seed(4869 + int(seed))
+        res = T.compute_pose_2d2d(c["kp_ref"], c["kp_cur"], c["K"])
+        pose = g[tag + "_pose"]
+        assert np.array_equal(res["inliers"], g[tag + "_inliers"]), tag
+        assert np.array_equal(res["R"], pose[:3, :3]) and np.array_equal(res["t"], pose[:3, 3:]), tag
+        if np.linalg.norm(res["t"]) != 0:
+            T21 = np.linalg.inv(pose)
+            scale = T.find_scale_from_depth(c["kp_ref"], c["kp_cur"], T21, c["depth_cur"], c["K"])
+            assert abs(scale - float(g[tag + "_scale"])) <= 1e-12 * abs(scale), tag
+        st = np.random.get_state()
+        assert np.array_equal(np.r_[st[1].astype(np.uint32), np.uint32(st[2])], g[tag + "_rng_after"]), tag

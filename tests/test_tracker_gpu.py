@@ -1,0 +1,164 @@
+"""GPU parity of the device-side tracker stages (keypoint selection, compute_pose_2d2d, scale recovery)
+against the oracle (oracle/tracker_np.py, pinned to the reference by tests/golden) on identical inputs
+and an identical numpy RandomState.  Bit-exact: keypoints (values and order), inlier masks, R, t, the
+RandomState after the call.  Within stated tolerance: GRIC scores (libm acos/sin/cos/log differ in the
+last bits between numpy and the device library), the final least-squares scale (sklearn goes through
+LAPACK gelsd)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from golden.make_golden import kp_case, tracker_case
+from oracle import tracker_np as T
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def trk(gpu):
+    lib = gpu.lib()
+    t = C.c_void_p()
+    gpu.check(lib.dfvo_tracker_create(None, C.byref(t)))
+    yield t
+    lib.dfvo_tracker_destroy(t)
+
+
+def np_state():
+    st = np.random.get_state()
+    return np.ascontiguousarray(np.r_[st[1].astype(np.uint32), np.uint32(st[2])])
+
+
+def push_rng(gpu, trk):
+    s = np_state()
+    gpu.check(gpu.lib().dfvo_tracker_set_rng_state(trk, gpu.as_ptr(s)))
+
+
+def pull_rng(gpu, trk):
+    s = np.zeros(625, np.uint32)
+    gpu.check(gpu.lib().dfvo_tracker_get_rng_state(trk, gpu.as_ptr(s)))
+    return s
+
+
+def test_device_seed_equals_numpy_seed(gpu, trk):
+    for seed in (4869, 0, 123456789):
+        gpu.check(gpu.lib().dfvo_tracker_seed(trk, seed))
+        np.random.seed(seed)
+        assert np.array_equal(pull_rng(gpu, trk), np_state())
+
+
+@pytest.mark.parametrize("h,w,seed,frac", [(192, 640, 11, 0.6), (376, 1241, 12, 0.35), (100, 130, 13, 0.02),
+                                            (120, 160, 14, 0.004), (376, 1241, 15, 0.0005), (1280, 1920, 16, 0.2)])
+def test_local_bestn_bit_exact(gpu, trk, h, w, seed, frac):
+    diff, flow = kp_case(h, w, seed, frac)
+    ref = T.local_bestN(flow, diff)
+    kp1 = np.zeros((2000, 2))
+    kp2 = np.zeros((2000, 2))
+    n, good = C.c_int(), C.c_int()
+    gpu.check(gpu.lib().dfvo_kp_local_bestn(trk, gpu.as_ptr(np.ascontiguousarray(flow)),
+                                            gpu.as_ptr(np.ascontiguousarray(diff[..., 0])), h, w, 10, 10, 2000, 0.1,
+                                            gpu.as_ptr(kp1), gpu.as_ptr(kp2), C.byref(n), C.byref(good)))
+    print("local_bestN %dx%d: oracle good=%s n=%s | hip good=%d n=%d" % (
+        h, w, ref["good_kp_found"], ref.get("kp1_best", np.zeros((1, 0, 2))).shape[1], good.value, n.value))
+    assert bool(good.value) == bool(ref["good_kp_found"])
+    if ref["good_kp_found"]:
+        assert n.value == ref["kp1_best"].shape[1]
+        assert np.array_equal(kp1[:n.value], ref["kp1_best"][0])
+        assert np.array_equal(kp2[:n.value], ref["kp2_best"][0])
+
+
+CASES = [(31, 2000, 0.3, 0.15), (32, 2000, 0.6, 0.3), (33, 600, 0.2, 0.1), (34, 2000, 0.97, 0.2), (35, 1234, 0.4, 0.2),
+         (36, 9, 0.0, 0.1)]
+
+
+@pytest.mark.parametrize("seed,n,of,noise", CASES)
+def test_compute_pose_2d2d_and_scale(gpu, trk, seed, n, of, noise):
+    lib = gpu.lib()
+    c = tracker_case(seed, n, of, noise)
+    K = c["K"]
+    np.random.seed(4869 + seed)
+    push_rng(gpu, trk)
+    ref = T.compute_pose_2d2d(c["kp_ref"], c["kp_cur"], K)
+    cfg = gpu.Pose2d2dCfg(fx=K[0, 0], cx=K[0, 2], cy=K[1, 2], reproj_thre=0.2, repeat=5, max_iters=1000)
+    KinvT, Kinv = np.linalg.inv(K.T), np.linalg.inv(K)
+    for i in range(9):
+        cfg.KinvT[i] = KinvT.flat[i]
+        cfg.Kinv[i] = Kinv.flat[i]
+    out = gpu.Pose2d2dOut()
+    inl = np.zeros(max(n, 1), np.uint8)
+    gpu.check(lib.dfvo_compute_pose_2d2d(trk, gpu.as_ptr(c["kp_ref"]), gpu.as_ptr(c["kp_cur"]), n, C.byref(cfg),
+                                         C.byref(out), gpu.as_ptr(inl)))
+    R = np.array(out.R[:]).reshape(3, 3)
+    t = np.array(out.t[:]).reshape(3, 1)
+    print("pose2d2d n=%d: oracle reps %s valid %s cheir %d | hip reps %s valid %s cheir %d" % (
+        n, ref["rep_inliers"], ref["rep_valid"], ref["cheirality"], list(out.rep_inliers[:5]), list(out.rep_valid[:5]),
+        out.cheirality))
+    if n > 10:
+        assert list(out.rep_inliers[:5]) == ref["rep_inliers"]
+        assert [bool(v) for v in out.rep_valid[:5]] == ref["rep_valid"]
+        assert abs(out.h_gric - ref["h_gric"]) <= 1e-9 * abs(ref["h_gric"])
+        for a, b in zip(out.rep_gric[:5], ref["rep_gric"]):
+            assert abs(a - b) <= 1e-9 * abs(b)
+        assert out.cheirality == ref["cheirality"]
+    assert np.array_equal(inl[:n] == 1, ref["inliers"])
+    assert np.array_equal(R, ref["R"]) and np.array_equal(t, ref["t"])
+    assert np.array_equal(pull_rng(gpu, trk), np_state()), "RandomState diverged after compute_pose_2d2d"
+    if np.linalg.norm(ref["t"]) == 0:
+        return
+    # ---- scale recovery with the same pose
+    pose = np.eye(4)
+    pose[:3, :3] = ref["R"]
+    pose[:3, 3:] = ref["t"]
+    T21 = np.ascontiguousarray(np.linalg.inv(pose))
+    diag = {}
+    s_ref = T.find_scale_from_depth(c["kp_ref"], c["kp_cur"], T21, c["depth_cur"], K, diag=diag)
+    scfg = gpu.ScaleCfg(cx=K[0, 2], cy=K[1, 2], fx=K[0, 0], fy=K[1, 1], min_samples=3, max_trials=100, stop_prob=0.99,
+                        thre=0.1)
+    scale = C.c_double()
+    info = np.zeros(4, np.int32)
+    h, w = c["depth_cur"].shape
+    gpu.check(lib.dfvo_find_scale_from_depth(trk, gpu.as_ptr(c["kp_ref"]), gpu.as_ptr(c["kp_cur"]), n, gpu.as_ptr(T21),
+                                             gpu.as_ptr(np.ascontiguousarray(c["depth_cur"])), h, w, C.byref(scfg),
+                                             C.byref(scale), gpu.as_ptr(info)))
+    print("scale: oracle %.15g (valid %s trials %s inliers %s) | hip %.15g info %s" % (
+        s_ref, diag.get("n_valid"), diag.get("n_trials"), diag.get("n_inliers"), scale.value, info.tolist()))
+    assert info[0] == diag["n_valid"]
+    if s_ref == -1:
+        assert scale.value == -1
+    else:
+        assert info[1] == diag["n_trials"] and info[2] == diag["n_inliers"]
+        assert abs(scale.value - s_ref) <= 1e-12 * abs(s_ref)
+    assert np.array_equal(pull_rng(gpu, trk), np_state()), "RandomState diverged after scale recovery"
+
+
+def test_scale_recovery_small_populations(gpu, trk):
+    """exercise sklearn's sample_without_replacement branches: permutation (n < 300) / tracking selection"""
+    lib = gpu.lib()
+    for seed, n in ((41, 40), (42, 150), (43, 299), (44, 301), (45, 12), (46, 8)):
+        c = tracker_case(seed, n, 0.1, 0.05)
+        K = c["K"]
+        pose = np.eye(4)
+        pose[:3, :3] = c["R"]
+        pose[:3, 3] = c["t"]
+        T21 = np.ascontiguousarray(pose)  # true relative pose ref -> cur
+        np.random.seed(seed)
+        push_rng(gpu, trk)
+        diag = {}
+        s_ref = T.find_scale_from_depth(c["kp_ref"], c["kp_cur"], T21, c["depth_cur"], K, diag=diag)
+        scfg = gpu.ScaleCfg(cx=K[0, 2], cy=K[1, 2], fx=K[0, 0], fy=K[1, 1], min_samples=3, max_trials=100,
+                            stop_prob=0.99, thre=0.1)
+        scale = C.c_double()
+        info = np.zeros(4, np.int32)
+        h, w = c["depth_cur"].shape
+        gpu.check(lib.dfvo_find_scale_from_depth(trk, gpu.as_ptr(c["kp_ref"]), gpu.as_ptr(c["kp_cur"]), n,
+                                                 gpu.as_ptr(T21), gpu.as_ptr(np.ascontiguousarray(c["depth_cur"])), h,
+                                                 w, C.byref(scfg), C.byref(scale), gpu.as_ptr(info)))
+        print("n=%d oracle %.12g %s | hip %.12g %s" % (n, s_ref, {k: v for k, v in diag.items() if k != "ratios"},
+                                                       scale.value, info.tolist()))
+        assert info[0] == diag["n_valid"]
+        if s_ref == -1:
+            assert scale.value == -1
+        else:
+            assert info[1] == diag["n_trials"] and info[2] == diag["n_inliers"]
+            assert abs(scale.value - s_ref) <= 1e-12 * abs(s_ref)
+        assert np.array_equal(pull_rng(gpu, trk), np_state())
