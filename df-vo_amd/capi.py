@@ -92,7 +92,7 @@ SIGNATURES = {
     "dfvo_tracker_get_rng_state": (_i, [_vp, _vp]),
     "dfvo_kp_local_bestn": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _ip, _ip]),
     "dfvo_compute_pose_2d2d": (_i, [_vp, _vp, _vp, _i, C.POINTER(Pose2d2dCfg), C.POINTER(Pose2d2dOut), _vp]),
-    "dfvo_find_scale_from_depth": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, C.POINTER(ScaleCfg), C.POINTER(_d), _ip]),
+    "dfvo_find_scale_from_depth": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, C.POINTER(ScaleCfg), C.POINTER(_d), _vp]),
 }
 
 

@@ -42,11 +42,12 @@ __global__ void k_kp_count(const float* __restrict__ diff, int n, float thre, in
 // lane 0 runs numpy's introselect on them; writes the picked local indices in argpartition order.
 __global__ __launch_bounds__(256) void k_kp_cell(const float* __restrict__ diff, int H, int W, int num_row, int num_col,
                                                   float thre, int n_best, int cap, int* __restrict__ cell_count,
-                                                  int* __restrict__ cell_sel /*[cells][n_best] (y<<16|x)*/) {
+                                                  int* __restrict__ cell_sel /*[cells][n_best] (y<<16|x)*/,
+                                                  unsigned short* __restrict__ lidx_all /*[cells][cap]*/) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* vals = reinterpret_cast<float*>(smem_raw);
     unsigned short* tosort = reinterpret_cast<unsigned short*>(vals + cap);
-    unsigned short* lidx = tosort + cap;
+    unsigned short* lidx = lidx_all + (size_t)blockIdx.x * cap;  // candidate -> tile element (global scratch)
     __shared__ int s_base, s_wave[4];
     const int cell = blockIdx.x;
     const int row = cell / num_col, col = cell - row * num_col;
@@ -142,10 +143,15 @@ int enqueue_local_bestn(TrackerBuffers& tb, const float* d_flow, const float* d_
     DFVO_ARG_CHECK(n_best >= 1 && n_best <= 256, "local_bestN: n_best out of range");
     const int cap = (H / num_row + 2) * (W / num_col + 2);
     DFVO_ARG_CHECK(cap < 65536, "local_bestN: cell larger than 65535 pixels");
-    const size_t lds = (size_t)cap * (4 + 2 + 2);
-    DFVO_ARG_CHECK(lds <= 150 * 1024, "local_bestN: cell does not fit in LDS");
+    const size_t lds = (size_t)cap * (4 + 2);
+    DFVO_ARG_CHECK(lds <= 158 * 1024, "local_bestN: cell does not fit in LDS");
     int rc = tb.ensure_kp(cells * n_best, cells, n_best);
     if (rc != DFVO_OK) return rc;
+    if ((size_t)cells * cap > tb.lidx_cap) {
+        if (tb.lidx) (void)hipFree(tb.lidx);
+        tb.lidx_cap = (size_t)cells * cap;
+        DFVO_HIP_CHECK(hipMalloc((void**)&tb.lidx, sizeof(unsigned short) * tb.lidx_cap));
+    }
     static size_t configured = 0;
     if (lds > configured) {
         DFVO_HIP_CHECK(hipFuncSetAttribute((const void*)k_kp_cell, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -154,7 +160,7 @@ int enqueue_local_bestn(TrackerBuffers& tb, const float* d_flow, const float* d_
     DFVO_HIP_CHECK(hipMemsetAsync(tb.kp_total, 0, sizeof(int), s));
     hipLaunchKernelGGL(k_kp_count, dim3(cdiv(H * W, 256)), dim3(256), 0, s, d_diff, H * W, thre, tb.kp_total);
     hipLaunchKernelGGL(k_kp_cell, dim3(cells), dim3(256), lds, s, d_diff, H, W, num_row, num_col, thre, n_best, cap,
-                       tb.cell_count, tb.cell_sel);
+                       tb.cell_count, tb.cell_sel, tb.lidx);
     // thresholds exactly as the python float comparisons: count < N*0.1 ; regions < rows*cols*0.1
     const int min_total = (int)ceil((double)num_bestN * 0.1);
     const int min_regions = (int)ceil((double)cells * 0.1);
@@ -279,6 +285,13 @@ __global__ void k_pose_state_init(PoseState* ps, const int* __restrict__ n_ptr, 
         ps->t[0] = ps->t[1] = ps->t[2] = 0;
         ps->cheirality = 0;
         ps->valid_case = 1;
+        ps->major_valid = 0;
+        ps->h_found = 0;
+        for (int k = 0; k < 8; k++) {
+            ps->rep_cnt[k] = 0;
+            ps->rep_valid[k] = 0;
+            ps->rep_gric[k] = 0;
+        }
     }
 }
 
@@ -570,7 +583,9 @@ void TrackerBuffers::release() {
     release_kp();
     ws_h.release();
     ws_e.release();
-    void* ptrs[] = {mt_state, kp_info, kp_total, pose, small, scale_out, winner};
+    void* ptrs[] = {mt_state, kp_info, kp_total, pose, small, scale_out, winner, lidx};
+    lidx = nullptr;
+    lidx_cap = 0;
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     mt_state = nullptr;

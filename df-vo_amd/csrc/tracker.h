@@ -57,6 +57,8 @@ struct TrackerBuffers {
     ScaleResult* scale_out = nullptr;
     int* winner = nullptr;
     size_t winner_cap = 0;
+    unsigned short* lidx = nullptr;
+    size_t lidx_cap = 0;
     // keypoint-sized buffers
     double *kp_ref = nullptr, *kp_cur = nullptr, *pa = nullptr, *pb = nullptr, *res = nullptr, *z2 = nullptr,
            *ratios = nullptr;

@@ -1,0 +1,74 @@
+"""Monodepth2DepthNet with the reference's surface
+(/root/reference/libs/deep_models/depth/monodepth2/monodepth2.py:22-139) over the dfvo_depthnet_* C ABI."""
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+from ..... import capi
+
+
+class Monodepth2DepthNet:
+    def __init__(self, height, width):
+        self.height = height
+        self.width = width
+        self.device = torch.device('cuda')
+        self.enable_finetune = False
+        self.depth_scales = [0]
+        self.model = None
+        self.pred_depths = {}
+        self.pred_disps = {}
+
+    def initialize_network_model(self, weight_path, dataset, finetune):
+        """monodepth2.py:30-89: directory with encoder.pth + depth.pth, or a dict
+        {'encoder': state_dict (with 'height','width'), 'decoder': state_dict}"""
+        if finetune:
+            raise NotImplementedError("online finetuning is training; out of scope of the inference hot path")
+        if isinstance(weight_path, dict):
+            enc, dec = weight_path['encoder'], weight_path['decoder']
+        else:
+            enc = torch.load(os.path.join(weight_path, 'encoder.pth'), map_location="cpu")
+            dec = torch.load(os.path.join(weight_path, 'depth.pth'), map_location="cpu")
+        self.feed_height = int(enc['height'])
+        self.feed_width = int(enc['width'])
+        if 'tum' in dataset:
+            self.min_depth, self.max_depth, self.stereo_baseline_multiplier = 0.1, 10, 1
+        else:
+            self.min_depth, self.max_depth, self.stereo_baseline_multiplier = 0.1, 100, 5.4
+        params = {}
+        for k, v in enc.items():
+            if hasattr(v, "detach") and v.dim() > 0 and "num_batches_tracked" not in k and not k.startswith("encoder.fc"):
+                params[k] = v.detach().cpu().float().numpy()
+        for k, v in dec.items():
+            params[k] = v.detach().cpu().float().numpy()
+        lib = capi.lib()
+        capi.require_gpu()
+        h = C.c_void_p()
+        capi.check(lib.dfvo_depthnet_create(self.feed_height, self.feed_width, float(self.min_depth), float(self.max_depth),
+                                            float(self.stereo_baseline_multiplier), None, C.byref(h)))
+        capi.set_params(lib.dfvo_depthnet_set_param, h, params)
+        capi.check(lib.dfvo_depthnet_finalize(h))
+        self.model = h
+
+    def inference_depth_u8(self, img_u8):
+        """uint8 [feed_h, feed_w, 3] -> float32 [feed_h, feed_w] depth (x baseline multiplier)"""
+        assert img_u8.shape == (self.feed_height, self.feed_width, 3) and img_u8.dtype == np.uint8
+        depth = np.zeros((self.feed_height, self.feed_width), np.float32)
+        capi.check(capi.lib().dfvo_depthnet_forward_host(self.model, capi.as_ptr(np.ascontiguousarray(img_u8)),
+                                                         capi.as_ptr(depth)))
+        return depth
+
+    def inference_depth(self, img):
+        """monodepth2.py:124-139: [1,3,h,w] float tensor in [0,1] (ToTensor of a uint8 image) -> [1,1,h,w]"""
+        a = img.detach().cpu().numpy()[0].transpose(1, 2, 0).astype(np.float64) * 255.0
+        u = np.rint(a)
+        if np.abs(a - u).max() > 1e-3:
+            raise capi.DfvoError("Monodepth2DepthNet.inference_depth expects images quantised to k/255")
+        d = self.inference_depth_u8(np.ascontiguousarray(u.astype(np.uint8)))
+        out = torch.from_numpy(d)[None, None]
+        self.pred_depths = {0: out / self.stereo_baseline_multiplier}
+        return out
+
+    def setup_train(self, deep_model, cfg):
+        raise NotImplementedError("online finetuning is out of scope of the inference hot path")

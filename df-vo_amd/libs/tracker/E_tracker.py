@@ -1,0 +1,103 @@
+"""EssTracker with the reference's surface (/root/reference/libs/tracker/E_tracker.py:124-307,442-507,
+571-643) over the C ABI: every cv2 / sklearn / gric call of the reference runs in HIP kernels
+(dfvo_compute_pose_2d2d, dfvo_find_scale_from_depth); this class only marshals numpy arrays and threads
+the global np.random stream through the device.  No CPU fallback."""
+import ctypes as C
+
+import numpy as np
+
+from ... import capi
+from ..geometry.camera_modules import SE3
+from . import _ctx
+
+
+class EssTracker:
+    def __init__(self, cfg, cam_intrinsics, timers):
+        self.cfg = cfg
+        self.prev_scale = 0
+        self.prev_pose = SE3()
+        self.cam_intrinsics = cam_intrinsics
+        self.timers = timers
+        if self.cfg.kp_selection.rigid_flow_kp.enable:
+            raise NotImplementedError("rigid_flow_kp (extended-paper configs) is not part of the MI355X hot path yet "
+                                      "(SURVEY.md section 8f rank 1)")
+        self.max_iters = 1000  # OpenCV 3.4.3's fixed findEssentialMat budget
+
+    def compute_pose_2d2d(self, kp_ref, kp_cur, is_iterative):
+        """E_tracker.py:154-307 -> {'pose': SE3 (cur -> ref), 'inliers': bool [N]}"""
+        valid_cfg = self.cfg.e_tracker.validity
+        if valid_cfg.method != "GRIC":
+            raise NotImplementedError("e_tracker.validity.method '%s': only GRIC runs on the device so far "
+                                      "(SURVEY.md section 8f rank 3)" % valid_cfg.method)
+        K = np.asarray(self.cam_intrinsics.mat, dtype=np.float64)
+        repeat = int(self.cfg.e_tracker.ransac.repeat) if is_iterative else 3
+        kp_ref = np.ascontiguousarray(kp_ref, dtype=np.float64)
+        kp_cur = np.ascontiguousarray(kp_cur, dtype=np.float64)
+        n = kp_ref.shape[0]
+        cfg = capi.Pose2d2dCfg(fx=float(self.cam_intrinsics.fx), cx=float(self.cam_intrinsics.cx),
+                               cy=float(self.cam_intrinsics.cy),
+                               reproj_thre=float(self.cfg.e_tracker.ransac.reproj_thre), repeat=repeat,
+                               max_iters=self.max_iters)
+        KinvT, Kinv = np.linalg.inv(K.T), np.linalg.inv(K)
+        for i in range(9):
+            cfg.KinvT[i] = KinvT.flat[i]
+            cfg.Kinv[i] = Kinv.flat[i]
+        out = capi.Pose2d2dOut()
+        inl = np.zeros(max(n, 1), np.uint8)
+        if self.timers is not None:
+            self.timers.start('find-Ess (full)', 'E-tracker')
+        _ctx.push_numpy_rng()
+        capi.check(capi.lib().dfvo_compute_pose_2d2d(_ctx.tracker(), capi.as_ptr(kp_ref), capi.as_ptr(kp_cur), n,
+                                                     C.byref(cfg), C.byref(out), capi.as_ptr(inl)))
+        _ctx.pull_numpy_rng()
+        if self.timers is not None:
+            self.timers.end('find-Ess (full)')
+        pose = SE3()
+        pose.R = np.array(out.R[:]).reshape(3, 3)
+        pose.t = np.array(out.t[:]).reshape(3, 1)
+        self.last_diag = out
+        return {"pose": pose, "inliers": inl[:n] == 1}
+
+    def scale_recovery(self, cur_data, ref_data, E_pose, is_iterative):
+        """E_tracker.py:442-471"""
+        if self.cfg.scale_recovery.method != "simple":
+            raise NotImplementedError("scale_recovery.method 'iterative' needs the rigid-flow layers "
+                                      "(SURVEY.md section 8f rank 1)")
+        return {"scale": self.scale_recovery_simple(cur_data, ref_data, E_pose, is_iterative)}
+
+    def scale_recovery_simple(self, cur_data, ref_data, E_pose, is_iterative):
+        """E_tracker.py:473-507"""
+        src = self.cfg.scale_recovery.iterative_kp.kp_src if is_iterative else self.cfg.scale_recovery.kp_src
+        return self.find_scale_from_depth(ref_data[src], cur_data[src], E_pose.inv_pose, cur_data['depth'])
+
+    def find_scale_from_depth(self, kp1, kp2, T_21, depth2):
+        """E_tracker.py:571-643 (ransac.method 'depth_ratio')"""
+        rc = self.cfg.scale_recovery.ransac
+        if rc.method != "depth_ratio":
+            raise NotImplementedError("scale_recovery.ransac.method '%s'" % rc.method)
+        kp1 = np.ascontiguousarray(kp1, dtype=np.float64)
+        kp2 = np.ascontiguousarray(kp2, dtype=np.float64)
+        depth2 = np.ascontiguousarray(depth2, dtype=np.float64)
+        T_21 = np.ascontiguousarray(T_21, dtype=np.float64)
+        h, w = depth2.shape[:2]
+        cam = self.cam_intrinsics
+        scfg = capi.ScaleCfg(cx=float(cam.cx), cy=float(cam.cy), fx=float(cam.fx), fy=float(cam.fy),
+                             min_samples=int(rc.min_samples), max_trials=int(rc.max_trials),
+                             stop_prob=float(rc.stop_prob), thre=float(rc.thre))
+        scale = C.c_double()
+        info = np.zeros(4, np.int32)
+        if self.timers is not None:
+            self.timers.start('scale ransac', 'scale_recovery')
+        _ctx.push_numpy_rng()
+        capi.check(capi.lib().dfvo_find_scale_from_depth(_ctx.tracker(), capi.as_ptr(kp1), capi.as_ptr(kp2), kp1.shape[0],
+                                                         capi.as_ptr(T_21), capi.as_ptr(depth2), h, w, C.byref(scfg),
+                                                         C.byref(scale), capi.as_ptr(info)))
+        _ctx.pull_numpy_rng()
+        if self.timers is not None:
+            self.timers.end('scale ransac')
+        if info[3] < 0:
+            raise ValueError("RANSAC could not find a valid consensus set (sklearn RANSACRegressor semantics)")
+        return -1 if scale.value == -1.0 else scale.value
+
+    def compute_rigid_flow_kp(self, cur_data, ref_data, pose):
+        raise NotImplementedError("compute_rigid_flow_kp: extended-paper path, SURVEY.md section 8f rank 1")

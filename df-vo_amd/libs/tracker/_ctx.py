@@ -1,0 +1,33 @@
+"""one shared dfvo_tracker handle (device workspaces + the device copy of the numpy RandomState)"""
+import ctypes as C
+
+import numpy as np
+
+from ... import capi
+
+_trk = None
+
+
+def tracker():
+    global _trk
+    if _trk is None:
+        capi.require_gpu()
+        h = C.c_void_p()
+        capi.check(capi.lib().dfvo_tracker_create(None, C.byref(h)))
+        _trk = h
+    return _trk
+
+
+def push_numpy_rng():
+    """upload np.random's global RandomState (the stream the reference consumes) to the device"""
+    st = np.random.get_state()
+    s = np.ascontiguousarray(np.r_[st[1].astype(np.uint32), np.uint32(st[2])])
+    capi.check(capi.lib().dfvo_tracker_set_rng_state(tracker(), capi.as_ptr(s)))
+
+
+def pull_numpy_rng():
+    """hand the advanced stream back to numpy (has_gauss / cached_gaussian are untouched by integer draws)"""
+    s = np.zeros(625, np.uint32)
+    capi.check(capi.lib().dfvo_tracker_get_rng_state(tracker(), capi.as_ptr(s)))
+    st = np.random.get_state()
+    np.random.set_state((st[0], s[:624].copy(), int(s[624]), st[3], st[4]))

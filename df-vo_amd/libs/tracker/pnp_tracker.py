@@ -1,0 +1,51 @@
+"""PnpTracker with the reference's surface (/root/reference/libs/tracker/pnp_tracker.py:22-125).
+The fallback path (E-tracker rejected or scale == -1, dfvo.py:225-250)."""
+import numpy as np
+
+from ... import capi
+from ..geometry.camera_modules import SE3
+from . import _ctx
+
+
+class PnpTracker:
+    def __init__(self, cfg, cam_intrinsics):
+        self.cfg = cfg
+        self.cam_intrinsics = cam_intrinsics
+        if self.cfg.kp_selection.rigid_flow_kp.enable:
+            raise NotImplementedError("rigid_flow_kp is not part of the MI355X hot path yet (SURVEY.md 8f rank 1)")
+
+    def compute_pose_3d2d(self, kp1, kp2, depth_1, is_iterative):
+        """pnp_tracker.py:45-125 -> {'pose': SE3 (view-2 -> view-1), 'kp1', 'kp2'}"""
+        import ctypes as C
+        lib = capi.lib()
+        if not hasattr(lib, "dfvo_compute_pose_3d2d"):
+            raise capi.DfvoError("PnP tracker (dfvo_compute_pose_3d2d) is not built into libdfvo_hip.so yet; "
+                                 "there is no CPU fallback")
+        kp1 = np.ascontiguousarray(kp1, dtype=np.float64)
+        kp2 = np.ascontiguousarray(kp2, dtype=np.float64)
+        depth_1 = np.ascontiguousarray(depth_1, dtype=np.float64)
+        h, w = depth_1.shape
+        n = kp1.shape[0]
+        cam = self.cam_intrinsics
+        repeat = int(self.cfg.pnp_tracker.ransac.repeat) if is_iterative else 3
+        cfg = capi.Pose3d2dCfg(fx=float(cam.fx), fy=float(cam.fy), cx=float(cam.cx), cy=float(cam.cy),
+                               min_depth=float(self.cfg.depth.min_depth), max_depth=float(self.cfg.depth.max_depth),
+                               iters=int(self.cfg.pnp_tracker.ransac.iter),
+                               reproj_thre=float(self.cfg.pnp_tracker.ransac.reproj_thre), repeat=repeat)
+        Kinv = np.linalg.inv(np.asarray(cam.mat, dtype=np.float64))
+        for i in range(9):
+            cfg.Kinv[i] = Kinv.flat[i]
+        pose44 = np.eye(4)
+        keep = np.zeros(max(n, 1), np.uint8)
+        info = np.zeros(4, np.int32)
+        _ctx.push_numpy_rng()
+        capi.check(lib.dfvo_compute_pose_3d2d(_ctx.tracker(), capi.as_ptr(kp1), capi.as_ptr(kp2), n,
+                                              capi.as_ptr(depth_1), h, w, C.byref(cfg), capi.as_ptr(pose44),
+                                              capi.as_ptr(keep), capi.as_ptr(info)))
+        _ctx.pull_numpy_rng()
+        pose = SE3(pose44)
+        sel = keep[:n] == 1
+        return {"pose": pose, "kp1": kp1[sel], "kp2": kp2[sel]}
+
+    def compute_rigid_flow_kp(self, cur_data, ref_data, pose):
+        raise NotImplementedError("compute_rigid_flow_kp: extended-paper path, SURVEY.md section 8f rank 1")
