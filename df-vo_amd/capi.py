@@ -35,6 +35,25 @@ class ScaleCfg(C.Structure):
                 ("min_samples", C.c_int), ("max_trials", C.c_int), ("stop_prob", C.c_double), ("thre", C.c_double)]
 
 
+class PipelineCfg(C.Structure):
+    _fields_ = [("img_h", C.c_int), ("img_w", C.c_int), ("feed_h", C.c_int), ("feed_w", C.c_int),
+                ("net_min_depth", C.c_float), ("net_max_depth", C.c_float), ("baseline_mult", C.c_float),
+                ("min_depth", C.c_double), ("max_depth", C.c_double), ("depth_crop", C.c_double * 4),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("KinvT", C.c_double * 9), ("Kinv", C.c_double * 9),
+                ("kp_num_row", C.c_int), ("kp_num_col", C.c_int), ("kp_num_bestN", C.c_int), ("kp_thre", C.c_double),
+                ("e_reproj_thre", C.c_double), ("e_repeat", C.c_int), ("e_max_iters", C.c_int),
+                ("scale_min_samples", C.c_int), ("scale_max_trials", C.c_int), ("scale_stop_prob", C.c_double),
+                ("scale_thre", C.c_double), ("seed", C.c_uint32)]
+
+
+class TrackOut(C.Structure):
+    _fields_ = [("R", C.c_double * 9), ("t", C.c_double * 3), ("scale", C.c_double), ("status", C.c_int),
+                ("n_kp", C.c_int), ("good_kp_found", C.c_int), ("best_inlier_cnt", C.c_int), ("num_valid", C.c_int),
+                ("cheirality", C.c_int), ("scale_n_valid", C.c_int), ("scale_n_trials", C.c_int),
+                ("scale_n_inliers", C.c_int)]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "N", "H", "W", "kh", "kw", "stride", "pad_h", "pad_w", "pad_mode",
@@ -56,6 +75,8 @@ SIGNATURES = {
     "dfvo_memcpy_h2d": (_i, [_vp, _vp, _sz]),
     "dfvo_memcpy_d2h": (_i, [_vp, _vp, _sz]),
     "dfvo_conv2d": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dfvo_conv_profile_begin": (_i, []),
+    "dfvo_conv_profile_end": (_i, [_vp, _vp, _vp]),
     "dfvo_correlation": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     "dfvo_backward_warp": (_i, [_vp, _vp, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "dfvo_deconv_dw4x4s2": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -92,6 +113,18 @@ SIGNATURES = {
     "dfvo_tracker_get_rng_state": (_i, [_vp, _vp]),
     "dfvo_kp_local_bestn": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _ip, _ip]),
     "dfvo_compute_pose_2d2d": (_i, [_vp, _vp, _vp, _i, C.POINTER(Pose2d2dCfg), C.POINTER(Pose2d2dOut), _vp]),
+    "dfvo_pipeline_create": (_i, [C.POINTER(PipelineCfg), C.POINTER(_vp)]),
+    "dfvo_pipeline_destroy": (None, [_vp]),
+    "dfvo_pipeline_set_flow_param": (_i, [_vp, C.c_char_p, _vp, _i, _ip]),
+    "dfvo_pipeline_set_depth_param": (_i, [_vp, C.c_char_p, _vp, _i, _ip]),
+    "dfvo_pipeline_finalize": (_i, [_vp]),
+    "dfvo_pipeline_seed": (_i, [_vp, C.c_uint32]),
+    "dfvo_pipeline_set_graph": (_i, [_vp, _i]),
+    "dfvo_pipeline_enqueue_nets": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "dfvo_pipeline_track": (_i, [_vp, _i, _vp, _vp, _vp, C.POINTER(TrackOut)]),
+    "dfvo_pipeline_get_flow": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "dfvo_pipeline_sync": (_i, [_vp]),
+    "dfvo_pipeline_net_flops": (_d, [_vp]),
     "dfvo_find_scale_from_depth": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, C.POINTER(ScaleCfg), C.POINTER(_d), _vp]),
 }
 

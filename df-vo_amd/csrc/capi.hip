@@ -107,6 +107,15 @@ int dfvo_conv2d(const dfvo_conv_desc* d, const float* d_src0, const float* d_src
     return DFVO_OK;
 }
 
+int dfvo_conv_profile_begin(void) {
+    conv_profile_begin();
+    return DFVO_OK;
+}
+int dfvo_conv_profile_end(double* h_ms8, double* h_flops8, int* h_launches8) {
+    DFVO_ARG_CHECK(h_ms8 && h_flops8 && h_launches8, "dfvo_conv_profile_end: null argument");
+    return conv_profile_end(h_ms8, h_flops8, h_launches8);
+}
+
 int dfvo_correlation(const float* d_first, const float* d_second, int N, int H, int W, int C, int stride,
                      float slope, float* d_out, void* stream) {
     DFVO_ARG_CHECK(d_first && d_second && d_out, "dfvo_correlation: null argument");

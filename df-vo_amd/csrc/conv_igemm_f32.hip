@@ -273,13 +273,63 @@ void conv_pack_weights(const float* w, const float* bias, int cout, int c0, int 
     }
 }
 
+// ---- optional per-launch timing with HIP events on the launch stream (bench.py roofline leg)
+struct ConvProfEntry {
+    hipEvent_t e0, e1;
+    int cfg;
+    double flops;
+};
+static std::vector<ConvProfEntry>* g_prof = nullptr;
+
+void conv_profile_begin() {
+    if (!g_prof) g_prof = new std::vector<ConvProfEntry>();
+    g_prof->clear();
+}
+// cfg ids: 0 <2,2,4,4>  1 <1,4,2,2>  2 <4,1,4,4>  3 <2,2,2,2>  4 <4,1,4,2>  5 <2,2,2,1>  6 <4,1,4,1>  7 <4,1,1,1>
+int conv_profile_end(double* ms, double* flops, int* launches) {
+    for (int i = 0; i < 8; i++) {
+        ms[i] = 0;
+        flops[i] = 0;
+        launches[i] = 0;
+    }
+    if (!g_prof) return DFVO_OK;
+    for (auto& e : *g_prof) {
+        float t = 0.f;
+        DFVO_HIP_CHECK(hipEventSynchronize(e.e1));
+        DFVO_HIP_CHECK(hipEventElapsedTime(&t, e.e0, e.e1));
+        ms[e.cfg] += t;
+        flops[e.cfg] += e.flops;
+        launches[e.cfg] += 1;
+        (void)hipEventDestroy(e.e0);
+        (void)hipEventDestroy(e.e1);
+    }
+    delete g_prof;
+    g_prof = nullptr;
+    return DFVO_OK;
+}
+
 template <int WM, int WN, int TM, int TN>
-static int launch_cfg(const ConvParams& p, hipStream_t stream) {
+static int launch_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
     const long long M = (long long)p.N * p.Ho * p.Wo;
     dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(p.cout_pad / BN), 1);
+    ConvProfEntry pe;
+    if (g_prof) {
+        DFVO_HIP_CHECK(hipEventCreate(&pe.e0));
+        DFVO_HIP_CHECK(hipEventCreate(&pe.e1));
+        pe.cfg = cfg_id;
+        const int cin = (p.G0 + p.G1) * 4;  // padded channels; the caller's useful-FLOP count is kept separately
+        (void)cin;
+        pe.flops = 0;
+        DFVO_HIP_CHECK(hipEventRecord(pe.e0, stream));
+    }
     hipLaunchKernelGGL((conv_igemm_f32_kernel<WM, WN, TM, TN>), grid, dim3(256), 0, stream, p);
     DFVO_HIP_CHECK(hipGetLastError());
+    if (g_prof) {
+        DFVO_HIP_CHECK(hipEventRecord(pe.e1, stream));
+        pe.flops = p.useful_flops;
+        g_prof->push_back(pe);
+    }
     return DFVO_OK;
 }
 
@@ -290,19 +340,19 @@ int launch_conv(const ConvParams& p, hipStream_t stream) {
     DFVO_ARG_CHECK((p.cs0 % 4) == 0 && (p.co0 % 4) == 0, "launch_conv: src0 stride/offset must be multiples of 4");
     DFVO_ARG_CHECK(p.G1 == 0 || ((p.cs1 % 4) == 0 && (p.co1 % 4) == 0), "launch_conv: src1 stride/offset");
     if (bn == 128) {
-        if (M <= 4096) return launch_cfg<1, 4, 2, 2>(p, stream);  // 32 x 128: more blocks for small maps
-        return launch_cfg<2, 2, 4, 4>(p, stream);                 // 128 x 128
+        if (M <= 4096) return launch_cfg<1, 4, 2, 2>(p, stream, 1);  // 32 x 128: more blocks for small maps
+        return launch_cfg<2, 2, 4, 4>(p, stream, 0);                 // 128 x 128
     }
     if (bn == 64) {
-        if (M <= 8192) return launch_cfg<2, 2, 2, 2>(p, stream);  // 64 x 64
-        return launch_cfg<4, 1, 4, 4>(p, stream);                 // 256 x 64
+        if (M <= 8192) return launch_cfg<2, 2, 2, 2>(p, stream, 3);  // 64 x 64
+        return launch_cfg<4, 1, 4, 4>(p, stream, 2);                 // 256 x 64
     }
     if (bn == 32) {
-        if (M <= 8192) return launch_cfg<2, 2, 2, 1>(p, stream);  // 64 x 32
-        return launch_cfg<4, 1, 4, 2>(p, stream);                 // 256 x 32
+        if (M <= 8192) return launch_cfg<2, 2, 2, 1>(p, stream, 5);  // 64 x 32
+        return launch_cfg<4, 1, 4, 2>(p, stream, 4);                 // 256 x 32
     }
-    if (M <= 8192) return launch_cfg<4, 1, 1, 1>(p, stream);      // 64 x 16
-    return launch_cfg<4, 1, 4, 1>(p, stream);                     // 256 x 16
+    if (M <= 8192) return launch_cfg<4, 1, 1, 1>(p, stream, 7);      // 64 x 16
+    return launch_cfg<4, 1, 4, 1>(p, stream, 6);                     // 256 x 16
 }
 
 }  // namespace dfvo

@@ -59,6 +59,8 @@ struct ConvParams {
     int dst_cs, dst_co;
     // when != 0 the epilogue also zero-fills channels [cout, dst_zero_to) of dst
     int dst_zero_to;
+    // 2 * MACs of the unpadded convolution (bookkeeping for the bench's roofline leg; not read on device)
+    double useful_flops;
 };
 
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
@@ -83,5 +85,7 @@ void conv_pack_weights(const float* w_oihw, const float* bias, int cout, int c0,
                        float* out_b);
 
 int launch_conv(const ConvParams& p, hipStream_t stream);
+void conv_profile_begin();
+int conv_profile_end(double* ms, double* flops, int* launches);
 
 }  // namespace dfvo

@@ -116,7 +116,8 @@ int run_conv(const ConvLayer& L, int N, int H, int W, View s0, int up0, View s1,
     p.dst_cs = dst_cs;
     p.dst_co = dst_co;
     p.dst_zero_to = dst_zero_to;
-    if (flops) *flops += 2.0 * (double)N * p.Ho * p.Wo * L.macs_per_pixel();
+    p.useful_flops = 2.0 * (double)N * p.Ho * p.Wo * L.macs_per_pixel();
+    if (flops) *flops += p.useful_flops;
     return launch_conv(p, s);
 }
 

@@ -1,0 +1,281 @@
+// Fused per-pair tracking pipeline: both CNNs, keypoint selection, E-tracker and scale recovery chained
+// on the device (three HIP streams), with two host round trips per pair (keypoint count, final pose).
+// Orchestration follows /root/reference/libs/dfvo.py:299-345 (deep_model_inference) and :121-262
+// (tracking): the host-side glue of the reference (cv2.resize nearest, preprocess_depth, dict passing)
+// becomes device kernels; the pose composition stays on the host (dfvo.py:109-119).
+#include "../../include/dfvo_hip.h"
+#include <cstring>
+
+#include "nets.h"
+#include "ops.h"
+#include "tracker.h"
+
+using namespace dfvo;
+
+struct dfvo_pipeline {
+    int H = 0, W = 0, feedH = 0, feedW = 0;
+    FlowNet flow;
+    DepthNet depth;
+    TrackerBuffers tb;
+    hipStream_t s_flow = nullptr, s_depth = nullptr, s_trk = nullptr;
+    hipEvent_t e_flow[2] = {nullptr, nullptr}, e_depth[2] = {nullptr, nullptr};
+    // per-slot outputs of the nets
+    float *fwd[2] = {nullptr, nullptr}, *bwd[2] = {nullptr, nullptr}, *diff[2] = {nullptr, nullptr};
+    float* raw_depth[2] = {nullptr, nullptr};
+    double* proc_depth[2] = {nullptr, nullptr};
+    float* depth_small = nullptr;
+    double* d_T21 = nullptr;
+    dfvo_pipeline_cfg cfg;
+    bool nets_ready = false;
+};
+
+// T21 = inverse of [R t; 0 1] written as 16 doubles (E_pose.inv_pose, E_tracker.py:504)
+__global__ void k_build_T21(const PoseState* ps, double* __restrict__ T) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double* R = ps->R;
+    const double* t = ps->t;
+    for (int r = 0; r < 3; r++) {
+        for (int c = 0; c < 3; c++) T[r * 4 + c] = R[c * 3 + r];
+        T[r * 4 + 3] = -(R[0 * 3 + r] * t[0] + R[1 * 3 + r] * t[1] + R[2 * 3 + r] * t[2]);
+    }
+    T[12] = T[13] = T[14] = 0;
+    T[15] = 1;
+}
+
+#define P_TRY(expr)                     \
+    do {                                \
+        int _rc = (expr);               \
+        if (_rc != DFVO_OK) return _rc; \
+    } while (0)
+
+extern "C" {
+
+int dfvo_pipeline_create(const dfvo_pipeline_cfg* cfg, dfvo_pipeline** out) {
+    DFVO_ARG_CHECK(cfg && out, "dfvo_pipeline_create: null argument");
+    dfvo_pipeline* p = new dfvo_pipeline();
+    p->cfg = *cfg;
+    p->H = cfg->img_h;
+    p->W = cfg->img_w;
+    p->feedH = cfg->feed_h;
+    p->feedW = cfg->feed_w;
+    auto fail = [&](int rc) {
+        delete p;
+        return rc;
+    };
+    if (hipStreamCreateWithFlags(&p->s_flow, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&p->s_depth, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&p->s_trk, hipStreamNonBlocking) != hipSuccess) {
+        dfvo::set_last_error("dfvo_pipeline_create: hipStreamCreate failed (no GPU?)");
+        return fail(DFVO_ERR_HIP);
+    }
+    for (int i = 0; i < 2; i++) {
+        if (hipEventCreateWithFlags(&p->e_flow[i], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&p->e_depth[i], hipEventDisableTiming) != hipSuccess) {
+            dfvo::set_last_error("dfvo_pipeline_create: hipEventCreate failed");
+            return fail(DFVO_ERR_HIP);
+        }
+    }
+    int rc = p->flow.init(p->H, p->W, p->s_flow);
+    if (rc != DFVO_OK) return fail(rc);
+    rc = p->depth.init(p->feedH, p->feedW, p->s_depth);
+    if (rc != DFVO_OK) return fail(rc);
+    p->depth.min_depth = cfg->net_min_depth;
+    p->depth.max_depth = cfg->net_max_depth;
+    p->depth.baseline_mult = cfg->baseline_mult;
+    rc = p->tb.init();
+    if (rc != DFVO_OK) return fail(rc);
+    const size_t px = (size_t)p->H * p->W;
+    for (int i = 0; i < 2; i++) {
+        if (hipMalloc((void**)&p->fwd[i], 2 * px * sizeof(float)) != hipSuccess ||
+            hipMalloc((void**)&p->bwd[i], 2 * px * sizeof(float)) != hipSuccess ||
+            hipMalloc((void**)&p->diff[i], px * sizeof(float)) != hipSuccess ||
+            hipMalloc((void**)&p->raw_depth[i], px * sizeof(float)) != hipSuccess ||
+            hipMalloc((void**)&p->proc_depth[i], px * sizeof(double)) != hipSuccess) {
+            dfvo::set_last_error("dfvo_pipeline_create: hipMalloc failed");
+            return fail(DFVO_ERR_HIP);
+        }
+    }
+    if (hipMalloc((void**)&p->depth_small, (size_t)p->feedH * p->feedW * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&p->d_T21, 16 * sizeof(double)) != hipSuccess) {
+        dfvo::set_last_error("dfvo_pipeline_create: hipMalloc failed");
+        return fail(DFVO_ERR_HIP);
+    }
+    enqueue_mt_seed(p->tb, cfg->seed, p->s_trk);
+    *out = p;
+    return DFVO_OK;
+}
+
+void dfvo_pipeline_destroy(dfvo_pipeline* p) {
+    if (!p) return;
+    (void)hipDeviceSynchronize();
+    p->flow.destroy();
+    p->depth.destroy();
+    p->tb.release();
+    for (int i = 0; i < 2; i++) {
+        void* ptrs[] = {p->fwd[i], p->bwd[i], p->diff[i], p->raw_depth[i], p->proc_depth[i]};
+        for (void* q : ptrs)
+            if (q) (void)hipFree(q);
+        if (p->e_flow[i]) (void)hipEventDestroy(p->e_flow[i]);
+        if (p->e_depth[i]) (void)hipEventDestroy(p->e_depth[i]);
+    }
+    if (p->depth_small) (void)hipFree(p->depth_small);
+    if (p->d_T21) (void)hipFree(p->d_T21);
+    if (p->s_flow) (void)hipStreamDestroy(p->s_flow);
+    if (p->s_depth) (void)hipStreamDestroy(p->s_depth);
+    if (p->s_trk) (void)hipStreamDestroy(p->s_trk);
+    delete p;
+}
+
+static int pipe_store(ParamStore* ps, const char* name, const float* h, int ndim, const int* shape) {
+    DFVO_ARG_CHECK(name && h && ndim >= 0 && ndim <= 8, "set_param: bad argument");
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        t.shape.push_back(shape[i]);
+        n *= (size_t)shape[i];
+    }
+    t.data.assign(h, h + n);
+    ps->t[name] = std::move(t);
+    return DFVO_OK;
+}
+
+int dfvo_pipeline_set_flow_param(dfvo_pipeline* p, const char* name, const float* h, int ndim, const int* shape) {
+    DFVO_ARG_CHECK(p && !p->nets_ready, "dfvo_pipeline_set_flow_param: bad state");
+    return pipe_store(&p->flow.params, name, h, ndim, shape);
+}
+int dfvo_pipeline_set_depth_param(dfvo_pipeline* p, const char* name, const float* h, int ndim, const int* shape) {
+    DFVO_ARG_CHECK(p && !p->nets_ready, "dfvo_pipeline_set_depth_param: bad state");
+    return pipe_store(&p->depth.params, name, h, ndim, shape);
+}
+int dfvo_pipeline_finalize(dfvo_pipeline* p) {
+    DFVO_ARG_CHECK(p, "null pipeline");
+    P_TRY(p->flow.finalize());
+    P_TRY(p->depth.finalize());
+    p->nets_ready = true;
+    return DFVO_OK;
+}
+int dfvo_pipeline_set_graph(dfvo_pipeline* p, int enable) {
+    DFVO_ARG_CHECK(p, "null pipeline");
+    p->flow.use_graph = enable != 0;
+    p->depth.use_graph = enable != 0;
+    return DFVO_OK;
+}
+int dfvo_pipeline_seed(dfvo_pipeline* p, uint32_t seed) {
+    DFVO_ARG_CHECK(p, "null pipeline");
+    return enqueue_mt_seed(p->tb, seed, p->s_trk);
+}
+
+int dfvo_pipeline_enqueue_nets(dfvo_pipeline* p, int slot, const uint8_t* d_ref, const uint8_t* d_cur,
+                               const uint8_t* d_cur_feed) {
+    DFVO_ARG_CHECK(p && p->nets_ready && (slot == 0 || slot == 1) && d_ref && d_cur && d_cur_feed,
+                   "dfvo_pipeline_enqueue_nets: bad argument");
+    const size_t px = (size_t)p->H * p->W;
+    // depth of the current frame (dfvo.py:305-319)
+    P_TRY(p->depth.forward(d_cur_feed, p->depth_small));
+    const dfvo_pipeline_cfg& c = p->cfg;
+    const int y0 = (int)(p->H * c.depth_crop[0]), y1 = (int)(p->H * c.depth_crop[1]);
+    const int x0 = (int)(p->W * c.depth_crop[2]), x1 = (int)(p->W * c.depth_crop[3]);
+    P_TRY(launch_depth_post(p->depth_small, p->feedH, p->feedW, p->H, p->W, y0, y1, x0, x1, (float)c.min_depth,
+                            (float)c.max_depth, p->raw_depth[slot], p->proc_depth[slot], p->s_depth));
+    DFVO_HIP_CHECK(hipEventRecord(p->e_depth[slot], p->s_depth));
+    // forward/backward flow (dfvo.py:321-335)
+    P_TRY(p->flow.forward(d_ref, d_cur, p->flow.out_fwd.p, p->flow.out_bwd.p, p->flow.out_diff.p));
+    DFVO_HIP_CHECK(hipMemcpyAsync(p->fwd[slot], p->flow.out_fwd.p, 2 * px * sizeof(float), hipMemcpyDeviceToDevice, p->s_flow));
+    DFVO_HIP_CHECK(hipMemcpyAsync(p->bwd[slot], p->flow.out_bwd.p, 2 * px * sizeof(float), hipMemcpyDeviceToDevice, p->s_flow));
+    DFVO_HIP_CHECK(hipMemcpyAsync(p->diff[slot], p->flow.out_diff.p, px * sizeof(float), hipMemcpyDeviceToDevice, p->s_flow));
+    DFVO_HIP_CHECK(hipEventRecord(p->e_flow[slot], p->s_flow));
+    return DFVO_OK;
+}
+
+int dfvo_pipeline_track(dfvo_pipeline* p, int slot, const float* d_flow_override, const float* d_diff_override,
+                        const double* d_depth_override, dfvo_track_out* out) {
+    DFVO_ARG_CHECK(p && out && (slot == 0 || slot == 1), "dfvo_pipeline_track: bad argument");
+    const dfvo_pipeline_cfg& c = p->cfg;
+    hipStream_t s = p->s_trk;
+    memset(out, 0, sizeof(*out));
+    for (int i = 0; i < 3; i++) out->R[i * 4] = 1.0;
+    DFVO_HIP_CHECK(hipStreamWaitEvent(s, p->e_flow[slot], 0));
+    const float* flow = d_flow_override ? d_flow_override : p->fwd[slot];
+    const float* diff = d_diff_override ? d_diff_override : p->diff[slot];
+    P_TRY(enqueue_local_bestn(p->tb, flow, diff, p->H, p->W, c.kp_num_row, c.kp_num_col, c.kp_num_bestN, (float)c.kp_thre, s));
+    int info[3];
+    DFVO_HIP_CHECK(hipMemcpyAsync(info, p->tb.kp_info, sizeof(info), hipMemcpyDeviceToHost, s));
+    DFVO_HIP_CHECK(hipStreamSynchronize(s));
+    out->n_kp = info[0];
+    out->good_kp_found = info[1];
+    if (!info[1]) {
+        out->status = DFVO_TRACK_CONSTANT_MOTION;
+        return DFVO_OK;
+    }
+    const int n = info[0];
+    PoseConfig pc;
+    pc.fx = c.fx;
+    pc.cx = c.cx;
+    pc.cy = c.cy;
+    pc.reproj_thre = c.e_reproj_thre;
+    pc.repeat = c.e_repeat;
+    pc.max_iters = c.e_max_iters;
+    for (int i = 0; i < 9; i++) {
+        pc.KinvT[i] = c.KinvT[i];
+        pc.Kinv[i] = c.Kinv[i];
+    }
+    P_TRY(enqueue_compute_pose_2d2d(p->tb, n, pc, s));
+    hipLaunchKernelGGL(k_build_T21, dim3(1), dim3(1), 0, s, p->tb.pose, p->d_T21);
+    DFVO_HIP_CHECK(hipStreamWaitEvent(s, p->e_depth[slot], 0));
+    ScaleConfig sc;
+    sc.cx = c.cx;
+    sc.cy = c.cy;
+    sc.fx = c.fx;
+    sc.fy = c.fy;
+    sc.min_samples = c.scale_min_samples;
+    sc.max_trials = c.scale_max_trials;
+    sc.stop_prob = c.scale_stop_prob;
+    sc.thre = c.scale_thre;
+    const double* depth = d_depth_override ? d_depth_override : p->proc_depth[slot];
+    P_TRY(enqueue_find_scale(p->tb, n, p->d_T21, depth, p->H, p->W, sc, s));
+    PoseState ps;
+    ScaleResult sr;
+    DFVO_HIP_CHECK(hipMemcpyAsync(&ps, p->tb.pose, sizeof(ps), hipMemcpyDeviceToHost, s));
+    DFVO_HIP_CHECK(hipMemcpyAsync(&sr, p->tb.scale_out, sizeof(sr), hipMemcpyDeviceToHost, s));
+    DFVO_HIP_CHECK(hipStreamSynchronize(s));
+    for (int i = 0; i < 9; i++) out->R[i] = ps.R[i];
+    for (int i = 0; i < 3; i++) out->t[i] = ps.t[i];
+    out->best_inlier_cnt = ps.best_cnt;
+    out->num_valid = ps.num_valid;
+    out->cheirality = ps.cheirality;
+    const bool t_zero = ps.t[0] == 0 && ps.t[1] == 0 && ps.t[2] == 0;
+    out->scale = t_zero ? 0.0 : sr.scale;  // dfvo.py:198: scale recovery only when ||t|| != 0
+    out->scale_n_valid = sr.n_valid;
+    out->scale_n_trials = sr.n_trials;
+    out->scale_n_inliers = sr.n_inliers;
+    if (t_zero || sr.scale == -1.0)
+        out->status = DFVO_TRACK_NEEDS_PNP;  // dfvo.py:225-250
+    else
+        out->status = DFVO_TRACK_E;
+    return DFVO_OK;
+}
+
+int dfvo_pipeline_get_flow(dfvo_pipeline* p, int slot, float* h_fwd, float* h_bwd, float* h_diff, float* h_raw_depth,
+                           double* h_depth) {
+    DFVO_ARG_CHECK(p && (slot == 0 || slot == 1), "dfvo_pipeline_get_flow: bad argument");
+    const size_t px = (size_t)p->H * p->W;
+    DFVO_HIP_CHECK(hipDeviceSynchronize());
+    if (h_fwd) DFVO_HIP_CHECK(hipMemcpy(h_fwd, p->fwd[slot], 2 * px * sizeof(float), hipMemcpyDeviceToHost));
+    if (h_bwd) DFVO_HIP_CHECK(hipMemcpy(h_bwd, p->bwd[slot], 2 * px * sizeof(float), hipMemcpyDeviceToHost));
+    if (h_diff) DFVO_HIP_CHECK(hipMemcpy(h_diff, p->diff[slot], px * sizeof(float), hipMemcpyDeviceToHost));
+    if (h_raw_depth) DFVO_HIP_CHECK(hipMemcpy(h_raw_depth, p->raw_depth[slot], px * sizeof(float), hipMemcpyDeviceToHost));
+    if (h_depth) DFVO_HIP_CHECK(hipMemcpy(h_depth, p->proc_depth[slot], px * sizeof(double), hipMemcpyDeviceToHost));
+    return DFVO_OK;
+}
+
+int dfvo_pipeline_sync(dfvo_pipeline* p) {
+    DFVO_ARG_CHECK(p, "null pipeline");
+    DFVO_HIP_CHECK(hipStreamSynchronize(p->s_flow));
+    DFVO_HIP_CHECK(hipStreamSynchronize(p->s_depth));
+    DFVO_HIP_CHECK(hipStreamSynchronize(p->s_trk));
+    return DFVO_OK;
+}
+
+double dfvo_pipeline_net_flops(const dfvo_pipeline* p) { return p ? p->flow.flops_last + p->depth.flops_last : 0.0; }
+
+}  // extern "C"

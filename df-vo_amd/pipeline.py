@@ -1,0 +1,126 @@
+"""Host driver of the fused per-pair pipeline (dfvo_pipeline_*): configuration marshalling, the
+double-buffered net/solver software pipeline, and pose accumulation as in
+/root/reference/libs/dfvo.py:109-119 (update_global_pose) and :121-262 (tracking, hybrid path)."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi
+
+DEFAULTS = dict(  # options/examples/default_configuration.yml
+    net_min_depth=0.1, net_max_depth=100.0, baseline_mult=5.4, min_depth=0.0, max_depth=50.0,
+    depth_crop=((0.3, 1.0), (0.0, 1.0)), kp_num_row=10, kp_num_col=10, kp_num_bestN=2000, kp_thre=0.1,
+    e_reproj_thre=0.2, e_repeat=5, e_max_iters=1000, scale_min_samples=3, scale_max_trials=100,
+    scale_stop_prob=0.99, scale_thre=0.1, seed=4869)
+
+STATUS = {0: "E", 1: "constant_motion", 2: "needs_pnp"}
+
+
+class TrackingPipeline:
+    def __init__(self, img_h, img_w, feed_h, feed_w, K, flow_sd, depth_sd, **overrides):
+        capi.require_gpu()
+        self.lib = capi.lib()
+        o = dict(DEFAULTS)
+        o.update(overrides)
+        self.opts = o
+        self.H, self.W, self.feed_h, self.feed_w = img_h, img_w, feed_h, feed_w
+        K = np.asarray(K, np.float64)
+        self.K = K
+        cfg = capi.PipelineCfg(img_h=img_h, img_w=img_w, feed_h=feed_h, feed_w=feed_w,
+                               net_min_depth=o["net_min_depth"], net_max_depth=o["net_max_depth"],
+                               baseline_mult=o["baseline_mult"], min_depth=o["min_depth"], max_depth=o["max_depth"],
+                               fx=K[0, 0], fy=K[1, 1], cx=K[0, 2], cy=K[1, 2], kp_num_row=o["kp_num_row"],
+                               kp_num_col=o["kp_num_col"], kp_num_bestN=o["kp_num_bestN"], kp_thre=o["kp_thre"],
+                               e_reproj_thre=o["e_reproj_thre"], e_repeat=o["e_repeat"], e_max_iters=o["e_max_iters"],
+                               scale_min_samples=o["scale_min_samples"], scale_max_trials=o["scale_max_trials"],
+                               scale_stop_prob=o["scale_stop_prob"], scale_thre=o["scale_thre"], seed=o["seed"])
+        (y0, y1), (x0, x1) = o["depth_crop"]
+        for i, v in enumerate((y0, y1, x0, x1)):
+            cfg.depth_crop[i] = v
+        KinvT, Kinv = np.linalg.inv(K.T), np.linalg.inv(K)
+        for i in range(9):
+            cfg.KinvT[i] = KinvT.flat[i]
+            cfg.Kinv[i] = Kinv.flat[i]
+        h = C.c_void_p()
+        capi.check(self.lib.dfvo_pipeline_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        nh, nw = self._net_size(img_h, img_w)
+        params = {k: (v.detach().cpu().float().numpy() if hasattr(v, "detach") else np.asarray(v, np.float32))
+                  for k, v in flow_sd.items()}
+        for l in range(1, 7):
+            params["aux.linspace_x.%d" % l] = torch.linspace(-1.0, 1.0, nw >> (l - 1)).numpy()
+            params["aux.linspace_y.%d" % l] = torch.linspace(-1.0, 1.0, nh >> (l - 1)).numpy()
+        capi.set_params(self.lib.dfvo_pipeline_set_flow_param, h, params)
+        dparams = {k: v.detach().cpu().float().numpy() for k, v in depth_sd.items()
+                   if hasattr(v, "detach") and v.dim() > 0 and "num_batches_tracked" not in k}
+        capi.set_params(self.lib.dfvo_pipeline_set_depth_param, h, dparams)
+        capi.check(self.lib.dfvo_pipeline_finalize(h))
+
+    @staticmethod
+    def _net_size(h, w):
+        import math
+        hh = 32 * np.array([[math.floor(h / 32), math.floor(h / 32) + 1]])
+        ww = 32 * np.array([[math.floor(w / 32), math.floor(w / 32) + 1]])
+        idx = np.argmin(np.abs(np.matmul(np.transpose(hh), 1 / ww) - h / w))
+        return int(hh[0, idx // 2]), int(ww[0, idx % 2])
+
+    def close(self):
+        if self.h is not None:
+            self.lib.dfvo_pipeline_destroy(self.h)
+            self.h = None
+
+    def seed(self, seed):
+        capi.check(self.lib.dfvo_pipeline_seed(self.h, int(seed) & 0xffffffff))
+
+    def set_graph(self, enable):
+        capi.check(self.lib.dfvo_pipeline_set_graph(self.h, int(enable)))
+
+    def enqueue_nets(self, slot, d_ref, d_cur, d_feed):
+        """device uint8 tensors (torch.cuda): ref/cur [H,W,3], feed [feed_h,feed_w,3]"""
+        p = lambda t: C.c_void_p(t.data_ptr())
+        capi.check(self.lib.dfvo_pipeline_enqueue_nets(self.h, slot, p(d_ref), p(d_cur), p(d_feed)))
+
+    def track(self, slot, flow=None, diff=None, depth=None):
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        out = capi.TrackOut()
+        capi.check(self.lib.dfvo_pipeline_track(self.h, slot, p(flow), p(diff), p(depth), C.byref(out)))
+        return out
+
+    def sync(self):
+        capi.check(self.lib.dfvo_pipeline_sync(self.h))
+
+    def net_flops(self):
+        return self.lib.dfvo_pipeline_net_flops(self.h)
+
+    def get_outputs(self, slot):
+        px = self.H * self.W
+        fwd = np.zeros((2, self.H, self.W), np.float32)
+        bwd = np.zeros((2, self.H, self.W), np.float32)
+        diff = np.zeros((self.H, self.W), np.float32)
+        raw = np.zeros((self.H, self.W), np.float32)
+        dep = np.zeros((self.H, self.W), np.float64)
+        capi.check(self.lib.dfvo_pipeline_get_flow(self.h, slot, capi.as_ptr(fwd), capi.as_ptr(bwd), capi.as_ptr(diff),
+                                                   capi.as_ptr(raw), capi.as_ptr(dep)))
+        return fwd, bwd, diff, raw, dep
+
+    # ---- hybrid pose + accumulation (dfvo.py:109-119, 163-262) -------------------------------------------
+    @staticmethod
+    def hybrid_pose(out, prev_motion):
+        """relative pose cur -> ref as a 4x4; `prev_motion` is used for the constant-motion fallback"""
+        T = np.eye(4)
+        if out.status == 1:
+            return prev_motion.copy(), "constant_motion"
+        if out.status == 2:
+            raise capi.DfvoError("PnP fallback required for this pair; use the PnpTracker stage")
+        T[:3, :3] = np.array(out.R[:]).reshape(3, 3)
+        T[:3, 3] = np.array(out.t[:]) * out.scale
+        return T, "E"
+
+    @staticmethod
+    def accumulate(global_pose, rel):
+        """update_global_pose (dfvo.py:109-119) with scale 1: t_w += R_w t ; R_w = R_w R"""
+        g = global_pose.copy()
+        g[:3, 3:] = g[:3, :3] @ rel[:3, 3:] + g[:3, 3:]
+        g[:3, :3] = g[:3, :3] @ rel[:3, :3]
+        return g

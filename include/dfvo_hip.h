@@ -64,6 +64,14 @@ typedef struct dfvo_conv_desc {
 int dfvo_conv2d(const dfvo_conv_desc* desc, const float* d_src0, const float* d_src1, const float* h_weight_oihw,
                 const float* h_bias, const float* d_res, float* d_dst, void* stream);
 
+/* Per-launch timing of the conv kernel family with HIP events recorded on the launch stream (the
+ * roofline leg of bench.py).  Between begin and end every conv launch is bracketed by two events;
+ * end() returns, per tile configuration (0: 128x128, 1: 32x128, 2: 256x64, 3: 64x64, 4: 256x32,
+ * 5: 64x32, 6: 256x16, 7: 64x16), the summed duration [ms], useful FLOPs and launch count.
+ * Do not use while a hipGraph capture is active (disable graphs on the nets first). */
+int dfvo_conv_profile_begin(void);
+int dfvo_conv_profile_end(double* h_ms8, double* h_flops8, int* h_launches8);
+
 /* correlation.py:38-106,281-340 (_FunctionCorrelation.forward) followed by leaky_relu(slope)
  * (lite_flow_net.py:145,148).  NHWC inputs [N,H,W,C]; output [N,ceil(H/s),ceil(W/s),52], 49 used.
  * slope = 1 gives the bare correlation. */
@@ -206,6 +214,57 @@ typedef struct dfvo_scale_cfg {
 int dfvo_find_scale_from_depth(dfvo_tracker* trk, const double* h_kp1, const double* h_kp2, int n,
                                const double* h_T21, const double* h_depth, int H, int W, const dfvo_scale_cfg* cfg,
                                double* scale, int* h_info);
+
+/* =====================================================================================
+ * Fused per-pair pipeline: images in HBM -> relative pose, everything between on the device
+ * (libs/dfvo.py:299-345 deep_model_inference + :121-262 tracking, hybrid E-tracker path).
+ * Two slots double-buffer the net outputs so that the nets of pair k+1 run under the solvers of pair k.
+ * ===================================================================================== */
+typedef struct dfvo_pipeline dfvo_pipeline;
+typedef struct dfvo_pipeline_cfg {
+    int img_h, img_w, feed_h, feed_w;
+    float net_min_depth, net_max_depth, baseline_mult;   /* monodepth2.py:74-89 */
+    double min_depth, max_depth;                         /* cfg.depth.{min,max}_depth (utils.py:89-114) */
+    double depth_crop[4];                                /* y0 y1 x0 x1 fractions (cfg.crop.depth_crop) */
+    double fx, fy, cx, cy;
+    double KinvT[9], Kinv[9];
+    int kp_num_row, kp_num_col, kp_num_bestN;
+    double kp_thre;
+    double e_reproj_thre;
+    int e_repeat, e_max_iters;
+    int scale_min_samples, scale_max_trials;
+    double scale_stop_prob, scale_thre;
+    uint32_t seed;                                       /* np.random.seed(cfg.seed), run.py:81-84 */
+} dfvo_pipeline_cfg;
+#define DFVO_TRACK_E 0                 /* pose from the essential matrix + depth scale */
+#define DFVO_TRACK_CONSTANT_MOTION 1   /* not enough keypoints: caller reuses the previous motion (dfvo.py:157-161) */
+#define DFVO_TRACK_NEEDS_PNP 2         /* E rejected or scale == -1: PnP fallback (dfvo.py:225-250) */
+typedef struct dfvo_track_out {
+    double R[9], t[3];        /* E-tracker pose cur -> ref (t has unit norm or is zero) */
+    double scale;
+    int status, n_kp, good_kp_found, best_inlier_cnt, num_valid, cheirality;
+    int scale_n_valid, scale_n_trials, scale_n_inliers;
+} dfvo_track_out;
+int dfvo_pipeline_create(const dfvo_pipeline_cfg* cfg, dfvo_pipeline** out);
+void dfvo_pipeline_destroy(dfvo_pipeline* p);
+int dfvo_pipeline_set_flow_param(dfvo_pipeline* p, const char* name, const float* h_data, int ndim, const int* shape);
+int dfvo_pipeline_set_depth_param(dfvo_pipeline* p, const char* name, const float* h_data, int ndim, const int* shape);
+int dfvo_pipeline_finalize(dfvo_pipeline* p);
+int dfvo_pipeline_seed(dfvo_pipeline* p, uint32_t seed);
+int dfvo_pipeline_set_graph(dfvo_pipeline* p, int enable);   /* hipGraph replay of the nets (default on) */
+/* enqueue both nets for one pair into `slot` (0/1); returns at once.  d_* uint8 device images:
+ * ref/cur [img_h,img_w,3], cur_feed [feed_h,feed_w,3] (the PIL-LANCZOS resized current frame) */
+int dfvo_pipeline_enqueue_nets(dfvo_pipeline* p, int slot, const uint8_t* d_ref, const uint8_t* d_cur,
+                               const uint8_t* d_cur_feed);
+/* keypoint selection + E-tracker + scale recovery on the outputs in `slot` (waits for its nets).
+ * Optional device overrides replace the forward flow [2,H,W] / consistency map [H,W] / processed depth
+ * [H,W] double that feed the solver stage (used by bench.py). Synchronous. */
+int dfvo_pipeline_track(dfvo_pipeline* p, int slot, const float* d_flow_override, const float* d_diff_override,
+                        const double* d_depth_override, dfvo_track_out* out);
+int dfvo_pipeline_get_flow(dfvo_pipeline* p, int slot, float* h_fwd, float* h_bwd, float* h_diff, float* h_raw_depth,
+                           double* h_depth);
+int dfvo_pipeline_sync(dfvo_pipeline* p);
+double dfvo_pipeline_net_flops(const dfvo_pipeline* p);
 
 #ifdef __cplusplus
 }

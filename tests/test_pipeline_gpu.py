@@ -1,0 +1,97 @@
+"""GPU: the fused per-pair pipeline (dfvo_pipeline_*) against (a) the stand-alone net executors it is
+built from and (b) the oracle's tracker chain on a synthetic rigid scene (identical flow / consistency /
+depth maps and identical numpy RandomState)."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets_torch as O
+from oracle import tracker_np as T
+from synth import image_pair, rigid_scene
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pipe_mod(gpu):
+    return importlib.import_module("df-vo_amd.pipeline")
+
+
+@pytest.mark.parametrize("h,w", [(192, 640), (376, 1241)])
+def test_pipeline_tracker_matches_oracle_chain(gpu, pipe_mod, h, w):
+    sc = rigid_scene(h, w, seed=3 + h)
+    K = sc["K"]
+    pipe = pipe_mod.TrackingPipeline(h, w, 192, 640, K, O.liteflownet_state_dict(4869), O.monodepth2_state_dict(4869),
+                                     seed=4869)
+    ref, cur = image_pair(h, w, seed=11)
+    feed, _ = image_pair(192, 640, seed=12)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    dref, dcur, dfeed = d(ref), d(cur), d(feed)
+    dflow, ddiff, ddepth = d(sc["flow"]), d(sc["diff"]), d(sc["depth_cur"])
+    poses = []
+    np.random.seed(4869)
+    for frame in range(3):  # the RandomState carries over from pair to pair, as in a sequence
+        pipe.enqueue_nets(frame % 2, dref, dcur, dfeed)
+        out = pipe.track(frame % 2, dflow, ddiff, ddepth)
+        kp = T.local_bestN(sc["flow"], sc["diff"][..., None])
+        assert out.good_kp_found == int(kp["good_kp_found"]) and out.n_kp == kp["kp1_best"].shape[1]
+        res = T.compute_pose_2d2d(kp["kp1_best"][0], kp["kp2_best"][0], K)
+        R = np.array(out.R[:]).reshape(3, 3)
+        t = np.array(out.t[:]).reshape(3, 1)
+        assert np.array_equal(R, res["R"]) and np.array_equal(t, res["t"]), "frame %d" % frame
+        pose = np.eye(4)
+        pose[:3, :3] = res["R"]
+        pose[:3, 3:] = res["t"]
+        diag = {}
+        s_ref = T.find_scale_from_depth(kp["kp1_best"][0], kp["kp2_best"][0], np.linalg.inv(pose), sc["depth_cur"], K,
+                                        diag=diag)
+        print("frame %d: status %d kp %d inliers %d | scale hip %.12g oracle %.12g (valid %d/%d trials %d/%d)" % (
+            frame, out.status, out.n_kp, out.best_inlier_cnt, out.scale, s_ref, out.scale_n_valid, diag["n_valid"],
+            out.scale_n_trials, diag.get("n_trials", 0)))
+        assert out.status == 0
+        assert out.scale_n_valid == diag["n_valid"]
+        assert abs(out.scale - s_ref) <= 1e-9 * abs(s_ref)
+        # geometry sanity: recovered motion is the inverse of the simulated ref -> cur motion
+        Tgt = np.eye(4)
+        Tgt[:3, :3] = sc["R"]
+        Tgt[:3, 3] = sc["t"]
+        Tinv = np.linalg.inv(Tgt)
+        rel, _ = pipe.hybrid_pose(out, np.eye(4))
+        assert np.abs(rel[:3, :3] - Tinv[:3, :3]).max() < 5e-3
+        assert np.linalg.norm(rel[:3, 3] - Tinv[:3, 3]) < 0.15 * np.linalg.norm(Tinv[:3, 3])
+        poses.append(rel)
+    pipe.close()
+
+
+def test_pipeline_nets_equal_standalone_executors(gpu, pipe_mod):
+    h, w = 192, 640
+    lib = gpu.lib()
+    fsd, dsd = O.liteflownet_state_dict(4869), O.monodepth2_state_dict(4869)
+    K = rigid_scene(64, 64, seed=1)["K"]
+    pipe = pipe_mod.TrackingPipeline(h, w, 192, 640, K, fsd, dsd)
+    ref, cur = image_pair(h, w, seed=21)
+    feed, _ = image_pair(192, 640, seed=22)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    pipe.enqueue_nets(1, d(ref), d(cur), d(feed))
+    pipe.sync()
+    fwd, bwd, diff, raw, dep = pipe.get_outputs(1)
+    pipe.close()
+    # stand-alone executors through the mirror classes
+    lf = importlib.import_module("df-vo_amd.libs.deep_models.flow.lite_flow_net.lite_flow").LiteFlow(h, w)
+    lf.initialize_network_model(fsd, False)
+    f2, b2, d2 = lf.inference_flow_u8(ref, cur)
+    assert np.array_equal(fwd, f2) and np.array_equal(bwd, b2) and np.array_equal(diff, d2[..., 0])
+    md = importlib.import_module("df-vo_amd.libs.deep_models.depth.monodepth2.monodepth2").Monodepth2DepthNet(h, w)
+    enc = {k: v for k, v in dsd.items() if k.startswith("encoder.")}
+    enc.update(height=192, width=640)
+    md.initialize_network_model({"encoder": enc, "decoder": {k: v for k, v in dsd.items() if k.startswith("decoder.")}},
+                                "kitti_odom", False)
+    depth_small = md.inference_depth_u8(feed)
+    from oracle import cv2_shim
+    want_raw = cv2_shim.resize(depth_small, (w, h), interpolation=cv2_shim.INTER_NEAREST)
+    assert np.array_equal(raw, want_raw)
+    want = T.preprocess_depth(want_raw, [[0.3, 1], [0, 1]], [0, 50])
+    assert np.array_equal(dep, want)
