@@ -1,0 +1,59 @@
+"""Frame-batch data parallelism: every rank tracks a contiguous chunk of frame
+pairs on its own GPU with no activation exchange; ONE RCCL all-gather of the per-frame relative poses
+(4x4 f64 = 128 B/frame) + a status word per frame, then the sequential prefix composition that
+reproduces DFVO.update_global_pose (libs/dfvo.py:109-119) including the constant-motion fallback
+(dfvo.py:157-161).  The collective is latency bound (KB per sequence), so it is issued once per chunk."""
+import numpy as np
+
+
+def chunk_bounds(n_pairs, world, rank):
+    """contiguous chunk [lo, hi) of frame pairs for `rank` (first ranks take the remainder)"""
+    q, r = divmod(n_pairs, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def allgather_poses(rel, status, world, rank, dist=None, backend_device="cuda"):
+    """rel [n_local,4,4] f64, status [n_local] int64 -> gathered [sum n,4,4+1] (pose | status) in rank order.
+    Uneven chunks are padded to the longest one for the fixed-size all-gather and trimmed afterwards."""
+    n_local = rel.shape[0]
+    if dist is None or world == 1:
+        out = np.zeros((n_local, 17))
+        out[:, :16] = rel.reshape(n_local, 16)
+        out[:, 16] = status
+        return out
+    import torch
+    dev = backend_device if dist.get_backend() == "nccl" else "cpu"
+    cnt = torch.tensor([n_local], dtype=torch.int64, device=dev)
+    cnts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(cnts, cnt)
+    counts = [int(c.item()) for c in cnts]
+    nmax = max(counts)
+    buf = torch.zeros((nmax, 17), dtype=torch.float64, device=dev)
+    if n_local:
+        buf[:n_local, :16] = torch.from_numpy(rel.reshape(n_local, 16)).to(dev)
+        buf[:n_local, 16] = torch.from_numpy(status.astype(np.float64)).to(dev)
+    bufs = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(bufs, buf)
+    return np.concatenate([b[:c].cpu().numpy() for b, c in zip(bufs, counts)], 0)
+
+
+def compose_trajectory(gathered, first_pose=None):
+    """sequential prefix composition over all gathered pairs -> global poses [n+1,4,4].
+    status 1 (constant motion) reuses the previous pair's relative motion, as the reference does."""
+    n = gathered.shape[0]
+    g = np.eye(4) if first_pose is None else first_pose.copy()
+    out = np.zeros((n + 1, 4, 4))
+    out[0] = g
+    prev = np.eye(4)
+    for i in range(n):
+        rel = gathered[i, :16].reshape(4, 4)
+        if int(gathered[i, 16]) == 1:
+            rel = prev
+        nxt = g.copy()
+        nxt[:3, 3:] = g[:3, :3] @ rel[:3, 3:] + g[:3, 3:]
+        nxt[:3, :3] = g[:3, :3] @ rel[:3, :3]
+        g = nxt
+        prev = rel
+        out[i + 1] = g
+    return out

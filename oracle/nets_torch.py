@@ -337,113 +337,15 @@ def depth_inference(sd, img_u8_feed, min_depth=0.1, max_depth=100, mult=5.4):
 
 
 # ----------------------------------------------------------------------------------------------
-# seeded synthetic weights: the reference's own initialisation
+# seeded synthetic weights live in df-vo_amd/synthetic.py (shared with bench.py); re-exported here
 # ----------------------------------------------------------------------------------------------
-def liteflownet_state_dict(seed=4869, gain=1.0):
-    """Kaiming-normal conv weights, zero bias (lite_flow_net.py:273-282); `gain` < 1 tames activations."""
-    g = torch.Generator().manual_seed(seed)
-    sd = {}
+import importlib as _importlib
+import os as _os
+import sys as _sys
 
-    def conv(name, cout, cin, kh, kw, bias=True):
-        fan_in = cin * kh * kw
-        std = math.sqrt(2.0) / math.sqrt(fan_in)
-        sd[name + '.weight'] = torch.randn(cout, cin, kh, kw, generator=g) * std * gain
-        if bias:
-            sd[name + '.bias'] = torch.randn(cout, generator=g) * 0.01
-
-    p = 'moduleFeatures.'
-    conv(p + 'moduleOne.0', 32, 3, 7, 7)
-    conv(p + 'moduleTwo.0', 32, 32, 3, 3)
-    conv(p + 'moduleTwo.2', 32, 32, 3, 3)
-    conv(p + 'moduleTwo.4', 32, 32, 3, 3)
-    conv(p + 'moduleThr.0', 64, 32, 3, 3)
-    conv(p + 'moduleThr.2', 64, 64, 3, 3)
-    conv(p + 'moduleFou.0', 96, 64, 3, 3)
-    conv(p + 'moduleFou.2', 96, 96, 3, 3)
-    conv(p + 'moduleFiv.0', 128, 96, 3, 3)
-    conv(p + 'moduleSix.0', 192, 128, 3, 3)
-    featc = [0, 32, 32, 64, 96, 128, 192]
-    for lvl in [2, 3, 4, 5, 6]:
-        k = KER[lvl]
-        cm = 64 if lvl == 2 else featc[lvl]
-        pm = 'moduleMatching.%d.' % (lvl - 2)
-        ps = 'moduleSubpixel.%d.' % (lvl - 2)
-        pr = 'moduleRegularization.%d.' % (lvl - 2)
-        if lvl == 2:
-            conv(pm + 'moduleFeat.0', 64, 32, 1, 1)
-            conv(ps + 'moduleFeat.0', 64, 32, 1, 1)
-        if lvl != 6:
-            # ConvTranspose2d(2, 2, 4, groups=2): weight [2, 1, 4, 4]; near-bilinear init keeps flows sane
-            sd[pm + 'moduleUpflow.weight'] = (torch.randn(2, 1, 4, 4, generator=g) * 0.05 + 0.25) * gain
-        if lvl < 4:
-            sd[pm + 'moduleUpcorr.weight'] = (torch.randn(49, 1, 4, 4, generator=g) * 0.05 + 0.25)
-        conv(pm + 'moduleMain.0', 128, 49, 3, 3)
-        conv(pm + 'moduleMain.2', 64, 128, 3, 3)
-        conv(pm + 'moduleMain.4', 32, 64, 3, 3)
-        conv(pm + 'moduleMain.6', 2, 32, k, k)
-        conv(ps + 'moduleMain.0', 128, 2 * cm + 2, 3, 3)
-        conv(ps + 'moduleMain.2', 64, 128, 3, 3)
-        conv(ps + 'moduleMain.4', 32, 64, 3, 3)
-        conv(ps + 'moduleMain.6', 2, 32, k, k)
-        if lvl < 5:
-            conv(pr + 'moduleFeat.0', 128, featc[lvl], 1, 1)
-        conv(pr + 'moduleMain.0', 128, 131 if lvl < 6 else 195, 3, 3)
-        conv(pr + 'moduleMain.2', 128, 128, 3, 3)
-        conv(pr + 'moduleMain.4', 64, 128, 3, 3)
-        conv(pr + 'moduleMain.6', 64, 64, 3, 3)
-        conv(pr + 'moduleMain.8', 32, 64, 3, 3)
-        conv(pr + 'moduleMain.10', 32, 32, 3, 3)
-        if lvl >= 5:
-            conv(pr + 'moduleDist.0', k * k, 32, k, k)
-        else:
-            conv(pr + 'moduleDist.0', k * k, 32, k, 1)
-            conv(pr + 'moduleDist.1', k * k, k * k, 1, k)
-        conv(pr + 'moduleScaleX', 1, k * k, 1, 1)
-        conv(pr + 'moduleScaleY', 1, k * k, 1, 1)
-    # flow heads: scale so that per-level flows are of the order of a pixel (warps get exercised)
-    for key in list(sd.keys()):
-        if key.endswith('moduleMain.6.weight'):
-            sd[key] = sd[key] * 3.0
-    return sd
-
-
-def monodepth2_state_dict(seed=4869):
-    """ResNet18 encoder (kaiming fan_out, BN identity-ish with seeded statistics) + decoder."""
-    g = torch.Generator().manual_seed(seed + 1)
-    sd = {}
-
-    def conv(name, cout, cin, k, bias):
-        std = math.sqrt(2.0 / (cin * k * k))
-        sd[name + '.weight'] = torch.randn(cout, cin, k, k, generator=g) * std
-        if bias:
-            sd[name + '.bias'] = torch.randn(cout, generator=g) * 0.01
-
-    def bn(name, c):
-        sd[name + '.weight'] = 1.0 + 0.1 * torch.randn(c, generator=g)
-        sd[name + '.bias'] = 0.05 * torch.randn(c, generator=g)
-        sd[name + '.running_mean'] = 0.05 * torch.randn(c, generator=g)
-        sd[name + '.running_var'] = 1.0 + 0.1 * torch.rand(c, generator=g)
-
-    conv('encoder.conv1', 64, 3, 7, False)
-    bn('encoder.bn1', 64)
-    ch = [64, 64, 128, 256, 512]
-    for li in range(1, 5):
-        cin, cout = ch[li - 1], ch[li]
-        for b in range(2):
-            p = 'encoder.layer%d.%d.' % (li, b)
-            conv(p + 'conv1', cout, cin if b == 0 else cout, 3, False)
-            bn(p + 'bn1', cout)
-            conv(p + 'conv2', cout, cout, 3, False)
-            bn(p + 'bn2', cout)
-            if li > 1 and b == 0:
-                conv(p + 'downsample.0', cout, cin, 1, False)
-                bn(p + 'downsample.1', cout)
-    dec = [16, 32, 64, 128, 256]
-    for i in range(4, -1, -1):
-        idx0 = (4 - i) * 2
-        cin0 = 512 if i == 4 else dec[i + 1]
-        conv('decoder.%d.conv.conv' % idx0, dec[i], cin0, 3, True)
-        conv('decoder.%d.conv.conv' % (idx0 + 1), dec[i], dec[i] + (ch[i - 1] if i > 0 else 0), 3, True)
-    for s in range(4):
-        conv('decoder.%d.conv' % (10 + s), 1, dec[s], 3, True)
-    return sd
+_root = _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__)))
+if _root not in _sys.path:
+    _sys.path.insert(0, _root)
+_syn = _importlib.import_module("df-vo_amd.synthetic")
+liteflownet_state_dict = _syn.liteflownet_state_dict
+monodepth2_state_dict = _syn.monodepth2_state_dict

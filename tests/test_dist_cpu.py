@@ -1,0 +1,98 @@
+"""CPU (gloo, world_size 2 and 3): the frame-batch data-parallel driver -- chunking, the single pose
+all-gather (uneven chunks), and the prefix composition with the constant-motion rule."""
+import importlib
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _poses(n, seed=5):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    rel = np.tile(np.eye(4), (n, 1, 1))
+    for i in range(n):
+        a = rng.normal(0, 0.01, 3)
+        th = np.linalg.norm(a)
+        k = a / th
+        Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        rel[i, :3, :3] = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+        rel[i, :3, 3] = rng.normal(0, 0.5, 3)
+    status = (rng.random(n) < 0.15).astype(np.int64)  # some constant-motion frames
+    status[0] = 0
+    return rel, status
+
+
+def _worker(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    dmod = importlib.import_module("df-vo_amd.dist")
+    rel, status = _poses(n)
+    lo, hi = dmod.chunk_bounds(n, world, rank)
+    g = dmod.allgather_poses(rel[lo:hi], status[lo:hi], world, rank, dist)
+    if rank == 0:
+        q.put(g)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(world, n):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    g = q.get(timeout=120)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return g
+
+
+def test_allgather_and_compose_world2_and_3():
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    dmod = importlib.import_module("df-vo_amd.dist")
+    for world, n in ((2, 11), (3, 10)):
+        rel, status = _poses(n)
+        g = _run(world, n)
+        assert g.shape == (n, 17)
+        assert np.array_equal(g[:, :16].reshape(n, 4, 4), rel) and np.array_equal(g[:, 16].astype(np.int64), status)
+        traj = dmod.compose_trajectory(g)
+        # sequential reference: dfvo.py:109-119 with the constant-motion rule of dfvo.py:157-161
+        cur = np.eye(4)
+        prev = np.eye(4)
+        for i in range(n):
+            r = prev if status[i] == 1 else rel[i]
+            t = cur[:3, :3] @ r[:3, 3:] + cur[:3, 3:]
+            R = cur[:3, :3] @ r[:3, :3]
+            cur = np.eye(4)
+            cur[:3, :3], cur[:3, 3:] = R, t
+            prev = r
+            assert np.allclose(traj[i + 1], cur, atol=0, rtol=0)
+
+
+def test_chunk_bounds_cover_everything():
+    dmod = importlib.import_module("df-vo_amd.dist")
+    for n in (0, 1, 7, 1590):
+        for world in (1, 2, 3, 8):
+            spans = [dmod.chunk_bounds(n, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for a, b in zip(spans, spans[1:]):
+                assert a[1] == b[0]
