@@ -391,10 +391,61 @@ SM_HD_NOINLINE int lu_solve(double* A, int astep, int m, double* b, int bstep, i
 // ------------------------------------------------------------------------------------------------
 // Durand-Kerner roots of sum_i c[i] x^i, degree 10 (cv::solvePoly, 300 iterations), register resident
 // ------------------------------------------------------------------------------------------------
-SM_HD_NOINLINE void solve_poly10(const double* c, double* rre, double* rim) {
-    int n = 10;
-    for (; n > 1; n--)
-        if (fabs(c[n]) + 0.0 > DBL_EPSILON) break;
+template <int N>
+SM_HD void solve_poly_fixed(const double* c, double* rre, double* rim) {
+    // N is a compile-time constant so that every index below is static after unrolling: the 2N root
+    // components and N+1 coefficients stay in registers on the GPU (300 x N x N complex steps per call)
+    double cr[N + 1], xr[N], xi[N];
+#pragma unroll
+    for (int i = 0; i <= N; i++) cr[i] = c[i];
+    {
+        double pre = 1, pim = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            xr[i] = pre;
+            xi[i] = pim;
+            const double tre = pre * 1.0 - pim * 1.0, tim = pre * 1.0 + pim * 1.0;
+            pre = tre;
+            pim = tim;
+        }
+    }
+    for (int iter = 0; iter < 300; iter++) {
+        double maxDiff = 0;
+#pragma unroll
+        for (int i = 0; i < N; i++) {
+            const double pre = xr[i], pim = xi[i];
+            double nre = cr[N], nim = 0, dre = cr[N], dim = 0;
+#pragma unroll
+            for (int j = 0; j < N; j++) {
+                double tre = nre * pre - nim * pim, tim = nre * pim + nim * pre;
+                nre = tre + cr[N - j - 1];
+                nim = tim + 0.0;
+                if (j != i) {
+                    const double qre = pre - xr[j], qim = pim - xi[j];
+                    tre = dre * qre - dim * qim;
+                    tim = dre * qim + dim * qre;
+                    dre = tre;
+                    dim = tim;
+                }
+            }
+            const double t = 1. / (dre * dre + dim * dim);
+            const double qre = (nre * dre + nim * dim) * t, qim = (-nre * dim + nim * dre) * t;
+            xr[i] = pre - qre;
+            xi[i] = pim - qim;
+            const double an = sqrt(qre * qre + qim * qim);
+            maxDiff = maxDiff > an ? maxDiff : an;
+        }
+        if (maxDiff <= 0) break;
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        rre[i] = xr[i];
+        rim[i] = fabs(xi[i]) < 1e-100 ? 0 : xi[i];
+    }
+}
+
+// generic degree (leading coefficients ~ 0): same algorithm with run-time n
+SM_HD_NOINLINE void solve_poly_generic(const double* c, int n, double* rre, double* rim) {
     double pre = 1, pim = 0;
     for (int i = 0; i < n; i++) {
         rre[i] = pre;
@@ -432,6 +483,17 @@ SM_HD_NOINLINE void solve_poly10(const double* c, double* rre, double* rim) {
     }
     for (int i = 0; i < n; i++)
         if (fabs(rim[i]) < 1e-100) rim[i] = 0;
+}
+
+SM_HD_NOINLINE void solve_poly10(const double* c, double* rre, double* rim) {
+    int n = 10;
+    for (; n > 1; n--)
+        if (fabs(c[n]) + 0.0 > DBL_EPSILON) break;
+    if (n == 10) {
+        solve_poly_fixed<10>(c, rre, rim);
+        return;
+    }
+    solve_poly_generic(c, n, rre, rim);
     for (; n < 10; n++) {
         rre[n] = rre[n - 1];
         rim[n] = rim[n - 1];

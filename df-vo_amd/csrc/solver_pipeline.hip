@@ -182,17 +182,24 @@ __global__ void k_mt_seed(uint32_t* __restrict__ st, uint32_t seed) {
     st[624] = 624;
 }
 
-// perm = np.arange(n); np.random.shuffle(perm)   (n read from device: info[0])
-__global__ __launch_bounds__(64) void k_mt_shuffle(uint32_t* __restrict__ st, const int* __restrict__ n_ptr,
-                                                    int* __restrict__ perm) {
+// `repeat` consecutive draws of  perm = np.arange(n); np.random.shuffle(perm)  (n = info[0] on the device).
+// The MT19937 state and the permutation being built live in LDS; one lane runs the Fisher-Yates chain.
+__global__ __launch_bounds__(256) void k_mt_shuffle_all(uint32_t* __restrict__ st, const int* __restrict__ n_ptr,
+                                                         int repeat, int cap, int* __restrict__ perm_all) {
     __shared__ sm::Mt19937 s;
+    extern __shared__ int s_perm[];
     const int t = threadIdx.x;
-    for (int i = t; i < 624; i += 64) s.key[i] = st[i];
+    const int n = *n_ptr;
+    for (int i = t; i < 624; i += 256) s.key[i] = st[i];
     if (t == 0) s.pos = (int)st[624];
     __syncthreads();
-    if (t == 0) sm::mt_shuffle_arange(s, *n_ptr, perm);
-    __syncthreads();
-    for (int i = t; i < 624; i += 64) st[i] = s.key[i];
+    for (int r = 0; r < repeat; r++) {
+        if (t == 0) sm::mt_shuffle_arange(s, n, s_perm);
+        __syncthreads();
+        for (int i = t; i < n; i += 256) perm_all[(size_t)r * cap + i] = s_perm[i];
+        __syncthreads();
+    }
+    for (int i = t; i < 624; i += 256) st[i] = s.key[i];
     if (t == 0) st[624] = (uint32_t)s.pos;
 }
 
@@ -251,20 +258,29 @@ __global__ void k_gric_h_residual(const double* __restrict__ Hm, const int* __re
     res[i] = (D1 * D1 + D2 * D2 - 2.0 * D1 * D2 * cos(alpha)) / sin(alpha);
 }
 
-// calc_GRIC (gric.py:95-132): the python loop's sequential sum, one lane
-__global__ void k_gric_sum(const double* __restrict__ res, const int* __restrict__ n_ptr, double sigma, int Kp, int D,
-                           double* __restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// calc_GRIC (gric.py:95-132): the python loop's sequential sum, one lane; residuals staged through LDS
+__global__ __launch_bounds__(256) void k_gric_sum(const double* __restrict__ res, const int* __restrict__ n_ptr,
+                                                   double sigma, int Kp, int D, double* __restrict__ out) {
+    __shared__ double s_res[2048];
     const int n = *n_ptr;
     const double R = 4, sigmasq1 = 1. / (sigma * sigma);
     const double lam3RD = 2.0 * (R - D);
     double sum = 0;
-    for (int i = 0; i < n; i++) {
-        const double tmp = res[i] * sigmasq1;
-        sum += tmp <= lam3RD ? tmp : lam3RD;
+    for (int c0 = 0; c0 < n; c0 += 2048) {
+        const int cnt = n - c0 < 2048 ? n - c0 : 2048;
+        for (int i = threadIdx.x; i < cnt; i += 256) s_res[i] = res[c0 + i];
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (int i = 0; i < cnt; i++) {
+                const double tmp = s_res[i] * sigmasq1;
+                sum += tmp <= lam3RD ? tmp : lam3RD;
+            }
+        __syncthreads();
     }
-    sum += n * D * log(R) + Kp * log(R * n);
-    *out = sum;
+    if (threadIdx.x == 0) {
+        sum += n * D * log(R) + Kp * log(R * n);
+        *out = sum;
+    }
 }
 
 // ================================================================================================
@@ -542,10 +558,10 @@ int TrackerBuffers::ensure_kp(int cap, int cells, int n_best) {
     sel_cap = cells * n_best > sel_cap ? cells * n_best : sel_cap;
     DFVO_HIP_CHECK(hipMalloc((void**)&kp_ref, sizeof(double) * 2 * kp_cap));
     DFVO_HIP_CHECK(hipMalloc((void**)&kp_cur, sizeof(double) * 2 * kp_cap));
-    DFVO_HIP_CHECK(hipMalloc((void**)&pa, sizeof(double) * 2 * kp_cap));
-    DFVO_HIP_CHECK(hipMalloc((void**)&pb, sizeof(double) * 2 * kp_cap));
-    DFVO_HIP_CHECK(hipMalloc((void**)&perm, sizeof(int) * (kp_cap + 8)));
-    DFVO_HIP_CHECK(hipMalloc((void**)&res, sizeof(double) * kp_cap));
+    DFVO_HIP_CHECK(hipMalloc((void**)&pa, sizeof(double) * 2 * kp_cap * MAX_REP));
+    DFVO_HIP_CHECK(hipMalloc((void**)&pb, sizeof(double) * 2 * kp_cap * MAX_REP));
+    DFVO_HIP_CHECK(hipMalloc((void**)&perm, sizeof(int) * (size_t)(kp_cap + 8) * MAX_REP));
+    DFVO_HIP_CHECK(hipMalloc((void**)&res, sizeof(double) * kp_cap * (MAX_REP + 1)));
     DFVO_HIP_CHECK(hipMalloc((void**)&best_inliers, kp_cap + 8));
     DFVO_HIP_CHECK(hipMalloc((void**)&cell_count, sizeof(int) * 1024));
     DFVO_HIP_CHECK(hipMalloc((void**)&cell_sel, sizeof(int) * sel_cap));
@@ -576,6 +592,11 @@ int TrackerBuffers::init() {
     DFVO_HIP_CHECK(hipMalloc((void**)&small, sizeof(double) * 128));
     DFVO_HIP_CHECK(hipMalloc((void**)&scale_out, sizeof(ScaleResult)));
     DFVO_HIP_CHECK(hipMemset(kp_info, 0, sizeof(int) * 8));
+    for (int r = 0; r < MAX_REP; r++) {
+        DFVO_HIP_CHECK(hipStreamCreateWithFlags(&s_rep[r], hipStreamNonBlocking));
+        DFVO_HIP_CHECK(hipEventCreateWithFlags(&ev_rep[r], hipEventDisableTiming));
+    }
+    DFVO_HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     return DFVO_OK;
 }
 
@@ -583,6 +604,15 @@ void TrackerBuffers::release() {
     release_kp();
     ws_h.release();
     ws_e.release();
+    for (int r = 0; r < MAX_REP; r++) {
+        ws_rep[r].release();
+        if (s_rep[r]) (void)hipStreamDestroy(s_rep[r]);
+        if (ev_rep[r]) (void)hipEventDestroy(ev_rep[r]);
+        s_rep[r] = nullptr;
+        ev_rep[r] = nullptr;
+    }
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    ev_fork = nullptr;
     void* ptrs[] = {mt_state, kp_info, kp_total, pose, small, scale_out, winner, lidx};
     lidx = nullptr;
     lidx_cap = 0;
@@ -617,33 +647,60 @@ int enqueue_compute_pose_2d2d(TrackerBuffers& tb, int n_host, const PoseConfig& 
     DFVO_HIP_CHECK(hipMemcpyAsync(tb.small, hk, sizeof(hk), hipMemcpyHostToDevice, s));
     hipLaunchKernelGGL(k_pose_state_init, dim3(cdiv(tb.kp_cap, 256)), dim3(256), 0, s, tb.pose, tb.kp_info,
                        tb.best_inliers, tb.kp_cap);
-    // ---- homography + GRIC-H (kp_cur -> kp_ref), only when more than 10 keypoints (E_tracker.py:196)
+    // only when more than 10 keypoints (E_tracker.py:196)
     if (n_host > 10) {
-        int rc = enqueue_find_homography(tb.ws_h, tb.kp_cur, tb.kp_ref, n_host, 1.0, 2000, 0.99, s);
+        DFVO_ARG_CHECK(cfg.repeat <= MAX_REP, "compute_pose_2d2d: repeat > MAX_REP");
+        const int cap = tb.kp_cap;
+        // all shuffles first (one sequential RNG chain), then the `repeat` RANSACs run concurrently on
+        // their own streams while the homography runs on `s`
+        const size_t perm_lds = sizeof(int) * (size_t)(n_host > 0 ? n_host : 1);
+        DFVO_ARG_CHECK(perm_lds <= 96 * 1024, "compute_pose_2d2d: too many keypoints for the LDS permutation buffer");
+        static size_t configured = 0;
+        if (perm_lds > configured) {
+            DFVO_HIP_CHECK(hipFuncSetAttribute((const void*)k_mt_shuffle_all, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)perm_lds));
+            configured = perm_lds;
+        }
+        hipLaunchKernelGGL(k_mt_shuffle_all, dim3(1), dim3(256), perm_lds, s, tb.mt_state, tb.kp_info, cfg.repeat, cap + 8,
+                           tb.perm);
+        for (int rep = 0; rep < cfg.repeat; ++rep)
+            hipLaunchKernelGGL(k_permute_points, dim3(nb), dim3(256), 0, s, tb.kp_info, tb.perm + (size_t)rep * (cap + 8),
+                               tb.kp_cur, tb.kp_ref, tb.pa + (size_t)rep * 2 * cap, tb.pb + (size_t)rep * 2 * cap);
+        DFVO_HIP_CHECK(hipEventRecord(tb.ev_fork, s));
+        int rc;
+        for (int rep = 0; rep < cfg.repeat; ++rep) {
+            hipStream_t sr = tb.s_rep[rep];
+            double* pa = tb.pa + (size_t)rep * 2 * cap;
+            double* pb = tb.pb + (size_t)rep * 2 * cap;
+            double* res = tb.res + (size_t)(rep + 1) * cap;
+            DFVO_HIP_CHECK(hipStreamWaitEvent(sr, tb.ev_fork, 0));
+            rc = enqueue_find_essential(tb.ws_rep[rep], pa, pb, n_host, cfg.fx, cfg.cx, cfg.cy, 0.99, cfg.reproj_thre,
+                                        cfg.max_iters, sr);
+            if (rc != DFVO_OK) return rc;
+            hipLaunchKernelGGL(k_gric_f_residual, dim3(nb), dim3(256), 0, sr, tb.ws_rep[rep].out, tb.small, tb.small + 9,
+                               tb.kp_info, pa, pb, res);
+            hipLaunchKernelGGL(k_gric_sum, dim3(1), dim3(256), 0, sr, res, tb.kp_info, 0.8, 5, 3, tb.small + 19 + rep);
+            DFVO_HIP_CHECK(hipEventRecord(tb.ev_rep[rep], sr));
+        }
+        // ---- homography + GRIC-H (kp_cur -> kp_ref)
+        rc = enqueue_find_homography(tb.ws_h, tb.kp_cur, tb.kp_ref, n_host, 1.0, 2000, 0.99, s);
         if (rc != DFVO_OK) return rc;
         hipLaunchKernelGGL(k_gric_h_residual, dim3(nb), dim3(256), 0, s, tb.ws_h.out, tb.kp_info, tb.kp_cur, tb.kp_ref,
                            tb.res);
-        hipLaunchKernelGGL(k_gric_sum, dim3(1), dim3(1), 0, s, tb.res, tb.kp_info, 0.8, 8, 2, tb.small + 18);
+        hipLaunchKernelGGL(k_gric_sum, dim3(1), dim3(256), 0, s, tb.res, tb.kp_info, 0.8, 8, 2, tb.small + 18);
         hipLaunchKernelGGL(k_set_h_gric, dim3(1), dim3(1), 0, s, tb.pose, tb.ws_h.state, tb.small + 18);
         for (int rep = 0; rep < cfg.repeat; ++rep) {
-            hipLaunchKernelGGL(k_mt_shuffle, dim3(1), dim3(64), 0, s, tb.mt_state, tb.kp_info, tb.perm);
-            hipLaunchKernelGGL(k_permute_points, dim3(nb), dim3(256), 0, s, tb.kp_info, tb.perm, tb.kp_cur, tb.kp_ref,
-                               tb.pa, tb.pb);
-            rc = enqueue_find_essential(tb.ws_e, tb.pa, tb.pb, n_host, cfg.fx, cfg.cx, cfg.cy, 0.99, cfg.reproj_thre,
-                                        cfg.max_iters, s);
-            if (rc != DFVO_OK) return rc;
-            hipLaunchKernelGGL(k_gric_f_residual, dim3(nb), dim3(256), 0, s, tb.ws_e.out, tb.small, tb.small + 9,
-                               tb.kp_info, tb.pa, tb.pb, tb.res);
-            hipLaunchKernelGGL(k_gric_sum, dim3(1), dim3(1), 0, s, tb.res, tb.kp_info, 0.8, 5, 3, tb.small + 19);
-            hipLaunchKernelGGL(k_rep_update, dim3(1), dim3(256), 0, s, tb.pose, tb.ws_e.state, tb.ws_e.out,
-                               tb.small + 19, tb.ws_e.mask, tb.perm, tb.best_inliers, rep);
+            DFVO_HIP_CHECK(hipStreamWaitEvent(s, tb.ev_rep[rep], 0));
+            hipLaunchKernelGGL(k_rep_update, dim3(1), dim3(256), 0, s, tb.pose, tb.ws_rep[rep].state, tb.ws_rep[rep].out,
+                               tb.small + 19 + rep, tb.ws_rep[rep].mask, tb.perm + (size_t)rep * (cap + 8),
+                               tb.best_inliers, rep);
         }
-        hipLaunchKernelGGL(k_pose_finish, dim3(1), dim3(1), 0, s, tb.pose, tb.ws_e.out + 16, cfg.repeat, 0);
+        hipLaunchKernelGGL(k_pose_finish, dim3(1), dim3(1), 0, s, tb.pose, tb.ws_rep[0].out + 16, cfg.repeat, 0);
         // recoverPose(best_E, kp_cur, kp_ref): always enqueued, consumed only when major_valid
-        rc = enqueue_recover_pose(tb.ws_e, (const double*)((const char*)tb.pose + offsetof(PoseState, best_E)), tb.kp_cur,
-                                  tb.kp_ref, n_host, cfg.fx, cfg.cx, cfg.cy, s);
+        rc = enqueue_recover_pose(tb.ws_rep[0], (const double*)((const char*)tb.pose + offsetof(PoseState, best_E)),
+                                  tb.kp_cur, tb.kp_ref, n_host, cfg.fx, cfg.cx, cfg.cy, s);
         if (rc != DFVO_OK) return rc;
-        hipLaunchKernelGGL(k_pose_finish, dim3(1), dim3(1), 0, s, tb.pose, tb.ws_e.out + 16, cfg.repeat, 1);
+        hipLaunchKernelGGL(k_pose_finish, dim3(1), dim3(1), 0, s, tb.pose, tb.ws_rep[0].out + 16, cfg.repeat, 1);
     }
     DFVO_HIP_CHECK(hipGetLastError());
     return DFVO_OK;

@@ -410,52 +410,62 @@ __global__ void k_h_mask(const RansacState* st, const double* __restrict__ model
 
 // ------------------------------------------------------------------------------------------------
 // post-RANSAC refinement on the inliers (findHomography tail): one 256-thread block.
-//   * ordered compaction of the inlier indices,
+//   * ordered (ballot) compaction of the inlier indices,
 //   * least-squares refit: every LtL entry / centroid / scale is a sequential sum over the inliers in
-//     index order, so one lane owns one accumulator (45 + 8 lanes) -> same rounding as the CPU loop,
-//   * Levenberg-Marquardt (<= 10 iterations): residuals/Jacobian rows per point in parallel, J^T J
-//     (36 unique entries) and J^T r (8) again one lane per accumulator, the 8x8 solve on lane 0.
-// lm workspace layout (doubles): r[2n] | rd[2n] | J[2n*8]
+//     index order, so ONE LANE OWNS ONE ACCUMULATOR (45 + 4 lanes) -> same rounding as the CPU loop;
+//     the per-point terms are produced 256 points at a time by all threads into LDS,
+//   * Levenberg-Marquardt (<= 10 iterations): residuals and the two Jacobian rows of 256 points per chunk
+//     in parallel into LDS, then J^T J (36 unique entries), J^T r (8), |r|^2 and |r|_inf again one lane
+//     per accumulator over the chunk; the 8x8 eigen-solve on lane 0.
 // ------------------------------------------------------------------------------------------------
-__device__ void h_refine_compute(const float* src, const float* dst, const int* cidx, int np, const double* h,
-                                 double* err, double* J) {
-    for (int i = threadIdx.x; i < np; i += blockDim.x) {
-        const int p = cidx[i];
-        const double Mx = src[p * 2], My = src[p * 2 + 1];
-        double ww = h[6] * Mx + h[7] * My + 1.;
-        ww = fabs(ww) > DBL_EPSILON ? 1. / ww : 0;
-        const double xi = (h[0] * Mx + h[1] * My + h[2]) * ww;
-        const double yi = (h[3] * Mx + h[4] * My + h[5]) * ww;
-        err[i * 2] = xi - dst[p * 2];
-        err[i * 2 + 1] = yi - dst[p * 2 + 1];
-        if (J) {
-            double* Jp = J + (size_t)i * 16;
-            Jp[0] = Mx * ww;
-            Jp[1] = My * ww;
-            Jp[2] = ww;
-            Jp[3] = Jp[4] = Jp[5] = 0.;
-            Jp[6] = -Mx * ww * xi;
-            Jp[7] = -My * ww * xi;
-            Jp[8] = Jp[9] = Jp[10] = 0.;
-            Jp[11] = Mx * ww;
-            Jp[12] = My * ww;
-            Jp[13] = ww;
-            Jp[14] = -Mx * ww * yi;
-            Jp[15] = -My * ww * yi;
-        }
+struct HRefineShared {
+    double buf[256 * 18];  // per-point Lx|Ly (refit) or J rows (16) + r (2) (LM)
+    float pts[256 * 4];    // Mx My mx my of the chunk
+    int wave_cnt[4];
+    int base;
+};
+
+__device__ __forceinline__ void h_chunk_points(HRefineShared& sh, const float* src, const float* dst, const int* cidx,
+                                               int c0, int np) {
+    const int t = threadIdx.x;
+    if (c0 + t < np) {
+        const int p = cidx[c0 + t];
+        sh.pts[t * 4 + 0] = src[p * 2];
+        sh.pts[t * 4 + 1] = src[p * 2 + 1];
+        sh.pts[t * 4 + 2] = dst[p * 2];
+        sh.pts[t * 4 + 3] = dst[p * 2 + 1];
     }
 }
 
-__device__ double seq_norm_l2sqr(const double* a, int n) {
-    double s = 0;
-    int i = 0;
-    for (; i <= n - 4; i += 4) {
-        const double v0 = a[i], v1 = a[i + 1], v2 = a[i + 2], v3 = a[i + 3];
-        s += v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
+// residuals (and Jacobian rows) of the chunk at parameters h into sh.buf: [t*18 + 0..7] row a, [8..15] row b,
+// [16],[17] residuals
+__device__ __forceinline__ void h_chunk_lm(HRefineShared& sh, const double* h, int cnt, bool with_j) {
+    const int t = threadIdx.x;
+    if (t >= cnt) return;
+    const double Mx = sh.pts[t * 4], My = sh.pts[t * 4 + 1];
+    double ww = h[6] * Mx + h[7] * My + 1.;
+    ww = fabs(ww) > DBL_EPSILON ? 1. / ww : 0;
+    const double xi = (h[0] * Mx + h[1] * My + h[2]) * ww;
+    const double yi = (h[3] * Mx + h[4] * My + h[5]) * ww;
+    double* o = sh.buf + t * 18;
+    o[16] = xi - sh.pts[t * 4 + 2];
+    o[17] = yi - sh.pts[t * 4 + 3];
+    if (with_j) {
+        o[0] = Mx * ww;
+        o[1] = My * ww;
+        o[2] = ww;
+        o[3] = o[4] = o[5] = 0.;
+        o[6] = -Mx * ww * xi;
+        o[7] = -My * ww * xi;
+        o[8] = o[9] = o[10] = 0.;
+        o[11] = Mx * ww;
+        o[12] = My * ww;
+        o[13] = ww;
+        o[14] = -Mx * ww * yi;
+        o[15] = -My * ww * yi;
     }
-    for (; i < n; i++) s += a[i] * a[i];
-    return s;
 }
+
 __device__ double seq_dot8(const double* a, const double* b) {
     double r = 0;
     r += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
@@ -467,37 +477,58 @@ __global__ __launch_bounds__(256) void k_h_refine(const RansacState* st, const f
                                                    const float* __restrict__ dst, int n,
                                                    const uint8_t* __restrict__ mask, int* __restrict__ cidx,
                                                    double* __restrict__ lm, double* __restrict__ H_io) {
-    __shared__ int s_np;
-    __shared__ double s_h[9], s_x[8], s_xd[8], s_d[8], s_v[8], s_A[64], s_S, s_Sd, s_norm[8], s_LtL[81];
+    __shared__ HRefineShared sh;
+    __shared__ double s_h[9], s_x[8], s_xd[8], s_d[8], s_v[8], s_A[64], s_D[8], s_norm[8], s_LtL[81];
+    __shared__ double s_S, s_Sd, s_rinf, s_lambda, s_lc;
     __shared__ int s_flag;
-    __shared__ double s_rinf;
+    (void)lm;
     if (!st->found) return;
-    const int t = threadIdx.x;
-    // ---- ordered compaction (single lane: n <= a few thousand)
-    if (t == 0) {
-        int np = 0;
-        for (int i = 0; i < n; i++)
-            if (mask[i]) cidx[np++] = i;
-        s_np = np;
-    }
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    // ---- ordered compaction of the inlier indices
+    if (t == 0) sh.base = 0;
     __syncthreads();
-    const int np = s_np;
+    for (int c0 = 0; c0 < n; c0 += 256) {
+        const int i = c0 + t;
+        const bool f = i < n && mask[i] != 0;
+        const unsigned long long b = __ballot(f);
+        if (lane == 0) sh.wave_cnt[wave] = __popcll(b);
+        __syncthreads();
+        int off = sh.base;
+        for (int w = 0; w < wave; w++) off += sh.wave_cnt[w];
+        if (f) cidx[off + __popcll(b & ((1ull << lane) - 1ull))] = i;
+        __syncthreads();
+        if (t == 0) sh.base += sh.wave_cnt[0] + sh.wave_cnt[1] + sh.wave_cnt[2] + sh.wave_cnt[3];
+        __syncthreads();
+    }
+    const int np = sh.base;
     if (np <= 0) return;
-    // ---- refit on all inliers: centroid sums (lanes 0..3), then scale sums (lanes 0..3)
-    if (t < 4) {
-        const float* a = (t < 2) ? dst : src;  // 0: cm.x 1: cm.y 2: cM.x 3: cM.y
-        double s = 0;
-        for (int i = 0; i < np; i++) s += a[cidx[i] * 2 + (t & 1)];
-        s_norm[t] = s / np;
+    // ---- refit: centroids (4 sequential sums), then scales (4 sequential sums)
+    double acc = 0;
+    for (int c0 = 0; c0 < np; c0 += 256) {
+        const int cnt = np - c0 < 256 ? np - c0 : 256;
+        h_chunk_points(sh, src, dst, cidx, c0, np);
+        __syncthreads();
+        if (t < 4) {  // 0: cm.x 1: cm.y 2: cM.x 3: cM.y
+            const int comp = t < 2 ? 2 + t : t - 2;
+            for (int k = 0; k < cnt; k++) acc += sh.pts[k * 4 + comp];
+        }
+        __syncthreads();
     }
+    if (t < 4) s_norm[t] = acc / np;
     __syncthreads();
-    if (t < 4) {
-        const float* a = (t < 2) ? dst : src;
-        const double c = s_norm[t];
-        double s = 0;
-        for (int i = 0; i < np; i++) s += fabs(a[cidx[i] * 2 + (t & 1)] - c);
-        s_norm[4 + t] = s;
+    acc = 0;
+    for (int c0 = 0; c0 < np; c0 += 256) {
+        const int cnt = np - c0 < 256 ? np - c0 : 256;
+        h_chunk_points(sh, src, dst, cidx, c0, np);
+        __syncthreads();
+        if (t < 4) {
+            const int comp = t < 2 ? 2 + t : t - 2;
+            const double c = s_norm[t];
+            for (int k = 0; k < cnt; k++) acc += fabs(sh.pts[k * 4 + comp] - c);
+        }
+        __syncthreads();
     }
+    if (t < 4) s_norm[4 + t] = acc;
     __syncthreads();
     sm::HNorm hn;
     hn.cmx = s_norm[0];
@@ -511,27 +542,38 @@ __global__ __launch_bounds__(256) void k_h_refine(const RansacState* st, const f
         hn.smy = np / s_norm[5];
         hn.sMx = np / s_norm[6];
         hn.sMy = np / s_norm[7];
+        int lj = 0, lk = 0;
+        if (t < 45) {  // lane t owns upper-triangular entry (lj, lk)
+            int rem = t;
+            while (rem >= 9 - lj) {
+                rem -= 9 - lj;
+                lj++;
+            }
+            lk = lj + rem;
+        }
+        acc = 0;
+        for (int c0 = 0; c0 < np; c0 += 256) {
+            const int cnt = np - c0 < 256 ? np - c0 : 256;
+            h_chunk_points(sh, src, dst, cidx, c0, np);
+            __syncthreads();
+            if (t < cnt) {
+                const double x = (sh.pts[t * 4 + 2] - hn.cmx) * hn.smx, y = (sh.pts[t * 4 + 3] - hn.cmy) * hn.smy;
+                const double X = (sh.pts[t * 4 + 0] - hn.cMx) * hn.sMx, Y = (sh.pts[t * 4 + 1] - hn.cMy) * hn.sMy;
+                double* o = sh.buf + t * 18;
+                o[0] = X; o[1] = Y; o[2] = 1; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = -x * X; o[7] = -x * Y; o[8] = -x;
+                o[9] = 0; o[10] = 0; o[11] = 0; o[12] = X; o[13] = Y; o[14] = 1; o[15] = -y * X; o[16] = -y * Y; o[17] = -y;
+            }
+            __syncthreads();
+            if (t < 45)
+                for (int k = 0; k < cnt; k++) {
+                    const double* o = sh.buf + k * 18;
+                    acc += o[lj] * o[lk] + o[9 + lj] * o[9 + lk];
+                }
+            __syncthreads();
+        }
         if (t < 81) s_LtL[t] = 0;
         __syncthreads();
-        if (t < 45) {
-            // lane t owns upper-triangular entry (j,k)
-            int j = 0, rem = t;
-            while (rem >= 9 - j) {
-                rem -= 9 - j;
-                j++;
-            }
-            const int k = j + rem;
-            double acc = 0;
-            for (int i = 0; i < np; i++) {
-                const int p = cidx[i];
-                const double x = (dst[p * 2] - hn.cmx) * hn.smx, y = (dst[p * 2 + 1] - hn.cmy) * hn.smy;
-                const double X = (src[p * 2] - hn.cMx) * hn.sMx, Y = (src[p * 2 + 1] - hn.cMy) * hn.sMy;
-                const double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
-                const double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
-                acc += Lx[j] * Lx[k] + Ly[j] * Ly[k];
-            }
-            s_LtL[j * 9 + k] = acc;
-        }
+        if (t < 45) s_LtL[lj * 9 + lk] = acc;
         __syncthreads();
         if (t == 0) {
             double LtL[81], model[9];
@@ -544,43 +586,99 @@ __global__ __launch_bounds__(256) void k_h_refine(const RansacState* st, const f
     }
     __syncthreads();
     // ---- Levenberg-Marquardt on the 8 free parameters
-    double* r = lm;
-    double* rd = lm + 2 * (size_t)n;
-    double* J = lm + 4 * (size_t)n;
-    const int rows = 2 * np;
     if (t < 8) s_x[t] = s_h[t];
     __syncthreads();
-    h_refine_compute(src, dst, cidx, np, s_x, r, J);
-    __syncthreads();
-    __shared__ double s_D[8];
-    __shared__ double s_lambda, s_lc;
-    auto accumulate_normal_eq = [&]() {
-        if (t < 36) {
-            int i = 0, rem = t;
-            while (rem >= 8 - i) {
-                rem -= 8 - i;
-                i++;
-            }
-            const int j = i + rem;
-            double s = 0;
-            for (int k = 0; k < rows; k++) s += J[(size_t)k * 8 + i] * J[(size_t)k * 8 + j];
-            s_A[i * 8 + j] = s;
-            s_A[j * 8 + i] = s;
-        } else if (t >= 64 && t < 72) {
-            const int i = t - 64;
-            double s = 0;
-            for (int k = 0; k < rows; k++) s += J[(size_t)k * 8 + i] * r[k];
-            s_v[i] = s;
-        } else if (t == 128) {
-            s_S = seq_norm_l2sqr(r, rows);
-        } else if (t == 192) {
-            double m = 0;
-            for (int k = 0; k < rows; k++) m = m > fabs(r[k]) ? m : fabs(r[k]);
-            s_rinf = m;
+    // accumulator roles: t < 36 -> JtJ(i,j); 64..71 -> Jtr(i); 128 -> |r|^2 (4-row groups); 192 -> |r|_inf
+    int ai = 0, aj = 0;
+    if (t < 36) {
+        int rem = t;
+        while (rem >= 8 - ai) {
+            rem -= 8 - ai;
+            ai++;
         }
+        aj = ai + rem;
+    }
+    auto full_pass = [&](const double* h) {  // residuals + Jacobian at h -> s_A, s_v, s_S, s_rinf
+        double a = 0;
+        for (int c0 = 0; c0 < np; c0 += 256) {
+            const int cnt = np - c0 < 256 ? np - c0 : 256;
+            h_chunk_points(sh, src, dst, cidx, c0, np);
+            __syncthreads();
+            h_chunk_lm(sh, h, cnt, true);
+            __syncthreads();
+            if (t < 36) {
+                for (int k = 0; k < cnt; k++) {
+                    const double* o = sh.buf + k * 18;
+                    a += o[ai] * o[aj];
+                    a += o[8 + ai] * o[8 + aj];
+                }
+            } else if (t >= 64 && t < 72) {
+                const int i = t - 64;
+                for (int k = 0; k < cnt; k++) {
+                    const double* o = sh.buf + k * 18;
+                    a += o[i] * o[16];
+                    a += o[8 + i] * o[17];
+                }
+            } else if (t == 128) {
+                int k = 0;
+                for (; k + 1 < cnt; k += 2) {
+                    const double v0 = sh.buf[k * 18 + 16], v1 = sh.buf[k * 18 + 17];
+                    const double v2 = sh.buf[(k + 1) * 18 + 16], v3 = sh.buf[(k + 1) * 18 + 17];
+                    a += v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
+                }
+                for (; k < cnt; k++) {  // only at the very end of the inlier list (chunks hold an even count otherwise)
+                    const double v0 = sh.buf[k * 18 + 16], v1 = sh.buf[k * 18 + 17];
+                    a += v0 * v0;
+                    a += v1 * v1;
+                }
+            } else if (t == 192) {
+                for (int k = 0; k < cnt; k++) {
+                    const double v0 = fabs(sh.buf[k * 18 + 16]), v1 = fabs(sh.buf[k * 18 + 17]);
+                    a = a > v0 ? a : v0;
+                    a = a > v1 ? a : v1;
+                }
+            }
+            __syncthreads();
+        }
+        if (t < 36) {
+            s_A[ai * 8 + aj] = a;
+            s_A[aj * 8 + ai] = a;
+        } else if (t >= 64 && t < 72) {
+            s_v[t - 64] = a;
+        } else if (t == 128) {
+            s_S = a;
+        } else if (t == 192) {
+            s_rinf = a;
+        }
+        __syncthreads();
     };
-    accumulate_normal_eq();
-    __syncthreads();
+    auto residual_pass = [&](const double* h) {  // |r(h)|^2 -> s_Sd
+        double a = 0;
+        for (int c0 = 0; c0 < np; c0 += 256) {
+            const int cnt = np - c0 < 256 ? np - c0 : 256;
+            h_chunk_points(sh, src, dst, cidx, c0, np);
+            __syncthreads();
+            h_chunk_lm(sh, h, cnt, false);
+            __syncthreads();
+            if (t == 128) {
+                int k = 0;
+                for (; k + 1 < cnt; k += 2) {
+                    const double v0 = sh.buf[k * 18 + 16], v1 = sh.buf[k * 18 + 17];
+                    const double v2 = sh.buf[(k + 1) * 18 + 16], v3 = sh.buf[(k + 1) * 18 + 17];
+                    a += v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
+                }
+                for (; k < cnt; k++) {
+                    const double v0 = sh.buf[k * 18 + 16], v1 = sh.buf[k * 18 + 17];
+                    a += v0 * v0;
+                    a += v1 * v1;
+                }
+            }
+            __syncthreads();
+        }
+        if (t == 128) s_Sd = a;
+        __syncthreads();
+    };
+    full_pass(s_x);
     if (t < 8) s_D[t] = s_A[t * 8 + t];
     if (t == 0) {
         s_lambda = 1;
@@ -605,20 +703,18 @@ __global__ __launch_bounds__(256) void k_h_refine(const RansacState* st, const f
             }
         }
         __syncthreads();
-        h_refine_compute(src, dst, cidx, np, s_xd, rd, nullptr);
-        __syncthreads();
+        residual_pass(s_xd);
         if (t == 0) {
-            const double Sd = seq_norm_l2sqr(rd, rows);
-            s_Sd = Sd;
+            const double Sd = s_Sd;
             double temp_d[8], d[8], v[8];
             for (int i = 0; i < 8; i++) {
                 d[i] = s_d[i];
                 v[i] = s_v[i];
             }
             for (int i = 0; i < 8; i++) {
-                double s = 0;
-                for (int k = 0; k < 8; k++) s += s_A[i * 8 + k] * d[k];
-                temp_d[i] = s * -1. + v[i] * 2.;
+                double sacc = 0;
+                for (int k = 0; k < 8; k++) sacc += s_A[i * 8 + k] * d[k];
+                temp_d[i] = sacc * -1. + v[i] * 2.;
             }
             const double dS = seq_dot8(d, temp_d);
             const double S = s_S;
@@ -655,10 +751,7 @@ __global__ __launch_bounds__(256) void k_h_refine(const RansacState* st, const f
                 s_xd[t] = tx;
             }
             __syncthreads();
-            h_refine_compute(src, dst, cidx, np, s_x, r, J);
-            __syncthreads();
-            accumulate_normal_eq();  // also refreshes S (= Sd) and |r|_inf
-            __syncthreads();
+            full_pass(s_x);  // refreshes A, v, S (= Sd) and |r|_inf
         }
         iter++;
         double dinf = 0;

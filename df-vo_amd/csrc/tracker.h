@@ -47,8 +47,14 @@ struct ScaleConfig {
     double stop_prob, thre;
 };
 
+constexpr int MAX_REP = 8;
+
 struct TrackerBuffers {
-    RansacWorkspace ws_h, ws_e;
+    RansacWorkspace ws_h, ws_e;          // ws_e: stand-alone findEssentialMat / recoverPose calls
+    RansacWorkspace ws_rep[MAX_REP];     // one workspace per repeated findEssentialMat (run concurrently)
+    hipStream_t s_rep[MAX_REP] = {};
+    hipEvent_t ev_rep[MAX_REP] = {};
+    hipEvent_t ev_fork = nullptr;
     uint32_t* mt_state = nullptr;  // numpy RandomState: key[624], pos
     int* kp_info = nullptr;        // [n, good_kp_found, regions]
     int* kp_total = nullptr;
