@@ -42,14 +42,17 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
     return i >= n ? 2 * n - 2 - i : i;
 }
 
-__device__ __forceinline__ f32x4 conv_load_a(const ConvParams& p, int n, int iy0, int ix0, bool vm, int g,
-                                             int G, int taps) {
-    const int tap = g / G;
-    const int cg = g - tap * G;
-    const int ky = tap / p.kw;
-    const int kx = tap - ky * p.kw;
+// k-group table entry built once per block in LDS: which tap / source / channel offset a k-group is
+struct KGroup {
+    uint32_t tap;  // ky | kx << 8 | valid << 16 | src << 17
+    uint32_t coff; // float offset of the 4 channels inside the pixel (view offset included)
+};
+constexpr int MAX_KGROUPS = 2048;
+
+__device__ __forceinline__ f32x4 conv_load_a(const ConvParams& p, int n, int iy0, int ix0, bool vm, KGroup kg) {
+    const int ky = kg.tap & 0xff, kx = (kg.tap >> 8) & 0xff;
     int iy = iy0 + ky, ix = ix0 + kx;
-    bool v = vm && (tap < taps);
+    bool v = vm && ((kg.tap >> 16) & 1);
     if (p.pad_mode == PAD_REFLECT) {
         iy = reflect_idx(iy, p.H);
         ix = reflect_idx(ix, p.W);
@@ -58,7 +61,7 @@ __device__ __forceinline__ f32x4 conv_load_a(const ConvParams& p, int n, int iy0
     }
     f32x4 r = {0.f, 0.f, 0.f, 0.f};
     if (v) {
-        if (cg < p.G0) {
+        if (((kg.tap >> 17) & 1) == 0) {
             int yy = iy, xx = ix, HH = p.H, WW = p.W;
             if (p.up0) {
                 yy >>= 1;
@@ -66,11 +69,9 @@ __device__ __forceinline__ f32x4 conv_load_a(const ConvParams& p, int n, int iy0
                 HH >>= 1;
                 WW >>= 1;
             }
-            r = *reinterpret_cast<const f32x4*>(p.src0 + ((size_t)(n * HH + yy) * WW + xx) * p.cs0 + p.co0 +
-                                                cg * 4);
+            r = *reinterpret_cast<const f32x4*>(p.src0 + ((size_t)(n * HH + yy) * WW + xx) * p.cs0 + kg.coff);
         } else {
-            r = *reinterpret_cast<const f32x4*>(p.src1 + ((size_t)(n * p.H + iy) * p.W + ix) * p.cs1 + p.co1 +
-                                                (cg - p.G0) * 4);
+            r = *reinterpret_cast<const f32x4*>(p.src1 + ((size_t)(n * p.H + iy) * p.W + ix) * p.cs1 + kg.coff);
         }
     }
     return r;
@@ -82,10 +83,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
     constexpr int BN = WN * TN * 16;
     constexpr int A_CNT = (BM * 4 + 255) / 256;
     constexpr int B_CNT = (BN * 4 + 255) / 256;
+    constexpr int TILE = BM * 16 + BN * 16;  // floats per stage
     static_assert(WM * WN == 4, "4 waves per block");
-    __shared__ __attribute__((aligned(16))) float lds[BM * 16 + BN * 16];
-    float* As = lds;
-    float* Bs = lds + BM * 16;
+    __shared__ __attribute__((aligned(16))) float lds[2 * TILE];
+    __shared__ KGroup ktab[MAX_KGROUPS];
 
     const int t = threadIdx.x;
     const int lane = t & 63;
@@ -106,6 +107,22 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
     const int M = p.N * p.Ho * p.Wo;
     const int G = p.G0 + p.G1;
     const int taps = p.kh * p.kw;
+    // split-K: this block contracts K-steps [s_begin, s_end)
+    const int per = (p.ksteps + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int s_begin = (int)blockIdx.z * per;
+    const int s_end = s_begin + per < p.ksteps ? s_begin + per : p.ksteps;
+
+    for (int g = s_begin * 4 + t; g < s_end * 4; g += 256) {
+        const int tap = g / G;
+        const int cg = g - tap * G;
+        const int ky = tap / p.kw, kx = tap - ky * p.kw;
+        KGroup e;
+        const uint32_t valid = tap < taps ? 1u : 0u;
+        const uint32_t src = cg < p.G0 ? 0u : 1u;
+        e.tap = (uint32_t)ky | ((uint32_t)kx << 8) | (valid << 16) | (src << 17);
+        e.coff = src == 0 ? (uint32_t)(p.co0 + cg * 4) : (uint32_t)(p.co1 + (cg - p.G0) * 4);
+        ktab[g - s_begin * 4] = e;
+    }
 
     // per-thread A staging slots
     int a_n[A_CNT], a_iy0[A_CNT], a_ix0[A_CNT];
@@ -125,14 +142,13 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
         a_ix0[r] = ox * p.stride - p.pad_w;
         a_vm[r] = vm;
     }
+    __syncthreads();
 
     f32x4 ra[A_CNT], rb[B_CNT];
     auto load_step = [&](int s) {
+        const KGroup kg = ktab[(s - s_begin) * 4 + (t & 3)];
 #pragma unroll
-        for (int r = 0; r < A_CNT; ++r) {
-            const int id = t + 256 * r;
-            ra[r] = conv_load_a(p, a_n[r], a_iy0[r], a_ix0[r], a_vm[r], 4 * s + (id & 3), G, taps);
-        }
+        for (int r = 0; r < A_CNT; ++r) ra[r] = conv_load_a(p, a_n[r], a_iy0[r], a_ix0[r], a_vm[r], kg);
 #pragma unroll
         for (int r = 0; r < B_CNT; ++r) {
             const int id = t + 256 * r;
@@ -142,7 +158,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
             }
         }
     };
-    auto store_step = [&]() {
+    auto store_step = [&](float* As, float* Bs) {
 #pragma unroll
         for (int r = 0; r < A_CNT; ++r) {
             const int id = t + 256 * r;
@@ -166,11 +182,18 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int li = lane & 15, kq = lane >> 4;
-    load_step(0);
-    store_step();
+    if (s_begin < s_end) {
+        load_step(s_begin);
+        store_step(lds, lds + BM * 16);
+    }
     __syncthreads();
-    for (int s = 0; s < p.ksteps; ++s) {
-        const bool more = (s + 1 < p.ksteps);
+    // double-buffered LDS, ONE barrier per K-step: while step s is contracted out of stage (s&1) the
+    // tiles of step s+1 travel global -> registers -> stage ((s+1)&1)
+    for (int s = s_begin; s < s_end; ++s) {
+        const int st = (s - s_begin) & 1;
+        const float* As = lds + st * TILE;
+        const float* Bs = As + BM * 16;
+        const bool more = (s + 1 < s_end);
         if (more) load_step(s + 1);
         f32x4 fa[TM], fb[TN];
 #pragma unroll
@@ -184,6 +207,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
             const int c = wn * TN * 16 + j * 16 + li;
             fb[j] = *reinterpret_cast<const f32x4*>(Bs + (kq * BN + c) * 4);
         }
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -191,12 +215,30 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][r], fb[j][r], acc[i][j], 0, 0, 0);
-        __syncthreads();
-        if (more) store_step();
+        __builtin_amdgcn_s_setprio(0);
+        if (more) {
+            float* An = lds + (st ^ 1) * TILE;
+            store_step(An, An + BM * 16);
+        }
         __syncthreads();
     }
 
     // epilogue: C/D layout col = lane&15, row = (lane>>4)*4 + reg
+    if (gridDim.z > 1) {  // split-K partial: raw accumulators to the workspace [z][M][cout_pad]
+        float* wsz = p.ws + (size_t)blockIdx.z * M * p.cout_pad;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * TN * 16 + j * 16 + li;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = m0 + wm * TM * 16 + i * 16 + kq * 4 + r;
+                    if (m < M) wsz[(size_t)m * p.cout_pad + col] = acc[i][j][r];
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = n0 + wn * TN * 16 + j * 16 + li;
@@ -221,6 +263,26 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
             }
         }
     }
+}
+
+// split-K second pass: ordered sum of the partials + bias + residual + activation
+__global__ void conv_splitk_epilogue(const ConvParams p, int splits) {
+    const int M = p.N * p.Ho * p.Wo;
+    const int cols = p.dst_zero_to > p.cout ? p.dst_zero_to : p.cout;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)M * cols) return;
+    const int col = (int)(idx % cols);
+    const int m = (int)(idx / cols);
+    if (col >= p.cout) {
+        p.dst[(size_t)m * p.dst_cs + p.dst_co + col] = 0.f;
+        return;
+    }
+    float v = 0.f;
+    for (int z = 0; z < splits; ++z) v += p.ws[((size_t)z * M + m) * p.cout_pad + col];
+    v += p.bias[col];
+    if (p.res) v += p.res[(size_t)m * p.res_cs + p.res_co + col];
+    v = apply_act(v, p.act, p.act_param);
+    p.dst[(size_t)m * p.dst_cs + p.dst_co + col] = v;
 }
 
 int conv_pick_bn(int cout, long long M) {
@@ -313,6 +375,21 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) {
     constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
     const long long M = (long long)p.N * p.Ho * p.Wo;
     dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(p.cout_pad / BN), 1);
+    DFVO_ARG_CHECK((p.G0 + p.G1) * p.kh * p.kw + 4 <= MAX_KGROUPS, "launch_conv: too many k-groups for the LDS table");
+    // split-K when the grid cannot fill the chip: partials to p.ws, ordered reduction in a second launch
+    int splits = 1;
+    const long long blocks = (long long)grid.x * grid.y;
+    if (p.ws && blocks < 192 && p.ksteps >= 16) {
+        splits = (int)((512 + blocks - 1) / blocks);
+        if (splits > p.ksteps / 8) splits = p.ksteps / 8;
+        if (splits > 32) splits = 32;
+        while (splits > 1 && (size_t)splits * M * p.cout_pad > p.ws_floats) --splits;
+        if (splits < 1) splits = 1;
+        // no empty z-slices
+        const int per = (p.ksteps + splits - 1) / splits;
+        splits = (p.ksteps + per - 1) / per;
+    }
+    grid.z = (unsigned)splits;
     ConvProfEntry pe;
     if (g_prof) {
         DFVO_HIP_CHECK(hipEventCreate(&pe.e0));
@@ -325,6 +402,12 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) {
     }
     hipLaunchKernelGGL((conv_igemm_f32_kernel<WM, WN, TM, TN>), grid, dim3(256), 0, stream, p);
     DFVO_HIP_CHECK(hipGetLastError());
+    if (splits > 1) {
+        const int cols = p.dst_zero_to > p.cout ? p.dst_zero_to : p.cout;
+        const long long total = M * cols;
+        hipLaunchKernelGGL(conv_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p, splits);
+        DFVO_HIP_CHECK(hipGetLastError());
+    }
     if (g_prof) {
         DFVO_HIP_CHECK(hipEventRecord(pe.e1, stream));
         pe.flops = p.useful_flops;

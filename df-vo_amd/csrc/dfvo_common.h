@@ -59,6 +59,9 @@ struct ConvParams {
     int dst_cs, dst_co;
     // when != 0 the epilogue also zero-fills channels [cout, dst_zero_to) of dst
     int dst_zero_to;
+    // split-K workspace (optional): partial accumulators [splits][M][cout_pad]
+    float* ws;
+    size_t ws_floats;
     // 2 * MACs of the unpadded convolution (bookkeeping for the bench's roofline leg; not read on device)
     double useful_flops;
 };

@@ -47,7 +47,8 @@ struct View {
 };
 
 int run_conv(const ConvLayer& L, int N, int H, int W, View s0, int up0, View s1, const float* res, int res_cs,
-             int res_co, float* dst, int dst_cs, int dst_co, int dst_zero_to, hipStream_t s, double* flops);
+             int res_co, float* dst, int dst_cs, int dst_co, int dst_zero_to, hipStream_t s, double* flops,
+             const DevBuf* splitk_ws = nullptr);
 
 // ------------------------------------------------------------------------------------------------
 struct FlowNet {
@@ -73,6 +74,7 @@ struct FlowNet {
             flowS, r0, dist_a, dist_b, flow, mean;
     } lv[7];
     DevBuf u8_ref, u8_cur;  // staging for the host-pointer entry point
+    DevBuf splitk;          // split-K partial sums of the small-grid convs (own buffer: the nets run on separate streams)
     DevBuf out_fwd, out_bwd, out_diff;
     double flops_last = 0.0;  // useful conv+corr FLOPs of the last forward (2*MAC)
     hipGraph_t graph = nullptr;
@@ -105,6 +107,7 @@ struct DepthNet {
     ConvLayer up[5][2], dispconv;
     DevBuf x0, f0, pool, tmp[4], feat[5], blk_t, blk_ds, blk_o[2], du[5], dx[5], disp, depth;
     DevBuf u8_in;
+    DevBuf splitk;
     double flops_last = 0.0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;

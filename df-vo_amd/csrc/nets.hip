@@ -79,7 +79,8 @@ void free_conv(ConvLayer* l) {
 }
 
 int run_conv(const ConvLayer& L, int N, int H, int W, View s0, int up0, View s1, const float* res, int res_cs,
-             int res_co, float* dst, int dst_cs, int dst_co, int dst_zero_to, hipStream_t s, double* flops) {
+             int res_co, float* dst, int dst_cs, int dst_co, int dst_zero_to, hipStream_t s, double* flops,
+             const DevBuf* splitk_ws) {
     ConvParams p;
     memset(&p, 0, sizeof(p));
     p.N = N;
@@ -116,6 +117,8 @@ int run_conv(const ConvLayer& L, int N, int H, int W, View s0, int up0, View s1,
     p.dst_cs = dst_cs;
     p.dst_co = dst_co;
     p.dst_zero_to = dst_zero_to;
+    p.ws = splitk_ws ? splitk_ws->p : nullptr;
+    p.ws_floats = splitk_ws ? splitk_ws->n : 0;
     p.useful_flops = 2.0 * (double)N * p.Ho * p.Wo * L.macs_per_pixel();
     if (flops) *flops += p.useful_flops;
     return launch_conv(p, s);
@@ -348,6 +351,7 @@ int FlowNet::finalize() {
     DFVO_TRY(out_fwd.alloc((size_t)2 * imgH * imgW));
     DFVO_TRY(out_bwd.alloc((size_t)2 * imgH * imgW));
     DFVO_TRY(out_diff.alloc((size_t)imgH * imgW));
+    DFVO_TRY(splitk.alloc((size_t)12 << 20));
     DFVO_TRY(u8_ref.alloc(((size_t)imgH * imgW * 3 + 3) / 4 + 1));
     DFVO_TRY(u8_cur.alloc(((size_t)imgH * imgW * 3 + 3) / 4 + 1));
     finalized = true;
@@ -372,25 +376,25 @@ int FlowNet::enqueue(const uint8_t* d_ref, const uint8_t* d_cur, float* d_fwd, f
         Level& L3 = lv[3];
         Level& L4 = lv[4];
         DFVO_TRY(run_conv(feat_convs[0], N, lh[1], lw[1], View{img[1].p, 4, 0}, 0, none, nullptr, 0, 0, feat[1].p, 32, 0,
-                          0, s, &fl));
+                          0, s, &fl, &splitk));
         DFVO_TRY(run_conv(feat_convs[1], N, lh[1], lw[1], View{feat[1].p, 32, 0}, 0, none, nullptr, 0, 0, L2.x32.p, 32,
-                          0, 0, s, &fl));
+                          0, 0, s, &fl, &splitk));
         DFVO_TRY(run_conv(feat_convs[2], N, lh[2], lw[2], View{L2.x32.p, 32, 0}, 0, none, nullptr, 0, 0, L2.x32b.p, 32,
-                          0, 0, s, &fl));
+                          0, 0, s, &fl, &splitk));
         DFVO_TRY(run_conv(feat_convs[3], N, lh[2], lw[2], View{L2.x32b.p, 32, 0}, 0, none, nullptr, 0, 0, feat[2].p, 32,
-                          0, 0, s, &fl));
+                          0, 0, s, &fl, &splitk));
         DFVO_TRY(run_conv(feat_convs[4], N, lh[2], lw[2], View{feat[2].p, 32, 0}, 0, none, nullptr, 0, 0, L3.x64.p, 64,
-                          0, 0, s, &fl));
+                          0, 0, s, &fl, &splitk));
         DFVO_TRY(run_conv(feat_convs[5], N, lh[3], lw[3], View{L3.x64.p, 64, 0}, 0, none, nullptr, 0, 0, feat[3].p, 64,
-                          0, 0, s, &fl));
+                          0, 0, s, &fl, &splitk));
         DFVO_TRY(run_conv(feat_convs[6], N, lh[3], lw[3], View{feat[3].p, 64, 0}, 0, none, nullptr, 0, 0, L4.x128.p, 96,
-                          0, 0, s, &fl));
+                          0, 0, s, &fl, &splitk));
         DFVO_TRY(run_conv(feat_convs[7], N, lh[4], lw[4], View{L4.x128.p, 96, 0}, 0, none, nullptr, 0, 0, feat[4].p, 96,
-                          0, 0, s, &fl));
+                          0, 0, s, &fl, &splitk));
         DFVO_TRY(run_conv(feat_convs[8], N, lh[4], lw[4], View{feat[4].p, 96, 0}, 0, none, nullptr, 0, 0, feat[5].p,
-                          128, 0, 0, s, &fl));
+                          128, 0, 0, s, &fl, &splitk));
         DFVO_TRY(run_conv(feat_convs[9], N, lh[5], lw[5], View{feat[5].p, 128, 0}, 0, none, nullptr, 0, 0, feat[6].p,
-                          192, 0, 0, s, &fl));
+                          192, 0, 0, s, &fl, &splitk));
     }
     const float* flow_prev = nullptr;
     for (int l = 6; l >= 2; --l) {
@@ -405,9 +409,9 @@ int FlowNet::enqueue(const uint8_t* d_ref, const uint8_t* d_cur, float* d_fwd, f
         const float* sf = feat[l].p;
         if (L.has_mfeat) {
             DFVO_TRY(run_conv(L.m_feat, N, h, w, View{feat[l].p, C, 0}, 0, none, nullptr, 0, 0, L.mfeat.p, 64, 0, 0, s,
-                              &fl));
+                              &fl, &splitk));
             DFVO_TRY(run_conv(L.s_feat, N, h, w, View{feat[l].p, C, 0}, 0, none, nullptr, 0, 0, L.sfeat.p, 64, 0, 0, s,
-                              &fl));
+                              &fl, &splitk));
             mf = L.mfeat.p;
             sf = L.sfeat.p;
         }
@@ -426,50 +430,50 @@ int FlowNet::enqueue(const uint8_t* d_ref, const uint8_t* d_cur, float* d_fwd, f
             DFVO_TRY(launch_deconv_dw(L.corr.p, 52, 0, N, h / 2, w / 2, 49, L.upcorr_w.p, L.corr_up.p, 52, 0, s));
             corr = L.corr_up.p;
         }
-        DFVO_TRY(run_conv(L.m_main[0], N, h, w, View{corr, 52, 0}, 0, none, nullptr, 0, 0, L.x128.p, 128, 0, 0, s, &fl));
+        DFVO_TRY(run_conv(L.m_main[0], N, h, w, View{corr, 52, 0}, 0, none, nullptr, 0, 0, L.x128.p, 128, 0, 0, s, &fl, &splitk));
         DFVO_TRY(run_conv(L.m_main[1], N, h, w, View{L.x128.p, 128, 0}, 0, none, nullptr, 0, 0, L.x64.p, 64, 0, 0, s,
-                          &fl));
-        DFVO_TRY(run_conv(L.m_main[2], N, h, w, View{L.x64.p, 64, 0}, 0, none, nullptr, 0, 0, L.x32.p, 32, 0, 0, s, &fl));
+                          &fl, &splitk));
+        DFVO_TRY(run_conv(L.m_main[2], N, h, w, View{L.x64.p, 64, 0}, 0, none, nullptr, 0, 0, L.x32.p, 32, 0, 0, s, &fl, &splitk));
         DFVO_TRY(run_conv(L.m_main[3], N, h, w, View{L.x32.p, 32, 0}, 0, none, flow_prev ? L.flow_up.p : nullptr, 4, 0,
-                          L.flowM.p, 4, 0, 0, s, &fl));
+                          L.flowM.p, 4, 0, 0, s, &fl, &splitk));
         // ------------------------------ Subpixel (lite_flow_net.py:182-190)
         DFVO_TRY(launch_warp(sf, Cm, 0, 1, L.flowM.p, 4, 0, dbl, N, h, w, Cm, lin_x[l].p, lin_y[l].p, L.b1.p, Cm + 4, 0,
                              1, s));
         DFVO_TRY(run_conv(L.s_main[0], N, h, w, View{sf, Cm, 0}, 0, View{L.b1.p, Cm + 4, 0}, nullptr, 0, 0, L.x128b.p,
-                          128, 0, 0, s, &fl));
+                          128, 0, 0, s, &fl, &splitk));
         DFVO_TRY(run_conv(L.s_main[1], N, h, w, View{L.x128b.p, 128, 0}, 0, none, nullptr, 0, 0, L.x64b.p, 64, 0, 0, s,
-                          &fl));
+                          &fl, &splitk));
         DFVO_TRY(run_conv(L.s_main[2], N, h, w, View{L.x64b.p, 64, 0}, 0, none, nullptr, 0, 0, L.x32b.p, 32, 0, 0, s,
-                          &fl));
+                          &fl, &splitk));
         DFVO_TRY(run_conv(L.s_main[3], N, h, w, View{L.x32b.p, 32, 0}, 0, none, L.flowM.p, 4, 0, L.flowS.p, 4, 0, 0, s,
-                          &fl));
+                          &fl, &splitk));
         // ------------------------------ Regularization (lite_flow_net.py:243-264)
         DFVO_TRY(launch_flow_mean(L.flowS.p, 4, 0, N, h * w, nullptr, L.mean.p, s));
         DFVO_TRY(launch_reg_prep(img[l].p, L.flowS.p, 4, 0, dbl, L.mean.p, N, h, w, lin_x[l].p, lin_y[l].p, L.r0.p, s));
         const float* rf = feat[l].p;
         if (L.has_rfeat) {
             DFVO_TRY(run_conv(L.r_feat, N, h, w, View{feat[l].p, C, 0}, 0, none, nullptr, 0, 0, L.rfeat.p, 128, 0, 0, s,
-                              &fl));
+                              &fl, &splitk));
             rf = L.rfeat.p;
         }
         DFVO_TRY(run_conv(L.r_main[0], N, h, w, View{L.r0.p, 4, 0}, 0, View{rf, Cr, 0}, nullptr, 0, 0, L.x128.p, 128, 0,
-                          0, s, &fl));
+                          0, s, &fl, &splitk));
         DFVO_TRY(run_conv(L.r_main[1], N, h, w, View{L.x128.p, 128, 0}, 0, none, nullptr, 0, 0, L.x128b.p, 128, 0, 0, s,
-                          &fl));
+                          &fl, &splitk));
         DFVO_TRY(run_conv(L.r_main[2], N, h, w, View{L.x128b.p, 128, 0}, 0, none, nullptr, 0, 0, L.x64.p, 64, 0, 0, s,
-                          &fl));
+                          &fl, &splitk));
         DFVO_TRY(run_conv(L.r_main[3], N, h, w, View{L.x64.p, 64, 0}, 0, none, nullptr, 0, 0, L.x64b.p, 64, 0, 0, s,
-                          &fl));
+                          &fl, &splitk));
         DFVO_TRY(run_conv(L.r_main[4], N, h, w, View{L.x64b.p, 64, 0}, 0, none, nullptr, 0, 0, L.x32.p, 32, 0, 0, s,
-                          &fl));
+                          &fl, &splitk));
         DFVO_TRY(run_conv(L.r_main[5], N, h, w, View{L.x32.p, 32, 0}, 0, none, nullptr, 0, 0, L.x32b.p, 32, 0, 0, s,
-                          &fl));
+                          &fl, &splitk));
         const float* dist = L.dist_a.p;
         DFVO_TRY(run_conv(L.r_dist[0], N, h, w, View{L.x32b.p, 32, 0}, 0, none, nullptr, 0, 0, L.dist_a.p, kkp, 0, kkp,
-                          s, &fl));
+                          s, &fl, &splitk));
         if (L.dist_sep) {
             DFVO_TRY(run_conv(L.r_dist[1], N, h, w, View{L.dist_a.p, kkp, 0}, 0, none, nullptr, 0, 0, L.dist_b.p, kkp, 0,
-                              kkp, s, &fl));
+                              kkp, s, &fl, &splitk));
             dist = L.dist_b.p;
         }
         DFVO_TRY(launch_reg_head(dist, kkp, k, L.flowS.p, 4, 0, L.scale_wx.p, L.scale_bx, L.scale_wy.p, L.scale_by, N,
@@ -545,6 +549,7 @@ void FlowNet::destroy() {
     out_fwd.release();
     out_bwd.release();
     out_diff.release();
+    splitk.release();
     u8_ref.release();
     u8_cur.release();
     if (own_stream && stream) (void)hipStreamDestroy(stream);
@@ -673,6 +678,7 @@ int DepthNet::finalize() {
     }
     DFVO_TRY(disp.alloc((size_t)N * H * W * 4));
     DFVO_TRY(depth.alloc((size_t)N * H * W));
+    DFVO_TRY(splitk.alloc((size_t)12 << 20));
     DFVO_TRY(u8_in.alloc(((size_t)H * W * 3 + 3) / 4 + 1));
     finalized = true;
     return DFVO_OK;
@@ -686,7 +692,7 @@ int DepthNet::enqueue(const uint8_t* d_img, float* d_depth) {
     const int ch[5] = {64, 64, 128, 256, 512};
     const int dec[5] = {16, 32, 64, 128, 256};
     DFVO_TRY(launch_img_u8_to_depth_input(d_img, H, W, x0.p, s));
-    DFVO_TRY(run_conv(conv1, N, H, W, View{x0.p, 4, 0}, 0, none, nullptr, 0, 0, feat[0].p, 64, 0, 0, s, &fl));
+    DFVO_TRY(run_conv(conv1, N, H, W, View{x0.p, 4, 0}, 0, none, nullptr, 0, 0, feat[0].p, 64, 0, 0, s, &fl, &splitk));
     DFVO_TRY(launch_maxpool3x3s2(feat[0].p, N, H / 2, W / 2, 64, pool.p, s));
     const float* x = pool.p;
     int hh = H / 4, ww = W / 4, c = 64;
@@ -696,15 +702,15 @@ int DepthNet::enqueue(const uint8_t* d_img, float* d_depth) {
             const int cout = ch[li + 1];
             const int ho = B.has_ds ? hh / 2 : hh, wo = B.has_ds ? ww / 2 : ww;
             float* out = (b == 1) ? feat[li + 1].p : blk_o[0].p;
-            DFVO_TRY(run_conv(B.c1, N, hh, ww, View{x, c, 0}, 0, none, nullptr, 0, 0, blk_t.p, cout, 0, 0, s, &fl));
+            DFVO_TRY(run_conv(B.c1, N, hh, ww, View{x, c, 0}, 0, none, nullptr, 0, 0, blk_t.p, cout, 0, 0, s, &fl, &splitk));
             const float* idn = x;
             int idn_cs = c;
             if (B.has_ds) {
-                DFVO_TRY(run_conv(B.ds, N, hh, ww, View{x, c, 0}, 0, none, nullptr, 0, 0, blk_ds.p, cout, 0, 0, s, &fl));
+                DFVO_TRY(run_conv(B.ds, N, hh, ww, View{x, c, 0}, 0, none, nullptr, 0, 0, blk_ds.p, cout, 0, 0, s, &fl, &splitk));
                 idn = blk_ds.p;
                 idn_cs = cout;
             }
-            DFVO_TRY(run_conv(B.c2, N, ho, wo, View{blk_t.p, cout, 0}, 0, none, idn, idn_cs, 0, out, cout, 0, 0, s, &fl));
+            DFVO_TRY(run_conv(B.c2, N, ho, wo, View{blk_t.p, cout, 0}, 0, none, idn, idn_cs, 0, out, cout, 0, 0, s, &fl, &splitk));
             x = out;
             hh = ho;
             ww = wo;
@@ -716,15 +722,15 @@ int DepthNet::enqueue(const uint8_t* d_img, float* d_depth) {
     int cc = 512;
     for (int i = 4; i >= 0; --i) {
         const int h0 = H >> (i + 1), w0 = W >> (i + 1);
-        DFVO_TRY(run_conv(up[i][0], N, h0, w0, View{cur, cc, 0}, 0, none, nullptr, 0, 0, du[i].p, dec[i], 0, 0, s, &fl));
+        DFVO_TRY(run_conv(up[i][0], N, h0, w0, View{cur, cc, 0}, 0, none, nullptr, 0, 0, du[i].p, dec[i], 0, 0, s, &fl, &splitk));
         View skip = none;
         if (i > 0) skip = View{feat[i - 1].p, ch[i - 1], 0};
         DFVO_TRY(run_conv(up[i][1], N, 2 * h0, 2 * w0, View{du[i].p, dec[i], 0}, 1, skip, nullptr, 0, 0, dx[i].p, dec[i],
-                          0, 0, s, &fl));
+                          0, 0, s, &fl, &splitk));
         cur = dx[i].p;
         cc = dec[i];
     }
-    DFVO_TRY(run_conv(dispconv, N, H, W, View{dx[0].p, 16, 0}, 0, none, nullptr, 0, 0, disp.p, 4, 0, 0, s, &fl));
+    DFVO_TRY(run_conv(dispconv, N, H, W, View{dx[0].p, 16, 0}, 0, none, nullptr, 0, 0, disp.p, 4, 0, 0, s, &fl, &splitk));
     const float min_disp = 1.0f / max_depth, max_disp = 1.0f / min_depth;
     DFVO_TRY(launch_disp_to_depth(disp.p, 4, 0, H * W, min_disp, (float)((double)max_disp - (double)min_disp),
                                   baseline_mult, d_depth, s));
@@ -778,7 +784,7 @@ void DepthNet::destroy() {
         dx[i].release();
     }
     free_conv(&dispconv);
-    DevBuf* bufs[] = {&x0, &pool, &blk_t, &blk_ds, &blk_o[0], &blk_o[1], &disp, &depth, &u8_in};
+    DevBuf* bufs[] = {&x0, &pool, &blk_t, &blk_ds, &blk_o[0], &blk_o[1], &disp, &depth, &u8_in, &splitk};
     for (DevBuf* b : bufs) b->release();
     if (own_stream && stream) (void)hipStreamDestroy(stream);
     stream = nullptr;
