@@ -49,32 +49,31 @@ struct KGroup {
 };
 constexpr int MAX_KGROUPS = 2048;
 
-__device__ __forceinline__ f32x4 conv_load_a(const ConvParams& p, int n, int iy0, int ix0, bool vm, KGroup kg) {
+// Branch-free A gather: the address is always clamped into the tensor and the load always issued;
+// out-of-image / padded / out-of-range lanes are zeroed by a select when the tile is written to LDS.
+// (Per-lane branches around the loads fragment the K-loop into exec-masked blocks and serialise it.)
+__device__ __forceinline__ f32x4 conv_load_a(const ConvParams& p, int n, int iy0, int ix0, bool vm, KGroup kg,
+                                             bool& valid) {
     const int ky = kg.tap & 0xff, kx = (kg.tap >> 8) & 0xff;
     int iy = iy0 + ky, ix = ix0 + kx;
     bool v = vm && ((kg.tap >> 16) & 1);
-    if (p.pad_mode == PAD_REFLECT) {
+    if (p.pad_mode == PAD_REFLECT) {  // wave-uniform
         iy = reflect_idx(iy, p.H);
         ix = reflect_idx(ix, p.W);
     } else {
         v = v && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
     }
-    f32x4 r = {0.f, 0.f, 0.f, 0.f};
-    if (v) {
-        if (((kg.tap >> 17) & 1) == 0) {
-            int yy = iy, xx = ix, HH = p.H, WW = p.W;
-            if (p.up0) {
-                yy >>= 1;
-                xx >>= 1;
-                HH >>= 1;
-                WW >>= 1;
-            }
-            r = *reinterpret_cast<const f32x4*>(p.src0 + ((size_t)(n * HH + yy) * WW + xx) * p.cs0 + kg.coff);
-        } else {
-            r = *reinterpret_cast<const f32x4*>(p.src1 + ((size_t)(n * p.H + iy) * p.W + ix) * p.cs1 + kg.coff);
-        }
-    }
-    return r;
+    iy = iy < 0 ? 0 : (iy >= p.H ? p.H - 1 : iy);
+    ix = ix < 0 ? 0 : (ix >= p.W ? p.W - 1 : ix);
+    const bool s1 = ((kg.tap >> 17) & 1) != 0;
+    const int sh = s1 ? 0 : p.up0;
+    const float* base = s1 ? p.src1 : p.src0;
+    const unsigned cs = (unsigned)(s1 ? p.cs1 : p.cs0);
+    const unsigned yy = (unsigned)(iy >> sh), xx = (unsigned)(ix >> sh);
+    const unsigned HH = (unsigned)(p.H >> sh), WW = (unsigned)(p.W >> sh);
+    const unsigned off = (((unsigned)n * HH + yy) * WW + xx) * cs + kg.coff;
+    valid = v;
+    return *reinterpret_cast<const f32x4*>(base + off);
 }
 
 template <int WM, int WN, int TM, int TN>
@@ -145,10 +144,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
     __syncthreads();
 
     f32x4 ra[A_CNT], rb[B_CNT];
+    bool rv[A_CNT];
     auto load_step = [&](int s) {
         const KGroup kg = ktab[(s - s_begin) * 4 + (t & 3)];
 #pragma unroll
-        for (int r = 0; r < A_CNT; ++r) ra[r] = conv_load_a(p, a_n[r], a_iy0[r], a_ix0[r], a_vm[r], kg);
+        for (int r = 0; r < A_CNT; ++r) ra[r] = conv_load_a(p, a_n[r], a_iy0[r], a_ix0[r], a_vm[r], kg, rv[r]);
 #pragma unroll
         for (int r = 0; r < B_CNT; ++r) {
             const int id = t + 256 * r;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
             if (id < BM * 4) {
                 const int m = id >> 2, gi = id & 3;
                 const int gs = gi ^ (((m >> 3) & 1) << 1);
-                *reinterpret_cast<f32x4*>(As + m * 16 + gs * 4) = ra[r];
+                *reinterpret_cast<f32x4*>(As + m * 16 + gs * 4) = rv[r] ? ra[r] : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
 #pragma unroll

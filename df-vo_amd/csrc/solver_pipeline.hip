@@ -183,24 +183,112 @@ __global__ void k_mt_seed(uint32_t* __restrict__ st, uint32_t seed) {
 }
 
 // `repeat` consecutive draws of  perm = np.arange(n); np.random.shuffle(perm)  (n = info[0] on the device).
-// The MT19937 state and the permutation being built live in LDS; one lane runs the Fisher-Yates chain.
+// MT19937 block regeneration (624 words, three dependency-free phases) and tempering run on all 256
+// threads; the Fisher-Yates chain itself is sequential (masked rejection + data-dependent swaps) and runs
+// on lane 0 out of LDS, handing control back whenever the block of tempered words is exhausted.
+__device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+__device__ __forceinline__ uint32_t mt_mix(uint32_t a, uint32_t b, uint32_t c) {
+    const uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+    return c ^ (y >> 1) ^ ((uint32_t)(-(int32_t)(y & 1)) & 0x9908b0dfu);
+}
+
 __global__ __launch_bounds__(256) void k_mt_shuffle_all(uint32_t* __restrict__ st, const int* __restrict__ n_ptr,
                                                          int repeat, int cap, int* __restrict__ perm_all) {
-    __shared__ sm::Mt19937 s;
+    __shared__ uint32_t key[624], outw[624];
+    __shared__ int s_pos, s_phase, s_rep, s_i, s_regen;
     extern __shared__ int s_perm[];
     const int t = threadIdx.x;
     const int n = *n_ptr;
-    for (int i = t; i < 624; i += 256) s.key[i] = st[i];
-    if (t == 0) s.pos = (int)st[624];
+    for (int i = t; i < 624; i += 256) {
+        key[i] = st[i];
+        outw[i] = mt_temper(st[i]);
+    }
+    if (t == 0) {
+        s_pos = (int)st[624];
+        s_phase = 0;
+        s_rep = 0;
+        s_i = 0;
+        s_regen = 0;
+    }
     __syncthreads();
-    for (int r = 0; r < repeat; r++) {
-        if (t == 0) sm::mt_shuffle_arange(s, n, s_perm);
-        __syncthreads();
-        for (int i = t; i < n; i += 256) perm_all[(size_t)r * cap + i] = s_perm[i];
+    for (;;) {
+        if (s_rep >= repeat) break;
+        if (s_regen) {
+            // key[i] <- key[i+397 mod 624] ^ twist(key[i], key[i+1]); phases [0,227) [227,454) [454,623) then 623
+            uint32_t v = 0;
+            if (t < 227) v = mt_mix(key[t], key[t + 1], key[t + 397]);
+            __syncthreads();
+            if (t < 227) key[t] = v;
+            __syncthreads();
+            if (t < 227) v = mt_mix(key[227 + t], key[228 + t], key[t]);
+            __syncthreads();
+            if (t < 227) key[227 + t] = v;
+            __syncthreads();
+            if (t < 169) v = mt_mix(key[454 + t], key[455 + t], key[227 + t]);
+            __syncthreads();
+            if (t < 169) key[454 + t] = v;
+            __syncthreads();
+            if (t == 0) {
+                key[623] = mt_mix(key[623], key[0], key[396]);
+                s_pos = 0;
+                s_regen = 0;
+            }
+            __syncthreads();
+            for (int i = t; i < 624; i += 256) outw[i] = mt_temper(key[i]);
+            __syncthreads();
+        }
+        const int phase = s_phase;
+        if (phase == 0) {
+            for (int i = t; i < n; i += 256) s_perm[i] = i;
+            if (t == 0) {
+                s_i = n - 1;
+                s_phase = 1;
+            }
+        } else if (phase == 1) {
+            if (t == 0) {
+                int i = s_i, pos = s_pos;
+                while (i >= 1) {
+                    uint32_t mask = (uint32_t)i;
+                    mask |= mask >> 1;
+                    mask |= mask >> 2;
+                    mask |= mask >> 4;
+                    mask |= mask >> 8;
+                    mask |= mask >> 16;
+                    if (pos == 624) break;
+                    const uint32_t v = outw[pos++] & mask;
+                    if (v > (uint32_t)i) continue;
+                    const int j = (int)v;
+                    const int tmp = s_perm[j];
+                    s_perm[j] = s_perm[i];
+                    s_perm[i] = tmp;
+                    i--;
+                }
+                s_i = i;
+                s_pos = pos;
+                if (i < 1)
+                    s_phase = 2;
+                else
+                    s_regen = 1;  // ran out of tempered words
+            }
+        } else {
+            for (int i = t; i < n; i += 256) perm_all[(size_t)s_rep * cap + i] = s_perm[i];
+            __syncthreads();
+            if (t == 0) {
+                s_rep = s_rep + 1;
+                s_phase = 0;
+            }
+        }
         __syncthreads();
     }
-    for (int i = t; i < 624; i += 256) st[i] = s.key[i];
-    if (t == 0) st[624] = (uint32_t)s.pos;
+    __syncthreads();
+    for (int i = t; i < 624; i += 256) st[i] = key[i];
+    if (t == 0) st[624] = (uint32_t)s_pos;
 }
 
 __global__ void k_permute_points(const int* __restrict__ n_ptr, const int* __restrict__ perm,
@@ -597,6 +685,7 @@ int TrackerBuffers::init() {
         DFVO_HIP_CHECK(hipEventCreateWithFlags(&ev_rep[r], hipEventDisableTiming));
     }
     DFVO_HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    DFVO_HIP_CHECK(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
     return DFVO_OK;
 }
 
@@ -612,7 +701,8 @@ void TrackerBuffers::release() {
         ev_rep[r] = nullptr;
     }
     if (ev_fork) (void)hipEventDestroy(ev_fork);
-    ev_fork = nullptr;
+    if (ev_start) (void)hipEventDestroy(ev_start);
+    ev_fork = ev_start = nullptr;
     void* ptrs[] = {mt_state, kp_info, kp_total, pose, small, scale_out, winner, lidx};
     lidx = nullptr;
     lidx_cap = 0;
@@ -661,12 +751,16 @@ int enqueue_compute_pose_2d2d(TrackerBuffers& tb, int n_host, const PoseConfig& 
                                                (int)perm_lds));
             configured = perm_lds;
         }
-        hipLaunchKernelGGL(k_mt_shuffle_all, dim3(1), dim3(256), perm_lds, s, tb.mt_state, tb.kp_info, cfg.repeat, cap + 8,
-                           tb.perm);
+        // the shuffle chain runs on s_rep[0] so that the homography (on s) starts at once
+        DFVO_HIP_CHECK(hipEventRecord(tb.ev_start, s));
+        DFVO_HIP_CHECK(hipStreamWaitEvent(tb.s_rep[0], tb.ev_start, 0));
+        hipLaunchKernelGGL(k_mt_shuffle_all, dim3(1), dim3(256), perm_lds, tb.s_rep[0], tb.mt_state, tb.kp_info,
+                           cfg.repeat, cap + 8, tb.perm);
         for (int rep = 0; rep < cfg.repeat; ++rep)
-            hipLaunchKernelGGL(k_permute_points, dim3(nb), dim3(256), 0, s, tb.kp_info, tb.perm + (size_t)rep * (cap + 8),
-                               tb.kp_cur, tb.kp_ref, tb.pa + (size_t)rep * 2 * cap, tb.pb + (size_t)rep * 2 * cap);
-        DFVO_HIP_CHECK(hipEventRecord(tb.ev_fork, s));
+            hipLaunchKernelGGL(k_permute_points, dim3(nb), dim3(256), 0, tb.s_rep[0], tb.kp_info,
+                               tb.perm + (size_t)rep * (cap + 8), tb.kp_cur, tb.kp_ref, tb.pa + (size_t)rep * 2 * cap,
+                               tb.pb + (size_t)rep * 2 * cap);
+        DFVO_HIP_CHECK(hipEventRecord(tb.ev_fork, tb.s_rep[0]));
         int rc;
         for (int rep = 0; rep < cfg.repeat; ++rep) {
             hipStream_t sr = tb.s_rep[rep];

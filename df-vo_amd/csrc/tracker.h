@@ -54,7 +54,7 @@ struct TrackerBuffers {
     RansacWorkspace ws_rep[MAX_REP];     // one workspace per repeated findEssentialMat (run concurrently)
     hipStream_t s_rep[MAX_REP] = {};
     hipEvent_t ev_rep[MAX_REP] = {};
-    hipEvent_t ev_fork = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_start = nullptr;
     uint32_t* mt_state = nullptr;  // numpy RandomState: key[624], pos
     int* kp_info = nullptr;        // [n, good_kp_found, regions]
     int* kp_total = nullptr;

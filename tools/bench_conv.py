@@ -1,0 +1,51 @@
+"""Micro-benchmark of one convolution shape through dfvo_conv2d's kernel (weights packed once).
+env: N H W C0 C1 COUT K STRIDE ITERS.  Prints TFLOP/s from HIP-event timing via torch."""
+import ctypes as C
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+capi = importlib.import_module("df-vo_amd.capi")
+
+
+def main():
+    e = lambda k, d: int(os.environ.get(k, d))
+    N, H, W, C0, C1, COUT, K, S, IT = e("N", 2), e("H", 192), e("W", 624), e("C0", 128), e("C1", 0), e("COUT", 128), e("K", 3), e("STRIDE", 1), e("ITERS", 20)
+    lib = capi.lib()
+    capi.require_gpu()
+    cs0 = (C0 + 3) // 4 * 4
+    cs1 = (C1 + 3) // 4 * 4 if C1 else 0
+    x0 = torch.randn(N, H, W, cs0, device="cuda")
+    x1 = torch.randn(N, H, W, cs1, device="cuda") if C1 else None
+    pad = (K - 1) // 2
+    Ho = (H + 2 * pad - K) // S + 1
+    Wo = (W + 2 * pad - K) // S + 1
+    dcs = (COUT + 3) // 4 * 4
+    dst = torch.zeros(N, Ho, Wo, dcs, device="cuda")
+    w = np.random.randn(COUT, C0 + C1, K, K).astype(np.float32)
+    b = np.zeros(COUT, np.float32)
+    desc = capi.ConvDesc(N=N, H=H, W=W, kh=K, kw=K, stride=S, pad_h=pad, pad_w=pad, pad_mode=0, c0=C0, cs0=cs0, co0=0, up0=0,
+                         c1=C1, cs1=cs1, co1=0, cout=COUT, act=1, act_param=0.1, res_cs=0, res_co=0, dst_cs=dcs, dst_co=0)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    for _ in range(2):
+        capi.check(lib.dfvo_conv2d(C.byref(desc), p(x0), p(x1), capi.as_ptr(w), capi.as_ptr(b), None, p(dst), None))
+    ms = np.zeros(8)
+    fl = np.zeros(8)
+    ln = np.zeros(8, np.int32)
+    capi.check(lib.dfvo_conv_profile_begin())
+    for _ in range(IT):
+        capi.check(lib.dfvo_conv2d(C.byref(desc), p(x0), p(x1), capi.as_ptr(w), capi.as_ptr(b), None, p(dst), None))
+    capi.check(lib.dfvo_conv_profile_end(capi.as_ptr(ms), capi.as_ptr(fl), capi.as_ptr(ln)))
+    flops = 2.0 * N * Ho * Wo * COUT * (C0 + C1) * K * K
+    i = int(np.argmax(ms))
+    print("conv N%d %dx%d c%d+%d->%d k%d s%d: cfg %d, %.1f us/launch, %.1f TFLOP/s" % (
+        N, H, W, C0, C1, COUT, K, S, i, ms[i] * 1e3 / ln[i], flops * ln[i] / (ms[i] * 1e-3) / 1e12))
+
+
+if __name__ == "__main__":
+    main()
