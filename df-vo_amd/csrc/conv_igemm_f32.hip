@@ -21,6 +21,8 @@
 #include "dfvo_common.h"
 
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 namespace dfvo {
@@ -340,6 +342,7 @@ struct ConvProfEntry {
     hipEvent_t e0, e1;
     int cfg;
     double flops;
+    int shape[12];  // N H W Ho Wo cin cout k stride gx gy gz
 };
 static std::vector<ConvProfEntry>* g_prof = nullptr;
 
@@ -355,16 +358,25 @@ int conv_profile_end(double* ms, double* flops, int* launches) {
         launches[i] = 0;
     }
     if (!g_prof) return DFVO_OK;
+    // DFVO_CONV_PROFILE_CSV=<path>: one line per launch (tuning aid)
+    const char* csv_path = getenv("DFVO_CONV_PROFILE_CSV");
+    FILE* csv = csv_path ? fopen(csv_path, "a") : nullptr;
+    if (csv) fprintf(csv, "cfg,N,H,W,Ho,Wo,cin,cout,k,stride,gx,gy,gz,us,tflops\n");
     for (auto& e : *g_prof) {
         float t = 0.f;
         DFVO_HIP_CHECK(hipEventSynchronize(e.e1));
         DFVO_HIP_CHECK(hipEventElapsedTime(&t, e.e0, e.e1));
         ms[e.cfg] += t;
+        if (csv)
+            fprintf(csv, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%.4f,%.4f\n", e.cfg, e.shape[0], e.shape[1], e.shape[2],
+                    e.shape[3], e.shape[4], e.shape[5], e.shape[6], e.shape[7], e.shape[8], e.shape[9], e.shape[10],
+                    e.shape[11], t * 1e3, e.flops / (t * 1e-3) / 1e12);
         flops[e.cfg] += e.flops;
         launches[e.cfg] += 1;
         (void)hipEventDestroy(e.e0);
         (void)hipEventDestroy(e.e1);
     }
+    if (csv) fclose(csv);
     delete g_prof;
     g_prof = nullptr;
     return DFVO_OK;
@@ -411,6 +423,8 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) {
     if (g_prof) {
         DFVO_HIP_CHECK(hipEventRecord(pe.e1, stream));
         pe.flops = p.useful_flops;
+        const int sh[12] = {p.N, p.H, p.W, p.Ho, p.Wo, (p.G0 + p.G1) * 4, p.cout, p.kh, p.stride, (int)grid.x, (int)grid.y, (int)grid.z};
+        for (int i = 0; i < 12; ++i) pe.shape[i] = sh[i];
         g_prof->push_back(pe);
     }
     return DFVO_OK;

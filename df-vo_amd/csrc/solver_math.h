@@ -72,7 +72,7 @@ SM_HD void mul33(const double* a, const double* b, double* d) {
 // W: n values (scratch + output), Vt: n x n or nullptr, n1: rows of At normalised on output; rows
 // n..n1-1 are completed with OpenCV's deterministic pseudo-random orthogonal basis.
 // ------------------------------------------------------------------------------------------------
-SM_HD_NOINLINE void jacobi_svd(double* At, int astep, double* W, double* Vt, int vstep, int m, int n, int n1) {
+SM_HD void jacobi_svd_impl(double* At, int astep, double* W, double* Vt, int vstep, int m, int n, int n1) {
     const double minval = DBL_MIN, eps = DBL_EPSILON * 10;
     int i, j, k, iter;
     const int max_iter = m > 30 ? m : 30;
@@ -193,6 +193,10 @@ SM_HD_NOINLINE void jacobi_svd(double* At, int astep, double* W, double* Vt, int
     }
 }
 
+SM_HD_NOINLINE void jacobi_svd(double* At, int astep, double* W, double* Vt, int vstep, int m, int n, int n1) {
+    jacobi_svd_impl(At, astep, W, Vt, vstep, m, n, n1);
+}
+
 // SVD of a square N x N matrix the way cv::SVD::compute(src, w, u, vt) does it (flags = 0):
 // rows of `at` = columns of src on input; on output u = at^T (columns), vt as is.
 template <int N>
@@ -209,12 +213,14 @@ SM_HD void svd_square(const double* src, double* w, double* u, double* vt) {
 // ------------------------------------------------------------------------------------------------
 // Jacobi eigen decomposition of a symmetric n x n matrix (rows of V = eigenvectors, descending)
 // ------------------------------------------------------------------------------------------------
+// `ind` = 2N ints of scratch (the row/column pivot tables); callers on the GPU hand in LDS so that the
+// data-dependent indexing does not go through scratch memory.
 template <int N>
-SM_HD_NOINLINE void jacobi_eigen(double* A, double* W, double* V) {
+SM_HD void jacobi_eigen_ws(double* A, double* W, double* V, int* ind) {
     const double eps = DBL_EPSILON;
     const int n = N, astep = N, vstep = N;
     int i, j, k, m;
-    int indR[N], indC[N];
+    int *indR = ind, *indC = ind + N;
     for (i = 0; i < n; i++) {
         for (j = 0; j < n; j++) V[i * vstep + j] = 0;
         V[i * vstep + i] = 1;
@@ -303,12 +309,19 @@ SM_HD_NOINLINE void jacobi_eigen(double* A, double* W, double* V) {
     }
 }
 
-// solve(A, b, x, DECOMP_EIG) / invert(A, DECOMP_EIG) for symmetric A (SVBkSb back-substitution)
 template <int N>
-SM_HD void solve_eig(const double* A, const double* b, double* x) {
-    double a[N * N], v[N * N], w[N];
+SM_HD_NOINLINE void jacobi_eigen(double* A, double* W, double* V) {
+    int ind[2 * N];
+    jacobi_eigen_ws<N>(A, W, V, ind);
+}
+
+// solve(A, b, x, DECOMP_EIG) / invert(A, DECOMP_EIG) for symmetric A (SVBkSb back-substitution)
+// ws: 2*N*N + 2*N doubles
+template <int N>
+SM_HD void solve_eig_ws(const double* A, const double* b, double* x, double* ws) {
+    double *a = ws, *v = ws + N * N, *w = ws + 2 * N * N;
     for (int i = 0; i < N * N; i++) a[i] = A[i];
-    jacobi_eigen<N>(a, w, v);
+    jacobi_eigen_ws<N>(a, w, v, reinterpret_cast<int*>(ws + 2 * N * N + N));
     const double eps = DBL_EPSILON * 2;
     double threshold = 0;
     for (int i = 0; i < N; i++) x[i] = 0;
@@ -326,10 +339,15 @@ SM_HD void solve_eig(const double* A, const double* b, double* x) {
     }
 }
 template <int N>
-SM_HD void invert_eig(const double* A, double* dst) {
-    double a[N * N], v[N * N], w[N];
+SM_HD void solve_eig(const double* A, const double* b, double* x) {
+    double ws[2 * N * N + 2 * N];
+    solve_eig_ws<N>(A, b, x, ws);
+}
+template <int N>
+SM_HD void invert_eig_ws(const double* A, double* dst, double* ws) {
+    double *a = ws, *v = ws + N * N, *w = ws + 2 * N * N;
     for (int i = 0; i < N * N; i++) a[i] = A[i];
-    jacobi_eigen<N>(a, w, v);
+    jacobi_eigen_ws<N>(a, w, v, reinterpret_cast<int*>(ws + 2 * N * N + N));
     const double eps = DBL_EPSILON * 2;
     double threshold = 0;
     for (int i = 0; i < N * N; i++) dst[i] = 0;
@@ -348,10 +366,16 @@ SM_HD void invert_eig(const double* A, double* dst) {
     }
 }
 
+template <int N>
+SM_HD void invert_eig(const double* A, double* dst) {
+    double ws[2 * N * N + 2 * N];
+    invert_eig_ws<N>(A, dst, ws);
+}
+
 // ------------------------------------------------------------------------------------------------
 // LU with partial pivoting, in place; b is m x n right-hand sides.  Returns 0 when singular.
 // ------------------------------------------------------------------------------------------------
-SM_HD_NOINLINE int lu_solve(double* A, int astep, int m, double* b, int bstep, int n) {
+SM_HD int lu_solve_impl(double* A, int astep, int m, double* b, int bstep, int n) {
     const double eps = DBL_EPSILON * 100;
     int i, j, k, p = 1;
     for (i = 0; i < m; i++) {
@@ -386,6 +410,9 @@ SM_HD_NOINLINE int lu_solve(double* A, int astep, int m, double* b, int bstep, i
             b[i * bstep + j] = s / A[i * astep + i];
         }
     return p;
+}
+SM_HD_NOINLINE int lu_solve(double* A, int astep, int m, double* b, int bstep, int n) {
+    return lu_solve_impl(A, astep, m, b, bstep, n);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -528,8 +555,13 @@ SM_HD void quad_mul_acc(const double* q, const double* l, bool plus, double* out
 
 // stage 1: 5 correspondences -> null-space basis EE[4][9] and the 3 x 13 polynomial matrix b, plus
 // the degree-10 coefficients c[11].  Returns false if the 10x10 block is singular.
-SM_HD_NOINLINE bool five_point_stage1(const double* q1, const double* q2, double* EE, double* b, double* c) {
-    double Vt[81], W[5];
+// ws layout (FIVE_POINT_WS doubles; on the GPU a per-lane LDS slice, see k_e_stage1):
+//   [0,200)   A (10 x 20)
+//   [200,400) phase 1: Vt[81] W[5] V5[25]; phase 2: L[36] m0 m1 m2 t[40] EEt[90] tr[10]; phase 3: A1[100] inv[100]
+//   [400,460) Ar (6 x 10)
+constexpr int FIVE_POINT_WS = 460;
+SM_HD bool five_point_stage1_ws(const double* q1, const double* q2, double* EE, double* b, double* c, double* ws) {
+    double *Vt = ws + 200, *W = ws + 281;
     for (int i = 0; i < 81; i++) Vt[i] = 0;
     for (int i = 0; i < 5; i++) {
         const double x1 = q1[i * 2], y1 = q1[i * 2 + 1], x2 = q2[i * 2], y2 = q2[i * 2 + 1];
@@ -544,19 +576,16 @@ SM_HD_NOINLINE bool five_point_stage1(const double* q1, const double* q2, double
         r[7] = y1;
         r[8] = 1.0;
     }
-    {
-        double V5[25];
-        jacobi_svd(Vt, 9, W, V5, 5, 9, 5, 9);  // SVD::compute(Q, FULL_UV): m < n -> works on Q's rows
-    }
+    jacobi_svd_impl(Vt, 9, W, ws + 286, 5, 9, 5, 9);  // SVD::compute(Q, FULL_UV): m < n -> works on Q's rows
     for (int i = 0; i < 36; i++) EE[i] = Vt[45 + i];
     // ---- coefficient matrix A (10 x 20)
-    double A[200];
+    double* A = ws;
     for (int i = 0; i < 200; i++) A[i] = 0;
-    double L[9][4];
+    double(*L)[4] = reinterpret_cast<double(*)[4]>(ws + 200);
     for (int e = 0; e < 9; e++)
         for (int v = 0; v < 4; v++) L[e][v] = EE[v * 9 + e];
     {
-        double m0[10], m1[10], m2[10], t[10];
+        double *m0 = ws + 236, *m1 = ws + 246, *m2 = ws + 256, *t = ws + 266;
         for (int k = 0; k < 10; k++) m0[k] = m1[k] = m2[k] = t[k] = 0;
         lin_mul_acc(L[4], L[8], m0);
         lin_mul_acc(L[5], L[7], t);
@@ -572,7 +601,8 @@ SM_HD_NOINLINE bool five_point_stage1(const double* q1, const double* q2, double
         quad_mul_acc(m2, L[2], true, A);
     }
     {
-        double EEt[9][10], tr[10];
+        double(*EEt)[10] = reinterpret_cast<double(*)[10]>(ws + 276);
+        double* tr = ws + 366;
         for (int i = 0; i < 9; i++)
             for (int k = 0; k < 10; k++) EEt[i][k] = 0;
         for (int i = 0; i < 3; i++)
@@ -588,14 +618,14 @@ SM_HD_NOINLINE bool five_point_stage1(const double* q1, const double* q2, double
             }
     }
     // ---- A(:,0:10)^-1 via LU on the identity, then times A(:,10:20)
-    double A1[100], inv[100];
+    double *A1 = ws + 200, *inv = ws + 300;
     for (int i = 0; i < 10; i++)
         for (int j = 0; j < 10; j++) {
             A1[i * 10 + j] = A[i * 20 + j];
             inv[i * 10 + j] = i == j ? 1.0 : 0.0;
         }
-    if (!lu_solve(A1, 10, 10, inv, 10, 10)) return false;
-    double Ar[60];  // rows 4..9 only
+    if (!lu_solve_impl(A1, 10, 10, inv, 10, 10)) return false;
+    double* Ar = ws + 400;  // rows 4..9 only
     for (int i = 4; i < 10; i++)
         for (int j = 0; j < 10; j++) {
             double s = 0;
@@ -653,6 +683,11 @@ SM_HD_NOINLINE bool five_point_stage1(const double* q1, const double* q2, double
     pmul(p[2], 5, mm, 7, pr);
     for (int k = 0; k < 11; k++) c[k] = c[k] + pr[k];
     return true;
+}
+
+SM_HD_NOINLINE bool five_point_stage1(const double* q1, const double* q2, double* EE, double* b, double* c) {
+    double ws[FIVE_POINT_WS];
+    return five_point_stage1_ws(q1, q2, EE, b, c, ws);
 }
 
 // stage 3: real roots -> essential matrices (up to 10 x 9 doubles); returns their number
@@ -758,11 +793,13 @@ SM_HD void homography_accumulate(const HNorm& h, float Mx_, float My_, float mx_
         for (int k = j; k < 9; k++) LtL[j * 9 + k] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
 }
 // finish: symmetric completion, eigen decomposition, de-normalisation, scale so that H[8] = 1
-SM_HD_NOINLINE void homography_finish(const HNorm& h, double* LtL, double* model) {
-    double W[9], V[81];
+constexpr int HOMOGRAPHY_FINISH_WS = 9 + 81 + 9;  // doubles: W, V, pivot tables
+constexpr int HOMOGRAPHY_KERNEL_WS = 81 + HOMOGRAPHY_FINISH_WS;
+SM_HD void homography_finish_ws(const HNorm& h, double* LtL, double* model, double* ws) {
+    double *W = ws, *V = ws + 9;
     for (int j = 0; j < 9; j++)
         for (int k = 0; k < j; k++) LtL[j * 9 + k] = LtL[k * 9 + j];
-    jacobi_eigen<9>(LtL, W, V);
+    jacobi_eigen_ws<9>(LtL, W, V, reinterpret_cast<int*>(ws + 90));
     const double invHnorm[9] = {1. / h.smx, 0, h.cmx, 0, 1. / h.smy, h.cmy, 0, 0, 1};
     const double Hnorm2[9] = {h.sMx, 0, -h.cMx * h.sMx, 0, h.sMy, -h.cMy * h.sMy, 0, 0, 1};
     double Htemp[9], H0[9];
@@ -771,8 +808,12 @@ SM_HD_NOINLINE void homography_finish(const HNorm& h, double* LtL, double* model
     const double s = 1. / H0[8];
     for (int k = 0; k < 9; k++) model[k] = H0[k] * s;
 }
+SM_HD_NOINLINE void homography_finish(const HNorm& h, double* LtL, double* model) {
+    double ws[HOMOGRAPHY_FINISH_WS];
+    homography_finish_ws(h, LtL, model, ws);
+}
 // whole kernel for a small set (the 4-point minimal sample); M = source points, m = destination
-SM_HD_NOINLINE bool homography_kernel(const float* M, const float* m, int count, double* model) {
+SM_HD bool homography_kernel_ws(const float* M, const float* m, int count, double* model, double* ws) {
     HNorm h;
     h.cMx = h.cMy = h.cmx = h.cmy = h.sMx = h.sMy = h.smx = h.smy = 0;
     for (int i = 0; i < count; i++) {
@@ -797,11 +838,15 @@ SM_HD_NOINLINE bool homography_kernel(const float* M, const float* m, int count,
     h.smy = count / h.smy;
     h.sMx = count / h.sMx;
     h.sMy = count / h.sMy;
-    double LtL[81];
+    double* LtL = ws;
     for (int i = 0; i < 81; i++) LtL[i] = 0;
     for (int i = 0; i < count; i++) homography_accumulate(h, M[i * 2], M[i * 2 + 1], m[i * 2], m[i * 2 + 1], LtL);
-    homography_finish(h, LtL, model);
+    homography_finish_ws(h, LtL, model, ws + 81);
     return true;
+}
+SM_HD_NOINLINE bool homography_kernel(const float* M, const float* m, int count, double* model) {
+    double ws[HOMOGRAPHY_KERNEL_WS];
+    return homography_kernel_ws(M, m, count, model, ws);
 }
 // squared reprojection error in float (HomographyEstimatorCallback::computeError)
 SM_HD float homography_error(const float* Hf, float Mx, float My, float mx, float my) {

@@ -198,29 +198,95 @@ __device__ __forceinline__ uint32_t mt_mix(uint32_t a, uint32_t b, uint32_t c) {
     return c ^ (y >> 1) ^ ((uint32_t)(-(int32_t)(y & 1)) & 0x9908b0dfu);
 }
 
+__device__ __forceinline__ uint32_t mt_mask_of(uint32_t v) {
+    v |= v >> 1;
+    v |= v >> 2;
+    v |= v >> 4;
+    v |= v >> 8;
+    v |= v >> 16;
+    return v;
+}
+
+// Two phases per group of `group` repeats (as many as fit the LDS):
+//  A  the masked-rejection draws  j_i = random_interval(i), i = n-1 .. 1  of every repeat, in stream order.
+//     One sequential chain, run on wave 0 with every loop-carried value wave-uniform (v_readlane of a
+//     64-word batch + scalar compare/branch), the MT19937 block regeneration + tempering on all threads.
+//  B  the swap chains  p[i] <-> p[j_i]  of the repeats, one lane per repeat in lockstep out of LDS
+//     (the repeats are independent once their j lists are known).
 __global__ __launch_bounds__(256) void k_mt_shuffle_all(uint32_t* __restrict__ st, const int* __restrict__ n_ptr,
-                                                         int repeat, int cap, int* __restrict__ perm_all) {
+                                                         int repeat, int group, int cap, int* __restrict__ perm_all) {
     __shared__ uint32_t key[624], outw[624];
-    __shared__ int s_pos, s_phase, s_rep, s_i, s_regen;
-    extern __shared__ int s_perm[];
+    __shared__ int s_pos, s_rep, s_i;
+    extern __shared__ int s_dyn[];
     const int t = threadIdx.x;
+    const int lane = t & 63;
     const int n = *n_ptr;
+    if (n <= 1) {  // nothing is drawn
+        if (t == 0 && n == 1)
+            for (int r = 0; r < repeat; ++r) perm_all[(size_t)r * cap] = 0;
+        return;
+    }
+    int* p = s_dyn;                                                      // [group][n]
+    unsigned short* jl = reinterpret_cast<unsigned short*>(s_dyn + (size_t)group * n);  // [group][n]
     for (int i = t; i < 624; i += 256) {
         key[i] = st[i];
         outw[i] = mt_temper(st[i]);
     }
     if (t == 0) {
         s_pos = (int)st[624];
-        s_phase = 0;
         s_rep = 0;
-        s_i = 0;
-        s_regen = 0;
+        s_i = n - 1;
     }
     __syncthreads();
-    for (;;) {
-        if (s_rep >= repeat) break;
-        if (s_regen) {
-            // key[i] <- key[i+397 mod 624] ^ twist(key[i], key[i+1]); phases [0,227) [227,454) [454,623) then 623
+    for (int g0 = 0; g0 < repeat; g0 += group) {
+        const int g_end = g0 + group < repeat ? g0 + group : repeat;
+        for (int i = t; i < (g_end - g0) * n; i += 256) p[i] = i % n;
+        // ---- phase A
+        for (;;) {
+            if (t < 64) {
+                int pos = __builtin_amdgcn_readfirstlane(s_pos);
+                int rep = __builtin_amdgcn_readfirstlane(s_rep);
+                int i = __builtin_amdgcn_readfirstlane(s_i);
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                while (pos < 624 && rep < g_end) {
+                    // a batch of up to 64 tempered words under one mask regime: word k is accepted iff
+                    // (w_k & mask) <= i - c_k, c_k = accepts before k.  Solved as a fixed point of wave ballots:
+                    // starting from the optimistic set the iterates alternate between super- and subsets of the
+                    // answer and agree with it on a strictly growing prefix.
+                    const int cnt = 624 - pos < 64 ? 624 - pos : 64;
+                    const uint32_t mask = mt_mask_of((uint32_t)i);
+                    const int lim = i - (int)(mask >> 1);  // accepts left before the mask shrinks (or the repeat ends)
+                    const bool have = lane < cnt;
+                    const uint32_t m = have ? (outw[pos + lane] & mask) : 0xffffffffu;
+                    unsigned long long acc = __ballot(have && m <= (uint32_t)i);
+                    for (;;) {
+                        const int c = __popcll(acc & lt);
+                        const unsigned long long nxt = __ballot(have && c < lim && m <= (uint32_t)(i - c));
+                        if (nxt == acc) break;
+                        acc = nxt;
+                    }
+                    const int c = __popcll(acc & lt);
+                    if ((acc >> lane) & 1ull) jl[(rep - g0) * n + (i - c)] = (unsigned short)m;
+                    const int total = __popcll(acc);
+                    // the batch ends at the word that exhausted the regime, otherwise all words were consumed
+                    const int used = total == lim ? 64 - __builtin_clzll(acc) : cnt;
+                    pos += used;
+                    i -= total;
+                    if (i == 0) {
+                        ++rep;
+                        i = n - 1;
+                    }
+                }
+                if (lane == 0) {
+                    s_pos = pos;
+                    s_rep = rep;
+                    s_i = i;
+                }
+            }
+            __syncthreads();
+            if (s_rep >= g_end) break;
+            // block regeneration: key[i] <- key[i+397 mod 624] ^ twist(key[i], key[i+1]) in three dependency-free
+            // ranges [0,227) [227,454) [454,623), then word 623
             uint32_t v = 0;
             if (t < 227) v = mt_mix(key[t], key[t + 1], key[t + 397]);
             __syncthreads();
@@ -237,56 +303,39 @@ __global__ __launch_bounds__(256) void k_mt_shuffle_all(uint32_t* __restrict__ s
             if (t == 0) {
                 key[623] = mt_mix(key[623], key[0], key[396]);
                 s_pos = 0;
-                s_regen = 0;
             }
             __syncthreads();
             for (int i = t; i < 624; i += 256) outw[i] = mt_temper(key[i]);
             __syncthreads();
         }
-        const int phase = s_phase;
-        if (phase == 0) {
-            for (int i = t; i < n; i += 256) s_perm[i] = i;
-            if (t == 0) {
-                s_i = n - 1;
-                s_phase = 1;
-            }
-        } else if (phase == 1) {
-            if (t == 0) {
-                int i = s_i, pos = s_pos;
-                while (i >= 1) {
-                    uint32_t mask = (uint32_t)i;
-                    mask |= mask >> 1;
-                    mask |= mask >> 2;
-                    mask |= mask >> 4;
-                    mask |= mask >> 8;
-                    mask |= mask >> 16;
-                    if (pos == 624) break;
-                    const uint32_t v = outw[pos++] & mask;
-                    if (v > (uint32_t)i) continue;
-                    const int j = (int)v;
-                    const int tmp = s_perm[j];
-                    s_perm[j] = s_perm[i];
-                    s_perm[i] = tmp;
-                    i--;
+        // ---- phase B
+        if (t < g_end - g0) {
+            int* pr = p + (size_t)t * n;
+            const unsigned short* jr = jl + (size_t)t * n;
+            int i = n - 1;
+            for (; i >= 8; i -= 8) {
+                int jj[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) jj[u] = jr[i - u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int a = pr[jj[u]], b = pr[i - u];
+                    pr[jj[u]] = b;
+                    pr[i - u] = a;
                 }
-                s_i = i;
-                s_pos = pos;
-                if (i < 1)
-                    s_phase = 2;
-                else
-                    s_regen = 1;  // ran out of tempered words
             }
-        } else {
-            for (int i = t; i < n; i += 256) perm_all[(size_t)s_rep * cap + i] = s_perm[i];
-            __syncthreads();
-            if (t == 0) {
-                s_rep = s_rep + 1;
-                s_phase = 0;
+            for (; i >= 1; --i) {
+                const int j = jr[i];
+                const int a = pr[j], b = pr[i];
+                pr[j] = b;
+                pr[i] = a;
             }
         }
         __syncthreads();
+        for (int r = g0; r < g_end; ++r)
+            for (int i = t; i < n; i += 256) perm_all[(size_t)r * cap + i] = p[(size_t)(r - g0) * n + i];
+        __syncthreads();
     }
-    __syncthreads();
     for (int i = t; i < 624; i += 256) st[i] = key[i];
     if (t == 0) st[624] = (uint32_t)s_pos;
 }
@@ -743,8 +792,11 @@ int enqueue_compute_pose_2d2d(TrackerBuffers& tb, int n_host, const PoseConfig& 
         const int cap = tb.kp_cap;
         // all shuffles first (one sequential RNG chain), then the `repeat` RANSACs run concurrently on
         // their own streams while the homography runs on `s`
-        const size_t perm_lds = sizeof(int) * (size_t)(n_host > 0 ? n_host : 1);
-        DFVO_ARG_CHECK(perm_lds <= 96 * 1024, "compute_pose_2d2d: too many keypoints for the LDS permutation buffer");
+        const size_t per_rep = 6 * (size_t)n_host;  // int permutation + uint16 draw list
+        DFVO_ARG_CHECK(per_rep <= 144 * 1024, "compute_pose_2d2d: too many keypoints for the LDS permutation buffer");
+        int group = (int)((144 * 1024) / per_rep);
+        if (group > cfg.repeat) group = cfg.repeat;
+        const size_t perm_lds = per_rep * group + 16;
         static size_t configured = 0;
         if (perm_lds > configured) {
             DFVO_HIP_CHECK(hipFuncSetAttribute((const void*)k_mt_shuffle_all, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -755,7 +807,7 @@ int enqueue_compute_pose_2d2d(TrackerBuffers& tb, int n_host, const PoseConfig& 
         DFVO_HIP_CHECK(hipEventRecord(tb.ev_start, s));
         DFVO_HIP_CHECK(hipStreamWaitEvent(tb.s_rep[0], tb.ev_start, 0));
         hipLaunchKernelGGL(k_mt_shuffle_all, dim3(1), dim3(256), perm_lds, tb.s_rep[0], tb.mt_state, tb.kp_info,
-                           cfg.repeat, cap + 8, tb.perm);
+                           cfg.repeat, group, cap + 8, tb.perm);
         for (int rep = 0; rep < cfg.repeat; ++rep)
             hipLaunchKernelGGL(k_permute_points, dim3(nb), dim3(256), 0, tb.s_rep[0], tb.kp_info,
                                tb.perm + (size_t)rep * (cap + 8), tb.kp_cur, tb.kp_ref, tb.pa + (size_t)rep * 2 * cap,

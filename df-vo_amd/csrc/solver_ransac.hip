@@ -123,10 +123,17 @@ __global__ void k_subsets_plain(RansacState* st, int* __restrict__ idx, int mode
     st->rng_state = rng.state;
 }
 
-__global__ __launch_bounds__(64) void k_e_stage1(const RansacState* st, const int* __restrict__ idx,
-                                                  const double* __restrict__ p1, const double* __restrict__ p2,
-                                                  int it0, int it1, double* __restrict__ ws, int* __restrict__ ok) {
-    const int it = it0 + blockIdx.x * 64 + threadIdx.x;
+// one hypothesis per lane, 16 lanes per block: the ~3.7 KB of dense work (9x9 SVD rows, the 10x20
+// constraint matrix, the 10x10 LU with its right-hand sides) of each lane sits in an LDS slice of odd
+// stride, so the pivoting / Jacobi subscripts never touch scratch memory
+constexpr int E_STAGE1_LANES = 16;
+constexpr int E_STAGE1_STRIDE = sm::FIVE_POINT_WS + 1;
+__global__ __launch_bounds__(E_STAGE1_LANES) void k_e_stage1(const RansacState* st, const int* __restrict__ idx,
+                                                              const double* __restrict__ p1,
+                                                              const double* __restrict__ p2, int it0, int it1,
+                                                              double* __restrict__ ws, int* __restrict__ ok) {
+    __shared__ double s_ws[E_STAGE1_LANES * E_STAGE1_STRIDE];
+    const int it = it0 + blockIdx.x * E_STAGE1_LANES + threadIdx.x;
     if (st->done || it >= it1) return;
     double q1[10], q2[10];
     for (int i = 0; i < 5; i++) {
@@ -137,7 +144,7 @@ __global__ __launch_bounds__(64) void k_e_stage1(const RansacState* st, const in
         q2[i * 2 + 1] = p2[k * 2 + 1];
     }
     double* w = ws + (size_t)it * E_WS;  // [EE 36 | b 39 | c 11 | roots 20]
-    ok[it] = sm::five_point_stage1(q1, q2, w, w + 36, w + 75) ? 1 : 0;
+    ok[it] = sm::five_point_stage1_ws(q1, q2, w, w + 36, w + 75, s_ws + threadIdx.x * E_STAGE1_STRIDE) ? 1 : 0;
 }
 
 __global__ __launch_bounds__(64) void k_e_poly(const RansacState* st, int it0, int it1, double* __restrict__ ws,
@@ -290,8 +297,8 @@ int enqueue_find_essential(RansacWorkspace& w, const double* d_pts1, const doubl
         if (it1 <= it0) continue;
         const int nh = it1 - it0;
         hipLaunchKernelGGL(k_subsets_plain, dim3(1), dim3(1), 0, s, w.state, w.idx, 5, n, it0, it1);
-        hipLaunchKernelGGL(k_e_stage1, dim3(cdiv(nh, 64)), dim3(64), 0, s, w.state, w.idx, w.norm_a, w.norm_b, it0, it1,
-                           w.ws, w.ok);
+        hipLaunchKernelGGL(k_e_stage1, dim3(cdiv(nh, E_STAGE1_LANES)), dim3(E_STAGE1_LANES), 0, s, w.state, w.idx, w.norm_a,
+                           w.norm_b, it0, it1, w.ws, w.ok);
         hipLaunchKernelGGL(k_e_poly, dim3(cdiv(nh, 64)), dim3(64), 0, s, w.state, it0, it1, w.ws, w.ok);
         hipLaunchKernelGGL(k_e_stage3, dim3(cdiv(nh, 64)), dim3(64), 0, s, w.state, it0, it1, w.ws, w.ok, w.models,
                            w.nmodels);
@@ -351,10 +358,17 @@ __global__ void k_h_subsets(RansacState* st, int* __restrict__ idx, const float*
     st->rng_state = rng.state;
 }
 
-__global__ __launch_bounds__(64) void k_h_solve(const RansacState* st, const int* __restrict__ idx,
-                                                 const float* __restrict__ src, const float* __restrict__ dst, int it0,
-                                                 int it1, double* __restrict__ models, int* __restrict__ nmodels) {
-    const int it = it0 + blockIdx.x * 64 + threadIdx.x;
+// one 4-point hypothesis per lane; the 9x9 LtL / eigenvector / pivot tables of a lane live in LDS (odd
+// per-lane stride: conflict-free when the lanes walk the same index) because the Jacobi sweeps index
+// them with data-dependent subscripts, which would otherwise go through scratch memory
+constexpr int H_SOLVE_LANES = 32;
+constexpr int H_SOLVE_STRIDE = sm::HOMOGRAPHY_KERNEL_WS + 1;  // 181 doubles
+__global__ __launch_bounds__(H_SOLVE_LANES) void k_h_solve(const RansacState* st, const int* __restrict__ idx,
+                                                            const float* __restrict__ src,
+                                                            const float* __restrict__ dst, int it0, int it1,
+                                                            double* __restrict__ models, int* __restrict__ nmodels) {
+    __shared__ double s_ws[H_SOLVE_LANES * H_SOLVE_STRIDE];
+    const int it = it0 + blockIdx.x * H_SOLVE_LANES + threadIdx.x;
     if (st->done || it >= it1) return;
     if (st->subset_fail_at >= 0 && it >= st->subset_fail_at) {
         nmodels[it] = 0;
@@ -368,7 +382,11 @@ __global__ __launch_bounds__(64) void k_h_solve(const RansacState* st, const int
         m[i * 2] = dst[k * 2];
         m[i * 2 + 1] = dst[k * 2 + 1];
     }
-    nmodels[it] = sm::homography_kernel(M, m, 4, models + (size_t)it * 9) ? 1 : 0;
+    double model[9];
+    const bool ok = sm::homography_kernel_ws(M, m, 4, model, s_ws + threadIdx.x * H_SOLVE_STRIDE);
+    if (ok)
+        for (int i = 0; i < 9; i++) models[(size_t)it * 9 + i] = model[i];
+    nmodels[it] = ok ? 1 : 0;
 }
 
 __global__ __launch_bounds__(256) void k_h_score(const RansacState* st, int it0, int it1,
@@ -439,17 +457,17 @@ __device__ __forceinline__ void h_chunk_points(HRefineShared& sh, const float* s
 
 // residuals (and Jacobian rows) of the chunk at parameters h into sh.buf: [t*18 + 0..7] row a, [8..15] row b,
 // [16],[17] residuals
-__device__ __forceinline__ void h_chunk_lm(HRefineShared& sh, const double* h, int cnt, bool with_j) {
+__device__ __forceinline__ void h_chunk_lm(HRefineShared& sh, const float* pts, const double* h, int cnt, bool with_j) {
     const int t = threadIdx.x;
     if (t >= cnt) return;
-    const double Mx = sh.pts[t * 4], My = sh.pts[t * 4 + 1];
+    const double Mx = pts[t * 4], My = pts[t * 4 + 1];
     double ww = h[6] * Mx + h[7] * My + 1.;
     ww = fabs(ww) > DBL_EPSILON ? 1. / ww : 0;
     const double xi = (h[0] * Mx + h[1] * My + h[2]) * ww;
     const double yi = (h[3] * Mx + h[4] * My + h[5]) * ww;
     double* o = sh.buf + t * 18;
-    o[16] = xi - sh.pts[t * 4 + 2];
-    o[17] = yi - sh.pts[t * 4 + 3];
+    o[16] = xi - pts[t * 4 + 2];
+    o[17] = yi - pts[t * 4 + 3];
     if (with_j) {
         o[0] = Mx * ww;
         o[1] = My * ww;
@@ -466,6 +484,79 @@ __device__ __forceinline__ void h_chunk_lm(HRefineShared& sh, const double* h, i
     }
 }
 
+// Sequential (reference-order) sums over the points of a chunk.  The products are independent, only the adds
+// form the chain; batches of 8 points are loaded and multiplied first so the LDS latency is paid once per batch.
+constexpr int H_UNROLL = 8;
+// a += o[i0]*o[i1]; a += o[i2]*o[i3]   per point
+__device__ __forceinline__ double seq_acc_two(const double* buf, int cnt, int i0, int i1, int i2, int i3, double a) {
+    int k = 0;
+    for (; k + H_UNROLL <= cnt; k += H_UNROLL) {
+        double p0[H_UNROLL], p1[H_UNROLL];
+#pragma unroll
+        for (int u = 0; u < H_UNROLL; ++u) {
+            const double* o = buf + (k + u) * 18;
+            p0[u] = o[i0] * o[i1];
+            p1[u] = o[i2] * o[i3];
+        }
+#pragma unroll
+        for (int u = 0; u < H_UNROLL; ++u) {
+            a += p0[u];
+            a += p1[u];
+        }
+    }
+    for (; k < cnt; k++) {
+        const double* o = buf + k * 18;
+        a += o[i0] * o[i1];
+        a += o[i2] * o[i3];
+    }
+    return a;
+}
+// a += o[i0]*o[i1] + o[i2]*o[i3]   per point
+__device__ __forceinline__ double seq_acc_pair(const double* buf, int cnt, int i0, int i1, int i2, int i3, double a) {
+    int k = 0;
+    for (; k + H_UNROLL <= cnt; k += H_UNROLL) {
+        double p[H_UNROLL];
+#pragma unroll
+        for (int u = 0; u < H_UNROLL; ++u) {
+            const double* o = buf + (k + u) * 18;
+            p[u] = o[i0] * o[i1] + o[i2] * o[i3];
+        }
+#pragma unroll
+        for (int u = 0; u < H_UNROLL; ++u) a += p[u];
+    }
+    for (; k < cnt; k++) {
+        const double* o = buf + k * 18;
+        a += o[i0] * o[i1] + o[i2] * o[i3];
+    }
+    return a;
+}
+// |r|^2 in groups of two points (four residual rows), the order the oracle's norm loop uses
+__device__ __forceinline__ double seq_acc_sq(const double* buf, int cnt, double a) {
+    int k = 0;
+    for (; k + H_UNROLL <= cnt; k += H_UNROLL) {
+        double p[H_UNROLL / 2];
+#pragma unroll
+        for (int u = 0; u < H_UNROLL / 2; ++u) {
+            const double v0 = buf[(k + 2 * u) * 18 + 16], v1 = buf[(k + 2 * u) * 18 + 17];
+            const double v2 = buf[(k + 2 * u + 1) * 18 + 16], v3 = buf[(k + 2 * u + 1) * 18 + 17];
+            p[u] = v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
+        }
+#pragma unroll
+        for (int u = 0; u < H_UNROLL / 2; ++u) a += p[u];
+    }
+    for (; k + 1 < cnt; k += 2) {
+        const double v0 = buf[k * 18 + 16], v1 = buf[k * 18 + 17];
+        const double v2 = buf[(k + 1) * 18 + 16], v3 = buf[(k + 1) * 18 + 17];
+        a += v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
+    }
+    for (; k < cnt; k++) {  // only at the very end of the inlier list (chunks hold an even count otherwise)
+        const double v0 = buf[k * 18 + 16], v1 = buf[k * 18 + 17];
+        a += v0 * v0;
+        a += v1 * v1;
+    }
+    return a;
+}
+
 __device__ double seq_dot8(const double* a, const double* b) {
     double r = 0;
     r += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
@@ -476,10 +567,12 @@ __device__ double seq_dot8(const double* a, const double* b) {
 __global__ __launch_bounds__(256) void k_h_refine(const RansacState* st, const float* __restrict__ src,
                                                    const float* __restrict__ dst, int n,
                                                    const uint8_t* __restrict__ mask, int* __restrict__ cidx,
-                                                   double* __restrict__ lm, double* __restrict__ H_io) {
+                                                   double* __restrict__ lm, double* __restrict__ H_io, int pts_cap) {
     __shared__ HRefineShared sh;
+    extern __shared__ float s_allpts[];  // Mx My mx my of every inlier when they fit (pts_cap points)
     __shared__ double s_h[9], s_x[8], s_xd[8], s_d[8], s_v[8], s_A[64], s_D[8], s_norm[8], s_LtL[81];
     __shared__ double s_S, s_Sd, s_rinf, s_lambda, s_lc;
+    __shared__ double s_Ap[64], s_eig[2 * 81 + 2 * 9];  // lane 0's dense 8x8 / 9x9 work (LDS, not scratch)
     __shared__ int s_flag;
     (void)lm;
     if (!st->found) return;
@@ -502,15 +595,40 @@ __global__ __launch_bounds__(256) void k_h_refine(const RansacState* st, const f
     }
     const int np = sh.base;
     if (np <= 0) return;
+    const bool cached = np <= pts_cap;
+    if (cached) {
+        for (int i = t; i < np; i += 256) {
+            const int p = cidx[i];
+            s_allpts[i * 4 + 0] = src[p * 2];
+            s_allpts[i * 4 + 1] = src[p * 2 + 1];
+            s_allpts[i * 4 + 2] = dst[p * 2];
+            s_allpts[i * 4 + 3] = dst[p * 2 + 1];
+        }
+        __syncthreads();
+    }
+    // points of the chunk starting at c0: the cached copy, or a fresh load into sh.pts
+    auto chunk_pts = [&](int c0) -> const float* {
+        if (cached) return s_allpts + (size_t)c0 * 4;
+        h_chunk_points(sh, src, dst, cidx, c0, np);
+        __syncthreads();
+        return sh.pts;
+    };
     // ---- refit: centroids (4 sequential sums), then scales (4 sequential sums)
     double acc = 0;
     for (int c0 = 0; c0 < np; c0 += 256) {
         const int cnt = np - c0 < 256 ? np - c0 : 256;
-        h_chunk_points(sh, src, dst, cidx, c0, np);
-        __syncthreads();
+        const float* cp = chunk_pts(c0);
         if (t < 4) {  // 0: cm.x 1: cm.y 2: cM.x 3: cM.y
             const int comp = t < 2 ? 2 + t : t - 2;
-            for (int k = 0; k < cnt; k++) acc += sh.pts[k * 4 + comp];
+            int k = 0;
+            for (; k + 8 <= cnt; k += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = cp[(k + u) * 4 + comp];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u];
+            }
+            for (; k < cnt; k++) acc += cp[k * 4 + comp];
         }
         __syncthreads();
     }
@@ -519,12 +637,19 @@ __global__ __launch_bounds__(256) void k_h_refine(const RansacState* st, const f
     acc = 0;
     for (int c0 = 0; c0 < np; c0 += 256) {
         const int cnt = np - c0 < 256 ? np - c0 : 256;
-        h_chunk_points(sh, src, dst, cidx, c0, np);
-        __syncthreads();
+        const float* cp = chunk_pts(c0);
         if (t < 4) {
             const int comp = t < 2 ? 2 + t : t - 2;
             const double c = s_norm[t];
-            for (int k = 0; k < cnt; k++) acc += fabs(sh.pts[k * 4 + comp] - c);
+            int k = 0;
+            for (; k + 8 <= cnt; k += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = fabs(cp[(k + u) * 4 + comp] - c);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u];
+            }
+            for (; k < cnt; k++) acc += fabs(cp[k * 4 + comp] - c);
         }
         __syncthreads();
     }
@@ -554,33 +679,23 @@ __global__ __launch_bounds__(256) void k_h_refine(const RansacState* st, const f
         acc = 0;
         for (int c0 = 0; c0 < np; c0 += 256) {
             const int cnt = np - c0 < 256 ? np - c0 : 256;
-            h_chunk_points(sh, src, dst, cidx, c0, np);
-            __syncthreads();
+            const float* cp = chunk_pts(c0);
             if (t < cnt) {
-                const double x = (sh.pts[t * 4 + 2] - hn.cmx) * hn.smx, y = (sh.pts[t * 4 + 3] - hn.cmy) * hn.smy;
-                const double X = (sh.pts[t * 4 + 0] - hn.cMx) * hn.sMx, Y = (sh.pts[t * 4 + 1] - hn.cMy) * hn.sMy;
+                const double x = (cp[t * 4 + 2] - hn.cmx) * hn.smx, y = (cp[t * 4 + 3] - hn.cmy) * hn.smy;
+                const double X = (cp[t * 4 + 0] - hn.cMx) * hn.sMx, Y = (cp[t * 4 + 1] - hn.cMy) * hn.sMy;
                 double* o = sh.buf + t * 18;
                 o[0] = X; o[1] = Y; o[2] = 1; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = -x * X; o[7] = -x * Y; o[8] = -x;
                 o[9] = 0; o[10] = 0; o[11] = 0; o[12] = X; o[13] = Y; o[14] = 1; o[15] = -y * X; o[16] = -y * Y; o[17] = -y;
             }
             __syncthreads();
-            if (t < 45)
-                for (int k = 0; k < cnt; k++) {
-                    const double* o = sh.buf + k * 18;
-                    acc += o[lj] * o[lk] + o[9 + lj] * o[9 + lk];
-                }
+            if (t < 45) acc = seq_acc_pair(sh.buf, cnt, lj, lk, 9 + lj, 9 + lk, acc);
             __syncthreads();
         }
         if (t < 81) s_LtL[t] = 0;
         __syncthreads();
         if (t < 45) s_LtL[lj * 9 + lk] = acc;
         __syncthreads();
-        if (t == 0) {
-            double LtL[81], model[9];
-            for (int i = 0; i < 81; i++) LtL[i] = s_LtL[i];
-            sm::homography_finish(hn, LtL, model);
-            for (int i = 0; i < 9; i++) s_h[i] = model[i];
-        }
+        if (t == 0) sm::homography_finish_ws(hn, s_LtL, s_h, s_eig);
     } else if (t == 0) {
         for (int i = 0; i < 9; i++) s_h[i] = H_io[i];
     }
@@ -602,37 +717,28 @@ __global__ __launch_bounds__(256) void k_h_refine(const RansacState* st, const f
         double a = 0;
         for (int c0 = 0; c0 < np; c0 += 256) {
             const int cnt = np - c0 < 256 ? np - c0 : 256;
-            h_chunk_points(sh, src, dst, cidx, c0, np);
-            __syncthreads();
-            h_chunk_lm(sh, h, cnt, true);
+            const float* cp = chunk_pts(c0);
+            h_chunk_lm(sh, cp, h, cnt, true);
             __syncthreads();
             if (t < 36) {
-                for (int k = 0; k < cnt; k++) {
-                    const double* o = sh.buf + k * 18;
-                    a += o[ai] * o[aj];
-                    a += o[8 + ai] * o[8 + aj];
-                }
+                a = seq_acc_two(sh.buf, cnt, ai, aj, 8 + ai, 8 + aj, a);
             } else if (t >= 64 && t < 72) {
-                const int i = t - 64;
-                for (int k = 0; k < cnt; k++) {
-                    const double* o = sh.buf + k * 18;
-                    a += o[i] * o[16];
-                    a += o[8 + i] * o[17];
-                }
+                a = seq_acc_two(sh.buf, cnt, t - 64, 16, 8 + t - 64, 17, a);
             } else if (t == 128) {
-                int k = 0;
-                for (; k + 1 < cnt; k += 2) {
-                    const double v0 = sh.buf[k * 18 + 16], v1 = sh.buf[k * 18 + 17];
-                    const double v2 = sh.buf[(k + 1) * 18 + 16], v3 = sh.buf[(k + 1) * 18 + 17];
-                    a += v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
-                }
-                for (; k < cnt; k++) {  // only at the very end of the inlier list (chunks hold an even count otherwise)
-                    const double v0 = sh.buf[k * 18 + 16], v1 = sh.buf[k * 18 + 17];
-                    a += v0 * v0;
-                    a += v1 * v1;
-                }
+                a = seq_acc_sq(sh.buf, cnt, a);
             } else if (t == 192) {
-                for (int k = 0; k < cnt; k++) {
+                int k = 0;
+                for (; k + 8 <= cnt; k += 8) {
+                    double v[16];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        v[2 * u] = fabs(sh.buf[(k + u) * 18 + 16]);
+                        v[2 * u + 1] = fabs(sh.buf[(k + u) * 18 + 17]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) a = a > v[u] ? a : v[u];
+                }
+                for (; k < cnt; k++) {
                     const double v0 = fabs(sh.buf[k * 18 + 16]), v1 = fabs(sh.buf[k * 18 + 17]);
                     a = a > v0 ? a : v0;
                     a = a > v1 ? a : v1;
@@ -656,23 +762,10 @@ __global__ __launch_bounds__(256) void k_h_refine(const RansacState* st, const f
         double a = 0;
         for (int c0 = 0; c0 < np; c0 += 256) {
             const int cnt = np - c0 < 256 ? np - c0 : 256;
-            h_chunk_points(sh, src, dst, cidx, c0, np);
+            const float* cp = chunk_pts(c0);
+            h_chunk_lm(sh, cp, h, cnt, false);
             __syncthreads();
-            h_chunk_lm(sh, h, cnt, false);
-            __syncthreads();
-            if (t == 128) {
-                int k = 0;
-                for (; k + 1 < cnt; k += 2) {
-                    const double v0 = sh.buf[k * 18 + 16], v1 = sh.buf[k * 18 + 17];
-                    const double v2 = sh.buf[(k + 1) * 18 + 16], v3 = sh.buf[(k + 1) * 18 + 17];
-                    a += v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
-                }
-                for (; k < cnt; k++) {
-                    const double v0 = sh.buf[k * 18 + 16], v1 = sh.buf[k * 18 + 17];
-                    a += v0 * v0;
-                    a += v1 * v1;
-                }
-            }
+            if (t == 128) a = seq_acc_sq(sh.buf, cnt, a);
             __syncthreads();
         }
         if (t == 128) s_Sd = a;
@@ -689,18 +782,12 @@ __global__ __launch_bounds__(256) void k_h_refine(const RansacState* st, const f
     const double epsx = FLT_EPSILON, epsf = FLT_EPSILON;
     int iter = 0;
     for (;;) {
+        if (t < 64) s_Ap[t] = s_A[t];
+        __syncthreads();
         if (t == 0) {
-            double Ap[64], v[8], d[8];
-            for (int i = 0; i < 64; i++) Ap[i] = s_A[i];
-            for (int i = 0; i < 8; i++) {
-                Ap[i * 8 + i] += s_lambda * s_D[i];
-                v[i] = s_v[i];
-            }
-            sm::solve_eig<8>(Ap, v, d);
-            for (int i = 0; i < 8; i++) {
-                s_d[i] = d[i];
-                s_xd[i] = s_x[i] - d[i];
-            }
+            for (int i = 0; i < 8; i++) s_Ap[i * 8 + i] += s_lambda * s_D[i];
+            sm::solve_eig_ws<8>(s_Ap, s_v, s_d, s_eig);
+            for (int i = 0; i < 8; i++) s_xd[i] = s_x[i] - s_d[i];
         }
         __syncthreads();
         residual_pass(s_xd);
@@ -729,9 +816,8 @@ __global__ __launch_bounds__(256) void k_h_refine(const RansacState* st, const f
                 nu = nu > 2. ? nu : 2.;
                 nu = nu < 10. ? nu : 10.;
                 if (lambda == 0) {
-                    double A[64], Ai[64];
-                    for (int i = 0; i < 64; i++) A[i] = s_A[i];
-                    sm::invert_eig<8>(A, Ai);
+                    double* Ai = s_Ap;
+                    sm::invert_eig_ws<8>(s_A, Ai, s_eig);
                     double maxval = DBL_EPSILON;
                     for (int i = 0; i < 8; i++) maxval = maxval > fabs(Ai[i * 8 + i]) ? maxval : fabs(Ai[i * 8 + i]);
                     lambda = lc = 1. / maxval;
@@ -787,15 +873,23 @@ int enqueue_find_homography(RansacWorkspace& w, const double* d_pts1, const doub
         if (it1 <= it0) continue;
         const int nh = it1 - it0;
         hipLaunchKernelGGL(k_h_subsets, dim3(1), dim3(1), 0, s, w.state, w.idx, w.f_a, w.f_b, n, it0, it1);
-        hipLaunchKernelGGL(k_h_solve, dim3(cdiv(nh, 64)), dim3(64), 0, s, w.state, w.idx, w.f_a, w.f_b, it0, it1,
-                           w.models, w.nmodels);
+        hipLaunchKernelGGL(k_h_solve, dim3(cdiv(nh, H_SOLVE_LANES)), dim3(H_SOLVE_LANES), 0, s, w.state, w.idx, w.f_a,
+                           w.f_b, it0, it1, w.models, w.nmodels);
         hipLaunchKernelGGL(k_h_score, dim3(cdiv(nh, 4)), dim3(256), 0, s, w.state, it0, it1, w.models, w.nmodels, w.f_a,
                            w.f_b, n, thr2, w.counts);
         hipLaunchKernelGGL(k_replay, dim3(1), dim3(1), 0, s, w.state, w.nmodels, w.counts, 1, it0, it1, n, 4, confidence);
     }
     hipLaunchKernelGGL(k_h_mask, dim3(cdiv(n > 9 ? n : 9, 256)), dim3(256), 0, s, w.state, w.models, w.f_a, w.f_b, n, thr2,
                        w.mask, w.out);
-    hipLaunchKernelGGL(k_h_refine, dim3(1), dim3(256), 0, s, w.state, w.f_a, w.f_b, n, w.mask, w.cidx, w.lm, w.out);
+    // every inlier's coordinates stay in LDS across the LM passes when they fit (16 B / point)
+    const int pts_cap = n <= 6144 ? n : 0;
+    static int configured = 0;
+    if (pts_cap * 16 > configured) {
+        DFVO_HIP_CHECK(hipFuncSetAttribute((const void*)k_h_refine, hipFuncAttributeMaxDynamicSharedMemorySize, 6144 * 16));
+        configured = 6144 * 16;
+    }
+    hipLaunchKernelGGL(k_h_refine, dim3(1), dim3(256), (size_t)pts_cap * 16, s, w.state, w.f_a, w.f_b, n, w.mask, w.cidx, w.lm,
+                       w.out, pts_cap);
     DFVO_HIP_CHECK(hipGetLastError());
     return DFVO_OK;
 }

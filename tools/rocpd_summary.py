@@ -1,5 +1,6 @@
 """Summarise a rocprofv3 (rocpd sqlite) kernel trace: per-kernel calls / total / average / share,
-optionally split by grid size.  Usage: python tools/rocpd_summary.py <results.db> [--by-grid] [--top N]"""
+optionally split by grid size.  Usage: python tools/rocpd_summary.py <results.db> [--by-grid] [--top N]
+       python tools/rocpd_summary.py <results.db> --timeline N   (the last N dispatches: start offset, stream/queue, duration)"""
 import sqlite3
 import sys
 
@@ -11,6 +12,17 @@ def main():
     if "--top" in sys.argv:
         top = int(sys.argv[sys.argv.index("--top") + 1])
     cur = db.cursor()
+    if "--timeline" in sys.argv:
+        n = int(sys.argv[sys.argv.index("--timeline") + 1])
+        cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+        qcol = "stream_id" if "stream_id" in cols else ("queue_id" if "queue_id" in cols else "0")
+        rows = list(cur.execute("select name, start, end, %s, grid_x from kernels order by start desc limit %d" % (qcol, n)))
+        rows.reverse()
+        t0 = rows[0][1]
+        print("columns:", cols)
+        for name, st, en, q, gx in rows:
+            print("%10.1f us  +%8.1f us  q=%-4s grid=%-7s %s" % ((st - t0) / 1e3, (en - st) / 1e3, q, gx, name[:60]))
+        return
     key = "name, grid_x, grid_y, grid_z" if by_grid else "name"
     rows = list(cur.execute(
         "select %s, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by %s "
