@@ -124,6 +124,135 @@ SM_HD_NOINLINE void kp_introselect(const float* v, IdxT* tosort, int num, int kt
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Same algorithm with the keys carried along: key[i] == v[tosort[i]] is kept true by swapping both
+// arrays, so every scan reads consecutive addresses (no dependent tosort -> v lookup) and the two
+// partition scans fetch four keys per round trip.  On the GPU both arrays sit in LDS, where the
+// dependent lookup costs a full LDS latency per element.  Results are identical to kp_introselect
+// (same comparisons on the same values in the same order); `key` is left permuted.
+// The 4-wide scans may LOAD up to 3 elements past the scanned range (never use them): the caller keeps
+// key[-3 .. num+2] readable.
+// ------------------------------------------------------------------------------------------------
+#define KP_SWAP2(i, j)               \
+    {                                \
+        IdxT _t = tosort[i];         \
+        tosort[i] = tosort[j];       \
+        tosort[j] = _t;              \
+        float _k = key[i];           \
+        key[i] = key[j];             \
+        key[j] = _k;                 \
+    }
+
+template <typename IdxT>
+SM_HD void kp_dumbselect_cp(float* key, IdxT* tosort, int num, int kth) {
+    for (int i = 0; i <= kth; i++) {
+        int minidx = i;
+        float minval = key[i];
+        for (int k = i + 1; k < num; k++) {
+            if (kp_lt(key[k], minval)) {
+                minidx = k;
+                minval = key[k];
+            }
+        }
+        KP_SWAP2(i, minidx);
+    }
+}
+
+template <typename IdxT>
+SM_HD int kp_median5_cp(float* key, IdxT* tosort) {
+    if (kp_lt(key[1], key[0])) KP_SWAP2(1, 0);
+    if (kp_lt(key[4], key[3])) KP_SWAP2(4, 3);
+    if (kp_lt(key[3], key[0])) KP_SWAP2(3, 0);
+    if (kp_lt(key[4], key[1])) KP_SWAP2(4, 1);
+    if (kp_lt(key[2], key[1])) KP_SWAP2(2, 1);
+    if (kp_lt(key[3], key[2])) {
+        if (kp_lt(key[3], key[1])) return 1;
+        return 3;
+    }
+    return 2;
+}
+
+template <typename IdxT>
+SM_HD_NOINLINE void kp_introselect_cp(float* key, IdxT* tosort, int num, int kth, int depth);
+
+template <typename IdxT>
+SM_HD int kp_median_of_median5_cp(float* key, IdxT* tosort, int num, int depth) {
+    const int right = num - 1;
+    const int nmed = (right + 1) / 5;
+    for (int i = 0, subleft = 0; i < nmed; i++, subleft += 5) {
+        const int m = kp_median5_cp(key + subleft, tosort + subleft);
+        KP_SWAP2(subleft + m, i);
+    }
+    if (nmed > 2 && depth < 4) kp_introselect_cp(key, tosort, nmed, nmed / 2, depth + 1);
+    return nmed / 2;
+}
+
+template <typename IdxT>
+SM_HD_NOINLINE void kp_introselect_cp(float* key, IdxT* tosort, int num, int kth, int depth) {
+    int low = 0, high = num - 1;
+    if (kth - low < 3) {
+        kp_dumbselect_cp(key + low, tosort + low, high - low + 1, kth - low);
+        return;
+    } else if (kth == num - 1) {
+        int maxidx = low;
+        float maxval = key[low];
+        for (int k = low + 1; k < num; k++) {
+            if (!kp_lt(key[k], maxval)) {
+                maxidx = k;
+                maxval = key[k];
+            }
+        }
+        KP_SWAP2(kth, maxidx);
+        return;
+    }
+    int depth_limit = kp_msb((unsigned)num) * 2;
+    for (; low + 1 < high;) {
+        int ll = low + 1, hh = high;
+        if (depth_limit > 0 || hh - ll < 5) {
+            const int mid = low + (high - low) / 2;
+            if (kp_lt(key[high], key[mid])) KP_SWAP2(high, mid);
+            if (kp_lt(key[high], key[low])) KP_SWAP2(high, low);
+            if (kp_lt(key[low], key[mid])) KP_SWAP2(low, mid);
+            KP_SWAP2(mid, low + 1);
+        } else {
+            const int mid = ll + kp_median_of_median5_cp(key + ll, tosort + ll, hh - ll, depth);
+            KP_SWAP2(mid, low);
+            ll--;
+            hh++;
+        }
+        depth_limit--;
+        const float pivot = key[low];
+        for (;;) {
+            // do ll++ while (key[ll] < pivot): four candidates per fetch
+            for (;;) {
+                const float k0 = key[ll + 1], k1 = key[ll + 2], k2 = key[ll + 3], k3 = key[ll + 4];
+                if (!kp_lt(k0, pivot)) { ll += 1; break; }
+                if (!kp_lt(k1, pivot)) { ll += 2; break; }
+                if (!kp_lt(k2, pivot)) { ll += 3; break; }
+                ll += 4;
+                if (!kp_lt(k3, pivot)) break;
+            }
+            // do hh-- while (pivot < key[hh])
+            for (;;) {
+                const float k0 = key[hh - 1], k1 = key[hh - 2], k2 = key[hh - 3], k3 = key[hh - 4];
+                if (!kp_lt(pivot, k0)) { hh -= 1; break; }
+                if (!kp_lt(pivot, k1)) { hh -= 2; break; }
+                if (!kp_lt(pivot, k2)) { hh -= 3; break; }
+                hh -= 4;
+                if (!kp_lt(pivot, k3)) break;
+            }
+            if (hh < ll) break;
+            KP_SWAP2(hh, ll);
+        }
+        KP_SWAP2(low, hh);
+        if (hh >= kth) high = hh - 1;
+        if (hh <= kth) low = ll;
+    }
+    if (high == low + 1) {
+        if (kp_lt(key[high], key[low])) KP_SWAP2(high, low);
+    }
+}
+
 // local_bestN cell bounds (kp_selection.py:129-131): python float arithmetic, int() truncation
 SM_HD void kp_cell_bounds(int h, int w, int num_row, int num_col, int row, int col, int* y0, int* y1, int* x0,
                           int* x1) {

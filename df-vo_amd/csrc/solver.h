@@ -4,6 +4,7 @@
 
 namespace dfvo {
 
+constexpr int MAX_E_BATCH = 8;  // problems per batched five-point RANSAC launch sequence
 constexpr int E_WS = 106;  // per-hypothesis scratch doubles: EE 36 | b 39 | c 11 | roots re/im 20
 
 struct RansacState {
@@ -40,6 +41,9 @@ struct RansacWorkspace {
 
 int enqueue_find_essential(RansacWorkspace& w, const double* d_pts1, const double* d_pts2, int n, double focal,
                            double ppx, double ppy, double prob, double threshold, int max_iters, hipStream_t s);
+int enqueue_find_essential_batch(RansacWorkspace* w, const double* const* d_pts1, const double* const* d_pts2, int nrep,
+                                 int n, double focal, double ppx, double ppy, double prob, double threshold,
+                                 int max_iters, hipStream_t s);
 int enqueue_find_homography(RansacWorkspace& w, const double* d_pts1, const double* d_pts2, int n, double thr,
                             int max_iters, double confidence, hipStream_t s);
 int enqueue_recover_pose(RansacWorkspace& w, const double* d_E, const double* d_pts1, const double* d_pts2, int n,

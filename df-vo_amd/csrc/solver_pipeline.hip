@@ -39,14 +39,15 @@ __global__ void k_kp_count(const float* __restrict__ diff, int n, float thre, in
 }
 
 // one 256-thread block per grid cell: ordered (row-major) compaction of the candidates into LDS, then
-// lane 0 runs numpy's introselect on them; writes the picked local indices in argpartition order.
+// lane 0 runs numpy's introselect on them (keys carried along with the indices, see kp_select.h); writes
+// the picked local indices in argpartition order.
 __global__ __launch_bounds__(256) void k_kp_cell(const float* __restrict__ diff, int H, int W, int num_row, int num_col,
                                                   float thre, int n_best, int cap, int* __restrict__ cell_count,
                                                   int* __restrict__ cell_sel /*[cells][n_best] (y<<16|x)*/,
                                                   unsigned short* __restrict__ lidx_all /*[cells][cap]*/) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    float* vals = reinterpret_cast<float*>(smem_raw);
-    unsigned short* tosort = reinterpret_cast<unsigned short*>(vals + cap);
+    float* vals = reinterpret_cast<float*>(smem_raw) + 4;  // 4 floats of slack on either side: the 4-wide scans over-read
+    unsigned short* tosort = reinterpret_cast<unsigned short*>(vals + cap + 4);
     unsigned short* lidx = lidx_all + (size_t)blockIdx.x * cap;  // candidate -> tile element (global scratch)
     __shared__ int s_base, s_wave[4];
     const int cell = blockIdx.x;
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void k_kp_cell(const float* __restrict__ diff,
     const int cnt = s_base;
     const int pick = cnt < n_best ? cnt : n_best;
     if (t == 0) {
-        if (pick > 0) sm::kp_introselect<unsigned short>(vals, tosort, cnt, pick - 1, 0);
+        if (pick > 0) sm::kp_introselect_cp<unsigned short>(vals, tosort, cnt, pick - 1, 0);
         cell_count[cell] = pick;
     }
     __syncthreads();
@@ -143,7 +144,7 @@ int enqueue_local_bestn(TrackerBuffers& tb, const float* d_flow, const float* d_
     DFVO_ARG_CHECK(n_best >= 1 && n_best <= 256, "local_bestN: n_best out of range");
     const int cap = (H / num_row + 2) * (W / num_col + 2);
     DFVO_ARG_CHECK(cap < 65536, "local_bestN: cell larger than 65535 pixels");
-    const size_t lds = (size_t)cap * (4 + 2);
+    const size_t lds = (size_t)cap * (4 + 2) + 32;
     DFVO_ARG_CHECK(lds <= 158 * 1024, "local_bestN: cell does not fit in LDS");
     int rc = tb.ensure_kp(cells * n_best, cells, n_best);
     if (rc != DFVO_OK) return rc;
@@ -340,11 +341,15 @@ __global__ __launch_bounds__(256) void k_mt_shuffle_all(uint32_t* __restrict__ s
     if (t == 0) st[624] = (uint32_t)s_pos;
 }
 
-__global__ void k_permute_points(const int* __restrict__ n_ptr, const int* __restrict__ perm,
+// blockIdx.y = repeat: perm / pa / pb advance by perm_stride / pts_stride elements per repeat
+__global__ void k_permute_points(const int* __restrict__ n_ptr, const int* __restrict__ perm, int perm_stride,
                                  const double* __restrict__ a, const double* __restrict__ b, double* __restrict__ pa,
-                                 double* __restrict__ pb) {
+                                 double* __restrict__ pb, int pts_stride) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= *n_ptr) return;
+    perm += (size_t)blockIdx.y * perm_stride;
+    pa += (size_t)blockIdx.y * pts_stride;
+    pb += (size_t)blockIdx.y * pts_stride;
     const int p = perm[i];
     pa[i * 2] = a[p * 2];
     pa[i * 2 + 1] = a[p * 2 + 1];
@@ -356,12 +361,20 @@ __global__ void k_permute_points(const int* __restrict__ n_ptr, const int* __res
 // GRIC
 // ================================================================================================
 // res = compute_fundamental_residual(F, kp1, kp2), F = KinvT @ E @ Kinv (gric.py:14-37)
-__global__ void k_gric_f_residual(const double* __restrict__ E, const double* __restrict__ KinvT,
+struct GricBatch {
+    const double* E[MAX_E_BATCH];
+};
+// blockIdx.y = repeat: kp1 / kp2 advance by pts_stride, res by res_stride elements per repeat
+__global__ void k_gric_f_residual(const GricBatch G, const double* __restrict__ KinvT,
                                   const double* __restrict__ Kinv, const int* __restrict__ n_ptr,
-                                  const double* __restrict__ kp1, const double* __restrict__ kp2,
-                                  double* __restrict__ res) {
+                                  const double* __restrict__ kp1, const double* __restrict__ kp2, int pts_stride,
+                                  double* __restrict__ res, int res_stride) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= *n_ptr) return;
+    const double* E = G.E[blockIdx.y];
+    kp1 += (size_t)blockIdx.y * pts_stride;
+    kp2 += (size_t)blockIdx.y * pts_stride;
+    res += (size_t)blockIdx.y * res_stride;
     double T[9], F[9];
     sm::mul33(KinvT, E, T);
     sm::mul33(T, Kinv, F);
@@ -396,10 +409,14 @@ __global__ void k_gric_h_residual(const double* __restrict__ Hm, const int* __re
 }
 
 // calc_GRIC (gric.py:95-132): the python loop's sequential sum, one lane; residuals staged through LDS
-__global__ __launch_bounds__(256) void k_gric_sum(const double* __restrict__ res, const int* __restrict__ n_ptr,
-                                                   double sigma, int Kp, int D, double* __restrict__ out) {
+// blockIdx.x = problem: res advances by res_stride, out by one element per problem
+__global__ __launch_bounds__(256) void k_gric_sum(const double* __restrict__ res, int res_stride,
+                                                   const int* __restrict__ n_ptr, double sigma, int Kp, int D,
+                                                   double* __restrict__ out) {
     __shared__ double s_res[2048];
     const int n = *n_ptr;
+    res += (size_t)blockIdx.x * res_stride;
+    out += blockIdx.x;
     const double R = 4, sigmasq1 = 1. / (sigma * sigma);
     const double lam3RD = 2.0 * (R - D);
     double sum = 0;
@@ -407,11 +424,23 @@ __global__ __launch_bounds__(256) void k_gric_sum(const double* __restrict__ res
         const int cnt = n - c0 < 2048 ? n - c0 : 2048;
         for (int i = threadIdx.x; i < cnt; i += 256) s_res[i] = res[c0 + i];
         __syncthreads();
-        if (threadIdx.x == 0)
-            for (int i = 0; i < cnt; i++) {
+        if (threadIdx.x == 0) {  // the reference's sequential np.sum order; terms batched so that LDS latency overlaps
+            int i = 0;
+            for (; i + 8 <= cnt; i += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double tmp = s_res[i + u] * sigmasq1;
+                    v[u] = tmp <= lam3RD ? tmp : lam3RD;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sum += v[u];
+            }
+            for (; i < cnt; i++) {
                 const double tmp = s_res[i] * sigmasq1;
                 sum += tmp <= lam3RD ? tmp : lam3RD;
             }
+        }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -806,37 +835,36 @@ int enqueue_compute_pose_2d2d(TrackerBuffers& tb, int n_host, const PoseConfig& 
         // the shuffle chain runs on s_rep[0] so that the homography (on s) starts at once
         DFVO_HIP_CHECK(hipEventRecord(tb.ev_start, s));
         DFVO_HIP_CHECK(hipStreamWaitEvent(tb.s_rep[0], tb.ev_start, 0));
-        hipLaunchKernelGGL(k_mt_shuffle_all, dim3(1), dim3(256), perm_lds, tb.s_rep[0], tb.mt_state, tb.kp_info,
-                           cfg.repeat, group, cap + 8, tb.perm);
-        for (int rep = 0; rep < cfg.repeat; ++rep)
-            hipLaunchKernelGGL(k_permute_points, dim3(nb), dim3(256), 0, tb.s_rep[0], tb.kp_info,
-                               tb.perm + (size_t)rep * (cap + 8), tb.kp_cur, tb.kp_ref, tb.pa + (size_t)rep * 2 * cap,
-                               tb.pb + (size_t)rep * 2 * cap);
-        DFVO_HIP_CHECK(hipEventRecord(tb.ev_fork, tb.s_rep[0]));
-        int rc;
+        hipStream_t sr = tb.s_rep[0];
+        const unsigned R = (unsigned)cfg.repeat;
+        hipLaunchKernelGGL(k_mt_shuffle_all, dim3(1), dim3(256), perm_lds, sr, tb.mt_state, tb.kp_info, cfg.repeat, group,
+                           cap + 8, tb.perm);
+        hipLaunchKernelGGL(k_permute_points, dim3(nb, R), dim3(256), 0, sr, tb.kp_info, tb.perm, cap + 8, tb.kp_cur,
+                           tb.kp_ref, tb.pa, tb.pb, 2 * cap);
+        // the `repeat` five-point RANSACs as one batched launch sequence (blockIdx.y = repeat)
+        const double *pas[MAX_REP], *pbs[MAX_REP];
+        GricBatch G;
         for (int rep = 0; rep < cfg.repeat; ++rep) {
-            hipStream_t sr = tb.s_rep[rep];
-            double* pa = tb.pa + (size_t)rep * 2 * cap;
-            double* pb = tb.pb + (size_t)rep * 2 * cap;
-            double* res = tb.res + (size_t)(rep + 1) * cap;
-            DFVO_HIP_CHECK(hipStreamWaitEvent(sr, tb.ev_fork, 0));
-            rc = enqueue_find_essential(tb.ws_rep[rep], pa, pb, n_host, cfg.fx, cfg.cx, cfg.cy, 0.99, cfg.reproj_thre,
-                                        cfg.max_iters, sr);
-            if (rc != DFVO_OK) return rc;
-            hipLaunchKernelGGL(k_gric_f_residual, dim3(nb), dim3(256), 0, sr, tb.ws_rep[rep].out, tb.small, tb.small + 9,
-                               tb.kp_info, pa, pb, res);
-            hipLaunchKernelGGL(k_gric_sum, dim3(1), dim3(256), 0, sr, res, tb.kp_info, 0.8, 5, 3, tb.small + 19 + rep);
-            DFVO_HIP_CHECK(hipEventRecord(tb.ev_rep[rep], sr));
+            pas[rep] = tb.pa + (size_t)rep * 2 * cap;
+            pbs[rep] = tb.pb + (size_t)rep * 2 * cap;
         }
+        int rc = enqueue_find_essential_batch(tb.ws_rep, pas, pbs, cfg.repeat, n_host, cfg.fx, cfg.cx, cfg.cy, 0.99,
+                                              cfg.reproj_thre, cfg.max_iters, sr);
+        if (rc != DFVO_OK) return rc;
+        for (int rep = 0; rep < MAX_E_BATCH; ++rep) G.E[rep] = rep < cfg.repeat ? tb.ws_rep[rep].out : nullptr;
+        hipLaunchKernelGGL(k_gric_f_residual, dim3(nb, R), dim3(256), 0, sr, G, tb.small, tb.small + 9, tb.kp_info, tb.pa,
+                           tb.pb, 2 * cap, tb.res + cap, cap);
+        hipLaunchKernelGGL(k_gric_sum, dim3(R), dim3(256), 0, sr, tb.res + cap, cap, tb.kp_info, 0.8, 5, 3, tb.small + 19);
+        DFVO_HIP_CHECK(hipEventRecord(tb.ev_rep[0], sr));
         // ---- homography + GRIC-H (kp_cur -> kp_ref)
         rc = enqueue_find_homography(tb.ws_h, tb.kp_cur, tb.kp_ref, n_host, 1.0, 2000, 0.99, s);
         if (rc != DFVO_OK) return rc;
         hipLaunchKernelGGL(k_gric_h_residual, dim3(nb), dim3(256), 0, s, tb.ws_h.out, tb.kp_info, tb.kp_cur, tb.kp_ref,
                            tb.res);
-        hipLaunchKernelGGL(k_gric_sum, dim3(1), dim3(256), 0, s, tb.res, tb.kp_info, 0.8, 8, 2, tb.small + 18);
+        hipLaunchKernelGGL(k_gric_sum, dim3(1), dim3(256), 0, s, tb.res, 0, tb.kp_info, 0.8, 8, 2, tb.small + 18);
         hipLaunchKernelGGL(k_set_h_gric, dim3(1), dim3(1), 0, s, tb.pose, tb.ws_h.state, tb.small + 18);
+        DFVO_HIP_CHECK(hipStreamWaitEvent(s, tb.ev_rep[0], 0));
         for (int rep = 0; rep < cfg.repeat; ++rep) {
-            DFVO_HIP_CHECK(hipStreamWaitEvent(s, tb.ev_rep[rep], 0));
             hipLaunchKernelGGL(k_rep_update, dim3(1), dim3(256), 0, s, tb.pose, tb.ws_rep[rep].state, tb.ws_rep[rep].out,
                                tb.small + 19 + rep, tb.ws_rep[rep].mask, tb.perm + (size_t)rep * (cap + 8),
                                tb.best_inliers, rep);

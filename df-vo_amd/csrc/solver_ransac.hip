@@ -18,6 +18,8 @@
 //      remaining chunks exit at once (device-side flag, no host round trip).
 // All arithmetic is f64 (scores are cast to float exactly where OpenCV casts) and this file is built
 // with -ffp-contract=off, so masks are bit-identical to the sequential algorithm.
+#include <cstring>
+
 #include "dfvo_common.h"
 #include "solver.h"
 #include "solver_math.h"
@@ -55,9 +57,8 @@ __global__ void k_ransac_init(RansacState* st, int max_iters, uint64_t seed) {
 }
 
 // replay of RANSACPointSetRegistrator::run over iterations [it0, it1)
-__global__ void k_replay(RansacState* st, const int* __restrict__ nmodels, const int* __restrict__ counts,
-                         int max_models, int it0, int it1, int count, int model_points, double confidence) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ void ransac_replay(RansacState* st, const int* __restrict__ nmodels, const int* __restrict__ counts,
+                              int max_models, int it0, int it1, int count, int model_points, double confidence) {
     if (st->done) return;
     int iter = st->iter;
     int niters = st->niters;
@@ -88,9 +89,18 @@ __global__ void k_replay(RansacState* st, const int* __restrict__ nmodels, const
     }
     (void)it0;
 }
+__global__ void k_replay(RansacState* st, const int* __restrict__ nmodels, const int* __restrict__ counts,
+                         int max_models, int it0, int it1, int count, int model_points, double confidence) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    ransac_replay(st, nmodels, counts, max_models, it0, it1, count, model_points, confidence);
+}
 
 // ================================================================================================
-// essential matrix
+// essential matrix.  The kernels take a batch of independent RANSAC problems over the same number of
+// correspondences (the `repeat` shuffled runs of compute_pose_2d2d): blockIdx.y = problem, so one launch
+// sequence on one stream serves them all.  cv::RANSAC seeds its RNG with the same constant in every
+// call and the five-point sampler has no data-dependent subset check, so the subset indices depend
+// only on the point count: they are drawn once and shared by the batch.
 // ================================================================================================
 __global__ void k_e_normalise(const double* __restrict__ pts, int n, double a, double bx, double by,
                               double* __restrict__ out) {
@@ -100,16 +110,57 @@ __global__ void k_e_normalise(const double* __restrict__ pts, int n, double a, d
     out[i * 2 + 1] = pts[i * 2 + 1] * a + by;
 }
 
-// one lane: subsets of iterations [it0, it1) from the sequential cv::RNG stream
-__global__ void k_subsets_plain(RansacState* st, int* __restrict__ idx, int model_points, int count, int it0,
-                                int it1) {
+struct ERep {
+    RansacState* state;
+    const double *pts1, *pts2;  // inputs
+    double *norm_a, *norm_b;
+    double* ws;
+    int* ok;
+    double* models;
+    int* nmodels;
+    int* counts;
+    uint8_t* mask;
+    double* out;
+};
+struct EBatch {
+    int nrep;
+    int* idx;  // shared subset indices [iters][5]
+    ERep r[MAX_E_BATCH];
+};
+
+__global__ void k_e_init_normalise(const EBatch B, int n, int max_iters, double a, double bx, double by) {
+    const ERep& R = B.r[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        RansacState* st = R.state;
+        st->rng_state = 0xffffffffffffffffULL;
+        st->niters = max_iters > 1 ? max_iters : 1;
+        st->iter = 0;
+        st->max_good = 0;
+        st->best_iter = -1;
+        st->best_model = -1;
+        st->done = 0;
+        st->subset_fail_at = -1;
+        st->found = 0;
+    }
+    if (i >= n) return;
+    R.norm_a[i * 2] = R.pts1[i * 2] * a + bx;
+    R.norm_a[i * 2 + 1] = R.pts1[i * 2 + 1] * a + by;
+    R.norm_b[i * 2] = R.pts2[i * 2] * a + bx;
+    R.norm_b[i * 2 + 1] = R.pts2[i * 2 + 1] * a + by;
+}
+
+// one lane: subsets of iterations [it0, it1) from the sequential cv::RNG stream, shared by the batch
+__global__ void k_e_subsets(const EBatch B, int count, int it0, int it1) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (st->done) return;
+    bool all_done = true;
+    for (int r = 0; r < B.nrep; ++r) all_done = all_done && B.r[r].state->done;
+    if (all_done) return;
     sm::CvRng rng;
-    rng.state = st->rng_state;
+    rng.state = B.r[0].state->rng_state;
     for (int it = it0; it < it1; ++it) {
-        int* id = idx + it * model_points;
-        for (int i = 0; i < model_points;) {
+        int* id = B.idx + it * 5;
+        for (int i = 0; i < 5;) {
             int v, j;
             for (;;) {
                 v = id[i] = sm::cvrng_uniform(rng, 0, count);
@@ -120,7 +171,7 @@ __global__ void k_subsets_plain(RansacState* st, int* __restrict__ idx, int mode
             i++;
         }
     }
-    st->rng_state = rng.state;
+    for (int r = 0; r < B.nrep; ++r) B.r[r].state->rng_state = rng.state;
 }
 
 // one hypothesis per lane, 16 lanes per block: the ~3.7 KB of dense work (9x9 SVD rows, the 10x20
@@ -128,11 +179,14 @@ __global__ void k_subsets_plain(RansacState* st, int* __restrict__ idx, int mode
 // stride, so the pivoting / Jacobi subscripts never touch scratch memory
 constexpr int E_STAGE1_LANES = 16;
 constexpr int E_STAGE1_STRIDE = sm::FIVE_POINT_WS + 1;
-__global__ __launch_bounds__(E_STAGE1_LANES) void k_e_stage1(const RansacState* st, const int* __restrict__ idx,
-                                                              const double* __restrict__ p1,
-                                                              const double* __restrict__ p2, int it0, int it1,
-                                                              double* __restrict__ ws, int* __restrict__ ok) {
+__global__ __launch_bounds__(E_STAGE1_LANES) void k_e_stage1(const EBatch B, int it0, int it1) {
     __shared__ double s_ws[E_STAGE1_LANES * E_STAGE1_STRIDE];
+    const ERep& R = B.r[blockIdx.y];
+    const RansacState* st = R.state;
+    const int* idx = B.idx;
+    const double *p1 = R.norm_a, *p2 = R.norm_b;
+    double* ws = R.ws;
+    int* ok = R.ok;
     const int it = it0 + blockIdx.x * E_STAGE1_LANES + threadIdx.x;
     if (st->done || it >= it1) return;
     double q1[10], q2[10];
@@ -147,8 +201,11 @@ __global__ __launch_bounds__(E_STAGE1_LANES) void k_e_stage1(const RansacState* 
     ok[it] = sm::five_point_stage1_ws(q1, q2, w, w + 36, w + 75, s_ws + threadIdx.x * E_STAGE1_STRIDE) ? 1 : 0;
 }
 
-__global__ __launch_bounds__(64) void k_e_poly(const RansacState* st, int it0, int it1, double* __restrict__ ws,
-                                                const int* __restrict__ ok) {
+__global__ __launch_bounds__(64) void k_e_poly(const EBatch B, int it0, int it1) {
+    const ERep& R = B.r[blockIdx.y];
+    const RansacState* st = R.state;
+    double* ws = R.ws;
+    const int* ok = R.ok;
     const int it = it0 + blockIdx.x * 64 + threadIdx.x;
     if (st->done || it >= it1) return;
     if (!ok[it]) return;
@@ -162,9 +219,13 @@ __global__ __launch_bounds__(64) void k_e_poly(const RansacState* st, int it0, i
     }
 }
 
-__global__ __launch_bounds__(64) void k_e_stage3(const RansacState* st, int it0, int it1,
-                                                  const double* __restrict__ ws, const int* __restrict__ ok,
-                                                  double* __restrict__ models, int* __restrict__ nmodels) {
+__global__ __launch_bounds__(64) void k_e_stage3(const EBatch B, int it0, int it1) {
+    const ERep& R = B.r[blockIdx.y];
+    const RansacState* st = R.state;
+    const double* ws = R.ws;
+    const int* ok = R.ok;
+    double* models = R.models;
+    int* nmodels = R.nmodels;
     const int it = it0 + blockIdx.x * 64 + threadIdx.x;
     if (st->done || it >= it1) return;
     int nm = 0;
@@ -176,11 +237,14 @@ __global__ __launch_bounds__(64) void k_e_stage3(const RansacState* st, int it0,
 }
 
 // one wavefront per hypothesis: Sampson error of every correspondence under each of its models
-__global__ __launch_bounds__(256) void k_e_score(const RansacState* st, int it0, int it1,
-                                                  const double* __restrict__ models, const int* __restrict__ nmodels,
-                                                  const double* __restrict__ p1, const double* __restrict__ p2, int n,
-                                                  float thr2, int* __restrict__ counts) {
+__global__ __launch_bounds__(256) void k_e_score(const EBatch B, int it0, int it1, int n, float thr2) {
     __shared__ double sE[4][90];
+    const ERep& R = B.r[blockIdx.y];
+    const RansacState* st = R.state;
+    const double* models = R.models;
+    const int* nmodels = R.nmodels;
+    const double *p1 = R.norm_a, *p2 = R.norm_b;
+    int* counts = R.counts;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int it = it0 + blockIdx.x * 4 + wave;
     const bool active = !st->done && it < it1;
@@ -210,9 +274,19 @@ __global__ __launch_bounds__(256) void k_e_score(const RansacState* st, int it0,
     }
 }
 
-__global__ void k_e_mask(const RansacState* st, const double* __restrict__ models, const double* __restrict__ p1,
-                         const double* __restrict__ p2, int n, float thr2, uint8_t* __restrict__ mask,
-                         double* __restrict__ E_out) {
+__global__ void k_e_replay(const EBatch B, int it0, int it1, int count, double confidence) {
+    if (threadIdx.x != 0) return;
+    const ERep& R = B.r[blockIdx.x];
+    ransac_replay(R.state, R.nmodels, R.counts, 10, it0, it1, count, 5, confidence);
+}
+
+__global__ void k_e_mask(const EBatch B, int n, float thr2) {
+    const ERep& R = B.r[blockIdx.y];
+    const RansacState* st = R.state;
+    const double* models = R.models;
+    const double *p1 = R.norm_a, *p2 = R.norm_b;
+    uint8_t* mask = R.mask;
+    double* E_out = R.out;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (!st->found) {
         if (i < n) mask[i] = 0;
@@ -270,46 +344,63 @@ static void chunk_bounds(int max_iters, int* b) {
     b[3] = max_iters;
 }
 
-// d_pts1/d_pts2: device [n][2] doubles.  Results: w.state (RansacState), w.out[0..8] = E, w.mask[n]
-int enqueue_find_essential(RansacWorkspace& w, const double* d_pts1, const double* d_pts2, int n, double focal,
-                           double ppx, double ppy, double prob, double threshold, int max_iters, hipStream_t s) {
-    DFVO_ARG_CHECK(n >= 0 && max_iters >= 1, "find_essential: bad sizes");
-    int rc = w.ensure(n > 8 ? n : 8, max_iters);
-    if (rc != DFVO_OK) return rc;
+// batch of `nrep` problems (workspaces w[r], inputs d_pts1[r]/d_pts2[r], all with n correspondences).
+// Results per problem: w[r].state (RansacState), w[r].out[0..8] = E, w[r].mask[n]
+int enqueue_find_essential_batch(RansacWorkspace* w, const double* const* d_pts1, const double* const* d_pts2, int nrep,
+                                 int n, double focal, double ppx, double ppy, double prob, double threshold,
+                                 int max_iters, hipStream_t s) {
+    DFVO_ARG_CHECK(n >= 0 && max_iters >= 1 && nrep >= 1 && nrep <= MAX_E_BATCH, "find_essential: bad sizes");
+    EBatch B;
+    memset(&B, 0, sizeof(B));
+    B.nrep = nrep;
+    for (int r = 0; r < nrep; ++r) {
+        int rc = w[r].ensure(n > 8 ? n : 8, max_iters);
+        if (rc != DFVO_OK) return rc;
+        ERep& R = B.r[r];
+        R.state = w[r].state;
+        R.pts1 = d_pts1[r];
+        R.pts2 = d_pts2[r];
+        R.norm_a = w[r].norm_a;
+        R.norm_b = w[r].norm_b;
+        R.ws = w[r].ws;
+        R.ok = w[r].ok;
+        R.models = w[r].models;
+        R.nmodels = w[r].nmodels;
+        R.counts = w[r].counts;
+        R.mask = w[r].mask;
+        R.out = w[r].out;
+    }
+    B.idx = w[0].idx;
     const double a = 1. / focal, bx = -ppx * a, by = -ppy * a;
     threshold /= (focal + focal) / 2;
     const float thr2 = (float)(threshold * threshold);
-    hipLaunchKernelGGL(k_ransac_init, dim3(1), dim3(1), 0, s, w.state, max_iters, (uint64_t)-1);
-    if (n < 5) {  // count < modelPoints: no model (state->found stays 0)
-        hipLaunchKernelGGL(k_e_mask, dim3(cdiv(n > 9 ? n : 9, 256)), dim3(256), 0, s, w.state, w.models, w.norm_a,
-                           w.norm_b, n, thr2, w.mask, w.out);
-        DFVO_HIP_CHECK(hipGetLastError());
-        return DFVO_OK;
+    const unsigned R = (unsigned)nrep;
+    hipLaunchKernelGGL(k_e_init_normalise, dim3(cdiv(n > 0 ? n : 1, 256), R), dim3(256), 0, s, B, n, max_iters, a, bx, by);
+    if (n >= 5) {  // count < modelPoints: no model (state->found stays 0)
+        // count == modelPoints would run the kernel once on all points; DF-VO never gets there (N >= 10
+        // is required upstream), treat it through the generic loop with the single possible subset order.
+        int cb[4];
+        chunk_bounds(max_iters, cb);
+        for (int c = 0; c < 3; ++c) {
+            const int it0 = cb[c], it1 = cb[c + 1];
+            if (it1 <= it0) continue;
+            const int nh = it1 - it0;
+            hipLaunchKernelGGL(k_e_subsets, dim3(1), dim3(1), 0, s, B, n, it0, it1);
+            hipLaunchKernelGGL(k_e_stage1, dim3(cdiv(nh, E_STAGE1_LANES), R), dim3(E_STAGE1_LANES), 0, s, B, it0, it1);
+            hipLaunchKernelGGL(k_e_poly, dim3(cdiv(nh, 64), R), dim3(64), 0, s, B, it0, it1);
+            hipLaunchKernelGGL(k_e_stage3, dim3(cdiv(nh, 64), R), dim3(64), 0, s, B, it0, it1);
+            hipLaunchKernelGGL(k_e_score, dim3(cdiv(nh, 4), R), dim3(256), 0, s, B, it0, it1, n, thr2);
+            hipLaunchKernelGGL(k_e_replay, dim3(R), dim3(1), 0, s, B, it0, it1, n, prob);
+        }
     }
-    hipLaunchKernelGGL(k_e_normalise, dim3(cdiv(n, 256)), dim3(256), 0, s, d_pts1, n, a, bx, by, w.norm_a);
-    hipLaunchKernelGGL(k_e_normalise, dim3(cdiv(n, 256)), dim3(256), 0, s, d_pts2, n, a, bx, by, w.norm_b);
-    // count == modelPoints would run the kernel once on all points; DF-VO never gets there (N >= 10
-    // is required upstream), treat it through the generic loop with the single possible subset order.
-    int cb[4];
-    chunk_bounds(max_iters, cb);
-    for (int c = 0; c < 3; ++c) {
-        const int it0 = cb[c], it1 = cb[c + 1];
-        if (it1 <= it0) continue;
-        const int nh = it1 - it0;
-        hipLaunchKernelGGL(k_subsets_plain, dim3(1), dim3(1), 0, s, w.state, w.idx, 5, n, it0, it1);
-        hipLaunchKernelGGL(k_e_stage1, dim3(cdiv(nh, E_STAGE1_LANES)), dim3(E_STAGE1_LANES), 0, s, w.state, w.idx, w.norm_a,
-                           w.norm_b, it0, it1, w.ws, w.ok);
-        hipLaunchKernelGGL(k_e_poly, dim3(cdiv(nh, 64)), dim3(64), 0, s, w.state, it0, it1, w.ws, w.ok);
-        hipLaunchKernelGGL(k_e_stage3, dim3(cdiv(nh, 64)), dim3(64), 0, s, w.state, it0, it1, w.ws, w.ok, w.models,
-                           w.nmodels);
-        hipLaunchKernelGGL(k_e_score, dim3(cdiv(nh, 4)), dim3(256), 0, s, w.state, it0, it1, w.models, w.nmodels,
-                           w.norm_a, w.norm_b, n, thr2, w.counts);
-        hipLaunchKernelGGL(k_replay, dim3(1), dim3(1), 0, s, w.state, w.nmodels, w.counts, 10, it0, it1, n, 5, prob);
-    }
-    hipLaunchKernelGGL(k_e_mask, dim3(cdiv(n > 9 ? n : 9, 256)), dim3(256), 0, s, w.state, w.models, w.norm_a, w.norm_b,
-                       n, thr2, w.mask, w.out);
+    hipLaunchKernelGGL(k_e_mask, dim3(cdiv(n > 9 ? n : 9, 256), R), dim3(256), 0, s, B, n, thr2);
     DFVO_HIP_CHECK(hipGetLastError());
     return DFVO_OK;
+}
+
+int enqueue_find_essential(RansacWorkspace& w, const double* d_pts1, const double* d_pts2, int n, double focal,
+                           double ppx, double ppy, double prob, double threshold, int max_iters, hipStream_t s) {
+    return enqueue_find_essential_batch(&w, &d_pts1, &d_pts2, 1, n, focal, ppx, ppy, prob, threshold, max_iters, s);
 }
 
 // ================================================================================================

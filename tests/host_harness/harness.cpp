@@ -54,6 +54,17 @@ void hh_mt_sample(uint32_t* state, int n_population, int n_samples, int* out) {
     for (int i = 0; i < 624; i++) state[i] = s.key[i];
     state[624] = (uint32_t)s.pos;
 }
+// keys-carried-along variant (what k_kp_cell runs out of LDS); padded so that the 4-wide scans may over-read
+void hh_argpartition_cp(const float* v, int num, int kth, int* tosort) {
+    float* key = new float[num + 8];
+    for (int i = 0; i < num + 8; i++) key[i] = 0.f;
+    for (int i = 0; i < num; i++) {
+        tosort[i] = i;
+        key[4 + i] = v[i];
+    }
+    if (num > 0) sm::kp_introselect_cp<int>(key + 4, tosort, num, kth, 0);
+    delete[] key;
+}
 void hh_argpartition(const float* v, int num, int kth, int* tosort) {
     for (int i = 0; i < num; i++) tosort[i] = i;
     if (num > 0) sm::kp_introselect<int>(v, tosort, num, kth, 0);

@@ -1,0 +1,126 @@
+"""CPU: the per-lane device functions of the HIP solvers (df-vo_amd/csrc/solver_math.h, np_legacy.h,
+kp_select.h), compiled for the host by tests/host_harness, bit-for-bit against the C oracle / numpy.
+This is the no-GPU check of the arithmetic the kernels run one lane at a time; the kernels themselves are
+compared with the oracle in the -m gpu tests."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import cv2_shim
+from oracle import tracker_np as T
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_dp = C.POINTER(C.c_double)
+
+
+def _p(a, t=C.c_double):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+@pytest.fixture(scope="module")
+def hh():
+    d = os.path.join(HERE, "host_harness")
+    subprocess.check_call(["make", "-s", "-C", d])
+    lib = C.CDLL(os.path.join(d, "build", "libhost_harness.so"))
+    lib.hh_five_point.restype = C.c_int
+    lib.hh_ransac_update_num_iters.restype = C.c_int
+    lib.hh_ransac_update_num_iters.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int]
+    return lib
+
+
+@pytest.fixture(scope="module")
+def cv3():
+    """a private handle on the oracle library with plain-pointer prototypes"""
+    cv2_shim.lib()  # builds it when stale
+    lib = C.CDLL(cv2_shim._SO)
+    lib.cv3_five_point.restype = C.c_int
+    lib.cv3_ransac_update_num_iters.restype = C.c_int
+    lib.cv3_ransac_update_num_iters.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int]
+    return lib
+
+
+def test_five_point_lane_matches_oracle(hh, cv3):
+    rng = np.random.default_rng(11)
+    checked = 0
+    for trial in range(200):
+        q1 = rng.normal(0, 0.3, (5, 2))
+        q2 = q1 + rng.normal(0, 0.05, (5, 2))
+        e_h, e_o = np.zeros(90), np.zeros(90)
+        n_h = hh.hh_five_point(_p(q1), _p(q2), _p(e_h))
+        n_o = cv3.cv3_five_point(_p(q1), _p(q2), _p(e_o))
+        assert n_h == n_o
+        assert np.array_equal(e_h[:9 * n_h], e_o[:9 * n_o])  # bit-exact
+        checked += n_h
+    assert checked > 200
+
+
+def test_eig_solvers_match_oracle(hh, cv3):
+    rng = np.random.default_rng(12)
+    for trial in range(50):
+        J = rng.normal(size=(40, 8)) * np.logspace(0, 4, 8)
+        A = np.ascontiguousarray(J.T @ J)
+        b = rng.normal(size=8)
+        x_h, x_o = np.zeros(8), np.zeros(8)
+        hh.hh_solve_eig8(_p(A), _p(b), _p(x_h))
+        cv3.cv3_solve_eig(_p(A), 8, _p(b), _p(x_o))
+        assert np.array_equal(x_h, x_o)
+        i_h, i_o = np.zeros(64), np.zeros(64)
+        hh.hh_invert_eig8(_p(A), _p(i_h))
+        cv3.cv3_invert_eig(_p(A), 8, _p(i_o))
+        assert np.array_equal(i_h, i_o)
+
+
+def test_decompose_and_num_iters_match_oracle(hh, cv3):
+    rng = np.random.default_rng(13)
+    for trial in range(50):
+        E = rng.normal(size=9)
+        out_h = [np.zeros(9), np.zeros(9), np.zeros(3)]
+        out_o = [np.zeros(9), np.zeros(9), np.zeros(3)]
+        hh.hh_decompose_essential(_p(E), *[_p(o) for o in out_h])
+        cv3.cv3_decompose_essential_mat(_p(E), *[_p(o) for o in out_o])
+        for a, b in zip(out_h, out_o):
+            assert np.array_equal(a, b)
+    for ep in [0.0, 0.05, 0.3, 0.7, 0.95, 1.0]:
+        for mp in (4, 5):
+            assert hh.hh_ransac_update_num_iters(0.99, ep, mp, 1000) == cv3.cv3_ransac_update_num_iters(0.99, ep, mp, 1000)
+
+
+def test_mt_shuffle_lane_matches_numpy(hh):
+    for n in (2, 3, 11, 257, 2000):
+        rs = np.random.RandomState(4869 + n)
+        rs.random_sample(7)  # move off the start of a block
+        st = rs.get_state()
+        state = np.concatenate([st[1], [st[2]]]).astype(np.uint32)
+        perm = np.zeros(n, np.int32)
+        hh.hh_mt_shuffle(_p(state, C.c_uint32), n, _p(perm, C.c_int))
+        want = np.arange(n)
+        rs.shuffle(want)
+        assert np.array_equal(perm, want)
+        st2 = rs.get_state()
+        assert np.array_equal(state[:624], st2[1]) and state[624] == st2[2]
+
+
+def test_argpartition_lane_matches_oracle(hh):
+    rng = np.random.default_rng(3)
+    for trial in range(60):
+        n = int(rng.integers(1, 5000))
+        v = rng.random(n).astype(np.float32)
+        if trial % 3 == 0:
+            v = np.round(v * 50) / 50
+        k = min(20, n)
+        tos = np.zeros(n, np.int32)
+        hh.hh_argpartition(_p(v, C.c_float), n, k - 1, _p(tos, C.c_int))
+        assert np.array_equal(tos[:k], T.argpartition_c(v, k - 1)[:k])
+        # the keys-carried-along variant used by k_kp_cell must leave the WHOLE permutation identical
+        tos2 = np.zeros(n, np.int32)
+        hh.hh_argpartition_cp(_p(v, C.c_float), n, k - 1, _p(tos2, C.c_int))
+        assert np.array_equal(tos2, tos)
+    for n, k in [(1, 1), (2, 1), (2, 2), (5, 5), (6, 3), (64, 64), (300, 299), (4000, 2000)]:
+        v = np.round(rng.random(n).astype(np.float32) * 7) / 7  # many ties
+        tos, tos2 = np.zeros(n, np.int32), np.zeros(n, np.int32)
+        hh.hh_argpartition(_p(v, C.c_float), n, k - 1, _p(tos, C.c_int))
+        hh.hh_argpartition_cp(_p(v, C.c_float), n, k - 1, _p(tos2, C.c_int))
+        assert np.array_equal(tos2, tos)
