@@ -2,6 +2,7 @@
  * {ptsetreg.cpp, five-point.cpp, fundam.cpp, triangulate.cpp, levmarq.cpp}.
  * Compile with -ffp-contract=off (OpenCV's generic x86-64 build has no FMA contraction). */
 #include "cv3_calib3d.h"
+#include "cv3_internal.h"
 
 #include <float.h>
 #include <math.h>
@@ -23,19 +24,6 @@ int cv3_ransac_update_num_iters(double p, double ep, int modelPoints, int maxIte
     denom = log(denom);
     return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : cv3_round(num / denom);
 }
-
-typedef struct {
-    int model_points;
-    int model_size; /* doubles per model */
-    /* runKernel: subset points (model_points of them) -> up to max models, returns count */
-    int (*run_kernel)(const void* ctx, const void* ms1, const void* ms2, int count, double* models);
-    /* computeError for all n points */
-    void (*compute_error)(const void* ctx, const void* m1, const void* m2, int n, const double* model, float* err);
-    /* checkSubset (may be NULL = always true) */
-    int (*check_subset)(const void* ctx, const void* ms1, const void* ms2, int count);
-    size_t esz1, esz2; /* bytes per point */
-    const void* ctx;
-} cv3_ransac_cb;
 
 static int ransac_get_subset(const cv3_ransac_cb* cb, const char* m1, const char* m2, int count, char* ms1, char* ms2,
                              cv3_rng* rng, int maxAttempts) {
@@ -76,7 +64,7 @@ static int ransac_find_inliers(const cv3_ransac_cb* cb, const void* m1, const vo
 
 /* RANSACPointSetRegistrator::run; returns 1 on success.  stats (optional): [0] iterations run,
  * [1] winning iteration, [2] winning model index */
-static int ransac_run(const cv3_ransac_cb* cb, const void* m1, const void* m2, int count, double threshold,
+int cv3_ransac_run(const cv3_ransac_cb* cb, const void* m1, const void* m2, int count, double threshold,
                       double confidence, int maxIters, double* model_out, unsigned char* mask_out, int* stats) {
     const int modelPoints = cb->model_points;
     int iter, niters = maxIters > 1 ? maxIters : 1;
@@ -426,7 +414,7 @@ int cv3_find_essential_mat_ex(const double* pts1, const double* pts2, int n, dou
     cb.check_subset = NULL;
     cb.esz1 = cb.esz2 = 2 * sizeof(double);
     int stats[3];
-    int r = ransac_run(&cb, p1, p2, n, threshold, prob, max_iters, E, mask, stats);
+    int r = cv3_ransac_run(&cb, p1, p2, n, threshold, prob, max_iters, E, mask, stats);
     if (iters_run) *iters_run = stats[0];
     if (best_iter) *best_iter = stats[1];
     if (best_model) *best_model = stats[2];
@@ -824,7 +812,7 @@ int cv3_find_homography(const double* pts1, const double* pts2, int n, double ra
         memset(tmask, 1, (size_t)n);
         result = h_run_kernel(NULL, src, dst, n, H) > 0;
     } else {
-        result = ransac_run(&cb, src, dst, n, ransac_thr, confidence, max_iters, H, tmask, NULL);
+        result = cv3_ransac_run(&cb, src, dst, n, ransac_thr, confidence, max_iters, H, tmask, NULL);
     }
     if (result && n > 4) {
         int np = 0;

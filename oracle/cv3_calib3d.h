@@ -58,6 +58,16 @@ void cv3_rodrigues_m2v(const double* R, double* r);
 int cv3_solve_pnp_ransac(const double* obj, const double* img, int n, const double* K, int iterations,
                          double reproj_err, double confidence, double* rvec, double* tvec, int* inliers,
                          int* n_inliers);
+/* pieces of the above, exported for unit tests: epnp::compute_pose on double points (us in pixels),
+ * cvFindExtrinsicCameraParams2 (DLT initialisation + CvLevMarq; -2 = planar case, not implemented),
+ * and the deterministic sin / cos / acos / lambda table the restatement uses in place of libm */
+void cv3_solve_pnp_epnp_f32(const double* K, const float* obj, const float* img, int n, double* rvec, double* tvec);
+void cv3_epnp(const double* K, const double* pws, const double* us, int n, double* R_out, double* t_out);
+int cv3_find_extrinsic(const double* M, const double* m, int n, const double* K, double* rvec, double* tvec, int* stats);
+double cv3_det_sin(double x);
+double cv3_det_cos(double x);
+double cv3_det_acos(double x);
+double cv3_lm_lambda(int lambdaLg10);
 
 #ifdef __cplusplus
 }

@@ -32,6 +32,125 @@ void hh_solve_eig8(const double* A, const double* b, double* x) { sm::solve_eig<
 void hh_invert_eig8(const double* A, double* d) { sm::invert_eig<8>(A, d); }
 }
 
+// ---- PnP fallback lane functions
+#include "../../df-vo_amd/csrc/pnp_math.h"
+extern "C" {
+double hh_det_sin(double x) { return sm::det_sin(x); }
+double hh_det_cos(double x) { return sm::det_cos(x); }
+double hh_det_acos(double x) { return sm::det_acos(x); }
+double hh_lm_lambda(int k) { return sm::lm_lambda(k); }
+void hh_rodrigues_v2m(const double* r, double* R, double* J) { sm::rodrigues_v2m(r, R, J); }
+void hh_rodrigues_m2v(const double* R, double* r) {
+    double ws[21];
+    sm::rodrigues_m2v(R, r, ws);
+}
+void hh_epnp_kernel(const double* K4, const float* obj, const float* img, double* rvec, double* tvec) {
+    double ws[sm::EPNP_WS];
+    sm::epnp_kernel(K4, obj, img, rvec, tvec, ws);
+}
+float hh_pnp_error(const double* rvec, const double* tvec, const double* K4, const float* obj, const float* img) {
+    double R[9];
+    sm::rodrigues_v2m(rvec, R, nullptr);
+    return sm::pnp_error(R, tvec, K4, obj, img);
+}
+// the flow of the refinement kernel (k_pnp_refine) written sequentially on the host with the same lane functions:
+// centroid / covariance planarity test, DLT initialisation, CvLevMarq loop.  Returns 1, or -2 (planar).
+int hh_find_extrinsic(const double* M, const double* m, int n, const double* K4, double* rvec, double* tvec) {
+    const double ifx = 1. / K4[0], ify = 1. / K4[1];
+    double Mc[3] = {0, 0, 0};
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < 3; j++) Mc[j] += M[i * 3 + j];
+    const double inv_n = 1. / n;
+    for (int j = 0; j < 3; j++) Mc[j] *= inv_n;
+    double MM[9], W[3], ut[9], V[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = i; j < 3; j++) {
+            double s = 0;
+            for (int k = 0; k < n; k++) s += (M[k * 3 + i] - Mc[i]) * (M[k * 3 + j] - Mc[j]);
+            MM[i * 3 + j] = MM[j * 3 + i] = s;
+        }
+    sm::svd_square_t<3>(MM, W, ut, V);
+    if (W[2] / W[1] < 1e-3 || n < 4) return -2;
+    double LL[144];
+    for (int a = 0; a < 12; a++)
+        for (int b = a; b < 12; b++) {
+            double s = 0;
+            for (int i = 0; i < n; i++) {
+                double L0[12], L1[12];
+                const double x = -((m[i * 2] - K4[2]) * ifx), y = -((m[i * 2 + 1] - K4[3]) * ify);
+                const double X = M[i * 3], Y = M[i * 3 + 1], Z = M[i * 3 + 2];
+                const double r0[12] = {X, Y, Z, 1., 0., 0., 0., 0., x * X, x * Y, x * Z, x};
+                const double r1[12] = {0., 0., 0., 0., X, Y, Z, 1., y * X, y * Y, y * Z, y};
+                for (int k = 0; k < 12; k++) L0[k] = r0[k], L1[k] = r1[k];
+                s += L0[a] * L0[b];
+                s += L1[a] * L1[b];
+            }
+            LL[a * 12 + b] = LL[b * 12 + a] = s;
+        }
+    double param[6], ws[sm::PNP_DLT_WS];
+    sm::pnp_dlt_finish(LL, param, ws);
+    double JtJ[36], JtErr[6], prev[6], lmws[sm::PNP_LM_WS];
+    double prevErrNorm = DBL_MAX, errNorm = 0;
+    int lambdaLg10 = -3, iters = 0;
+    bool calc_j = true;
+    double* J = new double[12 * n];
+    double* err = new double[2 * n];
+    auto norm_l2 = [](const double* a, int cnt) {
+        double s = 0;
+        int i = 0;
+        for (; i <= cnt - 4; i += 4) s += a[i] * a[i] + a[i + 1] * a[i + 1] + a[i + 2] * a[i + 2] + a[i + 3] * a[i + 3];
+        for (; i < cnt; i++) s += a[i] * a[i];
+        return sqrt(s);
+    };
+    for (;;) {
+        double R[9], dRdr[27];
+        sm::rodrigues_v2m(param, R, calc_j ? dRdr : nullptr);
+        for (int i = 0; i < n; i++) {
+            double u, v, jr[6], jt[6];
+            sm::project_point(R, param + 3, K4, M[i * 3], M[i * 3 + 1], M[i * 3 + 2], &u, &v, dRdr, calc_j ? jr : nullptr,
+                              calc_j ? jt : nullptr);
+            err[2 * i] = u - m[2 * i];
+            err[2 * i + 1] = v - m[2 * i + 1];
+            if (calc_j)
+                for (int j = 0; j < 3; j++) {
+                    J[(2 * i) * 6 + j] = jr[j];
+                    J[(2 * i) * 6 + 3 + j] = jt[j];
+                    J[(2 * i + 1) * 6 + j] = jr[3 + j];
+                    J[(2 * i + 1) * 6 + 3 + j] = jt[3 + j];
+                }
+        }
+        if (calc_j) {
+            sm::mul_transposed_ata(J, 2 * n, 6, JtJ);
+            for (int j = 0; j < 6; j++) {
+                double s = 0;
+                for (int k = 0; k < 2 * n; k++) s += J[k * 6 + j] * err[k];
+                JtErr[j] = s;
+            }
+            for (int i = 0; i < 6; i++) prev[i] = param[i];
+            sm::pnp_lm_step(JtJ, JtErr, lambdaLg10, prev, param, lmws);
+            if (iters == 0) prevErrNorm = norm_l2(err, 2 * n);
+            calc_j = false;
+            continue;
+        }
+        errNorm = norm_l2(err, 2 * n);
+        if (errNorm > prevErrNorm) {
+            if (++lambdaLg10 <= 16) {
+                sm::pnp_lm_step(JtJ, JtErr, lambdaLg10, prev, param, lmws);
+                continue;
+            }
+        }
+        lambdaLg10 = lambdaLg10 - 1 > -16 ? lambdaLg10 - 1 : -16;
+        if (++iters >= 20 || sm::pnp_rel_change6(param, prev) < FLT_EPSILON) break;
+        prevErrNorm = errNorm;
+        calc_j = true;
+    }
+    for (int i = 0; i < 3; i++) rvec[i] = param[i], tvec[i] = param[3 + i];
+    delete[] J;
+    delete[] err;
+    return 1;
+}
+}
+
 // ---- numpy legacy RandomState + argpartition emulation
 #include "../../df-vo_amd/csrc/kp_select.h"
 #include "../../df-vo_amd/csrc/np_legacy.h"

@@ -1,0 +1,139 @@
+"""CPU: the PnP fallback.  (1) the oracle's own restatement (oracle/cv3_pnp.c) against analytic ground truth and
+libm, (2) the per-lane device functions (df-vo_amd/csrc/pnp_math.h, host build) bit-for-bit against the oracle."""
+import ctypes as C
+import math
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import cv2_shim
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+K = np.array([[718.856, 0, 607.19], [0, 718.856, 185.22], [0, 0, 1.0]])
+K4 = np.array([K[0, 0], K[1, 1], K[0, 2], K[1, 2]])
+
+
+def _p(a, t=C.c_double):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+@pytest.fixture(scope="module")
+def hh():
+    d = os.path.join(HERE, "host_harness")
+    subprocess.check_call(["make", "-s", "-C", d])
+    lib = C.CDLL(os.path.join(d, "build", "libhost_harness.so"))
+    for f in ("hh_det_sin", "hh_det_cos", "hh_det_acos"):
+        getattr(lib, f).restype = C.c_double
+        getattr(lib, f).argtypes = [C.c_double]
+    lib.hh_lm_lambda.restype = C.c_double
+    lib.hh_pnp_error.restype = C.c_float
+    return lib
+
+
+@pytest.fixture(scope="module")
+def cv3():
+    cv2_shim.lib()
+    lib = C.CDLL(cv2_shim._SO)
+    for f in ("cv3_det_sin", "cv3_det_cos", "cv3_det_acos"):
+        getattr(lib, f).restype = C.c_double
+        getattr(lib, f).argtypes = [C.c_double]
+    lib.cv3_lm_lambda.restype = C.c_double
+    return lib
+
+
+def scene(seed, n=600, outliers=0.3, noise=0.15):
+    rng = np.random.default_rng(seed)
+    X = np.stack([rng.uniform(-20, 20, n), rng.uniform(-3, 3, n), rng.uniform(5, 60, n)], 1)
+    rv = np.array([0.002, 0.01, 0.001]) * rng.uniform(0.5, 3)
+    t = np.array([0.02, 0.01, 0.8]) * rng.uniform(0.5, 1.5)
+    R = cv2_shim.Rodrigues(rv)[0]
+    Xc = X @ R.T + t
+    uv = (Xc[:, :2] / Xc[:, 2:]) * [K[0, 0], K[1, 1]] + [K[0, 2], K[1, 2]]
+    uv += rng.normal(0, noise, uv.shape)
+    out = rng.random(n) < outliers
+    uv[out] = rng.uniform([0, 0], [1241, 376], (int(out.sum()), 2))
+    return X, uv, rv, t, out
+
+
+def test_deterministic_libm_is_within_one_ulp(cv3):
+    xs = np.concatenate([np.linspace(-7, 7, 4001), np.random.default_rng(0).normal(0, 3, 4000)])
+
+    def ulp(a, b):
+        return abs(a - b) / max(np.spacing(abs(b)), 1e-320)
+    assert max(ulp(cv3.cv3_det_sin(x), math.sin(x)) for x in xs) <= 1.0
+    assert max(ulp(cv3.cv3_det_cos(x), math.cos(x)) for x in xs) <= 1.0
+    xa = np.concatenate([np.linspace(-1, 1, 4001), 1 - np.logspace(-16, 0, 500), -1 + np.logspace(-16, 0, 500)])
+    assert max(ulp(cv3.cv3_det_acos(x), math.acos(x)) for x in xa) <= 1.0
+    # the LM damping table is exp(k * log(10.)) as this platform's libm evaluates it
+    assert all(cv3.cv3_lm_lambda(k) == math.exp(k * math.log(10.0)) for k in range(-16, 17))
+
+
+def test_oracle_solve_pnp_ransac_recovers_the_pose():
+    for seed in (1, 2, 3):
+        X, uv, rv, t, out = scene(seed)
+        ok, r, tt, inl = cv2_shim.solvePnPRansac(X, uv, K, None, iterationsCount=100, reprojectionError=1.0)
+        assert ok
+        assert np.abs(r.ravel() - rv).max() < 2e-3 and np.abs(tt.ravel() - t).max() < 2e-2
+        assert set(inl.ravel()) <= set(np.flatnonzero(~out)) and len(inl) > 0.7 * (~out).sum()  # mask of the best MINIMAL model
+        R = cv2_shim.Rodrigues(r)[0]
+        assert np.abs(cv2_shim.Rodrigues(R)[0].ravel() - r.ravel()).max() < 1e-12
+
+
+def test_lane_libm_and_rodrigues_match_oracle(hh, cv3):
+    rng = np.random.default_rng(5)
+    for x in np.concatenate([rng.normal(0, 3, 3000), [0.0, 1e-9, -1e-9, 0.7853981633974483, 3.141592653589793]]):
+        assert hh.hh_det_sin(x) == cv3.cv3_det_sin(x) and hh.hh_det_cos(x) == cv3.cv3_det_cos(x)
+    for x in np.concatenate([rng.uniform(-1, 1, 3000), [1.0, -1.0, 0.5, -0.5, 0.0, 1 - 1e-12]]):
+        assert hh.hh_det_acos(x) == cv3.cv3_det_acos(x)
+    assert all(hh.hh_lm_lambda(k) == cv3.cv3_lm_lambda(k) for k in range(-16, 17))
+    for trial in range(100):
+        r = rng.normal(0, 0.6, 3) if trial else np.zeros(3)
+        R_h, R_o, r_h, r_o = np.zeros(9), np.zeros(9), np.zeros(3), np.zeros(3)
+        hh.hh_rodrigues_v2m(_p(r), _p(R_h), None)
+        cv3.cv3_rodrigues_v2m(_p(r), _p(R_o))
+        assert np.array_equal(R_h, R_o)
+        hh.hh_rodrigues_m2v(_p(R_o), _p(r_h))
+        cv3.cv3_rodrigues_m2v(_p(R_o), _p(r_o))
+        assert np.array_equal(r_h, r_o)
+
+
+def test_lane_epnp_kernel_and_error_match_oracle(hh, cv3):
+    X, uv, rv, t, out = scene(7)
+    Xf, uvf = X.astype(np.float32), uv.astype(np.float32)
+    rng = np.random.default_rng(8)
+    for trial in range(200):
+        idx = rng.choice(len(X), 5, replace=False)
+        o, i = np.ascontiguousarray(Xf[idx]), np.ascontiguousarray(uvf[idx])
+        r_h, t_h, r_o, t_o = np.zeros(3), np.zeros(3), np.zeros(3), np.zeros(3)
+        hh.hh_epnp_kernel(_p(K4), _p(o, C.c_float), _p(i, C.c_float), _p(r_h), _p(t_h))
+        cv3.cv3_solve_pnp_epnp_f32(_p(K), _p(o, C.c_float), _p(i, C.c_float), 5, _p(r_o), _p(t_o))
+        assert np.array_equal(r_h, r_o) and np.array_equal(t_h, t_o)  # bit-exact
+    # reprojection error of single correspondences vs numpy in float32 at the documented conversion points
+    R = cv2_shim.Rodrigues(rv)[0]
+    for k in range(50):
+        e = hh.hh_pnp_error(_p(rv), _p(t), _p(K4), _p(np.ascontiguousarray(Xf[k]), C.c_float),
+                            _p(np.ascontiguousarray(uvf[k]), C.c_float))
+        xc = R @ Xf[k].astype(np.float64) + t
+        pr = np.array([xc[0] / xc[2] * K4[0] + K4[2], xc[1] / xc[2] * K4[1] + K4[3]])
+        assert abs(e - float(((uvf[k] - pr.astype(np.float32)) ** 2).sum())) <= 1e-3 * max(1.0, e)
+
+
+def test_lane_refinement_flow_matches_oracle(hh, cv3):
+    for seed in (11, 12, 13):
+        X, uv, rv, t, out = scene(seed, n=400, outliers=0.0, noise=0.3)
+        Xd = np.ascontiguousarray(X.astype(np.float32).astype(np.float64))
+        ud = np.ascontiguousarray(uv.astype(np.float32).astype(np.float64))
+        r_h, t_h, r_o, t_o = np.zeros(3), np.zeros(3), np.zeros(3), np.zeros(3)
+        rc_h = hh.hh_find_extrinsic(_p(Xd), _p(ud), len(Xd), _p(K4), _p(r_h), _p(t_h))
+        rc_o = cv3.cv3_find_extrinsic(_p(Xd), _p(ud), len(Xd), _p(K), _p(r_o), _p(t_o), None)
+        assert rc_h == rc_o == 1
+        assert np.array_equal(r_h, r_o) and np.array_equal(t_h, t_o)  # bit-exact
+        assert np.abs(r_o - rv).max() < 2e-3 and np.abs(t_o - t).max() < 3e-2
+    # coplanar object points take the (unimplemented) planar branch on both sides
+    X, uv, rv, t, out = scene(14, n=50, outliers=0.0)
+    X[:, 2] = 10.0
+    r_h, t_h = np.zeros(3), np.zeros(3)
+    assert hh.hh_find_extrinsic(_p(X), _p(np.ascontiguousarray(uv)), 50, _p(K4), _p(r_h), _p(t_h)) == -2
+    assert cv3.cv3_find_extrinsic(_p(X), _p(np.ascontiguousarray(uv)), 50, _p(K), _p(r_h), _p(t_h), None) == -2
