@@ -35,6 +35,17 @@ class ScaleCfg(C.Structure):
                 ("min_samples", C.c_int), ("max_trials", C.c_int), ("stop_prob", C.c_double), ("thre", C.c_double)]
 
 
+class Pose3d2dCfg(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("Kinv", C.c_double * 9), ("min_depth", C.c_double), ("max_depth", C.c_double),
+                ("repeat", C.c_int), ("iters", C.c_int), ("reproj_thre", C.c_double)]
+
+
+class Pose3d2dOut(C.Structure):
+    _fields_ = [("found", C.c_int), ("best_inliers", C.c_int), ("n_filtered", C.c_int), ("status", C.c_int),
+                ("rvec", C.c_double * 3), ("tvec", C.c_double * 3), ("R", C.c_double * 9)]
+
+
 class PipelineCfg(C.Structure):
     _fields_ = [("img_h", C.c_int), ("img_w", C.c_int), ("feed_h", C.c_int), ("feed_w", C.c_int),
                 ("net_min_depth", C.c_float), ("net_max_depth", C.c_float), ("baseline_mult", C.c_float),
@@ -126,6 +137,7 @@ SIGNATURES = {
     "dfvo_pipeline_sync": (_i, [_vp]),
     "dfvo_pipeline_net_flops": (_d, [_vp]),
     "dfvo_find_scale_from_depth": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, C.POINTER(ScaleCfg), C.POINTER(_d), _vp]),
+    "dfvo_compute_pose_3d2d": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, C.POINTER(Pose3d2dCfg), C.POINTER(Pose3d2dOut), _vp]),
 }
 
 

@@ -18,6 +18,7 @@ struct dfvo_tracker {
     double* d_small = nullptr;  // 64 doubles
     double *d_x1 = nullptr, *d_x2 = nullptr, *d_X4 = nullptr;
     int tri_cap = 0;
+    PnpBuffers pnp;
 };
 
 extern "C" {
@@ -48,6 +49,7 @@ int dfvo_tracker_create(void* stream, dfvo_tracker** out) {
 void dfvo_tracker_destroy(dfvo_tracker* t) {
     if (!t) return;
     t->tb.release();
+    t->pnp.release();
     if (t->d_flow) (void)hipFree(t->d_flow);
     if (t->d_diff) (void)hipFree(t->d_diff);
     if (t->d_depth) (void)hipFree(t->d_depth);
@@ -288,6 +290,52 @@ int dfvo_find_scale_from_depth(dfvo_tracker* t, const double* h_kp1, const doubl
         h_info[2] = sr.n_inliers;
         h_info[3] = sr.status;
     }
+    return DFVO_OK;
+}
+
+int dfvo_compute_pose_3d2d(dfvo_tracker* t, const double* h_kp1, const double* h_kp2, int n, const double* h_depth,
+                           int H, int W, const dfvo_pose3d2d_cfg* cfg, dfvo_pose3d2d_out* out, uint8_t* h_keep) {
+    DFVO_ARG_CHECK(t && h_kp1 && h_kp2 && h_depth && cfg && out && n >= 0 && H > 0 && W > 0,
+                   "dfvo_compute_pose_3d2d: bad argument");
+    DFVO_ARG_CHECK(cfg->repeat >= 1 && cfg->repeat <= MAX_REP && cfg->iters >= 1, "dfvo_compute_pose_3d2d: repeat/iters");
+    int rc = stage_kp(t, h_kp1, h_kp2, n);  // kp1 -> tb.kp_ref, kp2 -> tb.kp_cur
+    if (rc != DFVO_OK) return rc;
+    const size_t px = (size_t)H * W;
+    if (px > t->depth_cap) {
+        if (t->d_depth) (void)hipFree(t->d_depth);
+        t->depth_cap = px;
+        DFVO_HIP_CHECK(hipMalloc((void**)&t->d_depth, sizeof(double) * px));
+    }
+    DFVO_HIP_CHECK(hipMemcpyAsync(t->d_depth, h_depth, sizeof(double) * px, hipMemcpyHostToDevice, t->stream));
+    PnpConfig pc;
+    pc.fx = cfg->fx;
+    pc.fy = cfg->fy;
+    pc.cx = cfg->cx;
+    pc.cy = cfg->cy;
+    for (int i = 0; i < 9; i++) pc.inv_K[i] = cfg->Kinv[i];
+    pc.min_depth = cfg->min_depth;
+    pc.max_depth = cfg->max_depth;
+    pc.repeat = cfg->repeat;
+    pc.iters = cfg->iters;
+    pc.reproj_thre = cfg->reproj_thre;
+    rc = enqueue_compute_pose_3d2d(t->pnp, t->tb.mt_state, t->tb.kp_ref, t->tb.kp_cur, nullptr, n, t->d_depth, H, W, pc,
+                                   t->stream);
+    if (rc != DFVO_OK) return rc;
+    PnpResult res;
+    DFVO_HIP_CHECK(hipMemcpyAsync(&res, t->pnp.result, sizeof(res), hipMemcpyDeviceToHost, t->stream));
+    if (h_keep && n > 0) DFVO_HIP_CHECK(hipMemcpyAsync(h_keep, t->pnp.keep, (size_t)n, hipMemcpyDeviceToHost, t->stream));
+    DFVO_HIP_CHECK(hipStreamSynchronize(t->stream));
+    out->found = res.found;
+    out->best_inliers = res.best_inliers;
+    out->n_filtered = res.n_filtered;
+    out->status = res.status;
+    for (int i = 0; i < 3; i++) {
+        out->rvec[i] = res.rvec[i];
+        out->tvec[i] = res.tvec[i];
+    }
+    for (int i = 0; i < 9; i++) out->R[i] = res.R[i];
+    DFVO_ARG_CHECK(res.status != -2, "dfvo_compute_pose_3d2d: coplanar object points (planar initialisation of "
+                                     "cvFindExtrinsicCameraParams2 is not implemented)");
     return DFVO_OK;
 }
 

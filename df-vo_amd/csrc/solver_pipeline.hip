@@ -800,6 +800,26 @@ int enqueue_mt_seed(TrackerBuffers& tb, uint32_t seed, hipStream_t s) {
     return DFVO_OK;
 }
 
+// `repeat` x (perm = np.arange(n); np.random.shuffle(perm)) from the device-resident numpy stream `mt_state`;
+// n = *d_n on the device (n_host bounds it), perm[r * perm_stride + i]
+int enqueue_mt_shuffle(uint32_t* mt_state, const int* d_n, int n_host, int repeat, int perm_stride, int* perm,
+                       hipStream_t s) {
+    const size_t per_rep = 6 * (size_t)(n_host > 0 ? n_host : 1);  // int permutation + uint16 draw list
+    DFVO_ARG_CHECK(per_rep <= 144 * 1024, "shuffle: too many keypoints for the LDS permutation buffer");
+    int group = (int)((144 * 1024) / per_rep);
+    if (group > repeat) group = repeat;
+    const size_t perm_lds = per_rep * group + 16;
+    static size_t configured = 0;
+    if (perm_lds > configured) {
+        DFVO_HIP_CHECK(hipFuncSetAttribute((const void*)k_mt_shuffle_all, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)perm_lds));
+        configured = perm_lds;
+    }
+    hipLaunchKernelGGL(k_mt_shuffle_all, dim3(1), dim3(256), perm_lds, s, mt_state, d_n, repeat, group, perm_stride, perm);
+    DFVO_HIP_CHECK(hipGetLastError());
+    return DFVO_OK;
+}
+
 // EssTracker.compute_pose_2d2d with validity.method == "GRIC" on tb.kp_ref / tb.kp_cur (n = kp_info[0] on the
 // device, n_host = upper bound known to the host for launch sizing).
 // small[] layout: [0..8] KinvT, [9..17] Kinv, [18] H_gric, [19] E_gric
@@ -821,24 +841,13 @@ int enqueue_compute_pose_2d2d(TrackerBuffers& tb, int n_host, const PoseConfig& 
         const int cap = tb.kp_cap;
         // all shuffles first (one sequential RNG chain), then the `repeat` RANSACs run concurrently on
         // their own streams while the homography runs on `s`
-        const size_t per_rep = 6 * (size_t)n_host;  // int permutation + uint16 draw list
-        DFVO_ARG_CHECK(per_rep <= 144 * 1024, "compute_pose_2d2d: too many keypoints for the LDS permutation buffer");
-        int group = (int)((144 * 1024) / per_rep);
-        if (group > cfg.repeat) group = cfg.repeat;
-        const size_t perm_lds = per_rep * group + 16;
-        static size_t configured = 0;
-        if (perm_lds > configured) {
-            DFVO_HIP_CHECK(hipFuncSetAttribute((const void*)k_mt_shuffle_all, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)perm_lds));
-            configured = perm_lds;
-        }
         // the shuffle chain runs on s_rep[0] so that the homography (on s) starts at once
         DFVO_HIP_CHECK(hipEventRecord(tb.ev_start, s));
         DFVO_HIP_CHECK(hipStreamWaitEvent(tb.s_rep[0], tb.ev_start, 0));
         hipStream_t sr = tb.s_rep[0];
         const unsigned R = (unsigned)cfg.repeat;
-        hipLaunchKernelGGL(k_mt_shuffle_all, dim3(1), dim3(256), perm_lds, sr, tb.mt_state, tb.kp_info, cfg.repeat, group,
-                           cap + 8, tb.perm);
+        int rc = enqueue_mt_shuffle(tb.mt_state, tb.kp_info, n_host, cfg.repeat, cap + 8, tb.perm, sr);
+        if (rc != DFVO_OK) return rc;
         hipLaunchKernelGGL(k_permute_points, dim3(nb, R), dim3(256), 0, sr, tb.kp_info, tb.perm, cap + 8, tb.kp_cur,
                            tb.kp_ref, tb.pa, tb.pb, 2 * cap);
         // the `repeat` five-point RANSACs as one batched launch sequence (blockIdx.y = repeat)
@@ -848,7 +857,7 @@ int enqueue_compute_pose_2d2d(TrackerBuffers& tb, int n_host, const PoseConfig& 
             pas[rep] = tb.pa + (size_t)rep * 2 * cap;
             pbs[rep] = tb.pb + (size_t)rep * 2 * cap;
         }
-        int rc = enqueue_find_essential_batch(tb.ws_rep, pas, pbs, cfg.repeat, n_host, cfg.fx, cfg.cx, cfg.cy, 0.99,
+        rc = enqueue_find_essential_batch(tb.ws_rep, pas, pbs, cfg.repeat, n_host, cfg.fx, cfg.cx, cfg.cy, 0.99,
                                               cfg.reproj_thre, cfg.max_iters, sr);
         if (rc != DFVO_OK) return rc;
         for (int rep = 0; rep < MAX_E_BATCH; ++rep) G.E[rep] = rep < cfg.repeat ? tb.ws_rep[rep].out : nullptr;

@@ -1,0 +1,639 @@
+// PnP fallback of the tracker on the device: PnpTracker.compute_pose_3d2d
+// (/root/reference/libs/tracker/pnp_tracker.py:45-125) = keypoint filtering + unprojection
+// (ops_3d.py:70-94), `repeat` x [np.random.shuffle, cv2.solvePnPRansac(iter, reproj_thre)], best by inlier
+// count, cv2.Rodrigues.  The numerics follow oracle/cv3_pnp.c statement for statement (see pnp_math.h);
+// the parallel decomposition is the one of the five-point path:
+//   * the `repeat` problems form one batch (blockIdx.y = repeat) on one stream, subset draws shared;
+//   * one EPnP hypothesis per lane (k_pnp_solve; dense 12x12 work in per-lane LDS slices);
+//   * one hypothesis per wavefront for reprojection scoring (k_pnp_score), ds_swizzle count reduction;
+//   * single-lane replay of the sequential accept / RANSACUpdateNumIters scan;
+//   * refinement on the inliers (cvFindExtrinsicCameraParams2: DLT + CvLevMarq) by one workgroup per
+//     repeat: points are expanded to rows in LDS by all lanes, every sum that the CPU forms sequentially is
+//     owned by one lane that walks the rows in the same order (k_pnp_refine).
+// Built with -ffp-contract=off.
+#include <cstring>
+
+#include "pnp_math.h"
+#include "ransac_dev.h"
+#include "tracker.h"
+
+namespace dfvo {
+
+struct PRep {
+    RansacState* state;
+    const float *obj, *img;  // shuffled float32 points [n][3], [n][2]
+    double* models;          // [iters][6] = rvec | tvec
+    int *nmodels, *counts;   // [iters]
+    uint8_t* mask;           // [n]
+    float* pts5;             // compacted inliers [n][5] = X Y Z u v
+    PnpRepOut* out;
+};
+struct PBatch {
+    int nrep;
+    const int* n_ptr;  // filtered keypoint count (device)
+    int* idx;          // shared subset indices [iters][5]
+    double K4[4];
+    PRep r[MAX_REP];
+};
+
+// ------------------------------------------------------------------------------------------------
+// filtering + unprojection: ordered compaction of the keypoints that survive the three reference masks
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pnp_filter(const double* __restrict__ kp1, const double* __restrict__ kp2,
+                                                     const int* __restrict__ n_in_ptr, int n_in_host,
+                                                     const double* __restrict__ depth, int H, int W, PnpConfig cfg,
+                                                     double* __restrict__ fk1, double* __restrict__ fk2,
+                                                     double* __restrict__ xyz, uint8_t* __restrict__ keep,
+                                                     int* __restrict__ info) {
+    __shared__ int s_base, s_wave[4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n = n_in_ptr ? *n_in_ptr : n_in_host;
+    if (t == 0) s_base = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += 256) {
+        const int i = c0 + t;
+        bool f = false;
+        double x1 = 0, y1 = 0, x2 = 0, y2 = 0, d = 0;
+        if (i < n) {
+            x1 = kp1[i * 2];
+            y1 = kp1[i * 2 + 1];
+            x2 = kp2[i * 2];
+            y2 = kp2[i * 2 + 1];
+            f = (x2 >= 0) && (x2 < W) && (y2 >= 0) && (y2 < H);
+            if (f) {
+                int xi = (int)x1, yi = (int)y1;  // astype(int): truncation; python wraps negative indices
+                if (xi < 0) xi += W;
+                if (yi < 0) yi += H;
+                f = xi >= 0 && xi < W && yi >= 0 && yi < H;
+                if (f) {
+                    d = depth[(size_t)yi * W + xi];
+                    f = (d != 0) && (d < cfg.max_depth) && (d > cfg.min_depth);
+                }
+            }
+        }
+        if (i < n) keep[i] = f ? 1 : 0;
+        const unsigned long long b = __ballot(f);
+        if (lane == 0) s_wave[wave] = __popcll(b);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wave; w++) off += s_wave[w];
+        if (f) {
+            const int o = off + __popcll(b & ((1ull << lane) - 1ull));
+            fk1[o * 2] = x1;
+            fk1[o * 2 + 1] = y1;
+            fk2[o * 2] = x2;
+            fk2[o * 2 + 1] = y2;
+            // unprojection_kp: (inv_K @ [x, y, 1]) * depth, row by row, left to right
+            const double* iK = cfg.inv_K;
+            const double X = iK[0] * x1 + iK[1] * y1 + iK[2] * 1.0;
+            const double Y = iK[3] * x1 + iK[4] * y1 + iK[5] * 1.0;
+            const double Z = iK[6] * x1 + iK[7] * y1 + iK[8] * 1.0;
+            xyz[o * 3] = X * d;
+            xyz[o * 3 + 1] = Y * d;
+            xyz[o * 3 + 2] = Z * d;
+        }
+        __syncthreads();
+        if (t == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+    if (t == 0) info[0] = s_base;
+}
+
+// new_XYZ = XYZ[perm], new_kp2 = kp2[perm], converted to float32 as solvePnPRansac does (blockIdx.y = repeat)
+__global__ void k_pnp_permute(const int* __restrict__ n_ptr, const int* __restrict__ perm, int perm_stride,
+                              const double* __restrict__ xyz, const double* __restrict__ fk2, float* __restrict__ obj,
+                              float* __restrict__ img, int cap) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *n_ptr) return;
+    const int p = perm[(size_t)blockIdx.y * perm_stride + i];
+    float* o = obj + ((size_t)blockIdx.y * cap + i) * 3;
+    float* m = img + ((size_t)blockIdx.y * cap + i) * 2;
+    o[0] = (float)xyz[p * 3];
+    o[1] = (float)xyz[p * 3 + 1];
+    o[2] = (float)xyz[p * 3 + 2];
+    m[0] = (float)fk2[p * 2];
+    m[1] = (float)fk2[p * 2 + 1];
+}
+
+// ------------------------------------------------------------------------------------------------
+// RANSAC
+// ------------------------------------------------------------------------------------------------
+__global__ void k_pnp_init(const PBatch B, int max_iters) {
+    if (threadIdx.x != 0) return;
+    RansacState* st = B.r[blockIdx.x].state;
+    const int n = *B.n_ptr;
+    st->rng_state = 0xffffffffffffffffULL;
+    st->niters = max_iters > 1 ? max_iters : 1;
+    st->iter = 0;
+    st->max_good = 0;
+    st->best_iter = -1;
+    st->best_model = -1;
+    st->done = n > 4 ? 0 : 1;  // the reference only calls solvePnPRansac with more than 4 points
+    st->subset_fail_at = -1;
+    st->found = 0;
+}
+
+// one lane: the subset draws of iterations [it0, it1), shared by the batch (same seed, same count)
+__global__ void k_pnp_subsets(const PBatch B, int it0, int it1) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    bool all_done = true;
+    for (int r = 0; r < B.nrep; ++r) all_done = all_done && B.r[r].state->done;
+    if (all_done) return;
+    const int count = *B.n_ptr;
+    if (count == 5) {  // count == modelPoints: the kernel runs once on all points, nothing is drawn
+        for (int i = 0; i < 5; i++) B.idx[i] = i;
+        return;
+    }
+    sm::CvRng rng;
+    rng.state = B.r[0].state->rng_state;
+    for (int it = it0; it < it1; ++it) {
+        int* id = B.idx + it * 5;
+        for (int i = 0; i < 5;) {
+            int v, j;
+            for (;;) {
+                v = id[i] = sm::cvrng_uniform(rng, 0, count);
+                for (j = 0; j < i; j++)
+                    if (v == id[j]) break;
+                if (j == i) break;
+            }
+            i++;
+        }
+    }
+    for (int r = 0; r < B.nrep; ++r) B.r[r].state->rng_state = rng.state;
+}
+
+constexpr int PNP_SOLVE_LANES = 8;
+constexpr int PNP_SOLVE_STRIDE = sm::EPNP_WS + 1;
+__global__ __launch_bounds__(PNP_SOLVE_LANES) void k_pnp_solve(const PBatch B, int it0, int it1) {
+    __shared__ double s_ws[PNP_SOLVE_LANES * PNP_SOLVE_STRIDE];
+    const PRep& R = B.r[blockIdx.y];
+    const int it = it0 + blockIdx.x * PNP_SOLVE_LANES + threadIdx.x;
+    if (R.state->done || it >= it1) return;
+    if (*B.n_ptr == 5 && it > 0) return;  // count == modelPoints: one kernel run
+    float obj[15], img[10];
+    for (int i = 0; i < 5; i++) {
+        const int k = B.idx[it * 5 + i];
+        obj[i * 3] = R.obj[k * 3];
+        obj[i * 3 + 1] = R.obj[k * 3 + 1];
+        obj[i * 3 + 2] = R.obj[k * 3 + 2];
+        img[i * 2] = R.img[k * 2];
+        img[i * 2 + 1] = R.img[k * 2 + 1];
+    }
+    double rvec[3], tvec[3];
+    sm::epnp_kernel(B.K4, obj, img, rvec, tvec, s_ws + threadIdx.x * PNP_SOLVE_STRIDE);
+    double* m = R.models + (size_t)it * 6;
+    for (int i = 0; i < 3; i++) {
+        m[i] = rvec[i];
+        m[3 + i] = tvec[i];
+    }
+    R.nmodels[it] = 1;
+}
+
+// one wavefront per hypothesis: squared reprojection error of every correspondence
+__global__ __launch_bounds__(256) void k_pnp_score(const PBatch B, int it0, int it1, float thr2) {
+    const PRep& R = B.r[blockIdx.y];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int it = it0 + blockIdx.x * 4 + wave;
+    if (R.state->done || it >= it1) return;
+    const int n = *B.n_ptr;
+    if (n == 5) return;  // count == modelPoints: accepted without scoring
+    const double* m = R.models + (size_t)it * 6;
+    double Rm[9];
+    sm::rodrigues_v2m(m, Rm, nullptr);
+    const double tv[3] = {m[3], m[4], m[5]};
+    int cnt = 0;
+    for (int i = lane; i < n; i += 64) {
+        const float e = sm::pnp_error(Rm, tv, B.K4, R.obj + (size_t)i * 3, R.img + (size_t)i * 2);
+        cnt += (e <= thr2) ? 1 : 0;
+    }
+    const int s = wave_sum(cnt);
+    if (lane == 0) R.counts[it] = s;
+}
+
+__global__ void k_pnp_replay(const PBatch B, int it0, int it1, double confidence) {
+    if (threadIdx.x != 0) return;
+    const PRep& R = B.r[blockIdx.x];
+    if (*B.n_ptr == 5) {  // count == modelPoints: the single model is accepted, every point is an inlier
+        RansacState* st = R.state;
+        if (st->done) return;
+        st->best_iter = 0;
+        st->best_model = 0;
+        st->max_good = 5;
+        st->iter = 1;
+        st->done = 1;
+        st->found = 1;
+        return;
+    }
+    ransac_replay(R.state, R.nmodels, R.counts, 1, it0, it1, *B.n_ptr, 5, confidence);
+}
+
+__global__ void k_pnp_mask(const PBatch B, float thr2) {
+    const PRep& R = B.r[blockIdx.y];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = *B.n_ptr;
+    if (i >= n) return;
+    if (!R.state->found) {
+        R.mask[i] = 0;
+        return;
+    }
+    if (n == 5) {
+        R.mask[i] = 1;
+        return;
+    }
+    const double* m = R.models + (size_t)R.state->best_iter * 6;
+    double Rm[9];
+    sm::rodrigues_v2m(m, Rm, nullptr);
+    const double tv[3] = {m[3], m[4], m[5]};
+    const float e = sm::pnp_error(Rm, tv, B.K4, R.obj + (size_t)i * 3, R.img + (size_t)i * 2);
+    R.mask[i] = e <= thr2 ? 1 : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// refinement on the inliers: cvFindExtrinsicCameraParams2 (one workgroup per repeat)
+// ------------------------------------------------------------------------------------------------
+constexpr int PR_CHUNK = 256;
+constexpr int PR_ROW = 24;  // doubles per point in the row buffer
+constexpr int PR_UNROLL = 8;
+
+// a += buf[p][i0]*buf[p][i1]; a += buf[p][i2]*buf[p][i3]   per point p, sequentially (products batched)
+__device__ __forceinline__ double pr_acc_two(const double* buf, int cnt, int i0, int i1, int i2, int i3, double a) {
+    int k = 0;
+    for (; k + PR_UNROLL <= cnt; k += PR_UNROLL) {
+        double p0[PR_UNROLL], p1[PR_UNROLL];
+#pragma unroll
+        for (int u = 0; u < PR_UNROLL; ++u) {
+            const double* o = buf + (k + u) * PR_ROW;
+            p0[u] = o[i0] * o[i1];
+            p1[u] = o[i2] * o[i3];
+        }
+#pragma unroll
+        for (int u = 0; u < PR_UNROLL; ++u) {
+            a += p0[u];
+            a += p1[u];
+        }
+    }
+    for (; k < cnt; k++) {
+        const double* o = buf + k * PR_ROW;
+        a += o[i0] * o[i1];
+        a += o[i2] * o[i3];
+    }
+    return a;
+}
+
+__global__ __launch_bounds__(256) void k_pnp_refine(const PBatch B) {
+    __shared__ double s_buf[PR_CHUNK * PR_ROW];  // per-point rows (DLT: 2 x 12, LM: J 2 x 6 + err 2)
+    __shared__ float s_pts[PR_CHUNK * 5];
+    __shared__ double s_ws[sm::PNP_DLT_WS];
+    __shared__ double s_Mc[3], s_MM[9], s_LL[144], s_JtJ[36], s_JtErr[6], s_param[6], s_prev[6], s_R[9], s_dRdr[27];
+    __shared__ double s_errnorm2;
+    __shared__ int s_base, s_wave[4], s_flag;
+    const PRep& R = B.r[blockIdx.x];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    PnpRepOut* out = R.out;
+    if (t == 0) {
+        out->flag = 0;
+        out->n_inliers = 0;
+        out->status = 0;
+        out->lm_iters = 0;
+    }
+    if (!R.state->found) return;
+    const int n = *B.n_ptr;
+    // ---- ordered compaction of the inliers (float points, as solvePnPRansac hands them on)
+    if (t == 0) s_base = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += 256) {
+        const int i = c0 + t;
+        const bool f = i < n && R.mask[i] != 0;
+        const unsigned long long b = __ballot(f);
+        if (lane == 0) s_wave[wave] = __popcll(b);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wave; w++) off += s_wave[w];
+        if (f) {
+            float* p = R.pts5 + (size_t)(off + __popcll(b & ((1ull << lane) - 1ull))) * 5;
+            p[0] = R.obj[(size_t)i * 3];
+            p[1] = R.obj[(size_t)i * 3 + 1];
+            p[2] = R.obj[(size_t)i * 3 + 2];
+            p[3] = R.img[(size_t)i * 2];
+            p[4] = R.img[(size_t)i * 2 + 1];
+        }
+        __syncthreads();
+        if (t == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+    const int np = s_base;
+    __threadfence_block();
+    auto load_chunk = [&](int c0) {  // points [c0, c0 + 256) -> s_pts
+        const int cnt = np - c0 < PR_CHUNK ? np - c0 : PR_CHUNK;
+        for (int k = t; k < cnt * 5; k += 256) s_pts[k] = R.pts5[(size_t)c0 * 5 + k];
+        return cnt;
+    };
+    const double fx = B.K4[0], fy = B.K4[1], cx = B.K4[2], cy = B.K4[3], ifx = 1. / fx, ify = 1. / fy;
+    // ---- centroid (channel sums times 1/n) and covariance of the object points
+    double acc = 0;
+    for (int c0 = 0; c0 < np; c0 += PR_CHUNK) {
+        const int cnt = load_chunk(c0);
+        __syncthreads();
+        if (t < 3)
+            for (int k = 0; k < cnt; k++) acc += (double)s_pts[k * 5 + t];
+        __syncthreads();
+    }
+    if (t < 3) s_Mc[t] = acc * (1. / np);
+    __syncthreads();
+    int ma = 0, mb = 0;  // upper-triangle entry of the 3 x 3 covariance owned by lane t < 6
+    if (t < 6) {
+        const int ia[6] = {0, 0, 0, 1, 1, 2}, ib[6] = {0, 1, 2, 1, 2, 2};
+        ma = ia[t];
+        mb = ib[t];
+    }
+    acc = 0;
+    for (int c0 = 0; c0 < np; c0 += PR_CHUNK) {
+        const int cnt = load_chunk(c0);
+        __syncthreads();
+        if (t < 6) {
+            const double ca = s_Mc[ma], cb = s_Mc[mb];
+            for (int k = 0; k < cnt; k++) acc += ((double)s_pts[k * 5 + ma] - ca) * ((double)s_pts[k * 5 + mb] - cb);
+        }
+        __syncthreads();
+    }
+    if (t < 6) {
+        s_MM[ma * 3 + mb] = acc;
+        s_MM[mb * 3 + ma] = acc;
+    }
+    __syncthreads();
+    if (t == 0) {
+        double* W = s_ws;
+        sm::svd_square_t<3>(s_MM, W, s_ws + 3, s_ws + 12);
+        s_flag = (W[2] / W[1] < 1e-3 || np < 4) ? 1 : 0;
+    }
+    __syncthreads();
+    if (s_flag) {  // planar object points: initialisation branch not implemented (status -2, like the oracle)
+        if (t == 0) out->status = -2;
+        return;
+    }
+    // ---- DLT: LL = L^T L, L = 2 rows per point; lane t < 78 owns upper-triangle entry (la, lb)
+    int la = 0, lb = 0;
+    if (t < 78) {
+        int rem = t;
+        while (rem >= 12 - la) {
+            rem -= 12 - la;
+            la++;
+        }
+        lb = la + rem;
+    }
+    acc = 0;
+    for (int c0 = 0; c0 < np; c0 += PR_CHUNK) {
+        const int cnt = load_chunk(c0);
+        __syncthreads();
+        if (t < cnt) {
+            const double X = s_pts[t * 5], Y = s_pts[t * 5 + 1], Z = s_pts[t * 5 + 2];
+            const double x = -(((double)s_pts[t * 5 + 3] - cx) * ifx), y = -(((double)s_pts[t * 5 + 4] - cy) * ify);
+            double* o = s_buf + t * PR_ROW;
+            o[0] = X; o[1] = Y; o[2] = Z; o[3] = 1.; o[4] = 0.; o[5] = 0.; o[6] = 0.; o[7] = 0.;
+            o[8] = x * X; o[9] = x * Y; o[10] = x * Z; o[11] = x;
+            o[12] = 0.; o[13] = 0.; o[14] = 0.; o[15] = 0.; o[16] = X; o[17] = Y; o[18] = Z; o[19] = 1.;
+            o[20] = y * X; o[21] = y * Y; o[22] = y * Z; o[23] = y;
+        }
+        __syncthreads();
+        if (t < 78) acc = pr_acc_two(s_buf, cnt, la, lb, 12 + la, 12 + lb, acc);
+        __syncthreads();
+    }
+    if (t < 78) {
+        s_LL[la * 12 + lb] = acc;
+        s_LL[lb * 12 + la] = acc;
+    }
+    __syncthreads();
+    if (t == 0) sm::pnp_dlt_finish(s_LL, s_param, s_ws);
+    __syncthreads();
+    // ---- CvLevMarq(6 parameters, 2 np residuals, 20 iterations, FLT_EPSILON)
+    int ja = 0, jb = 0;  // lane t < 21: JtJ entry (ja, jb)
+    if (t < 21) {
+        int rem = t;
+        while (rem >= 6 - ja) {
+            rem -= 6 - ja;
+            ja++;
+        }
+        jb = ja + rem;
+    }
+    // residuals (and Jacobian rows) at s_param: row buffer [0..5] du/dp, [6..11] dv/dp, [12] eu, [13] ev
+    auto pass = [&](bool with_j) {
+        if (t == 0) sm::rodrigues_v2m(s_param, s_R, with_j ? s_dRdr : nullptr);
+        __syncthreads();
+        double a = 0;
+        for (int c0 = 0; c0 < np; c0 += PR_CHUNK) {
+            const int cnt = load_chunk(c0);
+            __syncthreads();
+            if (t < cnt) {
+                double u, v, jr[6], jt[6];
+                sm::project_point(s_R, s_param + 3, B.K4, s_pts[t * 5], s_pts[t * 5 + 1], s_pts[t * 5 + 2], &u, &v, s_dRdr,
+                                  with_j ? jr : nullptr, with_j ? jt : nullptr);
+                double* o = s_buf + t * PR_ROW;
+                o[12] = u - (double)s_pts[t * 5 + 3];
+                o[13] = v - (double)s_pts[t * 5 + 4];
+                if (with_j)
+                    for (int j = 0; j < 3; j++) {
+                        o[j] = jr[j];
+                        o[3 + j] = jt[j];
+                        o[6 + j] = jr[3 + j];
+                        o[9 + j] = jt[3 + j];
+                    }
+            }
+            __syncthreads();
+            if (with_j && t < 21) {
+                a = pr_acc_two(s_buf, cnt, ja, jb, 6 + ja, 6 + jb, a);
+            } else if (with_j && t >= 64 && t < 70) {
+                a = pr_acc_two(s_buf, cnt, t - 64, 12, 6 + t - 64, 13, a);
+            } else if (t == 128) {  // |err|^2, four residuals (two points) per step as cv::norm does
+                int k = 0;
+                for (; k + 1 < cnt; k += 2) {
+                    const double v0 = s_buf[k * PR_ROW + 12], v1 = s_buf[k * PR_ROW + 13];
+                    const double v2 = s_buf[(k + 1) * PR_ROW + 12], v3 = s_buf[(k + 1) * PR_ROW + 13];
+                    a += v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
+                }
+                for (; k < cnt; k++) {  // only the very last point of an odd-sized inlier set
+                    const double v0 = s_buf[k * PR_ROW + 12], v1 = s_buf[k * PR_ROW + 13];
+                    a += v0 * v0;
+                    a += v1 * v1;
+                }
+            }
+            __syncthreads();
+        }
+        if (with_j && t < 21) {
+            s_JtJ[ja * 6 + jb] = a;
+            s_JtJ[jb * 6 + ja] = a;
+        } else if (with_j && t >= 64 && t < 70) {
+            s_JtErr[t - 64] = a;
+        } else if (t == 128) {
+            s_errnorm2 = a;
+        }
+        __syncthreads();
+    };
+    double prevErrNorm = DBL_MAX;
+    int lambdaLg10 = -3, iters = 0;
+    bool calc_j = true;
+    for (;;) {
+        pass(calc_j);
+        if (calc_j) {
+            if (t == 0) {
+                for (int i = 0; i < 6; i++) s_prev[i] = s_param[i];
+                sm::pnp_lm_step(s_JtJ, s_JtErr, lambdaLg10, s_prev, s_param, s_ws);
+            }
+            if (iters == 0) prevErrNorm = sqrt(s_errnorm2);
+            calc_j = false;
+            __syncthreads();
+            continue;
+        }
+        const double errNorm = sqrt(s_errnorm2);
+        if (errNorm > prevErrNorm) {
+            if (++lambdaLg10 <= 16) {
+                if (t == 0) sm::pnp_lm_step(s_JtJ, s_JtErr, lambdaLg10, s_prev, s_param, s_ws);
+                __syncthreads();
+                continue;
+            }
+        }
+        lambdaLg10 = lambdaLg10 - 1 > -16 ? lambdaLg10 - 1 : -16;
+        if (++iters >= 20 || sm::pnp_rel_change6(s_param, s_prev) < FLT_EPSILON) break;
+        prevErrNorm = errNorm;
+        calc_j = true;
+    }
+    if (t == 0) {
+        out->flag = 1;
+        out->n_inliers = np;
+        out->status = 1;
+        out->lm_iters = iters;
+        for (int i = 0; i < 3; i++) {
+            out->rvec[i] = s_param[i];
+            out->tvec[i] = s_param[3 + i];
+        }
+    }
+}
+
+// best repeat by inlier count (first one wins ties), cv2.Rodrigues of its rotation vector
+__global__ void k_pnp_select(const PBatch B, PnpResult* __restrict__ res) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int best = -1, best_inlier = 0, status = 0;
+    for (int r = 0; r < B.nrep; ++r) {
+        const PnpRepOut* o = B.r[r].out;
+        if (o->status < 0) status = o->status;
+        if (o->flag && o->n_inliers > best_inlier) {
+            best = r;
+            best_inlier = o->n_inliers;
+        }
+    }
+    res->found = best >= 0 ? 1 : 0;
+    res->best_inliers = best_inlier;
+    res->n_filtered = *B.n_ptr;
+    res->status = status;
+    for (int i = 0; i < 3; i++) res->rvec[i] = res->tvec[i] = 0;
+    for (int i = 0; i < 9; i++) res->R[i] = (i % 4 == 0) ? 1. : 0.;
+    if (best >= 0) {
+        const PnpRepOut* o = B.r[best].out;
+        for (int i = 0; i < 3; i++) {
+            res->rvec[i] = o->rvec[i];
+            res->tvec[i] = o->tvec[i];
+        }
+        sm::rodrigues_v2m(o->rvec, res->R, nullptr);
+    }
+}
+
+// ================================================================================================
+int PnpBuffers::ensure(int n, int iters) {
+    if (n <= cap && iters <= iters_cap) return DFVO_OK;
+    release();
+    cap = n > cap ? n : cap;
+    iters_cap = iters > iters_cap ? iters : iters_cap;
+    const size_t c = (size_t)cap, it = (size_t)iters_cap;
+    DFVO_HIP_CHECK(hipMalloc((void**)&info, sizeof(int) * 4));
+    DFVO_HIP_CHECK(hipMalloc((void**)&fk1, sizeof(double) * 2 * c));
+    DFVO_HIP_CHECK(hipMalloc((void**)&fk2, sizeof(double) * 2 * c));
+    DFVO_HIP_CHECK(hipMalloc((void**)&xyz, sizeof(double) * 3 * c));
+    DFVO_HIP_CHECK(hipMalloc((void**)&perm, sizeof(int) * MAX_REP * (c + 8)));
+    DFVO_HIP_CHECK(hipMalloc((void**)&obj, sizeof(float) * MAX_REP * 3 * c));
+    DFVO_HIP_CHECK(hipMalloc((void**)&img, sizeof(float) * MAX_REP * 2 * c));
+    DFVO_HIP_CHECK(hipMalloc((void**)&state, sizeof(RansacState) * MAX_REP));
+    DFVO_HIP_CHECK(hipMalloc((void**)&idx, sizeof(int) * 5 * it));
+    DFVO_HIP_CHECK(hipMalloc((void**)&models, sizeof(double) * MAX_REP * 6 * it));
+    DFVO_HIP_CHECK(hipMalloc((void**)&nmodels, sizeof(int) * MAX_REP * it));
+    DFVO_HIP_CHECK(hipMalloc((void**)&counts, sizeof(int) * MAX_REP * it));
+    DFVO_HIP_CHECK(hipMalloc((void**)&mask, MAX_REP * c));
+    DFVO_HIP_CHECK(hipMalloc((void**)&keep, c));
+    DFVO_HIP_CHECK(hipMalloc((void**)&pts5, sizeof(float) * MAX_REP * 5 * c));
+    DFVO_HIP_CHECK(hipMalloc((void**)&rep_out, sizeof(PnpRepOut) * MAX_REP));
+    DFVO_HIP_CHECK(hipMalloc((void**)&result, sizeof(PnpResult)));
+    return DFVO_OK;
+}
+
+void PnpBuffers::release() {
+    void* ptrs[] = {info, fk1, fk2, xyz, perm, obj, img, state, idx, models, nmodels, counts, mask, keep, pts5, rep_out, result};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    info = perm = idx = nmodels = counts = nullptr;
+    fk1 = fk2 = xyz = models = nullptr;
+    obj = img = pts5 = nullptr;
+    state = nullptr;
+    mask = keep = nullptr;
+    rep_out = nullptr;
+    result = nullptr;
+    cap = iters_cap = 0;
+}
+
+// kp1 / kp2: device [n][2] doubles (n = *d_n when d_n != nullptr, else n_host); depth: device f64 [H][W].
+// Results: pb.result (PnpResult), pb.fk1 / pb.fk2 (filtered keypoints, pb.info[0] of them)
+int enqueue_compute_pose_3d2d(PnpBuffers& pb, uint32_t* mt_state, const double* d_kp1, const double* d_kp2,
+                              const int* d_n, int n_host, const double* d_depth, int H, int W, const PnpConfig& cfg,
+                              hipStream_t s) {
+    DFVO_ARG_CHECK(n_host >= 0 && cfg.repeat >= 1 && cfg.repeat <= MAX_REP && cfg.iters >= 1, "compute_pose_3d2d: bad sizes");
+    int rc = pb.ensure(n_host > 8 ? n_host : 8, cfg.iters);
+    if (rc != DFVO_OK) return rc;
+    const int cap = pb.cap;
+    hipLaunchKernelGGL(k_pnp_filter, dim3(1), dim3(256), 0, s, d_kp1, d_kp2, d_n, n_host, d_depth, H, W, cfg, pb.fk1,
+                       pb.fk2, pb.xyz, pb.keep, pb.info);
+    // the shuffles are drawn for every repeat, whatever the point count (pnp_tracker.py:90-92)
+    rc = enqueue_mt_shuffle(mt_state, pb.info, n_host, cfg.repeat, cap + 8, pb.perm, s);
+    if (rc != DFVO_OK) return rc;
+    const int nb = cdiv(n_host > 0 ? n_host : 1, 256);
+    const unsigned R = (unsigned)cfg.repeat;
+    hipLaunchKernelGGL(k_pnp_permute, dim3(nb, R), dim3(256), 0, s, pb.info, pb.perm, cap + 8, pb.xyz, pb.fk2, pb.obj,
+                       pb.img, cap);
+    PBatch B;
+    memset(&B, 0, sizeof(B));
+    B.nrep = cfg.repeat;
+    B.n_ptr = pb.info;
+    B.idx = pb.idx;
+    B.K4[0] = cfg.fx;
+    B.K4[1] = cfg.fy;
+    B.K4[2] = cfg.cx;
+    B.K4[3] = cfg.cy;
+    for (int r = 0; r < cfg.repeat; ++r) {
+        PRep& P = B.r[r];
+        P.state = pb.state + r;
+        P.obj = pb.obj + (size_t)r * cap * 3;
+        P.img = pb.img + (size_t)r * cap * 2;
+        P.models = pb.models + (size_t)r * pb.iters_cap * 6;
+        P.nmodels = pb.nmodels + (size_t)r * pb.iters_cap;
+        P.counts = pb.counts + (size_t)r * pb.iters_cap;
+        P.mask = pb.mask + (size_t)r * cap;
+        P.pts5 = pb.pts5 + (size_t)r * cap * 5;
+        P.out = pb.rep_out + r;
+    }
+    const float thr2 = (float)(cfg.reproj_thre * cfg.reproj_thre);
+    hipLaunchKernelGGL(k_pnp_init, dim3(R), dim3(1), 0, s, B, cfg.iters);
+    int cb[4];
+    chunk_bounds(cfg.iters, cb);
+    for (int c = 0; c < 3; ++c) {
+        const int it0 = cb[c], it1 = cb[c + 1];
+        if (it1 <= it0) continue;
+        const int nh = it1 - it0;
+        hipLaunchKernelGGL(k_pnp_subsets, dim3(1), dim3(1), 0, s, B, it0, it1);
+        hipLaunchKernelGGL(k_pnp_solve, dim3(cdiv(nh, PNP_SOLVE_LANES), R), dim3(PNP_SOLVE_LANES), 0, s, B, it0, it1);
+        hipLaunchKernelGGL(k_pnp_score, dim3(cdiv(nh, 4), R), dim3(256), 0, s, B, it0, it1, thr2);
+        hipLaunchKernelGGL(k_pnp_replay, dim3(R), dim3(1), 0, s, B, it0, it1, 0.99);
+    }
+    hipLaunchKernelGGL(k_pnp_mask, dim3(nb, R), dim3(256), 0, s, B, thr2);
+    hipLaunchKernelGGL(k_pnp_refine, dim3(R), dim3(256), 0, s, B);
+    hipLaunchKernelGGL(k_pnp_select, dim3(1), dim3(1), 0, s, B, pb.result);
+    DFVO_HIP_CHECK(hipGetLastError());
+    return DFVO_OK;
+}
+
+}  // namespace dfvo

@@ -21,24 +21,11 @@
 #include <cstring>
 
 #include "dfvo_common.h"
+#include "ransac_dev.h"
 #include "solver.h"
 #include "solver_math.h"
 
 namespace dfvo {
-
-// ------------------------------------------------------------------------------------------------
-// wave64 integer sum: ds_swizzle butterflies inside 32-lane halves, then one cross-half exchange
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int wave_sum(int v) {
-    // xor 1,2,4,8,16 within 32 lanes (BitMode swizzle: and_mask 0x1f, or 0, xor k)
-    v += __builtin_amdgcn_ds_swizzle(v, 0x041F);
-    v += __builtin_amdgcn_ds_swizzle(v, 0x081F);
-    v += __builtin_amdgcn_ds_swizzle(v, 0x101F);
-    v += __builtin_amdgcn_ds_swizzle(v, 0x201F);
-    v += __builtin_amdgcn_ds_swizzle(v, 0x401F);
-    v += __shfl_xor(v, 32, 64);
-    return v;
-}
 
 // ------------------------------------------------------------------------------------------------
 // shared RANSAC bookkeeping
@@ -56,39 +43,6 @@ __global__ void k_ransac_init(RansacState* st, int max_iters, uint64_t seed) {
     st->found = 0;
 }
 
-// replay of RANSACPointSetRegistrator::run over iterations [it0, it1)
-__device__ void ransac_replay(RansacState* st, const int* __restrict__ nmodels, const int* __restrict__ counts,
-                              int max_models, int it0, int it1, int count, int model_points, double confidence) {
-    if (st->done) return;
-    int iter = st->iter;
-    int niters = st->niters;
-    int max_good = st->max_good;
-    for (; iter < it1 && iter < niters; ++iter) {
-        if (st->subset_fail_at >= 0 && iter >= st->subset_fail_at) {
-            niters = iter;  // getSubset failed: the CPU loop breaks here
-            break;
-        }
-        const int nm = nmodels[iter];
-        for (int m = 0; m < nm; ++m) {
-            const int good = counts[iter * max_models + m];
-            const int lim = max_good > model_points - 1 ? max_good : model_points - 1;
-            if (good > lim) {
-                max_good = good;
-                st->best_iter = iter;
-                st->best_model = m;
-                niters = sm::ransac_update_num_iters(confidence, (double)(count - good) / count, model_points, niters);
-            }
-        }
-    }
-    st->iter = iter;
-    st->niters = niters;
-    st->max_good = max_good;
-    if (iter >= niters) {
-        st->done = 1;
-        st->found = max_good > 0 ? 1 : 0;
-    }
-    (void)it0;
-}
 __global__ void k_replay(RansacState* st, const int* __restrict__ nmodels, const int* __restrict__ counts,
                          int max_models, int it0, int it1, int count, int model_points, double confidence) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -337,12 +291,6 @@ void RansacWorkspace::release() {
     cap_n = cap_iters = 0;
 }
 
-static void chunk_bounds(int max_iters, int* b) {
-    b[0] = 0;
-    b[1] = max_iters < 128 ? max_iters : 128;
-    b[2] = max_iters < 512 ? max_iters : 512;
-    b[3] = max_iters;
-}
 
 // batch of `nrep` problems (workspaces w[r], inputs d_pts1[r]/d_pts2[r], all with n correspondences).
 // Results per problem: w[r].state (RansacState), w[r].out[0..8] = E, w[r].mask[n]

@@ -49,6 +49,48 @@ struct ScaleConfig {
 
 constexpr int MAX_REP = 8;
 
+// PnpTracker.compute_pose_3d2d (solver_pnp.hip)
+struct PnpConfig {
+    double fx, fy, cx, cy;
+    double inv_K[9];  // Intrinsics.inv_mat, row-major
+    double min_depth, max_depth;
+    int repeat;  // number of shuffled solvePnPRansac runs (cfg.pnp_tracker.ransac.repeat, or 3)
+    int iters;   // iterationsCount
+    double reproj_thre;
+};
+struct PnpRepOut {
+    int flag;       // solvePnPRansac returned true
+    int n_inliers;  // inlier.shape[0]
+    int status;     // 1 ok, 0 no model, -2 planar initialisation branch (not implemented)
+    int lm_iters;
+    double rvec[3], tvec[3];
+};
+struct PnpResult {
+    int found;         // len(best_rt) != 0
+    int best_inliers;
+    int n_filtered;    // keypoints that survived the in-image / depth-range masks
+    int status;        // 0, or -2 when a repeat met the planar branch
+    double rvec[3], tvec[3];
+    double R[9];       // cv2.Rodrigues(rvec)
+};
+struct PnpBuffers {
+    int cap = 0, iters_cap = 0;
+    int* info = nullptr;
+    double *fk1 = nullptr, *fk2 = nullptr, *xyz = nullptr;
+    int* perm = nullptr;
+    float *obj = nullptr, *img = nullptr;
+    RansacState* state = nullptr;
+    int* idx = nullptr;
+    double* models = nullptr;
+    int *nmodels = nullptr, *counts = nullptr;
+    uint8_t *mask = nullptr, *keep = nullptr;  // keep[i]: input keypoint i survived the filters
+    float* pts5 = nullptr;
+    PnpRepOut* rep_out = nullptr;
+    PnpResult* result = nullptr;
+    int ensure(int n, int iters);
+    void release();
+};
+
 struct TrackerBuffers {
     RansacWorkspace ws_h, ws_e;          // ws_e: stand-alone findEssentialMat / recoverPose calls
     RansacWorkspace ws_rep[MAX_REP];     // one workspace per repeated findEssentialMat (run concurrently)
@@ -81,6 +123,11 @@ int enqueue_local_bestn(TrackerBuffers& tb, const float* d_flow, const float* d_
                         int num_col, int num_bestN, float thre, hipStream_t s);
 int enqueue_mt_seed(TrackerBuffers& tb, uint32_t seed, hipStream_t s);
 int enqueue_compute_pose_2d2d(TrackerBuffers& tb, int n_host, const PoseConfig& cfg, hipStream_t s);
+int enqueue_mt_shuffle(uint32_t* mt_state, const int* d_n, int n_host, int repeat, int perm_stride, int* perm,
+                       hipStream_t s);
+int enqueue_compute_pose_3d2d(PnpBuffers& pb, uint32_t* mt_state, const double* d_kp1, const double* d_kp2,
+                              const int* d_n, int n_host, const double* d_depth, int H, int W, const PnpConfig& cfg,
+                              hipStream_t s);
 int enqueue_find_scale(TrackerBuffers& tb, int n_host, const double* d_T21, const double* d_depth, int H, int W,
                        const ScaleConfig& cfg, hipStream_t s);
 

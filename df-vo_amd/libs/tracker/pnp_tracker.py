@@ -18,9 +18,6 @@ class PnpTracker:
         """pnp_tracker.py:45-125 -> {'pose': SE3 (view-2 -> view-1), 'kp1', 'kp2'}"""
         import ctypes as C
         lib = capi.lib()
-        if not hasattr(lib, "dfvo_compute_pose_3d2d"):
-            raise capi.DfvoError("PnP tracker (dfvo_compute_pose_3d2d) is not built into libdfvo_hip.so yet; "
-                                 "there is no CPU fallback")
         kp1 = np.ascontiguousarray(kp1, dtype=np.float64)
         kp2 = np.ascontiguousarray(kp2, dtype=np.float64)
         depth_1 = np.ascontiguousarray(depth_1, dtype=np.float64)
@@ -32,18 +29,21 @@ class PnpTracker:
                                min_depth=float(self.cfg.depth.min_depth), max_depth=float(self.cfg.depth.max_depth),
                                iters=int(self.cfg.pnp_tracker.ransac.iter),
                                reproj_thre=float(self.cfg.pnp_tracker.ransac.reproj_thre), repeat=repeat)
-        Kinv = np.linalg.inv(np.asarray(cam.mat, dtype=np.float64))
+        Kinv = np.asarray(cam.inv_mat, dtype=np.float64)
         for i in range(9):
             cfg.Kinv[i] = Kinv.flat[i]
-        pose44 = np.eye(4)
+        out = capi.Pose3d2dOut()
         keep = np.zeros(max(n, 1), np.uint8)
-        info = np.zeros(4, np.int32)
         _ctx.push_numpy_rng()
         capi.check(lib.dfvo_compute_pose_3d2d(_ctx.tracker(), capi.as_ptr(kp1), capi.as_ptr(kp2), n,
-                                              capi.as_ptr(depth_1), h, w, C.byref(cfg), capi.as_ptr(pose44),
-                                              capi.as_ptr(keep), capi.as_ptr(info)))
+                                              capi.as_ptr(depth_1), h, w, C.byref(cfg), C.byref(out), capi.as_ptr(keep)))
         _ctx.pull_numpy_rng()
-        pose = SE3(pose44)
+        # format pose (pnp_tracker.py:112-118): identity when no repeat produced a model, then inverted
+        pose = SE3()
+        if out.found:
+            pose.R = np.array(out.R[:]).reshape(3, 3)
+            pose.t = np.array(out.tvec[:]).reshape(3, 1)
+        pose.pose = pose.inv_pose
         sel = keep[:n] == 1
         return {"pose": pose, "kp1": kp1[sel], "kp2": kp2[sel]}
 

@@ -215,6 +215,29 @@ int dfvo_find_scale_from_depth(dfvo_tracker* trk, const double* h_kp1, const dou
                                const double* h_T21, const double* h_depth, int H, int W, const dfvo_scale_cfg* cfg,
                                double* scale, int* h_info);
 
+/* PnpTracker.compute_pose_3d2d (pnp_tracker.py:45-125): masks (kp2 inside the image, depth_1[int(kp1)] != 0 and
+ * in (min_depth, max_depth)), unprojection_kp (ops_3d.py:70-94), `repeat` x [np.random.shuffle +
+ * cv2.solvePnPRansac(iterationsCount = iters, reprojectionError = reproj_thre)], best by inlier count,
+ * cv2.Rodrigues.  h_kp1 / h_kp2 [n][2] doubles, h_depth double [H,W] (depth of view 1).
+ * out->R / tvec: the solvePnP pose (view-1 points -> view-2 camera); the caller inverts it like the reference
+ * does (pose.pose = pose.inv_pose).  h_keep[n] (optional): 1 where the keypoint survived the masks.
+ * Consumes the tracker's RandomState (one shuffle per repeat, drawn even when too few points remain).
+ * Coplanar object points (planar initialisation of cvFindExtrinsicCameraParams2) -> DFVO_ERR_ARG. */
+typedef struct dfvo_pose3d2d_cfg {
+    double fx, fy, cx, cy;
+    double Kinv[9];                 /* Intrinsics.inv_mat, row-major */
+    double min_depth, max_depth;    /* cfg.depth.{min,max}_depth */
+    int repeat;                     /* cfg.pnp_tracker.ransac.repeat if is_iterative else 3 */
+    int iters;                      /* cfg.pnp_tracker.ransac.iter */
+    double reproj_thre;             /* cfg.pnp_tracker.ransac.reproj_thre */
+} dfvo_pose3d2d_cfg;
+typedef struct dfvo_pose3d2d_out {
+    int found, best_inliers, n_filtered, status;
+    double rvec[3], tvec[3], R[9];
+} dfvo_pose3d2d_out;
+int dfvo_compute_pose_3d2d(dfvo_tracker* trk, const double* h_kp1, const double* h_kp2, int n, const double* h_depth,
+                           int H, int W, const dfvo_pose3d2d_cfg* cfg, dfvo_pose3d2d_out* out, uint8_t* h_keep);
+
 /* =====================================================================================
  * Fused per-pair pipeline: images in HBM -> relative pose, everything between on the device
  * (libs/dfvo.py:299-345 deep_model_inference + :121-262 tracking, hybrid E-tracker path).

@@ -146,6 +146,9 @@ def solvePnPRansac(objectPoints, imagePoints, cameraMatrix, distCoeffs, iteratio
     cnt = C.c_int()
     ok = lib().cv3_solve_pnp_ransac(obj, img, n, K, int(iterationsCount), float(reprojectionError), float(confidence),
                                     r, t, inl, C.byref(cnt))
+    if ok < 0:
+        raise NotImplementedError("cv3_solve_pnp_ransac: branch %d of the restatement is not implemented "
+                                  "(-2 planar initialisation, -3 four-point P3P kernel)" % ok)
     if not ok:
         return False, r.reshape(3, 1), t.reshape(3, 1), None
     return True, r.reshape(3, 1), t.reshape(3, 1), inl[:cnt.value].reshape(-1, 1).copy()

@@ -325,3 +325,65 @@ def find_scale_from_depth(kp1, kp2, T_21, depth2, K, min_samples=3, max_trials=1
             diag["n_inliers"] = int(ransac.inlier_mask_.sum())
         return float(ransac.estimator_.coef_[0, 0])
     return -1
+
+
+# ----------------------------------------------------------------------------------------------
+# PnpTracker
+# ----------------------------------------------------------------------------------------------
+def unprojection_kp(kp, kp_depth, inv_K):
+    """ops_3d.py:70-94"""
+    N = kp.shape[0]
+    XYZ = np.ones((N, 3, 1))
+    XYZ[:, :2, 0] = kp
+    inv_K_b = np.ones((1, 3, 3))
+    inv_K_b[0] = inv_K
+    inv_K_b = np.repeat(inv_K_b, N, axis=0)
+    XYZ = np.matmul(inv_K_b, XYZ)[:, :, 0]
+    XYZ[:, 0] = XYZ[:, 0] * kp_depth
+    XYZ[:, 1] = XYZ[:, 1] * kp_depth
+    XYZ[:, 2] = XYZ[:, 2] * kp_depth
+    return XYZ
+
+
+def compute_pose_3d2d(kp1, kp2, depth_1, K, min_depth=0.0, max_depth=50.0, repeat=5, iters=100, reproj_thre=1.0):
+    """pnp_tracker.py:45-125.  Consumes np.random (one shuffle per repeat).  Returns dict(pose 4x4 (view-2 ->
+    view-1, i.e. after the final inversion), R, t of the best solvePnPRansac, kp1, kp2, XYZ, best_inlier)."""
+    height, width = depth_1.shape
+    x_idx = (kp2[:, 0] >= 0) * (kp2[:, 0] < width)
+    kp1 = kp1[x_idx]
+    kp2 = kp2[x_idx]
+    y_idx = (kp2[:, 1] >= 0) * (kp2[:, 1] < height)
+    kp1 = kp1[y_idx]
+    kp2 = kp2[y_idx]
+    kp1_int = kp1.astype(int)
+    kp_depths = depth_1[kp1_int[:, 1], kp1_int[:, 0]]
+    non_zero_mask = (kp_depths != 0)
+    depth_range_mask = (kp_depths < max_depth) * (kp_depths > min_depth)
+    valid_kp_mask = non_zero_mask * depth_range_mask
+    kp1 = kp1[valid_kp_mask]
+    kp2 = kp2[valid_kp_mask]
+    XYZ_kp1 = unprojection_kp(kp1, kp_depths[valid_kp_mask], np.linalg.inv(K))
+    best_rt = []
+    best_inlier = 0
+    for _ in range(repeat):
+        new_list = np.arange(0, kp2.shape[0], 1)
+        np.random.shuffle(new_list)
+        new_XYZ = XYZ_kp1.copy()[new_list]
+        new_kp2 = kp2.copy()[new_list]
+        if new_kp2.shape[0] > 4:
+            flag, r, t, inlier = cv2.solvePnPRansac(objectPoints=new_XYZ, imagePoints=new_kp2, cameraMatrix=K,
+                                                    distCoeffs=None, iterationsCount=iters,
+                                                    reprojectionError=reproj_thre)
+            if flag and inlier.shape[0] > best_inlier:
+                best_rt = [r, t]
+                best_inlier = inlier.shape[0]
+    pose = np.eye(4)
+    R, t = np.eye(3), np.zeros((3, 1))
+    if len(best_rt) != 0:
+        r, t = best_rt
+        R = cv2.Rodrigues(r)[0]
+        pose[:3, :3] = R
+        pose[:3, 3:] = np.asarray(t).reshape(3, 1)
+    pose = np.linalg.inv(pose)
+    return {"pose": pose, "R": R, "t": np.asarray(t).reshape(3, 1), "kp1": kp1, "kp2": kp2, "XYZ": XYZ_kp1,
+            "best_inlier": best_inlier}
