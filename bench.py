@@ -48,10 +48,14 @@ def cpu_baseline(syn, H, W, scenes, n_pairs=2):
         sc = scenes[i % len(scenes)]
         kp = T.local_bestN(sc["flow"], sc["diff"][..., None])
         res = T.compute_pose_2d2d(kp["kp1_best"][0], kp["kp2_best"][0], sc["K"])
+        scale = -1
         if np.linalg.norm(res["t"]) != 0:
             pose = np.eye(4)
             pose[:3, :3], pose[:3, 3:] = res["R"], res["t"]
-            T.find_scale_from_depth(kp["kp1_best"][0], kp["kp2_best"][0], np.linalg.inv(pose), sc["depth_cur"], sc["K"])
+            scale = T.find_scale_from_depth(kp["kp1_best"][0], kp["kp2_best"][0], np.linalg.inv(pose), sc["depth_cur"],
+                                            sc["K"])
+        if np.linalg.norm(res["t"]) == 0 or scale == -1:  # PnP fallback (dfvo.py:225-250)
+            T.compute_pose_3d2d(kp["kp1_best"][0], kp["kp2_best"][0], sc["depth_ref"], sc["K"])
     dt = time.time() - t0
     return {"value": n_pairs / dt, "unit": "frames/s", "cores": int(cores), "kind": "port",
             "sample": "%d frame pairs 1241x376: torch-CPU fp32 monodepth2 + LiteFlowNet (fwd+bwd) and the C/numpy "
@@ -101,6 +105,7 @@ def main():
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     d_ref, d_cur, d_feed = dev(ref), dev(cur), dev(feed)
     d_sc = [(dev(s["flow"]), dev(s["diff"]), dev(s["depth_cur"])) for s in scenes]
+    d_ref_depth = dev(scenes[0]["depth_ref"])
 
     def run(n):
         """software pipeline: the nets of pair k+1 are enqueued before the solver stage of pair k blocks"""
@@ -110,17 +115,14 @@ def main():
         status = np.zeros(n, np.int64)
         if n == 0:
             return rel_all, status
+        pipe.set_ref_depth(depth=d_ref_depth)  # depth of the first reference frame (PnP fallback input)
         pipe.enqueue_nets(0, d_ref, d_cur, d_feed)
         for k in range(n):
             if k + 1 < n:
                 pipe.enqueue_nets((k + 1) % 2, d_ref, d_cur, d_feed)
             f, dd, dp = d_sc[k % len(d_sc)]
-            out = pipe.track(k % 2, f, dd, dp)
-            if out.status == 2:  # PnP fallback not needed on this workload; keep rotation, zero translation
-                rel = np.eye(4)
-                rel[:3, :3] = np.array(out.R[:]).reshape(3, 3)
-            else:
-                rel, _ = pipe.hybrid_pose(out, prev)
+            out = pipe.track(k % 2, f, dd, dp)  # E-tracker, or the PnP fallback when its pose is rejected
+            rel, _ = pipe.hybrid_pose(out, prev)
             prev = rel
             g = pipe.accumulate(g, rel)
             rel_all[k] = rel
@@ -187,7 +189,7 @@ def main():
                        "frames_per_gpu": args.steps, "parallelism": "frame-batch DP x%d, one all-gather of poses" % world,
                        "solver_inputs": "synthetic rigid-scene flow/consistency/depth (random-weight nets give "
                                         "incoherent flow); net outputs are computed in the timed region",
-                       "tracked_by_E": n_e, "gathered_poses": int(gathered.shape[0])},
+                       "tracked_by_E": n_e, "tracked_by_PnP": int((status == 3).sum()), "gathered_poses": int(gathered.shape[0])},
             "roofline": roof, "cpu_baseline": base}
         print(json.dumps(line))
     if dist is not None:

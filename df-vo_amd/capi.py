@@ -55,14 +55,16 @@ class PipelineCfg(C.Structure):
                 ("kp_num_row", C.c_int), ("kp_num_col", C.c_int), ("kp_num_bestN", C.c_int), ("kp_thre", C.c_double),
                 ("e_reproj_thre", C.c_double), ("e_repeat", C.c_int), ("e_max_iters", C.c_int),
                 ("scale_min_samples", C.c_int), ("scale_max_trials", C.c_int), ("scale_stop_prob", C.c_double),
-                ("scale_thre", C.c_double), ("seed", C.c_uint32)]
+                ("scale_thre", C.c_double), ("seed", C.c_uint32), ("pnp_repeat", C.c_int), ("pnp_iters", C.c_int),
+                ("pnp_reproj_thre", C.c_double)]
 
 
 class TrackOut(C.Structure):
     _fields_ = [("R", C.c_double * 9), ("t", C.c_double * 3), ("scale", C.c_double), ("status", C.c_int),
                 ("n_kp", C.c_int), ("good_kp_found", C.c_int), ("best_inlier_cnt", C.c_int), ("num_valid", C.c_int),
                 ("cheirality", C.c_int), ("scale_n_valid", C.c_int), ("scale_n_trials", C.c_int),
-                ("scale_n_inliers", C.c_int)]
+                ("scale_n_inliers", C.c_int), ("pnp_found", C.c_int), ("pnp_inliers", C.c_int),
+                ("pnp_n_filtered", C.c_int)]
 
 
 class ConvDesc(C.Structure):
@@ -133,6 +135,7 @@ SIGNATURES = {
     "dfvo_pipeline_set_graph": (_i, [_vp, _i]),
     "dfvo_pipeline_enqueue_nets": (_i, [_vp, _i, _vp, _vp, _vp]),
     "dfvo_pipeline_track": (_i, [_vp, _i, _vp, _vp, _vp, C.POINTER(TrackOut)]),
+    "dfvo_pipeline_set_ref_depth": (_i, [_vp, _vp, _vp]),
     "dfvo_pipeline_get_flow": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "dfvo_pipeline_sync": (_i, [_vp]),
     "dfvo_pipeline_net_flops": (_d, [_vp]),

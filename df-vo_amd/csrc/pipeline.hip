@@ -25,6 +25,11 @@ struct dfvo_pipeline {
     double* proc_depth[2] = {nullptr, nullptr};
     float* depth_small = nullptr;
     double* d_T21 = nullptr;
+    // PnP fallback: processed depth of the reference frame (= the previous pair's current frame)
+    PnpBuffers pnp;
+    double* ref_depth = nullptr;
+    float* ref_raw = nullptr;
+    bool has_ref_depth = false;
     dfvo_pipeline_cfg cfg;
     bool nets_ready = false;
 };
@@ -96,6 +101,8 @@ int dfvo_pipeline_create(const dfvo_pipeline_cfg* cfg, dfvo_pipeline** out) {
         }
     }
     if (hipMalloc((void**)&p->depth_small, (size_t)p->feedH * p->feedW * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&p->ref_depth, px * sizeof(double)) != hipSuccess ||
+        hipMalloc((void**)&p->ref_raw, px * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&p->d_T21, 16 * sizeof(double)) != hipSuccess) {
         dfvo::set_last_error("dfvo_pipeline_create: hipMalloc failed");
         return fail(DFVO_ERR_HIP);
@@ -119,6 +126,9 @@ void dfvo_pipeline_destroy(dfvo_pipeline* p) {
         if (p->e_depth[i]) (void)hipEventDestroy(p->e_depth[i]);
     }
     if (p->depth_small) (void)hipFree(p->depth_small);
+    if (p->ref_depth) (void)hipFree(p->ref_depth);
+    if (p->ref_raw) (void)hipFree(p->ref_raw);
+    p->pnp.release();
     if (p->d_T21) (void)hipFree(p->d_T21);
     if (p->s_flow) (void)hipStreamDestroy(p->s_flow);
     if (p->s_depth) (void)hipStreamDestroy(p->s_depth);
@@ -187,6 +197,36 @@ int dfvo_pipeline_enqueue_nets(dfvo_pipeline* p, int slot, const uint8_t* d_ref,
     return DFVO_OK;
 }
 
+int dfvo_pipeline_set_ref_depth(dfvo_pipeline* p, const uint8_t* d_feed, const double* d_depth_override) {
+    DFVO_ARG_CHECK(p && p->nets_ready && ((d_feed != nullptr) != (d_depth_override != nullptr)),
+                   "dfvo_pipeline_set_ref_depth: exactly one of d_feed / d_depth_override");
+    const size_t px = (size_t)p->H * p->W;
+    if (d_depth_override) {
+        DFVO_HIP_CHECK(hipMemcpyAsync(p->ref_depth, d_depth_override, px * sizeof(double), hipMemcpyDeviceToDevice, p->s_trk));
+        DFVO_HIP_CHECK(hipStreamSynchronize(p->s_trk));
+    } else {
+        P_TRY(p->depth.forward(d_feed, p->depth_small));
+        const dfvo_pipeline_cfg& c = p->cfg;
+        const int y0 = (int)(p->H * c.depth_crop[0]), y1 = (int)(p->H * c.depth_crop[1]);
+        const int x0 = (int)(p->W * c.depth_crop[2]), x1 = (int)(p->W * c.depth_crop[3]);
+        P_TRY(launch_depth_post(p->depth_small, p->feedH, p->feedW, p->H, p->W, y0, y1, x0, x1, (float)c.min_depth,
+                                (float)c.max_depth, p->ref_raw, p->ref_depth, p->s_depth));
+        DFVO_HIP_CHECK(hipStreamSynchronize(p->s_depth));
+    }
+    p->has_ref_depth = true;
+    return DFVO_OK;
+}
+
+// the current frame's depth becomes the reference depth of the next pair (dfvo.py:  ref_data <- cur_data)
+static int roll_ref_depth(dfvo_pipeline* p, int slot, const double* d_depth_override) {
+    const size_t px = (size_t)p->H * p->W;
+    DFVO_HIP_CHECK(hipStreamWaitEvent(p->s_trk, p->e_depth[slot], 0));
+    const double* depth = d_depth_override ? d_depth_override : p->proc_depth[slot];
+    DFVO_HIP_CHECK(hipMemcpyAsync(p->ref_depth, depth, px * sizeof(double), hipMemcpyDeviceToDevice, p->s_trk));
+    p->has_ref_depth = true;
+    return DFVO_OK;
+}
+
 int dfvo_pipeline_track(dfvo_pipeline* p, int slot, const float* d_flow_override, const float* d_diff_override,
                         const double* d_depth_override, dfvo_track_out* out) {
     DFVO_ARG_CHECK(p && out && (slot == 0 || slot == 1), "dfvo_pipeline_track: bad argument");
@@ -205,6 +245,8 @@ int dfvo_pipeline_track(dfvo_pipeline* p, int slot, const float* d_flow_override
     out->good_kp_found = info[1];
     if (!info[1]) {
         out->status = DFVO_TRACK_CONSTANT_MOTION;
+        P_TRY(roll_ref_depth(p, slot, d_depth_override));
+        DFVO_HIP_CHECK(hipStreamSynchronize(s));
         return DFVO_OK;
     }
     const int n = info[0];
@@ -232,7 +274,7 @@ int dfvo_pipeline_track(dfvo_pipeline* p, int slot, const float* d_flow_override
     sc.stop_prob = c.scale_stop_prob;
     sc.thre = c.scale_thre;
     const double* depth = d_depth_override ? d_depth_override : p->proc_depth[slot];
-    P_TRY(enqueue_find_scale(p->tb, n, p->d_T21, depth, p->H, p->W, sc, s));
+    P_TRY(enqueue_find_scale(p->tb, n, p->d_T21, depth, p->H, p->W, sc, s, p->tb.pose));
     PoseState ps;
     ScaleResult sr;
     DFVO_HIP_CHECK(hipMemcpyAsync(&ps, p->tb.pose, sizeof(ps), hipMemcpyDeviceToHost, s));
@@ -248,10 +290,40 @@ int dfvo_pipeline_track(dfvo_pipeline* p, int slot, const float* d_flow_override
     out->scale_n_valid = sr.n_valid;
     out->scale_n_trials = sr.n_trials;
     out->scale_n_inliers = sr.n_inliers;
-    if (t_zero || sr.scale == -1.0)
-        out->status = DFVO_TRACK_NEEDS_PNP;  // dfvo.py:225-250
-    else
+    if (t_zero || sr.scale == -1.0) {  // dfvo.py:225-250: PnP on (ref keypoints + ref depth) -> cur keypoints
+        out->status = DFVO_TRACK_NEEDS_PNP;
+        if (p->has_ref_depth) {
+            PnpConfig pc3;
+            pc3.fx = c.fx;
+            pc3.fy = c.fy;
+            pc3.cx = c.cx;
+            pc3.cy = c.cy;
+            for (int i = 0; i < 9; i++) pc3.inv_K[i] = c.Kinv[i];
+            pc3.min_depth = c.min_depth;
+            pc3.max_depth = c.max_depth;
+            pc3.repeat = c.pnp_repeat;
+            pc3.iters = c.pnp_iters;
+            pc3.reproj_thre = c.pnp_reproj_thre;
+            P_TRY(enqueue_compute_pose_3d2d(p->pnp, p->tb.mt_state, p->tb.kp_ref, p->tb.kp_cur, p->tb.kp_info, n,
+                                            p->ref_depth, p->H, p->W, pc3, s));
+            PnpResult pr;
+            DFVO_HIP_CHECK(hipMemcpyAsync(&pr, p->pnp.result, sizeof(pr), hipMemcpyDeviceToHost, s));
+            DFVO_HIP_CHECK(hipStreamSynchronize(s));
+            DFVO_ARG_CHECK(pr.status != -2, "dfvo_pipeline_track: PnP met coplanar object points (planar initialisation "
+                                            "of cvFindExtrinsicCameraParams2 is not implemented)");
+            for (int i = 0; i < 9; i++) out->R[i] = pr.R[i];
+            for (int i = 0; i < 3; i++) out->t[i] = pr.tvec[i];
+            out->scale = 1.0;
+            out->pnp_found = pr.found;
+            out->pnp_inliers = pr.best_inliers;
+            out->pnp_n_filtered = pr.n_filtered;
+            out->status = DFVO_TRACK_PNP;
+        }
+    } else {
         out->status = DFVO_TRACK_E;
+    }
+    P_TRY(roll_ref_depth(p, slot, d_depth_override));
+    DFVO_HIP_CHECK(hipStreamSynchronize(s));
     return DFVO_OK;
 }
 

@@ -596,7 +596,8 @@ __global__ __launch_bounds__(256) void k_scale_ransac(uint32_t* __restrict__ mt_
                                                        const int* __restrict__ n_valid, int min_valid, int min_samples,
                                                        int max_trials, double stop_prob, double thr,
                                                        uint8_t* __restrict__ inl_a, uint8_t* __restrict__ inl_b,
-                                                       int* __restrict__ scratch, ScaleResult* __restrict__ out) {
+                                                       int* __restrict__ scratch, ScaleResult* __restrict__ out,
+                                                       const PoseState* __restrict__ gate) {
     __shared__ sm::Mt19937 s;
     __shared__ double s_coef;
     __shared__ int s_cnt[4], s_nz[4];
@@ -604,7 +605,10 @@ __global__ __launch_bounds__(256) void k_scale_ransac(uint32_t* __restrict__ mt_
     __shared__ int s_best_is_a;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int n = *n_valid;
-    if (!(n > min_valid)) {  // valid_mask2.sum() > 10
+    // fused pipeline: scale recovery only runs when ||t|| != 0 (dfvo.py:198); a rejected E-tracker pose must not
+    // draw from the numpy stream
+    const bool gated = gate && gate->t[0] == 0 && gate->t[1] == 0 && gate->t[2] == 0;
+    if (gated || !(n > min_valid)) {  // valid_mask2.sum() > 10
         if (t == 0) {
             out->scale = -1.0;
             out->n_valid = n;
@@ -891,7 +895,7 @@ int enqueue_compute_pose_2d2d(TrackerBuffers& tb, int n_host, const PoseConfig& 
 
 // find_scale_from_depth on tb.kp_ref (kp1) / tb.kp_cur (kp2); d_T21: 16 doubles; d_depth: H x W doubles
 int enqueue_find_scale(TrackerBuffers& tb, int n_host, const double* d_T21, const double* d_depth, int H, int W,
-                       const ScaleConfig& cfg, hipStream_t s) {
+                       const ScaleConfig& cfg, hipStream_t s, const PoseState* d_gate) {
     DFVO_ARG_CHECK(n_host >= 0 && n_host <= tb.kp_cap, "find_scale: keypoint capacity");
     if ((size_t)H * W > tb.winner_cap) {
         if (tb.winner) (void)hipFree(tb.winner);
@@ -907,7 +911,7 @@ int enqueue_find_scale(TrackerBuffers& tb, int n_host, const double* d_T21, cons
                        tb.z2, tb.pix, tb.winner, d_depth, tb.ratios, tb.kp_total);
     hipLaunchKernelGGL(k_scale_ransac, dim3(1), dim3(256), 0, s, tb.mt_state, tb.ratios, tb.kp_total, 10,
                        cfg.min_samples, cfg.max_trials, cfg.stop_prob, cfg.thre, tb.inl_a, tb.inl_b, tb.scratch,
-                       tb.scale_out);
+                       tb.scale_out, d_gate);
     DFVO_HIP_CHECK(hipGetLastError());
     return DFVO_OK;
 }

@@ -128,7 +128,8 @@ int enqueue_mt_shuffle(uint32_t* mt_state, const int* d_n, int n_host, int repea
 int enqueue_compute_pose_3d2d(PnpBuffers& pb, uint32_t* mt_state, const double* d_kp1, const double* d_kp2,
                               const int* d_n, int n_host, const double* d_depth, int H, int W, const PnpConfig& cfg,
                               hipStream_t s);
+// d_gate (optional): device PoseState whose zero translation suppresses the whole stage (no RandomState draws)
 int enqueue_find_scale(TrackerBuffers& tb, int n_host, const double* d_T21, const double* d_depth, int H, int W,
-                       const ScaleConfig& cfg, hipStream_t s);
+                       const ScaleConfig& cfg, hipStream_t s, const PoseState* d_gate = nullptr);
 
 }  // namespace dfvo

@@ -12,9 +12,9 @@ DEFAULTS = dict(  # options/examples/default_configuration.yml
     net_min_depth=0.1, net_max_depth=100.0, baseline_mult=5.4, min_depth=0.0, max_depth=50.0,
     depth_crop=((0.3, 1.0), (0.0, 1.0)), kp_num_row=10, kp_num_col=10, kp_num_bestN=2000, kp_thre=0.1,
     e_reproj_thre=0.2, e_repeat=5, e_max_iters=1000, scale_min_samples=3, scale_max_trials=100,
-    scale_stop_prob=0.99, scale_thre=0.1, seed=4869)
+    scale_stop_prob=0.99, scale_thre=0.1, seed=4869, pnp_repeat=5, pnp_iters=100, pnp_reproj_thre=1.0)
 
-STATUS = {0: "E", 1: "constant_motion", 2: "needs_pnp"}
+STATUS = {0: "E", 1: "constant_motion", 2: "needs_pnp", 3: "PnP"}
 
 
 class TrackingPipeline:
@@ -34,7 +34,9 @@ class TrackingPipeline:
                                kp_num_col=o["kp_num_col"], kp_num_bestN=o["kp_num_bestN"], kp_thre=o["kp_thre"],
                                e_reproj_thre=o["e_reproj_thre"], e_repeat=o["e_repeat"], e_max_iters=o["e_max_iters"],
                                scale_min_samples=o["scale_min_samples"], scale_max_trials=o["scale_max_trials"],
-                               scale_stop_prob=o["scale_stop_prob"], scale_thre=o["scale_thre"], seed=o["seed"])
+                               scale_stop_prob=o["scale_stop_prob"], scale_thre=o["scale_thre"], seed=o["seed"],
+                               pnp_repeat=o["pnp_repeat"], pnp_iters=o["pnp_iters"],
+                               pnp_reproj_thre=o["pnp_reproj_thre"])
         (y0, y1), (x0, x1) = o["depth_crop"]
         for i, v in enumerate((y0, y1, x0, x1)):
             cfg.depth_crop[i] = v
@@ -87,6 +89,11 @@ class TrackingPipeline:
         capi.check(self.lib.dfvo_pipeline_track(self.h, slot, p(flow), p(diff), p(depth), C.byref(out)))
         return out
 
+    def set_ref_depth(self, d_feed=None, depth=None):
+        """depth of the first reference frame: the uint8 feed image (runs the depth net) or a processed depth map"""
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        capi.check(self.lib.dfvo_pipeline_set_ref_depth(self.h, p(d_feed), p(depth)))
+
     def sync(self):
         capi.check(self.lib.dfvo_pipeline_sync(self.h))
 
@@ -112,7 +119,12 @@ class TrackingPipeline:
         if out.status == 1:
             return prev_motion.copy(), "constant_motion"
         if out.status == 2:
-            raise capi.DfvoError("PnP fallback required for this pair; use the PnpTracker stage")
+            raise capi.DfvoError("PnP fallback required but no reference depth is known: call set_ref_depth() "
+                                 "for the first frame")
+        if out.status == 3:  # pnp_tracker.py:112-118: SE3 from (R, t) of solvePnP, then pose = inv_pose
+            T[:3, :3] = np.array(out.R[:]).reshape(3, 3)
+            T[:3, 3] = np.array(out.t[:])
+            return np.linalg.inv(T), "PnP"
         T[:3, :3] = np.array(out.R[:]).reshape(3, 3)
         T[:3, 3] = np.array(out.t[:]) * out.scale
         return T, "E"

@@ -171,7 +171,7 @@ def two_view(n, out_frac=0.3, noise=0.15, seed=2002, w=1241, h=376):
 def rigid_scene(h, w, seed=1, T=None, noise_px=0.05, bad_frac=0.35):
     """Dense forward flow / consistency map / current-view depth of a static ramp scene seen from a
     moving camera: depth d(y) = max(5, 80 (1 - y/H)), KITTI-like intrinsics.
-    Returns dict(K, flow [2,h,w] f32, diff [h,w] f32, depth_cur [h,w] f64 (already cropped/capped), R, t)."""
+    Returns dict(K, flow [2,h,w] f32, diff [h,w] f32, depth_cur / depth_ref [h,w] f64 (already cropped/capped), R, t)."""
     from scipy import ndimage
     rng = np.random.Generator(np.random.PCG64(seed))
     f = 718.856 * w / 1241.0
@@ -215,5 +215,10 @@ def rigid_scene(h, w, seed=1, T=None, noise_px=0.05, bad_frac=0.35):
     proc = dc.copy()
     proc[:y0] = 0
     proc[~((proc < 50) & (proc > 0))] = 0
-    return dict(K=K, flow=flow.astype(np.float32), diff=diff.astype(np.float32), depth_cur=proc, R=R, t=tv,
-                scale_true=scale_true)
+    # reference-view depth (same noise model, same crop / cap), drawn last so that the other maps keep their values
+    dr = d * (1.0 + rng.normal(0, 0.02, d.shape))
+    proc_ref = dr.copy()
+    proc_ref[:y0] = 0
+    proc_ref[~((proc_ref < 50) & (proc_ref > 0))] = 0
+    return dict(K=K, flow=flow.astype(np.float32), diff=diff.astype(np.float32), depth_cur=proc, depth_ref=proc_ref, R=R,
+                t=tv, scale_true=scale_true)

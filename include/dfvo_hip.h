@@ -258,15 +258,21 @@ typedef struct dfvo_pipeline_cfg {
     int scale_min_samples, scale_max_trials;
     double scale_stop_prob, scale_thre;
     uint32_t seed;                                       /* np.random.seed(cfg.seed), run.py:81-84 */
+    int pnp_repeat, pnp_iters;                           /* cfg.pnp_tracker.ransac.{repeat,iter} */
+    double pnp_reproj_thre;                              /* cfg.pnp_tracker.ransac.reproj_thre */
 } dfvo_pipeline_cfg;
 #define DFVO_TRACK_E 0                 /* pose from the essential matrix + depth scale */
 #define DFVO_TRACK_CONSTANT_MOTION 1   /* not enough keypoints: caller reuses the previous motion (dfvo.py:157-161) */
-#define DFVO_TRACK_NEEDS_PNP 2         /* E rejected or scale == -1: PnP fallback (dfvo.py:225-250) */
+#define DFVO_TRACK_NEEDS_PNP 2         /* E rejected or scale == -1 and no reference depth is known yet (first pair) */
+#define DFVO_TRACK_PNP 3               /* E rejected or scale == -1: pose from the PnP fallback (dfvo.py:225-250) */
 typedef struct dfvo_track_out {
-    double R[9], t[3];        /* E-tracker pose cur -> ref (t has unit norm or is zero) */
+    double R[9], t[3];        /* DFVO_TRACK_E: E-tracker pose cur -> ref (t has unit norm or is zero);
+                                 DFVO_TRACK_PNP: the solvePnP pose (ref points -> cur camera; identity when no repeat
+                                 found a model), which the caller inverts as pnp_tracker.py:118 does */
     double scale;
     int status, n_kp, good_kp_found, best_inlier_cnt, num_valid, cheirality;
     int scale_n_valid, scale_n_trials, scale_n_inliers;
+    int pnp_found, pnp_inliers, pnp_n_filtered;
 } dfvo_track_out;
 int dfvo_pipeline_create(const dfvo_pipeline_cfg* cfg, dfvo_pipeline** out);
 void dfvo_pipeline_destroy(dfvo_pipeline* p);
@@ -279,9 +285,13 @@ int dfvo_pipeline_set_graph(dfvo_pipeline* p, int enable);   /* hipGraph replay 
  * ref/cur [img_h,img_w,3], cur_feed [feed_h,feed_w,3] (the PIL-LANCZOS resized current frame) */
 int dfvo_pipeline_enqueue_nets(dfvo_pipeline* p, int slot, const uint8_t* d_ref, const uint8_t* d_cur,
                                const uint8_t* d_cur_feed);
-/* keypoint selection + E-tracker + scale recovery on the outputs in `slot` (waits for its nets).
- * Optional device overrides replace the forward flow [2,H,W] / consistency map [H,W] / processed depth
- * [H,W] double that feed the solver stage (used by bench.py). Synchronous. */
+/* depth of the very first reference frame (dfvo.py computes the depth of every frame as it becomes `cur`; the first
+ * frame never is): exactly one of d_feed (uint8 [feed_h,feed_w,3], runs the depth net) or d_depth_override (processed
+ * depth, double [H,W]).  Later reference depths roll over from the current frame of each tracked pair. */
+int dfvo_pipeline_set_ref_depth(dfvo_pipeline* p, const uint8_t* d_feed, const double* d_depth_override);
+/* keypoint selection + E-tracker + scale recovery (+ the PnP fallback when the E-tracker result is rejected) on the
+ * outputs in `slot` (waits for its nets).  Optional device overrides replace the forward flow [2,H,W] / consistency
+ * map [H,W] / processed depth [H,W] double that feed the solver stage (used by bench.py). Synchronous. */
 int dfvo_pipeline_track(dfvo_pipeline* p, int slot, const float* d_flow_override, const float* d_diff_override,
                         const double* d_depth_override, dfvo_track_out* out);
 int dfvo_pipeline_get_flow(dfvo_pipeline* p, int slot, float* h_fwd, float* h_bwd, float* h_diff, float* h_raw_depth,

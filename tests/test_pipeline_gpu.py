@@ -33,6 +33,8 @@ def test_pipeline_tracker_matches_oracle_chain(gpu, pipe_mod, h, w):
     dflow, ddiff, ddepth = d(sc["flow"]), d(sc["diff"]), d(sc["depth_cur"])
     poses = []
     np.random.seed(4869)
+    pipe.set_ref_depth(depth=d(sc["depth_ref"]))  # depth of the first reference frame (PnP fallback input)
+    ref_depth = sc["depth_ref"]
     for frame in range(3):  # the RandomState carries over from pair to pair, as in a sequence
         pipe.enqueue_nets(frame % 2, dref, dcur, dfeed)
         out = pipe.track(frame % 2, dflow, ddiff, ddepth)
@@ -41,19 +43,30 @@ def test_pipeline_tracker_matches_oracle_chain(gpu, pipe_mod, h, w):
         res = T.compute_pose_2d2d(kp["kp1_best"][0], kp["kp2_best"][0], K)
         R = np.array(out.R[:]).reshape(3, 3)
         t = np.array(out.t[:]).reshape(3, 1)
-        assert np.array_equal(R, res["R"]) and np.array_equal(t, res["t"]), "frame %d" % frame
+        if out.status == 0:  # (with status 3 the E-tracker pose has been replaced by the PnP one, checked below)
+            assert np.array_equal(R, res["R"]) and np.array_equal(t, res["t"]), "frame %d" % frame
         pose = np.eye(4)
         pose[:3, :3] = res["R"]
         pose[:3, 3:] = res["t"]
-        diag = {}
-        s_ref = T.find_scale_from_depth(kp["kp1_best"][0], kp["kp2_best"][0], np.linalg.inv(pose), sc["depth_cur"], K,
-                                        diag=diag)
+        diag = {"n_valid": -1}
+        s_ref = -1
+        if np.linalg.norm(res["t"]) != 0:  # dfvo.py:198: scale recovery (and its RandomState draws) only then
+            s_ref = T.find_scale_from_depth(kp["kp1_best"][0], kp["kp2_best"][0], np.linalg.inv(pose), sc["depth_cur"], K,
+                                            diag=diag)
         print("frame %d: status %d kp %d inliers %d | scale hip %.12g oracle %.12g (valid %d/%d trials %d/%d)" % (
             frame, out.status, out.n_kp, out.best_inlier_cnt, out.scale, s_ref, out.scale_n_valid, diag["n_valid"],
             out.scale_n_trials, diag.get("n_trials", 0)))
         if np.linalg.norm(res["t"]) == 0 or s_ref == -1:  # E rejected (GRIC / cheirality) or no scale: PnP fallback
-            assert out.status == 2
+            assert out.status == 3
+            pnp = T.compute_pose_3d2d(kp["kp1_best"][0], kp["kp2_best"][0], ref_depth, K, 0.0, 50.0, 5, 100, 1.0)
+            assert out.pnp_n_filtered == len(pnp["kp1"]) and out.pnp_inliers == pnp["best_inlier"]
+            assert np.array_equal(np.array(out.R[:]).reshape(3, 3), pnp["R"])
+            assert np.array_equal(np.array(out.t[:]).reshape(3, 1), pnp["t"])
+            rel, mode = pipe.hybrid_pose(out, np.eye(4))
+            assert mode == "PnP" and np.abs(rel - pnp["pose"]).max() <= 1e-12
+            ref_depth = sc["depth_cur"]
             continue
+        ref_depth = sc["depth_cur"]  # the current depth rolls over to the reference slot
         assert out.status == 0
         assert out.scale_n_valid == diag["n_valid"]
         assert abs(out.scale - s_ref) <= 1e-9 * abs(s_ref)
