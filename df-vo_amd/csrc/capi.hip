@@ -111,9 +111,9 @@ int dfvo_conv_profile_begin(void) {
     conv_profile_begin();
     return DFVO_OK;
 }
-int dfvo_conv_profile_end(double* h_ms8, double* h_flops8, int* h_launches8) {
-    DFVO_ARG_CHECK(h_ms8 && h_flops8 && h_launches8, "dfvo_conv_profile_end: null argument");
-    return conv_profile_end(h_ms8, h_flops8, h_launches8);
+int dfvo_conv_profile_end(double* h_ms12, double* h_flops12, int* h_launches12) {
+    DFVO_ARG_CHECK(h_ms12 && h_flops12 && h_launches12, "dfvo_conv_profile_end: null argument");
+    return conv_profile_end(h_ms12, h_flops12, h_launches12);
 }
 
 int dfvo_correlation(const float* d_first, const float* d_second, int N, int H, int W, int C, int stride,

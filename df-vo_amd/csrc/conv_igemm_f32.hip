@@ -350,9 +350,11 @@ void conv_profile_begin() {
     if (!g_prof) g_prof = new std::vector<ConvProfEntry>();
     g_prof->clear();
 }
-// cfg ids: 0 <2,2,4,4>  1 <1,4,2,2>  2 <4,1,4,4>  3 <2,2,2,2>  4 <4,1,4,2>  5 <2,2,2,1>  6 <4,1,4,1>  7 <4,1,1,1>
+// cfg ids (BM x BN): 0 <2,2,4,4> 128x128  1 <1,4,2,2> 32x128  2 <4,1,4,4> 256x64  3 <2,2,2,2> 64x64  4 <4,1,4,2> 256x32
+//   5 <2,2,2,1> 64x32  6 <4,1,4,1> 256x16  7 <4,1,1,1> 64x16  8 <1,4,4,2> 64x128  9 <2,2,4,2> 128x64  10 <4,1,2,2> 128x32
+//   11 <4,1,2,1> 128x16
 int conv_profile_end(double* ms, double* flops, int* launches) {
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < CONV_NUM_CFGS; i++) {
         ms[i] = 0;
         flops[i] = 0;
         launches[i] = 0;
@@ -391,8 +393,8 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) {
     // split-K when the grid cannot fill the chip: partials to p.ws, ordered reduction in a second launch
     int splits = 1;
     const long long blocks = (long long)grid.x * grid.y;
-    if (p.ws && blocks < 192 && p.ksteps >= 16) {
-        splits = (int)((512 + blocks - 1) / blocks);
+    if (p.ws && blocks < 600 && p.ksteps >= 16) {
+        splits = (int)((1024 + blocks - 1) / blocks);
         if (splits > p.ksteps / 8) splits = p.ksteps / 8;
         if (splits > 32) splits = 32;
         while (splits > 1 && (size_t)splits * M * p.cout_pad > p.ws_floats) --splits;
@@ -430,26 +432,43 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) {
     return DFVO_OK;
 }
 
+// Tile choice: the widest N tile the layer's cout allows (conv_pick_bn); the M tile from a sweep on MI355X
+// (tools/sweep_conv.sh): 64-row tiles win or tie on every layer with BN <= 64 and on BN = 128 below ~1200
+// workgroups (more resident workgroups hide the global -> LDS staging latency; the per-tap gather is served by
+// L2 either way); 128 x 128 keeps the largest maps.  Small grids additionally split K inside launch_cfg.
+// DFVO_CONV_FORCE_BM=<rows> overrides the M tile (tuning aid).
 int launch_conv(const ConvParams& p, hipStream_t stream) {
     const long long M = (long long)p.N * p.Ho * p.Wo;
     const int bn = conv_pick_bn(p.cout, M);
     DFVO_ARG_CHECK(p.cout_pad % bn == 0, "launch_conv: cout_pad not a multiple of the N tile");
     DFVO_ARG_CHECK((p.cs0 % 4) == 0 && (p.co0 % 4) == 0, "launch_conv: src0 stride/offset must be multiples of 4");
     DFVO_ARG_CHECK(p.G1 == 0 || ((p.cs1 % 4) == 0 && (p.co1 % 4) == 0), "launch_conv: src1 stride/offset");
+    static const int force_bm = getenv("DFVO_CONV_FORCE_BM") ? atoi(getenv("DFVO_CONV_FORCE_BM")) : 0;
+    const long long ntiles_n = p.cout_pad / bn;
+    auto blocks = [&](int bm) { return ((M + bm - 1) / bm) * ntiles_n; };
     if (bn == 128) {
-        if (M <= 4096) return launch_cfg<1, 4, 2, 2>(p, stream, 1);  // 32 x 128: more blocks for small maps
-        return launch_cfg<2, 2, 4, 4>(p, stream, 0);                 // 128 x 128
+        int bm = blocks(128) >= 1200 ? 128 : 64;
+        if (M <= 4096) bm = 32;
+        if (force_bm == 128 || force_bm == 64 || force_bm == 32) bm = force_bm;
+        if (bm == 128) return launch_cfg<2, 2, 4, 4>(p, stream, 0);
+        if (bm == 64) return launch_cfg<1, 4, 4, 2>(p, stream, 8);
+        return launch_cfg<1, 4, 2, 2>(p, stream, 1);
     }
+    int bm = M >= 400000 ? 128 : 64;
+    if (force_bm == 256 || force_bm == 128 || force_bm == 64) bm = force_bm;
     if (bn == 64) {
-        if (M <= 8192) return launch_cfg<2, 2, 2, 2>(p, stream, 3);  // 64 x 64
-        return launch_cfg<4, 1, 4, 4>(p, stream, 2);                 // 256 x 64
+        if (bm == 256) return launch_cfg<4, 1, 4, 4>(p, stream, 2);
+        if (bm == 128) return launch_cfg<2, 2, 4, 2>(p, stream, 9);
+        return launch_cfg<2, 2, 2, 2>(p, stream, 3);
     }
     if (bn == 32) {
-        if (M <= 8192) return launch_cfg<2, 2, 2, 1>(p, stream, 5);  // 64 x 32
-        return launch_cfg<4, 1, 4, 2>(p, stream, 4);                 // 256 x 32
+        if (bm == 256) return launch_cfg<4, 1, 4, 2>(p, stream, 4);
+        if (bm == 128) return launch_cfg<4, 1, 2, 2>(p, stream, 10);
+        return launch_cfg<2, 2, 2, 1>(p, stream, 5);
     }
-    if (M <= 8192) return launch_cfg<4, 1, 1, 1>(p, stream, 7);      // 64 x 16
-    return launch_cfg<4, 1, 4, 1>(p, stream, 6);                     // 256 x 16
+    if (bm == 256) return launch_cfg<4, 1, 4, 1>(p, stream, 6);
+    if (bm == 128) return launch_cfg<4, 1, 2, 1>(p, stream, 11);
+    return launch_cfg<4, 1, 1, 1>(p, stream, 7);
 }
 
 }  // namespace dfvo

@@ -87,6 +87,7 @@ void conv_pack_weights(const float* w_oihw, const float* bias, int cout, int c0,
                        int cout_pad, const float* fold_scale, const float* fold_shift, float* out_w,
                        float* out_b);
 
+constexpr int CONV_NUM_CFGS = 12;  // tile configurations of the implicit-GEMM kernel (profile arrays have this size)
 int launch_conv(const ConvParams& p, hipStream_t stream);
 void conv_profile_begin();
 int conv_profile_end(double* ms, double* flops, int* launches);
