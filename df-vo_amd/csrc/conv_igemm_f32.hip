@@ -384,17 +384,16 @@ int conv_profile_end(double* ms, double* flops, int* launches) {
     return DFVO_OK;
 }
 
-template <int WM, int WN, int TM, int TN>
-static int launch_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) {
-    constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+// split-K when the grid cannot fill the chip: partials to p.ws, ordered reduction in a second launch
+static int conv_pick_splits(const ConvParams& p, long long blocks) {
     const long long M = (long long)p.N * p.Ho * p.Wo;
-    dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(p.cout_pad / BN), 1);
-    DFVO_ARG_CHECK((p.G0 + p.G1) * p.kh * p.kw + 4 <= MAX_KGROUPS, "launch_conv: too many k-groups for the LDS table");
-    // split-K when the grid cannot fill the chip: partials to p.ws, ordered reduction in a second launch
     int splits = 1;
-    const long long blocks = (long long)grid.x * grid.y;
-    if (p.ws && blocks < 600 && p.ksteps >= 16) {
+    if (!p.ws) return 1;
+    if (p.force_splits > 0)
+        splits = p.force_splits;
+    else if (blocks < 600 && p.ksteps >= 16)
         splits = (int)((1024 + blocks - 1) / blocks);
+    if (splits > 1) {
         if (splits > p.ksteps / 8) splits = p.ksteps / 8;
         if (splits > 32) splits = 32;
         while (splits > 1 && (size_t)splits * M * p.cout_pad > p.ws_floats) --splits;
@@ -403,6 +402,16 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) {
         const int per = (p.ksteps + splits - 1) / splits;
         splits = (p.ksteps + per - 1) / per;
     }
+    return splits;
+}
+
+template <int WM, int WN, int TM, int TN>
+static int launch_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) {
+    constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+    const long long M = (long long)p.N * p.Ho * p.Wo;
+    dim3 grid((unsigned)((M + BM - 1) / BM), (unsigned)(p.cout_pad / BN), 1);
+    DFVO_ARG_CHECK((p.G0 + p.G1) * p.kh * p.kw + 4 <= MAX_KGROUPS, "launch_conv: too many k-groups for the LDS table");
+    const int splits = conv_pick_splits(p, (long long)grid.x * grid.y);
     grid.z = (unsigned)splits;
     ConvProfEntry pe;
     if (g_prof) {
@@ -437,25 +446,43 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) {
 // workgroups (more resident workgroups hide the global -> LDS staging latency; the per-tap gather is served by
 // L2 either way); 128 x 128 keeps the largest maps.  Small grids additionally split K inside launch_cfg.
 // DFVO_CONV_FORCE_BM=<rows> overrides the M tile (tuning aid).
-int launch_conv(const ConvParams& p, hipStream_t stream) {
+static int conv_pick_bm(const ConvParams& p, int bn) {
     const long long M = (long long)p.N * p.Ho * p.Wo;
-    const int bn = conv_pick_bn(p.cout, M);
-    DFVO_ARG_CHECK(p.cout_pad % bn == 0, "launch_conv: cout_pad not a multiple of the N tile");
-    DFVO_ARG_CHECK((p.cs0 % 4) == 0 && (p.co0 % 4) == 0, "launch_conv: src0 stride/offset must be multiples of 4");
-    DFVO_ARG_CHECK(p.G1 == 0 || ((p.cs1 % 4) == 0 && (p.co1 % 4) == 0), "launch_conv: src1 stride/offset");
-    static const int force_bm = getenv("DFVO_CONV_FORCE_BM") ? atoi(getenv("DFVO_CONV_FORCE_BM")) : 0;
+    static const int env_bm = getenv("DFVO_CONV_FORCE_BM") ? atoi(getenv("DFVO_CONV_FORCE_BM")) : 0;
+    const int force_bm = p.force_bm ? p.force_bm : env_bm;
     const long long ntiles_n = p.cout_pad / bn;
     auto blocks = [&](int bm) { return ((M + bm - 1) / bm) * ntiles_n; };
     if (bn == 128) {
         int bm = blocks(128) >= 1200 ? 128 : 64;
         if (M <= 4096) bm = 32;
         if (force_bm == 128 || force_bm == 64 || force_bm == 32) bm = force_bm;
+        return bm;
+    }
+    int bm = M >= 400000 ? 128 : 64;
+    if (force_bm == 256 || force_bm == 128 || force_bm == 64) bm = force_bm;
+    return bm;
+}
+
+void conv_effective_config(const ConvParams& p, int* bm_out, int* splits_out) {
+    const long long M = (long long)p.N * p.Ho * p.Wo;
+    const int bn = conv_pick_bn(p.cout, M);
+    const int bm = conv_pick_bm(p, bn);
+    *bm_out = bm;
+    *splits_out = conv_pick_splits(p, ((M + bm - 1) / bm) * (p.cout_pad / bn));
+}
+
+int launch_conv(const ConvParams& p, hipStream_t stream) {
+    const long long M = (long long)p.N * p.Ho * p.Wo;
+    const int bn = conv_pick_bn(p.cout, M);
+    DFVO_ARG_CHECK(p.cout_pad % bn == 0, "launch_conv: cout_pad not a multiple of the N tile");
+    DFVO_ARG_CHECK((p.cs0 % 4) == 0 && (p.co0 % 4) == 0, "launch_conv: src0 stride/offset must be multiples of 4");
+    DFVO_ARG_CHECK(p.G1 == 0 || ((p.cs1 % 4) == 0 && (p.co1 % 4) == 0), "launch_conv: src1 stride/offset");
+    const int bm = conv_pick_bm(p, bn);
+    if (bn == 128) {
         if (bm == 128) return launch_cfg<2, 2, 4, 4>(p, stream, 0);
         if (bm == 64) return launch_cfg<1, 4, 4, 2>(p, stream, 8);
         return launch_cfg<1, 4, 2, 2>(p, stream, 1);
     }
-    int bm = M >= 400000 ? 128 : 64;
-    if (force_bm == 256 || force_bm == 128 || force_bm == 64) bm = force_bm;
     if (bn == 64) {
         if (bm == 256) return launch_cfg<4, 1, 4, 4>(p, stream, 2);
         if (bm == 128) return launch_cfg<2, 2, 4, 2>(p, stream, 9);

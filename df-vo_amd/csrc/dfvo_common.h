@@ -64,6 +64,8 @@ struct ConvParams {
     size_t ws_floats;
     // 2 * MACs of the unpadded convolution (bookkeeping for the bench's roofline leg; not read on device)
     double useful_flops;
+    // launch overrides chosen by the per-layer autotuner (0 = heuristic): M tile rows, split-K factor
+    int force_bm, force_splits;
 };
 
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
@@ -89,6 +91,8 @@ void conv_pack_weights(const float* w_oihw, const float* bias, int cout, int c0,
 
 constexpr int CONV_NUM_CFGS = 12;  // tile configurations of the implicit-GEMM kernel (profile arrays have this size)
 int launch_conv(const ConvParams& p, hipStream_t stream);
+// effective (bm, splits) the launcher would use for p (after clamping the overrides)
+void conv_effective_config(const ConvParams& p, int* bm, int* splits);
 void conv_profile_begin();
 int conv_profile_end(double* ms, double* flops, int* launches);
 

@@ -28,6 +28,9 @@ struct ConvLayer {
     int cout = 0, cout_pad = 0, c0 = 0, c1 = 0, kh = 0, kw = 0, ksteps = 0;
     int stride = 1, pad_h = 0, pad_w = 0, pad_mode = PAD_ZERO, act = ACT_NONE;
     float act_param = 0.f;
+    // per-layer launch configuration measured once on the device (conv autotuner, nets.hip); 0 = heuristic
+    mutable int tune_bm = 0, tune_splits = 0;
+    mutable bool tuned = false;
     double macs_per_pixel() const { return (double)cout * (c0 + c1) * kh * kw; }
 };
 
@@ -40,6 +43,10 @@ struct ParamStore {
 int make_conv(const ParamStore& ps, const std::string& wname, const std::string& bname, int c0, int c1,
               long long M_hint, const float* scale, const float* shift, ConvLayer* out);
 void free_conv(ConvLayer* l);
+
+// while set, run_conv times the candidate tile / split-K configurations of every not-yet-tuned layer on its
+// real shapes and keeps the fastest (set around the first eager forward of a net; never during graph capture)
+void conv_autotune_scope(bool on);
 
 struct View {
     const float* p;
@@ -83,6 +90,7 @@ struct FlowNet {
     const uint8_t* graph_cur = nullptr;
     float *graph_fwd = nullptr, *graph_bwd = nullptr, *graph_diff = nullptr;
     bool use_graph = true;
+    bool tuned_once = false;
 
     int init(int imgH, int imgW, hipStream_t s);
     int finalize();
@@ -114,6 +122,7 @@ struct DepthNet {
     const uint8_t* graph_in = nullptr;
     float* graph_out = nullptr;
     bool use_graph = true;
+    bool tuned_once = false;
 
     int init(int feedH, int feedW, hipStream_t s);
     int finalize();

@@ -4,6 +4,9 @@
 // depth/monodepth2/{resnet_encoder.py:87-98, depth_decoder.py:17-65, monodepth2.py:91-139}.
 #include "nets.h"
 
+#include <cstdlib>
+#include <utility>
+
 #include <cmath>
 #include <cstring>
 
@@ -78,6 +81,61 @@ void free_conv(ConvLayer* l) {
     l->wp = l->bias = nullptr;
 }
 
+// ---- per-layer autotuner: the candidates differ only in tiling / K splitting, the arithmetic is the same fp32 FMA
+// chain per output (split-K changes the summation order, within the nets' float tolerance)
+static bool g_conv_autotune = false;
+void conv_autotune_scope(bool on) {
+    // opt-in (DFVO_CONV_AUTOTUNE=1): measured gain over the sweep-derived rule in launch_conv is ~2 % on the KITTI
+    // shapes, and a timing-based choice makes the split-K summation order (last float bits) vary between runs
+    static const bool enabled = getenv("DFVO_CONV_AUTOTUNE") && atoi(getenv("DFVO_CONV_AUTOTUNE")) != 0;
+    g_conv_autotune = on && enabled;
+}
+
+static int autotune_conv(const ConvLayer& L, ConvParams p, hipStream_t s) {
+    const long long M = (long long)p.N * p.Ho * p.Wo;
+    const int bn = conv_pick_bn(p.cout, M);
+    const int bms128[3] = {128, 64, 32}, bms[3] = {256, 128, 64};
+    const int splits[6] = {1, 2, 4, 8, 16, 32};
+    hipEvent_t e0, e1;
+    DFVO_HIP_CHECK(hipEventCreate(&e0));
+    DFVO_HIP_CHECK(hipEventCreate(&e1));
+    float best = 1e30f;
+    int best_bm = 0, best_sp = 0;
+    std::vector<std::pair<int, int>> seen;
+    for (int bi = 0; bi < 3; ++bi)
+        for (int si = 0; si < 6; ++si) {
+            p.force_bm = bn == 128 ? bms128[bi] : bms[bi];
+            p.force_splits = splits[si];
+            int ebm, esp;
+            conv_effective_config(p, &ebm, &esp);
+            bool dup = false;
+            for (auto& q : seen) dup = dup || (q.first == ebm && q.second == esp);
+            if (dup) continue;
+            seen.push_back({ebm, esp});
+            const long long blocks = ((M + ebm - 1) / ebm) * (p.cout_pad / bn) * esp;
+            if (esp > 1 && blocks > 4096) continue;  // splitting an already full grid only adds traffic
+            int rc = launch_conv(p, s);  // warm-up
+            if (rc != DFVO_OK) return rc;
+            DFVO_HIP_CHECK(hipEventRecord(e0, s));
+            for (int r = 0; r < 3; ++r) launch_conv(p, s);
+            DFVO_HIP_CHECK(hipEventRecord(e1, s));
+            DFVO_HIP_CHECK(hipEventSynchronize(e1));
+            float ms = 0.f;
+            DFVO_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (ms < best) {
+                best = ms;
+                best_bm = ebm;
+                best_sp = esp;
+            }
+        }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    L.tune_bm = best_bm;
+    L.tune_splits = best_sp;
+    L.tuned = true;
+    return DFVO_OK;
+}
+
 int run_conv(const ConvLayer& L, int N, int H, int W, View s0, int up0, View s1, const float* res, int res_cs,
              int res_co, float* dst, int dst_cs, int dst_co, int dst_zero_to, hipStream_t s, double* flops,
              const DevBuf* splitk_ws) {
@@ -121,6 +179,9 @@ int run_conv(const ConvLayer& L, int N, int H, int W, View s0, int up0, View s1,
     p.ws_floats = splitk_ws ? splitk_ws->n : 0;
     p.useful_flops = 2.0 * (double)N * p.Ho * p.Wo * L.macs_per_pixel();
     if (flops) *flops += p.useful_flops;
+    if (g_conv_autotune && !L.tuned) DFVO_TRY(autotune_conv(L, p, s));
+    p.force_bm = L.tune_bm;
+    p.force_splits = L.tune_splits;
     return launch_conv(p, s);
 }
 
@@ -492,6 +553,14 @@ int FlowNet::forward(const uint8_t* d_ref, const uint8_t* d_cur, float* d_fwd, f
         set_last_error("FlowNet::forward before finalize");
         return DFVO_ERR_STATE;
     }
+    if (!tuned_once) {  // first call: eager run with the conv autotuner on (sizes are final from here on)
+        conv_autotune_scope(true);
+        int rc = enqueue(d_ref, d_cur, d_fwd, d_bwd, d_diff);
+        conv_autotune_scope(false);
+        if (rc != DFVO_OK) return rc;
+        DFVO_HIP_CHECK(hipStreamSynchronize(stream));
+        tuned_once = true;
+    }
     if (!use_graph) return enqueue(d_ref, d_cur, d_fwd, d_bwd, d_diff);
     if (graph_exec && (graph_ref != d_ref || graph_cur != d_cur || graph_fwd != d_fwd || graph_bwd != d_bwd ||
                        graph_diff != d_diff)) {
@@ -742,6 +811,14 @@ int DepthNet::forward(const uint8_t* d_img, float* d_depth) {
     if (!finalized) {
         set_last_error("DepthNet::forward before finalize");
         return DFVO_ERR_STATE;
+    }
+    if (!tuned_once) {
+        conv_autotune_scope(true);
+        int rc = enqueue(d_img, d_depth);
+        conv_autotune_scope(false);
+        if (rc != DFVO_OK) return rc;
+        DFVO_HIP_CHECK(hipStreamSynchronize(stream));
+        tuned_once = true;
     }
     if (!use_graph) return enqueue(d_img, d_depth);
     if (graph_exec && (graph_in != d_img || graph_out != d_depth)) {
