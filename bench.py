@@ -28,7 +28,9 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: FP32 mat
 CFG_NAMES = ["conv_igemm_f32<2,2,4,4> 128x128", "conv_igemm_f32<1,4,2,2> 32x128", "conv_igemm_f32<4,1,4,4> 256x64",
              "conv_igemm_f32<2,2,2,2> 64x64", "conv_igemm_f32<4,1,4,2> 256x32", "conv_igemm_f32<2,2,2,1> 64x32",
              "conv_igemm_f32<4,1,4,1> 256x16", "conv_igemm_f32<4,1,1,1> 64x16", "conv_igemm_f32<1,4,4,2> 64x128",
-             "conv_igemm_f32<2,2,4,2> 128x64", "conv_igemm_f32<4,1,2,2> 128x32", "conv_igemm_f32<4,1,2,1> 128x16"]
+             "conv_igemm_f32<2,2,4,2> 128x64", "conv_igemm_f32<4,1,2,2> 128x32", "conv_igemm_f32<4,1,2,1> 128x16",
+             "conv_win3_f32<2,2,4,4> (8x16)x128", "conv_win3_f32<2,2,4,2> (8x16)x64", "conv_win3_f32<4,1,2,2> (8x16)x32",
+             "conv_win3_f32<1,4,4,2> (4x16)x128"]
 
 
 def cpu_baseline(syn, H, W, scenes, n_pairs=2):
@@ -157,9 +159,9 @@ def main():
         capi.check(lib.dfvo_conv_profile_begin())
         nprof = 3
         run(nprof)
-        ms = np.zeros(12)
-        fl = np.zeros(12)
-        ln = np.zeros(12, np.int32)
+        ms = np.zeros(16)
+        fl = np.zeros(16)
+        ln = np.zeros(16, np.int32)
         capi.check(lib.dfvo_conv_profile_end(capi.as_ptr(ms), capi.as_ptr(fl), capi.as_ptr(ln)))
         pipe.set_graph(1)
         dom = int(np.argmax(ms))

@@ -73,7 +73,7 @@ int dfvo_conv2d(const dfvo_conv_desc* d, const float* d_src0, const float* d_src
     const long long M = (long long)d->N * Ho * Wo;
     const int cout_pad = conv_cout_pad(d->cout, M);
     const int ksteps = conv_ksteps(d->kh, d->kw, d->c0, d->c1);
-    std::vector<float> pw((size_t)ksteps * 4 * cout_pad * 4), pb(cout_pad);
+    std::vector<float> pw((size_t)(ksteps * 4 + 8) * cout_pad * 4), pb(cout_pad);  // slack: see make_conv
     conv_pack_weights(h_w, h_bias, d->cout, d->c0, d->c1, d->kh, d->kw, cout_pad, nullptr, nullptr, pw.data(),
                       pb.data());
     float *dw = nullptr, *db = nullptr;
@@ -111,9 +111,9 @@ int dfvo_conv_profile_begin(void) {
     conv_profile_begin();
     return DFVO_OK;
 }
-int dfvo_conv_profile_end(double* h_ms12, double* h_flops12, int* h_launches12) {
-    DFVO_ARG_CHECK(h_ms12 && h_flops12 && h_launches12, "dfvo_conv_profile_end: null argument");
-    return conv_profile_end(h_ms12, h_flops12, h_launches12);
+int dfvo_conv_profile_end(double* h_ms16, double* h_flops16, int* h_launches16) {
+    DFVO_ARG_CHECK(h_ms16 && h_flops16 && h_launches16, "dfvo_conv_profile_end: null argument");
+    return conv_profile_end(h_ms16, h_flops16, h_launches16);
 }
 
 int dfvo_correlation(const float* d_first, const float* d_second, int N, int H, int W, int C, int stride,

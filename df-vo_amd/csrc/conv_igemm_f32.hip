@@ -267,6 +267,191 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3x3 / stride-1 convolutions with an LDS-resident input window.
+// The gather kernel above re-fetches every input pixel once per tap (9x for a 3x3), which overflows the
+// per-XCD L2 on the large maps (profiles/r1k_pmc: 3.5x the algorithmic bytes at the fabric) and makes the
+// narrow-N layers vL1D-bound.  Here a workgroup owns a TH x 16 output tile: the (TH+2) x 18 input window of a
+// 16-channel chunk is loaded ONCE into LDS (padding, reflection, x2-upsample and the two-source concat resolved
+// at that load) and the nine taps read their A fragments straight out of it at compile-time offsets, so a
+// K-step (= one tap of the chunk: 4 k-groups) stages only its 16 x BN weight tile.  Window pixel stride is 20
+// floats: the 16 lanes of a ds_read_b128 service group hit 16 distinct 4-bank groups.
+// ------------------------------------------------------------------------------------------------
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void conv_win3_f32_kernel(const ConvParams p) {
+    constexpr int TH = WM * TM, TW = 16, WH = TH + 2, WW = TW + 2, PS = 20;
+    constexpr int BN = WN * TN * 16;
+    constexpr int WIN = WH * WW * PS;  // floats per window buffer
+    constexpr int BT = BN * 16;        // floats per weight stage
+    constexpr int W_ITEMS = WH * WW * 4;
+    constexpr int W_CNT = (W_ITEMS + 255) / 256;
+    constexpr int B_CNT = (BN * 4 + 255) / 256;
+    static_assert(WM * WN == 4, "4 waves per block");
+    __shared__ __attribute__((aligned(16))) float lds[2 * WIN + 2 * BT];
+    float* const win = lds;
+    float* const bst = lds + 2 * WIN;
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 15, kq = lane >> 4;
+    const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
+    const int nb = gridDim.x;
+    int bid = blockIdx.x;
+    {  // XCD-aware order: each XCD walks a contiguous run of tiles (neighbours share halo rows in its L2)
+        const int q = nb >> 3, r = nb & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int n = bid / (tiles_y * tiles_x);
+    const int trem = bid - n * (tiles_y * tiles_x);
+    const int ty0 = (trem / tiles_x) * TH, tx0 = (trem % tiles_x) * TW;
+    const int n0 = blockIdx.y * BN;
+    const int G = p.G0 + p.G1;
+    const int nchunk0 = (p.G0 + 3) >> 2, nchunk1 = (p.G1 + 3) >> 2, nchunks = nchunk0 + nchunk1;
+
+    // window items of this thread: (pixel, channel group within the chunk)
+    int w_off0[W_CNT], w_off1[W_CNT], w_lds[W_CNT];
+    bool w_ok[W_CNT];
+#pragma unroll
+    for (int r = 0; r < W_CNT; ++r) {
+        const int id = t + 256 * r;
+        const int px = id >> 2, q = id & 3;
+        const int wy = px / WW, wx = px - wy * WW;
+        int iy = ty0 - p.pad_h + wy, ix = tx0 - p.pad_w + wx;
+        bool v = id < W_ITEMS;
+        if (p.pad_mode == PAD_REFLECT) {
+            iy = reflect_idx(iy, p.H);
+            ix = reflect_idx(ix, p.W);
+        }
+        v = v && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        iy = iy < 0 ? 0 : (iy >= p.H ? p.H - 1 : iy);
+        ix = ix < 0 ? 0 : (ix >= p.W ? p.W - 1 : ix);
+        const int sh = p.up0;
+        w_off0[r] = (((n * (p.H >> sh) + (iy >> sh)) * (p.W >> sh) + (ix >> sh)) * p.cs0) + p.co0 + q * 4;
+        w_off1[r] = (((n * p.H + iy) * p.W + ix) * p.cs1) + p.co1 + q * 4;
+        w_ok[r] = v;
+        w_lds[r] = (px < WH * WW ? px : 0) * PS + q * 4;
+    }
+    f32x4 rw[W_CNT], rb[B_CNT];
+    bool rwv[W_CNT];
+    auto load_window = [&](int c) {
+        const bool s1 = c >= nchunk0;
+        const int cg0 = s1 ? (c - nchunk0) * 4 : c * 4;
+        const int Gs = s1 ? p.G1 : p.G0;
+        const float* base = s1 ? p.src1 : p.src0;
+#pragma unroll
+        for (int r = 0; r < W_CNT; ++r) {
+            const int q = (t + 256 * r) & 3;
+            const bool v = w_ok[r] && (cg0 + q) < Gs;
+            const int off = (s1 ? w_off1[r] : w_off0[r]) + (v ? cg0 * 4 : -(q * 4));  // masked lanes re-read channel 0
+            rw[r] = *reinterpret_cast<const f32x4*>(base + off);
+            rwv[r] = v;
+        }
+    };
+    auto store_window = [&](float* W) {
+#pragma unroll
+        for (int r = 0; r < W_CNT; ++r)
+            if (t + 256 * r < W_ITEMS)
+                *reinterpret_cast<f32x4*>(W + w_lds[r]) = rwv[r] ? rw[r] : f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto wrow_of = [&](int c) { return c >= nchunk0 ? p.G0 + (c - nchunk0) * 4 : c * 4; };
+    auto load_b = [&](int c, int tap) {
+        const int g0 = tap * G + wrow_of(c);
+#pragma unroll
+        for (int r = 0; r < B_CNT; ++r) {
+            const int id = t + 256 * r;
+            if (id < BN * 4) {
+                const int gi = id / BN, j = id - gi * BN;
+                rb[r] = *reinterpret_cast<const f32x4*>(p.wp + ((size_t)(g0 + gi) * p.cout_pad + n0 + j) * 4);
+            }
+        }
+    };
+    auto store_b = [&](float* Bs) {
+#pragma unroll
+        for (int r = 0; r < B_CNT; ++r) {
+            const int id = t + 256 * r;
+            if (id < BN * 4) *reinterpret_cast<f32x4*>(Bs + id * 4) = rb[r];
+        }
+    };
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    load_window(0);
+    load_b(0, 0);
+    store_window(win);
+    store_b(bst);
+    __syncthreads();
+    int stage = 0;
+    for (int c = 0; c < nchunks; ++c) {
+        const float* Wc = win + (c & 1) * WIN;
+        float* Wn = win + ((c + 1) & 1) * WIN;
+        const bool next_chunk = c + 1 < nchunks;
+        if (next_chunk) load_window(c + 1);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const float* Bs = bst + stage * BT;
+            const bool more = tap < 8 || next_chunk;
+            if (more) load_b(tap < 8 ? c : c + 1, tap < 8 ? tap + 1 : 0);
+            f32x4 fa[TM], fb[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm * TM + i;
+                fa[i] = *reinterpret_cast<const f32x4*>(Wc + ((row + ky) * WW + (li + kx)) * PS + kq * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = wn * TN * 16 + j * 16 + li;
+                fb[j] = *reinterpret_cast<const f32x4*>(Bs + (kq * BN + col) * 4);
+            }
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][r], fb[j][r], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            if (more) store_b(bst + (stage ^ 1) * BT);
+            if (tap == 4 && next_chunk) store_window(Wn);
+            __syncthreads();
+            stage ^= 1;
+        }
+    }
+
+    // epilogue: C/D layout col = lane&15 (cout), row = (lane>>4)*4 + reg (x position inside the 16-wide tile row)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn * TN * 16 + j * 16 + li;
+        const bool vcol = col < p.cout;
+        const bool zcol = !vcol && col < p.dst_zero_to;
+        const float b = vcol ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int oy = ty0 + wm * TM + i;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ox = tx0 + kq * 4 + r;
+                if (oy < p.Ho && ox < p.Wo) {
+                    const size_t m = ((size_t)n * p.Ho + oy) * p.Wo + ox;
+                    if (vcol) {
+                        float v = acc[i][j][r] + b;
+                        if (p.res) v += p.res[m * p.res_cs + p.res_co + col];
+                        v = apply_act(v, p.act, p.act_param);
+                        p.dst[m * p.dst_cs + p.dst_co + col] = v;
+                    } else if (zcol) {
+                        p.dst[m * p.dst_cs + p.dst_co + col] = 0.f;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // split-K second pass: ordered sum of the partials + bias + residual + activation
 __global__ void conv_splitk_epilogue(const ConvParams p, int splits) {
     const int M = p.N * p.Ho * p.Wo;
@@ -352,7 +537,7 @@ void conv_profile_begin() {
 }
 // cfg ids (BM x BN): 0 <2,2,4,4> 128x128  1 <1,4,2,2> 32x128  2 <4,1,4,4> 256x64  3 <2,2,2,2> 64x64  4 <4,1,4,2> 256x32
 //   5 <2,2,2,1> 64x32  6 <4,1,4,1> 256x16  7 <4,1,1,1> 64x16  8 <1,4,4,2> 64x128  9 <2,2,4,2> 128x64  10 <4,1,2,2> 128x32
-//   11 <4,1,2,1> 128x16
+//   11 <4,1,2,1> 128x16; LDS-window 3x3 kernel: 12 (8x16)x128  13 (8x16)x64  14 (8x16)x32  15 (4x16)x128
 int conv_profile_end(double* ms, double* flops, int* launches) {
     for (int i = 0; i < CONV_NUM_CFGS; i++) {
         ms[i] = 0;
@@ -446,6 +631,40 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) {
 // workgroups (more resident workgroups hide the global -> LDS staging latency; the per-tap gather is served by
 // L2 either way); 128 x 128 keeps the largest maps.  Small grids additionally split K inside launch_cfg.
 // DFVO_CONV_FORCE_BM=<rows> overrides the M tile (tuning aid).
+template <int WM, int WN, int TM, int TN>
+static int launch_win3(const ConvParams& p, hipStream_t stream, int cfg_id) {
+    constexpr int TH = WM * TM, BN = WN * TN * 16;
+    const int tiles = p.N * ((p.Ho + TH - 1) / TH) * ((p.Wo + 15) / 16);
+    dim3 grid((unsigned)tiles, (unsigned)(p.cout_pad / BN), 1);
+    ConvProfEntry pe;
+    if (g_prof) {
+        DFVO_HIP_CHECK(hipEventCreate(&pe.e0));
+        DFVO_HIP_CHECK(hipEventCreate(&pe.e1));
+        pe.cfg = cfg_id;
+        DFVO_HIP_CHECK(hipEventRecord(pe.e0, stream));
+    }
+    hipLaunchKernelGGL((conv_win3_f32_kernel<WM, WN, TM, TN>), grid, dim3(256), 0, stream, p);
+    DFVO_HIP_CHECK(hipGetLastError());
+    if (g_prof) {
+        DFVO_HIP_CHECK(hipEventRecord(pe.e1, stream));
+        pe.flops = p.useful_flops;
+        const int sh[12] = {p.N, p.H, p.W, p.Ho, p.Wo, (p.G0 + p.G1) * 4, p.cout, p.kh, p.stride, (int)grid.x, (int)grid.y, 1};
+        for (int i = 0; i < 12; ++i) pe.shape[i] = sh[i];
+        g_prof->push_back(pe);
+    }
+    return DFVO_OK;
+}
+
+// the LDS-window kernel serves 3x3 / stride-1 layers on maps large enough to fill the chip with TH x 16 tiles
+static bool conv_use_window(const ConvParams& p, int bn) {
+    static const int mode = getenv("DFVO_CONV_WINDOW") ? atoi(getenv("DFVO_CONV_WINDOW")) : 1;
+    if (!mode) return false;
+    if (p.kh != 3 || p.kw != 3 || p.stride != 1 || p.pad_h != 1 || p.pad_w != 1) return false;
+    if (bn < 32) return false;
+    const long long M = (long long)p.N * p.Ho * p.Wo;
+    return M >= 30000;
+}
+
 static int conv_pick_bm(const ConvParams& p, int bn) {
     const long long M = (long long)p.N * p.Ho * p.Wo;
     static const int env_bm = getenv("DFVO_CONV_FORCE_BM") ? atoi(getenv("DFVO_CONV_FORCE_BM")) : 0;
@@ -477,6 +696,12 @@ int launch_conv(const ConvParams& p, hipStream_t stream) {
     DFVO_ARG_CHECK(p.cout_pad % bn == 0, "launch_conv: cout_pad not a multiple of the N tile");
     DFVO_ARG_CHECK((p.cs0 % 4) == 0 && (p.co0 % 4) == 0, "launch_conv: src0 stride/offset must be multiples of 4");
     DFVO_ARG_CHECK(p.G1 == 0 || ((p.cs1 % 4) == 0 && (p.co1 % 4) == 0), "launch_conv: src1 stride/offset");
+    if (conv_use_window(p, bn)) {
+        const long long tiles8 = (long long)p.N * ((p.Ho + 7) / 8) * ((p.Wo + 15) / 16) * (p.cout_pad / bn);
+        if (bn == 128) return tiles8 >= 400 ? launch_win3<2, 2, 4, 4>(p, stream, 12) : launch_win3<1, 4, 4, 2>(p, stream, 15);
+        if (bn == 64) return launch_win3<2, 2, 4, 2>(p, stream, 13);
+        return launch_win3<4, 1, 2, 2>(p, stream, 14);
+    }
     const int bm = conv_pick_bm(p, bn);
     if (bn == 128) {
         if (bm == 128) return launch_cfg<2, 2, 4, 4>(p, stream, 0);

@@ -65,7 +65,7 @@ int make_conv(const ParamStore& ps, const std::string& wname, const std::string&
     L->kw = w->shape[3];
     L->cout_pad = conv_cout_pad(L->cout, M_hint);
     L->ksteps = conv_ksteps(L->kh, L->kw, c0, c1);
-    std::vector<float> pw((size_t)L->ksteps * 4 * L->cout_pad * 4), pb(L->cout_pad);
+    std::vector<float> pw((size_t)(L->ksteps * 4 + 8) * L->cout_pad * 4), pb(L->cout_pad);  // +8 k-groups: the window kernel rounds each source up to 4 groups
     conv_pack_weights(w->data.data(), b ? b->data.data() : nullptr, L->cout, c0, c1, L->kh, L->kw, L->cout_pad,
                       scale, shift, pw.data(), pb.data());
     DFVO_HIP_CHECK(hipMalloc((void**)&L->wp, pw.size() * sizeof(float)));

@@ -65,6 +65,16 @@ CASES = [
     ("big_M_128_128", 2, 96, 160, 128, 0, 128, 3, 3, 1, (1, 1), 0, 1, 0, False),
     ("big_M_64_32", 2, 96, 160, 64, 0, 32, 3, 3, 1, (1, 1), 0, 1, 0, False),
     ("big_M_32_2_5x5", 2, 96, 160, 32, 0, 2, 5, 5, 1, (2, 2), 0, 0, 0, True),
+    # shapes served by the LDS-window 3x3 kernel (M >= 30000): ragged tiles, two sources with a 4-channel tail,
+    # a source that is not a multiple of 16 channels, reflection + x2 upsample + concat, residual
+    ("win_ragged_128_128", 2, 99, 157, 128, 0, 128, 3, 3, 1, (1, 1), 0, 1, 0, False),
+    ("win_cat_128_4_to_128", 2, 96, 168, 128, 4, 128, 3, 3, 1, (1, 1), 0, 1, 0, False),
+    ("win_52_to_128", 2, 100, 152, 52, 0, 128, 3, 3, 1, (1, 1), 0, 1, 0, True),
+    ("win_128_64", 2, 96, 160, 128, 0, 64, 3, 3, 1, (1, 1), 0, 1, 0, False),
+    ("win_32_32_res", 2, 101, 163, 32, 0, 32, 3, 3, 1, (1, 1), 0, 1, 0, True),
+    ("win_64_49", 2, 96, 160, 64, 0, 49, 3, 3, 1, (1, 1), 0, 0, 0, False),
+    ("win_dec_refl_up_cat_elu", 1, 96, 160, 32, 64, 32, 3, 3, 1, (1, 1), 1, 3, 1, False),
+    ("win_small_grid_128", 1, 120, 264, 128, 0, 128, 3, 3, 1, (1, 1), 0, 1, 0, False),
 ]
 
 
