@@ -111,9 +111,9 @@ int dfvo_conv_profile_begin(void) {
     conv_profile_begin();
     return DFVO_OK;
 }
-int dfvo_conv_profile_end(double* h_ms16, double* h_flops16, int* h_launches16) {
-    DFVO_ARG_CHECK(h_ms16 && h_flops16 && h_launches16, "dfvo_conv_profile_end: null argument");
-    return conv_profile_end(h_ms16, h_flops16, h_launches16);
+int dfvo_conv_profile_end(double* h_ms18, double* h_flops18, int* h_launches18) {
+    DFVO_ARG_CHECK(h_ms18 && h_flops18 && h_launches18, "dfvo_conv_profile_end: null argument");
+    return conv_profile_end(h_ms18, h_flops18, h_launches18);
 }
 
 int dfvo_correlation(const float* d_first, const float* d_second, int N, int H, int W, int C, int stride,

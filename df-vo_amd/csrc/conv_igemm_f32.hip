@@ -44,6 +44,37 @@ __device__ __forceinline__ int reflect_idx(int i, int n) {
     return i >= n ? 2 * n - 2 - i : i;
 }
 
+// Epilogue of four consecutive output channels [col0, col0+4) of one pixel (linear index m).  The MFMAs are issued
+// with the weight fragment as the A operand, so a lane's four accumulator registers are four consecutive couts of
+// ONE pixel: bias / residual / store move as 16-byte vectors (a quarter of the store instructions, whole 64-byte
+// runs per pixel) whenever the layer's strides allow it.
+__device__ __forceinline__ void conv_epilogue_quad(const ConvParams& p, size_t m, int col0, f32x4 a, bool vec_ok) {
+    float* d = p.dst + m * p.dst_cs + p.dst_co + col0;
+    if (vec_ok && col0 + 3 < p.cout) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + col0);
+        f32x4 v = a + b;
+        if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + m * p.res_cs + p.res_co + col0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = apply_act(v[q], p.act, p.act_param);
+        *reinterpret_cast<f32x4*>(d) = v;
+        return;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int col = col0 + q;
+        if (col < p.cout) {
+            float v = a[q] + p.bias[col];
+            if (p.res) v += p.res[m * p.res_cs + p.res_co + col];
+            d[q] = apply_act(v, p.act, p.act_param);
+        } else if (col < p.dst_zero_to) {
+            d[q] = 0.f;
+        }
+    }
+}
+__device__ __forceinline__ bool conv_vec_ok(const ConvParams& p) {
+    return (((p.dst_cs | p.dst_co) & 3) == 0) && (!p.res || (((p.res_cs | p.res_co) & 3) == 0));
+}
+
 // k-group table entry built once per block in LDS: which tap / source / channel offset a k-group is
 struct KGroup {
     uint32_t tap;  // ky | kx << 8 | valid << 16 | src << 17
@@ -216,7 +247,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][r], fb[j][r], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j][r], fa[i][r], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         if (more) {
             float* An = lds + (st ^ 1) * TILE;
@@ -225,44 +256,28 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
         __syncthreads();
     }
 
-    // epilogue: C/D layout col = lane&15, row = (lane>>4)*4 + reg
+    // epilogue: D = W^T-fragment x pixels, so lane (li, kq) holds couts kq*4 .. kq*4+3 of pixel li
     if (gridDim.z > 1) {  // split-K partial: raw accumulators to the workspace [z][M][cout_pad]
         float* wsz = p.ws + (size_t)blockIdx.z * M * p.cout_pad;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * TN * 16 + j * 16 + li;
+            const int col0 = n0 + wn * TN * 16 + j * 16 + kq * 4;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = m0 + wm * TM * 16 + i * 16 + kq * 4 + r;
-                    if (m < M) wsz[(size_t)m * p.cout_pad + col] = acc[i][j][r];
-                }
+            for (int i = 0; i < TM; ++i) {
+                const int m = m0 + wm * TM * 16 + i * 16 + li;
+                if (m < M) *reinterpret_cast<f32x4*>(wsz + (size_t)m * p.cout_pad + col0) = acc[i][j];
+            }
         }
         return;
     }
+    const bool vec_ok = conv_vec_ok(p);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * TN * 16 + j * 16 + li;
-        const bool vcol = col < p.cout;
-        const bool zcol = !vcol && col < p.dst_zero_to;
-        const float b = vcol ? p.bias[col] : 0.f;
+        const int col0 = n0 + wn * TN * 16 + j * 16 + kq * 4;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + wm * TM * 16 + i * 16 + kq * 4 + r;
-                if (m < M) {
-                    if (vcol) {
-                        float v = acc[i][j][r] + b;
-                        if (p.res) v += p.res[(size_t)m * p.res_cs + p.res_co + col];
-                        v = apply_act(v, p.act, p.act_param);
-                        p.dst[(size_t)m * p.dst_cs + p.dst_co + col] = v;
-                    } else if (zcol) {
-                        p.dst[(size_t)m * p.dst_cs + p.dst_co + col] = 0.f;
-                    }
-                }
-            }
+            const int m = m0 + wm * TM * 16 + i * 16 + li;
+            if (m < M) conv_epilogue_quad(p, (size_t)m, col0, acc[i][j], vec_ok);
         }
     }
 }
@@ -277,9 +292,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
 // K-step (= one tap of the chunk: 4 k-groups) stages only its 16 x BN weight tile.  Window pixel stride is 20
 // floats: the 16 lanes of a ds_read_b128 service group hit 16 distinct 4-bank groups.
 // ------------------------------------------------------------------------------------------------
-template <int WM, int WN, int TM, int TN>
-__global__ __launch_bounds__(256) void conv_win3_f32_kernel(const ConvParams p) {
-    constexpr int TH = WM * TM, TW = 16, WH = TH + 2, WW = TW + 2, PS = 20;
+template <int WM, int WN, int TM, int TN, int KS>
+__global__ __launch_bounds__(256) void conv_win_f32_kernel(const ConvParams p) {
+    constexpr int TH = WM * TM, TW = 16, WH = TH + KS - 1, WW = TW + KS - 1, PS = 20;
     constexpr int BN = WN * TN * 16;
     constexpr int WIN = WH * WW * PS;  // floats per window buffer
     constexpr int BT = BN * 16;        // floats per weight stage
@@ -307,6 +322,10 @@ __global__ __launch_bounds__(256) void conv_win3_f32_kernel(const ConvParams p) 
     const int n0 = blockIdx.y * BN;
     const int G = p.G0 + p.G1;
     const int nchunk0 = (p.G0 + 3) >> 2, nchunk1 = (p.G1 + 3) >> 2, nchunks = nchunk0 + nchunk1;
+    // split-K over the channel chunks: this workgroup contracts chunks [c_begin, c_end)
+    const int cper = (nchunks + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int c_begin = (int)blockIdx.z * cper;
+    const int c_end = c_begin + cper < nchunks ? c_begin + cper : nchunks;
 
     // window items of this thread: (pixel, channel group within the chunk)
     int w_off0[W_CNT], w_off1[W_CNT], w_lds[W_CNT];
@@ -379,23 +398,26 @@ __global__ __launch_bounds__(256) void conv_win3_f32_kernel(const ConvParams p) 
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    load_window(0);
-    load_b(0, 0);
-    store_window(win);
-    store_b(bst);
+    constexpr int TAPS = KS * KS;
+    if (c_begin < c_end) {
+        load_window(c_begin);
+        load_b(c_begin, 0);
+        store_window(win + (c_begin & 1) * WIN);
+        store_b(bst);
+    }
     __syncthreads();
     int stage = 0;
-    for (int c = 0; c < nchunks; ++c) {
+    for (int c = c_begin; c < c_end; ++c) {
         const float* Wc = win + (c & 1) * WIN;
         float* Wn = win + ((c + 1) & 1) * WIN;
-        const bool next_chunk = c + 1 < nchunks;
+        const bool next_chunk = c + 1 < c_end;
         if (next_chunk) load_window(c + 1);
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap - ky * 3;
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int ky = tap / KS, kx = tap - ky * KS;
             const float* Bs = bst + stage * BT;
-            const bool more = tap < 8 || next_chunk;
-            if (more) load_b(tap < 8 ? c : c + 1, tap < 8 ? tap + 1 : 0);
+            const bool more = tap < TAPS - 1 || next_chunk;
+            if (more) load_b(tap < TAPS - 1 ? c : c + 1, tap < TAPS - 1 ? tap + 1 : 0);
             f32x4 fa[TM], fb[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -414,40 +436,40 @@ __global__ __launch_bounds__(256) void conv_win3_f32_kernel(const ConvParams p) 
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][r], fb[j][r], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[j][r], fa[i][r], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
             if (more) store_b(bst + (stage ^ 1) * BT);
-            if (tap == 4 && next_chunk) store_window(Wn);
+            if (tap == TAPS / 2 && next_chunk) store_window(Wn);
             __syncthreads();
             stage ^= 1;
         }
     }
 
-    // epilogue: C/D layout col = lane&15 (cout), row = (lane>>4)*4 + reg (x position inside the 16-wide tile row)
+    // epilogue: lane (li, kq) holds couts kq*4 .. kq*4+3 of the pixel at x = tx0 + li of its tile rows
+    const int ox = tx0 + li;
+    if (gridDim.z > 1) {  // split-K partial: raw accumulators to the workspace [z][M][cout_pad]
+        const size_t Mtot = (size_t)p.N * p.Ho * p.Wo;
+        float* wsz = p.ws + (size_t)blockIdx.z * Mtot * p.cout_pad;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col0 = n0 + wn * TN * 16 + j * 16 + kq * 4;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int oy = ty0 + wm * TM + i;
+                if (oy < p.Ho && ox < p.Wo)
+                    *reinterpret_cast<f32x4*>(wsz + (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.cout_pad + col0) = acc[i][j];
+            }
+        }
+        return;
+    }
+    const bool vec_ok = conv_vec_ok(p);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int col = n0 + wn * TN * 16 + j * 16 + li;
-        const bool vcol = col < p.cout;
-        const bool zcol = !vcol && col < p.dst_zero_to;
-        const float b = vcol ? p.bias[col] : 0.f;
+        const int col0 = n0 + wn * TN * 16 + j * 16 + kq * 4;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int oy = ty0 + wm * TM + i;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int ox = tx0 + kq * 4 + r;
-                if (oy < p.Ho && ox < p.Wo) {
-                    const size_t m = ((size_t)n * p.Ho + oy) * p.Wo + ox;
-                    if (vcol) {
-                        float v = acc[i][j][r] + b;
-                        if (p.res) v += p.res[m * p.res_cs + p.res_co + col];
-                        v = apply_act(v, p.act, p.act_param);
-                        p.dst[m * p.dst_cs + p.dst_co + col] = v;
-                    } else if (zcol) {
-                        p.dst[m * p.dst_cs + p.dst_co + col] = 0.f;
-                    }
-                }
-            }
+            if (oy < p.Ho && ox < p.Wo) conv_epilogue_quad(p, ((size_t)n * p.Ho + oy) * p.Wo + ox, col0, acc[i][j], vec_ok);
         }
     }
 }
@@ -538,6 +560,7 @@ void conv_profile_begin() {
 // cfg ids (BM x BN): 0 <2,2,4,4> 128x128  1 <1,4,2,2> 32x128  2 <4,1,4,4> 256x64  3 <2,2,2,2> 64x64  4 <4,1,4,2> 256x32
 //   5 <2,2,2,1> 64x32  6 <4,1,4,1> 256x16  7 <4,1,1,1> 64x16  8 <1,4,4,2> 64x128  9 <2,2,4,2> 128x64  10 <4,1,2,2> 128x32
 //   11 <4,1,2,1> 128x16; LDS-window 3x3 kernel: 12 (8x16)x128  13 (8x16)x64  14 (8x16)x32  15 (4x16)x128
+//   16 7x7 (8x16)x16  17 5x5 (8x16)x16
 int conv_profile_end(double* ms, double* flops, int* launches) {
     for (int i = 0; i < CONV_NUM_CFGS; i++) {
         ms[i] = 0;
@@ -631,11 +654,25 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) {
 // workgroups (more resident workgroups hide the global -> LDS staging latency; the per-tap gather is served by
 // L2 either way); 128 x 128 keeps the largest maps.  Small grids additionally split K inside launch_cfg.
 // DFVO_CONV_FORCE_BM=<rows> overrides the M tile (tuning aid).
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int KS = 3>
 static int launch_win3(const ConvParams& p, hipStream_t stream, int cfg_id) {
     constexpr int TH = WM * TM, BN = WN * TN * 16;
     const int tiles = p.N * ((p.Ho + TH - 1) / TH) * ((p.Wo + 15) / 16);
     dim3 grid((unsigned)tiles, (unsigned)(p.cout_pad / BN), 1);
+    // split the channel chunks when the tile grid cannot fill the chip
+    const int nchunks = ((p.G0 + 3) >> 2) + ((p.G1 + 3) >> 2);
+    const long long M = (long long)p.N * p.Ho * p.Wo;
+    int splits = 1;
+    const long long blocks = (long long)grid.x * grid.y;
+    if (p.ws && blocks < 600 && nchunks >= 4) {
+        splits = (int)((1024 + blocks - 1) / blocks);
+        if (splits > nchunks / 2) splits = nchunks / 2;
+        while (splits > 1 && (size_t)splits * M * p.cout_pad > p.ws_floats) --splits;
+        if (splits < 1) splits = 1;
+        const int per = (nchunks + splits - 1) / splits;
+        splits = (nchunks + per - 1) / per;
+    }
+    grid.z = (unsigned)splits;
     ConvProfEntry pe;
     if (g_prof) {
         DFVO_HIP_CHECK(hipEventCreate(&pe.e0));
@@ -643,12 +680,18 @@ static int launch_win3(const ConvParams& p, hipStream_t stream, int cfg_id) {
         pe.cfg = cfg_id;
         DFVO_HIP_CHECK(hipEventRecord(pe.e0, stream));
     }
-    hipLaunchKernelGGL((conv_win3_f32_kernel<WM, WN, TM, TN>), grid, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((conv_win_f32_kernel<WM, WN, TM, TN, KS>), grid, dim3(256), 0, stream, p);
     DFVO_HIP_CHECK(hipGetLastError());
+    if (splits > 1) {
+        const int cols = p.dst_zero_to > p.cout ? p.dst_zero_to : p.cout;
+        const long long total = M * cols;
+        hipLaunchKernelGGL(conv_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p, splits);
+        DFVO_HIP_CHECK(hipGetLastError());
+    }
     if (g_prof) {
         DFVO_HIP_CHECK(hipEventRecord(pe.e1, stream));
         pe.flops = p.useful_flops;
-        const int sh[12] = {p.N, p.H, p.W, p.Ho, p.Wo, (p.G0 + p.G1) * 4, p.cout, p.kh, p.stride, (int)grid.x, (int)grid.y, 1};
+        const int sh[12] = {p.N, p.H, p.W, p.Ho, p.Wo, (p.G0 + p.G1) * 4, p.cout, p.kh, p.stride, (int)grid.x, (int)grid.y, (int)grid.z};
         for (int i = 0; i < 12; ++i) pe.shape[i] = sh[i];
         g_prof->push_back(pe);
     }
@@ -659,10 +702,12 @@ static int launch_win3(const ConvParams& p, hipStream_t stream, int cfg_id) {
 static bool conv_use_window(const ConvParams& p, int bn) {
     static const int mode = getenv("DFVO_CONV_WINDOW") ? atoi(getenv("DFVO_CONV_WINDOW")) : 1;
     if (!mode) return false;
-    if (p.kh != 3 || p.kw != 3 || p.stride != 1 || p.pad_h != 1 || p.pad_w != 1) return false;
-    if (bn < 32) return false;
+    if (p.kh != p.kw || p.stride != 1 || p.pad_h != p.kh / 2 || p.pad_w != p.kw / 2) return false;
     const long long M = (long long)p.N * p.Ho * p.Wo;
-    return M >= 30000;
+    static const long long min_m = getenv("DFVO_CONV_WINDOW_MIN_M") ? atoll(getenv("DFVO_CONV_WINDOW_MIN_M")) : 30000;
+    if (p.kh == 3) return bn >= 32 && M >= min_m;
+    // 5x5 / 7x7 flow heads (32 -> 2 channels): the whole tap loop runs out of one window
+    return (p.kh == 5 || p.kh == 7) && bn == 16 && (p.G0 + p.G1) >= 4 && M >= 8000;
 }
 
 static int conv_pick_bm(const ConvParams& p, int bn) {
@@ -696,6 +741,8 @@ int launch_conv(const ConvParams& p, hipStream_t stream) {
     DFVO_ARG_CHECK(p.cout_pad % bn == 0, "launch_conv: cout_pad not a multiple of the N tile");
     DFVO_ARG_CHECK((p.cs0 % 4) == 0 && (p.co0 % 4) == 0, "launch_conv: src0 stride/offset must be multiples of 4");
     DFVO_ARG_CHECK(p.G1 == 0 || ((p.cs1 % 4) == 0 && (p.co1 % 4) == 0), "launch_conv: src1 stride/offset");
+    if (conv_use_window(p, bn) && p.kh == 7) return launch_win3<4, 1, 2, 1, 7>(p, stream, 16);
+    if (conv_use_window(p, bn) && p.kh == 5) return launch_win3<4, 1, 2, 1, 5>(p, stream, 17);
     if (conv_use_window(p, bn)) {
         const long long tiles8 = (long long)p.N * ((p.Ho + 7) / 8) * ((p.Wo + 15) / 16) * (p.cout_pad / bn);
         if (bn == 128) return tiles8 >= 400 ? launch_win3<2, 2, 4, 4>(p, stream, 12) : launch_win3<1, 4, 4, 2>(p, stream, 15);

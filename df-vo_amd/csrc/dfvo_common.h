@@ -89,7 +89,7 @@ void conv_pack_weights(const float* w_oihw, const float* bias, int cout, int c0,
                        int cout_pad, const float* fold_scale, const float* fold_shift, float* out_w,
                        float* out_b);
 
-constexpr int CONV_NUM_CFGS = 16;  // tile configurations of the implicit-GEMM kernel (profile arrays have this size)
+constexpr int CONV_NUM_CFGS = 18;  // tile configurations of the implicit-GEMM kernel (profile arrays have this size)
 int launch_conv(const ConvParams& p, hipStream_t stream);
 // effective (bm, splits) the launcher would use for p (after clamping the overrides)
 void conv_effective_config(const ConvParams& p, int* bm, int* splits);

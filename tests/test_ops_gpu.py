@@ -75,6 +75,8 @@ CASES = [
     ("win_64_49", 2, 96, 160, 64, 0, 49, 3, 3, 1, (1, 1), 0, 0, 0, False),
     ("win_dec_refl_up_cat_elu", 1, 96, 160, 32, 64, 32, 3, 3, 1, (1, 1), 1, 3, 1, False),
     ("win_small_grid_128", 1, 120, 264, 128, 0, 128, 3, 3, 1, (1, 1), 0, 1, 0, False),
+    ("win7_32_2_res", 2, 97, 170, 32, 0, 2, 7, 7, 1, (3, 3), 0, 0, 0, True),
+    ("win5_32_2", 2, 48, 156, 32, 0, 2, 5, 5, 1, (2, 2), 0, 0, 0, False),
 ]
 
 
