@@ -174,6 +174,19 @@ def main():
                 "share_of_conv_time": round(float(ms[dom] / ms.sum()), 3),
                 "conv_family_achieved": round(fam, 2), "conv_family_ms_per_pair": round(float(ms.sum() / nprof), 3),
                 "algorithmic_gflop_per_pair": round(net_flops / 1e9, 1)}
+    if roof is not None:
+        # HBM-side bytes per launch of that kernel from the committed rocprofv3 --pmc passes over this same command
+        # (tools/pmc_traffic.py: FETCH_SIZE x2 on gfx950 + WRITE_SIZE); None when no profile matches the kernel
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r1q_pmc_bench.json")))["kernels"]
+            key = CFG_NAMES[dom].split(" ")[0].replace("conv_igemm_f32<", "conv_igemm_f32_kernel<").replace(
+                "conv_win3_f32<", "conv_win_f32_kernel<").replace("conv_win_f32<", "conv_win_f32_kernel<")
+            cand = [k for k in prof if k.replace(" ", "").startswith(key.rstrip(">").replace(" ", ""))]
+            if cand:
+                roof["traffic"] = round(prof[cand[0]]["hbm_bytes_per_dispatch"])
+                roof["traffic_unit"] = "bytes per launch (rocprofv3 PMC, profiles/r1q_pmc_bench.json)"
+        except (OSError, KeyError, ValueError):
+            pass
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base = cpu_baseline(syn, H, W, scenes)
