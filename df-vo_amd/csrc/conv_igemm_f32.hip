@@ -744,6 +744,10 @@ int launch_conv(const ConvParams& p, hipStream_t stream) {
     if (conv_use_window(p, bn) && p.kh == 7) return launch_win3<4, 1, 2, 1, 7>(p, stream, 16);
     if (conv_use_window(p, bn) && p.kh == 5) return launch_win3<4, 1, 2, 1, 5>(p, stream, 17);
     if (conv_use_window(p, bn)) {
+        static const int force_cfg = getenv("DFVO_CONV_WIN_CFG") ? atoi(getenv("DFVO_CONV_WIN_CFG")) : 0;  // tuning aid
+        if (force_cfg == 13 && p.cout_pad % 64 == 0) return launch_win3<2, 2, 4, 2>(p, stream, 13);
+        if (force_cfg == 15 && bn == 128) return launch_win3<1, 4, 4, 2>(p, stream, 15);
+        if (force_cfg == 14 && p.cout_pad % 32 == 0) return launch_win3<4, 1, 2, 2>(p, stream, 14);
         const long long tiles8 = (long long)p.N * ((p.Ho + 7) / 8) * ((p.Wo + 15) / 16) * (p.cout_pad / bn);
         if (bn == 128) return tiles8 >= 400 ? launch_win3<2, 2, 4, 4>(p, stream, 12) : launch_win3<1, 4, 4, 2>(p, stream, 15);
         if (bn == 64) return launch_win3<2, 2, 4, 2>(p, stream, 13);

@@ -317,11 +317,18 @@ SM_HD_NOINLINE void jacobi_eigen(double* A, double* W, double* V) {
 
 // solve(A, b, x, DECOMP_EIG) / invert(A, DECOMP_EIG) for symmetric A (SVBkSb back-substitution)
 // ws: 2*N*N + 2*N doubles
+// SVBkSb for solve(DECOMP_EIG): x = sum_i (v_i . b / w_i) v_i over the eigenvector rows v_i
+template <int N>
+SM_HD void svbksb_eig_vec(const double* w, const double* v, const double* b, double* x);
 template <int N>
 SM_HD void solve_eig_ws(const double* A, const double* b, double* x, double* ws) {
     double *a = ws, *v = ws + N * N, *w = ws + 2 * N * N;
     for (int i = 0; i < N * N; i++) a[i] = A[i];
     jacobi_eigen_ws<N>(a, w, v, reinterpret_cast<int*>(ws + 2 * N * N + N));
+    svbksb_eig_vec<N>(w, v, b, x);
+}
+template <int N>
+SM_HD void svbksb_eig_vec(const double* w, const double* v, const double* b, double* x) {
     const double eps = DBL_EPSILON * 2;
     double threshold = 0;
     for (int i = 0; i < N; i++) x[i] = 0;
@@ -793,6 +800,7 @@ SM_HD void homography_accumulate(const HNorm& h, float Mx_, float My_, float mx_
         for (int k = j; k < 9; k++) LtL[j * 9 + k] += Lx[j] * Lx[k] + Ly[j] * Ly[k];
 }
 // finish: symmetric completion, eigen decomposition, de-normalisation, scale so that H[8] = 1
+SM_HD void homography_denormalise(const HNorm& h, const double* H0v, double* model);
 constexpr int HOMOGRAPHY_FINISH_WS = 9 + 81 + 9;  // doubles: W, V, pivot tables
 constexpr int HOMOGRAPHY_KERNEL_WS = 81 + HOMOGRAPHY_FINISH_WS;
 SM_HD void homography_finish_ws(const HNorm& h, double* LtL, double* model, double* ws) {
@@ -800,10 +808,14 @@ SM_HD void homography_finish_ws(const HNorm& h, double* LtL, double* model, doub
     for (int j = 0; j < 9; j++)
         for (int k = 0; k < j; k++) LtL[j * 9 + k] = LtL[k * 9 + j];
     jacobi_eigen_ws<9>(LtL, W, V, reinterpret_cast<int*>(ws + 90));
+    homography_denormalise(h, V + 72, model);
+}
+// H = invHnorm * H0 * Hnorm2 scaled so that H[8] = 1, H0 = the eigenvector of the smallest eigenvalue (row-major 3x3)
+SM_HD void homography_denormalise(const HNorm& h, const double* H0v, double* model) {
     const double invHnorm[9] = {1. / h.smx, 0, h.cmx, 0, 1. / h.smy, h.cmy, 0, 0, 1};
     const double Hnorm2[9] = {h.sMx, 0, -h.cMx * h.sMx, 0, h.sMy, -h.cMy * h.sMy, 0, 0, 1};
     double Htemp[9], H0[9];
-    mul33(invHnorm, V + 72, Htemp);
+    mul33(invHnorm, H0v, Htemp);
     mul33(Htemp, Hnorm2, H0);
     const double s = 1. / H0[8];
     for (int k = 0; k < 9; k++) model[k] = H0[k] * s;

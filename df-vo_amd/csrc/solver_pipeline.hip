@@ -848,9 +848,18 @@ int enqueue_compute_pose_2d2d(TrackerBuffers& tb, int n_host, const PoseConfig& 
         // the shuffle chain runs on s_rep[0] so that the homography (on s) starts at once
         DFVO_HIP_CHECK(hipEventRecord(tb.ev_start, s));
         DFVO_HIP_CHECK(hipStreamWaitEvent(tb.s_rep[0], tb.ev_start, 0));
+        // the homography chain is the longer one: it is enqueued FIRST so that the host's launch calls for the
+        // five-point batch do not delay it
+        // ---- homography + GRIC-H (kp_cur -> kp_ref)
+        int rc = enqueue_find_homography(tb.ws_h, tb.kp_cur, tb.kp_ref, n_host, 1.0, 2000, 0.99, s);
+        if (rc != DFVO_OK) return rc;
+        hipLaunchKernelGGL(k_gric_h_residual, dim3(nb), dim3(256), 0, s, tb.ws_h.out, tb.kp_info, tb.kp_cur, tb.kp_ref,
+                           tb.res);
+        hipLaunchKernelGGL(k_gric_sum, dim3(1), dim3(256), 0, s, tb.res, 0, tb.kp_info, 0.8, 8, 2, tb.small + 18);
+        hipLaunchKernelGGL(k_set_h_gric, dim3(1), dim3(1), 0, s, tb.pose, tb.ws_h.state, tb.small + 18);
         hipStream_t sr = tb.s_rep[0];
         const unsigned R = (unsigned)cfg.repeat;
-        int rc = enqueue_mt_shuffle(tb.mt_state, tb.kp_info, n_host, cfg.repeat, cap + 8, tb.perm, sr);
+        rc = enqueue_mt_shuffle(tb.mt_state, tb.kp_info, n_host, cfg.repeat, cap + 8, tb.perm, sr);
         if (rc != DFVO_OK) return rc;
         hipLaunchKernelGGL(k_permute_points, dim3(nb, R), dim3(256), 0, sr, tb.kp_info, tb.perm, cap + 8, tb.kp_cur,
                            tb.kp_ref, tb.pa, tb.pb, 2 * cap);
@@ -869,13 +878,6 @@ int enqueue_compute_pose_2d2d(TrackerBuffers& tb, int n_host, const PoseConfig& 
                            tb.pb, 2 * cap, tb.res + cap, cap);
         hipLaunchKernelGGL(k_gric_sum, dim3(R), dim3(256), 0, sr, tb.res + cap, cap, tb.kp_info, 0.8, 5, 3, tb.small + 19);
         DFVO_HIP_CHECK(hipEventRecord(tb.ev_rep[0], sr));
-        // ---- homography + GRIC-H (kp_cur -> kp_ref)
-        rc = enqueue_find_homography(tb.ws_h, tb.kp_cur, tb.kp_ref, n_host, 1.0, 2000, 0.99, s);
-        if (rc != DFVO_OK) return rc;
-        hipLaunchKernelGGL(k_gric_h_residual, dim3(nb), dim3(256), 0, s, tb.ws_h.out, tb.kp_info, tb.kp_cur, tb.kp_ref,
-                           tb.res);
-        hipLaunchKernelGGL(k_gric_sum, dim3(1), dim3(256), 0, s, tb.res, 0, tb.kp_info, 0.8, 8, 2, tb.small + 18);
-        hipLaunchKernelGGL(k_set_h_gric, dim3(1), dim3(1), 0, s, tb.pose, tb.ws_h.state, tb.small + 18);
         DFVO_HIP_CHECK(hipStreamWaitEvent(s, tb.ev_rep[0], 0));
         for (int rep = 0; rep < cfg.repeat; ++rep) {
             hipLaunchKernelGGL(k_rep_update, dim3(1), dim3(256), 0, s, tb.pose, tb.ws_rep[rep].state, tb.ws_rep[rep].out,

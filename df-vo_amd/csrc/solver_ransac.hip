@@ -397,20 +397,147 @@ __global__ void k_h_subsets(RansacState* st, int* __restrict__ idx, const float*
     st->rng_state = rng.state;
 }
 
-// one 4-point hypothesis per lane; the 9x9 LtL / eigenvector / pivot tables of a lane live in LDS (odd
-// per-lane stride: conflict-free when the lanes walk the same index) because the Jacobi sweeps index
-// them with data-dependent subscripts, which would otherwise go through scratch memory
-constexpr int H_SOLVE_LANES = 32;
-constexpr int H_SOLVE_STRIDE = sm::HOMOGRAPHY_KERNEL_WS + 1;  // 181 doubles
-__global__ __launch_bounds__(H_SOLVE_LANES) void k_h_solve(const RansacState* st, const int* __restrict__ idx,
-                                                            const float* __restrict__ src,
-                                                            const float* __restrict__ dst, int it0, int it1,
-                                                            double* __restrict__ models, int* __restrict__ nmodels) {
-    __shared__ double s_ws[H_SOLVE_LANES * H_SOLVE_STRIDE];
-    const int it = it0 + blockIdx.x * H_SOLVE_LANES + threadIdx.x;
+
+// ------------------------------------------------------------------------------------------------
+// Jacobi eigen decomposition run by ONE WAVEFRONT on a matrix in LDS (same arithmetic, element for element, as
+// sm::jacobi_eigen_ws: the rotation sequence is data dependent and stays sequential, but inside a rotation the
+// pivot search is a (value, scan order) max-reduction over <= 16 lanes, the element pairs of the two rows/columns
+// are rotated one per lane, and the four pivot-table rescans run on four lanes).  ~10x the single-lane rate.
+// ------------------------------------------------------------------------------------------------
+#define WAVE_LDS_SYNC()                                          \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   \
+        __builtin_amdgcn_wave_barrier();                         \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   \
+    } while (0)
+
+template <int N>
+__device__ void jacobi_eigen_coop(double* A, double* W, double* V, int* ind, int lane) {
+    const double eps = DBL_EPSILON;
+    int *indR = ind, *indC = ind + N;
+    auto scan_row = [&](int k) {  // first maximum of |A[k][i]|, i > k
+        int m = k + 1;
+        double mv = fabs(A[N * k + m]);
+        for (int i = k + 2; i < N; i++) {
+            const double val = fabs(A[N * k + i]);
+            if (mv < val) mv = val, m = i;
+        }
+        return m;
+    };
+    auto scan_col = [&](int k) {  // first maximum of |A[i][k]|, i < k
+        int m = 0;
+        double mv = fabs(A[k]);
+        for (int i = 1; i < k; i++) {
+            const double val = fabs(A[N * i + k]);
+            if (mv < val) mv = val, m = i;
+        }
+        return m;
+    };
+    for (int idx = lane; idx < N * N; idx += 64) V[idx] = (idx / N == idx % N) ? 1. : 0.;
+    if (lane < N) {
+        W[lane] = A[(N + 1) * lane];
+        if (lane < N - 1) indR[lane] = scan_row(lane);
+        if (lane > 0) indC[lane] = scan_col(lane);
+    }
+    WAVE_LDS_SYNC();
+    const int maxIters = N * N * 30;
+    for (int iters = 0; iters < maxIters; iters++) {
+        // pivot candidates in the sequential scan order: rows 0..N-2 (via indR), then columns 1..N-1 (via indC)
+        double val = -1.;
+        int ck = 0, cl = 0, ord = lane;
+        if (lane < N - 1) {
+            ck = lane;
+            cl = indR[lane];
+            val = fabs(A[N * ck + cl]);
+        } else if (lane < 2 * N - 2) {
+            cl = lane - (N - 1) + 1;
+            ck = indC[cl];
+            val = fabs(A[N * ck + cl]);
+        }
+#pragma unroll
+        for (int sh = 8; sh >= 1; sh >>= 1) {
+            const double ov = __shfl_xor(val, sh, 64);
+            const int oo = __shfl_xor(ord, sh, 64);
+            if (ov > val || (ov == val && oo < ord)) {
+                val = ov;
+                ord = oo;
+            }
+        }
+        ord = __shfl(ord, 0, 64);  // lanes 0..15 agree; broadcast to the rest of the wave
+        const int k = __shfl(ck, ord, 64), l = __shfl(cl, ord, 64);
+        const double p = A[N * k + l];
+        if (fabs(p) <= eps) break;
+        const double y = (W[l] - W[k]) * 0.5;
+        double t = fabs(y) + sm::hypot_p(p, y);
+        double sn = sm::hypot_p(p, t);
+        const double c = t / sn;
+        sn = p / sn;
+        t = (p / t) * p;
+        if (y < 0) sn = -sn, t = -t;
+        WAVE_LDS_SYNC();  // every lane has read W[k], W[l], A[k][l]
+        if (lane == 0) {
+            A[N * k + l] = 0;
+            W[k] -= t;
+            W[l] += t;
+        }
+        if (lane < N) {
+            const int i = lane;
+            double a0, b0;
+            if (i < k) {
+                a0 = A[N * i + k], b0 = A[N * i + l];
+                A[N * i + k] = a0 * c - b0 * sn;
+                A[N * i + l] = a0 * sn + b0 * c;
+            } else if (i > k && i < l) {
+                a0 = A[N * k + i], b0 = A[N * i + l];
+                A[N * k + i] = a0 * c - b0 * sn;
+                A[N * i + l] = a0 * sn + b0 * c;
+            } else if (i > l) {
+                a0 = A[N * k + i], b0 = A[N * l + i];
+                A[N * k + i] = a0 * c - b0 * sn;
+                A[N * l + i] = a0 * sn + b0 * c;
+            }
+            a0 = V[N * k + i], b0 = V[N * l + i];
+            V[N * k + i] = a0 * c - b0 * sn;
+            V[N * l + i] = a0 * sn + b0 * c;
+        }
+        WAVE_LDS_SYNC();
+        if (lane == 0 && k < N - 1) indR[k] = scan_row(k);
+        if (lane == 1 && k > 0) indC[k] = scan_col(k);
+        if (lane == 2 && l < N - 1) indR[l] = scan_row(l);
+        if (lane == 3 && l > 0) indC[l] = scan_col(l);
+        WAVE_LDS_SYNC();
+    }
+    if (lane == 0) {  // descending selection sort of the eigenvalues with their vectors
+        for (int k = 0; k < N - 1; k++) {
+            int m = k;
+            for (int i = k + 1; i < N; i++)
+                if (W[m] < W[i]) m = i;
+            if (k != m) {
+                double t = W[m];
+                W[m] = W[k];
+                W[k] = t;
+                for (int i = 0; i < N; i++) {
+                    t = V[N * m + i];
+                    V[N * m + i] = V[N * k + i];
+                    V[N * k + i] = t;
+                }
+            }
+        }
+    }
+    WAVE_LDS_SYNC();
+}
+
+// one 4-point hypothesis per wavefront: normalisation constants on lane 0, the 45 LtL entries one per lane, the
+// 9 x 9 eigen decomposition cooperatively (jacobi_eigen_coop), de-normalisation on lane 0
+__global__ __launch_bounds__(64) void k_h_solve(const RansacState* st, const int* __restrict__ idx,
+                                                 const float* __restrict__ src, const float* __restrict__ dst, int it0,
+                                                 int it1, double* __restrict__ models, int* __restrict__ nmodels) {
+    __shared__ double s_LtL[81], s_W[9], s_V[81], s_norm[8];
+    __shared__ int s_ind[18], s_ok;
+    const int it = it0 + blockIdx.x, lane = threadIdx.x;
     if (st->done || it >= it1) return;
     if (st->subset_fail_at >= 0 && it >= st->subset_fail_at) {
-        nmodels[it] = 0;
+        if (lane == 0) nmodels[it] = 0;
         return;
     }
     float M[8], m[8];
@@ -421,11 +548,72 @@ __global__ __launch_bounds__(H_SOLVE_LANES) void k_h_solve(const RansacState* st
         m[i * 2] = dst[k * 2];
         m[i * 2 + 1] = dst[k * 2 + 1];
     }
-    double model[9];
-    const bool ok = sm::homography_kernel_ws(M, m, 4, model, s_ws + threadIdx.x * H_SOLVE_STRIDE);
-    if (ok)
+    if (lane == 0) {  // HomographyEstimatorCallback::runKernel normalisation (sequential sums over the 4 points)
+        sm::HNorm h;
+        h.cMx = h.cMy = h.cmx = h.cmy = h.sMx = h.sMy = h.smx = h.smy = 0;
+        for (int i = 0; i < 4; i++) {
+            h.cmx += m[i * 2];
+            h.cmy += m[i * 2 + 1];
+            h.cMx += M[i * 2];
+            h.cMy += M[i * 2 + 1];
+        }
+        h.cmx /= 4;
+        h.cmy /= 4;
+        h.cMx /= 4;
+        h.cMy /= 4;
+        for (int i = 0; i < 4; i++) {
+            h.smx += fabs(m[i * 2] - h.cmx);
+            h.smy += fabs(m[i * 2 + 1] - h.cmy);
+            h.sMx += fabs(M[i * 2] - h.cMx);
+            h.sMy += fabs(M[i * 2 + 1] - h.cMy);
+        }
+        const bool deg = fabs(h.smx) < DBL_EPSILON || fabs(h.smy) < DBL_EPSILON || fabs(h.sMx) < DBL_EPSILON ||
+                         fabs(h.sMy) < DBL_EPSILON;
+        s_ok = deg ? 0 : 1;
+        if (!deg) {
+            h.smx = 4 / h.smx;
+            h.smy = 4 / h.smy;
+            h.sMx = 4 / h.sMx;
+            h.sMy = 4 / h.sMy;
+        }
+        s_norm[0] = h.cMx; s_norm[1] = h.cMy; s_norm[2] = h.cmx; s_norm[3] = h.cmy;
+        s_norm[4] = h.sMx; s_norm[5] = h.sMy; s_norm[6] = h.smx; s_norm[7] = h.smy;
+    }
+    __syncthreads();
+    if (!s_ok) {
+        if (lane == 0) nmodels[it] = 0;
+        return;
+    }
+    sm::HNorm h;
+    h.cMx = s_norm[0]; h.cMy = s_norm[1]; h.cmx = s_norm[2]; h.cmy = s_norm[3];
+    h.sMx = s_norm[4]; h.sMy = s_norm[5]; h.smx = s_norm[6]; h.smy = s_norm[7];
+    if (lane < 45) {  // upper-triangle entry (lj, lk): sequential sum over the points (homography_accumulate)
+        int lj = 0, rem = lane;
+        while (rem >= 9 - lj) {
+            rem -= 9 - lj;
+            lj++;
+        }
+        const int lk = lj + rem;
+        double acc = 0;
+        for (int i = 0; i < 4; i++) {
+            const double x = (m[i * 2] - h.cmx) * h.smx, y = (m[i * 2 + 1] - h.cmy) * h.smy;
+            const double X = (M[i * 2] - h.cMx) * h.sMx, Y = (M[i * 2 + 1] - h.cMy) * h.sMy;
+            const double Lx[9] = {X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x};
+            const double Ly[9] = {0, 0, 0, X, Y, 1, -y * X, -y * Y, -y};
+            acc += Lx[lj] * Lx[lk] + Ly[lj] * Ly[lk];
+        }
+        s_LtL[lj * 9 + lk] = acc;
+        s_LtL[lk * 9 + lj] = acc;
+    }
+    __syncthreads();
+    jacobi_eigen_coop<9>(s_LtL, s_W, s_V, s_ind, lane);
+    __syncthreads();
+    if (lane == 0) {
+        double model[9];
+        sm::homography_denormalise(h, s_V + 72, model);
         for (int i = 0; i < 9; i++) models[(size_t)it * 9 + i] = model[i];
-    nmodels[it] = ok ? 1 : 0;
+        nmodels[it] = 1;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_h_score(const RansacState* st, int it0, int it1,
@@ -734,7 +922,14 @@ __global__ __launch_bounds__(256) void k_h_refine(const RansacState* st, const f
         __syncthreads();
         if (t < 45) s_LtL[lj * 9 + lk] = acc;
         __syncthreads();
-        if (t == 0) sm::homography_finish_ws(hn, s_LtL, s_h, s_eig);
+        if (t < 81) {  // symmetric completion, then the 9 x 9 eigen decomposition on wave 0
+            const int j = t / 9, k = t % 9;
+            if (k < j) s_LtL[t] = s_LtL[k * 9 + j];
+        }
+        __syncthreads();
+        if (wave == 0) jacobi_eigen_coop<9>(s_LtL, s_eig, s_eig + 9, reinterpret_cast<int*>(s_eig + 90), lane);
+        __syncthreads();
+        if (t == 0) sm::homography_denormalise(hn, s_eig + 9 + 72, s_h);
     } else if (t == 0) {
         for (int i = 0; i < 9; i++) s_h[i] = H_io[i];
     }
@@ -823,9 +1018,13 @@ __global__ __launch_bounds__(256) void k_h_refine(const RansacState* st, const f
     for (;;) {
         if (t < 64) s_Ap[t] = s_A[t];
         __syncthreads();
+        if (t < 8) s_Ap[t * 8 + t] += s_lambda * s_D[t];
+        __syncthreads();
+        // solve(Ap, v, d, DECOMP_EIG): eigen decomposition on wave 0 (in place), back-substitution on lane 0
+        if (wave == 0) jacobi_eigen_coop<8>(s_Ap, s_eig + 64, s_eig, reinterpret_cast<int*>(s_eig + 72), lane);
+        __syncthreads();
         if (t == 0) {
-            for (int i = 0; i < 8; i++) s_Ap[i * 8 + i] += s_lambda * s_D[i];
-            sm::solve_eig_ws<8>(s_Ap, s_v, s_d, s_eig);
+            sm::svbksb_eig_vec<8>(s_eig + 64, s_eig, s_v, s_d);
             for (int i = 0; i < 8; i++) s_xd[i] = s_x[i] - s_d[i];
         }
         __syncthreads();
@@ -912,8 +1111,7 @@ int enqueue_find_homography(RansacWorkspace& w, const double* d_pts1, const doub
         if (it1 <= it0) continue;
         const int nh = it1 - it0;
         hipLaunchKernelGGL(k_h_subsets, dim3(1), dim3(1), 0, s, w.state, w.idx, w.f_a, w.f_b, n, it0, it1);
-        hipLaunchKernelGGL(k_h_solve, dim3(cdiv(nh, H_SOLVE_LANES)), dim3(H_SOLVE_LANES), 0, s, w.state, w.idx, w.f_a,
-                           w.f_b, it0, it1, w.models, w.nmodels);
+        hipLaunchKernelGGL(k_h_solve, dim3(nh), dim3(64), 0, s, w.state, w.idx, w.f_a, w.f_b, it0, it1, w.models, w.nmodels);
         hipLaunchKernelGGL(k_h_score, dim3(cdiv(nh, 4)), dim3(256), 0, s, w.state, it0, it1, w.models, w.nmodels, w.f_a,
                            w.f_b, n, thr2, w.counts);
         hipLaunchKernelGGL(k_replay, dim3(1), dim3(1), 0, s, w.state, w.nmodels, w.counts, 1, it0, it1, n, 4, confidence);

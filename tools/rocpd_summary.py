@@ -23,6 +23,23 @@ def main():
         for name, st, en, q, gx in rows:
             print("%10.1f us  +%8.1f us  q=%-4s grid=%-7s %s" % ((st - t0) / 1e3, (en - st) / 1e3, q, gx, name[:60]))
         return
+    if "--spans" in sys.argv:
+        # per-pair span of the solver stage (k_kp_count start -> last k_scale_ransac / k_pnp_select end) and of the nets
+        rows = list(cur.execute("select name, start, end from kernels order by start"))
+        starts = [r for r in rows if "k_kp_count" in r[0]]
+        ends = [r for r in rows if "k_scale_ransac" in r[0] or "k_pnp_select" in r[0]]
+        spans = []
+        for i, st in enumerate(starts):
+            nxt = starts[i + 1][1] if i + 1 < len(starts) else 1 << 62
+            e = [r[2] for r in ends if st[1] < r[2] < nxt]
+            if e:
+                busy = sum(r[2] - r[1] for r in rows if st[1] <= r[1] < max(e) and ("conv_" not in r[0]) and r[0].startswith("dfvo::k_") and not any(
+                    t in r[0] for t in ("k_correlation", "k_warp", "k_reg_", "k_deconv", "k_flow", "k_resize", "k_img", "k_maxpool", "k_depth", "k_disp")))
+                spans.append(((max(e) - st[1]) / 1e3, busy / 1e3))
+        print("solver-stage spans per pair (us): n=%d" % len(spans))
+        for sp, busy in spans[-12:]:
+            print("  span %8.1f   sum of its kernel durations %8.1f" % (sp, busy))
+        return
     key = "name, grid_x, grid_y, grid_z" if by_grid else "name"
     rows = list(cur.execute(
         "select %s, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by %s "
