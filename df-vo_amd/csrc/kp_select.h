@@ -187,6 +187,12 @@ SM_HD int kp_median_of_median5_cp(float* key, IdxT* tosort, int num, int depth) 
     return nmed / 2;
 }
 
+// main loop of the selection from an intermediate state (low, high, depth_limit): lets a caller run the first,
+// long partition passes some other way (k_kp_cell does them with the whole workgroup) and finish here
+template <typename IdxT>
+SM_HD_NOINLINE void kp_introselect_cp_from(float* key, IdxT* tosort, int kth, int depth, int low, int high,
+                                           int depth_limit);
+
 template <typename IdxT>
 SM_HD_NOINLINE void kp_introselect_cp(float* key, IdxT* tosort, int num, int kth, int depth) {
     int low = 0, high = num - 1;
@@ -205,7 +211,12 @@ SM_HD_NOINLINE void kp_introselect_cp(float* key, IdxT* tosort, int num, int kth
         KP_SWAP2(kth, maxidx);
         return;
     }
-    int depth_limit = kp_msb((unsigned)num) * 2;
+    kp_introselect_cp_from(key, tosort, kth, depth, low, high, kp_msb((unsigned)num) * 2);
+}
+
+template <typename IdxT>
+SM_HD_NOINLINE void kp_introselect_cp_from(float* key, IdxT* tosort, int kth, int depth, int low, int high,
+                                           int depth_limit) {
     for (; low + 1 < high;) {
         int ll = low + 1, hh = high;
         if (depth_limit > 0 || hh - ll < 5) {

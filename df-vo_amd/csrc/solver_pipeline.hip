@@ -38,16 +38,145 @@ __global__ void k_kp_count(const float* __restrict__ diff, int n, float thre, in
     if ((threadIdx.x & 63) == 0 && s) atomicAdd(total, s);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// numpy's introselect with the long partition passes run by the whole 256-thread workgroup.
+// One pass of the unguarded Hoare partition  for(;;){ do ll++ while(v[ll]<p); do hh-- while(p<v[hh]); if(hh<ll)
+// break; swap }  is equivalent to: L_k = k-th position (ascending, from low+2) whose value is not < pivot, R_k =
+// k-th position (descending, from high-1) whose value is not > pivot; swap (L_k, R_k) for every k with L_k <= R_k
+// (K of them, the pairs are disjoint); the scans of the crossing iteration stop at min(L_K, R_{K-1}) and
+// max(R_K, L_{K-1}) because the slots exchanged last now hold stoppers.  The stopper lists are built with an
+// ordered ballot/scan compaction, K by a count, the swaps one pair per thread.  Pivot choice, bookkeeping and the
+// final short ranges stay on thread 0 (sm::kp_introselect_cp_from), so the resulting order is numpy's.
+// ------------------------------------------------------------------------------------------------
+constexpr int KP_PAR_MIN = 256;  // ranges shorter than this finish sequentially
+
+__device__ __forceinline__ int kp_block_excl_scan2(int packed, int* s_wsum, int* total) {
+    // exclusive scan over 256 threads of two 16-bit counters packed in one int; *total = packed grand total
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int inc = packed;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) s_wsum[wave] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; w++) base += s_wsum[w];
+    *total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    __syncthreads();
+    return base + inc - packed;
+}
+
+__device__ void kp_introselect_block(float* key, unsigned short* tosort, int num, int kth, unsigned short* Lpos,
+                                     unsigned short* Rpos, int* s_ctl /*8 ints*/, int* s_wsum /*4 ints*/) {
+    const int t = threadIdx.x;
+    if (kth < 3 || kth == num - 1 || num < KP_PAR_MIN) {  // shortcuts of the scalar algorithm / small inputs
+        if (t == 0) sm::kp_introselect_cp<unsigned short>(key, tosort, num, kth, 0);
+        __syncthreads();
+        return;
+    }
+    int low = 0, high = num - 1, depth_limit = sm::kp_msb((unsigned)num) * 2;
+    while (low + 1 < high) {
+        if (high - low < KP_PAR_MIN || depth_limit <= 0) break;  // thread 0 finishes (incl. the median-of-medians path)
+        if (t == 0) {  // median of three -> pivot at low, its companion at low + 1
+            const int mid = low + (high - low) / 2;
+#define KPB_SWAP(i, j)                    \
+    {                                     \
+        unsigned short _t = tosort[i];    \
+        tosort[i] = tosort[j];            \
+        tosort[j] = _t;                   \
+        float _k = key[i];                \
+        key[i] = key[j];                  \
+        key[j] = _k;                      \
+    }
+            if (sm::kp_lt(key[high], key[mid])) KPB_SWAP(high, mid);
+            if (sm::kp_lt(key[high], key[low])) KPB_SWAP(high, low);
+            if (sm::kp_lt(key[low], key[mid])) KPB_SWAP(low, mid);
+            KPB_SWAP(mid, low + 1);
+        }
+        __syncthreads();
+        const float pivot = key[low];
+        // stopper lists over [low+1 .. high]: left stoppers from low+2 (high is one by construction), right stoppers
+        // down from high-1 (low+1 is one by construction); each thread owns a contiguous segment
+        const int r0 = low + 1, n_r = high - low;  // positions r0 .. r0 + n_r - 1
+        const int seg = (n_r + 255) / 256;
+        const int p0 = r0 + t * seg, p1 = p0 + seg < r0 + n_r ? p0 + seg : r0 + n_r;
+        int cl = 0, cr = 0;
+        for (int p = p0; p < p1; ++p) {
+            const float v = key[p];
+            cl += (p >= low + 2 && !sm::kp_lt(v, pivot)) ? 1 : 0;
+            cr += (p <= high - 1 && !sm::kp_lt(pivot, v)) ? 1 : 0;
+        }
+        int total;
+        const int ex = kp_block_excl_scan2(cl | (cr << 16), s_wsum, &total);
+        const int nL = total & 0xffff, nR = total >> 16;
+        int il = ex & 0xffff, ir = ex >> 16;
+        for (int p = p0; p < p1; ++p) {
+            const float v = key[p];
+            if (p >= low + 2 && !sm::kp_lt(v, pivot)) Lpos[il++] = (unsigned short)p;
+            if (p <= high - 1 && !sm::kp_lt(pivot, v)) Rpos[nR - 1 - (ir++)] = (unsigned short)p;
+        }
+        __syncthreads();
+        // K = number of leading pairs with L_k <= R_k (monotone predicate)
+        const int npair = nL < nR ? nL : nR;
+        int cnt = 0;
+        for (int k = t; k < npair; k += 256) cnt += Lpos[k] <= Rpos[k] ? 1 : 0;
+        int tot2;
+        (void)kp_block_excl_scan2(cnt, s_wsum, &tot2);
+        const int K = tot2 & 0xffff;
+        for (int k = t; k < K; k += 256) {
+            const int a = Lpos[k], b = Rpos[k];
+            if (a != b) KPB_SWAP(a, b);
+        }
+        __syncthreads();
+        if (t == 0) {
+            // crossing iteration: the scans run on from (L_{K-1}, R_{K-1}) and stop at the next original stopper or at
+            // the nearest slot exchanged earlier (it now holds a stopper), whichever comes first.  When the last
+            // exchanged pair was a self-pair (L == R, value == pivot) that slot lies behind both scans and the
+            // pair before it takes its place.  K < nL, nR: the lists end with the sentinels high / low+1.
+            int ll = Lpos[K], hh = Rpos[K];
+            if (K > 0) {
+                int rp = Rpos[K - 1], lp = Lpos[K - 1];
+                if (rp == lp) {
+                    rp = K > 1 ? Rpos[K - 2] : 0x7fffffff;
+                    lp = K > 1 ? Lpos[K - 2] : -1;
+                }
+                ll = ll < rp ? ll : rp;
+                hh = hh > lp ? hh : lp;
+            }
+            KPB_SWAP(low, hh);
+            int nlow = low, nhigh = high;
+            if (hh >= kth) nhigh = hh - 1;
+            if (hh <= kth) nlow = ll;
+            s_ctl[0] = nlow;
+            s_ctl[1] = nhigh;
+        }
+        __syncthreads();
+        low = s_ctl[0];
+        high = s_ctl[1];
+        depth_limit--;
+        __syncthreads();
+    }
+    if (t == 0) sm::kp_introselect_cp_from<unsigned short>(key, tosort, kth, 0, low, high, depth_limit);
+    __syncthreads();
+#undef KPB_SWAP
+}
+
 // one 256-thread block per grid cell: ordered (row-major) compaction of the candidates into LDS, then
 // lane 0 runs numpy's introselect on them (keys carried along with the indices, see kp_select.h); writes
 // the picked local indices in argpartition order.
 __global__ __launch_bounds__(256) void k_kp_cell(const float* __restrict__ diff, int H, int W, int num_row, int num_col,
                                                   float thre, int n_best, int cap, int* __restrict__ cell_count,
                                                   int* __restrict__ cell_sel /*[cells][n_best] (y<<16|x)*/,
-                                                  unsigned short* __restrict__ lidx_all /*[cells][cap]*/) {
+                                                  unsigned short* __restrict__ lidx_all /*[cells][cap]*/, int par) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     float* vals = reinterpret_cast<float*>(smem_raw) + 4;  // 4 floats of slack on either side: the 4-wide scans over-read
     unsigned short* tosort = reinterpret_cast<unsigned short*>(vals + cap + 4);
+    unsigned short* Lpos = tosort + cap + 2;  // stopper lists of the workgroup-parallel partition (par != 0)
+    unsigned short* Rpos = Lpos + cap + 2;
+    __shared__ int s_ctl[8], s_wsum[4];
     unsigned short* lidx = lidx_all + (size_t)blockIdx.x * cap;  // candidate -> tile element (global scratch)
     __shared__ int s_base, s_wave[4];
     const int cell = blockIdx.x;
@@ -86,10 +215,14 @@ __global__ __launch_bounds__(256) void k_kp_cell(const float* __restrict__ diff,
     }
     const int cnt = s_base;
     const int pick = cnt < n_best ? cnt : n_best;
-    if (t == 0) {
-        if (pick > 0) sm::kp_introselect_cp<unsigned short>(vals, tosort, cnt, pick - 1, 0);
-        cell_count[cell] = pick;
+    if (pick > 0) {
+        if (par) {
+            kp_introselect_block(vals, tosort, cnt, pick - 1, Lpos, Rpos, s_ctl, s_wsum);
+        } else if (t == 0) {
+            sm::kp_introselect_cp<unsigned short>(vals, tosort, cnt, pick - 1, 0);
+        }
     }
+    if (t == 0) cell_count[cell] = pick;
     __syncthreads();
     if (t < pick) {
         const int e = lidx[tosort[t]];
@@ -144,8 +277,11 @@ int enqueue_local_bestn(TrackerBuffers& tb, const float* d_flow, const float* d_
     DFVO_ARG_CHECK(n_best >= 1 && n_best <= 256, "local_bestN: n_best out of range");
     const int cap = (H / num_row + 2) * (W / num_col + 2);
     DFVO_ARG_CHECK(cap < 65536, "local_bestN: cell larger than 65535 pixels");
-    const size_t lds = (size_t)cap * (4 + 2) + 32;
+    size_t lds = (size_t)cap * (4 + 2) + 32;
     DFVO_ARG_CHECK(lds <= 158 * 1024, "local_bestN: cell does not fit in LDS");
+    // the workgroup-parallel partition needs two more index lists; very large cells keep the single-lane selection
+    const int par = lds + (size_t)cap * 4 + 16 <= 150 * 1024 ? 1 : 0;
+    if (par) lds += (size_t)cap * 4 + 16;
     int rc = tb.ensure_kp(cells * n_best, cells, n_best);
     if (rc != DFVO_OK) return rc;
     if ((size_t)cells * cap > tb.lidx_cap) {
@@ -161,7 +297,7 @@ int enqueue_local_bestn(TrackerBuffers& tb, const float* d_flow, const float* d_
     DFVO_HIP_CHECK(hipMemsetAsync(tb.kp_total, 0, sizeof(int), s));
     hipLaunchKernelGGL(k_kp_count, dim3(cdiv(H * W, 256)), dim3(256), 0, s, d_diff, H * W, thre, tb.kp_total);
     hipLaunchKernelGGL(k_kp_cell, dim3(cells), dim3(256), lds, s, d_diff, H, W, num_row, num_col, thre, n_best, cap,
-                       tb.cell_count, tb.cell_sel, tb.lidx);
+                       tb.cell_count, tb.cell_sel, tb.lidx, par);
     // thresholds exactly as the python float comparisons: count < N*0.1 ; regions < rows*cols*0.1
     const int min_total = (int)ceil((double)num_bestN * 0.1);
     const int min_regions = (int)ceil((double)cells * 0.1);

@@ -739,6 +739,27 @@ __device__ __forceinline__ double seq_acc_two(const double* buf, int cnt, int i0
     return a;
 }
 // a += o[i0]*o[i1] + o[i2]*o[i3]   per point
+// a += o[i0]*o[i1]   per point: the form used for accumulators one of whose two Jacobian rows is structurally zero
+// (the homography Jacobian rows are [* * * 0 0 0 * *] and [0 0 0 * * * * *]): the skipped term is an exact +-0
+// product, and x + (+-0) == x for every x the running sum can hold (it starts at +0 and can never become -0)
+__device__ __forceinline__ double seq_acc_one(const double* buf, int cnt, int i0, int i1, double a) {
+    int k = 0;
+    for (; k + H_UNROLL <= cnt; k += H_UNROLL) {
+        double p0[H_UNROLL];
+#pragma unroll
+        for (int u = 0; u < H_UNROLL; ++u) {
+            const double* o = buf + (k + u) * 18;
+            p0[u] = o[i0] * o[i1];
+        }
+#pragma unroll
+        for (int u = 0; u < H_UNROLL; ++u) a += p0[u];
+    }
+    for (; k < cnt; k++) {
+        const double* o = buf + k * 18;
+        a += o[i0] * o[i1];
+    }
+    return a;
+}
 __device__ __forceinline__ double seq_acc_pair(const double* buf, int cnt, int i0, int i1, int i2, int i3, double a) {
     int k = 0;
     for (; k + H_UNROLL <= cnt; k += H_UNROLL) {
@@ -955,9 +976,22 @@ __global__ __launch_bounds__(256) void k_h_refine(const RansacState* st, const f
             h_chunk_lm(sh, cp, h, cnt, true);
             __syncthreads();
             if (t < 36) {
-                a = seq_acc_two(sh.buf, cnt, ai, aj, 8 + ai, 8 + aj, a);
+                // row a is non-zero in columns {0,1,2,6,7}, row b in {3,4,5,6,7}
+                const bool ua = (ai < 3 || ai > 5) && (aj < 3 || aj > 5), ub = ai >= 3 && aj >= 3;
+                if (ua && ub)
+                    a = seq_acc_two(sh.buf, cnt, ai, aj, 8 + ai, 8 + aj, a);
+                else if (ua)
+                    a = seq_acc_one(sh.buf, cnt, ai, aj, a);
+                else if (ub)
+                    a = seq_acc_one(sh.buf, cnt, 8 + ai, 8 + aj, a);
             } else if (t >= 64 && t < 72) {
-                a = seq_acc_two(sh.buf, cnt, t - 64, 16, 8 + t - 64, 17, a);
+                const int i = t - 64;
+                if (i < 3)
+                    a = seq_acc_one(sh.buf, cnt, i, 16, a);
+                else if (i < 6)
+                    a = seq_acc_one(sh.buf, cnt, 8 + i, 17, a);
+                else
+                    a = seq_acc_two(sh.buf, cnt, i, 16, 8 + i, 17, a);
             } else if (t == 128) {
                 a = seq_acc_sq(sh.buf, cnt, a);
             } else if (t == 192) {

@@ -67,6 +67,25 @@ def test_local_bestn_bit_exact(gpu, trk, h, w, seed, frac):
         assert np.array_equal(kp2[:n.value], ref["kp2_best"][0])
 
 
+@pytest.mark.parametrize("h,w,seed,levels", [(376, 1241, 41, 8), (376, 1241, 42, 64), (192, 640, 43, 3), (376, 1241, 44, 1000)])
+def test_local_bestn_heavy_ties(gpu, trk, h, w, seed, levels):
+    """quantised consistency maps: most candidates of a cell tie with the pivot, which drives the workgroup-parallel
+    partition through its equal-to-pivot (self-pair) paths; order must still be numpy's scalar introselect order"""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    diff = (np.floor(rng.random((h, w, 1)) * levels) / levels * 0.12).astype(np.float32)
+    flow = (rng.standard_normal((2, h, w)) * 3).astype(np.float32)
+    ref = T.local_bestN(flow, diff)
+    kp1, kp2 = np.zeros((2000, 2)), np.zeros((2000, 2))
+    n, good = C.c_int(), C.c_int()
+    gpu.check(gpu.lib().dfvo_kp_local_bestn(trk, gpu.as_ptr(np.ascontiguousarray(flow)),
+                                            gpu.as_ptr(np.ascontiguousarray(diff[..., 0])), h, w, 10, 10, 2000, 0.1,
+                                            gpu.as_ptr(kp1), gpu.as_ptr(kp2), C.byref(n), C.byref(good)))
+    assert bool(good.value) == bool(ref["good_kp_found"]) and ref["good_kp_found"]
+    assert n.value == ref["kp1_best"].shape[1]
+    assert np.array_equal(kp1[:n.value], ref["kp1_best"][0])
+    assert np.array_equal(kp2[:n.value], ref["kp2_best"][0])
+
+
 CASES = [(31, 2000, 0.3, 0.15), (32, 2000, 0.6, 0.3), (33, 600, 0.2, 0.1), (34, 2000, 0.97, 0.2), (35, 1234, 0.4, 0.2),
          (36, 9, 0.0, 0.1)]
 
