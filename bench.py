@@ -24,6 +24,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+SLOTS = 4  # DFVO_PIPELINE_SLOTS
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: FP32 matrix (f32 in / f32 acc)
 CFG_NAMES = ["conv_igemm_f32<2,2,4,4> 128x128", "conv_igemm_f32<1,4,2,2> 32x128", "conv_igemm_f32<4,1,4,4> 256x64",
              "conv_igemm_f32<2,2,2,2> 64x64", "conv_igemm_f32<4,1,4,2> 256x32", "conv_igemm_f32<2,2,2,1> 64x32",
@@ -111,8 +112,10 @@ def main():
     d_sc = [(dev(s["flow"]), dev(s["diff"]), dev(s["depth_cur"])) for s in scenes]
     d_ref_depth = dev(scenes[0]["depth_ref"])
 
+    host_t = [0.0, 0.0]  # host seconds inside enqueue_nets / track (DFVO_BENCH_TRACE=1 prints them)
+
     def run(n):
-        """software pipeline: the nets of pair k+1 are enqueued before the solver stage of pair k blocks"""
+        """software pipeline: the nets of pairs k+1, k+2 are enqueued before the solver stage of pair k blocks the host"""
         g = np.eye(4)
         prev = np.eye(4)
         rel_all = np.zeros((n, 4, 4))
@@ -120,12 +123,18 @@ def main():
         if n == 0:
             return rel_all, status
         pipe.set_ref_depth(depth=d_ref_depth)  # depth of the first reference frame (PnP fallback input)
-        pipe.enqueue_nets(0, d_ref, d_cur, d_feed)
+        ahead = 2  # the nets run two pairs ahead: the host blocks in track(k) while nets(k+1), nets(k+2) queue up
+        for j in range(min(ahead, n)):
+            pipe.enqueue_nets(j % SLOTS, d_ref, d_cur, d_feed)
         for k in range(n):
-            if k + 1 < n:
-                pipe.enqueue_nets((k + 1) % 2, d_ref, d_cur, d_feed)
+            t_a = time.perf_counter()
+            if k + ahead < n:
+                pipe.enqueue_nets((k + ahead) % SLOTS, d_ref, d_cur, d_feed)
+            t_b = time.perf_counter()
             f, dd, dp = d_sc[k % len(d_sc)]
-            out = pipe.track(k % 2, f, dd, dp)  # E-tracker, or the PnP fallback when its pose is rejected
+            out = pipe.track(k % SLOTS, f, dd, dp)  # E-tracker, or the PnP fallback when its pose is rejected
+            host_t[0] += t_b - t_a
+            host_t[1] += time.perf_counter() - t_b
             rel, _ = pipe.hybrid_pose(out, prev)
             prev = rel
             g = pipe.accumulate(g, rel)
@@ -138,8 +147,12 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    host_t[0] = host_t[1] = 0.0
     t0 = time.perf_counter()
     rel_all, status = run(args.steps)
+    if os.environ.get("DFVO_BENCH_TRACE"):
+        sys.stderr.write("host ms/pair: enqueue_nets %.3f  track %.3f\n" % (host_t[0] * 1e3 / args.steps,
+                                                                            host_t[1] * 1e3 / args.steps))
     gathered = dmod.allgather_poses(rel_all, status, world, rank, dist)  # one RCCL all-gather of the chunk's poses
     torch.cuda.synchronize()
     if dist is not None:

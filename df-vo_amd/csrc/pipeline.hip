@@ -4,6 +4,9 @@
 // (tracking): the host-side glue of the reference (cv2.resize nearest, preprocess_depth, dict passing)
 // becomes device kernels; the pose composition stays on the host (dfvo.py:109-119).
 #include "../../include/dfvo_hip.h"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "nets.h"
@@ -18,11 +21,11 @@ struct dfvo_pipeline {
     DepthNet depth;
     TrackerBuffers tb;
     hipStream_t s_flow = nullptr, s_depth = nullptr, s_trk = nullptr;
-    hipEvent_t e_flow[2] = {nullptr, nullptr}, e_depth[2] = {nullptr, nullptr};
+    hipEvent_t e_flow[DFVO_PIPELINE_SLOTS] = {}, e_depth[DFVO_PIPELINE_SLOTS] = {};
     // per-slot outputs of the nets
-    float *fwd[2] = {nullptr, nullptr}, *bwd[2] = {nullptr, nullptr}, *diff[2] = {nullptr, nullptr};
-    float* raw_depth[2] = {nullptr, nullptr};
-    double* proc_depth[2] = {nullptr, nullptr};
+    float *fwd[DFVO_PIPELINE_SLOTS] = {}, *bwd[DFVO_PIPELINE_SLOTS] = {}, *diff[DFVO_PIPELINE_SLOTS] = {};
+    float* raw_depth[DFVO_PIPELINE_SLOTS] = {};
+    double* proc_depth[DFVO_PIPELINE_SLOTS] = {};
     float* depth_small = nullptr;
     double* d_T21 = nullptr;
     // PnP fallback: processed depth of the reference frame (= the previous pair's current frame)
@@ -33,19 +36,6 @@ struct dfvo_pipeline {
     dfvo_pipeline_cfg cfg;
     bool nets_ready = false;
 };
-
-// T21 = inverse of [R t; 0 1] written as 16 doubles (E_pose.inv_pose, E_tracker.py:504)
-__global__ void k_build_T21(const PoseState* ps, double* __restrict__ T) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const double* R = ps->R;
-    const double* t = ps->t;
-    for (int r = 0; r < 3; r++) {
-        for (int c = 0; c < 3; c++) T[r * 4 + c] = R[c * 3 + r];
-        T[r * 4 + 3] = -(R[0 * 3 + r] * t[0] + R[1 * 3 + r] * t[1] + R[2 * 3 + r] * t[2]);
-    }
-    T[12] = T[13] = T[14] = 0;
-    T[15] = 1;
-}
 
 #define P_TRY(expr)                     \
     do {                                \
@@ -73,7 +63,7 @@ int dfvo_pipeline_create(const dfvo_pipeline_cfg* cfg, dfvo_pipeline** out) {
         dfvo::set_last_error("dfvo_pipeline_create: hipStreamCreate failed (no GPU?)");
         return fail(DFVO_ERR_HIP);
     }
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < DFVO_PIPELINE_SLOTS; i++) {
         if (hipEventCreateWithFlags(&p->e_flow[i], hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&p->e_depth[i], hipEventDisableTiming) != hipSuccess) {
             dfvo::set_last_error("dfvo_pipeline_create: hipEventCreate failed");
@@ -90,7 +80,7 @@ int dfvo_pipeline_create(const dfvo_pipeline_cfg* cfg, dfvo_pipeline** out) {
     rc = p->tb.init();
     if (rc != DFVO_OK) return fail(rc);
     const size_t px = (size_t)p->H * p->W;
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < DFVO_PIPELINE_SLOTS; i++) {
         if (hipMalloc((void**)&p->fwd[i], 2 * px * sizeof(float)) != hipSuccess ||
             hipMalloc((void**)&p->bwd[i], 2 * px * sizeof(float)) != hipSuccess ||
             hipMalloc((void**)&p->diff[i], px * sizeof(float)) != hipSuccess ||
@@ -118,7 +108,7 @@ void dfvo_pipeline_destroy(dfvo_pipeline* p) {
     p->flow.destroy();
     p->depth.destroy();
     p->tb.release();
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < DFVO_PIPELINE_SLOTS; i++) {
         void* ptrs[] = {p->fwd[i], p->bwd[i], p->diff[i], p->raw_depth[i], p->proc_depth[i]};
         for (void* q : ptrs)
             if (q) (void)hipFree(q);
@@ -177,7 +167,7 @@ int dfvo_pipeline_seed(dfvo_pipeline* p, uint32_t seed) {
 
 int dfvo_pipeline_enqueue_nets(dfvo_pipeline* p, int slot, const uint8_t* d_ref, const uint8_t* d_cur,
                                const uint8_t* d_cur_feed) {
-    DFVO_ARG_CHECK(p && p->nets_ready && (slot == 0 || slot == 1) && d_ref && d_cur && d_cur_feed,
+    DFVO_ARG_CHECK(p && p->nets_ready && (slot >= 0 && slot < DFVO_PIPELINE_SLOTS) && d_ref && d_cur && d_cur_feed,
                    "dfvo_pipeline_enqueue_nets: bad argument");
     const size_t px = (size_t)p->H * p->W;
     // depth of the current frame (dfvo.py:305-319)
@@ -229,11 +219,19 @@ static int roll_ref_depth(dfvo_pipeline* p, int slot, const double* d_depth_over
 
 int dfvo_pipeline_track(dfvo_pipeline* p, int slot, const float* d_flow_override, const float* d_diff_override,
                         const double* d_depth_override, dfvo_track_out* out) {
-    DFVO_ARG_CHECK(p && out && (slot == 0 || slot == 1), "dfvo_pipeline_track: bad argument");
+    DFVO_ARG_CHECK(p && out && (slot >= 0 && slot < DFVO_PIPELINE_SLOTS), "dfvo_pipeline_track: bad argument");
     const dfvo_pipeline_cfg& c = p->cfg;
     hipStream_t s = p->s_trk;
+    static const bool trace = getenv("DFVO_TRACK_TRACE") != nullptr;  // host-side phase timing (tuning aid)
+    static double tr_acc[4] = {0, 0, 0, 0};
+    static int tr_n = 0;
+    const auto tr0 = std::chrono::steady_clock::now();
+    auto tr_ms = [&](std::chrono::steady_clock::time_point a) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
+    };
     memset(out, 0, sizeof(*out));
     for (int i = 0; i < 3; i++) out->R[i * 4] = 1.0;
+    P_TRY(enqueue_scale_prepare(p->tb, p->H, p->W));  // side stream: the scale stage's fills leave the dependent chain
     DFVO_HIP_CHECK(hipStreamWaitEvent(s, p->e_flow[slot], 0));
     const float* flow = d_flow_override ? d_flow_override : p->fwd[slot];
     const float* diff = d_diff_override ? d_diff_override : p->diff[slot];
@@ -241,6 +239,7 @@ int dfvo_pipeline_track(dfvo_pipeline* p, int slot, const float* d_flow_override
     int info[3];
     DFVO_HIP_CHECK(hipMemcpyAsync(info, p->tb.kp_info, sizeof(info), hipMemcpyDeviceToHost, s));
     DFVO_HIP_CHECK(hipStreamSynchronize(s));
+    const double tr_kp = tr_ms(tr0);
     out->n_kp = info[0];
     out->good_kp_found = info[1];
     if (!info[1]) {
@@ -261,8 +260,7 @@ int dfvo_pipeline_track(dfvo_pipeline* p, int slot, const float* d_flow_override
         pc.KinvT[i] = c.KinvT[i];
         pc.Kinv[i] = c.Kinv[i];
     }
-    P_TRY(enqueue_compute_pose_2d2d(p->tb, n, pc, s));
-    hipLaunchKernelGGL(k_build_T21, dim3(1), dim3(1), 0, s, p->tb.pose, p->d_T21);
+    P_TRY(enqueue_compute_pose_2d2d(p->tb, n, pc, s, p->d_T21));
     DFVO_HIP_CHECK(hipStreamWaitEvent(s, p->e_depth[slot], 0));
     ScaleConfig sc;
     sc.cx = c.cx;
@@ -274,7 +272,8 @@ int dfvo_pipeline_track(dfvo_pipeline* p, int slot, const float* d_flow_override
     sc.stop_prob = c.scale_stop_prob;
     sc.thre = c.scale_thre;
     const double* depth = d_depth_override ? d_depth_override : p->proc_depth[slot];
-    P_TRY(enqueue_find_scale(p->tb, n, p->d_T21, depth, p->H, p->W, sc, s, p->tb.pose));
+    P_TRY(enqueue_find_scale(p->tb, n, p->d_T21, depth, p->H, p->W, sc, s, p->tb.pose, true));
+    const double tr_enq = tr_ms(tr0);
     PoseState ps;
     ScaleResult sr;
     DFVO_HIP_CHECK(hipMemcpyAsync(&ps, p->tb.pose, sizeof(ps), hipMemcpyDeviceToHost, s));
@@ -324,12 +323,22 @@ int dfvo_pipeline_track(dfvo_pipeline* p, int slot, const float* d_flow_override
     }
     P_TRY(roll_ref_depth(p, slot, d_depth_override));
     DFVO_HIP_CHECK(hipStreamSynchronize(s));
+    if (trace) {
+        tr_acc[0] += tr_kp;
+        tr_acc[1] += tr_enq;
+        tr_acc[2] += tr_ms(tr0);
+        if (++tr_n % 20 == 0) {
+            fprintf(stderr, "track host ms: kp stage done %.3f | all enqueued %.3f | total %.3f\n", tr_acc[0] / 20, tr_acc[1] / 20,
+                    tr_acc[2] / 20);
+            tr_acc[0] = tr_acc[1] = tr_acc[2] = 0;
+        }
+    }
     return DFVO_OK;
 }
 
 int dfvo_pipeline_get_flow(dfvo_pipeline* p, int slot, float* h_fwd, float* h_bwd, float* h_diff, float* h_raw_depth,
                            double* h_depth) {
-    DFVO_ARG_CHECK(p && (slot == 0 || slot == 1), "dfvo_pipeline_get_flow: bad argument");
+    DFVO_ARG_CHECK(p && (slot >= 0 && slot < DFVO_PIPELINE_SLOTS), "dfvo_pipeline_get_flow: bad argument");
     const size_t px = (size_t)p->H * p->W;
     DFVO_HIP_CHECK(hipDeviceSynchronize());
     if (h_fwd) DFVO_HIP_CHECK(hipMemcpy(h_fwd, p->fwd[slot], 2 * px * sizeof(float), hipMemcpyDeviceToHost));

@@ -53,11 +53,13 @@ __device__ inline void ransac_replay(RansacState* st, const int* __restrict__ nm
     }
     (void)it0;
 }
-// hypothesis chunks enqueued back to back: [0,128) [128,512) [512,max_iters)
+// hypothesis chunks enqueued back to back: [0,128) [128,max_iters).  The first chunk almost always ends the run
+// (RANSACUpdateNumIters drops below 128 with the first good model); every further chunk is a chain of dependent
+// launches that each wait for a free compute unit while the nets run, so there is only one of them.
 static inline void chunk_bounds(int max_iters, int* b) {
     b[0] = 0;
     b[1] = max_iters < 128 ? max_iters : 128;
-    b[2] = max_iters < 512 ? max_iters : 512;
+    b[2] = max_iters;
     b[3] = max_iters;
 }
 

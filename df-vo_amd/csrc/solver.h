@@ -46,8 +46,14 @@ int enqueue_find_essential_batch(RansacWorkspace* w, const double* const* d_pts1
                                  int max_iters, hipStream_t s);
 int enqueue_find_homography(RansacWorkspace& w, const double* d_pts1, const double* d_pts2, int n, double thr,
                             int max_iters, double confidence, hipStream_t s);
+struct PoseState;
+// optional tail of recoverPose in the fused pipeline (null pointers: plain recoverPose)
+struct PoseFinish {
+    PoseState* ps = nullptr;
+    double* T21 = nullptr;
+};
 int enqueue_recover_pose(RansacWorkspace& w, const double* d_E, const double* d_pts1, const double* d_pts2, int n,
-                         double focal, double ppx, double ppy, hipStream_t s);
+                         double focal, double ppx, double ppy, hipStream_t s, PoseFinish fin = PoseFinish());
 int enqueue_triangulate(const double* d_P, const double* d_x1, const double* d_x2, int n, double* d_X4,
                         hipStream_t s);
 

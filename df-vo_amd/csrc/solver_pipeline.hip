@@ -585,6 +585,94 @@ __global__ __launch_bounds__(256) void k_gric_sum(const double* __restrict__ res
     }
 }
 
+// residual + calc_GRIC in one launch (the two kernels above, for the fused pipeline): the residual of point i is
+// produced straight into the LDS staging buffer the sequential sum reads.  blockIdx.x = problem.
+struct GricFusedBatch {
+    const double* M[MAX_E_BATCH];  // E (mode 0) or H (mode 1) per problem
+};
+__global__ __launch_bounds__(256) void k_gric_fused(const GricFusedBatch G, int mode, const double* __restrict__ KinvT,
+                                                     const double* __restrict__ Kinv, const int* __restrict__ n_ptr,
+                                                     const double* __restrict__ kp1, const double* __restrict__ kp2,
+                                                     int pts_stride, double sigma, int Kp, int D,
+                                                     double* __restrict__ out) {
+    __shared__ double s_res[2048];
+    __shared__ double s_M[9];
+    const int n = *n_ptr;
+    const double* Min = G.M[blockIdx.x];
+    kp1 += (size_t)blockIdx.x * pts_stride;
+    kp2 += (size_t)blockIdx.x * pts_stride;
+    out += blockIdx.x;
+    if (threadIdx.x == 0) {
+        if (mode == 0) {  // F = K^-T E K^-1
+            double T[9], F[9];
+            sm::mul33(KinvT, Min, T);
+            sm::mul33(T, Kinv, F);
+            for (int k = 0; k < 9; k++) s_M[k] = F[k];
+        } else {
+            for (int k = 0; k < 9; k++) s_M[k] = Min[k];
+        }
+    }
+    __syncthreads();
+    const double R = 4, sigmasq1 = 1. / (sigma * sigma);
+    const double lam3RD = 2.0 * (R - D);
+    double sum = 0;
+    for (int c0 = 0; c0 < n; c0 += 2048) {
+        const int cnt = n - c0 < 2048 ? n - c0 : 2048;
+        for (int k = threadIdx.x; k < cnt; k += 256) {
+            const int i = c0 + k;
+            double r;
+            if (mode == 0) {
+                const double* F = s_M;
+                const double m0[3] = {kp1[i * 2], kp1[i * 2 + 1], 1.0}, m1[3] = {kp2[i * 2], kp2[i * 2 + 1], 1.0};
+                double Fm0[3], Ftm1[3];
+                for (int q = 0; q < 3; q++) {
+                    Fm0[q] = F[q * 3] * m0[0] + F[q * 3 + 1] * m0[1] + F[q * 3 + 2] * m0[2];
+                    Ftm1[q] = F[q] * m1[0] + F[3 + q] * m1[1] + F[6 + q] * m1[2];
+                }
+                const double m1Fm0 = Fm0[0] * m1[0] + Fm0[1] * m1[1] + Fm0[2] * m1[2];
+                r = m1Fm0 * m1Fm0 / ((Fm0[0] * Fm0[0] + Fm0[1] * Fm0[1]) + (Ftm1[0] * Ftm1[0] + Ftm1[1] * Ftm1[1]));
+            } else {
+                const double* H = s_M;
+                const double m0x = kp1[i * 2], m0y = kp1[i * 2 + 1], m1x = kp2[i * 2], m1y = kp2[i * 2 + 1];
+                const double G00 = H[0] - m1x * H[6], G01 = H[1] - m1x * H[7], G02 = -m0x * H[6] - m0y * H[7] - H[8];
+                const double G10 = H[3] - m1y * H[6], G11 = H[4] - m1y * H[7], G12 = -m0x * H[6] - m0y * H[7] - H[8];
+                const double magG0 = sqrt(G00 * G00 + G01 * G01 + G02 * G02);
+                const double magG1 = sqrt(G10 * G10 + G11 * G11 + G12 * G12);
+                const double magG0G1 = G00 * G10 + G01 * G11;
+                const double alpha = acos(magG0G1 / (magG0 * magG1));
+                const double alg0 = m0x * H[0] + m0y * H[1] + H[2] - m1x * (m0x * H[6] + m0y * H[7] + H[8]);
+                const double alg1 = m0x * H[3] + m0y * H[4] + H[5] - m1y * (m0x * H[6] + m0y * H[7] + H[8]);
+                const double D1 = alg0 / magG0, D2 = alg1 / magG1;
+                r = (D1 * D1 + D2 * D2 - 2.0 * D1 * D2 * cos(alpha)) / sin(alpha);
+            }
+            s_res[k] = r;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int i = 0;
+            for (; i + 8 <= cnt; i += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const double tmp = s_res[i + u] * sigmasq1;
+                    v[u] = tmp <= lam3RD ? tmp : lam3RD;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) sum += v[u];
+            }
+            for (; i < cnt; i++) {
+                const double tmp = s_res[i] * sigmasq1;
+                sum += tmp <= lam3RD ? tmp : lam3RD;
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        sum += n * D * log(R) + Kp * log(R * n);
+        *out = sum;
+    }
+}
+
 // ================================================================================================
 // compute_pose_2d2d bookkeeping
 // ================================================================================================
@@ -660,6 +748,53 @@ __global__ void k_pose_finish(PoseState* ps, const double* __restrict__ rp_out, 
         for (int k = 0; k < 9; k++) ps->R[k] = rp_out[k];
         for (int k = 0; k < 3; k++) ps->t[k] = rp_out[9 + k];
     }
+}
+
+// the whole post-RANSAC bookkeeping of compute_pose_2d2d in one launch: H validity (k_set_h_gric), the `repeat`
+// sequential k_rep_update steps, and the major_valid decision (k_pose_finish stage 0)
+struct RepBatch {
+    const RansacState* st[MAX_REP];
+    const double* E[MAX_REP];
+    const uint8_t* mask[MAX_REP];
+};
+__global__ __launch_bounds__(256) void k_rep_update_all(PoseState* ps, const RansacState* hst, const double* __restrict__ h_gric,
+                                                         const RepBatch B, const double* __restrict__ e_gric,
+                                                         const int* __restrict__ perm, int perm_stride,
+                                                         uint8_t* __restrict__ best_inliers, int repeat) {
+    __shared__ int s_take;
+    const int n = ps->n;
+    if (threadIdx.x == 0) {
+        ps->h_found = hst->found;
+        ps->h_gric = hst->found ? *h_gric : INFINITY;
+    }
+    __syncthreads();
+    for (int rep = 0; rep < repeat; ++rep) {
+        if (threadIdx.x == 0) {
+            const RansacState* est = B.st[rep];
+            const int found = est->found;
+            const int cnt = found ? est->max_good : 0;
+            const bool valid = found && (ps->h_gric > e_gric[rep]);
+            ps->rep_cnt[rep] = cnt;
+            ps->rep_valid[rep] = valid ? 1 : 0;
+            ps->rep_gric[rep] = found ? e_gric[rep] : INFINITY;
+            ps->num_valid += valid ? 1 : 0;
+            s_take = (found && cnt > ps->best_cnt) ? 1 : 0;
+            if (s_take) {
+                ps->best_cnt = cnt;
+                ps->have_best = 1;
+                for (int k = 0; k < 9; k++) ps->best_E[k] = B.E[rep][k];
+            }
+        }
+        __syncthreads();
+        if (s_take) {
+            const uint8_t* mask = B.mask[rep];
+            const int* pm = perm + (size_t)rep * perm_stride;
+            for (int c = threadIdx.x; c < n; c += blockDim.x) best_inliers[pm[c]] = mask[c];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        ps->major_valid = ((double)ps->num_valid > (double)repeat / 2.0 && ps->have_best) ? 1 : 0;
 }
 
 // ================================================================================================
@@ -963,7 +1098,7 @@ int enqueue_mt_shuffle(uint32_t* mt_state, const int* d_n, int n_host, int repea
 // EssTracker.compute_pose_2d2d with validity.method == "GRIC" on tb.kp_ref / tb.kp_cur (n = kp_info[0] on the
 // device, n_host = upper bound known to the host for launch sizing).
 // small[] layout: [0..8] KinvT, [9..17] Kinv, [18] H_gric, [19] E_gric
-int enqueue_compute_pose_2d2d(TrackerBuffers& tb, int n_host, const PoseConfig& cfg, hipStream_t s) {
+int enqueue_compute_pose_2d2d(TrackerBuffers& tb, int n_host, const PoseConfig& cfg, hipStream_t s, double* d_T21) {
     DFVO_ARG_CHECK(n_host >= 0 && n_host <= tb.kp_cap, "compute_pose_2d2d: keypoint capacity");
     DFVO_ARG_CHECK(cfg.repeat >= 1 && cfg.repeat <= 8, "compute_pose_2d2d: repeat out of range");
     const int nb = cdiv(n_host > 0 ? n_host : 1, 256);
@@ -989,10 +1124,12 @@ int enqueue_compute_pose_2d2d(TrackerBuffers& tb, int n_host, const PoseConfig& 
         // ---- homography + GRIC-H (kp_cur -> kp_ref)
         int rc = enqueue_find_homography(tb.ws_h, tb.kp_cur, tb.kp_ref, n_host, 1.0, 2000, 0.99, s);
         if (rc != DFVO_OK) return rc;
-        hipLaunchKernelGGL(k_gric_h_residual, dim3(nb), dim3(256), 0, s, tb.ws_h.out, tb.kp_info, tb.kp_cur, tb.kp_ref,
-                           tb.res);
-        hipLaunchKernelGGL(k_gric_sum, dim3(1), dim3(256), 0, s, tb.res, 0, tb.kp_info, 0.8, 8, 2, tb.small + 18);
-        hipLaunchKernelGGL(k_set_h_gric, dim3(1), dim3(1), 0, s, tb.pose, tb.ws_h.state, tb.small + 18);
+        {
+            GricFusedBatch GH;
+            for (int r = 0; r < MAX_E_BATCH; ++r) GH.M[r] = tb.ws_h.out;
+            hipLaunchKernelGGL(k_gric_fused, dim3(1), dim3(256), 0, s, GH, 1, tb.small, tb.small + 9, tb.kp_info, tb.kp_cur,
+                               tb.kp_ref, 0, 0.8, 8, 2, tb.small + 18);
+        }
         hipStream_t sr = tb.s_rep[0];
         const unsigned R = (unsigned)cfg.repeat;
         rc = enqueue_mt_shuffle(tb.mt_state, tb.kp_info, n_host, cfg.repeat, cap + 8, tb.perm, sr);
@@ -1001,7 +1138,6 @@ int enqueue_compute_pose_2d2d(TrackerBuffers& tb, int n_host, const PoseConfig& 
                            tb.kp_ref, tb.pa, tb.pb, 2 * cap);
         // the `repeat` five-point RANSACs as one batched launch sequence (blockIdx.y = repeat)
         const double *pas[MAX_REP], *pbs[MAX_REP];
-        GricBatch G;
         for (int rep = 0; rep < cfg.repeat; ++rep) {
             pas[rep] = tb.pa + (size_t)rep * 2 * cap;
             pbs[rep] = tb.pb + (size_t)rep * 2 * cap;
@@ -1009,45 +1145,75 @@ int enqueue_compute_pose_2d2d(TrackerBuffers& tb, int n_host, const PoseConfig& 
         rc = enqueue_find_essential_batch(tb.ws_rep, pas, pbs, cfg.repeat, n_host, cfg.fx, cfg.cx, cfg.cy, 0.99,
                                               cfg.reproj_thre, cfg.max_iters, sr);
         if (rc != DFVO_OK) return rc;
-        for (int rep = 0; rep < MAX_E_BATCH; ++rep) G.E[rep] = rep < cfg.repeat ? tb.ws_rep[rep].out : nullptr;
-        hipLaunchKernelGGL(k_gric_f_residual, dim3(nb, R), dim3(256), 0, sr, G, tb.small, tb.small + 9, tb.kp_info, tb.pa,
-                           tb.pb, 2 * cap, tb.res + cap, cap);
-        hipLaunchKernelGGL(k_gric_sum, dim3(R), dim3(256), 0, sr, tb.res + cap, cap, tb.kp_info, 0.8, 5, 3, tb.small + 19);
+        {
+            GricFusedBatch GE;
+            for (int rep = 0; rep < MAX_E_BATCH; ++rep) GE.M[rep] = rep < cfg.repeat ? tb.ws_rep[rep].out : nullptr;
+            hipLaunchKernelGGL(k_gric_fused, dim3(R), dim3(256), 0, sr, GE, 0, tb.small, tb.small + 9, tb.kp_info, tb.pa, tb.pb,
+                               2 * cap, 0.8, 5, 3, tb.small + 19);
+        }
         DFVO_HIP_CHECK(hipEventRecord(tb.ev_rep[0], sr));
         DFVO_HIP_CHECK(hipStreamWaitEvent(s, tb.ev_rep[0], 0));
-        for (int rep = 0; rep < cfg.repeat; ++rep) {
-            hipLaunchKernelGGL(k_rep_update, dim3(1), dim3(256), 0, s, tb.pose, tb.ws_rep[rep].state, tb.ws_rep[rep].out,
-                               tb.small + 19 + rep, tb.ws_rep[rep].mask, tb.perm + (size_t)rep * (cap + 8),
-                               tb.best_inliers, rep);
+        {
+            RepBatch RB;
+            for (int rep = 0; rep < MAX_REP; ++rep) {
+                RB.st[rep] = rep < cfg.repeat ? tb.ws_rep[rep].state : nullptr;
+                RB.E[rep] = rep < cfg.repeat ? tb.ws_rep[rep].out : nullptr;
+                RB.mask[rep] = rep < cfg.repeat ? tb.ws_rep[rep].mask : nullptr;
+            }
+            hipLaunchKernelGGL(k_rep_update_all, dim3(1), dim3(256), 0, s, tb.pose, tb.ws_h.state, tb.small + 18, RB,
+                               tb.small + 19, tb.perm, cap + 8, tb.best_inliers, cfg.repeat);
         }
-        hipLaunchKernelGGL(k_pose_finish, dim3(1), dim3(1), 0, s, tb.pose, tb.ws_rep[0].out + 16, cfg.repeat, 0);
-        // recoverPose(best_E, kp_cur, kp_ref): always enqueued, consumed only when major_valid
+        // recoverPose(best_E, kp_cur, kp_ref): always enqueued, consumed only when major_valid; its last kernel also
+        // writes the pose bookkeeping and (fused pipeline) the inverse pose for the scale stage
+        PoseFinish fin;
+        fin.ps = tb.pose;
+        fin.T21 = d_T21;
         rc = enqueue_recover_pose(tb.ws_rep[0], (const double*)((const char*)tb.pose + offsetof(PoseState, best_E)),
-                                  tb.kp_cur, tb.kp_ref, n_host, cfg.fx, cfg.cx, cfg.cy, s);
+                                  tb.kp_cur, tb.kp_ref, n_host, cfg.fx, cfg.cx, cfg.cy, s, fin);
         if (rc != DFVO_OK) return rc;
-        hipLaunchKernelGGL(k_pose_finish, dim3(1), dim3(1), 0, s, tb.pose, tb.ws_rep[0].out + 16, cfg.repeat, 1);
     }
     DFVO_HIP_CHECK(hipGetLastError());
     return DFVO_OK;
 }
 
 // find_scale_from_depth on tb.kp_ref (kp1) / tb.kp_cur (kp2); d_T21: 16 doubles; d_depth: H x W doubles
-int enqueue_find_scale(TrackerBuffers& tb, int n_host, const double* d_T21, const double* d_depth, int H, int W,
-                       const ScaleConfig& cfg, hipStream_t s, const PoseState* d_gate) {
-    DFVO_ARG_CHECK(n_host >= 0 && n_host <= tb.kp_cap, "find_scale: keypoint capacity");
+// clears the scatter map and the ratio counter of the scale stage on a side stream (tb.s_rep[1]) and records
+// tb.ev_rep[1]; enqueue_find_scale(prepared = true) then only waits for that event, so the two fills leave the
+// solver's chain of dependent launches
+int enqueue_scale_prepare(TrackerBuffers& tb, int H, int W) {
     if ((size_t)H * W > tb.winner_cap) {
         if (tb.winner) (void)hipFree(tb.winner);
         tb.winner_cap = (size_t)H * W;
         DFVO_HIP_CHECK(hipMalloc((void**)&tb.winner, sizeof(int) * tb.winner_cap));
     }
-    DFVO_HIP_CHECK(hipMemsetAsync(tb.winner, 0xff, sizeof(int) * (size_t)H * W, s));
-    DFVO_HIP_CHECK(hipMemsetAsync(tb.kp_total, 0, sizeof(int), s));
+    hipStream_t side = tb.s_rep[1];
+    DFVO_HIP_CHECK(hipMemsetAsync(tb.winner, 0xff, sizeof(int) * (size_t)H * W, side));
+    DFVO_HIP_CHECK(hipMemsetAsync(tb.kp_total + 4, 0, sizeof(int), side));
+    DFVO_HIP_CHECK(hipEventRecord(tb.ev_rep[1], side));
+    return DFVO_OK;
+}
+
+int enqueue_find_scale(TrackerBuffers& tb, int n_host, const double* d_T21, const double* d_depth, int H, int W,
+                       const ScaleConfig& cfg, hipStream_t s, const PoseState* d_gate, bool prepared) {
+    DFVO_ARG_CHECK(n_host >= 0 && n_host <= tb.kp_cap, "find_scale: keypoint capacity");
+    if (prepared) {
+        DFVO_ARG_CHECK((size_t)H * W <= tb.winner_cap, "find_scale: enqueue_scale_prepare was not called for this size");
+        DFVO_HIP_CHECK(hipStreamWaitEvent(s, tb.ev_rep[1], 0));
+    } else {
+        if ((size_t)H * W > tb.winner_cap) {
+            if (tb.winner) (void)hipFree(tb.winner);
+            tb.winner_cap = (size_t)H * W;
+            DFVO_HIP_CHECK(hipMalloc((void**)&tb.winner, sizeof(int) * tb.winner_cap));
+        }
+        DFVO_HIP_CHECK(hipMemsetAsync(tb.winner, 0xff, sizeof(int) * (size_t)H * W, s));
+        DFVO_HIP_CHECK(hipMemsetAsync(tb.kp_total + 4, 0, sizeof(int), s));
+    }
     const int nb = cdiv(n_host > 0 ? n_host : 1, 256);
     hipLaunchKernelGGL(k_scale_triangulate, dim3(nb), dim3(256), 0, s, tb.kp_info, tb.kp_ref, tb.kp_cur, d_T21, cfg.cx,
                        cfg.cy, cfg.fx, cfg.fy, H, W, tb.z2, tb.pix, tb.winner);
     hipLaunchKernelGGL(k_scale_ratios, dim3(1), dim3(256), sizeof(int) * (size_t)(n_host > 0 ? n_host : 1), s, tb.kp_info,
-                       tb.z2, tb.pix, tb.winner, d_depth, tb.ratios, tb.kp_total);
-    hipLaunchKernelGGL(k_scale_ransac, dim3(1), dim3(256), 0, s, tb.mt_state, tb.ratios, tb.kp_total, 10,
+                       tb.z2, tb.pix, tb.winner, d_depth, tb.ratios, tb.kp_total + 4);
+    hipLaunchKernelGGL(k_scale_ransac, dim3(1), dim3(256), 0, s, tb.mt_state, tb.ratios, tb.kp_total + 4, 10,
                        cfg.min_samples, cfg.max_trials, cfg.stop_prob, cfg.thre, tb.inl_a, tb.inl_b, tb.scratch,
                        tb.scale_out, d_gate);
     DFVO_HIP_CHECK(hipGetLastError());

@@ -24,6 +24,7 @@
 #include "ransac_dev.h"
 #include "solver.h"
 #include "solver_math.h"
+#include "tracker.h"
 
 namespace dfvo {
 
@@ -357,6 +358,28 @@ int enqueue_find_essential(RansacWorkspace& w, const double* d_pts1, const doubl
 __global__ void k_to_float(const double* __restrict__ a, int n, float* __restrict__ o) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) o[i] = (float)a[i];
+}
+
+// findHomography prologue in one launch: RANSAC state reset + both point sets converted to float (blockIdx.y)
+__global__ void k_h_init_to_float(RansacState* st, int max_iters, const double* __restrict__ a, const double* __restrict__ b,
+                                  int n2, float* __restrict__ fa, float* __restrict__ fb) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && blockIdx.y == 0) {
+        st->rng_state = 0xffffffffffffffffULL;
+        st->niters = max_iters > 1 ? max_iters : 1;
+        st->iter = 0;
+        st->max_good = 0;
+        st->best_iter = -1;
+        st->best_model = -1;
+        st->done = 0;
+        st->subset_fail_at = -1;
+        st->found = 0;
+    }
+    if (i >= n2) return;
+    if (blockIdx.y == 0)
+        fa[i] = (float)a[i];
+    else
+        fb[i] = (float)b[i];
 }
 
 // one lane: subsets with HomographyEstimatorCallback::checkSubset, up to 10000 attempts each
@@ -814,8 +837,9 @@ __device__ double seq_dot8(const double* a, const double* b) {
 
 __global__ __launch_bounds__(256) void k_h_refine(const RansacState* st, const float* __restrict__ src,
                                                    const float* __restrict__ dst, int n,
-                                                   const uint8_t* __restrict__ mask, int* __restrict__ cidx,
-                                                   double* __restrict__ lm, double* __restrict__ H_io, int pts_cap) {
+                                                   uint8_t* __restrict__ mask, int* __restrict__ cidx,
+                                                   double* __restrict__ lm, double* __restrict__ H_io, int pts_cap,
+                                                   const double* __restrict__ models, float thr2) {
     __shared__ HRefineShared sh;
     extern __shared__ float s_allpts[];  // Mx My mx my of every inlier when they fit (pts_cap points)
     __shared__ double s_h[9], s_x[8], s_xd[8], s_d[8], s_v[8], s_A[64], s_D[8], s_norm[8], s_LtL[81];
@@ -823,14 +847,28 @@ __global__ __launch_bounds__(256) void k_h_refine(const RansacState* st, const f
     __shared__ double s_Ap[64], s_eig[2 * 81 + 2 * 9];  // lane 0's dense 8x8 / 9x9 work (LDS, not scratch)
     __shared__ int s_flag;
     (void)lm;
-    if (!st->found) return;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    // ---- ordered compaction of the inlier indices
+    if (!st->found) {  // no model: all-zero mask (what k_h_mask writes in the stand-alone path)
+        for (int i = t; i < n; i += 256) mask[i] = 0;
+        return;
+    }
+    // ---- inlier mask of the winning model (findInliers on the best hypothesis) + ordered compaction of its indices
+    float Hf[8];
+    {
+        const double* Hb = models + (size_t)st->best_iter * 9;
+#pragma unroll
+        for (int k = 0; k < 8; k++) Hf[k] = (float)Hb[k];
+        if (t < 9) H_io[t] = Hb[t];
+    }
     if (t == 0) sh.base = 0;
     __syncthreads();
     for (int c0 = 0; c0 < n; c0 += 256) {
         const int i = c0 + t;
-        const bool f = i < n && mask[i] != 0;
+        bool f = false;
+        if (i < n) {
+            f = sm::homography_error(Hf, src[i * 2], src[i * 2 + 1], dst[i * 2], dst[i * 2 + 1]) <= thr2;
+            mask[i] = f ? 1 : 0;
+        }
         const unsigned long long b = __ballot(f);
         if (lane == 0) sh.wave_cnt[wave] = __popcll(b);
         __syncthreads();
@@ -1129,15 +1167,15 @@ int enqueue_find_homography(RansacWorkspace& w, const double* d_pts1, const doub
     if (rc != DFVO_OK) return rc;
     if (thr <= 0) thr = 3;
     const float thr2 = (float)(thr * thr);
-    hipLaunchKernelGGL(k_ransac_init, dim3(1), dim3(1), 0, s, w.state, max_iters, (uint64_t)-1);
     if (n < 5) {  // n < 4: no model; n == 4 is not reachable from DF-VO (kp count > 10 is checked upstream)
+        hipLaunchKernelGGL(k_ransac_init, dim3(1), dim3(1), 0, s, w.state, max_iters, (uint64_t)-1);
         hipLaunchKernelGGL(k_h_mask, dim3(cdiv(n > 9 ? n : 9, 256)), dim3(256), 0, s, w.state, w.models, w.f_a, w.f_b, n,
                            thr2, w.mask, w.out);
         DFVO_HIP_CHECK(hipGetLastError());
         return DFVO_OK;
     }
-    hipLaunchKernelGGL(k_to_float, dim3(cdiv(2 * n, 256)), dim3(256), 0, s, d_pts1, 2 * n, w.f_a);
-    hipLaunchKernelGGL(k_to_float, dim3(cdiv(2 * n, 256)), dim3(256), 0, s, d_pts2, 2 * n, w.f_b);
+    hipLaunchKernelGGL(k_h_init_to_float, dim3(cdiv(2 * n, 256), 2), dim3(256), 0, s, w.state, max_iters, d_pts1, d_pts2,
+                       2 * n, w.f_a, w.f_b);
     int cb[4];
     chunk_bounds(max_iters, cb);
     for (int c = 0; c < 3; ++c) {
@@ -1150,8 +1188,6 @@ int enqueue_find_homography(RansacWorkspace& w, const double* d_pts1, const doub
                            w.f_b, n, thr2, w.counts);
         hipLaunchKernelGGL(k_replay, dim3(1), dim3(1), 0, s, w.state, w.nmodels, w.counts, 1, it0, it1, n, 4, confidence);
     }
-    hipLaunchKernelGGL(k_h_mask, dim3(cdiv(n > 9 ? n : 9, 256)), dim3(256), 0, s, w.state, w.models, w.f_a, w.f_b, n, thr2,
-                       w.mask, w.out);
     // every inlier's coordinates stay in LDS across the LM passes when they fit (16 B / point)
     const int pts_cap = n <= 6144 ? n : 0;
     static int configured = 0;
@@ -1159,8 +1195,9 @@ int enqueue_find_homography(RansacWorkspace& w, const double* d_pts1, const doub
         DFVO_HIP_CHECK(hipFuncSetAttribute((const void*)k_h_refine, hipFuncAttributeMaxDynamicSharedMemorySize, 6144 * 16));
         configured = 6144 * 16;
     }
+    // inlier mask of the winner + refit + LM in one launch
     hipLaunchKernelGGL(k_h_refine, dim3(1), dim3(256), (size_t)pts_cap * 16, s, w.state, w.f_a, w.f_b, n, w.mask, w.cidx, w.lm,
-                       w.out, pts_cap);
+                       w.out, pts_cap, w.models, thr2);
     DFVO_HIP_CHECK(hipGetLastError());
     return DFVO_OK;
 }
@@ -1169,8 +1206,7 @@ int enqueue_find_homography(RansacWorkspace& w, const double* d_pts1, const doub
 // recoverPose / triangulation
 // ================================================================================================
 // out layout: [0..8] R1, [9..17] R2, [18..20] t, then 4 x 12 projection matrices from 24
-__global__ void k_pose_candidates(const double* __restrict__ E, double* __restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ void pose_candidates(const double* __restrict__ E, double* __restrict__ out) {
     double R1[9], R2[9], t[3];
     sm::decompose_essential(E, R1, R2, t);
     for (int i = 0; i < 9; i++) {
@@ -1210,9 +1246,29 @@ __global__ void k_cheirality(const double* __restrict__ cand, const double* __re
     }
 }
 
+// recoverPose prologue in one launch: both point sets normalised (blockIdx.y), the four (R, t) candidates of E and
+// the zeroed vote counters on thread 0 of block (0, 0)
+__global__ void k_pose_prepare(const double* __restrict__ E, const double* __restrict__ p1, const double* __restrict__ p2,
+                               int n, double a, double bx, double by, double* __restrict__ n1, double* __restrict__ n2,
+                               double* __restrict__ cand, int* __restrict__ good) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const double* src = blockIdx.y == 0 ? p1 : p2;
+        double* dst = blockIdx.y == 0 ? n1 : n2;
+        dst[i * 2] = src[i * 2] * a + bx;
+        dst[i * 2 + 1] = src[i * 2 + 1] * a + by;
+    }
+    if (i == 0 && blockIdx.y == 0) {
+        good[0] = good[1] = good[2] = good[3] = 0;
+        pose_candidates(E, cand);
+    }
+}
+
+// fin (optional): PoseState of the fused pipeline; its recoverPose bookkeeping (E_tracker.py:292-300) and the
+// inverse pose T21 for the scale stage are written by the same thread that selects the winner
 __global__ void k_pose_select(const double* __restrict__ cand, const int* __restrict__ good,
                               const uint8_t* __restrict__ flags, int n, double* __restrict__ out,
-                              uint8_t* __restrict__ mask) {
+                              uint8_t* __restrict__ mask, PoseFinish fin) {
     // out: [0..8] R, [9..11] t, [12] good count (as double)
     const int g0 = good[0], g1 = good[1], g2 = good[2], g3 = good[3];
     int sel;
@@ -1231,27 +1287,45 @@ __global__ void k_pose_select(const double* __restrict__ cand, const int* __rest
         for (int k = 0; k < 9; k++) out[k] = R[k];
         for (int k = 0; k < 3; k++) out[9 + k] = sel >= 2 ? -cand[18 + k] : cand[18 + k];
         out[12] = (double)good[sel];
+        if (fin.ps && fin.ps->major_valid) {
+            PoseState* ps = fin.ps;
+            const int g = good[sel];
+            ps->cheirality = g;
+            if ((double)g > (double)ps->n * 0.1) {
+                for (int k = 0; k < 9; k++) ps->R[k] = out[k];
+                for (int k = 0; k < 3; k++) ps->t[k] = out[9 + k];
+            }
+        }
+        if (fin.ps && fin.T21) {  // T21 = inverse of [R t; 0 1] (E_pose.inv_pose, E_tracker.py:504)
+            const double* R = fin.ps->R;
+            const double* tt = fin.ps->t;
+            double* T = fin.T21;
+            for (int r = 0; r < 3; r++) {
+                for (int c = 0; c < 3; c++) T[r * 4 + c] = R[c * 3 + r];
+                T[r * 4 + 3] = -(R[0 * 3 + r] * tt[0] + R[1 * 3 + r] * tt[1] + R[2 * 3 + r] * tt[2]);
+            }
+            T[12] = T[13] = T[14] = 0;
+            T[15] = 1;
+        }
     }
 }
 
 // d_E: device 9 doubles; points device [n][2].  Results in w.out[16..28] (R, t, count), w.mask
 int enqueue_recover_pose(RansacWorkspace& w, const double* d_E, const double* d_pts1, const double* d_pts2, int n,
-                         double focal, double ppx, double ppy, hipStream_t s) {
+                         double focal, double ppx, double ppy, hipStream_t s, PoseFinish fin) {
     int rc = w.ensure(n > 8 ? n : 8, w.cap_iters > 0 ? w.cap_iters : 16);
     if (rc != DFVO_OK) return rc;
     DFVO_ARG_CHECK(4 * (size_t)n <= sizeof(double) * 10 * 2 * (size_t)w.cap_n, "recover_pose: workspace");
     const double a = 1. / focal, bx = -ppx * a, by = -ppy * a;
-    hipLaunchKernelGGL(k_e_normalise, dim3(cdiv(n > 0 ? n : 1, 256)), dim3(256), 0, s, d_pts1, n, a, bx, by, w.norm_a);
-    hipLaunchKernelGGL(k_e_normalise, dim3(cdiv(n > 0 ? n : 1, 256)), dim3(256), 0, s, d_pts2, n, a, bx, by, w.norm_b);
     double* cand = w.lm;                        // 72 doubles
     int* good = (int*)(w.lm + 80);              // 4 ints
     uint8_t* flags = (uint8_t*)(w.lm + 96);     // 4 * n bytes
-    DFVO_HIP_CHECK(hipMemsetAsync(good, 0, 4 * sizeof(int), s));
-    hipLaunchKernelGGL(k_pose_candidates, dim3(1), dim3(1), 0, s, d_E, cand);
+    hipLaunchKernelGGL(k_pose_prepare, dim3(cdiv(n > 0 ? n : 1, 256), 2), dim3(256), 0, s, d_E, d_pts1, d_pts2, n, a, bx, by,
+                       w.norm_a, w.norm_b, cand, good);
     hipLaunchKernelGGL(k_cheirality, dim3(cdiv(n > 0 ? n : 1, 256)), dim3(256), 0, s, cand, w.norm_a, w.norm_b, n, flags,
                        good);
     hipLaunchKernelGGL(k_pose_select, dim3(cdiv(n > 0 ? n : 1, 256)), dim3(256), 0, s, cand, good, flags, n, w.out + 16,
-                       w.mask);
+                       w.mask, fin);
     DFVO_HIP_CHECK(hipGetLastError());
     return DFVO_OK;
 }

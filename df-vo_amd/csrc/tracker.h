@@ -122,7 +122,9 @@ struct TrackerBuffers {
 int enqueue_local_bestn(TrackerBuffers& tb, const float* d_flow, const float* d_diff, int H, int W, int num_row,
                         int num_col, int num_bestN, float thre, hipStream_t s);
 int enqueue_mt_seed(TrackerBuffers& tb, uint32_t seed, hipStream_t s);
-int enqueue_compute_pose_2d2d(TrackerBuffers& tb, int n_host, const PoseConfig& cfg, hipStream_t s);
+// d_T21 (optional): 16 doubles that receive the inverse of the accepted pose (input of the scale stage)
+int enqueue_compute_pose_2d2d(TrackerBuffers& tb, int n_host, const PoseConfig& cfg, hipStream_t s,
+                              double* d_T21 = nullptr);
 int enqueue_mt_shuffle(uint32_t* mt_state, const int* d_n, int n_host, int repeat, int perm_stride, int* perm,
                        hipStream_t s);
 int enqueue_compute_pose_3d2d(PnpBuffers& pb, uint32_t* mt_state, const double* d_kp1, const double* d_kp2,
@@ -130,6 +132,7 @@ int enqueue_compute_pose_3d2d(PnpBuffers& pb, uint32_t* mt_state, const double* 
                               hipStream_t s);
 // d_gate (optional): device PoseState whose zero translation suppresses the whole stage (no RandomState draws)
 int enqueue_find_scale(TrackerBuffers& tb, int n_host, const double* d_T21, const double* d_depth, int H, int W,
-                       const ScaleConfig& cfg, hipStream_t s, const PoseState* d_gate = nullptr);
+                       const ScaleConfig& cfg, hipStream_t s, const PoseState* d_gate = nullptr, bool prepared = false);
+int enqueue_scale_prepare(TrackerBuffers& tb, int H, int W);
 
 }  // namespace dfvo

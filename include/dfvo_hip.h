@@ -243,7 +243,7 @@ int dfvo_compute_pose_3d2d(dfvo_tracker* trk, const double* h_kp1, const double*
 /* =====================================================================================
  * Fused per-pair pipeline: images in HBM -> relative pose, everything between on the device
  * (libs/dfvo.py:299-345 deep_model_inference + :121-262 tracking, hybrid E-tracker path).
- * Two slots double-buffer the net outputs so that the nets of pair k+1 run under the solvers of pair k.
+ * DFVO_PIPELINE_SLOTS slots buffer the net outputs so that the nets of the following pairs run under the solvers of pair k.
  * ===================================================================================== */
 typedef struct dfvo_pipeline dfvo_pipeline;
 typedef struct dfvo_pipeline_cfg {
@@ -283,7 +283,10 @@ int dfvo_pipeline_set_depth_param(dfvo_pipeline* p, const char* name, const floa
 int dfvo_pipeline_finalize(dfvo_pipeline* p);
 int dfvo_pipeline_seed(dfvo_pipeline* p, uint32_t seed);
 int dfvo_pipeline_set_graph(dfvo_pipeline* p, int enable);   /* hipGraph replay of the nets (default on) */
-/* enqueue both nets for one pair into `slot` (0/1); returns at once.  d_* uint8 device images:
+/* number of output slots: the host may run the nets this many pairs ahead of the solver stage (the nets of pairs
+ * k+1 .. k+3 queue up behind each other on their streams while dfvo_pipeline_track(k) blocks the host) */
+#define DFVO_PIPELINE_SLOTS 4
+/* enqueue both nets for one pair into `slot` (0 .. DFVO_PIPELINE_SLOTS-1); returns at once.  d_* uint8 device images:
  * ref/cur [img_h,img_w,3], cur_feed [feed_h,feed_w,3] (the PIL-LANCZOS resized current frame) */
 int dfvo_pipeline_enqueue_nets(dfvo_pipeline* p, int slot, const uint8_t* d_ref, const uint8_t* d_cur,
                                const uint8_t* d_cur_feed);

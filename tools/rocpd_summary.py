@@ -23,6 +23,19 @@ def main():
         for name, st, en, q, gx in rows:
             print("%10.1f us  +%8.1f us  q=%-4s grid=%-7s %s" % ((st - t0) / 1e3, (en - st) / 1e3, q, gx, name[:60]))
         return
+    if "--netspans" in sys.argv:
+        # flow-net passes: first k_img_u8_to_flow_input -> k_flow_consistency; busy = sum of net kernel durations inside
+        rows = list(cur.execute("select name, start, end from kernels order by start"))
+        starts = [r[1] for r in rows if "k_img_u8_to_flow_input" in r[0]][::2]
+        ends = [r[2] for r in rows if "k_flow_consistency" in r[0]]
+        print("flow-net passes: %d" % len(ends))
+        prev_end = None
+        for i, e in enumerate(ends):
+            st = max(x for x in starts if x < e)
+            gap = (st - prev_end) / 1e3 if prev_end else 0.0
+            print("  pass %2d: span %8.1f us   gap since previous pass end %8.1f us" % (i, (e - st) / 1e3, gap))
+            prev_end = e
+        return
     if "--spans" in sys.argv:
         # per-pair span of the solver stage (k_kp_count start -> last k_scale_ransac / k_pnp_select end) and of the nets
         rows = list(cur.execute("select name, start, end from kernels order by start"))
