@@ -25,6 +25,7 @@ def run():
     ref, cur = syn.image_pair(h, w, seed=2)
     feed, _ = syn.image_pair(64, 96, seed=3)
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    pipe.set_ref_depth(depth=d(sc["depth_ref"]))  # reference-frame depth: input of the PnP fallback
     pipe.enqueue_nets(0, d(ref), d(cur), d(feed))
     out = pipe.track(0, d(sc["flow"]), d(sc["diff"]), d(sc["depth_cur"]))
     fwd, bwd, diff, raw, dep = pipe.get_outputs(0)
@@ -42,7 +43,20 @@ def run():
     assert out.good_kp_found == int(kp["good_kp_found"])
     if kp["good_kp_found"]:
         res = T.compute_pose_2d2d(kp["kp1_best"][0], kp["kp2_best"][0], sc["K"])
-        assert np.array_equal(np.array(out.R[:]).reshape(3, 3), res["R"])
-        assert np.array_equal(np.array(out.t[:]).reshape(3, 1), res["t"])
+        scale = -1
+        if np.linalg.norm(res["t"]) != 0:
+            pose = np.eye(4)
+            pose[:3, :3], pose[:3, 3:] = res["R"], res["t"]
+            scale = T.find_scale_from_depth(kp["kp1_best"][0], kp["kp2_best"][0], np.linalg.inv(pose), sc["depth_cur"],
+                                            sc["K"])
+        if np.linalg.norm(res["t"]) == 0 or scale == -1:  # hybrid path: PnP fallback (dfvo.py:225-250)
+            pnp = T.compute_pose_3d2d(kp["kp1_best"][0], kp["kp2_best"][0], sc["depth_ref"], sc["K"])
+            assert out.status == 3 and out.pnp_inliers == pnp["best_inlier"]
+            assert np.array_equal(np.array(out.R[:]).reshape(3, 3), pnp["R"])
+            assert np.array_equal(np.array(out.t[:]).reshape(3, 1), pnp["t"])
+        else:
+            assert out.status == 0
+            assert np.array_equal(np.array(out.R[:]).reshape(3, 3), res["R"])
+            assert np.array_equal(np.array(out.t[:]).reshape(3, 1), res["t"])
     print("smoke ok: flow max err %.2e, status %d, kp %d, inliers %d, scale %.6f" % (e, out.status, out.n_kp,
                                                                                   out.best_inlier_cnt, out.scale))
