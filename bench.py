@@ -23,6 +23,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before torch / HIP initialise: see df-vo_amd/__init__.py
 
 SLOTS = 4  # DFVO_PIPELINE_SLOTS
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: FP32 matrix (f32 in / f32 acc)
@@ -167,12 +168,16 @@ def main():
     roof = None
     if rank == 0 and not args.no_roofline:
         # per-launch durations of the conv kernel family, HIP events on the launch streams, graphs off
+        # (one pair in flight at a time here: overlapping passes would stretch each other's launches)
         pipe.set_graph(0)
-        run(1)
+        pipe.enqueue_nets(0, d_ref, d_cur, d_feed)
+        pipe.sync()
         lib = capi.lib()
         capi.check(lib.dfvo_conv_profile_begin())
         nprof = 3
-        run(nprof)
+        for _ in range(nprof):
+            pipe.enqueue_nets(0, d_ref, d_cur, d_feed)
+            pipe.sync()
         ms = np.zeros(18)
         fl = np.zeros(18)
         ln = np.zeros(18, np.int32)

@@ -18,6 +18,12 @@ using namespace dfvo;
 struct dfvo_pipeline {
     int H = 0, W = 0, feedH = 0, feedW = 0;
     FlowNet flow;
+    // further flow-net instances, each on its own stream (DFVO_FLOW_INSTANCES, default 2): consecutive pairs rotate
+    // over the instances, so the latency-bound coarse pyramid levels of one pass overlap the throughput-bound fine
+    // levels of another (8.7 -> 7.1 ms per pair with two); costs one set of activations (~1.3 GB) per instance
+    FlowNet flow_x[DFVO_PIPELINE_SLOTS - 1];
+    hipStream_t s_flow_x[DFVO_PIPELINE_SLOTS - 1] = {};
+    int flow_instances = 1;
     DepthNet depth;
     TrackerBuffers tb;
     hipStream_t s_flow = nullptr, s_depth = nullptr, s_trk = nullptr;
@@ -72,6 +78,14 @@ int dfvo_pipeline_create(const dfvo_pipeline_cfg* cfg, dfvo_pipeline** out) {
     }
     int rc = p->flow.init(p->H, p->W, p->s_flow);
     if (rc != DFVO_OK) return fail(rc);
+    p->flow_instances = getenv("DFVO_FLOW_INSTANCES") ? atoi(getenv("DFVO_FLOW_INSTANCES")) : 2;
+    if (p->flow_instances < 1) p->flow_instances = 1;
+    if (p->flow_instances > DFVO_PIPELINE_SLOTS) p->flow_instances = DFVO_PIPELINE_SLOTS;
+    for (int i = 0; i + 1 < p->flow_instances; ++i) {
+        if (hipStreamCreateWithFlags(&p->s_flow_x[i], hipStreamNonBlocking) != hipSuccess) return fail(DFVO_ERR_HIP);
+        rc = p->flow_x[i].init(p->H, p->W, p->s_flow_x[i]);
+        if (rc != DFVO_OK) return fail(rc);
+    }
     rc = p->depth.init(p->feedH, p->feedW, p->s_depth);
     if (rc != DFVO_OK) return fail(rc);
     p->depth.min_depth = cfg->net_min_depth;
@@ -106,6 +120,10 @@ void dfvo_pipeline_destroy(dfvo_pipeline* p) {
     if (!p) return;
     (void)hipDeviceSynchronize();
     p->flow.destroy();
+    for (int i = 0; i + 1 < p->flow_instances; ++i) {
+        p->flow_x[i].destroy();
+        if (p->s_flow_x[i]) (void)hipStreamDestroy(p->s_flow_x[i]);
+    }
     p->depth.destroy();
     p->tb.release();
     for (int i = 0; i < DFVO_PIPELINE_SLOTS; i++) {
@@ -141,6 +159,7 @@ static int pipe_store(ParamStore* ps, const char* name, const float* h, int ndim
 
 int dfvo_pipeline_set_flow_param(dfvo_pipeline* p, const char* name, const float* h, int ndim, const int* shape) {
     DFVO_ARG_CHECK(p && !p->nets_ready, "dfvo_pipeline_set_flow_param: bad state");
+    for (int i = 0; i + 1 < p->flow_instances; ++i) P_TRY(pipe_store(&p->flow_x[i].params, name, h, ndim, shape));
     return pipe_store(&p->flow.params, name, h, ndim, shape);
 }
 int dfvo_pipeline_set_depth_param(dfvo_pipeline* p, const char* name, const float* h, int ndim, const int* shape) {
@@ -150,6 +169,7 @@ int dfvo_pipeline_set_depth_param(dfvo_pipeline* p, const char* name, const floa
 int dfvo_pipeline_finalize(dfvo_pipeline* p) {
     DFVO_ARG_CHECK(p, "null pipeline");
     P_TRY(p->flow.finalize());
+    for (int i = 0; i + 1 < p->flow_instances; ++i) P_TRY(p->flow_x[i].finalize());
     P_TRY(p->depth.finalize());
     p->nets_ready = true;
     return DFVO_OK;
@@ -157,6 +177,7 @@ int dfvo_pipeline_finalize(dfvo_pipeline* p) {
 int dfvo_pipeline_set_graph(dfvo_pipeline* p, int enable) {
     DFVO_ARG_CHECK(p, "null pipeline");
     p->flow.use_graph = enable != 0;
+    for (int i = 0; i + 1 < p->flow_instances; ++i) p->flow_x[i].use_graph = enable != 0;
     p->depth.use_graph = enable != 0;
     return DFVO_OK;
 }
@@ -179,11 +200,14 @@ int dfvo_pipeline_enqueue_nets(dfvo_pipeline* p, int slot, const uint8_t* d_ref,
                             (float)c.max_depth, p->raw_depth[slot], p->proc_depth[slot], p->s_depth));
     DFVO_HIP_CHECK(hipEventRecord(p->e_depth[slot], p->s_depth));
     // forward/backward flow (dfvo.py:321-335)
-    P_TRY(p->flow.forward(d_ref, d_cur, p->flow.out_fwd.p, p->flow.out_bwd.p, p->flow.out_diff.p));
-    DFVO_HIP_CHECK(hipMemcpyAsync(p->fwd[slot], p->flow.out_fwd.p, 2 * px * sizeof(float), hipMemcpyDeviceToDevice, p->s_flow));
-    DFVO_HIP_CHECK(hipMemcpyAsync(p->bwd[slot], p->flow.out_bwd.p, 2 * px * sizeof(float), hipMemcpyDeviceToDevice, p->s_flow));
-    DFVO_HIP_CHECK(hipMemcpyAsync(p->diff[slot], p->flow.out_diff.p, px * sizeof(float), hipMemcpyDeviceToDevice, p->s_flow));
-    DFVO_HIP_CHECK(hipEventRecord(p->e_flow[slot], p->s_flow));
+    const int inst = slot % p->flow_instances;
+    FlowNet& fn = inst == 0 ? p->flow : p->flow_x[inst - 1];
+    hipStream_t sf = fn.stream;
+    P_TRY(fn.forward(d_ref, d_cur, fn.out_fwd.p, fn.out_bwd.p, fn.out_diff.p));
+    DFVO_HIP_CHECK(hipMemcpyAsync(p->fwd[slot], fn.out_fwd.p, 2 * px * sizeof(float), hipMemcpyDeviceToDevice, sf));
+    DFVO_HIP_CHECK(hipMemcpyAsync(p->bwd[slot], fn.out_bwd.p, 2 * px * sizeof(float), hipMemcpyDeviceToDevice, sf));
+    DFVO_HIP_CHECK(hipMemcpyAsync(p->diff[slot], fn.out_diff.p, px * sizeof(float), hipMemcpyDeviceToDevice, sf));
+    DFVO_HIP_CHECK(hipEventRecord(p->e_flow[slot], sf));
     return DFVO_OK;
 }
 
@@ -352,6 +376,7 @@ int dfvo_pipeline_get_flow(dfvo_pipeline* p, int slot, float* h_fwd, float* h_bw
 int dfvo_pipeline_sync(dfvo_pipeline* p) {
     DFVO_ARG_CHECK(p, "null pipeline");
     DFVO_HIP_CHECK(hipStreamSynchronize(p->s_flow));
+    for (int i = 0; i + 1 < p->flow_instances; ++i) DFVO_HIP_CHECK(hipStreamSynchronize(p->s_flow_x[i]));
     DFVO_HIP_CHECK(hipStreamSynchronize(p->s_depth));
     DFVO_HIP_CHECK(hipStreamSynchronize(p->s_trk));
     return DFVO_OK;

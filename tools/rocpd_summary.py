@@ -23,6 +23,31 @@ def main():
         for name, st, en, q, gx in rows:
             print("%10.1f us  +%8.1f us  q=%-4s grid=%-7s %s" % ((st - t0) / 1e3, (en - st) / 1e3, q, gx, name[:60]))
         return
+    if "--flowgaps" in sys.argv:
+        # last flow-net pass: per-queue busy time vs span, and the idle gaps between consecutive kernels of the queue
+        cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+        qcol = "stream_id" if "stream_id" in cols else "queue_id"
+        rows = list(cur.execute("select name, start, end, %s from kernels order by start" % qcol))
+        ends = [i for i, r in enumerate(rows) if "k_flow_consistency" in r[0]]
+        starts = [i for i, r in enumerate(rows) if "k_img_u8_to_flow_input" in r[0]]
+        e = ends[-1]
+        st = max(i for i in starts[::2] if i < e)
+        q = rows[e][3]
+        ks = [r for r in rows[st:e + 1] if r[3] == q]
+        span = (ks[-1][2] - ks[0][1]) / 1e3
+        busy = sum(r[2] - r[1] for r in ks) / 1e3
+        gaps = [(ks[i + 1][1] - ks[i][2]) / 1e3 for i in range(len(ks) - 1)]
+        print("flow pass: %d kernels, span %.1f us, busy %.1f us, idle %.1f us (mean gap %.2f us, max %.1f us)" % (
+            len(ks), span, busy, span - busy, sum(gaps) / len(gaps), max(gaps)))
+        import collections
+        byname = collections.defaultdict(lambda: [0, 0.0])
+        for r in ks:
+            k = r[0].split("(")[0][-48:]
+            byname[k][0] += 1
+            byname[k][1] += (r[2] - r[1]) / 1e3
+        for k, v in sorted(byname.items(), key=lambda kv: -kv[1][1])[:14]:
+            print("  %-50s n=%3d %8.1f us" % (k, v[0], v[1]))
+        return
     if "--netspans" in sys.argv:
         # flow-net passes: first k_img_u8_to_flow_input -> k_flow_consistency; busy = sum of net kernel durations inside
         rows = list(cur.execute("select name, start, end from kernels order by start"))
