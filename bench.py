@@ -23,9 +23,10 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before torch / HIP initialise: see df-vo_amd/__init__.py
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")  # before torch / HIP initialise: see df-vo_amd/__init__.py
 
-SLOTS = 4  # DFVO_PIPELINE_SLOTS
+SLOTS = 4
+PREFETCH = os.environ.get("DFVO_BENCH_PREFETCH", "1") != "0"  # DFVO_PIPELINE_SLOTS
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: FP32 matrix (f32 in / f32 acc)
 CFG_NAMES = ["conv_igemm_f32<2,2,4,4> 128x128", "conv_igemm_f32<1,4,2,2> 32x128", "conv_igemm_f32<4,1,4,4> 256x64",
              "conv_igemm_f32<2,2,2,2> 64x64", "conv_igemm_f32<4,1,4,2> 256x32", "conv_igemm_f32<2,2,2,1> 64x32",
@@ -125,12 +126,17 @@ def main():
             return rel_all, status
         pipe.set_ref_depth(depth=d_ref_depth)  # depth of the first reference frame (PnP fallback input)
         ahead = 2  # the nets run two pairs ahead: the host blocks in track(k) while nets(k+1), nets(k+2) queue up
-        for j in range(min(ahead, n)):
+        def feed(j):  # nets of pair j, then the RNG-independent half of its solver stage right behind them
             pipe.enqueue_nets(j % SLOTS, d_ref, d_cur, d_feed)
+            if PREFETCH:
+                pipe.prefetch_track(j % SLOTS, d_sc[j % len(d_sc)][0], d_sc[j % len(d_sc)][1])
+
+        for j in range(min(ahead, n)):
+            feed(j)
         for k in range(n):
             t_a = time.perf_counter()
             if k + ahead < n:
-                pipe.enqueue_nets((k + ahead) % SLOTS, d_ref, d_cur, d_feed)
+                feed(k + ahead)
             t_b = time.perf_counter()
             f, dd, dp = d_sc[k % len(d_sc)]
             out = pipe.track(k % SLOTS, f, dd, dp)  # E-tracker, or the PnP fallback when its pose is rejected

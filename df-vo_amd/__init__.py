@@ -13,11 +13,11 @@ Sub-modules
 """
 import os
 
-# The fused pipeline keeps six HIP streams busy (two flow-net instances, depth net, solver chain and its two side
-# streams).  ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a queue
+# The fused pipeline keeps eight HIP streams busy (two flow-net instances, depth net, solver chain and its two side
+# streams, two prefetch streams).  ROCm maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4); streams that share a queue
 # serialise, which costs ~20 % of the pair rate.  Must be in the environment before the HIP runtime initialises, so
 # it is set (without overriding the user's choice) when the package is imported.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "lib", "libdfvo_hip.so")

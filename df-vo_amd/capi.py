@@ -136,6 +136,7 @@ SIGNATURES = {
     "dfvo_pipeline_enqueue_nets": (_i, [_vp, _i, _vp, _vp, _vp]),
     "dfvo_pipeline_track": (_i, [_vp, _i, _vp, _vp, _vp, C.POINTER(TrackOut)]),
     "dfvo_pipeline_set_ref_depth": (_i, [_vp, _vp, _vp]),
+    "dfvo_pipeline_prefetch_track": (_i, [_vp, _i, _vp, _vp]),
     "dfvo_pipeline_get_flow": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "dfvo_pipeline_sync": (_i, [_vp]),
     "dfvo_pipeline_net_flops": (_d, [_vp]),

@@ -25,7 +25,13 @@ struct dfvo_pipeline {
     hipStream_t s_flow_x[DFVO_PIPELINE_SLOTS - 1] = {};
     int flow_instances = 1;
     DepthNet depth;
-    TrackerBuffers tb;
+    TrackerBuffers tbs[DFVO_PIPELINE_SLOTS];  // [0] owns the numpy RandomState and the RNG-side streams, the others share them
+    // RNG-independent half of the solver stage (keypoint selection, homography chain) enqueued ahead of time
+    // (dfvo_pipeline_prefetch_track): two streams used alternately, per-slot completion event and pinned keypoint info
+    hipStream_t s_pre[2] = {nullptr, nullptr};
+    hipEvent_t e_pre[DFVO_PIPELINE_SLOTS] = {};
+    int* h_info[DFVO_PIPELINE_SLOTS] = {};
+    bool prefetched[DFVO_PIPELINE_SLOTS] = {};
     hipStream_t s_flow = nullptr, s_depth = nullptr, s_trk = nullptr;
     hipEvent_t e_flow[DFVO_PIPELINE_SLOTS] = {}, e_depth[DFVO_PIPELINE_SLOTS] = {};
     // per-slot outputs of the nets
@@ -91,8 +97,19 @@ int dfvo_pipeline_create(const dfvo_pipeline_cfg* cfg, dfvo_pipeline** out) {
     p->depth.min_depth = cfg->net_min_depth;
     p->depth.max_depth = cfg->net_max_depth;
     p->depth.baseline_mult = cfg->baseline_mult;
-    rc = p->tb.init();
+    rc = p->tbs[0].init();
     if (rc != DFVO_OK) return fail(rc);
+    for (int i = 1; i < DFVO_PIPELINE_SLOTS; i++) {
+        rc = p->tbs[i].init_shared(p->tbs[0]);
+        if (rc != DFVO_OK) return fail(rc);
+    }
+    for (int i = 0; i < 2; i++)
+        if (hipStreamCreateWithFlags(&p->s_pre[i], hipStreamNonBlocking) != hipSuccess) return fail(DFVO_ERR_HIP);
+    for (int i = 0; i < DFVO_PIPELINE_SLOTS; i++) {
+        if (hipEventCreateWithFlags(&p->e_pre[i], hipEventDisableTiming) != hipSuccess ||
+            hipHostMalloc((void**)&p->h_info[i], 4 * sizeof(int), hipHostMallocDefault) != hipSuccess)
+            return fail(DFVO_ERR_HIP);
+    }
     const size_t px = (size_t)p->H * p->W;
     for (int i = 0; i < DFVO_PIPELINE_SLOTS; i++) {
         if (hipMalloc((void**)&p->fwd[i], 2 * px * sizeof(float)) != hipSuccess ||
@@ -111,7 +128,7 @@ int dfvo_pipeline_create(const dfvo_pipeline_cfg* cfg, dfvo_pipeline** out) {
         dfvo::set_last_error("dfvo_pipeline_create: hipMalloc failed");
         return fail(DFVO_ERR_HIP);
     }
-    enqueue_mt_seed(p->tb, cfg->seed, p->s_trk);
+    enqueue_mt_seed(p->tbs[0], cfg->seed, p->s_trk);
     *out = p;
     return DFVO_OK;
 }
@@ -125,7 +142,13 @@ void dfvo_pipeline_destroy(dfvo_pipeline* p) {
         if (p->s_flow_x[i]) (void)hipStreamDestroy(p->s_flow_x[i]);
     }
     p->depth.destroy();
-    p->tb.release();
+    for (int i = DFVO_PIPELINE_SLOTS - 1; i >= 0; i--) p->tbs[i].release();
+    for (int i = 0; i < 2; i++)
+        if (p->s_pre[i]) (void)hipStreamDestroy(p->s_pre[i]);
+    for (int i = 0; i < DFVO_PIPELINE_SLOTS; i++) {
+        if (p->e_pre[i]) (void)hipEventDestroy(p->e_pre[i]);
+        if (p->h_info[i]) (void)hipHostFree(p->h_info[i]);
+    }
     for (int i = 0; i < DFVO_PIPELINE_SLOTS; i++) {
         void* ptrs[] = {p->fwd[i], p->bwd[i], p->diff[i], p->raw_depth[i], p->proc_depth[i]};
         for (void* q : ptrs)
@@ -183,7 +206,7 @@ int dfvo_pipeline_set_graph(dfvo_pipeline* p, int enable) {
 }
 int dfvo_pipeline_seed(dfvo_pipeline* p, uint32_t seed) {
     DFVO_ARG_CHECK(p, "null pipeline");
-    return enqueue_mt_seed(p->tb, seed, p->s_trk);
+    return enqueue_mt_seed(p->tbs[0], seed, p->s_trk);
 }
 
 int dfvo_pipeline_enqueue_nets(dfvo_pipeline* p, int slot, const uint8_t* d_ref, const uint8_t* d_cur,
@@ -241,11 +264,53 @@ static int roll_ref_depth(dfvo_pipeline* p, int slot, const double* d_depth_over
     return DFVO_OK;
 }
 
+static void fill_pose_cfg(const dfvo_pipeline_cfg& c, PoseConfig* pc) {
+    pc->fx = c.fx;
+    pc->cx = c.cx;
+    pc->cy = c.cy;
+    pc->reproj_thre = c.e_reproj_thre;
+    pc->repeat = c.e_repeat;
+    pc->max_iters = c.e_max_iters;
+    for (int i = 0; i < 9; i++) {
+        pc->KinvT[i] = c.KinvT[i];
+        pc->Kinv[i] = c.Kinv[i];
+    }
+}
+
+// RNG-independent half of the solver stage of `slot` (keypoint selection, homography RANSAC + refinement, GRIC-H):
+// waits on the device for the slot's flow outputs and runs on a stream of its own, so it executes as soon as those
+// nets are done -- typically while dfvo_pipeline_track of the previous pair is still blocking the host.  The numpy
+// RandomState is not touched here; all RNG consumers stay in dfvo_pipeline_track, in pair order.
+static int enqueue_pre_part(dfvo_pipeline* p, int slot, const float* d_flow_override, const float* d_diff_override,
+                            hipStream_t sp) {
+    const dfvo_pipeline_cfg& c = p->cfg;
+    TrackerBuffers& tb = p->tbs[slot];
+    DFVO_HIP_CHECK(hipStreamWaitEvent(sp, p->e_flow[slot], 0));
+    const float* flow = d_flow_override ? d_flow_override : p->fwd[slot];
+    const float* diff = d_diff_override ? d_diff_override : p->diff[slot];
+    P_TRY(enqueue_local_bestn(tb, flow, diff, p->H, p->W, c.kp_num_row, c.kp_num_col, c.kp_num_bestN, (float)c.kp_thre, sp));
+    DFVO_HIP_CHECK(hipMemcpyAsync(p->h_info[slot], tb.kp_info, 3 * sizeof(int), hipMemcpyDeviceToHost, sp));
+    DFVO_HIP_CHECK(hipEventRecord(p->e_pre[slot], sp));  // the host only needs the keypoint count; tb.ev_h orders the rest
+    PoseConfig pc;
+    fill_pose_cfg(c, &pc);
+    P_TRY(enqueue_pose_h_part(tb, tb.kp_cap, pc, sp));  // keypoint count read on the device; kp_cap bounds the launches
+    return DFVO_OK;
+}
+
+int dfvo_pipeline_prefetch_track(dfvo_pipeline* p, int slot, const float* d_flow_override, const float* d_diff_override) {
+    DFVO_ARG_CHECK(p && (slot >= 0 && slot < DFVO_PIPELINE_SLOTS), "dfvo_pipeline_prefetch_track: bad argument");
+    DFVO_ARG_CHECK(!p->prefetched[slot], "dfvo_pipeline_prefetch_track: slot already prefetched and not yet tracked");
+    P_TRY(enqueue_pre_part(p, slot, d_flow_override, d_diff_override, p->s_pre[slot & 1]));
+    p->prefetched[slot] = true;
+    return DFVO_OK;
+}
+
 int dfvo_pipeline_track(dfvo_pipeline* p, int slot, const float* d_flow_override, const float* d_diff_override,
                         const double* d_depth_override, dfvo_track_out* out) {
     DFVO_ARG_CHECK(p && out && (slot >= 0 && slot < DFVO_PIPELINE_SLOTS), "dfvo_pipeline_track: bad argument");
     const dfvo_pipeline_cfg& c = p->cfg;
     hipStream_t s = p->s_trk;
+    TrackerBuffers& tb = p->tbs[slot];
     static const bool trace = getenv("DFVO_TRACK_TRACE") != nullptr;  // host-side phase timing (tuning aid)
     static double tr_acc[4] = {0, 0, 0, 0};
     static int tr_n = 0;
@@ -255,14 +320,11 @@ int dfvo_pipeline_track(dfvo_pipeline* p, int slot, const float* d_flow_override
     };
     memset(out, 0, sizeof(*out));
     for (int i = 0; i < 3; i++) out->R[i * 4] = 1.0;
-    P_TRY(enqueue_scale_prepare(p->tb, p->H, p->W));  // side stream: the scale stage's fills leave the dependent chain
-    DFVO_HIP_CHECK(hipStreamWaitEvent(s, p->e_flow[slot], 0));
-    const float* flow = d_flow_override ? d_flow_override : p->fwd[slot];
-    const float* diff = d_diff_override ? d_diff_override : p->diff[slot];
-    P_TRY(enqueue_local_bestn(p->tb, flow, diff, p->H, p->W, c.kp_num_row, c.kp_num_col, c.kp_num_bestN, (float)c.kp_thre, s));
-    int info[3];
-    DFVO_HIP_CHECK(hipMemcpyAsync(info, p->tb.kp_info, sizeof(info), hipMemcpyDeviceToHost, s));
-    DFVO_HIP_CHECK(hipStreamSynchronize(s));
+    P_TRY(enqueue_scale_prepare(tb, p->H, p->W));  // side stream: the scale stage's fills leave the dependent chain
+    if (!p->prefetched[slot]) P_TRY(enqueue_pre_part(p, slot, d_flow_override, d_diff_override, p->s_pre[slot & 1]));
+    p->prefetched[slot] = false;
+    DFVO_HIP_CHECK(hipEventSynchronize(p->e_pre[slot]));  // keypoint info is in pinned host memory now
+    const int* info = p->h_info[slot];
     const double tr_kp = tr_ms(tr0);
     out->n_kp = info[0];
     out->good_kp_found = info[1];
@@ -274,17 +336,8 @@ int dfvo_pipeline_track(dfvo_pipeline* p, int slot, const float* d_flow_override
     }
     const int n = info[0];
     PoseConfig pc;
-    pc.fx = c.fx;
-    pc.cx = c.cx;
-    pc.cy = c.cy;
-    pc.reproj_thre = c.e_reproj_thre;
-    pc.repeat = c.e_repeat;
-    pc.max_iters = c.e_max_iters;
-    for (int i = 0; i < 9; i++) {
-        pc.KinvT[i] = c.KinvT[i];
-        pc.Kinv[i] = c.Kinv[i];
-    }
-    P_TRY(enqueue_compute_pose_2d2d(p->tb, n, pc, s, p->d_T21));
+    fill_pose_cfg(c, &pc);
+    P_TRY(enqueue_pose_e_part(tb, n, pc, s, p->d_T21));  // waits for tb.ev_h (the prefetched half) on the device
     DFVO_HIP_CHECK(hipStreamWaitEvent(s, p->e_depth[slot], 0));
     ScaleConfig sc;
     sc.cx = c.cx;
@@ -296,12 +349,12 @@ int dfvo_pipeline_track(dfvo_pipeline* p, int slot, const float* d_flow_override
     sc.stop_prob = c.scale_stop_prob;
     sc.thre = c.scale_thre;
     const double* depth = d_depth_override ? d_depth_override : p->proc_depth[slot];
-    P_TRY(enqueue_find_scale(p->tb, n, p->d_T21, depth, p->H, p->W, sc, s, p->tb.pose, true));
+    P_TRY(enqueue_find_scale(tb, n, p->d_T21, depth, p->H, p->W, sc, s, tb.pose, true));
     const double tr_enq = tr_ms(tr0);
     PoseState ps;
     ScaleResult sr;
-    DFVO_HIP_CHECK(hipMemcpyAsync(&ps, p->tb.pose, sizeof(ps), hipMemcpyDeviceToHost, s));
-    DFVO_HIP_CHECK(hipMemcpyAsync(&sr, p->tb.scale_out, sizeof(sr), hipMemcpyDeviceToHost, s));
+    DFVO_HIP_CHECK(hipMemcpyAsync(&ps, tb.pose, sizeof(ps), hipMemcpyDeviceToHost, s));
+    DFVO_HIP_CHECK(hipMemcpyAsync(&sr, tb.scale_out, sizeof(sr), hipMemcpyDeviceToHost, s));
     DFVO_HIP_CHECK(hipStreamSynchronize(s));
     for (int i = 0; i < 9; i++) out->R[i] = ps.R[i];
     for (int i = 0; i < 3; i++) out->t[i] = ps.t[i];
@@ -327,7 +380,7 @@ int dfvo_pipeline_track(dfvo_pipeline* p, int slot, const float* d_flow_override
             pc3.repeat = c.pnp_repeat;
             pc3.iters = c.pnp_iters;
             pc3.reproj_thre = c.pnp_reproj_thre;
-            P_TRY(enqueue_compute_pose_3d2d(p->pnp, p->tb.mt_state, p->tb.kp_ref, p->tb.kp_cur, p->tb.kp_info, n,
+            P_TRY(enqueue_compute_pose_3d2d(p->pnp, tb.mt_state, tb.kp_ref, tb.kp_cur, tb.kp_info, n,
                                             p->ref_depth, p->H, p->W, pc3, s));
             PnpResult pr;
             DFVO_HIP_CHECK(hipMemcpyAsync(&pr, p->pnp.result, sizeof(pr), hipMemcpyDeviceToHost, s));

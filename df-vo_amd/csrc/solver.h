@@ -45,7 +45,7 @@ int enqueue_find_essential_batch(RansacWorkspace* w, const double* const* d_pts1
                                  int n, double focal, double ppx, double ppy, double prob, double threshold,
                                  int max_iters, hipStream_t s);
 int enqueue_find_homography(RansacWorkspace& w, const double* d_pts1, const double* d_pts2, int n, double thr,
-                            int max_iters, double confidence, hipStream_t s);
+                            int max_iters, double confidence, hipStream_t s, const int* d_n = nullptr);
 struct PoseState;
 // optional tail of recoverPose in the fused pipeline (null pointers: plain recoverPose)
 struct PoseFinish {

@@ -1039,6 +1039,26 @@ int TrackerBuffers::init() {
     }
     DFVO_HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
     DFVO_HIP_CHECK(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
+    DFVO_HIP_CHECK(hipEventCreateWithFlags(&ev_h, hipEventDisableTiming));
+    return DFVO_OK;
+}
+
+int TrackerBuffers::init_shared(const TrackerBuffers& first) {
+    shared = true;
+    mt_state = first.mt_state;
+    for (int r = 0; r < MAX_REP; r++) {
+        s_rep[r] = first.s_rep[r];
+        ev_rep[r] = first.ev_rep[r];
+    }
+    ev_fork = first.ev_fork;
+    DFVO_HIP_CHECK(hipMalloc((void**)&kp_info, sizeof(int) * 8));
+    DFVO_HIP_CHECK(hipMalloc((void**)&kp_total, sizeof(int) * 8));
+    DFVO_HIP_CHECK(hipMalloc((void**)&pose, sizeof(PoseState)));
+    DFVO_HIP_CHECK(hipMalloc((void**)&small, sizeof(double) * 128));
+    DFVO_HIP_CHECK(hipMalloc((void**)&scale_out, sizeof(ScaleResult)));
+    DFVO_HIP_CHECK(hipMemset(kp_info, 0, sizeof(int) * 8));
+    DFVO_HIP_CHECK(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
+    DFVO_HIP_CHECK(hipEventCreateWithFlags(&ev_h, hipEventDisableTiming));
     return DFVO_OK;
 }
 
@@ -1048,14 +1068,18 @@ void TrackerBuffers::release() {
     ws_e.release();
     for (int r = 0; r < MAX_REP; r++) {
         ws_rep[r].release();
-        if (s_rep[r]) (void)hipStreamDestroy(s_rep[r]);
-        if (ev_rep[r]) (void)hipEventDestroy(ev_rep[r]);
+        if (!shared) {
+            if (s_rep[r]) (void)hipStreamDestroy(s_rep[r]);
+            if (ev_rep[r]) (void)hipEventDestroy(ev_rep[r]);
+        }
         s_rep[r] = nullptr;
         ev_rep[r] = nullptr;
     }
-    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_fork && !shared) (void)hipEventDestroy(ev_fork);
     if (ev_start) (void)hipEventDestroy(ev_start);
-    ev_fork = ev_start = nullptr;
+    if (ev_h) (void)hipEventDestroy(ev_h);
+    ev_fork = ev_start = ev_h = nullptr;
+    if (shared) mt_state = nullptr;
     void* ptrs[] = {mt_state, kp_info, kp_total, pose, small, scale_out, winner, lidx};
     lidx = nullptr;
     lidx_cap = 0;
@@ -1098,41 +1122,50 @@ int enqueue_mt_shuffle(uint32_t* mt_state, const int* d_n, int n_host, int repea
 // EssTracker.compute_pose_2d2d with validity.method == "GRIC" on tb.kp_ref / tb.kp_cur (n = kp_info[0] on the
 // device, n_host = upper bound known to the host for launch sizing).
 // small[] layout: [0..8] KinvT, [9..17] Kinv, [18] H_gric, [19] E_gric
-int enqueue_compute_pose_2d2d(TrackerBuffers& tb, int n_host, const PoseConfig& cfg, hipStream_t s, double* d_T21) {
-    DFVO_ARG_CHECK(n_host >= 0 && n_host <= tb.kp_cap, "compute_pose_2d2d: keypoint capacity");
-    DFVO_ARG_CHECK(cfg.repeat >= 1 && cfg.repeat <= 8, "compute_pose_2d2d: repeat out of range");
-    const int nb = cdiv(n_host > 0 ? n_host : 1, 256);
+// RNG-independent half of compute_pose_2d2d: state reset, findHomography + refinement, GRIC-H.  Everything reads the
+// keypoint count from the device (tb.kp_info[0]; n_bound only sizes the launches), so it can be enqueued before the
+// host knows that count -- the fused pipeline runs it right behind the nets of a pair, while the solver stage of the
+// previous pair is still busy.  Records tb.ev_start (keypoints ready) and tb.ev_h (this half done) on sh.
+int enqueue_pose_h_part(TrackerBuffers& tb, int n_bound, const PoseConfig& cfg, hipStream_t sh) {
+    DFVO_ARG_CHECK(n_bound >= 0 && n_bound <= tb.kp_cap, "compute_pose_2d2d: keypoint capacity");
     double hk[18];
     for (int i = 0; i < 9; i++) {
         hk[i] = cfg.KinvT[i];
         hk[9 + i] = cfg.Kinv[i];
     }
-    DFVO_HIP_CHECK(hipMemcpyAsync(tb.small, hk, sizeof(hk), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_pose_state_init, dim3(cdiv(tb.kp_cap, 256)), dim3(256), 0, s, tb.pose, tb.kp_info,
+    DFVO_HIP_CHECK(hipMemcpyAsync(tb.small, hk, sizeof(hk), hipMemcpyHostToDevice, sh));
+    hipLaunchKernelGGL(k_pose_state_init, dim3(cdiv(tb.kp_cap, 256)), dim3(256), 0, sh, tb.pose, tb.kp_info,
                        tb.best_inliers, tb.kp_cap);
+    DFVO_HIP_CHECK(hipEventRecord(tb.ev_start, sh));
+    // ---- homography + GRIC-H (kp_cur -> kp_ref); with 10 or fewer keypoints the result is never consumed
+    // (E_tracker.py:196) and with fewer than 5 the chain marks itself "no model"
+    int rc = enqueue_find_homography(tb.ws_h, tb.kp_cur, tb.kp_ref, n_bound, 1.0, 2000, 0.99, sh, tb.kp_info);
+    if (rc != DFVO_OK) return rc;
+    {
+        GricFusedBatch GH;
+        for (int r = 0; r < MAX_E_BATCH; ++r) GH.M[r] = tb.ws_h.out;
+        hipLaunchKernelGGL(k_gric_fused, dim3(1), dim3(256), 0, sh, GH, 1, tb.small, tb.small + 9, tb.kp_info, tb.kp_cur,
+                           tb.kp_ref, 0, 0.8, 8, 2, tb.small + 18);
+    }
+    DFVO_HIP_CHECK(hipEventRecord(tb.ev_h, sh));
+    DFVO_HIP_CHECK(hipGetLastError());
+    return DFVO_OK;
+}
+
+// RNG-consuming half: `repeat` x (shuffle, findEssentialMat, GRIC-E) as one batch on tb.s_rep[0] (after tb.ev_start),
+// then on s (after tb.ev_h): validity bookkeeping, recoverPose, pose / T21.  n_host = the keypoint count.
+int enqueue_pose_e_part(TrackerBuffers& tb, int n_host, const PoseConfig& cfg, hipStream_t s, double* d_T21) {
+    DFVO_ARG_CHECK(n_host >= 0 && n_host <= tb.kp_cap, "compute_pose_2d2d: keypoint capacity");
+    DFVO_ARG_CHECK(cfg.repeat >= 1 && cfg.repeat <= MAX_REP, "compute_pose_2d2d: repeat out of range");
+    DFVO_HIP_CHECK(hipStreamWaitEvent(s, tb.ev_h, 0));
     // only when more than 10 keypoints (E_tracker.py:196)
     if (n_host > 10) {
-        DFVO_ARG_CHECK(cfg.repeat <= MAX_REP, "compute_pose_2d2d: repeat > MAX_REP");
+        const int nb = cdiv(n_host, 256);
         const int cap = tb.kp_cap;
-        // all shuffles first (one sequential RNG chain), then the `repeat` RANSACs run concurrently on
-        // their own streams while the homography runs on `s`
-        // the shuffle chain runs on s_rep[0] so that the homography (on s) starts at once
-        DFVO_HIP_CHECK(hipEventRecord(tb.ev_start, s));
-        DFVO_HIP_CHECK(hipStreamWaitEvent(tb.s_rep[0], tb.ev_start, 0));
-        // the homography chain is the longer one: it is enqueued FIRST so that the host's launch calls for the
-        // five-point batch do not delay it
-        // ---- homography + GRIC-H (kp_cur -> kp_ref)
-        int rc = enqueue_find_homography(tb.ws_h, tb.kp_cur, tb.kp_ref, n_host, 1.0, 2000, 0.99, s);
-        if (rc != DFVO_OK) return rc;
-        {
-            GricFusedBatch GH;
-            for (int r = 0; r < MAX_E_BATCH; ++r) GH.M[r] = tb.ws_h.out;
-            hipLaunchKernelGGL(k_gric_fused, dim3(1), dim3(256), 0, s, GH, 1, tb.small, tb.small + 9, tb.kp_info, tb.kp_cur,
-                               tb.kp_ref, 0, 0.8, 8, 2, tb.small + 18);
-        }
         hipStream_t sr = tb.s_rep[0];
         const unsigned R = (unsigned)cfg.repeat;
-        rc = enqueue_mt_shuffle(tb.mt_state, tb.kp_info, n_host, cfg.repeat, cap + 8, tb.perm, sr);
+        DFVO_HIP_CHECK(hipStreamWaitEvent(sr, tb.ev_start, 0));
+        int rc = enqueue_mt_shuffle(tb.mt_state, tb.kp_info, n_host, cfg.repeat, cap + 8, tb.perm, sr);
         if (rc != DFVO_OK) return rc;
         hipLaunchKernelGGL(k_permute_points, dim3(nb, R), dim3(256), 0, sr, tb.kp_info, tb.perm, cap + 8, tb.kp_cur,
                            tb.kp_ref, tb.pa, tb.pb, 2 * cap);
@@ -1143,7 +1176,7 @@ int enqueue_compute_pose_2d2d(TrackerBuffers& tb, int n_host, const PoseConfig& 
             pbs[rep] = tb.pb + (size_t)rep * 2 * cap;
         }
         rc = enqueue_find_essential_batch(tb.ws_rep, pas, pbs, cfg.repeat, n_host, cfg.fx, cfg.cx, cfg.cy, 0.99,
-                                              cfg.reproj_thre, cfg.max_iters, sr);
+                                          cfg.reproj_thre, cfg.max_iters, sr);
         if (rc != DFVO_OK) return rc;
         {
             GricFusedBatch GE;
@@ -1174,6 +1207,15 @@ int enqueue_compute_pose_2d2d(TrackerBuffers& tb, int n_host, const PoseConfig& 
     }
     DFVO_HIP_CHECK(hipGetLastError());
     return DFVO_OK;
+}
+
+// EssTracker.compute_pose_2d2d with validity.method == "GRIC" on tb.kp_ref / tb.kp_cur (n = kp_info[0] on the
+// device, n_host = the same count known to the host).  small[] layout: [0..8] KinvT, [9..17] Kinv, [18] H_gric,
+// [19..] E_gric per repeat
+int enqueue_compute_pose_2d2d(TrackerBuffers& tb, int n_host, const PoseConfig& cfg, hipStream_t s, double* d_T21) {
+    int rc = enqueue_pose_h_part(tb, n_host, cfg, s);
+    if (rc != DFVO_OK) return rc;
+    return enqueue_pose_e_part(tb, n_host, cfg, s, d_T21);
 }
 
 // find_scale_from_depth on tb.kp_ref (kp1) / tb.kp_cur (kp2); d_T21: 16 doubles; d_depth: H x W doubles

@@ -45,9 +45,10 @@ __global__ void k_ransac_init(RansacState* st, int max_iters, uint64_t seed) {
 }
 
 __global__ void k_replay(RansacState* st, const int* __restrict__ nmodels, const int* __restrict__ counts,
-                         int max_models, int it0, int it1, int count, int model_points, double confidence) {
+                         int max_models, int it0, int it1, int count, const int* __restrict__ d_n, int model_points,
+                         double confidence) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    ransac_replay(st, nmodels, counts, max_models, it0, it1, count, model_points, confidence);
+    ransac_replay(st, nmodels, counts, max_models, it0, it1, d_n ? *d_n : count, model_points, confidence);
 }
 
 // ================================================================================================
@@ -361,9 +362,13 @@ __global__ void k_to_float(const double* __restrict__ a, int n, float* __restric
 }
 
 // findHomography prologue in one launch: RANSAC state reset + both point sets converted to float (blockIdx.y)
+// d_n (optional): the point count lives on the device (fused pipeline, chain enqueued before the host knows it);
+// then n_arg is only the launch bound.  Fewer than 5 points: no model (state done, found = 0).
 __global__ void k_h_init_to_float(RansacState* st, int max_iters, const double* __restrict__ a, const double* __restrict__ b,
-                                  int n2, float* __restrict__ fa, float* __restrict__ fb) {
+                                  int n_arg, const int* __restrict__ d_n, float* __restrict__ fa, float* __restrict__ fb) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = d_n ? *d_n : n_arg;
+    const int n2 = 2 * n;
     if (i == 0 && blockIdx.y == 0) {
         st->rng_state = 0xffffffffffffffffULL;
         st->niters = max_iters > 1 ? max_iters : 1;
@@ -371,7 +376,7 @@ __global__ void k_h_init_to_float(RansacState* st, int max_iters, const double* 
         st->max_good = 0;
         st->best_iter = -1;
         st->best_model = -1;
-        st->done = 0;
+        st->done = n < 5 ? 1 : 0;
         st->subset_fail_at = -1;
         st->found = 0;
     }
@@ -384,9 +389,10 @@ __global__ void k_h_init_to_float(RansacState* st, int max_iters, const double* 
 
 // one lane: subsets with HomographyEstimatorCallback::checkSubset, up to 10000 attempts each
 __global__ void k_h_subsets(RansacState* st, int* __restrict__ idx, const float* __restrict__ src,
-                            const float* __restrict__ dst, int count, int it0, int it1) {
+                            const float* __restrict__ dst, int count_arg, const int* __restrict__ d_n, int it0, int it1) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (st->done || st->subset_fail_at >= 0) return;
+    const int count = d_n ? *d_n : count_arg;
     sm::CvRng rng;
     rng.state = st->rng_state;
     for (int it = it0; it < it1; ++it) {
@@ -641,12 +647,13 @@ __global__ __launch_bounds__(64) void k_h_solve(const RansacState* st, const int
 
 __global__ __launch_bounds__(256) void k_h_score(const RansacState* st, int it0, int it1,
                                                   const double* __restrict__ models, const int* __restrict__ nmodels,
-                                                  const float* __restrict__ src, const float* __restrict__ dst, int n,
-                                                  float thr2, int* __restrict__ counts) {
+                                                  const float* __restrict__ src, const float* __restrict__ dst, int n_arg,
+                                                  const int* __restrict__ d_n, float thr2, int* __restrict__ counts) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int it = it0 + blockIdx.x * 4 + wave;
     if (st->done || it >= it1) return;
     if (nmodels[it] <= 0) return;
+    const int n = d_n ? *d_n : n_arg;
     float Hf[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) Hf[k] = (float)models[(size_t)it * 9 + k];
@@ -836,7 +843,7 @@ __device__ double seq_dot8(const double* a, const double* b) {
 }
 
 __global__ __launch_bounds__(256) void k_h_refine(const RansacState* st, const float* __restrict__ src,
-                                                   const float* __restrict__ dst, int n,
+                                                   const float* __restrict__ dst, int n_arg, const int* __restrict__ d_n,
                                                    uint8_t* __restrict__ mask, int* __restrict__ cidx,
                                                    double* __restrict__ lm, double* __restrict__ H_io, int pts_cap,
                                                    const double* __restrict__ models, float thr2) {
@@ -848,6 +855,7 @@ __global__ __launch_bounds__(256) void k_h_refine(const RansacState* st, const f
     __shared__ int s_flag;
     (void)lm;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n = d_n ? *d_n : n_arg;
     if (!st->found) {  // no model: all-zero mask (what k_h_mask writes in the stand-alone path)
         for (int i = t; i < n; i += 256) mask[i] = 0;
         return;
@@ -1160,33 +1168,35 @@ __global__ __launch_bounds__(256) void k_h_refine(const RansacState* st, const f
     if (t == 8) H_io[8] = s_h[8];
 }
 
+// d_n (optional): device-resident point count (n is then the upper bound used for launch sizes)
 int enqueue_find_homography(RansacWorkspace& w, const double* d_pts1, const double* d_pts2, int n, double thr,
-                            int max_iters, double confidence, hipStream_t s) {
+                            int max_iters, double confidence, hipStream_t s, const int* d_n) {
     DFVO_ARG_CHECK(n >= 0 && max_iters >= 1, "find_homography: bad sizes");
     int rc = w.ensure(n > 8 ? n : 8, max_iters);
     if (rc != DFVO_OK) return rc;
     if (thr <= 0) thr = 3;
     const float thr2 = (float)(thr * thr);
-    if (n < 5) {  // n < 4: no model; n == 4 is not reachable from DF-VO (kp count > 10 is checked upstream)
+    if (n < 5 && !d_n) {  // n < 4: no model; n == 4 is not reachable from DF-VO (kp count > 10 is checked upstream)
         hipLaunchKernelGGL(k_ransac_init, dim3(1), dim3(1), 0, s, w.state, max_iters, (uint64_t)-1);
         hipLaunchKernelGGL(k_h_mask, dim3(cdiv(n > 9 ? n : 9, 256)), dim3(256), 0, s, w.state, w.models, w.f_a, w.f_b, n,
                            thr2, w.mask, w.out);
         DFVO_HIP_CHECK(hipGetLastError());
         return DFVO_OK;
     }
-    hipLaunchKernelGGL(k_h_init_to_float, dim3(cdiv(2 * n, 256), 2), dim3(256), 0, s, w.state, max_iters, d_pts1, d_pts2,
-                       2 * n, w.f_a, w.f_b);
+    hipLaunchKernelGGL(k_h_init_to_float, dim3(cdiv(2 * (n > 0 ? n : 1), 256), 2), dim3(256), 0, s, w.state, max_iters, d_pts1,
+                       d_pts2, n, d_n, w.f_a, w.f_b);
     int cb[4];
     chunk_bounds(max_iters, cb);
     for (int c = 0; c < 3; ++c) {
         const int it0 = cb[c], it1 = cb[c + 1];
         if (it1 <= it0) continue;
         const int nh = it1 - it0;
-        hipLaunchKernelGGL(k_h_subsets, dim3(1), dim3(1), 0, s, w.state, w.idx, w.f_a, w.f_b, n, it0, it1);
+        hipLaunchKernelGGL(k_h_subsets, dim3(1), dim3(1), 0, s, w.state, w.idx, w.f_a, w.f_b, n, d_n, it0, it1);
         hipLaunchKernelGGL(k_h_solve, dim3(nh), dim3(64), 0, s, w.state, w.idx, w.f_a, w.f_b, it0, it1, w.models, w.nmodels);
         hipLaunchKernelGGL(k_h_score, dim3(cdiv(nh, 4)), dim3(256), 0, s, w.state, it0, it1, w.models, w.nmodels, w.f_a,
-                           w.f_b, n, thr2, w.counts);
-        hipLaunchKernelGGL(k_replay, dim3(1), dim3(1), 0, s, w.state, w.nmodels, w.counts, 1, it0, it1, n, 4, confidence);
+                           w.f_b, n, d_n, thr2, w.counts);
+        hipLaunchKernelGGL(k_replay, dim3(1), dim3(1), 0, s, w.state, w.nmodels, w.counts, 1, it0, it1, n, d_n, 4,
+                           confidence);
     }
     // every inlier's coordinates stay in LDS across the LM passes when they fit (16 B / point)
     const int pts_cap = n <= 6144 ? n : 0;
@@ -1196,8 +1206,8 @@ int enqueue_find_homography(RansacWorkspace& w, const double* d_pts1, const doub
         configured = 6144 * 16;
     }
     // inlier mask of the winner + refit + LM in one launch
-    hipLaunchKernelGGL(k_h_refine, dim3(1), dim3(256), (size_t)pts_cap * 16, s, w.state, w.f_a, w.f_b, n, w.mask, w.cidx, w.lm,
-                       w.out, pts_cap, w.models, thr2);
+    hipLaunchKernelGGL(k_h_refine, dim3(1), dim3(256), (size_t)pts_cap * 16, s, w.state, w.f_a, w.f_b, n, d_n, w.mask, w.cidx,
+                       w.lm, w.out, pts_cap, w.models, thr2);
     DFVO_HIP_CHECK(hipGetLastError());
     return DFVO_OK;
 }

@@ -96,7 +96,8 @@ struct TrackerBuffers {
     RansacWorkspace ws_rep[MAX_REP];     // one workspace per repeated findEssentialMat (run concurrently)
     hipStream_t s_rep[MAX_REP] = {};
     hipEvent_t ev_rep[MAX_REP] = {};
-    hipEvent_t ev_fork = nullptr, ev_start = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_start = nullptr, ev_h = nullptr;
+    bool shared = false;  // streams / events / RandomState borrowed from another TrackerBuffers (see share_from)
     uint32_t* mt_state = nullptr;  // numpy RandomState: key[624], pos
     int* kp_info = nullptr;        // [n, good_kp_found, regions]
     int* kp_total = nullptr;
@@ -114,6 +115,9 @@ struct TrackerBuffers {
     uint8_t *best_inliers = nullptr, *inl_a = nullptr, *inl_b = nullptr;
     int kp_cap = 0, sel_cap = 0;
     int init();
+    // second and further buffer sets of the fused pipeline: own keypoint / RANSAC workspaces, but the numpy
+    // RandomState and the (serialised anyway) RNG-side streams and events of `first`
+    int init_shared(const TrackerBuffers& first);
     int ensure_kp(int cap, int cells, int n_best);
     void release_kp();
     void release();
@@ -125,6 +129,8 @@ int enqueue_mt_seed(TrackerBuffers& tb, uint32_t seed, hipStream_t s);
 // d_T21 (optional): 16 doubles that receive the inverse of the accepted pose (input of the scale stage)
 int enqueue_compute_pose_2d2d(TrackerBuffers& tb, int n_host, const PoseConfig& cfg, hipStream_t s,
                               double* d_T21 = nullptr);
+int enqueue_pose_h_part(TrackerBuffers& tb, int n_bound, const PoseConfig& cfg, hipStream_t sh);
+int enqueue_pose_e_part(TrackerBuffers& tb, int n_host, const PoseConfig& cfg, hipStream_t s, double* d_T21);
 int enqueue_mt_shuffle(uint32_t* mt_state, const int* d_n, int n_host, int repeat, int perm_stride, int* perm,
                        hipStream_t s);
 int enqueue_compute_pose_3d2d(PnpBuffers& pb, uint32_t* mt_state, const double* d_kp1, const double* d_kp2,

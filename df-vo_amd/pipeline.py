@@ -83,6 +83,12 @@ class TrackingPipeline:
         p = lambda t: C.c_void_p(t.data_ptr())
         capi.check(self.lib.dfvo_pipeline_enqueue_nets(self.h, slot, p(d_ref), p(d_cur), p(d_feed)))
 
+    def prefetch_track(self, slot, flow=None, diff=None):
+        """enqueue keypoint selection + the homography chain of `slot` now (call right after enqueue_nets(slot));
+        track(slot) then only runs the RandomState consumers"""
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        capi.check(self.lib.dfvo_pipeline_prefetch_track(self.h, slot, p(flow), p(diff)))
+
     def track(self, slot, flow=None, diff=None, depth=None):
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         out = capi.TrackOut()

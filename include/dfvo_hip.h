@@ -294,6 +294,12 @@ int dfvo_pipeline_enqueue_nets(dfvo_pipeline* p, int slot, const uint8_t* d_ref,
  * frame never is): exactly one of d_feed (uint8 [feed_h,feed_w,3], runs the depth net) or d_depth_override (processed
  * depth, double [H,W]).  Later reference depths roll over from the current frame of each tracked pair. */
 int dfvo_pipeline_set_ref_depth(dfvo_pipeline* p, const uint8_t* d_feed, const double* d_depth_override);
+/* Optional: enqueue the RNG-independent half of the solver stage of `slot` (keypoint selection, homography RANSAC +
+ * refinement, GRIC-H) right after dfvo_pipeline_enqueue_nets(slot, ...).  It waits for the slot's flow outputs on the
+ * device and runs on its own stream, i.e. under the nets / solver stage of earlier pairs; dfvo_pipeline_track(slot)
+ * then only adds the numpy-RandomState consumers (shuffles, five-point RANSAC, scale, PnP), in pair order.  The
+ * overrides, when given, must be the ones later passed to dfvo_pipeline_track.  Returns at once. */
+int dfvo_pipeline_prefetch_track(dfvo_pipeline* p, int slot, const float* d_flow_override, const float* d_diff_override);
 /* keypoint selection + E-tracker + scale recovery (+ the PnP fallback when the E-tracker result is rejected) on the
  * outputs in `slot` (waits for its nets).  Optional device overrides replace the forward flow [2,H,W] / consistency
  * map [H,W] / processed depth [H,W] double that feed the solver stage (used by bench.py). Synchronous. */

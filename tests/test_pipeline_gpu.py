@@ -37,6 +37,8 @@ def test_pipeline_tracker_matches_oracle_chain(gpu, pipe_mod, h, w):
     ref_depth = sc["depth_ref"]
     for frame in range(3):  # the RandomState carries over from pair to pair, as in a sequence
         pipe.enqueue_nets(frame % 2, dref, dcur, dfeed)
+        if frame == 1:  # one pair through the prefetch path (keypoints + homography chain enqueued ahead of track)
+            pipe.prefetch_track(frame % 2, dflow, ddiff)
         out = pipe.track(frame % 2, dflow, ddiff, ddepth)
         kp = T.local_bestN(sc["flow"], sc["diff"][..., None])
         assert out.good_kp_found == int(kp["good_kp_found"]) and out.n_kp == kp["kp1_best"].shape[1]

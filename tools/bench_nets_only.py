@@ -4,7 +4,7 @@ import os
 import sys
 import time
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
