@@ -33,8 +33,8 @@ CFG_NAMES = ["conv_igemm_f32<2,2,4,4> 128x128", "conv_igemm_f32<1,4,2,2> 32x128"
              "conv_igemm_f32<4,1,4,1> 256x16", "conv_igemm_f32<4,1,1,1> 64x16", "conv_igemm_f32<1,4,4,2> 64x128",
              "conv_igemm_f32<2,2,4,2> 128x64", "conv_igemm_f32<4,1,2,2> 128x32", "conv_igemm_f32<4,1,2,1> 128x16",
              "conv_win3_f32<2,2,4,4> (8x16)x128", "conv_win3_f32<2,2,4,2> (8x16)x64", "conv_win3_f32<4,1,2,2> (8x16)x32",
-             "conv_win3_f32<1,4,4,2> (4x16)x128", "conv_win_f32<4,1,2,1,7> 7x7 (8x16)x16",
-             "conv_win_f32<4,1,2,1,5> 5x5 (8x16)x16"]
+             "conv_win3_f32<1,4,4,2> (4x16)x128", "conv_head_f32<7> 7x7 heads (direct)",
+             "conv_head_f32<5> 5x5 heads (direct)", "conv_head_f32<3> 3x3 heads (direct)"]
 
 
 def cpu_baseline(syn, H, W, scenes, n_pairs=2):
@@ -184,9 +184,9 @@ def main():
         for _ in range(nprof):
             pipe.enqueue_nets(0, d_ref, d_cur, d_feed)
             pipe.sync()
-        ms = np.zeros(18)
-        fl = np.zeros(18)
-        ln = np.zeros(18, np.int32)
+        ms = np.zeros(19)
+        fl = np.zeros(19)
+        ln = np.zeros(19, np.int32)
         capi.check(lib.dfvo_conv_profile_end(capi.as_ptr(ms), capi.as_ptr(fl), capi.as_ptr(ln)))
         pipe.set_graph(1)
         dom = int(np.argmax(ms))

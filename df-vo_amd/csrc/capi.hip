@@ -83,6 +83,14 @@ int dfvo_conv2d(const dfvo_conv_desc* d, const float* d_src0, const float* d_src
     DFVO_HIP_CHECK(hipMemcpy(db, pb.data(), pb.size() * sizeof(float), hipMemcpyHostToDevice));
     ConvLayer L;
     L.wp = dw;
+    {
+        const int hrc = make_head_weights(h_w, d->cout, d->c0, d->c1, d->kh, d->kw, nullptr, &L.wh);
+        if (hrc != DFVO_OK) {
+            (void)hipFree(dw);
+            (void)hipFree(db);
+            return hrc;
+        }
+    }
     L.bias = db;
     L.cout = d->cout;
     L.cout_pad = cout_pad;
@@ -102,6 +110,7 @@ int dfvo_conv2d(const dfvo_conv_desc* d, const float* d_src0, const float* d_src
     hipError_t e = hipStreamSynchronize(s);
     (void)hipFree(dw);
     (void)hipFree(db);
+    if (L.wh) (void)hipFree(L.wh);
     if (rc != DFVO_OK) return rc;
     DFVO_HIP_CHECK(e);
     return DFVO_OK;
@@ -111,9 +120,9 @@ int dfvo_conv_profile_begin(void) {
     conv_profile_begin();
     return DFVO_OK;
 }
-int dfvo_conv_profile_end(double* h_ms18, double* h_flops18, int* h_launches18) {
-    DFVO_ARG_CHECK(h_ms18 && h_flops18 && h_launches18, "dfvo_conv_profile_end: null argument");
-    return conv_profile_end(h_ms18, h_flops18, h_launches18);
+int dfvo_conv_profile_end(double* h_ms19, double* h_flops19, int* h_launches19) {
+    DFVO_ARG_CHECK(h_ms19 && h_flops19 && h_launches19, "dfvo_conv_profile_end: null argument");
+    return conv_profile_end(h_ms19, h_flops19, h_launches19);
 }
 
 int dfvo_correlation(const float* d_first, const float* d_second, int N, int H, int W, int C, int stride,

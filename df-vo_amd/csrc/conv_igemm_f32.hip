@@ -544,6 +544,189 @@ void conv_pack_weights(const float* w, const float* bias, int cout, int c0, int 
     }
 }
 
+size_t conv_head_weight_floats(int cout, int c0, int c1, int k) {
+    return (size_t)(cdiv(c0, 8) + cdiv(c1, 8)) * k * 2 * k * cout * 4;
+}
+void conv_pack_head_weights(const float* w, int cout, int c0, int c1, int k, const float* fold_scale, float* out) {
+    const int nchunk0 = cdiv(c0, 8), nchunks = nchunk0 + cdiv(c1, 8), cin = c0 + c1;
+    std::fill(out, out + conv_head_weight_floats(cout, c0, c1, k), 0.f);
+    for (int c = 0; c < nchunks; ++c)
+        for (int kx = 0; kx < k; ++kx)
+            for (int cg = 0; cg < 2; ++cg)
+                for (int ky = 0; ky < k; ++ky)
+                    for (int o = 0; o < cout; ++o)
+                        for (int q = 0; q < 4; ++q) {
+                            const int cl = (c < nchunk0 ? c : c - nchunk0) * 8 + cg * 4 + q;  // channel inside its source
+                            if (cl >= (c < nchunk0 ? c0 : c1)) continue;
+                            const int ci = c < nchunk0 ? cl : c0 + cl;
+                            float v = w[(((size_t)o * cin + ci) * k + ky) * k + kx];
+                            if (fold_scale) v *= fold_scale[o];
+                            out[(((((size_t)c * k + kx) * 2 + cg) * k + ky) * cout + o) * 4 + q] = v;
+                        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Direct (VALU) convolution for the 1- and 2-channel heads: LiteFlowNet's flow outputs (7x7 / 5x5 / 3x3, 32 -> 2) and
+// monodepth2's disparity outputs (3x3, C -> 1).  On the MFMA kernels these layers pad cout to a 16-wide tile and
+// throw 7/8 (15/16) of the matrix work away (8.5 TFLOP/s "useful" on the 7x7 head).  Here a thread owns PY = 2
+// vertically adjacent output pixels of one column: for every (kx, channel group) it reads the PY + KS - 1 window
+// rows once from LDS and feeds all KS vertical taps of both pixels from registers (14 FMA quads per 8 LDS reads at
+// 7x7), with the weights arriving through the scalar cache (the address is wave-uniform), so neither LDS nor VGPR
+// bandwidth is spent on them.  Window: 8-channel chunks, pixel stride 12 floats (16 consecutive lanes of a
+// ds_read_b128 hit 16 distinct 4-bank groups).
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(4))) const f32x4 cf32x4;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int KS, int CO>
+__global__ __launch_bounds__(256) void conv_head_f32_kernel(const ConvParams p) {
+    constexpr int PY = 2, TW = 16, TH = 16 * PY, WH = TH + KS - 1, WW = TW + KS - 1, PS = 12;
+    constexpr int WIN = WH * WW * PS;
+    constexpr int W_ITEMS = WH * WW * 2;  // (pixel, half of the 8-channel chunk)
+    constexpr int W_CNT = (W_ITEMS + 255) / 256;
+    constexpr int NR = PY + KS - 1;
+    __shared__ __attribute__((aligned(16))) float win[WIN];
+    const int t = threadIdx.x, tx = t & 15, ty = t >> 4;
+    const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
+    const int nb = gridDim.x;
+    int bid = blockIdx.x;
+    {  // XCD-aware order, as in the window kernel
+        const int q = nb >> 3, r = nb & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int n = bid / (tiles_y * tiles_x);
+    const int trem = bid - n * (tiles_y * tiles_x);
+    const int ty0 = (trem / tiles_x) * TH, tx0 = (trem % tiles_x) * TW;
+    const int nchunk0 = (p.G0 + 1) >> 1, nchunk1 = (p.G1 + 1) >> 1, nchunks = nchunk0 + nchunk1;
+
+    int w_off0[W_CNT], w_off1[W_CNT], w_lds[W_CNT];
+    bool w_ok[W_CNT];
+#pragma unroll
+    for (int r = 0; r < W_CNT; ++r) {
+        const int id = t + 256 * r;
+        const int px = id >> 1, q = id & 1;
+        const int wy = px / WW, wx = px - wy * WW;
+        int iy = ty0 - p.pad_h + wy, ix = tx0 - p.pad_w + wx;
+        bool v = id < W_ITEMS;
+        if (p.pad_mode == PAD_REFLECT) {
+            iy = reflect_idx(iy, p.H);
+            ix = reflect_idx(ix, p.W);
+        }
+        v = v && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        iy = iy < 0 ? 0 : (iy >= p.H ? p.H - 1 : iy);
+        ix = ix < 0 ? 0 : (ix >= p.W ? p.W - 1 : ix);
+        const int sh = p.up0;
+        w_off0[r] = (((n * (p.H >> sh) + (iy >> sh)) * (p.W >> sh) + (ix >> sh)) * p.cs0) + p.co0 + q * 4;
+        w_off1[r] = (((n * p.H + iy) * p.W + ix) * p.cs1) + p.co1 + q * 4;
+        w_ok[r] = v;
+        w_lds[r] = (px < WH * WW ? px : 0) * PS + q * 4;
+    }
+    const cf32x4* const wq = (const cf32x4*)(unsigned long long)p.wh;  // constant address space: scalar loads
+
+    f32x2 acc[PY][CO];
+#pragma unroll
+    for (int y = 0; y < PY; ++y)
+#pragma unroll
+        for (int o = 0; o < CO; ++o) acc[y][o] = f32x2{0.f, 0.f};
+
+    f32x4 rw[W_CNT];
+    auto load_window = [&](int c) {
+        const bool s1 = c >= nchunk0;
+        const int cg0 = s1 ? (c - nchunk0) * 2 : c * 2;
+        const int Gs = s1 ? p.G1 : p.G0;
+        const float* base = s1 ? p.src1 : p.src0;
+#pragma unroll
+        for (int r = 0; r < W_CNT; ++r) {
+            const int q = (t + 256 * r) & 1;
+            const bool v = w_ok[r] && (cg0 + q) < Gs;
+            const int off = (s1 ? w_off1[r] : w_off0[r]) + (v ? cg0 * 4 : -(q * 4));  // masked lanes re-read channel 0
+            const f32x4 x = *reinterpret_cast<const f32x4*>(base + off);
+            rw[r] = v ? x : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    // The tap loop is software-pipelined over steps (kx, channel group, half of the ky range): the weights of step
+    // s + 1 (scalar loads) and the window rows of its (kx, group) are requested before the FMAs of step s issue, so
+    // the scalar-cache / LDS latency of a step hides behind the arithmetic of the previous one.
+    constexpr int HALVES = KS == 7 ? 2 : 1;          // 7x7: two steps per (kx, group), 2 x 32 weight SGPRs in flight
+    constexpr int KH0 = (KS + HALVES - 1) / HALVES;  // ky range of half 0: [0, KH0), half 1: [KH0, KS)
+    constexpr int STEPS = KS * 2 * HALVES;           // (kx, cg, half)
+    struct Wts {
+        f32x4 w[KH0][CO];
+    };
+    load_window(0);
+    for (int c = 0; c < nchunks; ++c) {
+        if (c > 0) __syncthreads();  // every lane is done with the previous chunk's window
+#pragma unroll
+        for (int r = 0; r < W_CNT; ++r)
+            if (t + 256 * r < W_ITEMS) *reinterpret_cast<f32x4*>(win + w_lds[r]) = rw[r];
+        __syncthreads();
+        if (c + 1 < nchunks) load_window(c + 1);  // in flight during this chunk's taps
+        const cf32x4* const wb = wq + (size_t)c * (KS * 2 * KS * CO);  // this chunk's weights, in step order
+        auto load_w = [&](int step, Wts& W) {
+            const int kc = step / HALVES, kx = kc >> 1, cg = kc & 1, half = step % HALVES;
+#pragma unroll
+            for (int k = 0; k < KH0; ++k) {
+                const int ky = half * KH0 + k;
+                if (ky < KS) {
+#pragma unroll
+                    for (int o = 0; o < CO; ++o) W.w[k][o] = wb[((kx * 2 + cg) * KS + ky) * CO + o];
+                }
+            }
+        };
+        auto load_a = [&](int step, f32x4* a) {
+            const int kc = step / HALVES, kx = kc >> 1, cg = kc & 1;
+#pragma unroll
+            for (int r = 0; r < NR; ++r)
+                a[r] = *reinterpret_cast<const f32x4*>(win + ((ty * PY + r) * WW + tx + kx) * PS + cg * 4);
+        };
+        Wts wbuf[2];       // ping-pong: step s reads wbuf[s & 1] while wbuf[(s + 1) & 1] fills
+        f32x4 abuf[2][NR];  // window rows of the current / next (kx, group): index (s / HALVES) & 1
+        load_w(0, wbuf[0]);
+        load_a(0, abuf[0]);
+#pragma unroll
+        for (int step = 0; step < STEPS; ++step) {
+            const int half = step % HALVES;
+            if (step + 1 < STEPS) {
+                load_w(step + 1, wbuf[(step + 1) & 1]);
+                if (half == HALVES - 1) load_a(step + 1, abuf[((step + 1) / HALVES) & 1]);  // next step: new (kx, group)
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the prefetch distance at one step (SGPR budget)
+#pragma unroll
+            for (int k = 0; k < KH0; ++k) {
+                const int ky = half * KH0 + k;
+                if (ky < KS) {
+#pragma unroll
+                    for (int o = 0; o < CO; ++o) {
+                        // packed FMAs on the natural register pairs: (x0, x1) * (w0, w1), then (x2, x3) * (w2, w3)
+                        const f32x4 w = wbuf[step & 1].w[k][o];
+                        const f32x2 wlo = {w[0], w[1]}, whi = {w[2], w[3]};
+#pragma unroll
+                        for (int y = 0; y < PY; ++y) {
+                            const f32x4 x = abuf[(step / HALVES) & 1][y + ky];
+                            const f32x2 xlo = {x[0], x[1]}, xhi = {x[2], x[3]};
+                            acc[y][o] = __builtin_elementwise_fma(xlo, wlo, acc[y][o]);
+                            acc[y][o] = __builtin_elementwise_fma(xhi, whi, acc[y][o]);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const bool vec_ok = conv_vec_ok(p);
+    const int ox = tx0 + tx;
+#pragma unroll
+    for (int y = 0; y < PY; ++y) {
+        const int oy = ty0 + ty * PY + y;
+        if (oy < p.Ho && ox < p.Wo) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int o = 0; o < CO; ++o) v[o] = acc[y][o][0] + acc[y][o][1];
+            conv_epilogue_quad(p, ((size_t)n * p.Ho + oy) * p.Wo + ox, 0, v, vec_ok);
+        }
+    }
+}
+
+
 // ---- optional per-launch timing with HIP events on the launch stream (bench.py roofline leg)
 struct ConvProfEntry {
     hipEvent_t e0, e1;
@@ -560,7 +743,7 @@ void conv_profile_begin() {
 // cfg ids (BM x BN): 0 <2,2,4,4> 128x128  1 <1,4,2,2> 32x128  2 <4,1,4,4> 256x64  3 <2,2,2,2> 64x64  4 <4,1,4,2> 256x32
 //   5 <2,2,2,1> 64x32  6 <4,1,4,1> 256x16  7 <4,1,1,1> 64x16  8 <1,4,4,2> 64x128  9 <2,2,4,2> 128x64  10 <4,1,2,2> 128x32
 //   11 <4,1,2,1> 128x16; LDS-window 3x3 kernel: 12 (8x16)x128  13 (8x16)x64  14 (8x16)x32  15 (4x16)x128
-//   16 7x7 (8x16)x16  17 5x5 (8x16)x16
+//   16 7x7 heads  17 5x5 heads  18 3x3 heads (direct kernel for cout <= 2; the window kernel (8x16)x16 above that)
 int conv_profile_end(double* ms, double* flops, int* launches) {
     for (int i = 0; i < CONV_NUM_CFGS; i++) {
         ms[i] = 0;
@@ -698,6 +881,38 @@ static int launch_win3(const ConvParams& p, hipStream_t stream, int cfg_id) {
     return DFVO_OK;
 }
 
+template <int KS, int CO>
+static int launch_head(const ConvParams& p, hipStream_t stream, int cfg_id) {
+    const int tiles = p.N * ((p.Ho + 31) / 32) * ((p.Wo + 15) / 16);
+    dim3 grid((unsigned)tiles, 1, 1);
+    ConvProfEntry pe;
+    if (g_prof) {
+        DFVO_HIP_CHECK(hipEventCreate(&pe.e0));
+        DFVO_HIP_CHECK(hipEventCreate(&pe.e1));
+        pe.cfg = cfg_id;
+        DFVO_HIP_CHECK(hipEventRecord(pe.e0, stream));
+    }
+    hipLaunchKernelGGL((conv_head_f32_kernel<KS, CO>), grid, dim3(256), 0, stream, p);
+    DFVO_HIP_CHECK(hipGetLastError());
+    if (g_prof) {
+        DFVO_HIP_CHECK(hipEventRecord(pe.e1, stream));
+        pe.flops = p.useful_flops;
+        const int sh[12] = {p.N, p.H, p.W, p.Ho, p.Wo, (p.G0 + p.G1) * 4, p.cout, p.kh, p.stride, (int)grid.x, 1, 1};
+        for (int i = 0; i < 12; ++i) pe.shape[i] = sh[i];
+        g_prof->push_back(pe);
+    }
+    return DFVO_OK;
+}
+
+// the direct kernel serves the square, stride-1, "same"-padded heads with one or two output channels
+static bool conv_use_head(const ConvParams& p) {
+    static const int mode = getenv("DFVO_CONV_HEAD") ? atoi(getenv("DFVO_CONV_HEAD")) : 1;
+    if (!mode || p.cout > 2 || !p.wh) return false;
+    if (p.kh != p.kw || p.stride != 1 || p.pad_h != p.kh / 2 || p.pad_w != p.kw / 2) return false;
+    if (p.kh != 3 && p.kh != 5 && p.kh != 7) return false;
+    return (long long)p.N * p.Ho * p.Wo >= 1024;
+}
+
 // the LDS-window kernel serves 3x3 / stride-1 layers on maps large enough to fill the chip with TH x 16 tiles
 static bool conv_use_window(const ConvParams& p, int bn) {
     static const int mode = getenv("DFVO_CONV_WINDOW") ? atoi(getenv("DFVO_CONV_WINDOW")) : 1;
@@ -741,6 +956,11 @@ int launch_conv(const ConvParams& p, hipStream_t stream) {
     DFVO_ARG_CHECK(p.cout_pad % bn == 0, "launch_conv: cout_pad not a multiple of the N tile");
     DFVO_ARG_CHECK((p.cs0 % 4) == 0 && (p.co0 % 4) == 0, "launch_conv: src0 stride/offset must be multiples of 4");
     DFVO_ARG_CHECK(p.G1 == 0 || ((p.cs1 % 4) == 0 && (p.co1 % 4) == 0), "launch_conv: src1 stride/offset");
+    if (conv_use_head(p)) {
+        if (p.kh == 7) return p.cout == 2 ? launch_head<7, 2>(p, stream, 16) : launch_head<7, 1>(p, stream, 16);
+        if (p.kh == 5) return p.cout == 2 ? launch_head<5, 2>(p, stream, 17) : launch_head<5, 1>(p, stream, 17);
+        return p.cout == 2 ? launch_head<3, 2>(p, stream, 18) : launch_head<3, 1>(p, stream, 18);
+    }
     if (conv_use_window(p, bn) && p.kh == 7) return launch_win3<4, 1, 2, 1, 7>(p, stream, 16);
     if (conv_use_window(p, bn) && p.kh == 5) return launch_win3<4, 1, 2, 1, 5>(p, stream, 17);
     if (conv_use_window(p, bn)) {

@@ -49,6 +49,8 @@ struct ConvParams {
     // packed weights [ksteps*4][cout_pad][4], bias[cout_pad]
     const float* wp;
     const float* bias;
+    // head layout of the same weights (one- / two-channel square layers only, else null): see conv_pack_head_weights
+    const float* wh;
     int cout, cout_pad, ksteps;
     // optional residual (added before activation)
     const float* res;
@@ -85,11 +87,15 @@ static inline int conv_cout_pad(int cout, long long M) {
 // Pack OIHW weights (cin = c0 + c1) into the kernel layout. `out` must hold
 // conv_ksteps*4*cout_pad*4 floats. fold_scale/fold_shift (per-cout, may be null)
 // implement eval-mode BatchNorm folding: w' = w*scale, b' = b*scale + shift.
+// weights of a one- / two-channel k x k layer in the order the direct head kernel consumes them:
+// [8-channel chunk (source 0 first, each source rounded up)][kx][4-channel group of the chunk (2)][ky][cout][4]
+size_t conv_head_weight_floats(int cout, int c0, int c1, int k);
+void conv_pack_head_weights(const float* w_oihw, int cout, int c0, int c1, int k, const float* fold_scale, float* out);
 void conv_pack_weights(const float* w_oihw, const float* bias, int cout, int c0, int c1, int kh, int kw,
                        int cout_pad, const float* fold_scale, const float* fold_shift, float* out_w,
                        float* out_b);
 
-constexpr int CONV_NUM_CFGS = 18;  // tile configurations of the implicit-GEMM kernel (profile arrays have this size)
+constexpr int CONV_NUM_CFGS = 19;  // tile configurations of the implicit-GEMM kernel (profile arrays have this size)
 int launch_conv(const ConvParams& p, hipStream_t stream);
 // effective (bm, splits) the launcher would use for p (after clamping the overrides)
 void conv_effective_config(const ConvParams& p, int* bm, int* splits);

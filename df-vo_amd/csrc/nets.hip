@@ -72,13 +72,24 @@ int make_conv(const ParamStore& ps, const std::string& wname, const std::string&
     DFVO_HIP_CHECK(hipMalloc((void**)&L->bias, pb.size() * sizeof(float)));
     DFVO_HIP_CHECK(hipMemcpy(L->wp, pw.data(), pw.size() * sizeof(float), hipMemcpyHostToDevice));
     DFVO_HIP_CHECK(hipMemcpy(L->bias, pb.data(), pb.size() * sizeof(float), hipMemcpyHostToDevice));
+    return make_head_weights(w->data.data(), L->cout, c0, c1, L->kh, L->kw, scale, &L->wh);
+}
+
+int make_head_weights(const float* w, int cout, int c0, int c1, int kh, int kw, const float* scale, float** wh) {
+    *wh = nullptr;
+    if (cout > 2 || kh != kw || (kh != 3 && kh != 5 && kh != 7)) return DFVO_OK;
+    std::vector<float> ph(conv_head_weight_floats(cout, c0, c1, kh));
+    conv_pack_head_weights(w, cout, c0, c1, kh, scale, ph.data());
+    DFVO_HIP_CHECK(hipMalloc((void**)wh, ph.size() * sizeof(float)));
+    DFVO_HIP_CHECK(hipMemcpy(*wh, ph.data(), ph.size() * sizeof(float), hipMemcpyHostToDevice));
     return DFVO_OK;
 }
 
 void free_conv(ConvLayer* l) {
     if (l->wp) (void)hipFree(l->wp);
     if (l->bias) (void)hipFree(l->bias);
-    l->wp = l->bias = nullptr;
+    if (l->wh) (void)hipFree(l->wh);
+    l->wp = l->bias = l->wh = nullptr;
 }
 
 // ---- per-layer autotuner: the candidates differ only in tiling / K splitting, the arithmetic is the same fp32 FMA
@@ -162,6 +173,7 @@ int run_conv(const ConvLayer& L, int N, int H, int W, View s0, int up0, View s1,
     p.cs1 = s1.cs;
     p.co1 = s1.co;
     p.wp = L.wp;
+    p.wh = L.wh;
     p.bias = L.bias;
     p.cout = L.cout;
     p.cout_pad = L.cout_pad;

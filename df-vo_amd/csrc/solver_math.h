@@ -466,7 +466,7 @@ SM_HD void solve_poly_fixed(const double* c, double* rre, double* rim) {
             const double qre = (nre * dre + nim * dim) * t, qim = (-nre * dim + nim * dre) * t;
             xr[i] = pre - qre;
             xi[i] = pim - qim;
-            const double an = sqrt(qre * qre + qim * qim);
+            const double an = qre * qre + qim * qim;  // |q|^2: only `maxDiff <= 0` is tested, and sqrt keeps 0 / NaN / order
             maxDiff = maxDiff > an ? maxDiff : an;
         }
         if (maxDiff <= 0) break;
@@ -510,7 +510,7 @@ SM_HD_NOINLINE void solve_poly_generic(const double* c, int n, double* rre, doub
             const double qre = (nre * dre + nim * dim) * t, qim = (-nre * dim + nim * dre) * t;
             rre[i] = pre - qre;
             rim[i] = pim - qim;
-            const double an = sqrt(qre * qre + qim * qim);
+            const double an = qre * qre + qim * qim;  // |q|^2: only `maxDiff <= 0` is tested, and sqrt keeps 0 / NaN / order
             maxDiff = maxDiff > an ? maxDiff : an;
         }
         if (maxDiff <= 0) break;

@@ -1234,26 +1234,23 @@ __device__ void pose_candidates(const double* __restrict__ E, double* __restrict
     }
 }
 
-// one lane per correspondence: triangulate against each of the four candidates, cheirality flags
+// one lane per (correspondence, candidate): triangulate against the candidate (blockIdx.y), cheirality flag
 __global__ void k_cheirality(const double* __restrict__ cand, const double* __restrict__ p1,
                              const double* __restrict__ p2, int n, uint8_t* __restrict__ flags,
                              int* __restrict__ good) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.y;
     const double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-    int f[4] = {0, 0, 0, 0};
+    int f = 0;
     if (i < n) {
-        for (int c = 0; c < 4; c++) {
-            const double* P = cand + 24 + c * 12;
-            double X4[4];
-            sm::triangulate_point(P0, P, p1[i * 2], p1[i * 2 + 1], p2[i * 2], p2[i * 2 + 1], X4);
-            f[c] = sm::cheirality_ok(P, X4, 50.0) ? 1 : 0;
-            flags[c * n + i] = f[c] ? 255 : 0;
-        }
+        const double* P = cand + 24 + c * 12;
+        double X4[4];
+        sm::triangulate_point(P0, P, p1[i * 2], p1[i * 2 + 1], p2[i * 2], p2[i * 2 + 1], X4);
+        f = sm::cheirality_ok(P, X4, 50.0) ? 1 : 0;
+        flags[c * n + i] = f ? 255 : 0;
     }
-    for (int c = 0; c < 4; c++) {
-        const int s = wave_sum(f[c]);
-        if ((threadIdx.x & 63) == 0 && s) atomicAdd(&good[c], s);
-    }
+    const int s = wave_sum(f);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(&good[c], s);
 }
 
 // recoverPose prologue in one launch: both point sets normalised (blockIdx.y), the four (R, t) candidates of E and
@@ -1332,7 +1329,7 @@ int enqueue_recover_pose(RansacWorkspace& w, const double* d_E, const double* d_
     uint8_t* flags = (uint8_t*)(w.lm + 96);     // 4 * n bytes
     hipLaunchKernelGGL(k_pose_prepare, dim3(cdiv(n > 0 ? n : 1, 256), 2), dim3(256), 0, s, d_E, d_pts1, d_pts2, n, a, bx, by,
                        w.norm_a, w.norm_b, cand, good);
-    hipLaunchKernelGGL(k_cheirality, dim3(cdiv(n > 0 ? n : 1, 256)), dim3(256), 0, s, cand, w.norm_a, w.norm_b, n, flags,
+    hipLaunchKernelGGL(k_cheirality, dim3(cdiv(n > 0 ? n : 1, 64), 4), dim3(64), 0, s, cand, w.norm_a, w.norm_b, n, flags,
                        good);
     hipLaunchKernelGGL(k_pose_select, dim3(cdiv(n > 0 ? n : 1, 256)), dim3(256), 0, s, cand, good, flags, n, w.out + 16,
                        w.mask, fin);

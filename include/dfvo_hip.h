@@ -68,11 +68,12 @@ int dfvo_conv2d(const dfvo_conv_desc* desc, const float* d_src0, const float* d_
  * roofline leg of bench.py).  Between begin and end every conv launch is bracketed by two events;
  * end() returns, per tile configuration (0: 128x128, 1: 32x128, 2: 256x64, 3: 64x64, 4: 256x32,
  * 5: 64x32, 6: 256x16, 7: 64x16, 8: 64x128, 9: 128x64, 10: 128x32, 11: 128x16, 12-15: the LDS-window 3x3 kernel
- * with (8x16)x128, (8x16)x64, (8x16)x32, (4x16)x128 tiles, 16/17: its 7x7 / 5x5 (8x16)x16 variants; arrays of 18), the
+ * with (8x16)x128, (8x16)x64, (8x16)x32, (4x16)x128 tiles, 16/17/18: the 7x7 / 5x5 / 3x3 one- and two-channel
+ * heads (direct kernel; wider 5x5 / 7x7 layers use the window kernel under the same ids); arrays of 19), the
  * summed duration [ms], useful FLOPs and launch count.
  * Do not use while a hipGraph capture is active (disable graphs on the nets first). */
 int dfvo_conv_profile_begin(void);
-int dfvo_conv_profile_end(double* h_ms18, double* h_flops18, int* h_launches18);
+int dfvo_conv_profile_end(double* h_ms19, double* h_flops19, int* h_launches19);
 
 /* correlation.py:38-106,281-340 (_FunctionCorrelation.forward) followed by leaky_relu(slope)
  * (lite_flow_net.py:145,148).  NHWC inputs [N,H,W,C]; output [N,ceil(H/s),ceil(W/s),52], 49 used.

@@ -77,6 +77,13 @@ CASES = [
     ("win_small_grid_128", 1, 120, 264, 128, 0, 128, 3, 3, 1, (1, 1), 0, 1, 0, False),
     ("win7_32_2_res", 2, 97, 170, 32, 0, 2, 7, 7, 1, (3, 3), 0, 0, 0, True),
     ("win5_32_2", 2, 48, 156, 32, 0, 2, 5, 5, 1, (2, 2), 0, 0, 0, False),
+    # one- / two-channel heads on the direct kernel: two sources with a 4-channel tail, reflection padding, a source
+    # that is not a multiple of 8 channels, ragged tiles; and a 5-channel 5x5 layer that stays on the window kernel
+    ("head3_cat_32_4_to_2", 2, 45, 77, 32, 4, 2, 3, 3, 1, (1, 1), 0, 0, 0, True),
+    ("head3_refl_sigmoid_64_1", 1, 96, 320, 64, 0, 1, 3, 3, 1, (1, 1), 1, 4, 0, False),
+    ("head5_20_1", 2, 50, 70, 20, 0, 1, 5, 5, 1, (2, 2), 0, 1, 0, False),
+    ("head7_up_refl_12_2", 1, 33, 50, 12, 0, 2, 7, 7, 1, (3, 3), 1, 0, 1, False),
+    ("win5_32_5", 2, 48, 156, 32, 0, 5, 5, 5, 1, (2, 2), 0, 0, 0, False),
 ]
 
 
