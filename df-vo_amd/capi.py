@@ -93,6 +93,7 @@ SIGNATURES = {
     "dfvo_correlation": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     "dfvo_backward_warp": (_i, [_vp, _vp, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "dfvo_deconv_dw4x4s2": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "dfvo_resize_lanczos_u8": (_i, [_vp, _i, _i, _vp, _i, _i, _vp]),
     "dfvo_resize_bilinear": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "dfvo_flownet_create": (_i, [_i, _i, _vp, C.POINTER(_vp)]),
     "dfvo_flownet_destroy": (None, [_vp]),
@@ -112,6 +113,7 @@ SIGNATURES = {
     "dfvo_depthnet_set_graph": (_i, [_vp, _i]),
     "dfvo_depthnet_forward": (_i, [_vp, _vp, _vp]),
     "dfvo_depthnet_forward_host": (_i, [_vp, _vp, _vp]),
+    "dfvo_depthnet_forward_image_host": (_i, [_vp, _vp, _i, _i, _vp]),
     "dfvo_depthnet_last_flops": (_d, [_vp]),
     "dfvo_depthnet_sync": (_i, [_vp]),
     "dfvo_depth_postprocess": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
@@ -136,6 +138,7 @@ SIGNATURES = {
     "dfvo_pipeline_enqueue_nets": (_i, [_vp, _i, _vp, _vp, _vp]),
     "dfvo_pipeline_track": (_i, [_vp, _i, _vp, _vp, _vp, C.POINTER(TrackOut)]),
     "dfvo_pipeline_set_ref_depth": (_i, [_vp, _vp, _vp]),
+    "dfvo_pipeline_set_ref_image": (_i, [_vp, _vp]),
     "dfvo_pipeline_prefetch_track": (_i, [_vp, _i, _vp, _vp]),
     "dfvo_pipeline_get_flow": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "dfvo_pipeline_sync": (_i, [_vp]),

@@ -6,6 +6,7 @@
 
 #include "nets.h"
 #include "ops.h"
+#include "resize_lanczos.h"
 
 namespace dfvo {
 static thread_local std::string g_err;
@@ -20,6 +21,9 @@ struct dfvo_flownet {
 };
 struct dfvo_depthnet {
     DepthNet net;
+    LanczosResizer resize;      // dfvo_depthnet_forward_image_host: tables for the last image size seen
+    uint8_t* img_full = nullptr;
+    size_t img_full_bytes = 0;
 };
 
 #define API_TRY(expr)                   \
@@ -295,6 +299,8 @@ int dfvo_depthnet_create(int feed_h, int feed_w, float min_depth, float max_dept
 void dfvo_depthnet_destroy(dfvo_depthnet* n) {
     if (!n) return;
     n->net.destroy();
+    n->resize.release();
+    if (n->img_full) (void)hipFree(n->img_full);
     delete n;
 }
 int dfvo_depthnet_set_param(dfvo_depthnet* n, const char* name, const float* h, int ndim, const int* shape) {
@@ -324,6 +330,39 @@ int dfvo_depthnet_forward_host(dfvo_depthnet* n, const uint8_t* h_img, float* h_
     API_TRY(d.forward((const uint8_t*)d.u8_in.p, d.depth.p));
     DFVO_HIP_CHECK(hipMemcpyAsync(h_depth, d.depth.p, px * sizeof(float), hipMemcpyDeviceToHost, d.stream));
     DFVO_HIP_CHECK(hipStreamSynchronize(d.stream));
+    return DFVO_OK;
+}
+int dfvo_depthnet_forward_image_host(dfvo_depthnet* n, const uint8_t* h_img, int img_h, int img_w, float* h_depth) {
+    DFVO_ARG_CHECK(n && h_img && h_depth && img_h > 0 && img_w > 0, "dfvo_depthnet_forward_image_host: bad argument");
+    DepthNet& d = n->net;
+    DFVO_ARG_CHECK(d.finalized, "forward before finalize");
+    if (n->resize.H != img_h || n->resize.W != img_w || n->resize.oh != d.H || n->resize.ow != d.W)
+        API_TRY(n->resize.init(img_h, img_w, d.H, d.W));
+    const size_t bytes = (size_t)img_h * img_w * 3;
+    if (bytes > n->img_full_bytes) {
+        if (n->img_full) (void)hipFree(n->img_full);
+        n->img_full = nullptr;
+        n->img_full_bytes = 0;
+        DFVO_HIP_CHECK(hipMalloc((void**)&n->img_full, bytes));
+        n->img_full_bytes = bytes;
+    }
+    const size_t px = (size_t)d.H * d.W;
+    DFVO_HIP_CHECK(hipMemcpyAsync(n->img_full, h_img, bytes, hipMemcpyHostToDevice, d.stream));
+    API_TRY(n->resize.enqueue(n->img_full, (uint8_t*)d.u8_in.p, d.stream));
+    API_TRY(d.forward((const uint8_t*)d.u8_in.p, d.depth.p));
+    DFVO_HIP_CHECK(hipMemcpyAsync(h_depth, d.depth.p, px * sizeof(float), hipMemcpyDeviceToHost, d.stream));
+    DFVO_HIP_CHECK(hipStreamSynchronize(d.stream));
+    return DFVO_OK;
+}
+int dfvo_resize_lanczos_u8(const uint8_t* d_src, int H, int W, uint8_t* d_dst, int out_h, int out_w, void* stream) {
+    DFVO_ARG_CHECK(d_src && d_dst, "dfvo_resize_lanczos_u8: null argument");
+    LanczosResizer r;
+    int rc = r.init(H, W, out_h, out_w);
+    if (rc == DFVO_OK) rc = r.enqueue(d_src, d_dst, (hipStream_t)stream);
+    hipError_t e = hipStreamSynchronize((hipStream_t)stream);  // the tables die with r
+    r.release();
+    if (rc != DFVO_OK) return rc;
+    DFVO_HIP_CHECK(e);
     return DFVO_OK;
 }
 double dfvo_depthnet_last_flops(const dfvo_depthnet* n) { return n ? n->net.flops_last : 0.0; }

@@ -11,6 +11,7 @@
 
 #include "nets.h"
 #include "ops.h"
+#include "resize_lanczos.h"
 #include "tracker.h"
 
 using namespace dfvo;
@@ -39,6 +40,8 @@ struct dfvo_pipeline {
     float* raw_depth[DFVO_PIPELINE_SLOTS] = {};
     double* proc_depth[DFVO_PIPELINE_SLOTS] = {};
     float* depth_small = nullptr;
+    LanczosResizer feed_resize;  // current frame -> depth-net feed size (when the caller passes no resized frame)
+    uint8_t* feed_buf = nullptr;
     double* d_T21 = nullptr;
     // PnP fallback: processed depth of the reference frame (= the previous pair's current frame)
     PnpBuffers pnp;
@@ -128,6 +131,11 @@ int dfvo_pipeline_create(const dfvo_pipeline_cfg* cfg, dfvo_pipeline** out) {
         dfvo::set_last_error("dfvo_pipeline_create: hipMalloc failed");
         return fail(DFVO_ERR_HIP);
     }
+    if (hipMalloc((void**)&p->feed_buf, (size_t)p->feedH * p->feedW * 3) != hipSuccess) {
+        dfvo::set_last_error("dfvo_pipeline_create: hipMalloc failed");
+        return fail(DFVO_ERR_HIP);
+    }
+    if (p->feed_resize.init(p->H, p->W, p->feedH, p->feedW) != DFVO_OK) return fail(DFVO_ERR_HIP);
     enqueue_mt_seed(p->tbs[0], cfg->seed, p->s_trk);
     *out = p;
     return DFVO_OK;
@@ -157,6 +165,8 @@ void dfvo_pipeline_destroy(dfvo_pipeline* p) {
         if (p->e_depth[i]) (void)hipEventDestroy(p->e_depth[i]);
     }
     if (p->depth_small) (void)hipFree(p->depth_small);
+    p->feed_resize.release();
+    if (p->feed_buf) (void)hipFree(p->feed_buf);
     if (p->ref_depth) (void)hipFree(p->ref_depth);
     if (p->ref_raw) (void)hipFree(p->ref_raw);
     p->pnp.release();
@@ -211,10 +221,15 @@ int dfvo_pipeline_seed(dfvo_pipeline* p, uint32_t seed) {
 
 int dfvo_pipeline_enqueue_nets(dfvo_pipeline* p, int slot, const uint8_t* d_ref, const uint8_t* d_cur,
                                const uint8_t* d_cur_feed) {
-    DFVO_ARG_CHECK(p && p->nets_ready && (slot >= 0 && slot < DFVO_PIPELINE_SLOTS) && d_ref && d_cur && d_cur_feed,
+    DFVO_ARG_CHECK(p && p->nets_ready && (slot >= 0 && slot < DFVO_PIPELINE_SLOTS) && d_ref && d_cur,
                    "dfvo_pipeline_enqueue_nets: bad argument");
     const size_t px = (size_t)p->H * p->W;
-    // depth of the current frame (dfvo.py:305-319)
+    // depth of the current frame (dfvo.py:305-319); without a caller-resized frame the LANCZOS resize of
+    // deep_models.py:195-199 runs here, ahead of the net on its stream
+    if (!d_cur_feed) {
+        P_TRY(p->feed_resize.enqueue(d_cur, p->feed_buf, p->s_depth));
+        d_cur_feed = p->feed_buf;
+    }
     P_TRY(p->depth.forward(d_cur_feed, p->depth_small));
     const dfvo_pipeline_cfg& c = p->cfg;
     const int y0 = (int)(p->H * c.depth_crop[0]), y1 = (int)(p->H * c.depth_crop[1]);
@@ -252,6 +267,12 @@ int dfvo_pipeline_set_ref_depth(dfvo_pipeline* p, const uint8_t* d_feed, const d
     }
     p->has_ref_depth = true;
     return DFVO_OK;
+}
+
+int dfvo_pipeline_set_ref_image(dfvo_pipeline* p, const uint8_t* d_img) {
+    DFVO_ARG_CHECK(p && p->nets_ready && d_img, "dfvo_pipeline_set_ref_image: bad argument");
+    P_TRY(p->feed_resize.enqueue(d_img, p->feed_buf, p->s_depth));
+    return dfvo_pipeline_set_ref_depth(p, p->feed_buf, nullptr);
 }
 
 // the current frame's depth becomes the reference depth of the next pair (dfvo.py:  ref_data <- cur_data)

@@ -1,0 +1,22 @@
+// Pillow-exact 8-bit LANCZOS resize on the device (the depth net's input stage).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace dfvo {
+
+// uint8 [H, W, 3] -> uint8 [oh, ow, 3]: horizontal pass into `tmp`, vertical pass into the destination, each with
+// Pillow's 22-bit fixed-point coefficient tables (built on the host at init, resident on the device)
+struct LanczosResizer {
+    int H = 0, W = 0, oh = 0, ow = 0;
+    int ksx = 0, ksy = 0;                 // coefficients per output column / row
+    int *bx = nullptr, *kx = nullptr;     // [ow][2] (first input column, count), [ow][ksx]
+    int *by = nullptr, *ky = nullptr;     // [oh][2], [oh][ksy]
+    uint8_t* tmp = nullptr;               // [H][ow][3]
+    int init(int H, int W, int oh, int ow);
+    int enqueue(const uint8_t* d_src, uint8_t* d_dst, hipStream_t s) const;
+    void release();
+};
+
+}  // namespace dfvo

@@ -1,8 +1,7 @@
 """DeepModel with the reference's surface (/root/reference/libs/deep_models/deep_models.py:25-206):
 builds the two nets and provides forward_depth / forward_flow with the reference's argument and
-return conventions; everything after the host-side PIL resize runs in libdfvo_hip.so."""
+return conventions; everything, the PIL-LANCZOS resize of the depth input included, runs in libdfvo_hip.so."""
 import numpy as np
-import PIL.Image as pil
 import torch
 
 from .depth.monodepth2.monodepth2 import Monodepth2DepthNet
@@ -62,9 +61,9 @@ class DeepModel:
         return flows
 
     def forward_depth(self, imgs):
-        """deep_models.py:184-206: PIL LANCZOS resize to the feed size (host, as in the reference), then the net"""
-        img = pil.fromarray(imgs[0]).resize((self.depth.feed_width, self.depth.feed_height), pil.LANCZOS)
-        return self.depth.inference_depth_u8(np.ascontiguousarray(np.asarray(img)))
+        """deep_models.py:184-206: LANCZOS resize to the feed size (Pillow's 8-bit arithmetic, on the device), then
+        the net; only the raw frame crosses PCIe"""
+        return self.depth.inference_depth_image_u8(np.ascontiguousarray(imgs[0]))
 
     def forward_pose(self, imgs):
         raise NotImplementedError("deep_pose is 'Experiment Ver. only' in the reference; out of scope")

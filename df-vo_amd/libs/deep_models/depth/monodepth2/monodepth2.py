@@ -59,6 +59,16 @@ class Monodepth2DepthNet:
                                                          capi.as_ptr(depth)))
         return depth
 
+    def inference_depth_image_u8(self, img_u8):
+        """uint8 [H, W, 3] of any size -> float32 [feed_h, feed_w]: the Pillow-exact LANCZOS resize to the feed size
+        (deep_models.py:195-199) runs on the device in front of the net"""
+        assert img_u8.ndim == 3 and img_u8.shape[2] == 3 and img_u8.dtype == np.uint8
+        depth = np.zeros((self.feed_height, self.feed_width), np.float32)
+        capi.check(capi.lib().dfvo_depthnet_forward_image_host(self.model, capi.as_ptr(np.ascontiguousarray(img_u8)),
+                                                               int(img_u8.shape[0]), int(img_u8.shape[1]),
+                                                               capi.as_ptr(depth)))
+        return depth
+
     def inference_depth(self, img):
         """monodepth2.py:124-139: [1,3,h,w] float tensor in [0,1] (ToTensor of a uint8 image) -> [1,1,h,w]"""
         a = img.detach().cpu().numpy()[0].transpose(1, 2, 0).astype(np.float64) * 255.0

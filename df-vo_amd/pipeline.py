@@ -78,9 +78,10 @@ class TrackingPipeline:
     def set_graph(self, enable):
         capi.check(self.lib.dfvo_pipeline_set_graph(self.h, int(enable)))
 
-    def enqueue_nets(self, slot, d_ref, d_cur, d_feed):
-        """device uint8 tensors (torch.cuda): ref/cur [H,W,3], feed [feed_h,feed_w,3]"""
-        p = lambda t: C.c_void_p(t.data_ptr())
+    def enqueue_nets(self, slot, d_ref, d_cur, d_feed=None):
+        """device uint8 tensors (torch.cuda): ref/cur [H,W,3]; feed [feed_h,feed_w,3] = the LANCZOS-resized current
+        frame, or None to have the pipeline resize d_cur on the device"""
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         capi.check(self.lib.dfvo_pipeline_enqueue_nets(self.h, slot, p(d_ref), p(d_cur), p(d_feed)))
 
     def prefetch_track(self, slot, flow=None, diff=None):
@@ -99,6 +100,10 @@ class TrackingPipeline:
         """depth of the first reference frame: the uint8 feed image (runs the depth net) or a processed depth map"""
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         capi.check(self.lib.dfvo_pipeline_set_ref_depth(self.h, p(d_feed), p(depth)))
+
+    def set_ref_image(self, d_img):
+        """depth of the first reference frame from the full-size uint8 frame (device LANCZOS resize + depth net)"""
+        capi.check(self.lib.dfvo_pipeline_set_ref_image(self.h, C.c_void_p(d_img.data_ptr())))
 
     def sync(self):
         capi.check(self.lib.dfvo_pipeline_sync(self.h))

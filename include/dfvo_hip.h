@@ -91,6 +91,10 @@ int dfvo_deconv_dw4x4s2(const float* d_src, int N, int H, int W, int C, int cs, 
                         float* d_dst, void* stream);
 
 /* F.interpolate(mode='bilinear') on dense NHWC, C % 4 == 0 */
+/* uint8 [H,W,3] -> uint8 [out_h,out_w,3], bit-exact with Pillow's Image.resize((out_w,out_h), Image.LANCZOS): 22-bit
+ * fixed-point coefficient tables, horizontal pass then vertical pass, each rounded to uint8 (replaces the host-side
+ * PIL call at deep_models.py:195-199).  Builds the tables per call; the nets keep theirs resident. */
+int dfvo_resize_lanczos_u8(const uint8_t* d_src, int H, int W, uint8_t* d_dst, int out_h, int out_w, void* stream);
 int dfvo_resize_bilinear(const float* d_src, int N, int H, int W, int C, float* d_dst, int Ho, int Wo,
                          int align_corners, void* stream);
 
@@ -134,6 +138,9 @@ int dfvo_depthnet_set_graph(dfvo_depthnet* net, int enable);
 /* img uint8 [feed_h, feed_w, 3] -> depth float [feed_h, feed_w] (metres, x baseline multiplier) */
 int dfvo_depthnet_forward(dfvo_depthnet* net, const uint8_t* d_img, float* d_depth);
 int dfvo_depthnet_forward_host(dfvo_depthnet* net, const uint8_t* h_img, float* h_depth);
+/* DeepModel.forward_depth in one call (deep_models.py:184-206): host uint8 image [img_h,img_w,3] of any size ->
+ * Pillow-exact LANCZOS resize to the feed size on the device -> net -> host depth [feed_h,feed_w] */
+int dfvo_depthnet_forward_image_host(dfvo_depthnet* net, const uint8_t* h_img, int img_h, int img_w, float* h_depth);
 double dfvo_depthnet_last_flops(const dfvo_depthnet* net);
 int dfvo_depthnet_sync(dfvo_depthnet* net);
 /* dfvo.py:314-319 + utils.py:89-114: nearest resize to (H,W), crop rows/cols, range mask.
@@ -288,13 +295,16 @@ int dfvo_pipeline_set_graph(dfvo_pipeline* p, int enable);   /* hipGraph replay 
  * k+1 .. k+3 queue up behind each other on their streams while dfvo_pipeline_track(k) blocks the host) */
 #define DFVO_PIPELINE_SLOTS 4
 /* enqueue both nets for one pair into `slot` (0 .. DFVO_PIPELINE_SLOTS-1); returns at once.  d_* uint8 device images:
- * ref/cur [img_h,img_w,3], cur_feed [feed_h,feed_w,3] (the PIL-LANCZOS resized current frame) */
+ * ref/cur [img_h,img_w,3], cur_feed [feed_h,feed_w,3] (the PIL-LANCZOS resized current frame) or NULL: the current frame
+ * is then resized on the device (dfvo_resize_lanczos_u8's arithmetic) ahead of the depth net */
 int dfvo_pipeline_enqueue_nets(dfvo_pipeline* p, int slot, const uint8_t* d_ref, const uint8_t* d_cur,
                                const uint8_t* d_cur_feed);
 /* depth of the very first reference frame (dfvo.py computes the depth of every frame as it becomes `cur`; the first
  * frame never is): exactly one of d_feed (uint8 [feed_h,feed_w,3], runs the depth net) or d_depth_override (processed
  * depth, double [H,W]).  Later reference depths roll over from the current frame of each tracked pair. */
 int dfvo_pipeline_set_ref_depth(dfvo_pipeline* p, const uint8_t* d_feed, const double* d_depth_override);
+/* same from the full-size first frame [img_h,img_w,3]: device LANCZOS resize, then the depth net */
+int dfvo_pipeline_set_ref_image(dfvo_pipeline* p, const uint8_t* d_img);
 /* Optional: enqueue the RNG-independent half of the solver stage of `slot` (keypoint selection, homography RANSAC +
  * refinement, GRIC-H) right after dfvo_pipeline_enqueue_nets(slot, ...).  It waits for the slot's flow outputs on the
  * device and runs on its own stream, i.e. under the nets / solver stage of earlier pairs; dfvo_pipeline_track(slot)

@@ -242,12 +242,44 @@ def golden_tracker():
     np.savez_compressed(os.path.join(HERE, "e_tracker.npz"), **out)
 
 
+LANCZOS_CASES = [  # (seed, H, W, out_h, out_w): KITTI frame -> monodepth2 feed, RobotCar crop -> feed, down / up / one axis
+    (31, 376, 1241, 192, 640), (32, 768, 1280, 256, 640), (33, 37, 53, 20, 31), (34, 20, 31, 37, 53),
+    (35, 100, 100, 100, 57), (36, 64, 48, 192, 48)]
+
+
+def lanczos_case(seed, h, w):
+    """seeded uint8 test image: smooth structure + noise + saturated patches (also imported by the tests)"""
+    rng = np.random.Generator(np.random.PCG64(int(seed)))
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = 128 + 90 * np.sin(xx / 7.0)[..., None] * np.cos(yy / 5.0)[..., None] * np.array([1.0, 0.7, -0.8])
+    img = np.clip(base + rng.normal(0, 40, (h, w, 3)), 0, 255).astype(np.uint8)
+    img[: h // 5, : w // 4] = 255
+    img[-(h // 6):, -(w // 3):] = 0
+    return img
+
+
+def golden_lanczos():
+    """Pillow itself (the reference's forward_depth calls img.resize(..., pil.LANCZOS), deep_models.py:195-199)"""
+    import zlib
+    from PIL import Image
+    import PIL
+    out = {"pillow_version": np.array(PIL.__version__)}
+    for seed, h, w, oh, ow in LANCZOS_CASES:
+        img = lanczos_case(seed, h, w)
+        res = np.asarray(Image.fromarray(img).resize((ow, oh), Image.LANCZOS))
+        key = "%d_%dx%d_%dx%d" % (seed, h, w, oh, ow)
+        out["crc_" + key] = np.array(zlib.crc32(res.tobytes()), np.uint32)
+        out["rows_" + key] = res[:: max(1, oh // 8)].copy()  # every (oh/8)-th output row in full
+    np.savez_compressed(os.path.join(HERE, "lanczos.npz"), **out)
+    print("wrote lanczos.npz (Pillow %s)" % PIL.__version__)
+
+
 if __name__ == "__main__":
     apply_compat()
     torch.set_num_threads(8)
     which = [a for a in sys.argv[1:] if not a.startswith("--")]
     todo = {"liteflownet": golden_liteflownet, "monodepth2": golden_monodepth2, "kp": golden_kp_selection,
-            "gric": golden_gric, "tracker": golden_tracker}
+            "gric": golden_gric, "tracker": golden_tracker, "lanczos": golden_lanczos}
     for name, fn in todo.items():
         if not which or name in which:
             print("==", name)

@@ -23,10 +23,11 @@ def run():
     fsd, dsd = syn.liteflownet_state_dict(4869), syn.monodepth2_state_dict(4869)
     pipe = pmod.TrackingPipeline(h, w, 64, 96, sc["K"], fsd, dsd, seed=4869)
     ref, cur = syn.image_pair(h, w, seed=2)
-    feed, _ = syn.image_pair(64, 96, seed=3)
+    from oracle.pil_resample import resize_lanczos_u8
+    feed = resize_lanczos_u8(cur, 96, 64)  # what the pipeline's device LANCZOS resize must produce from `cur`
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     pipe.set_ref_depth(depth=d(sc["depth_ref"]))  # reference-frame depth: input of the PnP fallback
-    pipe.enqueue_nets(0, d(ref), d(cur), d(feed))
+    pipe.enqueue_nets(0, d(ref), d(cur))  # depth input resized on the device
     out = pipe.track(0, d(sc["flow"]), d(sc["diff"]), d(sc["depth_cur"]))
     fwd, bwd, diff, raw, dep = pipe.get_outputs(0)
     pipe.close()
