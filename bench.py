@@ -202,13 +202,13 @@ def main():
         # HBM-side bytes per launch of that kernel from the committed rocprofv3 --pmc passes over this same command
         # (tools/pmc_traffic.py: FETCH_SIZE x2 on gfx950 + WRITE_SIZE); None when no profile matches the kernel
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r1q_pmc_bench.json")))["kernels"]
+            prof = json.load(open(os.path.join(ROOT, "profiles", "r1z_pmc_bench.json")))["kernels"]
             key = CFG_NAMES[dom].split(" ")[0].replace("conv_igemm_f32<", "conv_igemm_f32_kernel<").replace(
                 "conv_win3_f32<", "conv_win_f32_kernel<").replace("conv_win_f32<", "conv_win_f32_kernel<")
             cand = [k for k in prof if k.replace(" ", "").startswith(key.rstrip(">").replace(" ", ""))]
             if cand:
                 roof["traffic"] = round(prof[cand[0]]["hbm_bytes_per_dispatch"])
-                roof["traffic_unit"] = "bytes per launch (rocprofv3 PMC, profiles/r1q_pmc_bench.json)"
+                roof["traffic_unit"] = "bytes per launch (rocprofv3 PMC, profiles/r1z_pmc_bench.json)"
         except (OSError, KeyError, ValueError):
             pass
     base = None
