@@ -697,40 +697,45 @@ SM_HD_NOINLINE bool five_point_stage1(const double* q1, const double* q2, double
     return five_point_stage1_ws(q1, q2, EE, b, c, ws);
 }
 
+// stage 3 for ONE root: false when the root is complex or its (x, y, 1) null vector degenerates; else E (9 doubles,
+// unit Frobenius norm).  five_point_stage3 below is this in root order with the survivors compacted; on the GPU the
+// ten roots of a hypothesis run on ten lanes (k_e_stage3).
+SM_HD bool five_point_root_to_E(const double* EE, const double* b, double rre, double rim, double* Ev) {
+    if (fabs(rim) > 1e-10) return false;
+    const double z1 = rre;
+    const double z2 = z1 * z1, z3 = z2 * z1, z4 = z3 * z1;
+    double bz[9];
+    for (int j = 0; j < 3; j++) {
+        const double* br = b + j * 13;
+        bz[j * 3 + 0] = br[0] * z3 + br[1] * z2 + br[2] * z1 + br[3];
+        bz[j * 3 + 1] = br[4] * z3 + br[5] * z2 + br[6] * z1 + br[7];
+        bz[j * 3 + 2] = br[8] * z4 + br[9] * z3 + br[10] * z2 + br[11] * z1 + br[12];
+    }
+    double w3[3], vt3[9];
+    svd_square<3>(bz, w3, nullptr, vt3);
+    const double* xy1 = vt3 + 6;
+    if (fabs(xy1[2]) < 1e-10) return false;
+    const double xs = xy1[0] / xy1[2], ys = xy1[1] / xy1[2], zs = z1;
+    for (int k = 0; k < 9; k++) {
+        const double t = EE[k] * xs + EE[9 + k] * ys;
+        const double u = t + EE[18 + k] * zs;
+        Ev[k] = u + EE[27 + k];
+    }
+    double s = 0;
+    s += Ev[0] * Ev[0] + Ev[1] * Ev[1] + Ev[2] * Ev[2] + Ev[3] * Ev[3];
+    s += Ev[4] * Ev[4] + Ev[5] * Ev[5] + Ev[6] * Ev[6] + Ev[7] * Ev[7];
+    s += Ev[8] * Ev[8];
+    const double inv = 1. / sqrt(s);
+    for (int k = 0; k < 9; k++) Ev[k] = Ev[k] * inv;
+    return true;
+}
+
 // stage 3: real roots -> essential matrices (up to 10 x 9 doubles); returns their number
 SM_HD_NOINLINE int five_point_stage3(const double* EE, const double* b, const double* rre, const double* rim,
                                      double* E_out) {
     int count = 0;
-    for (int i = 0; i < 10; i++) {
-        if (fabs(rim[i]) > 1e-10) continue;
-        const double z1 = rre[i];
-        const double z2 = z1 * z1, z3 = z2 * z1, z4 = z3 * z1;
-        double bz[9];
-        for (int j = 0; j < 3; j++) {
-            const double* br = b + j * 13;
-            bz[j * 3 + 0] = br[0] * z3 + br[1] * z2 + br[2] * z1 + br[3];
-            bz[j * 3 + 1] = br[4] * z3 + br[5] * z2 + br[6] * z1 + br[7];
-            bz[j * 3 + 2] = br[8] * z4 + br[9] * z3 + br[10] * z2 + br[11] * z1 + br[12];
-        }
-        double w3[3], vt3[9];
-        svd_square<3>(bz, w3, nullptr, vt3);
-        const double* xy1 = vt3 + 6;
-        if (fabs(xy1[2]) < 1e-10) continue;
-        const double xs = xy1[0] / xy1[2], ys = xy1[1] / xy1[2], zs = z1;
-        double* Ev = E_out + count * 9;
-        for (int k = 0; k < 9; k++) {
-            const double t = EE[k] * xs + EE[9 + k] * ys;
-            const double u = t + EE[18 + k] * zs;
-            Ev[k] = u + EE[27 + k];
-        }
-        double s = 0;
-        s += Ev[0] * Ev[0] + Ev[1] * Ev[1] + Ev[2] * Ev[2] + Ev[3] * Ev[3];
-        s += Ev[4] * Ev[4] + Ev[5] * Ev[5] + Ev[6] * Ev[6] + Ev[7] * Ev[7];
-        s += Ev[8] * Ev[8];
-        const double inv = 1. / sqrt(s);
-        for (int k = 0; k < 9; k++) Ev[k] = Ev[k] * inv;
-        count++;
-    }
+    for (int i = 0; i < 10; i++)
+        if (five_point_root_to_E(EE, b, rre[i], rim[i], E_out + count * 9)) count++;
     return count;
 }
 

@@ -175,6 +175,9 @@ __global__ __launch_bounds__(64) void k_e_poly(const EBatch B, int it0, int it1)
     }
 }
 
+// sixteen lanes per hypothesis, one root per lane (ten active): a root's 3x3 SVD and its E are independent of the
+// other roots; the survivors are stored compacted in root order (slot = number of surviving lower roots), which is
+// exactly the sequential loop's output
 __global__ __launch_bounds__(64) void k_e_stage3(const EBatch B, int it0, int it1) {
     const ERep& R = B.r[blockIdx.y];
     const RansacState* st = R.state;
@@ -182,14 +185,25 @@ __global__ __launch_bounds__(64) void k_e_stage3(const EBatch B, int it0, int it
     const int* ok = R.ok;
     double* models = R.models;
     int* nmodels = R.nmodels;
-    const int it = it0 + blockIdx.x * 64 + threadIdx.x;
-    if (st->done || it >= it1) return;
-    int nm = 0;
-    if (ok[it]) {
+    const int grp = threadIdx.x >> 4, root = threadIdx.x & 15;
+    const int it = it0 + blockIdx.x * 4 + grp;
+    if (st->done) return;
+    const bool active = it < it1;
+    bool valid = false;
+    double Ev[9];
+    if (active && root < 10 && ok[it]) {
         const double* w = ws + (size_t)it * E_WS;
-        nm = sm::five_point_stage3(w, w + 36, w + 86, w + 96, models + (size_t)it * 90);
+        valid = sm::five_point_root_to_E(w, w + 36, w[86 + root], w[96 + root], Ev);
     }
-    nmodels[it] = nm;
+    const unsigned long long m = __ballot(valid);
+    const unsigned grp_mask = (unsigned)((m >> (grp * 16)) & 0xffffull);
+    if (valid) {
+        const int slot = __popc(grp_mask & ((1u << root) - 1u));
+        double* dst = models + (size_t)it * 90 + slot * 9;
+#pragma unroll
+        for (int k = 0; k < 9; k++) dst[k] = Ev[k];
+    }
+    if (active && root == 0) nmodels[it] = __popc(grp_mask);
 }
 
 // one wavefront per hypothesis: Sampson error of every correspondence under each of its models
@@ -338,7 +352,7 @@ int enqueue_find_essential_batch(RansacWorkspace* w, const double* const* d_pts1
             hipLaunchKernelGGL(k_e_subsets, dim3(1), dim3(1), 0, s, B, n, it0, it1);
             hipLaunchKernelGGL(k_e_stage1, dim3(cdiv(nh, E_STAGE1_LANES), R), dim3(E_STAGE1_LANES), 0, s, B, it0, it1);
             hipLaunchKernelGGL(k_e_poly, dim3(cdiv(nh, 64), R), dim3(64), 0, s, B, it0, it1);
-            hipLaunchKernelGGL(k_e_stage3, dim3(cdiv(nh, 64), R), dim3(64), 0, s, B, it0, it1);
+            hipLaunchKernelGGL(k_e_stage3, dim3(cdiv(nh, 4), R), dim3(64), 0, s, B, it0, it1);
             hipLaunchKernelGGL(k_e_score, dim3(cdiv(nh, 4), R), dim3(256), 0, s, B, it0, it1, n, thr2);
             hipLaunchKernelGGL(k_e_replay, dim3(R), dim3(1), 0, s, B, it0, it1, n, prob);
         }
