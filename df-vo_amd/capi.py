@@ -20,7 +20,8 @@ _lib = None
 
 class Pose2d2dCfg(C.Structure):
     _fields_ = [("fx", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("reproj_thre", C.c_double),
-                ("repeat", C.c_int), ("max_iters", C.c_int), ("KinvT", C.c_double * 9), ("Kinv", C.c_double * 9)]
+                ("repeat", C.c_int), ("max_iters", C.c_int), ("KinvT", C.c_double * 9), ("Kinv", C.c_double * 9),
+                ("validity_method", C.c_int), ("validity_thre", C.c_double)]
 
 
 class Pose2d2dOut(C.Structure):
@@ -127,6 +128,7 @@ SIGNATURES = {
     "dfvo_tracker_set_rng_state": (_i, [_vp, _vp]),
     "dfvo_tracker_get_rng_state": (_i, [_vp, _vp]),
     "dfvo_kp_local_bestn": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _ip, _ip]),
+    "dfvo_kp_sampled": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "dfvo_compute_pose_2d2d": (_i, [_vp, _vp, _vp, _i, C.POINTER(Pose2d2dCfg), C.POINTER(Pose2d2dOut), _vp]),
     "dfvo_pipeline_create": (_i, [C.POINTER(PipelineCfg), C.POINTER(_vp)]),
     "dfvo_pipeline_destroy": (None, [_vp]),

@@ -201,6 +201,47 @@ int dfvo_kp_local_bestn(dfvo_tracker* t, const float* h_flow, const float* h_dif
     return DFVO_OK;
 }
 
+int dfvo_kp_sampled(dfvo_tracker* t, const float* h_flow, int H, int W, int y0, int y1, int x0, int x1, const int* h_idx,
+                    int n, double* h_kp1, double* h_kp2) {
+    DFVO_ARG_CHECK(t && h_flow && h_idx && h_kp1 && h_kp2 && H > 0 && W > 0 && n >= 0, "dfvo_kp_sampled: bad argument");
+    const long long cells = (long long)(y1 - y0) * (x1 - x0);
+    for (int i = 0; i < n; ++i) DFVO_ARG_CHECK(h_idx[i] >= 0 && h_idx[i] < cells, "dfvo_kp_sampled: index outside the cropped grid");
+    const size_t px = (size_t)H * W;
+    if (px > t->flow_cap) {
+        if (t->d_flow) (void)hipFree(t->d_flow);
+        if (t->d_diff) (void)hipFree(t->d_diff);
+        t->flow_cap = px;
+        DFVO_HIP_CHECK(hipMalloc((void**)&t->d_flow, sizeof(float) * 2 * px));
+        DFVO_HIP_CHECK(hipMalloc((void**)&t->d_diff, sizeof(float) * px));
+    }
+    if (n == 0) return DFVO_OK;
+    int* d_idx = nullptr;
+    double* d_kp = nullptr;
+    DFVO_HIP_CHECK(hipMalloc((void**)&d_idx, sizeof(int) * n));
+    if (hipMalloc((void**)&d_kp, sizeof(double) * 4 * n) != hipSuccess) {
+        (void)hipFree(d_idx);
+        set_last_error("dfvo_kp_sampled: hipMalloc failed");
+        return DFVO_ERR_HIP;
+    }
+    hipError_t e = hipMemcpyAsync(t->d_flow, h_flow, sizeof(float) * 2 * px, hipMemcpyHostToDevice, t->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_idx, h_idx, sizeof(int) * n, hipMemcpyHostToDevice, t->stream);
+    int rc = e == hipSuccess ? enqueue_kp_sampled(t->d_flow, H, W, y0, y1, x0, x1, d_idx, n, d_kp, d_kp + 2 * n, t->stream)
+                             : DFVO_ERR_HIP;
+    if (rc == DFVO_OK) {
+        e = hipMemcpyAsync(h_kp1, d_kp, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, t->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_kp2, d_kp + 2 * n, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, t->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(t->stream);
+        if (e != hipSuccess) {
+            set_last_error(std::string("dfvo_kp_sampled: ") + hipGetErrorString(e));
+            rc = DFVO_ERR_HIP;
+        }
+    }
+    (void)hipStreamSynchronize(t->stream);
+    (void)hipFree(d_idx);
+    (void)hipFree(d_kp);
+    return rc;
+}
+
 static int stage_kp(dfvo_tracker* t, const double* h_a, const double* h_b, int n) {
     int rc = t->tb.ensure_kp(n > 16 ? n : 16, 1, 1);
     if (rc != DFVO_OK) return rc;
@@ -230,6 +271,10 @@ int dfvo_compute_pose_2d2d(dfvo_tracker* t, const double* h_kp_ref, const double
         pc.KinvT[i] = cfg->KinvT[i];
         pc.Kinv[i] = cfg->Kinv[i];
     }
+    DFVO_ARG_CHECK(cfg->validity_method == DFVO_VALIDITY_GRIC || cfg->validity_method == DFVO_VALIDITY_FLOW,
+                   "dfvo_compute_pose_2d2d: unknown validity_method");
+    pc.validity = cfg->validity_method;
+    pc.validity_thre = cfg->validity_thre;
     rc = enqueue_compute_pose_2d2d(t->tb, n, pc, t->stream);
     if (rc != DFVO_OK) return rc;
     PoseState ps;
@@ -241,7 +286,7 @@ int dfvo_compute_pose_2d2d(dfvo_tracker* t, const double* h_kp_ref, const double
     out->n = ps.n;
     out->best_inlier_cnt = ps.best_cnt;
     out->num_valid = ps.num_valid;
-    out->major_valid = n > 10 ? ps.major_valid : 0;
+    out->major_valid = (cfg->validity_method == DFVO_VALIDITY_FLOW ? n >= 5 : n > 10) ? ps.major_valid : 0;
     out->cheirality = ps.cheirality;
     out->h_found = ps.h_found;
     out->h_gric = ps.h_gric;

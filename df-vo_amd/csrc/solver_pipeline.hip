@@ -269,6 +269,30 @@ __global__ __launch_bounds__(256) void k_kp_gather(const int* __restrict__ cell_
     }
 }
 
+// sampled_kp (kp_selection.py:327-378): the k-th pixel (row-major) of the cropped grid [y0:y1, x0:x1] for every k of
+// the uniform index list; kp1 = (x, y), kp2 = kp1 + flow (float32 promoted to float64, as numpy does)
+__global__ void k_kp_sampled(const float* __restrict__ flow, int H, int W, int y0, int x0, int cw,
+                             const int* __restrict__ idx, int n, double* __restrict__ kp1, double* __restrict__ kp2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int k = idx[i];
+    const int yy = y0 + k / cw, xx = x0 + k % cw;
+    const double x = (double)xx, y = (double)yy;
+    kp1[i * 2] = x;
+    kp1[i * 2 + 1] = y;
+    kp2[i * 2] = x + (double)flow[(size_t)yy * W + xx];
+    kp2[i * 2 + 1] = y + (double)flow[((size_t)H + yy) * W + xx];
+}
+
+int enqueue_kp_sampled(const float* d_flow, int H, int W, int y0, int y1, int x0, int x1, const int* d_idx, int n,
+                       double* d_kp1, double* d_kp2, hipStream_t s) {
+    DFVO_ARG_CHECK(0 <= y0 && y0 < y1 && y1 <= H && 0 <= x0 && x0 < x1 && x1 <= W, "sampled_kp: crop outside the image");
+    if (n <= 0) return DFVO_OK;
+    hipLaunchKernelGGL(k_kp_sampled, dim3(cdiv(n, 256)), dim3(256), 0, s, d_flow, H, W, y0, x0, x1 - x0, d_idx, n, d_kp1, d_kp2);
+    DFVO_HIP_CHECK(hipGetLastError());
+    return DFVO_OK;
+}
+
 int enqueue_local_bestn(TrackerBuffers& tb, const float* d_flow, const float* d_diff, int H, int W, int num_row,
                         int num_col, int num_bestN, float thre, hipStream_t s) {
     const int cells = num_row * num_col;
@@ -797,6 +821,98 @@ __global__ __launch_bounds__(256) void k_rep_update_all(PoseState* ps, const Ran
         ps->major_valid = ((double)ps->num_valid > (double)repeat / 2.0 && ps->have_best) ? 1 : 0;
 }
 
+// ---- e_tracker.validity.method == "flow" (ablation_model_sel_flow.yml) ------------------------------------------
+// np.add.reduce over a contiguous float64 array: numpy's pairwise summation (loops.c.src pairwise_sum_DOUBLE): below 8
+// elements a plain loop, up to 128 eight interleaved partial sums combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) and
+// the tail added one by one, above that a split at n/2 rounded down to a multiple of 8
+__device__ double np_pairwise_sum(const double* a, int n) {
+    if (n < 8) {
+        double res = 0.;
+        for (int i = 0; i < n; i++) res += a[i];
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; j++) r[j] = a[j];
+        int i;
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+
+// valid_case = np.mean(np.linalg.norm(kp_ref - kp_cur, axis=1)) > thre (E_tracker.py:182-185).  gate[0] = the keypoint
+// count the shuffles see (n when the pair is tracked, 0 otherwise: a closed gate draws nothing from np.random),
+// gate[1] = valid_case; the mean goes to *avg_out
+__global__ __launch_bounds__(256) void k_flow_gate(const int* __restrict__ kp_info, const double* __restrict__ kp_ref,
+                                                    const double* __restrict__ kp_cur, double thre, double* __restrict__ norms,
+                                                    double* __restrict__ avg_out, int* __restrict__ gate) {
+    const int n = kp_info[0];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const double dx = kp_ref[i * 2] - kp_cur[i * 2], dy = kp_ref[i * 2 + 1] - kp_cur[i * 2 + 1];
+        norms[i] = sqrt(dx * dx + dy * dy);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double avg = np_pairwise_sum(norms, n) / (double)n;  // n == 0: nan, compares false like numpy's
+        *avg_out = avg;
+        const int open = avg > thre ? 1 : 0;
+        gate[0] = open ? n : 0;
+        gate[1] = open;
+    }
+}
+
+__global__ void k_copy_double(double* __restrict__ dst, const double* __restrict__ src) { *dst = *src; }
+
+// the per-repeat bookkeeping of the "flow" validity: validity of a repeat = its recoverPose cheirality count above
+// 10 % of the keypoints, best model = most RANSAC inliers among the repeats whose count is above 5 %
+__global__ __launch_bounds__(256) void k_rep_update_flow(PoseState* ps, const int* __restrict__ gate, const double* __restrict__ avg_flow,
+                                                          const RepBatch B, const double* __restrict__ cheir,
+                                                          const int* __restrict__ perm, int perm_stride,
+                                                          uint8_t* __restrict__ best_inliers, int repeat) {
+    __shared__ int s_take;
+    const int n = ps->n;
+    const int open = gate[1];
+    if (threadIdx.x == 0) {
+        ps->h_found = 0;
+        ps->h_gric = *avg_flow;
+    }
+    __syncthreads();
+    for (int rep = 0; rep < repeat; ++rep) {
+        if (threadIdx.x == 0) {
+            const RansacState* est = B.st[rep];
+            const int found = open && est->found;
+            const int cnt = found ? est->max_good : 0;
+            const double c = found ? cheir[rep] : 0.0;
+            const bool valid = found && c > (double)n * 0.1;
+            ps->rep_cnt[rep] = cnt;
+            ps->rep_valid[rep] = valid ? 1 : 0;
+            ps->rep_gric[rep] = c;
+            ps->num_valid += valid ? 1 : 0;
+            s_take = (found && cnt > ps->best_cnt && c > (double)n * 0.05) ? 1 : 0;
+            if (s_take) {
+                ps->best_cnt = cnt;
+                ps->have_best = 1;
+                for (int k = 0; k < 9; k++) ps->best_E[k] = B.E[rep][k];
+            }
+        }
+        __syncthreads();
+        if (s_take) {
+            const uint8_t* mask = B.mask[rep];
+            const int* pm = perm + (size_t)rep * perm_stride;
+            for (int c = threadIdx.x; c < n; c += blockDim.x) best_inliers[pm[c]] = mask[c];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        ps->major_valid = ((double)ps->num_valid > (double)repeat / 2.0 && ps->have_best) ? 1 : 0;
+}
+
 // ================================================================================================
 // scale recovery (find_scale_from_depth)
 // ================================================================================================
@@ -1137,6 +1253,13 @@ int enqueue_pose_h_part(TrackerBuffers& tb, int n_bound, const PoseConfig& cfg, 
     hipLaunchKernelGGL(k_pose_state_init, dim3(cdiv(tb.kp_cap, 256)), dim3(256), 0, sh, tb.pose, tb.kp_info,
                        tb.best_inliers, tb.kp_cap);
     DFVO_HIP_CHECK(hipEventRecord(tb.ev_start, sh));
+    if (cfg.validity == 1) {  // "flow": no homography; the mean displacement decides whether the pair is tracked
+        hipLaunchKernelGGL(k_flow_gate, dim3(1), dim3(256), 0, sh, tb.kp_info, tb.kp_ref, tb.kp_cur, cfg.validity_thre,
+                           tb.pa, tb.small + 18, tb.kp_total + 5);
+        DFVO_HIP_CHECK(hipEventRecord(tb.ev_h, sh));
+        DFVO_HIP_CHECK(hipGetLastError());
+        return DFVO_OK;
+    }
     // ---- homography + GRIC-H (kp_cur -> kp_ref); with 10 or fewer keypoints the result is never consumed
     // (E_tracker.py:196) and with fewer than 5 the chain marks itself "no model"
     int rc = enqueue_find_homography(tb.ws_h, tb.kp_cur, tb.kp_ref, n_bound, 1.0, 2000, 0.99, sh, tb.kp_info);
@@ -1158,16 +1281,19 @@ int enqueue_pose_e_part(TrackerBuffers& tb, int n_host, const PoseConfig& cfg, h
     DFVO_ARG_CHECK(n_host >= 0 && n_host <= tb.kp_cap, "compute_pose_2d2d: keypoint capacity");
     DFVO_ARG_CHECK(cfg.repeat >= 1 && cfg.repeat <= MAX_REP, "compute_pose_2d2d: repeat out of range");
     DFVO_HIP_CHECK(hipStreamWaitEvent(s, tb.ev_h, 0));
-    // only when more than 10 keypoints (E_tracker.py:196)
-    if (n_host > 10) {
+    const bool by_flow = cfg.validity == 1;
+    // GRIC: only when more than 10 keypoints (E_tracker.py:196); flow: whenever the five-point solver has its 5 points
+    if (by_flow ? n_host >= 5 : n_host > 10) {
         const int nb = cdiv(n_host, 256);
         const int cap = tb.kp_cap;
         hipStream_t sr = tb.s_rep[0];
         const unsigned R = (unsigned)cfg.repeat;
-        DFVO_HIP_CHECK(hipStreamWaitEvent(sr, tb.ev_start, 0));
-        int rc = enqueue_mt_shuffle(tb.mt_state, tb.kp_info, n_host, cfg.repeat, cap + 8, tb.perm, sr);
+        // flow: the shuffles (and with them np.random) only run behind an open gate: their count is gate[0] = n or 0
+        const int* d_n = by_flow ? tb.kp_total + 5 : tb.kp_info;
+        DFVO_HIP_CHECK(hipStreamWaitEvent(sr, by_flow ? tb.ev_h : tb.ev_start, 0));
+        int rc = enqueue_mt_shuffle(tb.mt_state, d_n, n_host, cfg.repeat, cap + 8, tb.perm, sr);
         if (rc != DFVO_OK) return rc;
-        hipLaunchKernelGGL(k_permute_points, dim3(nb, R), dim3(256), 0, sr, tb.kp_info, tb.perm, cap + 8, tb.kp_cur,
+        hipLaunchKernelGGL(k_permute_points, dim3(nb, R), dim3(256), 0, sr, d_n, tb.perm, cap + 8, tb.kp_cur,
                            tb.kp_ref, tb.pa, tb.pb, 2 * cap);
         // the `repeat` five-point RANSACs as one batched launch sequence (blockIdx.y = repeat)
         const double *pas[MAX_REP], *pbs[MAX_REP];
@@ -1178,7 +1304,15 @@ int enqueue_pose_e_part(TrackerBuffers& tb, int n_host, const PoseConfig& cfg, h
         rc = enqueue_find_essential_batch(tb.ws_rep, pas, pbs, cfg.repeat, n_host, cfg.fx, cfg.cx, cfg.cy, 0.99,
                                           cfg.reproj_thre, cfg.max_iters, sr);
         if (rc != DFVO_OK) return rc;
-        {
+        if (by_flow) {
+            // cv2.recoverPose(E_rep, shuffled points): only its count is used (E_tracker.py:243-250); the homography
+            // workspace, idle in this mode, is the scratch of the `repeat` calls
+            for (int rep = 0; rep < cfg.repeat; ++rep) {
+                rc = enqueue_recover_pose(tb.ws_h, tb.ws_rep[rep].out, pas[rep], pbs[rep], n_host, cfg.fx, cfg.cx, cfg.cy, sr);
+                if (rc != DFVO_OK) return rc;
+                hipLaunchKernelGGL(k_copy_double, dim3(1), dim3(1), 0, sr, tb.small + 19 + rep, tb.ws_h.out + 16 + 12);
+            }
+        } else {
             GricFusedBatch GE;
             for (int rep = 0; rep < MAX_E_BATCH; ++rep) GE.M[rep] = rep < cfg.repeat ? tb.ws_rep[rep].out : nullptr;
             hipLaunchKernelGGL(k_gric_fused, dim3(R), dim3(256), 0, sr, GE, 0, tb.small, tb.small + 9, tb.kp_info, tb.pa, tb.pb,
@@ -1193,8 +1327,12 @@ int enqueue_pose_e_part(TrackerBuffers& tb, int n_host, const PoseConfig& cfg, h
                 RB.E[rep] = rep < cfg.repeat ? tb.ws_rep[rep].out : nullptr;
                 RB.mask[rep] = rep < cfg.repeat ? tb.ws_rep[rep].mask : nullptr;
             }
-            hipLaunchKernelGGL(k_rep_update_all, dim3(1), dim3(256), 0, s, tb.pose, tb.ws_h.state, tb.small + 18, RB,
-                               tb.small + 19, tb.perm, cap + 8, tb.best_inliers, cfg.repeat);
+            if (by_flow)
+                hipLaunchKernelGGL(k_rep_update_flow, dim3(1), dim3(256), 0, s, tb.pose, tb.kp_total + 5, tb.small + 18, RB,
+                                   tb.small + 19, tb.perm, cap + 8, tb.best_inliers, cfg.repeat);
+            else
+                hipLaunchKernelGGL(k_rep_update_all, dim3(1), dim3(256), 0, s, tb.pose, tb.ws_h.state, tb.small + 18, RB,
+                                   tb.small + 19, tb.perm, cap + 8, tb.best_inliers, cfg.repeat);
         }
         // recoverPose(best_E, kp_cur, kp_ref): always enqueued, consumed only when major_valid; its last kernel also
         // writes the pose bookkeeping and (fused pipeline) the inverse pose for the scale stage

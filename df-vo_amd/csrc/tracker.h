@@ -39,6 +39,8 @@ struct PoseConfig {
     int repeat;
     int max_iters;
     double KinvT[9], Kinv[9];
+    int validity = 0;           // e_tracker.validity.method: 0 GRIC, 1 flow (E_tracker.py:182-185, 243-250)
+    double validity_thre = 0;   // flow: mean keypoint displacement [px] above which the pair is tracked at all
 };
 
 struct ScaleConfig {
@@ -125,6 +127,8 @@ struct TrackerBuffers {
 
 int enqueue_local_bestn(TrackerBuffers& tb, const float* d_flow, const float* d_diff, int H, int W, int num_row,
                         int num_col, int num_bestN, float thre, hipStream_t s);
+int enqueue_kp_sampled(const float* d_flow, int H, int W, int y0, int y1, int x0, int x1, const int* d_idx, int n,
+                       double* d_kp1, double* d_kp2, hipStream_t s);
 int enqueue_mt_seed(TrackerBuffers& tb, uint32_t seed, hipStream_t s);
 // d_T21 (optional): 16 doubles that receive the inverse of the accepted pose (input of the scale stage)
 int enqueue_compute_pose_2d2d(TrackerBuffers& tb, int n_host, const PoseConfig& cfg, hipStream_t s,

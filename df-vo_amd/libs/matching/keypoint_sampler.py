@@ -1,5 +1,5 @@
 """KeypointSampler with the reference's surface (/root/reference/libs/matching/keypoint_sampler.py:18-163)
-over dfvo_kp_local_bestn (local_bestN, kp_selection.py:74-200)."""
+over dfvo_kp_local_bestn (local_bestN, kp_selection.py:74-200) and dfvo_kp_sampled (sampled_kp, :327-378)."""
 import ctypes as C
 
 import numpy as np
@@ -13,20 +13,54 @@ class KeypointSampler:
         self.cfg = cfg
         self.kps = {}
         ks = self.cfg.kp_selection
-        if ks.sampled_kp.enable or ks.bestN.enable:
-            raise NotImplementedError("kp_selection.sampled_kp / bestN are ablation selectors "
-                                      "(SURVEY.md section 8f rank 3); only local_bestN runs on the device")
+        if ks.bestN.enable:
+            raise NotImplementedError("kp_selection.bestN (whole-image argpartition, ablation_correspondences_best_n.yml) "
+                                      "is not on the device yet; local_bestN and sampled_kp are")
+        if ks.sampled_kp.enable:  # keypoint_sampler.py:29-36
+            self.kps['uniform'] = self.generate_kp_samples(img_h=self.cfg.image.height, img_w=self.cfg.image.width,
+                                                           crop=self.cfg.crop.flow_crop, N=ks.sampled_kp.num_kp)
         if ks.local_bestN.enable and ks.local_bestN.score_method != "flow":
             raise NotImplementedError("local_bestN.score_method '%s'" % ks.local_bestN.score_method)
         if ks.depth_consistency.enable:
             raise NotImplementedError("depth_consistency is experiment-only in the reference (out of scope)")
 
+    def generate_kp_samples(self, img_h, img_w, crop, N):
+        """keypoint_sampler.py:51-74"""
+        y0, y1 = int(crop[0][0] * img_h), int(crop[0][1] * img_h)
+        x0, x1 = int(crop[1][0] * img_w), int(crop[1][1] * img_w)
+        total_num = (x1 - x0) * (y1 - y0) - 1
+        return np.linspace(0, total_num, N, dtype=int)
+
     def kp_selection(self, cur_data, ref_data):
-        """keypoint_sampler.py:76-143 -> {'good_kp_found', 'kp1_best' [1,N,2], 'kp2_best' [1,N,2], 'fb_flow_mask'}"""
+        """keypoint_sampler.py:76-143 -> {'good_kp_found', 'kp1_best' [1,N,2], 'kp2_best' [1,N,2], 'fb_flow_mask'}
+        and / or {'kp1_list', 'kp2_list'} [1,N,2] (sampled_kp)"""
+        outputs = {"good_kp_found": True}
+        if self.cfg.kp_selection.local_bestN.enable:
+            outputs.update(self._local_bestN(cur_data, ref_data))
+        if self.cfg.kp_selection.sampled_kp.enable:
+            outputs.update(self._sampled_kp(cur_data, ref_data))
+        return outputs
+
+    def _sampled_kp(self, cur_data, ref_data):
+        """kp_selection.py:327-378 on the device (dfvo_kp_sampled)"""
+        flow = np.ascontiguousarray(ref_data['flow'], dtype=np.float32)
+        h, w = ref_data['depth'].shape
+        assert flow.shape == (2, h, w)
+        crop = self.cfg.crop.flow_crop
+        y0, y1, x0, x1 = 0, h, 0, w
+        if crop is not None:
+            y0, y1 = int(h * crop[0][0]), int(h * crop[0][1])
+            x0, x1 = int(w * crop[1][0]), int(w * crop[1][1])
+        idx = np.ascontiguousarray(self.kps['uniform'], dtype=np.int32)
+        kp1 = np.zeros((len(idx), 2))
+        kp2 = np.zeros((len(idx), 2))
+        capi.check(capi.lib().dfvo_kp_sampled(_ctx.tracker(), capi.as_ptr(flow), h, w, y0, y1, x0, x1, capi.as_ptr(idx),
+                                              len(idx), capi.as_ptr(kp1), capi.as_ptr(kp2)))
+        return {"kp1_list": kp1[None], "kp2_list": kp2[None]}
+
+    def _local_bestN(self, cur_data, ref_data):
         outputs = {"good_kp_found": True}
         c = self.cfg.kp_selection.local_bestN
-        if not c.enable:
-            return outputs
         flow = np.ascontiguousarray(ref_data['flow'], dtype=np.float32)
         diff = np.ascontiguousarray(ref_data['flow_diff'], dtype=np.float32)
         h, w = cur_data['depth'].shape
@@ -55,3 +89,6 @@ class KeypointSampler:
             ref_data['kp_best'] = kp_sel_outputs['kp1_best'][0]
             cur_data['kp_best'] = kp_sel_outputs['kp2_best'][0]
             cur_data['fb_flow_mask'] = kp_sel_outputs['fb_flow_mask']
+        if self.cfg.kp_selection.sampled_kp.enable:
+            ref_data['kp_list'] = kp_sel_outputs['kp1_list'][0]
+            cur_data['kp_list'] = kp_sel_outputs['kp2_list'][0]

@@ -26,9 +26,9 @@ class EssTracker:
     def compute_pose_2d2d(self, kp_ref, kp_cur, is_iterative):
         """E_tracker.py:154-307 -> {'pose': SE3 (cur -> ref), 'inliers': bool [N]}"""
         valid_cfg = self.cfg.e_tracker.validity
-        if valid_cfg.method != "GRIC":
-            raise NotImplementedError("e_tracker.validity.method '%s': only GRIC runs on the device so far "
-                                      "(SURVEY.md section 8f rank 3)" % valid_cfg.method)
+        if valid_cfg.method not in ("GRIC", "flow"):
+            raise NotImplementedError("e_tracker.validity.method '%s': GRIC and flow run on the device "
+                                      "(homo_ratio appears in no shipped configuration)" % valid_cfg.method)
         K = np.asarray(self.cam_intrinsics.mat, dtype=np.float64)
         repeat = int(self.cfg.e_tracker.ransac.repeat) if is_iterative else 3
         kp_ref = np.ascontiguousarray(kp_ref, dtype=np.float64)
@@ -37,7 +37,8 @@ class EssTracker:
         cfg = capi.Pose2d2dCfg(fx=float(self.cam_intrinsics.fx), cx=float(self.cam_intrinsics.cx),
                                cy=float(self.cam_intrinsics.cy),
                                reproj_thre=float(self.cfg.e_tracker.ransac.reproj_thre), repeat=repeat,
-                               max_iters=self.max_iters)
+                               max_iters=self.max_iters, validity_method=1 if valid_cfg.method == "flow" else 0,
+                               validity_thre=float(valid_cfg.thre) if valid_cfg.method == "flow" else 0.0)
         KinvT, Kinv = np.linalg.inv(K.T), np.linalg.inv(K)
         for i in range(9):
             cfg.KinvT[i] = KinvT.flat[i]

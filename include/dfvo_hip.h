@@ -190,10 +190,21 @@ int dfvo_tracker_get_rng_state(dfvo_tracker* trk, uint32_t* h_state625);
 int dfvo_kp_local_bestn(dfvo_tracker* trk, const float* h_flow, const float* h_diff, int H, int W, int num_row,
                         int num_col, int num_bestN, float thre, double* h_kp1, double* h_kp2, int* n_out,
                         int* good_kp_found);
+/* sampled_kp (kp_selection.py:327-378, the "uniform" correspondences of ablation_correspondences_uniform.yml): for each
+ * index k of h_idx[n] (KeypointSampler.generate_kp_samples' linspace over the cropped grid [y0:y1, x0:x1], row-major)
+ * kp1 = (x, y) of that pixel and kp2 = kp1 + flow there; h_kp1 / h_kp2 [n,2] */
+int dfvo_kp_sampled(dfvo_tracker* trk, const float* h_flow, int H, int W, int y0, int y1, int x0, int x1,
+                    const int* h_idx, int n, double* h_kp1, double* h_kp2);
 
-/* EssTracker.compute_pose_2d2d with validity.method == "GRIC" (E_tracker.py:154-307): homography +
- * GRIC-H, `repeat` x (shuffle, findEssentialMat, GRIC-E), best-of by inlier count, recoverPose,
- * cheirality > 10 %.  Consumes the tracker's RandomState for the shuffles. */
+/* EssTracker.compute_pose_2d2d (E_tracker.py:154-307).  validity_method DFVO_VALIDITY_GRIC (default configuration):
+ * homography + GRIC-H, `repeat` x (shuffle, findEssentialMat, GRIC-E), best-of by inlier count, recoverPose,
+ * cheirality > 10 %.  DFVO_VALIDITY_FLOW (ablation_model_sel_flow.yml): the pair is tracked only when the mean keypoint
+ * displacement exceeds validity_thre (else identity and no RandomState draw); a repeat is valid when the cheirality
+ * count of recoverPose(E_rep) exceeds 10 % of the keypoints, and it can only become the best model above 5 %
+ * (out: h_gric = the mean displacement, rep_gric[] = the per-repeat cheirality counts).
+ * Consumes the tracker's RandomState for the shuffles. */
+#define DFVO_VALIDITY_GRIC 0
+#define DFVO_VALIDITY_FLOW 1
 typedef struct dfvo_pose2d2d_cfg {
     double fx, cx, cy;       /* focal = fx, principal point (E_tracker.py:231-239) */
     double reproj_thre;      /* e_tracker.ransac.reproj_thre */
@@ -201,6 +212,8 @@ typedef struct dfvo_pose2d2d_cfg {
     int max_iters;           /* 1000 = OpenCV 3.4.3 */
     double KinvT[9];         /* np.linalg.inv(K.T) */
     double Kinv[9];          /* np.linalg.inv(K)   */
+    int validity_method;     /* e_tracker.validity.method: DFVO_VALIDITY_GRIC / DFVO_VALIDITY_FLOW */
+    double validity_thre;    /* e_tracker.validity.thre (flow only) */
 } dfvo_pose2d2d_cfg;
 typedef struct dfvo_pose2d2d_out {
     double R[9], t[3];       /* pose cur -> ref (identity / zero when rejected) */

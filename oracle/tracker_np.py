@@ -168,6 +168,28 @@ def local_bestN(flow, flow_diff, num_bestN=2000, num_row=10, num_col=10, thre=0.
     return out
 
 
+def generate_kp_samples(img_h, img_w, crop, N):
+    """keypoint_sampler.py:51-74: N indices spread uniformly over the cropped grid (row-major)"""
+    y0, y1 = int(crop[0][0] * img_h), int(crop[0][1] * img_h)
+    x0, x1 = int(crop[1][0] * img_w), int(crop[1][1] * img_w)
+    total_num = (x1 - x0) * (y1 - y0) - 1
+    return np.linspace(0, total_num, N, dtype=int)
+
+
+def sampled_kp(flow, kp_list, crop=None):
+    """kp_selection.py:327-378.  flow [2,H,W] f32 -> kp1_list, kp2_list [1,N,2] at the indices kp_list of the cropped grid"""
+    h, w = flow.shape[1:]
+    kp1 = np.expand_dims(image_grid(h, w), 0)
+    kp2 = kp1 + np.transpose(np.expand_dims(flow, 0), (0, 2, 3, 1))
+    if crop is not None:
+        y0, y1 = int(h * crop[0][0]), int(h * crop[0][1])
+        x0, x1 = int(w * crop[1][0]), int(w * crop[1][1])
+        kp1, kp2 = kp1[:, y0:y1, x0:x1], kp2[:, y0:y1, x0:x1]
+    a = np.transpose(kp1.reshape(1, -1, 2), (1, 0, 2))[kp_list]
+    b = np.transpose(kp2.reshape(1, -1, 2), (1, 0, 2))[kp_list]
+    return np.transpose(a, (1, 0, 2)), np.transpose(b, (1, 0, 2))
+
+
 def preprocess_depth(depth, crop, depth_range):
     """utils.py:89-114"""
     min_depth, max_depth = depth_range
@@ -223,9 +245,12 @@ def calc_GRIC(res, sigma, n, model):
 # ----------------------------------------------------------------------------------------------
 # EssTracker
 # ----------------------------------------------------------------------------------------------
-def compute_pose_2d2d(kp_ref, kp_cur, K, reproj_thre=0.2, repeat=5, max_iters=1000):
-    """E_tracker.py:154-307, validity.method == 'GRIC'.  Consumes np.random (global RandomState).
-    Returns dict(R, t, inliers, and diagnostics)."""
+def compute_pose_2d2d(kp_ref, kp_cur, K, reproj_thre=0.2, repeat=5, max_iters=1000, validity="GRIC", validity_thre=None):
+    """E_tracker.py:154-307, validity.method 'GRIC' (default configuration) or 'flow' (ablation_model_sel_flow.yml).
+    Consumes np.random (global RandomState).  Returns dict(R, t, inliers, and diagnostics)."""
+    if validity == "flow":
+        return _compute_pose_2d2d_flow(kp_ref, kp_cur, K, reproj_thre, repeat, max_iters, validity_thre)
+    assert validity == "GRIC"
     fx, cx, cy = K[0, 0], K[0, 2], K[1, 2]
     n = kp_ref.shape[0]
     R, t = np.eye(3), np.zeros((3, 1))
@@ -256,6 +281,52 @@ def compute_pose_2d2d(kp_ref, kp_cur, K, reproj_thre=0.2, repeat=5, max_iters=10
             diag["rep_valid"].append(bool(valid_case))
             diag["rep_gric"].append(float(E_gric))
             if inl.sum() > best_cnt:
+                best_E, best_cnt = E, inl.sum()
+                revert = np.zeros_like(new_list)
+                for cnt, i in enumerate(new_list):
+                    revert[i] = cnt
+                best_inliers = inl[list(revert)]
+            num_valid += valid_case * 1
+        diag["num_valid"] = int(num_valid)
+        if num_valid > (repeat / 2):
+            diag["major_valid"] = True
+            good, Rr, tr, _ = cv2.recoverPose(best_E, kp_cur, kp_ref, focal=fx, pp=(cx, cy))
+            diag["cheirality"] = int(good)
+            if good > n * 0.1:
+                R, t = Rr, tr
+    out = {"R": R, "t": t, "inliers": best_inliers[:, 0] == 1, "best_inlier_cnt": int(best_cnt)}
+    out.update(diag)
+    return out
+
+
+def _compute_pose_2d2d_flow(kp_ref, kp_cur, K, reproj_thre, repeat, max_iters, thre):
+    """E_tracker.py:182-185 (mean flow magnitude gate), :243-250 (per-repeat recoverPose cheirality as the validity and
+    as a second condition of the best-model update), :281-300 (unchanged ending)"""
+    fx, cx, cy = K[0, 0], K[0, 2], K[1, 2]
+    n = kp_ref.shape[0]
+    R, t = np.eye(3), np.zeros((3, 1))
+    best_cnt = 0
+    best_inliers = np.ones((n, 1)) == 1
+    diag = {"rep_inliers": [], "rep_valid": [], "rep_cheirality": [], "num_valid": 0, "major_valid": False,
+            "cheirality": 0}
+    avg_flow = np.mean(np.linalg.norm(kp_ref - kp_cur, axis=1))
+    diag["avg_flow"] = float(avg_flow)
+    valid_case = avg_flow > thre
+    best_E = None
+    if valid_case:
+        num_valid = 0
+        for _ in range(repeat):
+            new_list = np.arange(0, n, 1)
+            np.random.shuffle(new_list)
+            a, b = kp_cur.copy()[new_list], kp_ref.copy()[new_list]
+            E, inl = cv2.findEssentialMat(a, b, focal=fx, pp=(cx, cy), method=cv2.RANSAC, prob=0.99,
+                                          threshold=reproj_thre, maxIters=max_iters)
+            cheir, _, _, _ = cv2.recoverPose(E, a, b, focal=fx, pp=(cx, cy))
+            valid_case = cheir > n * 0.1
+            diag["rep_inliers"].append(int(inl.sum()))
+            diag["rep_valid"].append(bool(valid_case))
+            diag["rep_cheirality"].append(int(cheir))
+            if inl.sum() > best_cnt and cheir > n * 0.05:
                 best_E, best_cnt = E, inl.sum()
                 revert = np.zeros_like(new_list)
                 for cnt, i in enumerate(new_list):

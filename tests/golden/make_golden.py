@@ -156,6 +156,37 @@ def golden_kp_selection():
     np.savez_compressed(os.path.join(HERE, "local_bestN.npz"), **out)
 
 
+def golden_kp_sampled():
+    """the reference's sampled_kp + KeypointSampler.generate_kp_samples (ablation_correspondences_uniform.yml)"""
+    from oracle import cv2_shim
+    sys.modules["cv2"] = cv2_shim
+    import libs.matching.kp_selection as kps
+    import libs.matching.keypoint_sampler as sampler
+    from easydict import EasyDict
+    out = {}
+    for tag, (h, w, seed, crop, nkp) in {"a": (192, 640, 41, [[0, 1], [0, 1]], 2000),
+                                          "b": (376, 1241, 42, [[0.1, 0.9], [0.05, 0.95]], 2000),
+                                          "c": (61, 83, 43, [[0.3, 1], [0, 0.7]], 37)}.items():
+        _, flow = kp_case(h, w, seed, 0.5)
+        cfg = EasyDict({"kp_selection": {"sampled_kp": {"enable": True, "num_kp": nkp}, "local_bestN": {"enable": False},
+                                         "bestN": {"enable": False}},
+                        "crop": {"flow_crop": crop}, "image": {"height": h, "width": w}})
+        ks = sampler.KeypointSampler(cfg)
+        x = np.linspace(0, w - 1, w)
+        y = np.linspace(0, h - 1, h)
+        xv, yv = np.meshgrid(x, y)
+        kp1 = np.expand_dims(np.transpose(np.stack([xv, yv]), (1, 2, 0)), 0)
+        kp2 = kp1 + np.transpose(np.expand_dims(flow, 0), (0, 2, 3, 1))
+        res = kps.sampled_kp(kp1=kp1, kp2=kp2, ref_data={"depth": np.zeros((h, w))}, kp_list=ks.kps["uniform"], cfg=cfg,
+                             outputs={})
+        out[tag + "_spec"] = np.array([h, w, seed, nkp] + [v for r in crop for v in r], np.float64)
+        out[tag + "_idx"] = np.asarray(ks.kps["uniform"], np.int64)
+        out[tag + "_kp1"] = res["kp1_list"]
+        out[tag + "_kp2"] = res["kp2_list"]
+        print("  sampled", tag, res["kp1_list"].shape)
+    np.savez_compressed(os.path.join(HERE, "sampled_kp.npz"), **out)
+
+
 def golden_gric():
     gric = load_by_path("ref_gric", os.path.join(REF, "libs/tracker/gric.py"))
     rng = np.random.Generator(np.random.PCG64(21))
@@ -242,6 +273,51 @@ def golden_tracker():
     np.savez_compressed(os.path.join(HERE, "e_tracker.npz"), **out)
 
 
+def golden_tracker_flow():
+    """the reference's EssTracker with e_tracker.validity.method 'flow' (ablation_model_sel_flow.yml) over the cv2 shim"""
+    from oracle import cv2_shim
+    sys.modules["cv2"] = cv2_shim
+    try:
+        import matplotlib.pyplot  # noqa: F401
+    except Exception:
+        mpl = types.ModuleType("matplotlib")
+        mpl.pyplot = types.ModuleType("matplotlib.pyplot")
+        sys.modules["matplotlib"] = mpl
+        sys.modules["matplotlib.pyplot"] = mpl.pyplot
+    from easydict import EasyDict
+    from libs.tracker.E_tracker import EssTracker
+    from libs.general.timer import Timer
+    from libs.geometry.camera_modules import Intrinsics
+    cfg = EasyDict({
+        "kp_selection": {"rigid_flow_kp": {"enable": False}},
+        "e_tracker": {"ransac": {"reproj_thre": 0.2, "repeat": 5}, "validity": {"method": "flow", "thre": 5},
+                      "kp_src": "kp_best", "iterative_kp": {"enable": False}},
+        "scale_recovery": {"method": "simple", "kp_src": "kp_best", "iterative_kp": {"enable": False, "kp_src": "kp_depth"},
+                           "ransac": {"method": "depth_ratio", "min_samples": 3, "max_trials": 100, "stop_prob": 0.99,
+                                      "thre": 0.1}},
+        "image": {"height": 376, "width": 1241}})
+    out = {}
+    # a, b: ordinary motion (mean flow well above 5 px); c: nearly static pair (gate closed: identity pose and NO draw
+    # from np.random); d: almost only outliers
+    for tag, (seed, n, of, noise, shrink) in {"a": (51, 2000, 0.3, 0.15, 1.0), "b": (52, 1200, 0.6, 0.3, 1.0),
+                                              "c": (53, 2000, 0.2, 0.1, 0.02), "d": (54, 2000, 0.97, 0.2, 1.0)}.items():
+        c = tracker_case(seed, n, of, noise)
+        kp_ref = c["kp_ref"]
+        kp_cur = kp_ref + (c["kp_cur"] - kp_ref) * shrink
+        K = c["K"]
+        cam = Intrinsics([K[0, 2], K[1, 2], K[0, 0], K[1, 1]])
+        trk = EssTracker(cfg, cam, Timer())
+        np.random.seed(4869 + seed)
+        res = trk.compute_pose_2d2d(kp_ref, kp_cur, True)
+        out[tag + "_spec"] = np.array([seed, n, of, noise, shrink])
+        out[tag + "_pose"] = res["pose"].pose.copy()
+        out[tag + "_inliers"] = res["inliers"].copy()
+        st = np.random.get_state()
+        out[tag + "_rng_after"] = np.r_[st[1].astype(np.uint32), np.uint32(st[2])]
+        print("  tracker(flow)", tag, "inliers", int(res["inliers"].sum()), "t", res["pose"].t.ravel())
+    np.savez_compressed(os.path.join(HERE, "e_tracker_flow.npz"), **out)
+
+
 LANCZOS_CASES = [  # (seed, H, W, out_h, out_w): KITTI frame -> monodepth2 feed, RobotCar crop -> feed, down / up / one axis
     (31, 376, 1241, 192, 640), (32, 768, 1280, 256, 640), (33, 37, 53, 20, 31), (34, 20, 31, 37, 53),
     (35, 100, 100, 100, 57), (36, 64, 48, 192, 48)]
@@ -279,7 +355,8 @@ if __name__ == "__main__":
     torch.set_num_threads(8)
     which = [a for a in sys.argv[1:] if not a.startswith("--")]
     todo = {"liteflownet": golden_liteflownet, "monodepth2": golden_monodepth2, "kp": golden_kp_selection,
-            "gric": golden_gric, "tracker": golden_tracker, "lanczos": golden_lanczos}
+            "gric": golden_gric, "tracker": golden_tracker, "lanczos": golden_lanczos, "sampled": golden_kp_sampled,
+            "tracker_flow": golden_tracker_flow}
     for name, fn in todo.items():
         if not which or name in which:
             print("==", name)

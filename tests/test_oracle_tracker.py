@@ -83,3 +83,38 @@ def test_e_tracker_matches_reference_fixture():
             assert abs(scale - float(g[tag + "_scale"])) <= 1e-12 * abs(scale), tag
         st = np.random.get_state()
         assert np.array_equal(np.r_[st[1].astype(np.uint32), np.uint32(st[2])], g[tag + "_rng_after"]), tag
+
+
+def flow_case(g, tag):
+    """inputs of the e_tracker_flow fixtures: tracker_case with the displacement scaled by `shrink`"""
+    seed, n, of, noise, shrink = g[tag + "_spec"]
+    c = tracker_case(int(seed), int(n), float(of), float(noise))
+    kp_cur = c["kp_ref"] + (c["kp_cur"] - c["kp_ref"]) * float(shrink)
+    return int(seed), c["kp_ref"], kp_cur, c["K"]
+
+
+def test_e_tracker_flow_validity_matches_reference_fixture():
+    """e_tracker.validity.method 'flow' (ablation_model_sel_flow.yml): poses, masks and the RandomState afterwards"""
+    g = np.load(os.path.join(G, "e_tracker_flow.npz"))
+    for tag in "abcd":
+        seed, kp_ref, kp_cur, K = flow_case(g, tag)
+        np.random.seed(4869 + seed)
+        res = T.compute_pose_2d2d(kp_ref, kp_cur, K, validity="flow", validity_thre=5)
+        pose = g[tag + "_pose"]
+        assert np.array_equal(res["inliers"], g[tag + "_inliers"]), tag
+        assert np.array_equal(res["R"], pose[:3, :3]) and np.array_equal(res["t"], pose[:3, 3:]), tag
+        st = np.random.get_state()
+        assert np.array_equal(np.r_[st[1].astype(np.uint32), np.uint32(st[2])], g[tag + "_rng_after"]), tag
+
+
+def test_sampled_kp_matches_reference_fixture():
+    """sampled_kp + generate_kp_samples (ablation_correspondences_uniform.yml)"""
+    g = np.load(os.path.join(G, "sampled_kp.npz"))
+    for tag in "abc":
+        h, w, seed, nkp = [int(v) for v in g[tag + "_spec"][:4]]
+        crop = [[float(g[tag + "_spec"][4]), float(g[tag + "_spec"][5])], [float(g[tag + "_spec"][6]), float(g[tag + "_spec"][7])]]
+        _, flow = kp_case(h, w, seed, 0.5)
+        idx = T.generate_kp_samples(h, w, crop, nkp)
+        assert np.array_equal(idx, g[tag + "_idx"]), tag
+        kp1, kp2 = T.sampled_kp(flow, idx, crop)
+        assert np.array_equal(kp1, g[tag + "_kp1"]) and np.array_equal(kp2, g[tag + "_kp2"]), tag

@@ -181,3 +181,67 @@ def test_scale_recovery_small_populations(gpu, trk):
             assert info[1] == diag["n_trials"] and info[2] == diag["n_inliers"]
             assert abs(scale.value - s_ref) <= 1e-12 * abs(s_ref)
         assert np.array_equal(pull_rng(gpu, trk), np_state())
+
+
+def _pose2d2d(gpu, trk, kp_ref, kp_cur, K, **kw):
+    n = kp_ref.shape[0]
+    cfg = gpu.Pose2d2dCfg(fx=K[0, 0], cx=K[0, 2], cy=K[1, 2], reproj_thre=0.2, repeat=5, max_iters=1000, **kw)
+    KinvT, Kinv = np.linalg.inv(K.T), np.linalg.inv(K)
+    for i in range(9):
+        cfg.KinvT[i] = KinvT.flat[i]
+        cfg.Kinv[i] = Kinv.flat[i]
+    out = gpu.Pose2d2dOut()
+    inl = np.zeros(max(n, 1), np.uint8)
+    gpu.check(gpu.lib().dfvo_compute_pose_2d2d(trk, gpu.as_ptr(np.ascontiguousarray(kp_ref)),
+                                               gpu.as_ptr(np.ascontiguousarray(kp_cur)), n, C.byref(cfg), C.byref(out),
+                                               gpu.as_ptr(inl)))
+    return out, inl[:n] == 1
+
+
+@pytest.mark.parametrize("tag", list("abcd"))
+def test_compute_pose_2d2d_flow_validity(gpu, trk, tag):
+    """e_tracker.validity.method 'flow' (ablation_model_sel_flow.yml) against the reference fixture and the oracle:
+    pose, inlier mask, per-repeat counts and the RandomState afterwards (a closed gate draws nothing)"""
+    import os
+    from test_oracle_tracker import flow_case
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "e_tracker_flow.npz"))
+    seed, kp_ref, kp_cur, K = flow_case(g, tag)
+    np.random.seed(4869 + seed)
+    push_rng(gpu, trk)
+    ref = T.compute_pose_2d2d(kp_ref, kp_cur, K, validity="flow", validity_thre=5)
+    out, inl = _pose2d2d(gpu, trk, kp_ref, kp_cur, K, validity_method=1, validity_thre=5.0)
+    R = np.array(out.R[:]).reshape(3, 3)
+    t = np.array(out.t[:]).reshape(3, 1)
+    print("flow validity %s: avg flow %.3f | oracle reps %s cheir %s valid %s | hip reps %s cheir %s valid %s" % (
+        tag, ref["avg_flow"], ref["rep_inliers"], ref["rep_cheirality"], ref["rep_valid"], list(out.rep_inliers[:5]),
+        [int(v) for v in out.rep_gric[:5]], list(out.rep_valid[:5])))
+    assert abs(out.h_gric - ref["avg_flow"]) == 0  # numpy's pairwise mean, bit for bit
+    if ref["rep_inliers"]:
+        assert list(out.rep_inliers[:5]) == ref["rep_inliers"]
+        assert [int(v) for v in out.rep_gric[:5]] == ref["rep_cheirality"]
+        assert [bool(v) for v in out.rep_valid[:5]] == ref["rep_valid"]
+    else:
+        assert out.num_valid == 0 and out.best_inlier_cnt == 0
+    pose = g[tag + "_pose"]
+    assert np.array_equal(inl, ref["inliers"]) and np.array_equal(inl, g[tag + "_inliers"])
+    assert np.array_equal(R, ref["R"]) and np.array_equal(t, ref["t"])
+    assert np.array_equal(R, pose[:3, :3]) and np.array_equal(t, pose[:3, 3:])
+    assert np.array_equal(pull_rng(gpu, trk), np_state()), "RandomState diverged"
+    assert np.array_equal(pull_rng(gpu, trk), g[tag + "_rng_after"])
+
+
+@pytest.mark.parametrize("tag", list("abc"))
+def test_sampled_kp_bit_exact(gpu, trk, tag):
+    """sampled_kp (ablation_correspondences_uniform.yml) against the reference fixture"""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sampled_kp.npz"))
+    spec = g[tag + "_spec"]
+    h, w, seed, nkp = [int(v) for v in spec[:4]]
+    crop = [[float(spec[4]), float(spec[5])], [float(spec[6]), float(spec[7])]]
+    _, flow = kp_case(h, w, seed, 0.5)
+    idx = np.ascontiguousarray(T.generate_kp_samples(h, w, crop, nkp), np.int32)
+    y0, y1, x0, x1 = int(h * crop[0][0]), int(h * crop[0][1]), int(w * crop[1][0]), int(w * crop[1][1])
+    kp1, kp2 = np.zeros((nkp, 2)), np.zeros((nkp, 2))
+    gpu.check(gpu.lib().dfvo_kp_sampled(trk, gpu.as_ptr(np.ascontiguousarray(flow)), h, w, y0, y1, x0, x1, gpu.as_ptr(idx),
+                                        nkp, gpu.as_ptr(kp1), gpu.as_ptr(kp2)))
+    assert np.array_equal(kp1, g[tag + "_kp1"][0]) and np.array_equal(kp2, g[tag + "_kp2"][0])
