@@ -104,3 +104,36 @@ def test_depthnet_vs_oracle(gpu, h, w):
     lib.dfvo_depthnet_destroy(net)
     assert np.isfinite(depth).all()
     assert e <= 1e-3 * max(1.0, s)
+
+
+@pytest.mark.parametrize("h,w,check_oracle", [(960, 1280, True), (1280, 1920, False)])
+def test_flownet_large_configs(gpu, h, w, check_oracle):
+    """BASELINE configs 4 / 5 (RobotCar 1280x960 frames, synthetic 1920x1280 pairs).  Size-independent property: the net
+    runs the (ref, cur) and (cur, ref) pairs as the two samples of one batch, so swapping the inputs must swap the
+    forward and backward flows bit for bit.  At 960x1280 the coarse pyramid levels and the final flow are additionally
+    compared with the torch-CPU oracle (tolerance as in test_flownet_vs_oracle)."""
+    lib = gpu.lib()
+    sd = O.liteflownet_state_dict(4869)
+    ref_img, cur_img = image_pair(h, w, seed=2000 + h)
+    net, nh, nw = make_flownet(gpu, h, w, sd)
+    assert (nh, nw) == O.get_target_size(h, w)
+    outs = []
+    for a, b in ((ref_img, cur_img), (cur_img, ref_img)):
+        fwd = np.zeros((2, h, w), np.float32)
+        bwd = np.zeros((2, h, w), np.float32)
+        diff = np.zeros((h, w), np.float32)
+        gpu.check(lib.dfvo_flownet_forward_host(net, gpu.as_ptr(a), gpu.as_ptr(b), gpu.as_ptr(fwd), gpu.as_ptr(bwd),
+                                                gpu.as_ptr(diff)))
+        outs.append((fwd, bwd, diff))
+    print("   %dx%d (net %dx%d): useful GFLOP per forward %.1f" % (h, w, nh, nw, lib.dfvo_flownet_last_flops(net) / 1e9))
+    lib.dfvo_flownet_destroy(net)
+    for o in outs:
+        assert all(np.isfinite(x).all() for x in o)
+    assert np.array_equal(outs[0][0], outs[1][1]) and np.array_equal(outs[0][1], outs[1][0])
+    assert np.abs(outs[0][0]).max() > 0
+    if check_oracle:
+        O._grid_cache.clear()
+        ofwd, obwd, odiff = O.flow_inference(sd, ref_img, cur_img)
+        e1, s1 = report("fwd flow %dx%d" % (h, w), outs[0][0], ofwd)
+        e2, s2 = report("bwd flow %dx%d" % (h, w), outs[0][1], obwd)
+        assert e1 <= 2e-3 * max(1.0, s1 / 10) and e2 <= 2e-3 * max(1.0, s2 / 10)
