@@ -24,6 +24,12 @@ class Pose2d2dCfg(C.Structure):
                 ("validity_method", C.c_int), ("validity_thre", C.c_double)]
 
 
+class RigidKpCfg(C.Structure):
+    _fields_ = [("num_row", C.c_int), ("num_col", C.c_int), ("num_bestN", C.c_int), ("rigid_flow_thre", C.c_double),
+                ("optical_flow_thre", C.c_double), ("score_method", C.c_int), ("K", C.c_double * 9),
+                ("Kinv", C.c_double * 9), ("T_ref_to_cur", C.c_double * 16)]
+
+
 class Pose2d2dOut(C.Structure):
     _fields_ = [("R", C.c_double * 9), ("t", C.c_double * 3), ("n", C.c_int), ("best_inlier_cnt", C.c_int),
                 ("num_valid", C.c_int), ("major_valid", C.c_int), ("cheirality", C.c_int), ("h_found", C.c_int),
@@ -129,6 +135,7 @@ SIGNATURES = {
     "dfvo_tracker_get_rng_state": (_i, [_vp, _vp]),
     "dfvo_kp_local_bestn": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _ip, _ip]),
     "dfvo_kp_sampled": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "dfvo_kp_rigid_flow": (_i, [_vp, _vp, _vp, _vp, _i, _i, C.POINTER(RigidKpCfg), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dfvo_compute_pose_2d2d": (_i, [_vp, _vp, _vp, _i, C.POINTER(Pose2d2dCfg), C.POINTER(Pose2d2dOut), _vp]),
     "dfvo_pipeline_create": (_i, [C.POINTER(PipelineCfg), C.POINTER(_vp)]),
     "dfvo_pipeline_destroy": (None, [_vp]),

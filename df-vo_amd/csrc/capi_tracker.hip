@@ -11,6 +11,7 @@ struct dfvo_tracker {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     TrackerBuffers tb;
+    RigidKpBuffers rigid;
     RansacWorkspace& ws = tb.ws_e;
     float *d_flow = nullptr, *d_diff = nullptr;
     double* d_depth = nullptr;
@@ -50,6 +51,7 @@ void dfvo_tracker_destroy(dfvo_tracker* t) {
     if (!t) return;
     t->tb.release();
     t->pnp.release();
+    t->rigid.release();
     if (t->d_flow) (void)hipFree(t->d_flow);
     if (t->d_diff) (void)hipFree(t->d_diff);
     if (t->d_depth) (void)hipFree(t->d_depth);
@@ -240,6 +242,68 @@ int dfvo_kp_sampled(dfvo_tracker* t, const float* h_flow, int H, int W, int y0, 
     (void)hipFree(d_idx);
     (void)hipFree(d_kp);
     return rc;
+}
+
+int dfvo_kp_rigid_flow(dfvo_tracker* t, const float* h_flow, const float* h_flow_diff, const float* h_raw_depth, int H,
+                       int W, const dfvo_rigid_kp_cfg* cfg, const float* h_rigid_diff_override, double* h_kp1_best,
+                       double* h_kp2_best, double* h_kp1_uniform, double* h_kp2_uniform, int* n_out,
+                       float* h_rigid_flow_diff) {
+    DFVO_ARG_CHECK(t && h_flow && h_flow_diff && h_raw_depth && cfg && h_kp1_best && h_kp2_best && h_kp1_uniform &&
+                       h_kp2_uniform && n_out && H > 0 && W > 0,
+                   "dfvo_kp_rigid_flow: bad argument");
+    DFVO_ARG_CHECK(cfg->score_method == 0 || cfg->score_method == 1, "dfvo_kp_rigid_flow: score_method");
+    const size_t px = (size_t)H * W;
+    if (px > t->flow_cap) {
+        if (t->d_flow) (void)hipFree(t->d_flow);
+        if (t->d_diff) (void)hipFree(t->d_diff);
+        t->flow_cap = px;
+        DFVO_HIP_CHECK(hipMalloc((void**)&t->d_flow, sizeof(float) * 2 * px));
+        DFVO_HIP_CHECK(hipMalloc((void**)&t->d_diff, sizeof(float) * px));
+    }
+    RigidKpConfig rc;
+    rc.num_row = cfg->num_row;
+    rc.num_col = cfg->num_col;
+    rc.num_bestN = cfg->num_bestN;
+    rc.rigid_thre = (float)cfg->rigid_flow_thre;
+    rc.opt_thre = (float)cfg->optical_flow_thre;
+    rc.score_rigid = cfg->score_method;
+    for (int i = 0; i < 9; i++) {
+        rc.K[i] = (float)cfg->K[i];
+        rc.Kinv[i] = (float)cfg->Kinv[i];
+    }
+    for (int i = 0; i < 16; i++) rc.T[i] = (float)cfg->T_ref_to_cur[i];
+    DFVO_ARG_CHECK(rc.num_row > 0 && rc.num_col > 0, "dfvo_kp_rigid_flow: grid");
+    const int cells = rc.num_row * rc.num_col;
+    int rcode = t->rigid.ensure(H, W, cells, rc.num_bestN / cells > 0 ? rc.num_bestN / cells : 1,
+                                (H / rc.num_row + 2) * (W / rc.num_col + 2));
+    if (rcode != DFVO_OK) return rcode;
+    hipStream_t s = t->stream;
+    DFVO_HIP_CHECK(hipMemcpyAsync(t->d_flow, h_flow, sizeof(float) * 2 * px, hipMemcpyHostToDevice, s));
+    DFVO_HIP_CHECK(hipMemcpyAsync(t->d_diff, h_flow_diff, sizeof(float) * px, hipMemcpyHostToDevice, s));
+    DFVO_HIP_CHECK(hipMemcpyAsync(t->rigid.depth32, h_raw_depth, sizeof(float) * px, hipMemcpyHostToDevice, s));
+    const float* ovr = nullptr;
+    if (h_rigid_diff_override) {
+        DFVO_HIP_CHECK(hipMemcpyAsync(t->rigid.rdiff, h_rigid_diff_override, sizeof(float) * px, hipMemcpyHostToDevice, s));
+        ovr = t->rigid.rdiff;
+    }
+    rcode = enqueue_rigid_flow_kp(t->rigid, t->d_flow, t->d_diff, t->rigid.depth32, H, W, rc, ovr, s);
+    if (rcode != DFVO_OK) return rcode;
+    int info[8];
+    DFVO_HIP_CHECK(hipMemcpyAsync(info, t->rigid.info, sizeof(info), hipMemcpyDeviceToHost, s));
+    DFVO_HIP_CHECK(hipStreamSynchronize(s));
+    const int n = info[0];
+    DFVO_ARG_CHECK(n == info[4], "dfvo_kp_rigid_flow: internal count mismatch");
+    *n_out = n;
+    if (n > 0) {
+        const size_t sc = (size_t)t->rigid.sel_cap * 2, bytes = sizeof(double) * 2 * n;
+        DFVO_HIP_CHECK(hipMemcpy(h_kp1_best, t->rigid.kp, bytes, hipMemcpyDeviceToHost));
+        DFVO_HIP_CHECK(hipMemcpy(h_kp2_best, t->rigid.kp + sc, bytes, hipMemcpyDeviceToHost));
+        DFVO_HIP_CHECK(hipMemcpy(h_kp1_uniform, t->rigid.kp + 2 * sc, bytes, hipMemcpyDeviceToHost));
+        DFVO_HIP_CHECK(hipMemcpy(h_kp2_uniform, t->rigid.kp + 3 * sc, bytes, hipMemcpyDeviceToHost));
+    }
+    if (h_rigid_flow_diff)
+        DFVO_HIP_CHECK(hipMemcpy(h_rigid_flow_diff, t->rigid.rdiff, sizeof(float) * px, hipMemcpyDeviceToHost));
+    return DFVO_OK;
 }
 
 static int stage_kp(dfvo_tracker* t, const double* h_a, const double* h_b, int n) {

@@ -269,6 +269,229 @@ __global__ __launch_bounds__(256) void k_kp_gather(const int* __restrict__ cell_
     }
 }
 
+// ================================================================================================
+// rigid-flow keypoints (RigidFlow layer + opt_rigid_flow_kp, the "kp_depth" correspondences of
+// scale_recovery.method iterative / the extended-paper configurations)
+// ================================================================================================
+// RigidFlow(depth, T, K, inv_K, normalized=False) (geometry/rigid_flow.py, backprojection.py:56-62,
+// transformation3d.py:29, projection.py:46-52, layers.py PixToFlow:262) and its distance to the optical flow
+// (E_tracker.py:685-689), all in float32.  Every matmul row is a short dot product that torch's CPU GEMM evaluates as
+// a0*b0 rounded, then fused multiply-adds in ascending k; written out the same way, the result is bit-identical to the
+// torch-CPU oracle.  Kinv: 3x3, T: 4x4, K: 3x3 (its 4th column in the reference is zero).
+__global__ void k_rigid_flow_diff(const float* __restrict__ depth, const float* __restrict__ flow, int H, int W,
+                                  const float* __restrict__ mats /*Kinv[9] | T[16] | K[9]*/, float* __restrict__ rdiff,
+                                  float* __restrict__ rflow /*optional [2,H,W]*/) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= H * W) return;
+    const float* Ki = mats;
+    const float* T = mats + 9;
+    const float* K = mats + 25;
+    const float x = (float)(i % W), y = (float)(i / W);
+    const float d = depth[i];
+    float P[4];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        float a = Ki[r * 3] * x;
+        a = __builtin_fmaf(Ki[r * 3 + 1], y, a);
+        a = __builtin_fmaf(Ki[r * 3 + 2], 1.0f, a);
+        P[r] = d * a;
+    }
+    P[3] = 1.0f;
+    float Q[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float a = T[r * 4] * P[0];
+        a = __builtin_fmaf(T[r * 4 + 1], P[1], a);
+        a = __builtin_fmaf(T[r * 4 + 2], P[2], a);
+        a = __builtin_fmaf(T[r * 4 + 3], P[3], a);
+        Q[r] = a;
+    }
+    float U[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        float a = K[r * 3] * Q[0];
+        a = __builtin_fmaf(K[r * 3 + 1], Q[1], a);
+        a = __builtin_fmaf(K[r * 3 + 2], Q[2], a);
+        a = __builtin_fmaf(0.0f, Q[3], a);  // the zero 4th column of the 3x4 intrinsics
+        U[r] = a;
+    }
+    const float den = U[2] + 1e-7f;
+    const float rx = U[0] / den - x, ry = U[1] / den - y;
+    if (rflow) {
+        rflow[i] = rx;
+        rflow[(size_t)H * W + i] = ry;
+    }
+    const float dx = rx - flow[i], dy = ry - flow[(size_t)H * W + i];
+    rdiff[i] = sqrtf(dx * dx + dy * dy);  // np.linalg.norm(axis=0) on float32: sqrt(x*x + y*y), each step rounded
+}
+
+// opt_rigid_flow_kp (kp_selection.py:203-324), one workgroup per grid cell: candidates = pixels of the cell (last row /
+// column dropped) with rigid-flow distance < thr_r AND forward-backward distance < thr_o, in row-major order;
+// "uniform" picks every step-th candidate, "best" the num_to_pick smallest scores in numpy's argpartition order
+__global__ __launch_bounds__(256) void k_kp_cell_rigid(const float* __restrict__ odiff, const float* __restrict__ rdiff,
+                                                        int H, int W, int num_row, int num_col, float thr_o, float thr_r,
+                                                        int score_rigid, int n_best, int cap, int* __restrict__ cell_count,
+                                                        int* __restrict__ cell_sel, int* __restrict__ cell_sel_uni,
+                                                        unsigned short* __restrict__ lidx_all, int par) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    float* vals = reinterpret_cast<float*>(smem_raw) + 4;
+    unsigned short* tosort = reinterpret_cast<unsigned short*>(vals + cap + 4);
+    unsigned short* Lpos = tosort + cap + 2;
+    unsigned short* Rpos = Lpos + cap + 2;
+    __shared__ int s_ctl[8], s_wsum[4];
+    unsigned short* lidx = lidx_all + (size_t)blockIdx.x * cap;
+    __shared__ int s_base, s_wave[4];
+    const int cell = blockIdx.x;
+    const int row = cell / num_col, col = cell - row * num_col;
+    int y0, y1, x0, x1;
+    sm::kp_cell_bounds(H, W, num_row, num_col, row, col, &y0, &y1, &x0, &x1);
+    const int th = y1 - y0 > 0 ? y1 - y0 : 0, tw = x1 - x0 > 0 ? x1 - x0 : 0;
+    const int total = th * tw;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) s_base = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < total; c0 += 256) {
+        const int e = c0 + t;
+        bool f = false;
+        float v = 0.f;
+        if (e < total) {
+            const int ly = e / tw, lx = e - ly * tw;
+            const size_t g = (size_t)(y0 + ly) * W + x0 + lx;
+            const float vr = rdiff[g], vo = odiff[g];
+            f = (vr < thr_r) && (vo < thr_o);
+            v = score_rigid ? vr : vo;
+        }
+        const unsigned long long b = __ballot(f);
+        const int before = __popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[wave] = __popcll(b);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wave; w++) off += s_wave[w];
+        if (f) {
+            const int pos = off + before;
+            vals[pos] = v;
+            tosort[pos] = (unsigned short)pos;
+            lidx[pos] = (unsigned short)e;
+        }
+        __syncthreads();
+        if (t == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+    }
+    const int cnt = s_base;
+    const int pick = cnt < n_best ? cnt : n_best;
+    if (pick > 0) {
+        const int step = cnt / pick;  // np.arange(0, cnt, step)[:pick]
+        if (t < pick) {
+            const int e = lidx[t * step];
+            const int ly = e / tw, lx = e - ly * tw;
+            cell_sel_uni[cell * n_best + t] = ((y0 + ly) << 16) | (x0 + lx);
+        }
+        if (par) {
+            kp_introselect_block(vals, tosort, cnt, pick - 1, Lpos, Rpos, s_ctl, s_wsum);
+        } else if (t == 0) {
+            sm::kp_introselect_cp<unsigned short>(vals, tosort, cnt, pick - 1, 0);
+        }
+    }
+    if (t == 0) cell_count[cell] = pick;
+    __syncthreads();
+    if (t < pick) {
+        const int e = lidx[tosort[t]];
+        const int ly = e / tw, lx = e - ly * tw;
+        cell_sel[cell * n_best + t] = ((y0 + ly) << 16) | (x0 + lx);
+    }
+}
+
+void RigidKpBuffers::release() {
+    void* ptrs[] = {depth32, rdiff, mats, cell_count, cell_sel, cell_sel_uni, lidx, kp, info, zero};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    depth32 = rdiff = mats = nullptr;
+    cell_count = cell_sel = cell_sel_uni = info = zero = nullptr;
+    lidx = nullptr;
+    kp = nullptr;
+    px_cap = sel_cap = 0;
+    lidx_cap = 0;
+}
+
+int RigidKpBuffers::ensure(int H, int W, int cells, int n_best, int cap) {
+    const size_t px = (size_t)H * W;
+    if (px > px_cap) {
+        if (depth32) (void)hipFree(depth32);
+        if (rdiff) (void)hipFree(rdiff);
+        px_cap = px;
+        DFVO_HIP_CHECK(hipMalloc((void**)&depth32, sizeof(float) * px));
+        DFVO_HIP_CHECK(hipMalloc((void**)&rdiff, sizeof(float) * px));
+    }
+    if (!mats) {
+        DFVO_HIP_CHECK(hipMalloc((void**)&mats, sizeof(float) * 40));
+        DFVO_HIP_CHECK(hipMalloc((void**)&cell_count, sizeof(int) * 1024));
+        DFVO_HIP_CHECK(hipMalloc((void**)&info, sizeof(int) * 8));
+        DFVO_HIP_CHECK(hipMalloc((void**)&zero, sizeof(int) * 2));
+        DFVO_HIP_CHECK(hipMemset(zero, 0, sizeof(int) * 2));
+    }
+    if (cells * n_best > sel_cap) {
+        for (void* p : {(void*)cell_sel, (void*)cell_sel_uni, (void*)kp})
+            if (p) (void)hipFree(p);
+        sel_cap = cells * n_best;
+        DFVO_HIP_CHECK(hipMalloc((void**)&cell_sel, sizeof(int) * sel_cap));
+        DFVO_HIP_CHECK(hipMalloc((void**)&cell_sel_uni, sizeof(int) * sel_cap));
+        DFVO_HIP_CHECK(hipMalloc((void**)&kp, sizeof(double) * 8 * sel_cap));
+    }
+    if ((size_t)cells * cap > lidx_cap) {
+        if (lidx) (void)hipFree(lidx);
+        lidx_cap = (size_t)cells * cap;
+        DFVO_HIP_CHECK(hipMalloc((void**)&lidx, sizeof(unsigned short) * lidx_cap));
+    }
+    return DFVO_OK;
+}
+
+// rigid flow of the reference depth under `T` (ref -> cur), its distance to the optical flow (kept in rb.rdiff), then
+// the two keypoint sets: rb.kp = [kp1_best | kp2_best | kp1_uniform | kp2_uniform], each sel_cap x 2 doubles;
+// rb.info[0] = their common count.  d_rdiff_override (optional) replaces the computed distance map.
+int enqueue_rigid_flow_kp(RigidKpBuffers& rb, const float* d_flow, const float* d_odiff, const float* d_depth32, int H,
+                          int W, const RigidKpConfig& cfg, const float* d_rdiff_override, hipStream_t s) {
+    const int cells = cfg.num_row * cfg.num_col;
+    DFVO_ARG_CHECK(cells > 0 && cells <= 1024 && H < 65536 && W < 65536, "rigid_flow_kp: grid too large");
+    const int n_best = cfg.num_bestN / cells;
+    DFVO_ARG_CHECK(n_best >= 1 && n_best <= 256, "rigid_flow_kp: n_best out of range");
+    const int cap = (H / cfg.num_row + 2) * (W / cfg.num_col + 2);
+    DFVO_ARG_CHECK(cap < 65536, "rigid_flow_kp: cell larger than 65535 pixels");
+    size_t lds = (size_t)cap * (4 + 2) + 32;
+    DFVO_ARG_CHECK(lds <= 158 * 1024, "rigid_flow_kp: cell does not fit in LDS");
+    const int par = lds + (size_t)cap * 4 + 16 <= 150 * 1024 ? 1 : 0;
+    if (par) lds += (size_t)cap * 4 + 16;
+    int rc = rb.ensure(H, W, cells, n_best, cap);
+    if (rc != DFVO_OK) return rc;
+    static size_t configured = 0;
+    if (lds > configured) {
+        DFVO_HIP_CHECK(hipFuncSetAttribute((const void*)k_kp_cell_rigid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        configured = lds;
+    }
+    const float* rdiff = d_rdiff_override;
+    if (!rdiff) {
+        float m[34];
+        for (int i = 0; i < 9; i++) m[i] = cfg.Kinv[i];
+        for (int i = 0; i < 16; i++) m[9 + i] = cfg.T[i];
+        for (int i = 0; i < 9; i++) m[25 + i] = cfg.K[i];
+        DFVO_HIP_CHECK(hipMemcpyAsync(rb.mats, m, sizeof(m), hipMemcpyHostToDevice, s));
+        DFVO_HIP_CHECK(hipStreamSynchronize(s));  // `m` is a stack buffer
+        hipLaunchKernelGGL(k_rigid_flow_diff, dim3(cdiv(H * W, 256)), dim3(256), 0, s, d_depth32, d_flow, H, W, rb.mats,
+                           rb.rdiff, (float*)nullptr);
+        rdiff = rb.rdiff;
+    }
+    hipLaunchKernelGGL(k_kp_cell_rigid, dim3(cells), dim3(256), lds, s, d_odiff, rdiff, H, W, cfg.num_row, cfg.num_col,
+                       cfg.opt_thre, cfg.rigid_thre, cfg.score_rigid, n_best, cap, rb.cell_count, rb.cell_sel,
+                       rb.cell_sel_uni, rb.lidx, par);
+    // both sets in cell order; no "enough keypoints" rules here (the reference asserts a non-empty selection)
+    const size_t sc = (size_t)rb.sel_cap * 2;
+    hipLaunchKernelGGL(k_kp_gather, dim3(1), dim3(256), 0, s, rb.cell_count, rb.cell_sel, cells, n_best, d_flow, H, W, rb.zero, 0,
+                       0, rb.kp, rb.kp + sc, rb.info);
+    hipLaunchKernelGGL(k_kp_gather, dim3(1), dim3(256), 0, s, rb.cell_count, rb.cell_sel_uni, cells, n_best, d_flow, H, W,
+                       rb.zero, 0, 0, rb.kp + 2 * sc, rb.kp + 3 * sc, rb.info + 4);
+    DFVO_HIP_CHECK(hipGetLastError());
+    return DFVO_OK;
+}
+
 // sampled_kp (kp_selection.py:327-378): the k-th pixel (row-major) of the cropped grid [y0:y1, x0:x1] for every k of
 // the uniform index list; kp1 = (x, y), kp2 = kp1 + flow (float32 promoted to float64, as numpy does)
 __global__ void k_kp_sampled(const float* __restrict__ flow, int H, int W, int y0, int x0, int cw,

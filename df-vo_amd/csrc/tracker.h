@@ -127,6 +127,25 @@ struct TrackerBuffers {
 
 int enqueue_local_bestn(TrackerBuffers& tb, const float* d_flow, const float* d_diff, int H, int W, int num_row,
                         int num_col, int num_bestN, float thre, hipStream_t s);
+// rigid-flow keypoints (E_tracker.py:645-705 kp_selection_good_depth)
+struct RigidKpConfig {
+    int num_row, num_col, num_bestN;
+    float rigid_thre, opt_thre;
+    int score_rigid;              // 1: score = rigid-flow distance, 0: forward-backward distance
+    float K[9], Kinv[9], T[16];   // float32 intrinsics, their inverse, the ref -> cur motion (row-major)
+};
+struct RigidKpBuffers {
+    float *depth32 = nullptr, *rdiff = nullptr, *mats = nullptr;
+    int *cell_count = nullptr, *cell_sel = nullptr, *cell_sel_uni = nullptr, *info = nullptr, *zero = nullptr;
+    unsigned short* lidx = nullptr;
+    double* kp = nullptr;         // [4][sel_cap][2]: kp1 best, kp2 best, kp1 uniform, kp2 uniform
+    size_t px_cap = 0, lidx_cap = 0;
+    int sel_cap = 0;
+    int ensure(int H, int W, int cells, int n_best, int cap);
+    void release();
+};
+int enqueue_rigid_flow_kp(RigidKpBuffers& rb, const float* d_flow, const float* d_odiff, const float* d_depth32, int H,
+                          int W, const RigidKpConfig& cfg, const float* d_rdiff_override, hipStream_t s);
 int enqueue_kp_sampled(const float* d_flow, int H, int W, int y0, int y1, int x0, int x1, const int* d_idx, int n,
                        double* d_kp1, double* d_kp2, hipStream_t s);
 int enqueue_mt_seed(TrackerBuffers& tb, uint32_t seed, hipStream_t s);

@@ -2,13 +2,14 @@
 571-643) over the C ABI: every cv2 / sklearn / gric call of the reference runs in HIP kernels
 (dfvo_compute_pose_2d2d, dfvo_find_scale_from_depth); this class only marshals numpy arrays and threads
 the global np.random stream through the device.  No CPU fallback."""
+import copy
 import ctypes as C
 
 import numpy as np
 
 from ... import capi
 from ..geometry.camera_modules import SE3
-from . import _ctx
+from . import _ctx, rigid_kp
 
 
 class EssTracker:
@@ -18,9 +19,6 @@ class EssTracker:
         self.prev_pose = SE3()
         self.cam_intrinsics = cam_intrinsics
         self.timers = timers
-        if self.cfg.kp_selection.rigid_flow_kp.enable:
-            raise NotImplementedError("rigid_flow_kp (extended-paper configs) is not part of the MI355X hot path yet "
-                                      "(SURVEY.md section 8f rank 1)")
         self.max_iters = 1000  # OpenCV 3.4.3's fixed findEssentialMat budget
 
     def compute_pose_2d2d(self, kp_ref, kp_cur, is_iterative):
@@ -61,10 +59,50 @@ class EssTracker:
 
     def scale_recovery(self, cur_data, ref_data, E_pose, is_iterative):
         """E_tracker.py:442-471"""
-        if self.cfg.scale_recovery.method != "simple":
-            raise NotImplementedError("scale_recovery.method 'iterative' needs the rigid-flow layers "
-                                      "(SURVEY.md section 8f rank 1)")
-        return {"scale": self.scale_recovery_simple(cur_data, ref_data, E_pose, is_iterative)}
+        outputs = {}
+        if self.cfg.scale_recovery.method == "simple":
+            outputs['scale'] = self.scale_recovery_simple(cur_data, ref_data, E_pose, is_iterative)
+        elif self.cfg.scale_recovery.method == "iterative":
+            iter_outputs = self.scale_recovery_iterative(cur_data, ref_data, E_pose)
+            outputs['scale'] = iter_outputs['scale']
+            outputs['cur_kp_depth'] = iter_outputs['cur_kp']
+            outputs['ref_kp_depth'] = iter_outputs['ref_kp']
+            outputs['rigid_flow_mask'] = iter_outputs['rigid_flow_mask']
+        else:
+            raise NotImplementedError("scale_recovery.method '%s'" % self.cfg.scale_recovery.method)
+        return outputs
+
+    def scale_recovery_iterative(self, cur_data, ref_data, E_pose):
+        """E_tracker.py:509-569: up to five rounds of (rigid-flow keypoints under the current scale -> depth-ratio scale)"""
+        outputs = {}
+        scale = self.prev_scale
+        delta = 0.001
+        for _ in range(5):
+            rigid_flow_pose = copy.deepcopy(E_pose)
+            rigid_flow_pose.t *= scale
+            ref_data['rigid_flow_pose'] = SE3(rigid_flow_pose.inv_pose)
+            kp_sel_outputs = self.kp_selection_good_depth(cur_data, ref_data,
+                                                          self.cfg.scale_recovery.iterative_kp.score_method)
+            ref_data['kp_depth'] = kp_sel_outputs['kp1_depth_uniform'][0]
+            cur_data['kp_depth'] = kp_sel_outputs['kp2_depth_uniform'][0]
+            cur_data['rigid_flow_mask'] = kp_sel_outputs['rigid_flow_mask']
+            cur_kp = cur_data[self.cfg.scale_recovery.kp_src]
+            ref_kp = ref_data[self.cfg.scale_recovery.kp_src]
+            new_scale = self.find_scale_from_depth(ref_kp, cur_kp, E_pose.inv_pose, cur_data['depth'])
+            delta_scale = np.abs(new_scale - scale)
+            scale = new_scale
+            self.prev_scale = new_scale
+            outputs['scale'] = scale
+            outputs['cur_kp'] = cur_data['kp_depth']
+            outputs['ref_kp'] = ref_data['kp_depth']
+            outputs['rigid_flow_mask'] = cur_data['rigid_flow_mask']
+            if delta_scale < delta:
+                return outputs
+        return outputs
+
+    def kp_selection_good_depth(self, cur_data, ref_data, rigid_kp_score_method):
+        """E_tracker.py:645-705 (see rigid_kp.kp_selection_good_depth)"""
+        return rigid_kp.kp_selection_good_depth(self.cfg, self.cam_intrinsics, cur_data, ref_data, rigid_kp_score_method)
 
     def scale_recovery_simple(self, cur_data, ref_data, E_pose, is_iterative):
         """E_tracker.py:473-507"""
@@ -101,4 +139,12 @@ class EssTracker:
         return -1 if scale.value == -1.0 else scale.value
 
     def compute_rigid_flow_kp(self, cur_data, ref_data, pose):
-        raise NotImplementedError("compute_rigid_flow_kp: extended-paper path, SURVEY.md section 8f rank 1")
+        """E_tracker.py:422-440"""
+        rigid_pose = copy.deepcopy(pose)
+        ref_data['rigid_flow_pose'] = SE3(rigid_pose.inv_pose)
+        kp_sel_outputs = self.kp_selection_good_depth(cur_data, ref_data, self.cfg.e_tracker.iterative_kp.score_method)
+        ref_data['kp_depth'] = kp_sel_outputs['kp1_depth'][0]
+        cur_data['kp_depth'] = kp_sel_outputs['kp2_depth'][0]
+        ref_data['kp_depth_uniform'] = kp_sel_outputs['kp1_depth_uniform'][0]
+        cur_data['kp_depth_uniform'] = kp_sel_outputs['kp2_depth_uniform'][0]
+        cur_data['rigid_flow_mask'] = kp_sel_outputs['rigid_flow_mask']

@@ -1,18 +1,18 @@
 """PnpTracker with the reference's surface (/root/reference/libs/tracker/pnp_tracker.py:22-125).
 The fallback path (E-tracker rejected or scale == -1, dfvo.py:225-250)."""
+import copy
+
 import numpy as np
 
 from ... import capi
 from ..geometry.camera_modules import SE3
-from . import _ctx
+from . import _ctx, rigid_kp
 
 
 class PnpTracker:
     def __init__(self, cfg, cam_intrinsics):
         self.cfg = cfg
         self.cam_intrinsics = cam_intrinsics
-        if self.cfg.kp_selection.rigid_flow_kp.enable:
-            raise NotImplementedError("rigid_flow_kp is not part of the MI355X hot path yet (SURVEY.md 8f rank 1)")
 
     def compute_pose_3d2d(self, kp1, kp2, depth_1, is_iterative):
         """pnp_tracker.py:45-125 -> {'pose': SE3 (view-2 -> view-1), 'kp1', 'kp2'}"""
@@ -48,4 +48,16 @@ class PnpTracker:
         return {"pose": pose, "kp1": kp1[sel], "kp2": kp2[sel]}
 
     def compute_rigid_flow_kp(self, cur_data, ref_data, pose):
-        raise NotImplementedError("compute_rigid_flow_kp: extended-paper path, SURVEY.md section 8f rank 1")
+        """pnp_tracker.py:127-145"""
+        rigid_pose = copy.deepcopy(pose)
+        ref_data['rigid_flow_pose'] = SE3(rigid_pose.inv_pose)
+        kp_sel_outputs = self.kp_selection_good_depth(cur_data, ref_data, self.cfg.pnp_tracker.iterative_kp.score_method)
+        ref_data['kp_depth'] = kp_sel_outputs['kp1_depth'][0]
+        cur_data['kp_depth'] = kp_sel_outputs['kp2_depth'][0]
+        ref_data['kp_depth_uniform'] = kp_sel_outputs['kp1_depth_uniform'][0]
+        cur_data['kp_depth_uniform'] = kp_sel_outputs['kp2_depth_uniform'][0]
+        cur_data['rigid_flow_mask'] = kp_sel_outputs['rigid_flow_mask']
+
+    def kp_selection_good_depth(self, cur_data, ref_data, rigid_kp_score_method):
+        """pnp_tracker.py:148-213 (see rigid_kp.kp_selection_good_depth)"""
+        return rigid_kp.kp_selection_good_depth(self.cfg, self.cam_intrinsics, cur_data, ref_data, rigid_kp_score_method)

@@ -196,6 +196,26 @@ int dfvo_kp_local_bestn(dfvo_tracker* trk, const float* h_flow, const float* h_d
 int dfvo_kp_sampled(dfvo_tracker* trk, const float* h_flow, int H, int W, int y0, int y1, int x0, int x1,
                     const int* h_idx, int n, double* h_kp1, double* h_kp2);
 
+/* EssTracker.kp_selection_good_depth (E_tracker.py:645-705): RigidFlow layer of the reference
+ * depth under the ref -> cur motion (geometry/{rigid_flow,reprojection,backprojection,transformation3d,projection}.py,
+ * float32), its per-pixel distance to the optical flow, then opt_rigid_flow_kp (kp_selection.py:203-324): per grid
+ * cell the pixels with rigid distance < rigid_flow_thre and forward-backward distance < optical_flow_thre; "best" =
+ * argpartition by the score, "uniform" = every step-th candidate.  h_raw_depth float [H,W] (the unprocessed CNN depth of
+ * the reference frame), h_flow float [2,H,W], h_flow_diff float [H,W].  Outputs [num_bestN,2] doubles each, *n_out rows
+ * valid (same count for both sets); h_rigid_flow_diff (optional, float [H,W]) receives the distance map ("rigid_flow_mask");
+ * h_rigid_diff_override (optional) is used instead of the computed map. */
+typedef struct dfvo_rigid_kp_cfg {
+    int num_row, num_col, num_bestN;       /* kp_selection.rigid_flow_kp.{num_row,num_col,num_bestN} */
+    double rigid_flow_thre, optical_flow_thre;
+    int score_method;                      /* 0 "opt_flow", 1 "rigid_flow" */
+    double K[9], Kinv[9];                  /* intrinsics and np.linalg.inv of them (cast to float32 like .float()) */
+    double T_ref_to_cur[16];               /* ref_data['rigid_flow_pose'].pose */
+} dfvo_rigid_kp_cfg;
+int dfvo_kp_rigid_flow(dfvo_tracker* trk, const float* h_flow, const float* h_flow_diff, const float* h_raw_depth, int H,
+                       int W, const dfvo_rigid_kp_cfg* cfg, const float* h_rigid_diff_override, double* h_kp1_best,
+                       double* h_kp2_best, double* h_kp1_uniform, double* h_kp2_uniform, int* n_out,
+                       float* h_rigid_flow_diff);
+
 /* EssTracker.compute_pose_2d2d (E_tracker.py:154-307).  validity_method DFVO_VALIDITY_GRIC (default configuration):
  * homography + GRIC-H, `repeat` x (shuffle, findEssentialMat, GRIC-E), best-of by inlier count, recoverPose,
  * cheirality > 10 %.  DFVO_VALIDITY_FLOW (ablation_model_sel_flow.yml): the pair is tracked only when the mean keypoint

@@ -190,6 +190,118 @@ def sampled_kp(flow, kp_list, crop=None):
     return np.transpose(a, (1, 0, 2)), np.transpose(b, (1, 0, 2))
 
 
+def _dot_fma_f32(coefs, vals):
+    """float32 dot product the way the fixtures' torch-CPU GEMM evaluates it: a0*b0 rounded, then fused multiply-adds in
+    ascending k.  fma(a, b, c) is emulated through float64 (the product of two float32 is exact there)."""
+    acc = None
+    for a, v in zip(coefs, vals):
+        if acc is None:
+            acc = (np.float32(a) * v).astype(np.float32)
+        else:
+            acc = (np.float64(a) * v.astype(np.float64) + acc.astype(np.float64)).astype(np.float32)
+    return acc
+
+
+def rigid_flow(raw_depth, T, K):
+    """RigidFlow layer (geometry/rigid_flow.py:17-58 = Backprojection (backprojection.py:56-62) -> Transformation3D
+    (transformation3d.py:29) -> Projection(normalized=False) (projection.py:46-52) -> PixToFlow (layers.py:262)) in
+    float32, as E_tracker.py:672-683 calls it.  raw_depth [H,W] f32, T [4,4], K [3,3] -> [2,H,W] f32.
+    torch.matmul's float32 rounding depends on the BLAS kernel the host CPU selects (the same torch build gives
+    different last bits on the build container and on the GPU box), so the three small matmuls are written out with the
+    operation order of the machine that produced tests/golden/rigid_flow_kp.npz by running the reference itself;
+    tests/test_oracle_tracker.py pins this restatement to that fixture bit for bit."""
+    f32 = np.float32
+    h, w = raw_depth.shape
+    K4, iK4 = np.eye(4), np.eye(4)
+    K4[:3, :3] = K
+    iK4[:3, :3] = np.linalg.inv(K)
+    K4, iK4, Tf = K4.astype(f32), iK4.astype(f32), np.asarray(T).astype(f32)
+    xx, yy = np.meshgrid(np.arange(w, dtype=f32), np.arange(h, dtype=f32))
+    one = np.ones_like(xx)
+    d = np.ascontiguousarray(raw_depth, dtype=f32)
+    P = [(d * _dot_fma_f32(iK4[r, :3], [xx, yy, one])).astype(f32) for r in range(3)] + [one]
+    Q = [_dot_fma_f32(Tf[r], P) for r in range(4)]
+    U = [_dot_fma_f32(K4[r], Q) for r in range(3)]
+    den = (U[2] + f32(1e-7)).astype(f32)
+    return np.stack([((U[0] / den).astype(f32) - xx).astype(f32), ((U[1] / den).astype(f32) - yy).astype(f32)])
+
+
+def opt_rigid_flow_kp(flow, flow_diff, rigid_flow_diff, score_method="opt_flow", num_bestN=2000, num_row=10, num_col=10,
+                      rigid_thre=5, opt_thre=0.1, argpartition=argpartition_c):
+    """kp_selection.py:203-324.  flow [2,H,W] f32, flow_diff / rigid_flow_diff [H,W,1] f32 ->
+    dict(kp1_depth, kp2_depth, kp1_depth_uniform, kp2_depth_uniform [1,N,2], rigid_flow_mask [H,W])"""
+    h, w, _ = rigid_flow_diff.shape
+    kp1 = np.expand_dims(image_grid(h, w), 0)
+    kp2 = kp1 + np.transpose(np.expand_dims(flow, 0), (0, 2, 3, 1))
+    n_best = math.floor(num_bestN / (num_col * num_row))
+    rdiff = np.expand_dims(rigid_flow_diff, 0)
+    odiff = np.expand_dims(flow_diff, 0)
+    best, uni = [], []
+    for row in range(num_row):
+        for col in range(num_col):
+            x0 = [int(h / num_row * row), int(w / num_col * col)]
+            x1 = [int(h / num_row * (row + 1)) - 1, int(w / num_col * (col + 1)) - 1]
+            to = odiff[:, x0[0]:x1[0], x0[1]:x1[1]].copy()
+            tr = rdiff[:, x0[0]:x1[0], x0[1]:x1[1]].copy()
+            mask = (tr < rigid_thre) * (to < opt_thre)
+            score = tr if score_method == "rigid_flow" else to
+            where = np.where(mask)
+            cnt = len(where[0])
+            num_to_pick = min(n_best, cnt)
+            if num_to_pick > 0:
+                step = int(cnt / num_to_pick)
+                sel = np.arange(0, cnt, step)[:num_to_pick]
+            else:
+                sel = []
+            for i in sel:
+                uni.append((where[1][i] + x0[0], where[2][i] + x0[1]))
+            order = argpartition(score[where], num_to_pick - 1)[:num_to_pick]
+            for i in order:
+                best.append((where[1][i] + x0[0], where[2][i] + x0[1]))
+    assert len(best) != 0, "sampling threshold is too small."
+    out = {}
+    for name, sel in (("depth", best), ("depth_uniform", uni)):
+        ys = np.asarray([s[0] for s in sel], np.int64)
+        xs = np.asarray([s[1] for s in sel], np.int64)
+        out["kp1_" + name] = kp1[:, ys, xs].copy()
+        out["kp2_" + name] = kp2[:, ys, xs].copy()
+    out["rigid_flow_mask"] = rdiff[0, :, :, 0]
+    return out
+
+
+def kp_selection_good_depth(flow, flow_diff, raw_depth, rigid_flow_pose, K, score_method="opt_flow", **kw):
+    """E_tracker.py:645-705: rigid flow of the reference depth under `rigid_flow_pose`, its distance to the optical flow,
+    then opt_rigid_flow_kp"""
+    rf = rigid_flow(raw_depth, rigid_flow_pose, K)
+    rdiff = np.linalg.norm(rf - flow, axis=0)
+    return opt_rigid_flow_kp(flow, flow_diff, np.expand_dims(rdiff, 2), score_method, **kw)
+
+
+def scale_recovery_iterative(flow, flow_diff, raw_depth, depth_cur, E_pose, K, prev_scale=0, score_method="opt_flow",
+                             kp_src="kp_depth", kp_best=None, **kw):
+    """E_tracker.py:509-569.  E_pose: 4x4 cur -> ref with unit translation.  Returns dict(scale, cur_kp, ref_kp,
+    n_iter); consumes np.random through find_scale_from_depth."""
+    scale = prev_scale
+    out = {}
+    for it in range(5):
+        P = np.array(E_pose, dtype=np.float64, copy=True)
+        P[:3, 3] *= scale
+        sel = kp_selection_good_depth(flow, flow_diff, raw_depth, np.linalg.inv(P), K, score_method, **kw)
+        ref_kp_depth, cur_kp_depth = sel["kp1_depth_uniform"][0], sel["kp2_depth_uniform"][0]
+        if kp_src == "kp_depth":
+            ref_kp, cur_kp = ref_kp_depth, cur_kp_depth
+        else:
+            ref_kp, cur_kp = kp_best
+        new_scale = find_scale_from_depth(ref_kp, cur_kp, np.linalg.inv(np.asarray(E_pose, np.float64)), depth_cur, K)
+        delta = np.abs(new_scale - scale)
+        scale = new_scale
+        out = {"scale": scale, "cur_kp": cur_kp_depth, "ref_kp": ref_kp_depth, "rigid_flow_mask": sel["rigid_flow_mask"],
+               "n_iter": it + 1}
+        if delta < 0.001:
+            return out
+    return out
+
+
 def preprocess_depth(depth, crop, depth_range):
     """utils.py:89-114"""
     min_depth, max_depth = depth_range

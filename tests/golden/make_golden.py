@@ -318,6 +318,90 @@ def golden_tracker_flow():
     np.savez_compressed(os.path.join(HERE, "e_tracker_flow.npz"), **out)
 
 
+RIGID_CASES = {"a": (192, 640, 61, "opt_flow"), "b": (192, 640, 62, "rigid_flow"), "c": (120, 200, 63, "opt_flow")}
+
+
+def rigid_case(h, w, seed):
+    """inputs of the rigid-flow keypoint fixtures (also imported by the tests): a synthetic rigid scene, its reference
+    depth as the float32 `raw_depth`, the true ref -> cur motion"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from synth import rigid_scene
+    sc = rigid_scene(int(h), int(w), seed=int(seed))
+    T = np.eye(4)
+    T[:3, :3] = sc["R"]
+    T[:3, 3] = sc["t"]
+    return dict(K=sc["K"], flow=sc["flow"], diff=sc["diff"], raw_depth=sc["depth_ref"].astype(np.float32),
+                depth_cur=sc["depth_cur"], T_ref_to_cur=T)
+
+
+def golden_rigid_flow():
+    """the reference's EssTracker.kp_selection_good_depth / scale_recovery_iterative (RigidFlow layer + opt_rigid_flow_kp,
+    ablation_scale_iterative.yml) on CPU torch"""
+    import zlib
+    from oracle import cv2_shim
+    sys.modules["cv2"] = cv2_shim
+    import sklearn.linear_model as lm
+    if getattr(lm.RANSACRegressor, "__name__", "") != "ransac_regressor_compat":
+        _RR = lm.RANSACRegressor
+
+        def ransac_regressor_compat(base_estimator=None, **kw):
+            return _RR(estimator=base_estimator, **kw)
+        lm.RANSACRegressor = ransac_regressor_compat
+    _to = torch.nn.Module.to
+    torch.nn.Module.to = lambda self, *a, **k: self  # the layers are moved "to cuda" in their constructors
+    try:
+        import matplotlib.pyplot  # noqa: F401
+    except Exception:
+        mpl = types.ModuleType("matplotlib")
+        mpl.pyplot = types.ModuleType("matplotlib.pyplot")
+        sys.modules["matplotlib"] = mpl
+        sys.modules["matplotlib.pyplot"] = mpl.pyplot
+    from easydict import EasyDict
+    from libs.tracker.E_tracker import EssTracker
+    from libs.general.timer import Timer
+    from libs.geometry.camera_modules import Intrinsics, SE3
+    out = {}
+    for tag, (h, w, seed, score) in RIGID_CASES.items():
+        c = rigid_case(h, w, seed)
+        K = c["K"]
+        cfg = EasyDict({
+            "kp_selection": {"rigid_flow_kp": {"enable": True, "num_bestN": 2000, "num_row": 10, "num_col": 10,
+                                               "score_method": score, "rigid_flow_thre": 5, "optical_flow_thre": 0.1}},
+            "e_tracker": {"ransac": {"reproj_thre": 0.2, "repeat": 5}, "validity": {"method": "GRIC", "thre": None},
+                          "kp_src": "kp_best", "iterative_kp": {"enable": False, "kp_src": "kp_depth", "score_method": score}},
+            "scale_recovery": {"method": "iterative", "kp_src": "kp_depth",
+                               "iterative_kp": {"enable": False, "kp_src": "kp_depth", "score_method": score},
+                               "ransac": {"method": "depth_ratio", "min_samples": 3, "max_trials": 100, "stop_prob": 0.99,
+                                          "thre": 0.1}},
+            "image": {"height": h, "width": w}})
+        cam = Intrinsics([K[0, 2], K[1, 2], K[0, 0], K[1, 1]])
+        trk = EssTracker(cfg, cam, Timer())
+        ref = {"flow": c["flow"], "flow_diff": c["diff"][..., None], "raw_depth": c["raw_depth"],
+               "rigid_flow_pose": SE3(c["T_ref_to_cur"])}
+        cur = {"depth": c["depth_cur"]}
+        res = trk.kp_selection_good_depth(cur, ref, score)
+        out[tag + "_spec"] = np.array([h, w, seed, 0 if score == "opt_flow" else 1])
+        for k in ("kp1_depth", "kp2_depth", "kp1_depth_uniform", "kp2_depth_uniform"):
+            out[tag + "_" + k] = res[k]
+        m = np.ascontiguousarray(res["rigid_flow_mask"], np.float32)
+        out[tag + "_mask_crc"] = np.array(zlib.crc32(m.tobytes()), np.uint32)
+        out[tag + "_mask_rows"] = m[:: max(1, h // 8)].copy()
+        # scale_recovery_iterative from prev_scale = 0 with the unit-translation pose of the E-tracker (cur -> ref)
+        E_pose = SE3(np.linalg.inv(c["T_ref_to_cur"]))
+        E_pose.t = E_pose.t / np.linalg.norm(E_pose.t)
+        np.random.seed(4869 + seed)
+        trk.prev_scale = 0
+        it = trk.scale_recovery_iterative(cur, ref, E_pose)
+        out[tag + "_iter_scale"] = np.array(float(it["scale"]))
+        out[tag + "_iter_cur_kp"] = it["cur_kp"]
+        out[tag + "_iter_ref_kp"] = it["ref_kp"]
+        st = np.random.get_state()
+        out[tag + "_rng_after"] = np.r_[st[1].astype(np.uint32), np.uint32(st[2])]
+        print("  rigid", tag, res["kp1_depth"].shape, res["kp1_depth_uniform"].shape, "iterative scale", it["scale"])
+    torch.nn.Module.to = _to
+    np.savez_compressed(os.path.join(HERE, "rigid_flow_kp.npz"), **out)
+
+
 LANCZOS_CASES = [  # (seed, H, W, out_h, out_w): KITTI frame -> monodepth2 feed, RobotCar crop -> feed, down / up / one axis
     (31, 376, 1241, 192, 640), (32, 768, 1280, 256, 640), (33, 37, 53, 20, 31), (34, 20, 31, 37, 53),
     (35, 100, 100, 100, 57), (36, 64, 48, 192, 48)]
@@ -356,7 +440,7 @@ if __name__ == "__main__":
     which = [a for a in sys.argv[1:] if not a.startswith("--")]
     todo = {"liteflownet": golden_liteflownet, "monodepth2": golden_monodepth2, "kp": golden_kp_selection,
             "gric": golden_gric, "tracker": golden_tracker, "lanczos": golden_lanczos, "sampled": golden_kp_sampled,
-            "tracker_flow": golden_tracker_flow}
+            "tracker_flow": golden_tracker_flow, "rigid": golden_rigid_flow}
     for name, fn in todo.items():
         if not which or name in which:
             print("==", name)

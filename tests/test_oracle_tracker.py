@@ -118,3 +118,28 @@ def test_sampled_kp_matches_reference_fixture():
         assert np.array_equal(idx, g[tag + "_idx"]), tag
         kp1, kp2 = T.sampled_kp(flow, idx, crop)
         assert np.array_equal(kp1, g[tag + "_kp1"]) and np.array_equal(kp2, g[tag + "_kp2"]), tag
+
+
+def test_rigid_flow_kp_and_iterative_scale_match_reference_fixture():
+    """RigidFlow layer + opt_rigid_flow_kp + scale_recovery_iterative (ablation_scale_iterative.yml)
+    against fixtures produced by the reference's own E_tracker.py / kp_selection.py / geometry layers on CPU torch"""
+    import zlib
+    from golden.make_golden import RIGID_CASES, rigid_case
+    g = np.load(os.path.join(G, "rigid_flow_kp.npz"))
+    for tag, (h, w, seed, score) in RIGID_CASES.items():
+        c = rigid_case(h, w, seed)
+        res = T.kp_selection_good_depth(c["flow"], c["diff"][..., None], c["raw_depth"], c["T_ref_to_cur"], c["K"], score)
+        for k in ("kp1_depth", "kp2_depth", "kp1_depth_uniform", "kp2_depth_uniform"):
+            assert np.array_equal(res[k], g[tag + "_" + k]), (tag, k)
+        m = np.ascontiguousarray(res["rigid_flow_mask"], np.float32)
+        assert np.array_equal(m[:: max(1, h // 8)], g[tag + "_mask_rows"])
+        assert zlib.crc32(m.tobytes()) == int(g[tag + "_mask_crc"])
+        E_pose = np.linalg.inv(c["T_ref_to_cur"])
+        E_pose[:3, 3] /= np.linalg.norm(E_pose[:3, 3])
+        np.random.seed(4869 + seed)
+        it = T.scale_recovery_iterative(c["flow"], c["diff"][..., None], c["raw_depth"], c["depth_cur"], E_pose, c["K"], 0,
+                                        score)
+        assert abs(it["scale"] - float(g[tag + "_iter_scale"])) <= 1e-12 * abs(it["scale"]), tag
+        assert np.array_equal(it["cur_kp"], g[tag + "_iter_cur_kp"]) and np.array_equal(it["ref_kp"], g[tag + "_iter_ref_kp"])
+        st = np.random.get_state()
+        assert np.array_equal(np.r_[st[1].astype(np.uint32), np.uint32(st[2])], g[tag + "_rng_after"]), tag

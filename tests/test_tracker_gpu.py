@@ -245,3 +245,56 @@ def test_sampled_kp_bit_exact(gpu, trk, tag):
     gpu.check(gpu.lib().dfvo_kp_sampled(trk, gpu.as_ptr(np.ascontiguousarray(flow)), h, w, y0, y1, x0, x1, gpu.as_ptr(idx),
                                         nkp, gpu.as_ptr(kp1), gpu.as_ptr(kp2)))
     assert np.array_equal(kp1, g[tag + "_kp1"][0]) and np.array_equal(kp2, g[tag + "_kp2"][0])
+
+
+@pytest.mark.parametrize("tag", list("abc"))
+def test_rigid_flow_kp_and_iterative_scale(gpu, trk, tag):
+    """SURVEY 8f rank 1 (ablation_scale_iterative.yml): RigidFlow layer + opt_rigid_flow_kp + scale_recovery_iterative
+    through the mirror classes, against the fixtures produced by the reference's own code on CPU torch.  Float32
+    rigid-flow distance map: bit-exact (the fused multiply-add order of the torch-CPU GEMM that produced the fixture); keypoints: bit-exact values
+    and order; iterative scale: 1e-12 relative; RandomState afterwards identical."""
+    import importlib
+    import os
+    import zlib
+    from types import SimpleNamespace as NS
+    from golden.make_golden import RIGID_CASES, rigid_case
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "rigid_flow_kp.npz"))
+    h, w, seed, score = RIGID_CASES[tag]
+    c = rigid_case(h, w, seed)
+    K = c["K"]
+    cam_mod = importlib.import_module("df-vo_amd.libs.geometry.camera_modules")
+    E_mod = importlib.import_module("df-vo_amd.libs.tracker.E_tracker")
+    ctx = importlib.import_module("df-vo_amd.libs.tracker._ctx")
+    rfk = NS(enable=True, num_bestN=2000, num_row=10, num_col=10, score_method=score, rigid_flow_thre=5, optical_flow_thre=0.1)
+    cfg = NS(kp_selection=NS(rigid_flow_kp=rfk),
+             e_tracker=NS(ransac=NS(reproj_thre=0.2, repeat=5), validity=NS(method="GRIC", thre=None), kp_src="kp_best",
+                          iterative_kp=NS(enable=False, kp_src="kp_depth", score_method=score)),
+             scale_recovery=NS(method="iterative", kp_src="kp_depth",
+                               iterative_kp=NS(enable=False, kp_src="kp_depth", score_method=score),
+                               ransac=NS(method="depth_ratio", min_samples=3, max_trials=100, stop_prob=0.99, thre=0.1)),
+             image=NS(height=h, width=w))
+    cam = cam_mod.Intrinsics([K[0, 2], K[1, 2], K[0, 0], K[1, 1]])
+    et = E_mod.EssTracker(cfg, cam, None)
+    ref = {"flow": c["flow"], "flow_diff": c["diff"][..., None], "raw_depth": c["raw_depth"],
+           "rigid_flow_pose": cam_mod.SE3(c["T_ref_to_cur"].copy())}
+    cur = {"depth": c["depth_cur"]}
+    res = et.kp_selection_good_depth(cur, ref, score)
+    m = np.ascontiguousarray(res["rigid_flow_mask"], np.float32)
+    want = T.kp_selection_good_depth(c["flow"], c["diff"][..., None], c["raw_depth"], c["T_ref_to_cur"], K, score)
+    nbad = int((m != want["rigid_flow_mask"]).sum())
+    print("rigid-flow distance map %s: %d / %d differ from the oracle, max |diff| %.3g" % (
+        tag, nbad, m.size, float(np.abs(m - want["rigid_flow_mask"]).max())))
+    assert nbad == 0
+    assert zlib.crc32(m.tobytes()) == int(g[tag + "_mask_crc"])
+    for k in ("kp1_depth", "kp2_depth", "kp1_depth_uniform", "kp2_depth_uniform"):
+        assert np.array_equal(res[k], g[tag + "_" + k]), (tag, k)
+    # scale_recovery_iterative from prev_scale = 0 (the numpy stream runs through the device-resident RandomState)
+    E_pose = cam_mod.SE3(np.linalg.inv(c["T_ref_to_cur"]))
+    E_pose.t = E_pose.t / np.linalg.norm(E_pose.t)
+    np.random.seed(4869 + seed)
+    et.prev_scale = 0
+    out = et.scale_recovery(cur, ref, E_pose, False)
+    assert abs(out["scale"] - float(g[tag + "_iter_scale"])) <= 1e-12 * abs(out["scale"])
+    assert np.array_equal(out["cur_kp_depth"], g[tag + "_iter_cur_kp"]) and np.array_equal(out["ref_kp_depth"], g[tag + "_iter_ref_kp"])
+    st = np.random.get_state()
+    assert np.array_equal(np.r_[st[1].astype(np.uint32), np.uint32(st[2])], g[tag + "_rng_after"])
