@@ -135,6 +135,7 @@ SIGNATURES = {
     "dfvo_tracker_get_rng_state": (_i, [_vp, _vp]),
     "dfvo_kp_local_bestn": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _ip, _ip]),
     "dfvo_kp_sampled": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "dfvo_kp_bestn": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "dfvo_kp_rigid_flow": (_i, [_vp, _vp, _vp, _vp, _i, _i, C.POINTER(RigidKpCfg), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dfvo_compute_pose_2d2d": (_i, [_vp, _vp, _vp, _i, C.POINTER(Pose2d2dCfg), C.POINTER(Pose2d2dOut), _vp]),
     "dfvo_pipeline_create": (_i, [C.POINTER(PipelineCfg), C.POINTER(_vp)]),

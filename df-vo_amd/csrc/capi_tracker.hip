@@ -12,6 +12,7 @@ struct dfvo_tracker {
     bool own_stream = false;
     TrackerBuffers tb;
     RigidKpBuffers rigid;
+    BestNBuffers bestn;
     RansacWorkspace& ws = tb.ws_e;
     float *d_flow = nullptr, *d_diff = nullptr;
     double* d_depth = nullptr;
@@ -52,6 +53,7 @@ void dfvo_tracker_destroy(dfvo_tracker* t) {
     t->tb.release();
     t->pnp.release();
     t->rigid.release();
+    t->bestn.release();
     if (t->d_flow) (void)hipFree(t->d_flow);
     if (t->d_diff) (void)hipFree(t->d_diff);
     if (t->d_depth) (void)hipFree(t->d_depth);
@@ -199,6 +201,33 @@ int dfvo_kp_local_bestn(dfvo_tracker* t, const float* h_flow, const float* h_dif
     if (info[1] && info[0] > 0) {
         DFVO_HIP_CHECK(hipMemcpy(h_kp1, t->tb.kp_ref, sizeof(double) * 2 * info[0], hipMemcpyDeviceToHost));
         DFVO_HIP_CHECK(hipMemcpy(h_kp2, t->tb.kp_cur, sizeof(double) * 2 * info[0], hipMemcpyDeviceToHost));
+    }
+    return DFVO_OK;
+}
+
+int dfvo_kp_bestn(dfvo_tracker* t, const float* h_flow, const float* h_diff, int H, int W, int num_bestN, double* h_kp1,
+                  double* h_kp2, int* n_out) {
+    DFVO_ARG_CHECK(t && h_flow && h_diff && h_kp1 && h_kp2 && n_out && H > 0 && W > 0 && num_bestN >= 1,
+                   "dfvo_kp_bestn: bad argument");
+    const size_t px = (size_t)H * W;
+    if (px > t->flow_cap) {
+        if (t->d_flow) (void)hipFree(t->d_flow);
+        if (t->d_diff) (void)hipFree(t->d_diff);
+        t->flow_cap = px;
+        DFVO_HIP_CHECK(hipMalloc((void**)&t->d_flow, sizeof(float) * 2 * px));
+        DFVO_HIP_CHECK(hipMalloc((void**)&t->d_diff, sizeof(float) * px));
+    }
+    DFVO_HIP_CHECK(hipMemcpyAsync(t->d_flow, h_flow, sizeof(float) * 2 * px, hipMemcpyHostToDevice, t->stream));
+    DFVO_HIP_CHECK(hipMemcpyAsync(t->d_diff, h_diff, sizeof(float) * px, hipMemcpyHostToDevice, t->stream));
+    int rc = enqueue_bestn_flow_kp(t->bestn, t->d_flow, t->d_diff, H, W, num_bestN, t->stream);
+    if (rc != DFVO_OK) return rc;
+    int n = 0;
+    DFVO_HIP_CHECK(hipMemcpyAsync(&n, t->bestn.count + 1, sizeof(int), hipMemcpyDeviceToHost, t->stream));
+    DFVO_HIP_CHECK(hipStreamSynchronize(t->stream));
+    *n_out = n;
+    if (n > 0) {
+        DFVO_HIP_CHECK(hipMemcpy(h_kp1, t->bestn.kp, sizeof(double) * 2 * n, hipMemcpyDeviceToHost));
+        DFVO_HIP_CHECK(hipMemcpy(h_kp2, t->bestn.kp + 2 * (size_t)num_bestN, sizeof(double) * 2 * n, hipMemcpyDeviceToHost));
     }
     return DFVO_OK;
 }

@@ -164,6 +164,229 @@ __device__ void kp_introselect_block(float* key, unsigned short* tosort, int num
 #undef KPB_SWAP
 }
 
+// The same partition for arrays that live in global memory and are too long for 16-bit positions (bestN_flow_kp selects
+// over the whole image): int positions, two plain 32-bit scans instead of one packed scan.
+__device__ __forceinline__ int kp_block_excl_scan(int v, int* s_wsum, int* total) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    int inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) s_wsum[wave] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; w++) base += s_wsum[w];
+    *total = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+    __syncthreads();
+    return base + inc - v;
+}
+
+__device__ void kp_introselect_block_global(float* key, int* tosort, int num, int kth, int* Lpos, int* Rpos, int* s_ctl,
+                                            int* s_wsum) {
+    const int t = threadIdx.x;
+    if (kth < 3 || kth == num - 1 || num < KP_PAR_MIN) {
+        if (t == 0) sm::kp_introselect_cp<int>(key, tosort, num, kth, 0);
+        __syncthreads();
+        return;
+    }
+    int low = 0, high = num - 1, depth_limit = sm::kp_msb((unsigned)num) * 2;
+    while (low + 1 < high) {
+        if (high - low < KP_PAR_MIN || depth_limit <= 0) break;
+        if (t == 0) {
+            const int mid = low + (high - low) / 2;
+#define KPG_SWAP(i, j)             \
+    {                              \
+        int _t = tosort[i];        \
+        tosort[i] = tosort[j];     \
+        tosort[j] = _t;            \
+        float _k = key[i];         \
+        key[i] = key[j];           \
+        key[j] = _k;               \
+    }
+            if (sm::kp_lt(key[high], key[mid])) KPG_SWAP(high, mid);
+            if (sm::kp_lt(key[high], key[low])) KPG_SWAP(high, low);
+            if (sm::kp_lt(key[low], key[mid])) KPG_SWAP(low, mid);
+            KPG_SWAP(mid, low + 1);
+        }
+        __threadfence_block();
+        __syncthreads();
+        const float pivot = key[low];
+        const int r0 = low + 1, n_r = high - low;
+        const int seg = (n_r + 255) / 256;
+        const int p0 = r0 + t * seg, p1 = p0 + seg < r0 + n_r ? p0 + seg : r0 + n_r;
+        int cl = 0, cr = 0;
+        for (int p = p0; p < p1; ++p) {
+            const float v = key[p];
+            cl += (p >= low + 2 && !sm::kp_lt(v, pivot)) ? 1 : 0;
+            cr += (p <= high - 1 && !sm::kp_lt(pivot, v)) ? 1 : 0;
+        }
+        int nL, nR;
+        int il = kp_block_excl_scan(cl, s_wsum, &nL);
+        int ir = kp_block_excl_scan(cr, s_wsum, &nR);
+        for (int p = p0; p < p1; ++p) {
+            const float v = key[p];
+            if (p >= low + 2 && !sm::kp_lt(v, pivot)) Lpos[il++] = p;
+            if (p <= high - 1 && !sm::kp_lt(pivot, v)) Rpos[nR - 1 - (ir++)] = p;
+        }
+        __threadfence_block();
+        __syncthreads();
+        const int npair = nL < nR ? nL : nR;
+        int cnt = 0;
+        for (int k = t; k < npair; k += 256) cnt += Lpos[k] <= Rpos[k] ? 1 : 0;
+        int K;
+        (void)kp_block_excl_scan(cnt, s_wsum, &K);
+        for (int k = t; k < K; k += 256) {
+            const int a = Lpos[k], b = Rpos[k];
+            if (a != b) KPG_SWAP(a, b);
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (t == 0) {  // crossing iteration, as in kp_introselect_block
+            int ll = Lpos[K], hh = Rpos[K];
+            if (K > 0) {
+                int rp = Rpos[K - 1], lp = Lpos[K - 1];
+                if (rp == lp) {
+                    rp = K > 1 ? Rpos[K - 2] : 0x7fffffff;
+                    lp = K > 1 ? Lpos[K - 2] : -1;
+                }
+                ll = ll < rp ? ll : rp;
+                hh = hh > lp ? hh : lp;
+            }
+            KPG_SWAP(low, hh);
+            int nlow = low, nhigh = high;
+            if (hh >= kth) nhigh = hh - 1;
+            if (hh <= kth) nlow = ll;
+            s_ctl[0] = nlow;
+            s_ctl[1] = nhigh;
+        }
+        __threadfence_block();
+        __syncthreads();
+        low = s_ctl[0];
+        high = s_ctl[1];
+        depth_limit--;
+        __syncthreads();
+    }
+    if (t == 0) sm::kp_introselect_cp_from<int>(key, tosort, kth, 0, low, high, depth_limit);
+    __syncthreads();
+#undef KPG_SWAP
+}
+
+// bestN_flow_kp (kp_selection.py:33-71, ablation_correspondences_best_n.yml): np.where(flow_diff >= 0) keeps every
+// non-NaN pixel in row-major order; np.argpartition(values, N)[:N] then picks N of them in introselect order
+__global__ void k_bestn_fill(const float* __restrict__ diff, int n, float* __restrict__ key, int* __restrict__ tosort,
+                             int* __restrict__ count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int ok = 0;
+    if (i < n) {
+        const float v = diff[i];
+        key[i] = v;
+        tosort[i] = i;
+        ok = v >= 0.f ? 1 : 0;
+    }
+    const int c = wave_sum_i(ok);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, c);
+}
+
+// one workgroup: (only when some pixels fail `>= 0`) ordered compaction, then the selection and the gather of the
+// first N picks; info[0] = number of keypoints (0 when the image has N or fewer candidates: numpy would raise)
+__global__ __launch_bounds__(256) void k_bestn_select(const float* __restrict__ diff, const float* __restrict__ flow, int H,
+                                                       int W, int N, float* __restrict__ key, int* __restrict__ tosort,
+                                                       int* __restrict__ map, int* __restrict__ Lpos, int* __restrict__ Rpos,
+                                                       const int* __restrict__ count, double* __restrict__ kp1,
+                                                       double* __restrict__ kp2, int* __restrict__ info) {
+    __shared__ int s_ctl[8], s_wsum[4], s_base;
+    const int t = threadIdx.x;
+    const int n = H * W;
+    int cnt = *count;
+    const bool identity = cnt == n;
+    if (!identity) {  // ordered compaction of the pixels that pass `>= 0`
+        if (t == 0) s_base = 0;
+        __syncthreads();
+        for (int c0 = 0; c0 < n; c0 += 256) {
+            const int e = c0 + t;
+            const float v = e < n ? diff[e] : -1.f;
+            const int f = (e < n && v >= 0.f) ? 1 : 0;
+            int tot;
+            const int ex = kp_block_excl_scan(f, s_wsum, &tot);
+            if (f) {
+                const int pos = s_base + ex;
+                key[pos] = v;
+                tosort[pos] = pos;
+                map[pos] = e;
+            }
+            __syncthreads();
+            if (t == 0) s_base += tot;
+            __syncthreads();
+        }
+        cnt = s_base;
+    }
+    if (cnt <= N) {  // kth = N out of bounds
+        if (t == 0) info[0] = 0;
+        return;
+    }
+    __threadfence_block();
+    __syncthreads();
+    kp_introselect_block_global(key, tosort, cnt, N, Lpos, Rpos, s_ctl, s_wsum);
+    __threadfence_block();
+    __syncthreads();
+    for (int i = t; i < N; i += 256) {
+        const int c = tosort[i];
+        const int e = identity ? c : map[c];
+        const int y = e / W, x = e - y * W;
+        kp1[i * 2] = (double)x;
+        kp1[i * 2 + 1] = (double)y;
+        kp2[i * 2] = (double)x + (double)flow[e];
+        kp2[i * 2 + 1] = (double)y + (double)flow[(size_t)n + e];
+    }
+    if (t == 0) info[0] = N;
+}
+
+void BestNBuffers::release() {
+    void* ptrs[] = {key_base, tosort, map, Lpos, Rpos, count, kp};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    key_base = nullptr;
+    tosort = map = Lpos = Rpos = count = nullptr;
+    kp = nullptr;
+    cap = 0;
+    kp_cap = 0;
+}
+
+int enqueue_bestn_flow_kp(BestNBuffers& bb, const float* d_flow, const float* d_diff, int H, int W, int N, hipStream_t s) {
+    DFVO_ARG_CHECK(H > 0 && W > 0 && N >= 1 && (long long)H * W < (1ll << 30), "bestN: bad size");
+    const int n = H * W;
+    if ((size_t)n > bb.cap) {
+        const int keep_kp = bb.kp_cap;
+        double* kp_keep = bb.kp;
+        bb.kp = nullptr;
+        bb.release();
+        bb.kp = kp_keep;
+        bb.kp_cap = keep_kp;
+        bb.cap = (size_t)n;
+        DFVO_HIP_CHECK(hipMalloc((void**)&bb.key_base, sizeof(float) * ((size_t)n + 16)));  // slack: the 4-wide scans over-read
+        DFVO_HIP_CHECK(hipMemset(bb.key_base, 0, sizeof(float) * ((size_t)n + 16)));
+        DFVO_HIP_CHECK(hipMalloc((void**)&bb.tosort, sizeof(int) * (size_t)n));
+        DFVO_HIP_CHECK(hipMalloc((void**)&bb.map, sizeof(int) * (size_t)n));
+        DFVO_HIP_CHECK(hipMalloc((void**)&bb.Lpos, sizeof(int) * ((size_t)n + 2)));
+        DFVO_HIP_CHECK(hipMalloc((void**)&bb.Rpos, sizeof(int) * ((size_t)n + 2)));
+        DFVO_HIP_CHECK(hipMalloc((void**)&bb.count, sizeof(int) * 4));
+    }
+    if (N > bb.kp_cap) {
+        if (bb.kp) (void)hipFree(bb.kp);
+        bb.kp_cap = N;
+        DFVO_HIP_CHECK(hipMalloc((void**)&bb.kp, sizeof(double) * 4 * (size_t)N));
+    }
+    float* key = bb.key_base + 8;
+    DFVO_HIP_CHECK(hipMemsetAsync(bb.count, 0, sizeof(int) * 4, s));
+    hipLaunchKernelGGL(k_bestn_fill, dim3(cdiv(n, 256)), dim3(256), 0, s, d_diff, n, key, bb.tosort, bb.count);
+    hipLaunchKernelGGL(k_bestn_select, dim3(1), dim3(256), 0, s, d_diff, d_flow, H, W, N, key, bb.tosort, bb.map, bb.Lpos,
+                       bb.Rpos, bb.count, bb.kp, bb.kp + 2 * (size_t)N, bb.count + 1);
+    DFVO_HIP_CHECK(hipGetLastError());
+    return DFVO_OK;
+}
+
 // one 256-thread block per grid cell: ordered (row-major) compaction of the candidates into LDS, then
 // lane 0 runs numpy's introselect on them (keys carried along with the indices, see kp_select.h); writes
 // the picked local indices in argpartition order.

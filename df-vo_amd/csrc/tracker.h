@@ -127,6 +127,17 @@ struct TrackerBuffers {
 
 int enqueue_local_bestn(TrackerBuffers& tb, const float* d_flow, const float* d_diff, int H, int W, int num_row,
                         int num_col, int num_bestN, float thre, hipStream_t s);
+// bestN_flow_kp (kp_selection.py:33-71): whole-image argpartition
+struct BestNBuffers {
+    float* key_base = nullptr;   // keys carried along with the index array, with slack on either side
+    int *tosort = nullptr, *map = nullptr, *Lpos = nullptr, *Rpos = nullptr, *count = nullptr;  // count[1] = result size
+    double* kp = nullptr;        // [kp1 | kp2], N x 2 doubles each
+    size_t cap = 0;
+    int kp_cap = 0;
+    void release();
+};
+int enqueue_bestn_flow_kp(BestNBuffers& bb, const float* d_flow, const float* d_diff, int H, int W, int N, hipStream_t s);
+
 // rigid-flow keypoints (E_tracker.py:645-705 kp_selection_good_depth)
 struct RigidKpConfig {
     int num_row, num_col, num_bestN;

@@ -1,5 +1,6 @@
 """KeypointSampler with the reference's surface (/root/reference/libs/matching/keypoint_sampler.py:18-163)
-over dfvo_kp_local_bestn (local_bestN, kp_selection.py:74-200) and dfvo_kp_sampled (sampled_kp, :327-378)."""
+over dfvo_kp_local_bestn (local_bestN, kp_selection.py:74-200), dfvo_kp_bestn (bestN_flow_kp, :33-71) and
+dfvo_kp_sampled (sampled_kp, :327-378)."""
 import ctypes as C
 
 import numpy as np
@@ -13,9 +14,6 @@ class KeypointSampler:
         self.cfg = cfg
         self.kps = {}
         ks = self.cfg.kp_selection
-        if ks.bestN.enable:
-            raise NotImplementedError("kp_selection.bestN (whole-image argpartition, ablation_correspondences_best_n.yml) "
-                                      "is not on the device yet; local_bestN and sampled_kp are")
         if ks.sampled_kp.enable:  # keypoint_sampler.py:29-36
             self.kps['uniform'] = self.generate_kp_samples(img_h=self.cfg.image.height, img_w=self.cfg.image.width,
                                                            crop=self.cfg.crop.flow_crop, N=ks.sampled_kp.num_kp)
@@ -37,9 +35,26 @@ class KeypointSampler:
         outputs = {"good_kp_found": True}
         if self.cfg.kp_selection.local_bestN.enable:
             outputs.update(self._local_bestN(cur_data, ref_data))
+        elif self.cfg.kp_selection.bestN.enable:
+            outputs.update(self._bestN(cur_data, ref_data))
         if self.cfg.kp_selection.sampled_kp.enable:
             outputs.update(self._sampled_kp(cur_data, ref_data))
         return outputs
+
+    def _bestN(self, cur_data, ref_data):
+        """bestN_flow_kp (kp_selection.py:33-71) on the device (dfvo_kp_bestn)"""
+        flow = np.ascontiguousarray(ref_data['flow'], dtype=np.float32)
+        diff = np.ascontiguousarray(ref_data['flow_diff'], dtype=np.float32)
+        h, w = cur_data['depth'].shape
+        assert flow.shape == (2, h, w) and diff.shape[:2] == (h, w)
+        N = int(self.cfg.kp_selection.bestN.num_bestN)
+        kp1, kp2 = np.zeros((N, 2)), np.zeros((N, 2))
+        n = C.c_int()
+        capi.check(capi.lib().dfvo_kp_bestn(_ctx.tracker(), capi.as_ptr(flow), capi.as_ptr(diff.reshape(h, w)), h, w, N,
+                                            capi.as_ptr(kp1), capi.as_ptr(kp2), C.byref(n)))
+        if n.value != N:
+            raise ValueError("kth(=%d) out of bounds (%d)" % (N, h * w))  # what np.argpartition raises in the reference
+        return {"kp1_best": kp1[None], "kp2_best": kp2[None], "fb_flow_mask": diff.reshape(h, w)}
 
     def _sampled_kp(self, cur_data, ref_data):
         """kp_selection.py:327-378 on the device (dfvo_kp_sampled)"""
@@ -85,7 +100,7 @@ class KeypointSampler:
 
     def update_kp_data(self, cur_data, ref_data, kp_sel_outputs):
         """keypoint_sampler.py:145-163"""
-        if self.cfg.kp_selection.local_bestN.enable:
+        if self.cfg.kp_selection.local_bestN.enable or self.cfg.kp_selection.bestN.enable:
             ref_data['kp_best'] = kp_sel_outputs['kp1_best'][0]
             cur_data['kp_best'] = kp_sel_outputs['kp2_best'][0]
             cur_data['fb_flow_mask'] = kp_sel_outputs['fb_flow_mask']

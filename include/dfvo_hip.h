@@ -190,6 +190,12 @@ int dfvo_tracker_get_rng_state(dfvo_tracker* trk, uint32_t* h_state625);
 int dfvo_kp_local_bestn(dfvo_tracker* trk, const float* h_flow, const float* h_diff, int H, int W, int num_row,
                         int num_col, int num_bestN, float thre, double* h_kp1, double* h_kp2, int* n_out,
                         int* good_kp_found);
+/* bestN_flow_kp (kp_selection.py:33-71, ablation_correspondences_best_n.yml): the num_bestN pixels of the whole image
+ * with the least forward-backward inconsistency, in np.argpartition(flow_diff[flow_diff >= 0], num_bestN)[:num_bestN]
+ * order (numpy's scalar introselect).  *n_out = num_bestN, or 0 when the image has no more than num_bestN candidates
+ * (numpy raises there). */
+int dfvo_kp_bestn(dfvo_tracker* trk, const float* h_flow, const float* h_diff, int H, int W, int num_bestN,
+                  double* h_kp1, double* h_kp2, int* n_out);
 /* sampled_kp (kp_selection.py:327-378, the "uniform" correspondences of ablation_correspondences_uniform.yml): for each
  * index k of h_idx[n] (KeypointSampler.generate_kp_samples' linspace over the cropped grid [y0:y1, x0:x1], row-major)
  * kp1 = (x, y) of that pixel and kp2 = kp1 + flow there; h_kp1 / h_kp2 [n,2] */

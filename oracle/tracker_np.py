@@ -168,6 +168,18 @@ def local_bestN(flow, flow_diff, num_bestN=2000, num_row=10, num_col=10, thre=0.
     return out
 
 
+def bestN_flow_kp(flow, flow_diff, N=2000, argpartition=argpartition_c):
+    """kp_selection.py:33-71.  flow [2,H,W] f32, flow_diff [H,W,1] f32 -> kp1_best, kp2_best [1,N,2]"""
+    h, w, _ = flow_diff.shape
+    kp1 = np.expand_dims(image_grid(h, w), 0)
+    kp2 = kp1 + np.transpose(np.expand_dims(flow, 0), (0, 2, 3, 1))
+    diff = np.expand_dims(flow_diff, 0)
+    where = np.where(diff >= 0)
+    sel = argpartition(diff[where], N)[:N]
+    ys, xs = where[1][sel], where[2][sel]
+    return kp1[:, ys, xs], kp2[:, ys, xs]
+
+
 def generate_kp_samples(img_h, img_w, crop, N):
     """keypoint_sampler.py:51-74: N indices spread uniformly over the cropped grid (row-major)"""
     y0, y1 = int(crop[0][0] * img_h), int(crop[0][1] * img_h)

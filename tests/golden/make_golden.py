@@ -187,6 +187,41 @@ def golden_kp_sampled():
     np.savez_compressed(os.path.join(HERE, "sampled_kp.npz"), **out)
 
 
+BESTN_CASES = {"a": (192, 640, 71, 0.6, 2000, 0), "b": (376, 1241, 72, 0.35, 2000, 0), "c": (60, 90, 73, 0.5, 300, 0),
+               "d": (120, 200, 74, 0.5, 1000, 1)}  # (h, w, seed, frac, N, with ties and NaNs)
+
+
+def bestn_case(h, w, seed, frac, hard):
+    diff, flow = kp_case(h, w, seed, frac)
+    if hard:
+        rng = np.random.Generator(np.random.PCG64(int(seed) + 1))
+        diff = (np.round(diff * 400) / 400).astype(np.float32)       # heavy ties
+        diff[rng.random(diff.shape) < 0.002] = np.float32("nan")      # NaN fails `>= 0`: dropped before the selection
+    return diff, flow
+
+
+def golden_kp_bestn():
+    """the reference's bestN_flow_kp (ablation_correspondences_best_n.yml); needs the scalar numpy selection (re-exec)"""
+    from oracle import cv2_shim
+    sys.modules["cv2"] = cv2_shim
+    import libs.matching.kp_selection as kps
+    from easydict import EasyDict
+    out = {}
+    for tag, (h, w, seed, frac, N, hard) in BESTN_CASES.items():
+        diff, flow = bestn_case(h, w, seed, frac, hard)
+        cfg = EasyDict({"kp_selection": {"bestN": {"enable": True, "num_bestN": N}}})
+        x = np.linspace(0, w - 1, w)
+        y = np.linspace(0, h - 1, h)
+        xv, yv = np.meshgrid(x, y)
+        kp1 = np.expand_dims(np.transpose(np.stack([xv, yv]), (1, 2, 0)), 0)
+        kp2 = kp1 + np.transpose(np.expand_dims(flow, 0), (0, 2, 3, 1))
+        res = kps.bestN_flow_kp(kp1=kp1, kp2=kp2, ref_data={"flow_diff": diff}, cfg=cfg, outputs={})
+        out[tag + "_kp1"] = res["kp1_best"]
+        out[tag + "_kp2"] = res["kp2_best"]
+        print("  bestN", tag, res["kp1_best"].shape)
+    np.savez_compressed(os.path.join(HERE, "bestN.npz"), **out)
+
+
 def golden_gric():
     gric = load_by_path("ref_gric", os.path.join(REF, "libs/tracker/gric.py"))
     rng = np.random.Generator(np.random.PCG64(21))
@@ -440,7 +475,7 @@ if __name__ == "__main__":
     which = [a for a in sys.argv[1:] if not a.startswith("--")]
     todo = {"liteflownet": golden_liteflownet, "monodepth2": golden_monodepth2, "kp": golden_kp_selection,
             "gric": golden_gric, "tracker": golden_tracker, "lanczos": golden_lanczos, "sampled": golden_kp_sampled,
-            "tracker_flow": golden_tracker_flow, "rigid": golden_rigid_flow}
+            "tracker_flow": golden_tracker_flow, "rigid": golden_rigid_flow, "bestn": golden_kp_bestn}
     for name, fn in todo.items():
         if not which or name in which:
             print("==", name)

@@ -143,3 +143,13 @@ def test_rigid_flow_kp_and_iterative_scale_match_reference_fixture():
         assert np.array_equal(it["cur_kp"], g[tag + "_iter_cur_kp"]) and np.array_equal(it["ref_kp"], g[tag + "_iter_ref_kp"])
         st = np.random.get_state()
         assert np.array_equal(np.r_[st[1].astype(np.uint32), np.uint32(st[2])], g[tag + "_rng_after"]), tag
+
+
+def test_bestN_flow_kp_matches_reference_fixture():
+    """bestN_flow_kp (ablation_correspondences_best_n.yml): whole-image argpartition order, incl. ties and NaNs"""
+    from golden.make_golden import BESTN_CASES, bestn_case
+    g = np.load(os.path.join(G, "bestN.npz"))
+    for tag, (h, w, seed, frac, N, hard) in BESTN_CASES.items():
+        diff, flow = bestn_case(h, w, seed, frac, hard)
+        kp1, kp2 = T.bestN_flow_kp(flow, diff, N)
+        assert np.array_equal(kp1, g[tag + "_kp1"]) and np.array_equal(kp2, g[tag + "_kp2"]), tag

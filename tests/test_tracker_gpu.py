@@ -298,3 +298,41 @@ def test_rigid_flow_kp_and_iterative_scale(gpu, trk, tag):
     assert np.array_equal(out["cur_kp_depth"], g[tag + "_iter_cur_kp"]) and np.array_equal(out["ref_kp_depth"], g[tag + "_iter_ref_kp"])
     st = np.random.get_state()
     assert np.array_equal(np.r_[st[1].astype(np.uint32), np.uint32(st[2])], g[tag + "_rng_after"])
+
+
+@pytest.mark.parametrize("tag", list("abcd"))
+def test_bestn_flow_kp_bit_exact(gpu, trk, tag):
+    """bestN_flow_kp (ablation_correspondences_best_n.yml): whole-image selection in numpy's introselect order, against
+    the fixture produced by the reference's own kp_selection.py and against the oracle"""
+    import os
+    from golden.make_golden import BESTN_CASES, bestn_case
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bestN.npz"))
+    h, w, seed, frac, N, hard = BESTN_CASES[tag]
+    diff, flow = bestn_case(h, w, seed, frac, hard)
+    kp1, kp2 = np.zeros((N, 2)), np.zeros((N, 2))
+    n = C.c_int()
+    gpu.check(gpu.lib().dfvo_kp_bestn(trk, gpu.as_ptr(np.ascontiguousarray(flow)),
+                                      gpu.as_ptr(np.ascontiguousarray(diff.reshape(h, w))), h, w, N, gpu.as_ptr(kp1),
+                                      gpu.as_ptr(kp2), C.byref(n)))
+    assert n.value == N
+    assert np.array_equal(kp1, g[tag + "_kp1"][0]) and np.array_equal(kp2, g[tag + "_kp2"][0])
+    o1, o2 = T.bestN_flow_kp(flow, diff, N)
+    assert np.array_equal(kp1, o1[0]) and np.array_equal(kp2, o2[0])
+
+
+def test_bestn_large_image_vs_oracle(gpu, trk):
+    """1280 x 1920 (BASELINE config 5 size): 2.4 M candidates through the workgroup-parallel global-memory partition"""
+    h, w, N = 1280, 1920, 2000
+    diff, flow = kp_case(h, w, 81, 0.5)
+    kp1, kp2 = np.zeros((N, 2)), np.zeros((N, 2))
+    n = C.c_int()
+    gpu.check(gpu.lib().dfvo_kp_bestn(trk, gpu.as_ptr(np.ascontiguousarray(flow)),
+                                      gpu.as_ptr(np.ascontiguousarray(diff.reshape(h, w))), h, w, N, gpu.as_ptr(kp1),
+                                      gpu.as_ptr(kp2), C.byref(n)))
+    o1, o2 = T.bestN_flow_kp(flow, diff, N)
+    assert n.value == N and np.array_equal(kp1, o1[0]) and np.array_equal(kp2, o2[0])
+    # too few candidates: numpy raises "kth out of bounds"; the C entry reports zero keypoints
+    gpu.check(gpu.lib().dfvo_kp_bestn(trk, gpu.as_ptr(np.ascontiguousarray(flow[:, :10, :10])),
+                                      gpu.as_ptr(np.ascontiguousarray(diff[:10, :10, 0])), 10, 10, 100, gpu.as_ptr(kp1),
+                                      gpu.as_ptr(kp2), C.byref(n)))
+    assert n.value == 0
