@@ -224,9 +224,10 @@ def main():
             "value": round(world * args.steps / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "KITTI seq-09-sized 1241x376 frame pairs (flow net 384x1248 batch 2, depth net "
-                                   "192x640), 2000 keypoints, findHomography + 5x findEssentialMat(1000-iteration "
-                                   "budget) + GRIC + recoverPose + depth-ratio scale RANSAC",
+            "config": {"workload": "KITTI seq-09-sized 1241x376 frame pairs (flow net 384x1248 batch 2; device LANCZOS "
+                                   "resize + depth net 192x640), 2000 keypoints, findHomography + 5x findEssentialMat"
+                                   "(1000-iteration budget) + GRIC + recoverPose + depth-ratio scale RANSAC, PnP "
+                                   "fallback (5x solvePnPRansac) where the reference takes it",
                        "frames_per_gpu": args.steps, "parallelism": "frame-batch DP x%d, one all-gather of poses" % world,
                        "solver_inputs": "synthetic rigid-scene flow/consistency/depth (random-weight nets give "
                                         "incoherent flow); net outputs are computed in the timed region",
