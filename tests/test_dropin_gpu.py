@@ -1,0 +1,158 @@
+"""GPU: the drop-in boundary as libs/dfvo.py uses it.  `track_sequence` below restates the control flow of
+DFVO.tracking (/root/reference/libs/dfvo.py:121-262: keypoint selection, E-tracker, scale recovery, optional iterative
+refinement, PnP fallback, update_global_pose :109-119) against an object with the reference's class surface.  It is run
+once over the mirror classes (df-vo_amd/libs/**, everything on the device) and once over the same surface backed by the
+oracle, on a short synthetic sequence with the numpy RandomState carried from pair to pair: poses, tracking modes and
+the RandomState must agree bit for bit (pose tolerance of the contract: 1e-4 Frobenius)."""
+import copy
+import importlib
+
+import numpy as np
+import pytest
+
+from oracle import tracker_np as T
+from synth import rigid_scene
+
+pytestmark = pytest.mark.gpu
+
+
+class NS(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+
+def make_cfg(h, w, selector="local_bestN", validity="GRIC", scale_method="simple"):
+    kp_src = "kp_list" if selector == "sampled_kp" else "kp_best"
+    it = NS(enable=False, kp_src="kp_depth", score_method="opt_flow")
+    return NS(
+        image=NS(height=h, width=w), crop=NS(flow_crop=[[0, 1], [0, 1]]), tracking_method="hybrid",
+        depth=NS(min_depth=0.0, max_depth=50.0),
+        kp_selection=NS(local_bestN=NS(enable=selector == "local_bestN", num_bestN=2000, num_row=10, num_col=10,
+                                       score_method="flow", thre=0.1),
+                        bestN=NS(enable=selector == "bestN", num_bestN=2000),
+                        sampled_kp=NS(enable=selector == "sampled_kp", num_kp=2000),
+                        rigid_flow_kp=NS(enable=scale_method == "iterative", num_bestN=2000, num_row=10, num_col=10,
+                                         score_method="opt_flow", rigid_flow_thre=5, optical_flow_thre=0.1),
+                        depth_consistency=NS(enable=False, thre=0.05)),
+        e_tracker=NS(ransac=NS(reproj_thre=0.2, repeat=5), validity=NS(method=validity, thre=5 if validity == "flow" else None),
+                     kp_src=kp_src, iterative_kp=NS(it)),
+        scale_recovery=NS(method=scale_method, kp_src="kp_depth" if scale_method == "iterative" else kp_src,
+                          iterative_kp=NS(it),
+                          ransac=NS(method="depth_ratio", min_samples=3, max_trials=100, stop_prob=0.99, thre=0.1)),
+        pnp_tracker=NS(ransac=NS(iter=100, reproj_thre=1.0, repeat=5), kp_src=kp_src, iterative_kp=NS(it)))
+
+
+class OracleSurface:
+    """KeypointSampler / EssTracker / PnpTracker methods as track_sequence calls them, answered by oracle/tracker_np.py"""
+
+    def __init__(self, cfg, K, SE3):
+        self.cfg, self.K, self.SE3, self.prev_scale = cfg, K, SE3, 0
+        if cfg.kp_selection.sampled_kp.enable:
+            self.idx = T.generate_kp_samples(cfg.image.height, cfg.image.width, cfg.crop.flow_crop, cfg.kp_selection.sampled_kp.num_kp)
+
+    def kp_selection(self, cur, ref):
+        ks = self.cfg.kp_selection
+        out = {"good_kp_found": True}
+        if ks.local_bestN.enable:
+            r = T.local_bestN(ref["flow"], ref["flow_diff"])
+            out["good_kp_found"] = r["good_kp_found"]
+            if r["good_kp_found"]:
+                out["kp1_best"], out["kp2_best"] = r["kp1_best"], r["kp2_best"]
+        elif ks.bestN.enable:
+            out["kp1_best"], out["kp2_best"] = T.bestN_flow_kp(ref["flow"], ref["flow_diff"], ks.bestN.num_bestN)
+        if ks.sampled_kp.enable:
+            out["kp1_list"], out["kp2_list"] = T.sampled_kp(ref["flow"], self.idx, self.cfg.crop.flow_crop)
+        return out
+
+    def update_kp_data(self, cur, ref, out):
+        if "kp1_best" in out:
+            ref["kp_best"], cur["kp_best"] = out["kp1_best"][0], out["kp2_best"][0]
+        if "kp1_list" in out:
+            ref["kp_list"], cur["kp_list"] = out["kp1_list"][0], out["kp2_list"][0]
+
+    def compute_pose_2d2d(self, kp_ref, kp_cur, is_iterative):
+        v = self.cfg.e_tracker.validity
+        r = T.compute_pose_2d2d(kp_ref, kp_cur, self.K, validity=v.method, validity_thre=v.thre)
+        pose = self.SE3()
+        pose.R, pose.t = r["R"], r["t"]
+        return {"pose": pose, "inliers": r["inliers"]}
+
+    def scale_recovery(self, cur, ref, E_pose, is_iterative):
+        if self.cfg.scale_recovery.method == "simple":
+            src = self.cfg.scale_recovery.kp_src
+            return {"scale": T.find_scale_from_depth(ref[src], cur[src], E_pose.inv_pose, cur["depth"], self.K)}
+        r = T.scale_recovery_iterative(ref["flow"], ref["flow_diff"], ref["raw_depth"], cur["depth"], E_pose.pose, self.K,
+                                       self.prev_scale, self.cfg.scale_recovery.iterative_kp.score_method)
+        self.prev_scale = r["scale"]
+        return {"scale": r["scale"], "cur_kp_depth": r["cur_kp"], "ref_kp_depth": r["ref_kp"],
+                "rigid_flow_mask": r["rigid_flow_mask"]}
+
+    def compute_pose_3d2d(self, kp1, kp2, depth_1, is_iterative):
+        r = T.compute_pose_3d2d(kp1, kp2, depth_1, self.K, 0.0, 50.0, 5, 100, 1.0)
+        return {"pose": self.SE3(r["pose"])}
+
+
+def track_sequence(frames, cfg, sampler, e_tracker, pnp_tracker, SE3):
+    """dfvo.py:121-262 for tracking_method 'hybrid' without the iterative keypoint refinement; frames[k] holds what
+    deep_model_inference leaves in ref_data / cur_data for pair k"""
+    global_pose = SE3()
+    out = []
+    for fr in frames:
+        ref = {"flow": fr["flow"], "flow_diff": fr["diff"][..., None], "depth": fr["depth_ref"],
+               "raw_depth": fr["depth_ref"].astype(np.float32)}
+        cur = {"depth": fr["depth_cur"]}
+        kp_sel = sampler.kp_selection(cur, ref)                                  # dfvo.py:147
+        if not kp_sel["good_kp_found"]:
+            out.append(("Constant motion", global_pose.pose.copy()))              # dfvo.py:151-161
+            continue
+        sampler.update_kp_data(cur, ref, kp_sel)
+        hybrid_pose = SE3()
+        mode = "Ess. Mat."
+        e_out = e_tracker.compute_pose_2d2d(ref[cfg.e_tracker.kp_src], cur[cfg.e_tracker.kp_src], True)   # :168
+        E_pose = e_out["pose"]
+        hybrid_pose.R = E_pose.R
+        scale = -1
+        if np.linalg.norm(E_pose.t) != 0:                                        # :184
+            scale = e_tracker.scale_recovery(cur, ref, E_pose, False)["scale"]
+            if scale != -1:
+                hybrid_pose.t = E_pose.t * scale
+        if np.linalg.norm(E_pose.t) == 0 or scale == -1:                         # :227
+            p = pnp_tracker.compute_pose_3d2d(ref[cfg.pnp_tracker.kp_src], cur[cfg.pnp_tracker.kp_src], ref["depth"], True)
+            hybrid_pose = p["pose"]
+            mode = "PnP"
+        pose = copy.deepcopy(hybrid_pose)
+        global_pose.t = global_pose.R @ pose.t * 1 + global_pose.t                # update_global_pose, dfvo.py:109-119
+        global_pose.R = global_pose.R @ pose.R
+        out.append((mode, global_pose.pose.copy()))
+    return out
+
+
+@pytest.mark.parametrize("selector,validity,scale_method", [("local_bestN", "GRIC", "simple"), ("sampled_kp", "flow", "simple"),
+                                                            ("bestN", "GRIC", "simple"), ("local_bestN", "GRIC", "iterative"),
+                                                            ("local_bestN", "flow", "iterative")])
+def test_tracking_loop_over_mirrors_equals_oracle(gpu, selector, validity, scale_method):
+    h, w = 192, 640
+    cfg = make_cfg(h, w, selector, validity, scale_method)
+    frames = [rigid_scene(h, w, seed=300 + i, bad_frac=0.3 + 0.1 * i) for i in range(3)]
+    K = frames[0]["K"]
+    cam_mod = importlib.import_module("df-vo_amd.libs.geometry.camera_modules")
+    ks_mod = importlib.import_module("df-vo_amd.libs.matching.keypoint_sampler")
+    trk_mod = importlib.import_module("df-vo_amd.libs.tracker")
+    cam = cam_mod.Intrinsics([K[0, 2], K[1, 2], K[0, 0], K[1, 1]])
+    np.random.seed(4869)
+    got = track_sequence(frames, cfg, ks_mod.KeypointSampler(cfg), trk_mod.EssTracker(cfg, cam, None),
+                         trk_mod.PnpTracker(cfg, cam), cam_mod.SE3)
+    st_hip = np.random.get_state()
+    np.random.seed(4869)
+    ora = OracleSurface(cfg, K, cam_mod.SE3)
+    want = track_sequence(frames, cfg, ora, ora, ora, cam_mod.SE3)
+    st_ref = np.random.get_state()
+    print("modes:", [m for m, _ in got], "| final translation", got[-1][1][:3, 3])
+    assert [m for m, _ in got] == [m for m, _ in want]
+    for (_, a), (_, b) in zip(got, want):
+        assert np.abs(a - b).max() <= 1e-12, np.abs(a - b).max()
+    assert np.array_equal(st_hip[1], st_ref[1]) and st_hip[2] == st_ref[2]
+    assert any(np.linalg.norm(p[:3, 3]) > 0.3 for _, p in got)  # the sequence really moved
