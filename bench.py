@@ -26,8 +26,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")  # before torch / HIP initialise: see df-vo_amd/__init__.py
 
-SLOTS = 4
-PREFETCH = os.environ.get("DFVO_BENCH_PREFETCH", "1") != "0"  # DFVO_PIPELINE_SLOTS
+SLOTS = 4  # DFVO_PIPELINE_SLOTS
+PREFETCH = os.environ.get("DFVO_BENCH_PREFETCH", "1") != "0"  # RNG-independent solver half enqueued behind the nets
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: FP32 matrix (f32 in / f32 acc)
 CFG_NAMES = ["conv_igemm_f32<2,2,4,4> 128x128", "conv_igemm_f32<1,4,2,2> 32x128", "conv_igemm_f32<4,1,4,4> 256x64",
              "conv_igemm_f32<2,2,2,2> 64x64", "conv_igemm_f32<4,1,4,2> 256x32", "conv_igemm_f32<2,2,2,1> 64x32",
@@ -125,7 +125,9 @@ def main():
         if n == 0:
             return rel_all, status
         pipe.set_ref_depth(depth=d_ref_depth)  # depth of the first reference frame (PnP fallback input)
-        ahead = 2  # the nets run two pairs ahead: the host blocks in track(k) while nets(k+1), nets(k+2) queue up
+        # nets run `ahead` pairs ahead of the solver stage (<= SLOTS - 1): with 3, each of the two flow-net instances always
+        # has its next pair queued behind the current one while track(k) blocks the host
+        ahead = int(os.environ.get("DFVO_BENCH_AHEAD", "3"))
         def feed(j):  # nets of pair j, then the RNG-independent half of its solver stage right behind them
             pipe.enqueue_nets(j % SLOTS, d_ref, d_cur, d_feed)
             if PREFETCH:
