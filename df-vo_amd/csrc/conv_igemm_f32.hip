@@ -272,11 +272,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
     }
     const bool vec_ok = conv_vec_ok(p);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col0 = n0 + wn * TN * 16 + j * 16 + kq * 4;
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + wm * TM * 16 + i * 16 + li;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + wm * TM * 16 + i * 16 + li;
+        for (int j = 0; j < TN; ++j) {  // inner: the 64-byte runs of one pixel row back to back
+            const int col0 = n0 + wn * TN * 16 + j * 16 + kq * 4;
             if (m < M) conv_epilogue_quad(p, (size_t)m, col0, acc[i][j], vec_ok);
         }
     }
@@ -464,11 +464,11 @@ __global__ __launch_bounds__(256) void conv_win_f32_kernel(const ConvParams p) {
     }
     const bool vec_ok = conv_vec_ok(p);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col0 = n0 + wn * TN * 16 + j * 16 + kq * 4;
+    for (int i = 0; i < TM; ++i) {
+        const int oy = ty0 + wm * TM + i;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int oy = ty0 + wm * TM + i;
+        for (int j = 0; j < TN; ++j) {  // inner: the 64-byte runs of one pixel back to back
+            const int col0 = n0 + wn * TN * 16 + j * 16 + kq * 4;
             if (oy < p.Ho && ox < p.Wo) conv_epilogue_quad(p, ((size_t)n * p.Ho + oy) * p.Wo + ox, col0, acc[i][j], vec_ok);
         }
     }
