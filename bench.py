@@ -29,6 +29,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")  # before torch / HIP initialis
 SLOTS = 4  # DFVO_PIPELINE_SLOTS
 PREFETCH = os.environ.get("DFVO_BENCH_PREFETCH", "1") != "0"  # RNG-independent solver half enqueued behind the nets
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: FP32 matrix (f32 in / f32 acc)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # same table: BF16 MFMA dense (only used for the opt-in split-precision modes)
 CFG_NAMES = ["conv_igemm_f32<2,2,4,4> 128x128", "conv_igemm_f32<1,4,2,2> 32x128", "conv_igemm_f32<4,1,4,4> 256x64",
              "conv_igemm_f32<2,2,2,2> 64x64", "conv_igemm_f32<4,1,4,2> 256x32", "conv_igemm_f32<2,2,2,1> 64x32",
              "conv_igemm_f32<4,1,4,1> 256x16", "conv_igemm_f32<4,1,1,1> 64x16", "conv_igemm_f32<1,4,4,2> 64x128",
@@ -79,7 +80,11 @@ def main():
     ap.add_argument("--width", type=int, default=1241)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--conv-precision", default=os.environ.get("DFVO_CONV_PRECISION", "fp32"), choices=["fp32", "bf16x6", "bf16x3"],
+                    help="fp32 (default, the parity-gated exact path); bf16x6 / bf16x3: opt-in split-precision MFMA modes "
+                         "of the 3x3 window layers (DESIGN.md section 3) -- reported in config.conv_precision, never the default")
     args = ap.parse_args()
+    os.environ["DFVO_CONV_PRECISION"] = args.conv_precision  # read once by the library when the layers are packed
 
     import torch
     rank = int(os.environ.get("RANK", 0))
@@ -194,8 +199,13 @@ def main():
         dom = int(np.argmax(ms))
         ach = fl[dom] / (ms[dom] * 1e-3) / 1e12
         fam = fl.sum() / (ms.sum() * 1e-3) / 1e12
-        roof = {"bound": "mfma", "kernel": CFG_NAMES[dom], "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+        # exact fp32: the fp32-MFMA peak.  Opt-in split modes: the window layers issue 4 (bf16x3) / 6 (bf16x6) bf16 products
+        # per fp32 product, so the ceiling for USEFUL fp32-equivalent FLOPs is the dense bf16 peak divided by that
+        terms = {"fp32": 0, "bf16x3": 4, "bf16x6": 6}[args.conv_precision]
+        peak = PEAK_F32_MFMA_TFLOPS if not terms else PEAK_BF16_MFMA_TFLOPS / terms
+        roof = {"bound": "mfma", "kernel": CFG_NAMES[dom].replace("conv_win3_f32", "conv_win3_f32" if not terms else "conv_win3_bf16s"),
+                "achieved": round(ach, 2), "peak": round(peak, 1),
+                "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                 "avg_launch_us": round(ms[dom] * 1e3 / max(1, ln[dom]), 2), "launches_per_pair": int(ln[dom] // nprof),
                 "share_of_conv_time": round(float(ms[dom] / ms.sum()), 3),
                 "conv_family_achieved": round(fam, 2), "conv_family_ms_per_pair": round(float(ms.sum() / nprof), 3),
@@ -225,12 +235,14 @@ def main():
                       "kp selection + E/H RANSAC + scale)",
             "value": round(world * args.steps / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.conv_precision == "fp32" else "f32 accumulate, %s split-bf16 products in the 3x3 window layers (opt-in)" % args.conv_precision,
+            "data": "synthetic",
             "config": {"workload": "KITTI seq-09-sized 1241x376 frame pairs (flow net 384x1248 batch 2; device LANCZOS "
                                    "resize + depth net 192x640), 2000 keypoints, findHomography + 5x findEssentialMat"
                                    "(1000-iteration budget) + GRIC + recoverPose + depth-ratio scale RANSAC, PnP "
                                    "fallback (5x solvePnPRansac) where the reference takes it",
-                       "frames_per_gpu": args.steps, "parallelism": "frame-batch DP x%d, one all-gather of poses" % world,
+                       "conv_precision": args.conv_precision, "frames_per_gpu": args.steps, "parallelism": "frame-batch DP x%d, one all-gather of poses" % world,
                        "solver_inputs": "synthetic rigid-scene flow/consistency/depth (random-weight nets give "
                                         "incoherent flow); net outputs are computed in the timed region",
                        "tracked_by_E": n_e, "tracked_by_PnP": int((status == 3).sum()), "gathered_poses": int(gathered.shape[0])},

@@ -1,6 +1,7 @@
 // extern "C" surface declared in include/dfvo_hip.h (part 1: device helpers, operators, nets).
 #include "../../include/dfvo_hip.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -87,6 +88,11 @@ int dfvo_conv2d(const dfvo_conv_desc* d, const float* d_src0, const float* d_src
     DFVO_HIP_CHECK(hipMemcpy(db, pb.data(), pb.size() * sizeof(float), hipMemcpyHostToDevice));
     ConvLayer L;
     L.wp = dw;
+    if (make_split_weights(pw, d->kh, d->kw, &L) != DFVO_OK) {  // opt-in split-precision modes, as in make_conv
+        (void)hipFree(dw);
+        (void)hipFree(db);
+        return DFVO_ERR_HIP;
+    }
     {
         const int hrc = make_head_weights(h_w, d->cout, d->c0, d->c1, d->kh, d->kw, nullptr, &L.wh);
         if (hrc != DFVO_OK) {
@@ -115,6 +121,7 @@ int dfvo_conv2d(const dfvo_conv_desc* d, const float* d_src0, const float* d_src
     (void)hipFree(dw);
     (void)hipFree(db);
     if (L.wh) (void)hipFree(L.wh);
+    if (L.wsp) (void)hipFree(L.wsp);
     if (rc != DFVO_OK) return rc;
     DFVO_HIP_CHECK(e);
     return DFVO_OK;

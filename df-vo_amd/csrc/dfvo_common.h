@@ -51,6 +51,10 @@ struct ConvParams {
     const float* bias;
     // head layout of the same weights (one- / two-channel square layers only, else null): see conv_pack_head_weights
     const float* wh;
+    // bf16 planes of wp (plane-major, wsp_plane dwords each), only in the opt-in DFVO_CONV_PRECISION=bf16x3|bf16x6 modes
+    const float* wsp;
+    size_t wsp_plane;
+    int wsp_planes;
     int cout, cout_pad, ksteps;
     // optional residual (added before activation)
     const float* res;
@@ -89,6 +93,8 @@ static inline int conv_cout_pad(int cout, long long M) {
 // implement eval-mode BatchNorm folding: w' = w*scale, b' = b*scale + shift.
 // weights of a one- / two-channel k x k layer in the order the direct head kernel consumes them:
 // [8-channel chunk (source 0 first, each source rounded up)][kx][4-channel group of the chunk (2)][ky][cout][4]
+void conv_split_weights_bf16(const float* packed, size_t n_floats, int planes, unsigned short* out);
+int conv_split_mode();  // 0 exact fp32 (default), 2 = bf16x3, 3 = bf16x6
 size_t conv_head_weight_floats(int cout, int c0, int c1, int k);
 void conv_pack_head_weights(const float* w_oihw, int cout, int c0, int c1, int k, const float* fold_scale, float* out);
 void conv_pack_weights(const float* w_oihw, const float* bias, int cout, int c0, int c1, int kh, int kw,

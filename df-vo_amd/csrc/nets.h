@@ -25,6 +25,9 @@ struct DevBuf {
 struct ConvLayer {
     float* wp = nullptr;
     float* bias = nullptr;
+    float* wsp = nullptr;  // bf16 planes of wp (opt-in split-precision modes, 3x3 layers only)
+    size_t wsp_plane = 0;  // dwords per plane
+    int wsp_planes = 0;
     float* wh = nullptr;  // head layout (cout <= 2, square 3/5/7 kernels), see conv_pack_head_weights
     int cout = 0, cout_pad = 0, c0 = 0, c1 = 0, kh = 0, kw = 0, ksteps = 0;
     int stride = 1, pad_h = 0, pad_w = 0, pad_mode = PAD_ZERO, act = ACT_NONE;
@@ -45,6 +48,8 @@ int make_conv(const ParamStore& ps, const std::string& wname, const std::string&
               long long M_hint, const float* scale, const float* shift, ConvLayer* out);
 void free_conv(ConvLayer* l);
 // uploads the head-layout copy of the weights when the layer qualifies for the direct head kernel (else leaves wh null)
+// uploads the bf16-plane copy of the packed weights when a split-precision mode is on and the layer is 3x3
+int make_split_weights(const std::vector<float>& packed, int kh, int kw, ConvLayer* L);
 int make_head_weights(const float* w_oihw, int cout, int c0, int c1, int kh, int kw, const float* scale, float** wh);
 
 // while set, run_conv times the candidate tile / split-K configurations of every not-yet-tuned layer on its

@@ -72,7 +72,31 @@ int make_conv(const ParamStore& ps, const std::string& wname, const std::string&
     DFVO_HIP_CHECK(hipMalloc((void**)&L->bias, pb.size() * sizeof(float)));
     DFVO_HIP_CHECK(hipMemcpy(L->wp, pw.data(), pw.size() * sizeof(float), hipMemcpyHostToDevice));
     DFVO_HIP_CHECK(hipMemcpy(L->bias, pb.data(), pb.size() * sizeof(float), hipMemcpyHostToDevice));
+    DFVO_TRY(make_split_weights(pw, L->kh, L->kw, L));
     return make_head_weights(w->data.data(), L->cout, c0, c1, L->kh, L->kw, scale, &L->wh);
+}
+
+int conv_split_mode() {
+    static const int mode = [] {
+        const char* e = getenv("DFVO_CONV_PRECISION");
+        if (!e) return 0;
+        if (!strcmp(e, "bf16x3")) return 2;
+        if (!strcmp(e, "bf16x6")) return 3;
+        return 0;
+    }();
+    return mode;
+}
+
+int make_split_weights(const std::vector<float>& packed, int kh, int kw, ConvLayer* L) {
+    const int planes = conv_split_mode();
+    if (!planes || kh != 3 || kw != 3) return DFVO_OK;
+    std::vector<unsigned short> ps(packed.size() * planes);
+    conv_split_weights_bf16(packed.data(), packed.size(), planes, ps.data());
+    DFVO_HIP_CHECK(hipMalloc((void**)&L->wsp, ps.size() * sizeof(unsigned short)));
+    DFVO_HIP_CHECK(hipMemcpy(L->wsp, ps.data(), ps.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+    L->wsp_plane = packed.size() / 2;
+    L->wsp_planes = planes;
+    return DFVO_OK;
 }
 
 int make_head_weights(const float* w, int cout, int c0, int c1, int kh, int kw, const float* scale, float** wh) {
@@ -89,7 +113,8 @@ void free_conv(ConvLayer* l) {
     if (l->wp) (void)hipFree(l->wp);
     if (l->bias) (void)hipFree(l->bias);
     if (l->wh) (void)hipFree(l->wh);
-    l->wp = l->bias = l->wh = nullptr;
+    if (l->wsp) (void)hipFree(l->wsp);
+    l->wp = l->bias = l->wh = l->wsp = nullptr;
 }
 
 // ---- per-layer autotuner: the candidates differ only in tiling / K splitting, the arithmetic is the same fp32 FMA
@@ -174,6 +199,9 @@ int run_conv(const ConvLayer& L, int N, int H, int W, View s0, int up0, View s1,
     p.co1 = s1.co;
     p.wp = L.wp;
     p.wh = L.wh;
+    p.wsp = L.wsp;
+    p.wsp_plane = L.wsp_plane;
+    p.wsp_planes = L.wsp_planes;
     p.bias = L.bias;
     p.cout = L.cout;
     p.cout_pad = L.cout_pad;

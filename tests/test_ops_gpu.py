@@ -187,3 +187,23 @@ def test_resize_bilinear(gpu, ac, h, w, ho, wo):
     torch.cuda.synchronize()
     err, scale = report("resize ac=%d" % ac, nchw_host(dst, 4), ref)
     assert err <= 1e-5 * max(1.0, scale)
+
+
+def test_split_precision_modes(gpu):
+    """opt-in conv modes (DFVO_CONV_PRECISION): exact fp32 (default), bf16x6 (three bf16 planes per operand, six product
+    terms: fp32-class accuracy) and bf16x3 (two planes, 16 mantissa bits).  The mode is per process, hence subprocesses."""
+    import os
+    import subprocess
+    import sys
+    probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "split_mode_probe.py")
+    err = {}
+    for mode in ("fp32", "bf16x6", "bf16x3"):
+        env = dict(os.environ, DFVO_CONV_PRECISION=mode)
+        out = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        err[mode] = float([l for l in out.stdout.splitlines() if l.startswith("relerr")][-1].split()[1])
+    print("   window conv 132 -> 64, max relative error vs torch fp32:", err)
+    assert err["fp32"] <= 2e-6       # exact fp32 products, summation order only
+    assert err["bf16x6"] <= 4e-6     # dropped terms ~2^-24 per product: the same class
+    assert err["bf16x3"] <= 2e-5     # 16 mantissa bits per operand, all four product terms
+    assert err["bf16x3"] > err["bf16x6"]
