@@ -487,6 +487,7 @@ __global__ __launch_bounds__(256) void conv_win_f32_kernel(const ConvParams p) {
 // memory, and plane / k-group-major in the LDS stage with a 32-dword skew between k-groups).
 // NOT the default: the nets' parity gate is the exact fp32 path.
 // ------------------------------------------------------------------------------------------------
+constexpr bool SPLIT_SETPRIO = false;  // raising the wave priority around the short bf16 MFMA bursts costs ~4 % here
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -656,7 +657,7 @@ __global__ __launch_bounds__(256) void conv_win_bf16s_kernel(const ConvParams p)
 #pragma unroll
                 for (int q = 0; q < NPL; ++q) fb[j][q] = *reinterpret_cast<const s16x4*>(Bs + (q * 4 + kq) * BKQ + col * 2);
             }
-            __builtin_amdgcn_s_setprio(1);
+            if (SPLIT_SETPRIO) __builtin_amdgcn_s_setprio(1);
             // gfx950's double-rate v_mfma_f32_16x16x32_bf16 takes 8 bf16 per lane: two planes side by side contract two
             // product terms per instruction.  NPL = 2: [w0|w1].[x1|x1] + [w0|w1].[x0|x0] (all four terms);
             // NPL = 3: [w0|w2].[x2|x0] + [w0|w1].[x1|x1] + [w0|w1].[x0|x0] (the six terms down to 2^-16), small first.
@@ -681,7 +682,7 @@ __global__ __launch_bounds__(256) void conv_win_bf16s_kernel(const ConvParams p)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w01[j]), __builtin_bit_cast(bf16x8, x11[i]), acc[i][j], 0, 0, 0);
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w01[j]), __builtin_bit_cast(bf16x8, x00[i]), acc[i][j], 0, 0, 0);
                 }
-            __builtin_amdgcn_s_setprio(0);
+            if (SPLIT_SETPRIO) __builtin_amdgcn_s_setprio(0);
             if (more) store_b(bst + (stage ^ 1) * BT);
             if (tap == TAPS / 2 && next_chunk) store_window(Wn);
             __syncthreads();
