@@ -41,6 +41,10 @@ int main() {
     run<16>(2, 20000);
     run<16>(3, 20000);
     run<4>(2, 40000);
+    run<8>(1, 40000);  // 8 accumulators = the (8x16)x64 window tile: dependent distance 8 MFMAs
+    run<8>(2, 40000);
+    run<8>(3, 40000);
+    run<4>(3, 40000);
     run<16>(3, 200000);  // ~1 s: sustained clocks
     return 0;
 }
