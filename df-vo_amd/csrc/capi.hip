@@ -361,6 +361,9 @@ int dfvo_depthnet_forward_image_host(dfvo_depthnet* n, const uint8_t* h_img, int
     DFVO_HIP_CHECK(hipStreamSynchronize(d.stream));
     return DFVO_OK;
 }
+int dfvo_lanczos_coeffs(int in_size, int out_size, int* h_bounds, int* h_coeffs, int coeff_cap, int* ksize) {
+    return lanczos_coeffs_host(in_size, out_size, h_bounds, h_coeffs, coeff_cap, ksize);
+}
 int dfvo_resize_lanczos_u8(const uint8_t* d_src, int H, int W, uint8_t* d_dst, int out_h, int out_w, void* stream) {
     DFVO_ARG_CHECK(d_src && d_dst, "dfvo_resize_lanczos_u8: null argument");
     LanczosResizer r;

@@ -19,4 +19,6 @@ struct LanczosResizer {
     void release();
 };
 
+int lanczos_coeffs_host(int in_size, int out_size, int* bounds, int* coeffs, int coeff_cap, int* ksize);
+
 }  // namespace dfvo

@@ -11,6 +11,7 @@
 // kernels, one thread per output pixel (3 channels).  The oracle (oracle/pil_resample.py) is pinned to Pillow itself.
 #include "resize_lanczos.h"
 
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -104,6 +105,17 @@ int upload(const std::vector<int>& h, int** d) {
     return DFVO_OK;
 }
 }  // namespace
+
+// host-only view of the tables (no device involved): lets the CPU test suite compare them with Pillow's
+int lanczos_coeffs_host(int in_size, int out_size, int* bounds, int* coeffs, int coeff_cap, int* ksize) {
+    DFVO_ARG_CHECK(in_size > 0 && out_size > 0 && bounds && coeffs && ksize, "lanczos_coeffs: bad argument");
+    std::vector<int> b, k;
+    precompute_coeffs(in_size, out_size, &b, &k, ksize);
+    DFVO_ARG_CHECK((size_t)coeff_cap >= k.size(), "lanczos_coeffs: coefficient buffer too small");
+    std::copy(b.begin(), b.end(), bounds);
+    std::copy(k.begin(), k.end(), coeffs);
+    return DFVO_OK;
+}
 
 int LanczosResizer::init(int H_, int W_, int oh_, int ow_) {
     DFVO_ARG_CHECK(H_ > 0 && W_ > 0 && oh_ > 0 && ow_ > 0, "LanczosResizer: bad size");

@@ -95,6 +95,10 @@ int dfvo_deconv_dw4x4s2(const float* d_src, int N, int H, int W, int C, int cs, 
  * fixed-point coefficient tables, horizontal pass then vertical pass, each rounded to uint8 (replaces the host-side
  * PIL call at deep_models.py:195-199).  Builds the tables per call; the nets keep theirs resident. */
 int dfvo_resize_lanczos_u8(const uint8_t* d_src, int H, int W, uint8_t* d_dst, int out_h, int out_w, void* stream);
+/* the resize's fixed-point tables for one axis (host only, no device needed): h_bounds [out_size][2] = (first input
+ * sample, count), h_coeffs [out_size][*ksize] 22-bit coefficients (coeff_cap ints available) -- Pillow's
+ * precompute_coeffs + normalize_coeffs_8bpc */
+int dfvo_lanczos_coeffs(int in_size, int out_size, int* h_bounds, int* h_coeffs, int coeff_cap, int* ksize);
 int dfvo_resize_bilinear(const float* d_src, int N, int H, int W, int C, float* d_dst, int Ho, int Wo,
                          int align_corners, void* stream);
 
