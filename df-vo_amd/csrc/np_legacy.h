@@ -106,4 +106,28 @@ SM_HD void mt_sample_without_replacement(Mt19937& s, int n_population, int n_sam
     }
 }
 
+// np.add.reduce over a contiguous float64 array: numpy's pairwise summation (loops.c.src pairwise_sum_DOUBLE): below 8
+// elements a plain loop, up to 128 eight interleaved partial sums combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) and
+// the tail added one by one, above that a split at n/2 rounded down to a multiple of 8
+SM_HD_NOINLINE double np_pairwise_sum(const double* a, int n) {
+    if (n < 8) {
+        double res = 0.;
+        for (int i = 0; i < n; i++) res += a[i];
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int j = 0; j < 8; j++) r[j] = a[j];
+        int i;
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+
 }  // namespace sm

@@ -1268,30 +1268,6 @@ __global__ __launch_bounds__(256) void k_rep_update_all(PoseState* ps, const Ran
 }
 
 // ---- e_tracker.validity.method == "flow" (ablation_model_sel_flow.yml) ------------------------------------------
-// np.add.reduce over a contiguous float64 array: numpy's pairwise summation (loops.c.src pairwise_sum_DOUBLE): below 8
-// elements a plain loop, up to 128 eight interleaved partial sums combined as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) and
-// the tail added one by one, above that a split at n/2 rounded down to a multiple of 8
-__device__ double np_pairwise_sum(const double* a, int n) {
-    if (n < 8) {
-        double res = 0.;
-        for (int i = 0; i < n; i++) res += a[i];
-        return res;
-    }
-    if (n <= 128) {
-        double r[8];
-        for (int j = 0; j < 8; j++) r[j] = a[j];
-        int i;
-        for (i = 8; i < n - (n % 8); i += 8)
-            for (int j = 0; j < 8; j++) r[j] += a[i + j];
-        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-        for (; i < n; i++) res += a[i];
-        return res;
-    }
-    int n2 = n / 2;
-    n2 -= n2 % 8;
-    return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
-}
-
 // valid_case = np.mean(np.linalg.norm(kp_ref - kp_cur, axis=1)) > thre (E_tracker.py:182-185).  gate[0] = the keypoint
 // count the shuffles see (n when the pair is tracked, 0 otherwise: a closed gate draws nothing from np.random),
 // gate[1] = valid_case; the mean goes to *avg_out
@@ -1305,7 +1281,7 @@ __global__ __launch_bounds__(256) void k_flow_gate(const int* __restrict__ kp_in
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        const double avg = np_pairwise_sum(norms, n) / (double)n;  // n == 0: nan, compares false like numpy's
+        const double avg = sm::np_pairwise_sum(norms, n) / (double)n;  // n == 0: nan, compares false like numpy's
         *avg_out = avg;
         const int open = avg > thre ? 1 : 0;
         gate[0] = open ? n : 0;

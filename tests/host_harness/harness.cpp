@@ -191,4 +191,5 @@ void hh_argpartition(const float* v, int num, int kth, int* tosort) {
 void hh_cell_bounds(int h, int w, int nr, int nc, int row, int col, int* out) {
     sm::kp_cell_bounds(h, w, nr, nc, row, col, out, out + 1, out + 2, out + 3);
 }
+double hh_np_pairwise_sum(const double* a, int n) { return sm::np_pairwise_sum(a, n); }
 }

@@ -124,3 +124,15 @@ def test_argpartition_lane_matches_oracle(hh):
         hh.hh_argpartition(_p(v, C.c_float), n, k - 1, _p(tos, C.c_int))
         hh.hh_argpartition_cp(_p(v, C.c_float), n, k - 1, _p(tos2, C.c_int))
         assert np.array_equal(tos2, tos)
+
+
+def test_pairwise_sum_lane_matches_numpy(hh):
+    """np.add.reduce's pairwise summation (the mean displacement of validity.method 'flow'), every size class: below 8,
+    up to the 128-element block, and the recursive split, with magnitudes spread so that the order matters"""
+    hh.hh_np_pairwise_sum.restype = C.c_double
+    rng = np.random.default_rng(12)
+    for n in list(range(0, 20)) + [63, 64, 127, 128, 129, 255, 256, 257, 1000, 1999, 2000, 2001, 4097, 20000]:
+        a = np.ascontiguousarray(rng.standard_normal(n) * 10.0 ** rng.integers(-6, 7, n))
+        got = hh.hh_np_pairwise_sum(_p(a), n)
+        want = float(np.add.reduce(a)) if n else 0.0
+        assert got == want, (n, got, want)
