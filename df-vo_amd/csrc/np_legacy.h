@@ -130,4 +130,36 @@ SM_HD_NOINLINE double np_pairwise_sum(const double* a, int n) {
     return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
 }
 
+// RigidFlow layer for one pixel (geometry/{backprojection,transformation3d,projection}.py, layers.py PixToFlow) in
+// float32: every matmul row is a0*b0 rounded, then fused multiply-adds in ascending k (the order of the torch-CPU GEMM
+// that produced tests/golden/rigid_flow_kp.npz).  Ki: inverse intrinsics 3x3, T: 4x4 motion, K: intrinsics 3x3.
+SM_HD void rigid_flow_px(const float* Ki, const float* T, const float* K, float x, float y, float d, float* rx, float* ry) {
+    float P[4];
+    for (int r = 0; r < 3; ++r) {
+        float a = Ki[r * 3] * x;
+        a = __builtin_fmaf(Ki[r * 3 + 1], y, a);
+        a = __builtin_fmaf(Ki[r * 3 + 2], 1.0f, a);
+        P[r] = d * a;
+    }
+    P[3] = 1.0f;
+    float Q[4];
+    for (int r = 0; r < 4; ++r) {
+        float a = T[r * 4] * P[0];
+        a = __builtin_fmaf(T[r * 4 + 1], P[1], a);
+        a = __builtin_fmaf(T[r * 4 + 2], P[2], a);
+        a = __builtin_fmaf(T[r * 4 + 3], P[3], a);
+        Q[r] = a;
+    }
+    float U[3];
+    for (int r = 0; r < 3; ++r) {
+        float a = K[r * 3] * Q[0];
+        a = __builtin_fmaf(K[r * 3 + 1], Q[1], a);
+        a = __builtin_fmaf(K[r * 3 + 2], Q[2], a);
+        a = __builtin_fmaf(0.0f, Q[3], a);  // the zero 4th column of the 3x4 intrinsics
+        U[r] = a;
+    }
+    const float den = U[2] + 1e-7f;
+    *rx = U[0] / den - x;
+    *ry = U[1] / den - y;
+}
 }  // namespace sm

@@ -506,40 +506,9 @@ __global__ void k_rigid_flow_diff(const float* __restrict__ depth, const float* 
                                   float* __restrict__ rflow /*optional [2,H,W]*/) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= H * W) return;
-    const float* Ki = mats;
-    const float* T = mats + 9;
-    const float* K = mats + 25;
     const float x = (float)(i % W), y = (float)(i / W);
-    const float d = depth[i];
-    float P[4];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        float a = Ki[r * 3] * x;
-        a = __builtin_fmaf(Ki[r * 3 + 1], y, a);
-        a = __builtin_fmaf(Ki[r * 3 + 2], 1.0f, a);
-        P[r] = d * a;
-    }
-    P[3] = 1.0f;
-    float Q[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float a = T[r * 4] * P[0];
-        a = __builtin_fmaf(T[r * 4 + 1], P[1], a);
-        a = __builtin_fmaf(T[r * 4 + 2], P[2], a);
-        a = __builtin_fmaf(T[r * 4 + 3], P[3], a);
-        Q[r] = a;
-    }
-    float U[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        float a = K[r * 3] * Q[0];
-        a = __builtin_fmaf(K[r * 3 + 1], Q[1], a);
-        a = __builtin_fmaf(K[r * 3 + 2], Q[2], a);
-        a = __builtin_fmaf(0.0f, Q[3], a);  // the zero 4th column of the 3x4 intrinsics
-        U[r] = a;
-    }
-    const float den = U[2] + 1e-7f;
-    const float rx = U[0] / den - x, ry = U[1] / den - y;
+    float rx, ry;
+    sm::rigid_flow_px(mats, mats + 9, mats + 25, x, y, depth[i], &rx, &ry);
     if (rflow) {
         rflow[i] = rx;
         rflow[(size_t)H * W + i] = ry;

@@ -192,4 +192,9 @@ void hh_cell_bounds(int h, int w, int nr, int nc, int row, int col, int* out) {
     sm::kp_cell_bounds(h, w, nr, nc, row, col, out, out + 1, out + 2, out + 3);
 }
 double hh_np_pairwise_sum(const double* a, int n) { return sm::np_pairwise_sum(a, n); }
+// k_rigid_flow_diff per pixel: mats = Kinv[9] | T[16] | K[9]; out [2][H][W] rigid flow
+void hh_rigid_flow(const float* mats, const float* depth, int H, int W, float* out) {
+    for (int i = 0; i < H * W; i++)
+        sm::rigid_flow_px(mats, mats + 9, mats + 25, (float)(i % W), (float)(i / W), depth[i], out + i, out + (size_t)H * W + i);
+}
 }

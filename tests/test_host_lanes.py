@@ -136,3 +136,17 @@ def test_pairwise_sum_lane_matches_numpy(hh):
         got = hh.hh_np_pairwise_sum(_p(a), n)
         want = float(np.add.reduce(a)) if n else 0.0
         assert got == want, (n, got, want)
+
+
+def test_rigid_flow_lane_matches_oracle(hh):
+    """the per-pixel RigidFlow arithmetic of k_rigid_flow_diff (float32, fused multiply-add order of the fixture's GEMM)
+    against the oracle restatement, which tests/test_oracle_tracker.py pins to the reference's own layers"""
+    from golden.make_golden import rigid_case
+    c = rigid_case(120, 200, 63)
+    K = c["K"]
+    mats = np.ascontiguousarray(np.r_[np.linalg.inv(K).ravel(), c["T_ref_to_cur"].ravel(), K.ravel()].astype(np.float32))
+    depth = np.ascontiguousarray(c["raw_depth"], np.float32)
+    out = np.zeros((2, 120, 200), np.float32)
+    hh.hh_rigid_flow(_p(mats, C.c_float), _p(depth, C.c_float), 120, 200, _p(out, C.c_float))
+    want = T.rigid_flow(depth, c["T_ref_to_cur"], K)
+    assert np.array_equal(out, want)
