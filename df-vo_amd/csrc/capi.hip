@@ -361,6 +361,11 @@ int dfvo_depthnet_forward_image_host(dfvo_depthnet* n, const uint8_t* h_img, int
     DFVO_HIP_CHECK(hipStreamSynchronize(d.stream));
     return DFVO_OK;
 }
+int dfvo_split_bf16_planes(const float* h_in, int n, int planes, uint16_t* h_out) {
+    DFVO_ARG_CHECK(h_in && h_out && n >= 0 && (planes == 2 || planes == 3), "dfvo_split_bf16_planes: bad argument");
+    conv_split_weights_bf16(h_in, (size_t)n, planes, h_out);
+    return DFVO_OK;
+}
 int dfvo_lanczos_coeffs(int in_size, int out_size, int* h_bounds, int* h_coeffs, int coeff_cap, int* ksize) {
     return lanczos_coeffs_host(in_size, out_size, h_bounds, h_coeffs, coeff_cap, ksize);
 }

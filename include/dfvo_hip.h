@@ -73,6 +73,9 @@ int dfvo_conv2d(const dfvo_conv_desc* desc, const float* d_src0, const float* d_
  * summed duration [ms], useful FLOPs and launch count.
  * Do not use while a hipGraph capture is active (disable graphs on the nets first). */
 int dfvo_conv_profile_begin(void);
+/* host only: the bf16 planes the opt-in split-precision conv modes (DFVO_CONV_PRECISION=bf16x3 | bf16x6) give a weight:
+ * h_out[q * n + i] = plane q of h_in[i], x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1), round to nearest even */
+int dfvo_split_bf16_planes(const float* h_in, int n, int planes, uint16_t* h_out);
 int dfvo_conv_profile_end(double* h_ms19, double* h_flops19, int* h_launches19);
 
 /* correlation.py:38-106,281-340 (_FunctionCorrelation.forward) followed by leaky_relu(slope)
