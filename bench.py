@@ -5,11 +5,18 @@ One step = one frame pair (1241x376): monodepth2 depth + LiteFlowNet forward/bac
 (HIP fp32-MFMA nets), local_bestN keypoint selection, homography + 5 x five-point RANSAC + GRIC +
 recoverPose, depth-ratio scale RANSAC (PnP fallback where the reference takes it), pose out.  Inputs (the two uint8
 frames) are resident in HBM before the timed region; the Pillow-exact LANCZOS resize of the depth input runs on the
-device inside it.  Random-weight nets give incoherent flow, so the solver stage is
-fed a synthetic rigid-scene flow / consistency / depth triple of the same shape (also HBM resident) and
-does the full work it does on KITTI; the nets' own outputs are still computed inside the timed region.
+device inside it.
 
-    python bench.py [--gpus N --steps K --warmup W]      (N > 1: launched by torch.distributed.run)
+--solver-inputs nets (default): the product data path -- the solver stage consumes the nets' own flow / consistency /
+depth.  The two frames come from the coded tunnel world (df-vo_amd/synthetic.py: frames that carry their flow and depth
+as colour codes, decoded by a few channels of otherwise random weights), tracked ping-pong (A->B, B->A, ...) so that
+every pair, including the rolled-over reference depth of the PnP fallback, is physically consistent.
+--solver-inputs synthetic: round 1's mode -- random-weight nets (incoherent flow) computed in the timed region, the
+solver stage fed a synthetic rigid-scene flow / consistency / depth triple of the same shape.
+
+    python bench.py [--gpus N --steps K --warmup W]
+N > 1: one process per GPU over RCCL.  Under torch.distributed.run (WORLD_SIZE set) this process is one rank; run
+directly, bench.py re-launches itself under torch.distributed.run with N ranks on 127.0.0.1.
 
 Prints ONE JSON line on rank 0 (contract in the task description; `roofline` and `cpu_baseline` added).
 """
@@ -37,6 +44,21 @@ CFG_NAMES = ["conv_igemm_f32<2,2,4,4> 128x128", "conv_igemm_f32<1,4,2,2> 32x128"
              "conv_win3_f32<2,2,4,4> (8x16)x128", "conv_win3_f32<2,2,4,2> (8x16)x64", "conv_win3_f32<4,1,2,2> (8x16)x32",
              "conv_win3_f32<1,4,4,2> (4x16)x128", "conv_head_f32<7> 7x7 heads (direct)",
              "conv_head_f32<5> 5x5 heads (direct)", "conv_head_f32<3> 3x3 heads (direct)"]
+
+
+def cpu_baseline_nets(frames, fsd, dsd, K, H, W, n_pairs=3):
+    """the oracle's image-level frame loop (oracle/pipeline_np.py: torch-CPU nets + C/numpy solvers) over the same coded
+    frames, ping-pong like the timed region, on the host cores"""
+    import torch
+    from oracle import pipeline_np as P
+    cores = torch.get_num_threads()
+    seq = [frames[i % 2] for i in range(n_pairs + 1)]
+    t0 = time.time()
+    r = P.track_sequence(seq, fsd, dsd, K, seed=4869)
+    dt = time.time() - t0
+    return {"value": n_pairs / dt, "unit": "frames/s", "cores": int(cores), "kind": "port",
+            "sample": "%d frame pairs %dx%d through the oracle frame loop (torch-CPU fp32 monodepth2 + LiteFlowNet fwd+bwd, "
+                      "C/numpy solvers on their outputs; tracked %s), %.1f s" % (n_pairs, W, H, "/".join(r["status"]), dt)}
 
 
 def cpu_baseline(syn, H, W, scenes, n_pairs=2):
@@ -71,7 +93,63 @@ def cpu_baseline(syn, H, W, scenes, n_pairs=2):
                       "solver oracle on the same synthetic inputs, %.1f s" % (n_pairs, dt)}
 
 
-def main():
+def spawn_ranks(n):
+    """`python bench.py --gpus N` run directly: re-launch under torch.distributed.run, one rank per GPU, rendezvous on 127.0.0.1"""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def world_setup(args, torch):
+    """(rank, world, local_rank, dist or None); backend nccl (= RCCL) on GPUs, gloo when DFVO_BENCH_BACKEND=gloo (CPU tests)"""
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world > 1 and world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        backend = os.environ.get("DFVO_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local_rank, dist
+
+
+def ranks_seen(dist, world, rank, local_rank, torch):
+    """distinct (rank, device) pairs that took part, from an all-gather"""
+    if torch.cuda.is_available():
+        pr = torch.cuda.get_device_properties(local_rank if world > 1 else 0)
+        me = (rank, local_rank if world > 1 else 0, getattr(pr, "uuid", None) and str(pr.uuid), getattr(pr, "pci_bus_id", None))
+    else:
+        me = (rank, -1, None, None)
+    if dist is None:
+        return [me]
+    out = [None] * world
+    dist.all_gather_object(out, me)
+    return out
+
+
+def to_device(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def device_sync():
+    import torch
+    torch.cuda.synchronize()
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -83,21 +161,20 @@ def main():
     ap.add_argument("--conv-precision", default=os.environ.get("DFVO_CONV_PRECISION", "fp32"), choices=["fp32", "bf16x6", "bf16x3"],
                     help="fp32 (default, the parity-gated exact path); bf16x6 / bf16x3: opt-in split-precision MFMA modes "
                          "of the 3x3 window layers (DESIGN.md section 3) -- reported in config.conv_precision, never the default")
-    args = ap.parse_args()
+    ap.add_argument("--solver-inputs", default="nets", choices=["nets", "synthetic"],
+                    help="nets: the solver stage consumes the nets' own outputs (coded-world frames, the product data path); "
+                         "synthetic: random-weight nets + a synthetic rigid-scene flow/consistency/depth triple (round-1 mode)")
+    ap.add_argument("--e-max-iters", type=int, default=1000, help="findEssentialMat hypothesis budget (config 5: 8192)")
+    ap.add_argument("--kp-bestn", type=int, default=2000, help="kp_selection.local_bestN.num_bestN (config 5: 20000)")
+    args = ap.parse_args(argv)
     os.environ["DFVO_CONV_PRECISION"] = args.conv_precision  # read once by the library when the layers are packed
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
-    rank = int(os.environ.get("RANK", 0))
-    world = int(os.environ.get("WORLD_SIZE", 1))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    else:
+    rank, world, local_rank, dist = world_setup(args, torch)
+    on_gpu = dist is None or dist.get_backend() == "nccl"  # (gloo: CPU test of the multi-rank logic, tests/test_bench_cpu.py)
+    if world == 1:
         torch.cuda.set_device(0)
 
     pkg = importlib.import_module("df-vo_amd")  # noqa: F841
@@ -105,19 +182,31 @@ def main():
     syn = importlib.import_module("df-vo_amd.synthetic")
     pmod = importlib.import_module("df-vo_amd.pipeline")
     dmod = importlib.import_module("df-vo_amd.dist")
-    capi.check(capi.lib().dfvo_set_device(local_rank if world > 1 else 0))
+    if on_gpu:
+        capi.check(capi.lib().dfvo_set_device(local_rank if world > 1 else 0))
 
     H, W = args.height, args.width
-    scenes = [syn.rigid_scene(H, W, seed=100 + 7 * rank + i) for i in range(4)]
-    K = scenes[0]["K"]
-    pipe = pmod.TrackingPipeline(H, W, 192, 640, K, syn.liteflownet_state_dict(4869), syn.monodepth2_state_dict(4869),
-                                 seed=4869 ^ rank)  # per-rank stream: "per-frame-seed" mode of the DP driver
-    ref, cur = syn.image_pair(H, W, seed=1 + rank)
-    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
-    d_ref, d_cur = dev(ref), dev(cur)
+    nets_mode = args.solver_inputs == "nets"
+    dev = to_device
     d_feed = None  # the pipeline resizes the current frame itself (device LANCZOS, bit-exact with Pillow)
-    d_sc = [(dev(s["flow"]), dev(s["diff"]), dev(s["depth_cur"])) for s in scenes]
-    d_ref_depth = dev(scenes[0]["depth_ref"])
+    popts = dict(seed=4869 ^ rank, e_max_iters=args.e_max_iters, kp_num_bestN=args.kp_bestn)  # per-rank RandomState: DP mode
+    if nets_mode:
+        # coded tunnel world: multiplexed encoding when the frame needs no input resize, potential encoding otherwise
+        code_mode = "mux" if syn._net_size(H, W) == (H, W) else "pot"
+        seq = syn.coded_tunnel_sequence(H, W, 2, mode=code_mode, step=1.0 if code_mode == "mux" else 0.3, seed=7 + rank)
+        K = seq["K"]
+        fsd, dsd = syn.crafted_liteflownet_state_dict(H, W, code_mode), syn.crafted_monodepth2_state_dict()
+        scenes = None
+        d_frames = [dev(seq["frames"][0]), dev(seq["frames"][1])]
+    else:
+        scenes = [syn.rigid_scene(H, W, seed=100 + 7 * rank + i) for i in range(4)]
+        K = scenes[0]["K"]
+        fsd, dsd = syn.liteflownet_state_dict(4869), syn.monodepth2_state_dict(4869)
+        ref, cur = syn.image_pair(H, W, seed=1 + rank)
+        d_frames = [dev(ref), dev(cur)]
+        d_sc = [(dev(s["flow"]), dev(s["diff"]), dev(s["depth_cur"])) for s in scenes]
+        d_ref_depth = dev(scenes[0]["depth_ref"])
+    pipe = pmod.TrackingPipeline(H, W, 192, 640, K, fsd, dsd, **popts)
 
     host_t = [0.0, 0.0]  # host seconds inside enqueue_nets / track (DFVO_BENCH_TRACE=1 prints them)
 
@@ -129,12 +218,20 @@ def main():
         status = np.zeros(n, np.int64)
         if n == 0:
             return rel_all, status
-        pipe.set_ref_depth(depth=d_ref_depth)  # depth of the first reference frame (PnP fallback input)
+        if nets_mode:
+            pipe.set_ref_image(d_frames[0])  # depth of the first reference frame (PnP fallback input), from the frame itself
+        else:
+            pipe.set_ref_depth(depth=d_ref_depth)
         # nets run `ahead` pairs ahead of the solver stage (<= SLOTS - 1): with 3, each of the two flow-net instances always
         # has its next pair queued behind the current one while track(k) blocks the host
         ahead = int(os.environ.get("DFVO_BENCH_AHEAD", "3"))
         def feed(j):  # nets of pair j, then the RNG-independent half of its solver stage right behind them
-            pipe.enqueue_nets(j % SLOTS, d_ref, d_cur, d_feed)
+            if nets_mode:  # ping-pong A->B, B->A: every pair (and the rolled-over reference depth) is consistent
+                pipe.enqueue_nets(j % SLOTS, d_frames[j % 2], d_frames[1 - j % 2], d_feed)
+                if PREFETCH:
+                    pipe.prefetch_track(j % SLOTS)
+                return
+            pipe.enqueue_nets(j % SLOTS, d_frames[0], d_frames[1], d_feed)
             if PREFETCH:
                 pipe.prefetch_track(j % SLOTS, d_sc[j % len(d_sc)][0], d_sc[j % len(d_sc)][1])
 
@@ -145,8 +242,11 @@ def main():
             if k + ahead < n:
                 feed(k + ahead)
             t_b = time.perf_counter()
-            f, dd, dp = d_sc[k % len(d_sc)]
-            out = pipe.track(k % SLOTS, f, dd, dp)  # E-tracker, or the PnP fallback when its pose is rejected
+            if nets_mode:
+                out = pipe.track(k % SLOTS)  # no overrides: keypoints / RANSAC / scale / PnP on the nets' own outputs
+            else:
+                f, dd, dp = d_sc[k % len(d_sc)]
+                out = pipe.track(k % SLOTS, f, dd, dp)  # E-tracker, or the PnP fallback when its pose is rejected
             host_t[0] += t_b - t_a
             host_t[1] += time.perf_counter() - t_b
             rel, _ = pipe.hybrid_pose(out, prev)
@@ -160,20 +260,22 @@ def main():
     run(args.warmup)
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    device_sync()
     host_t[0] = host_t[1] = 0.0
     t0 = time.perf_counter()
     rel_all, status = run(args.steps)
     if os.environ.get("DFVO_BENCH_TRACE"):
         sys.stderr.write("host ms/pair: enqueue_nets %.3f  track %.3f\n" % (host_t[0] * 1e3 / args.steps,
                                                                             host_t[1] * 1e3 / args.steps))
-    gathered = dmod.allgather_poses(rel_all, status, world, rank, dist)  # one RCCL all-gather of the chunk's poses
-    torch.cuda.synchronize()
+    gathered = dmod.allgather_poses(rel_all, status, world, rank, dist, "cuda" if on_gpu else "cpu")  # one RCCL all-gather of the chunk's poses
+    if (status == 2).any():
+        raise SystemExit("bench.py: a pair needed the PnP fallback without a reference depth")
+    device_sync()
     if dist is not None:
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     net_flops = pipe.net_flops()
@@ -183,13 +285,13 @@ def main():
         # per-launch durations of the conv kernel family, HIP events on the launch streams, graphs off
         # (one pair in flight at a time here: overlapping passes would stretch each other's launches)
         pipe.set_graph(0)
-        pipe.enqueue_nets(0, d_ref, d_cur, d_feed)
+        pipe.enqueue_nets(0, d_frames[0], d_frames[1], d_feed)
         pipe.sync()
         lib = capi.lib()
         capi.check(lib.dfvo_conv_profile_begin())
         nprof = 3
         for _ in range(nprof):
-            pipe.enqueue_nets(0, d_ref, d_cur, d_feed)
+            pipe.enqueue_nets(0, d_frames[0], d_frames[1], d_feed)
             pipe.sync()
         ms = np.zeros(19)
         fl = np.zeros(19)
@@ -225,11 +327,26 @@ def main():
             pass
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        base = cpu_baseline(syn, H, W, scenes)
+        base = cpu_baseline_nets(seq["frames"], fsd, dsd, K, H, W) if nets_mode else cpu_baseline(syn, H, W, scenes)
+    seen = ranks_seen(dist, world, rank, local_rank, torch)
     pipe.close()
 
     if rank == 0:
         n_e = int((status == 0).sum())
+        if roof is not None:
+            roof["whole_pair_tflops"] = round(net_flops * world * args.steps / dt / 1e12, 2)  # issued net FLOPs / timed wall time
+            roof["note"] = ("achieved/frac: the conv tile configuration with the largest time share, per-launch HIP-event "
+                            "durations, graphs off, ONE pair in flight (conv_family_ms_per_pair sums those and exceeds "
+                            "ms_per_step, whose timed region overlaps two flow-net instances and the solver stage); "
+                            "whole_pair_tflops = issued net FLOPs / timed wall time; traffic: rocprofv3 PMC pass over this "
+                            "command, committed under profiles/ (counters cannot be read from inside the process)")
+        net_h, net_w = syn._net_size(H, W)
+        if nets_mode:
+            si = ("the nets' own outputs (product data path, no overrides): coded tunnel-world frames, '%s' encoding, "
+                  "tracked ping-pong A->B, B->A" % code_mode)
+        else:
+            si = ("synthetic rigid-scene flow/consistency/depth overrides (random-weight nets give incoherent flow); net "
+                  "outputs are computed in the timed region")
         line = {
             "metric": "KITTI-odom frames/sec (DF-VO per-pair tracking hot path: monodepth2 + LiteFlowNet fwd/bwd + "
                       "kp selection + E/H RANSAC + scale)",
@@ -238,14 +355,17 @@ def main():
             "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.conv_precision == "fp32" else "f32 accumulate, %s split-bf16 products in the 3x3 window layers (opt-in)" % args.conv_precision,
             "data": "synthetic",
-            "config": {"workload": "KITTI seq-09-sized 1241x376 frame pairs (flow net 384x1248 batch 2; device LANCZOS "
-                                   "resize + depth net 192x640), 2000 keypoints, findHomography + 5x findEssentialMat"
-                                   "(1000-iteration budget) + GRIC + recoverPose + depth-ratio scale RANSAC, PnP "
-                                   "fallback (5x solvePnPRansac) where the reference takes it",
-                       "conv_precision": args.conv_precision, "frames_per_gpu": args.steps, "parallelism": "frame-batch DP x%d, one all-gather of poses" % world,
-                       "solver_inputs": "synthetic rigid-scene flow/consistency/depth (random-weight nets give "
-                                        "incoherent flow); net outputs are computed in the timed region",
-                       "tracked_by_E": n_e, "tracked_by_PnP": int((status == 3).sum()), "gathered_poses": int(gathered.shape[0])},
+            "config": {"workload": "%dx%d frame pairs%s (flow net %dx%d batch 2; device LANCZOS resize + depth net 192x640), "
+                                   "local_bestN %d keypoints, findHomography + 5x findEssentialMat(%d-iteration budget) + GRIC + "
+                                   "recoverPose + depth-ratio scale RANSAC, PnP fallback (5x solvePnPRansac) where the "
+                                   "reference takes it" % (W, H, " (KITTI seq-09 size)" if (H, W) == (376, 1241) else "", net_h,
+                                                           net_w, args.kp_bestn, args.e_max_iters),
+                       "conv_precision": args.conv_precision, "frames_per_gpu": args.steps,
+                       "parallelism": "frame-batch DP x%d, one all-gather of poses" % world,
+                       "solver_inputs": si,
+                       "tracked_by_E": n_e, "tracked_by_PnP": int((status == 3).sum()),
+                       "constant_motion": int((status == 1).sum()), "gathered_poses": int(gathered.shape[0]),
+                       "ranks_seen": len(set(r[0] for r in seen)), "devices_seen": len(set((r[1], r[2], r[3]) for r in seen))},
             "roofline": roof, "cpu_baseline": base}
         print(json.dumps(line))
     if dist is not None:

@@ -153,6 +153,9 @@ SIGNATURES = {
     "dfvo_pipeline_set_ref_image": (_i, [_vp, _vp]),
     "dfvo_pipeline_prefetch_track": (_i, [_vp, _i, _vp, _vp]),
     "dfvo_pipeline_get_flow": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "dfvo_pipeline_get_keypoints": (_i, [_vp, _i, _i, _vp, _vp, _vp, _ip]),
+    "dfvo_pipeline_get_rng_state": (_i, [_vp, _vp]),
+    "dfvo_pipeline_set_rng_state": (_i, [_vp, _vp]),
     "dfvo_pipeline_sync": (_i, [_vp]),
     "dfvo_pipeline_net_flops": (_d, [_vp]),
     "dfvo_find_scale_from_depth": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, C.POINTER(ScaleCfg), C.POINTER(_d), _vp]),

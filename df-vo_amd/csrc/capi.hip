@@ -3,6 +3,9 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <utility>
 #include <vector>
 
 #include "nets.h"
@@ -13,6 +16,20 @@ namespace dfvo {
 static thread_local std::string g_err;
 void set_last_error(const std::string& s) { g_err = s; }
 const char* last_error() { return g_err.c_str(); }
+
+int ensure_dyn_lds(const void* kernel, size_t bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, size_t> configured;
+    int dev = 0;
+    DFVO_HIP_CHECK(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& have = configured[{dev, kernel}];
+    if (bytes > have) {
+        DFVO_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+        have = bytes;
+    }
+    return DFVO_OK;
+}
 }  // namespace dfvo
 
 using namespace dfvo;

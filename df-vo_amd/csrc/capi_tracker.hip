@@ -161,7 +161,10 @@ int dfvo_triangulate_points(dfvo_tracker* t, const double* h_P1, const double* h
 
 int dfvo_tracker_seed(dfvo_tracker* t, uint32_t seed) {
     DFVO_ARG_CHECK(t, "null tracker");
-    return enqueue_mt_seed(t->tb, seed, t->stream);
+    int rc = enqueue_mt_seed(t->tb, seed, t->stream);
+    if (rc != DFVO_OK) return rc;
+    DFVO_HIP_CHECK(hipStreamSynchronize(t->stream));  // the shuffles read the key on another stream (see dfvo_pipeline_seed)
+    return DFVO_OK;
 }
 int dfvo_tracker_set_rng_state(dfvo_tracker* t, const uint32_t* h) {
     DFVO_ARG_CHECK(t && h, "dfvo_tracker_set_rng_state: null argument");

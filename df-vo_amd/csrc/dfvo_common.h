@@ -30,6 +30,10 @@ const char* last_error();
         }                                           \
     } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device function attribute: remembered per (device, kernel) so that a
+// process that drives several GPUs (dfvo_set_device) or several pipelines from different threads configures each one
+int ensure_dyn_lds(const void* kernel, size_t bytes);
+
 enum Act { ACT_NONE = 0, ACT_LEAKY = 1, ACT_RELU = 2, ACT_ELU = 3, ACT_SIGMOID = 4 };
 enum PadMode { PAD_ZERO = 0, PAD_REFLECT = 1 };
 

@@ -94,8 +94,6 @@ struct FlowNet {
     double flops_last = 0.0;  // useful conv+corr FLOPs of the last forward (2*MAC)
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
-    const uint8_t* graph_ref = nullptr;
-    const uint8_t* graph_cur = nullptr;
     float *graph_fwd = nullptr, *graph_bwd = nullptr, *graph_diff = nullptr;
     bool use_graph = true;
     bool tuned_once = false;
@@ -103,7 +101,8 @@ struct FlowNet {
     int init(int imgH, int imgW, hipStream_t s);
     int finalize();
     int forward(const uint8_t* d_ref, const uint8_t* d_cur, float* d_fwd, float* d_bwd, float* d_diff);
-    int enqueue(const uint8_t* d_ref, const uint8_t* d_cur, float* d_fwd, float* d_bwd, float* d_diff);
+    int enqueue_input(const uint8_t* d_ref, const uint8_t* d_cur);  // uint8 frames -> level-1 net input (not captured)
+    int enqueue(float* d_fwd, float* d_bwd, float* d_diff);         // everything after that (captured into the graph)
     void destroy();
 };
 

@@ -459,15 +459,21 @@ int FlowNet::finalize() {
     return DFVO_OK;
 }
 
-int FlowNet::enqueue(const uint8_t* d_ref, const uint8_t* d_cur, float* d_fwd, float* d_bwd, float* d_diff) {
+// the only two launches that read the caller's frames: kept OUT of the captured graph, so that the graph (everything
+// from the image pyramid on) is replayed unchanged for every pair of a sequence whatever buffers the frames live in
+int FlowNet::enqueue_input(const uint8_t* d_ref, const uint8_t* d_cur) {
+    // batch sample 0 = ref, sample 1 = cur: "first" = X[n], "second" = X[1-n]  (lite_flow.py:108-110)
+    const size_t img_px = (size_t)H * W;
+    DFVO_TRY(launch_img_u8_to_flow_input(d_ref, imgH, imgW, img[1].p, H, W, stream));
+    DFVO_TRY(launch_img_u8_to_flow_input(d_cur, imgH, imgW, img[1].p + img_px * 4, H, W, stream));
+    return DFVO_OK;
+}
+
+int FlowNet::enqueue(float* d_fwd, float* d_bwd, float* d_diff) {
     const int N = 2;
     hipStream_t s = stream;
     double fl = 0.0;
     const View none{nullptr, 0, 0};
-    // batch sample 0 = ref, sample 1 = cur: "first" = X[n], "second" = X[1-n]  (lite_flow.py:108-110)
-    const size_t img_px = (size_t)H * W;
-    DFVO_TRY(launch_img_u8_to_flow_input(d_ref, imgH, imgW, img[1].p, H, W, s));
-    DFVO_TRY(launch_img_u8_to_flow_input(d_cur, imgH, imgW, img[1].p + img_px * 4, H, W, s));
     // image pyramid (lite_flow_net.py:307-309)
     for (int l = 2; l <= 6; ++l)
         DFVO_TRY(launch_resize_bilinear(img[l - 1].p, N, lh[l - 1], lw[l - 1], 4, img[l].p, lh[l], lw[l], 0, s));
@@ -593,17 +599,17 @@ int FlowNet::forward(const uint8_t* d_ref, const uint8_t* d_cur, float* d_fwd, f
         set_last_error("FlowNet::forward before finalize");
         return DFVO_ERR_STATE;
     }
+    DFVO_TRY(enqueue_input(d_ref, d_cur));
     if (!tuned_once) {  // first call: eager run with the conv autotuner on (sizes are final from here on)
         conv_autotune_scope(true);
-        int rc = enqueue(d_ref, d_cur, d_fwd, d_bwd, d_diff);
+        int rc = enqueue(d_fwd, d_bwd, d_diff);
         conv_autotune_scope(false);
         if (rc != DFVO_OK) return rc;
         DFVO_HIP_CHECK(hipStreamSynchronize(stream));
         tuned_once = true;
     }
-    if (!use_graph) return enqueue(d_ref, d_cur, d_fwd, d_bwd, d_diff);
-    if (graph_exec && (graph_ref != d_ref || graph_cur != d_cur || graph_fwd != d_fwd || graph_bwd != d_bwd ||
-                       graph_diff != d_diff)) {
+    if (!use_graph) return enqueue(d_fwd, d_bwd, d_diff);
+    if (graph_exec && (graph_fwd != d_fwd || graph_bwd != d_bwd || graph_diff != d_diff)) {
         (void)hipGraphExecDestroy(graph_exec);
         (void)hipGraphDestroy(graph);
         graph_exec = nullptr;
@@ -611,16 +617,14 @@ int FlowNet::forward(const uint8_t* d_ref, const uint8_t* d_cur, float* d_fwd, f
     }
     if (!graph_exec) {
         // run once eagerly (configures function attributes), then capture
-        DFVO_TRY(enqueue(d_ref, d_cur, d_fwd, d_bwd, d_diff));
+        DFVO_TRY(enqueue(d_fwd, d_bwd, d_diff));
         DFVO_HIP_CHECK(hipStreamSynchronize(stream));
         DFVO_HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-        int rc = enqueue(d_ref, d_cur, d_fwd, d_bwd, d_diff);
+        int rc = enqueue(d_fwd, d_bwd, d_diff);
         hipError_t e = hipStreamEndCapture(stream, &graph);
         if (rc != DFVO_OK) return rc;
         DFVO_HIP_CHECK(e);
         DFVO_HIP_CHECK(hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0));
-        graph_ref = d_ref;
-        graph_cur = d_cur;
         graph_fwd = d_fwd;
         graph_bwd = d_bwd;
         graph_diff = d_diff;

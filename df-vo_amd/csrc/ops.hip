@@ -394,12 +394,7 @@ int launch_correlation(const float* f1, int cs1, int co1, const float* f2, int c
     if (C > 96) { TH = 4; TW = 4; }
     const size_t lds = (size_t)(TH * TW + (TH + 6) * (TW + 6)) * (C + 1) * sizeof(float);
     DFVO_ARG_CHECK(lds <= 160 * 1024, "correlation: channel count too large for the LDS tile");
-    static size_t configured = 0;
-    if (lds > configured) {
-        DFVO_HIP_CHECK(hipFuncSetAttribute((const void*)k_correlation, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)lds));
-        configured = lds;
-    }
+    if (int rc_lds = ensure_dyn_lds((const void*)k_correlation, lds)) return rc_lds;
     dim3 grid(cdiv(Wo, TW), cdiv(Ho, TH), N);
     hipLaunchKernelGGL(k_correlation, grid, dim3(256), lds, s, f1, cs1, co1, f2, cs2, co2, swap2, N, H, W, C, stride,
                        Ho, Wo, TH, TW, dst, dcs, slope);

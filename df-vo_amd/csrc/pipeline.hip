@@ -137,6 +137,7 @@ int dfvo_pipeline_create(const dfvo_pipeline_cfg* cfg, dfvo_pipeline** out) {
     }
     if (p->feed_resize.init(p->H, p->W, p->feedH, p->feedW) != DFVO_OK) return fail(DFVO_ERR_HIP);
     enqueue_mt_seed(p->tbs[0], cfg->seed, p->s_trk);
+    (void)hipStreamSynchronize(p->s_trk);
     *out = p;
     return DFVO_OK;
 }
@@ -216,7 +217,11 @@ int dfvo_pipeline_set_graph(dfvo_pipeline* p, int enable) {
 }
 int dfvo_pipeline_seed(dfvo_pipeline* p, uint32_t seed) {
     DFVO_ARG_CHECK(p, "null pipeline");
-    return enqueue_mt_seed(p->tbs[0], seed, p->s_trk);
+    // synchronous: the first RandomState consumer of the next pair (the keypoint shuffles) runs on tb.s_rep[0], which is
+    // ordered after the keypoint stage but not after s_trk -- the new key must be in place before track() is called
+    P_TRY(enqueue_mt_seed(p->tbs[0], seed, p->s_trk));
+    DFVO_HIP_CHECK(hipStreamSynchronize(p->s_trk));
+    return DFVO_OK;
 }
 
 int dfvo_pipeline_enqueue_nets(dfvo_pipeline* p, int slot, const uint8_t* d_ref, const uint8_t* d_cur,
@@ -241,7 +246,7 @@ int dfvo_pipeline_enqueue_nets(dfvo_pipeline* p, int slot, const uint8_t* d_ref,
     const int inst = slot % p->flow_instances;
     FlowNet& fn = inst == 0 ? p->flow : p->flow_x[inst - 1];
     hipStream_t sf = fn.stream;
-    P_TRY(fn.forward(d_ref, d_cur, fn.out_fwd.p, fn.out_bwd.p, fn.out_diff.p));
+    P_TRY(fn.forward(d_ref, d_cur, fn.out_fwd.p, fn.out_bwd.p, fn.out_diff.p));  // frame pointers may change per pair (not captured)
     DFVO_HIP_CHECK(hipMemcpyAsync(p->fwd[slot], fn.out_fwd.p, 2 * px * sizeof(float), hipMemcpyDeviceToDevice, sf));
     DFVO_HIP_CHECK(hipMemcpyAsync(p->bwd[slot], fn.out_bwd.p, 2 * px * sizeof(float), hipMemcpyDeviceToDevice, sf));
     DFVO_HIP_CHECK(hipMemcpyAsync(p->diff[slot], fn.out_diff.p, px * sizeof(float), hipMemcpyDeviceToDevice, sf));
@@ -444,6 +449,36 @@ int dfvo_pipeline_get_flow(dfvo_pipeline* p, int slot, float* h_fwd, float* h_bw
     if (h_diff) DFVO_HIP_CHECK(hipMemcpy(h_diff, p->diff[slot], px * sizeof(float), hipMemcpyDeviceToHost));
     if (h_raw_depth) DFVO_HIP_CHECK(hipMemcpy(h_raw_depth, p->raw_depth[slot], px * sizeof(float), hipMemcpyDeviceToHost));
     if (h_depth) DFVO_HIP_CHECK(hipMemcpy(h_depth, p->proc_depth[slot], px * sizeof(double), hipMemcpyDeviceToHost));
+    return DFVO_OK;
+}
+
+int dfvo_pipeline_get_keypoints(dfvo_pipeline* p, int slot, int cap, double* h_kp_ref, double* h_kp_cur,
+                                uint8_t* h_inliers, int* n_out) {
+    DFVO_ARG_CHECK(p && n_out && (slot >= 0 && slot < DFVO_PIPELINE_SLOTS) && cap >= 0,
+                   "dfvo_pipeline_get_keypoints: bad argument");
+    TrackerBuffers& tb = p->tbs[slot];
+    DFVO_HIP_CHECK(hipDeviceSynchronize());
+    int info[3] = {0, 0, 0};
+    DFVO_HIP_CHECK(hipMemcpy(info, tb.kp_info, sizeof(info), hipMemcpyDeviceToHost));
+    *n_out = info[0];
+    const int n = info[0] < cap ? info[0] : cap;
+    if (n > 0 && h_kp_ref) DFVO_HIP_CHECK(hipMemcpy(h_kp_ref, tb.kp_ref, sizeof(double) * 2 * n, hipMemcpyDeviceToHost));
+    if (n > 0 && h_kp_cur) DFVO_HIP_CHECK(hipMemcpy(h_kp_cur, tb.kp_cur, sizeof(double) * 2 * n, hipMemcpyDeviceToHost));
+    if (n > 0 && h_inliers) DFVO_HIP_CHECK(hipMemcpy(h_inliers, tb.best_inliers, n, hipMemcpyDeviceToHost));
+    return DFVO_OK;
+}
+
+int dfvo_pipeline_get_rng_state(dfvo_pipeline* p, uint32_t* h_state) {
+    DFVO_ARG_CHECK(p && h_state, "dfvo_pipeline_get_rng_state: null argument");
+    DFVO_HIP_CHECK(hipStreamSynchronize(p->s_trk));
+    DFVO_HIP_CHECK(hipMemcpy(h_state, p->tbs[0].mt_state, 625 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return DFVO_OK;
+}
+
+int dfvo_pipeline_set_rng_state(dfvo_pipeline* p, const uint32_t* h_state) {
+    DFVO_ARG_CHECK(p && h_state, "dfvo_pipeline_set_rng_state: null argument");
+    DFVO_HIP_CHECK(hipStreamSynchronize(p->s_trk));
+    DFVO_HIP_CHECK(hipMemcpy(p->tbs[0].mt_state, h_state, 625 * sizeof(uint32_t), hipMemcpyHostToDevice));
     return DFVO_OK;
 }
 

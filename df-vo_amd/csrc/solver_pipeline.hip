@@ -654,11 +654,7 @@ int enqueue_rigid_flow_kp(RigidKpBuffers& rb, const float* d_flow, const float* 
     if (par) lds += (size_t)cap * 4 + 16;
     int rc = rb.ensure(H, W, cells, n_best, cap);
     if (rc != DFVO_OK) return rc;
-    static size_t configured = 0;
-    if (lds > configured) {
-        DFVO_HIP_CHECK(hipFuncSetAttribute((const void*)k_kp_cell_rigid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = lds;
-    }
+    if (int rc_lds = ensure_dyn_lds((const void*)k_kp_cell_rigid, lds)) return rc_lds;
     const float* rdiff = d_rdiff_override;
     if (!rdiff) {
         float m[34];
@@ -728,11 +724,7 @@ int enqueue_local_bestn(TrackerBuffers& tb, const float* d_flow, const float* d_
         tb.lidx_cap = (size_t)cells * cap;
         DFVO_HIP_CHECK(hipMalloc((void**)&tb.lidx, sizeof(unsigned short) * tb.lidx_cap));
     }
-    static size_t configured = 0;
-    if (lds > configured) {
-        DFVO_HIP_CHECK(hipFuncSetAttribute((const void*)k_kp_cell, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        configured = lds;
-    }
+    if (int rc_lds = ensure_dyn_lds((const void*)k_kp_cell, lds)) return rc_lds;
     DFVO_HIP_CHECK(hipMemsetAsync(tb.kp_total, 0, sizeof(int), s));
     hipLaunchKernelGGL(k_kp_count, dim3(cdiv(H * W, 256)), dim3(256), 0, s, d_diff, H * W, thre, tb.kp_total);
     hipLaunchKernelGGL(k_kp_cell, dim3(cells), dim3(256), lds, s, d_diff, H, W, num_row, num_col, thre, n_best, cap,
@@ -1538,6 +1530,7 @@ int TrackerBuffers::init() {
     DFVO_HIP_CHECK(hipMalloc((void**)&kp_total, sizeof(int) * 8));
     DFVO_HIP_CHECK(hipMalloc((void**)&pose, sizeof(PoseState)));
     DFVO_HIP_CHECK(hipMalloc((void**)&small, sizeof(double) * 128));
+    DFVO_HIP_CHECK(hipHostMalloc((void**)&h_small, sizeof(double) * 18, hipHostMallocDefault));
     DFVO_HIP_CHECK(hipMalloc((void**)&scale_out, sizeof(ScaleResult)));
     DFVO_HIP_CHECK(hipMemset(kp_info, 0, sizeof(int) * 8));
     for (int r = 0; r < MAX_REP; r++) {
@@ -1562,6 +1555,7 @@ int TrackerBuffers::init_shared(const TrackerBuffers& first) {
     DFVO_HIP_CHECK(hipMalloc((void**)&kp_total, sizeof(int) * 8));
     DFVO_HIP_CHECK(hipMalloc((void**)&pose, sizeof(PoseState)));
     DFVO_HIP_CHECK(hipMalloc((void**)&small, sizeof(double) * 128));
+    DFVO_HIP_CHECK(hipHostMalloc((void**)&h_small, sizeof(double) * 18, hipHostMallocDefault));
     DFVO_HIP_CHECK(hipMalloc((void**)&scale_out, sizeof(ScaleResult)));
     DFVO_HIP_CHECK(hipMemset(kp_info, 0, sizeof(int) * 8));
     DFVO_HIP_CHECK(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
@@ -1587,6 +1581,8 @@ void TrackerBuffers::release() {
     if (ev_h) (void)hipEventDestroy(ev_h);
     ev_fork = ev_start = ev_h = nullptr;
     if (shared) mt_state = nullptr;
+    if (h_small) (void)hipHostFree(h_small);
+    h_small = nullptr;
     void* ptrs[] = {mt_state, kp_info, kp_total, pose, small, scale_out, winner, lidx};
     lidx = nullptr;
     lidx_cap = 0;
@@ -1615,12 +1611,7 @@ int enqueue_mt_shuffle(uint32_t* mt_state, const int* d_n, int n_host, int repea
     int group = (int)((144 * 1024) / per_rep);
     if (group > repeat) group = repeat;
     const size_t perm_lds = per_rep * group + 16;
-    static size_t configured = 0;
-    if (perm_lds > configured) {
-        DFVO_HIP_CHECK(hipFuncSetAttribute((const void*)k_mt_shuffle_all, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)perm_lds));
-        configured = perm_lds;
-    }
+    if (int rc_lds = ensure_dyn_lds((const void*)k_mt_shuffle_all, perm_lds)) return rc_lds;
     hipLaunchKernelGGL(k_mt_shuffle_all, dim3(1), dim3(256), perm_lds, s, mt_state, d_n, repeat, group, perm_stride, perm);
     DFVO_HIP_CHECK(hipGetLastError());
     return DFVO_OK;
@@ -1635,12 +1626,14 @@ int enqueue_mt_shuffle(uint32_t* mt_state, const int* d_n, int n_host, int repea
 // previous pair is still busy.  Records tb.ev_start (keypoints ready) and tb.ev_h (this half done) on sh.
 int enqueue_pose_h_part(TrackerBuffers& tb, int n_bound, const PoseConfig& cfg, hipStream_t sh) {
     DFVO_ARG_CHECK(n_bound >= 0 && n_bound <= tb.kp_cap, "compute_pose_2d2d: keypoint capacity");
-    double hk[18];
+    // pinned source: the copy may still be pending when this function returns (sh can be blocked on the slot's nets);
+    // a slot is re-enqueued only after its previous track() returned, i.e. after the previous copy was consumed
+    double* hk = tb.h_small;
     for (int i = 0; i < 9; i++) {
         hk[i] = cfg.KinvT[i];
         hk[9 + i] = cfg.Kinv[i];
     }
-    DFVO_HIP_CHECK(hipMemcpyAsync(tb.small, hk, sizeof(hk), hipMemcpyHostToDevice, sh));
+    DFVO_HIP_CHECK(hipMemcpyAsync(tb.small, hk, 18 * sizeof(double), hipMemcpyHostToDevice, sh));
     hipLaunchKernelGGL(k_pose_state_init, dim3(cdiv(tb.kp_cap, 256)), dim3(256), 0, sh, tb.pose, tb.kp_info,
                        tb.best_inliers, tb.kp_cap);
     DFVO_HIP_CHECK(hipEventRecord(tb.ev_start, sh));

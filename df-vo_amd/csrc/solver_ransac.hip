@@ -1214,11 +1214,8 @@ int enqueue_find_homography(RansacWorkspace& w, const double* d_pts1, const doub
     }
     // every inlier's coordinates stay in LDS across the LM passes when they fit (16 B / point)
     const int pts_cap = n <= 6144 ? n : 0;
-    static int configured = 0;
-    if (pts_cap * 16 > configured) {
-        DFVO_HIP_CHECK(hipFuncSetAttribute((const void*)k_h_refine, hipFuncAttributeMaxDynamicSharedMemorySize, 6144 * 16));
-        configured = 6144 * 16;
-    }
+    if (pts_cap)
+        if (int rc_lds = ensure_dyn_lds((const void*)k_h_refine, 6144 * 16)) return rc_lds;
     // inlier mask of the winner + refit + LM in one launch
     hipLaunchKernelGGL(k_h_refine, dim3(1), dim3(256), (size_t)pts_cap * 16, s, w.state, w.f_a, w.f_b, n, d_n, w.mask, w.cidx,
                        w.lm, w.out, pts_cap, w.models, thr2);

@@ -105,6 +105,7 @@ struct TrackerBuffers {
     int* kp_total = nullptr;
     PoseState* pose = nullptr;
     double* small = nullptr;
+    double* h_small = nullptr;     // pinned staging for the 18 intrinsics doubles uploaded into `small` (async-safe source)
     ScaleResult* scale_out = nullptr;
     int* winner = nullptr;
     size_t winner_cap = 0;

@@ -42,6 +42,10 @@ def compose_trajectory(gathered, first_pose=None):
     """sequential prefix composition over all gathered pairs -> global poses [n+1,4,4].
     status 1 (constant motion) reuses the previous pair's relative motion, as the reference does."""
     n = gathered.shape[0]
+    bad = np.nonzero(gathered[:, 16] == 2)[0]
+    if bad.size:  # DFVO_TRACK_NEEDS_PNP: the row holds no pose (the chunk started without a reference depth)
+        raise ValueError("compose_trajectory: pair(s) %s need the PnP fallback but had no reference depth; start every "
+                         "chunk with TrackingPipeline.set_ref_image(first frame of the chunk)" % bad[:8].tolist())
     g = np.eye(4) if first_pose is None else first_pose.copy()
     out = np.zeros((n + 1, 4, 4))
     out[0] = g

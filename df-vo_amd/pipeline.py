@@ -122,6 +122,29 @@ class TrackingPipeline:
                                                    capi.as_ptr(raw), capi.as_ptr(dep)))
         return fwd, bwd, diff, raw, dep
 
+    def get_keypoints(self, slot, cap=4096):
+        """kp_best of the reference / current frame [n,2] f64 and the E-tracker's inlier mask [n] bool for `slot`"""
+        kr = np.zeros((cap, 2))
+        kc = np.zeros((cap, 2))
+        inl = np.zeros(cap, np.uint8)
+        n = C.c_int(0)
+        capi.check(self.lib.dfvo_pipeline_get_keypoints(self.h, slot, cap, capi.as_ptr(kr), capi.as_ptr(kc), capi.as_ptr(inl),
+                                                        C.byref(n)))
+        assert n.value <= cap
+        return kr[:n.value], kc[:n.value], inl[:n.value].astype(bool)
+
+    def get_rng_state(self):
+        """the device-resident numpy RandomState as np.random.get_state() would return it"""
+        st = np.zeros(625, np.uint32)
+        capi.check(self.lib.dfvo_pipeline_get_rng_state(self.h, capi.as_ptr(st)))
+        return ("MT19937", st[:624].copy(), int(st[624]), 0, 0.0)
+
+    def set_rng_state(self, state):
+        st = np.zeros(625, np.uint32)
+        st[:624] = state[1]
+        st[624] = state[2]
+        capi.check(self.lib.dfvo_pipeline_set_rng_state(self.h, capi.as_ptr(st)))
+
     # ---- hybrid pose + accumulation (dfvo.py:109-119, 163-262) -------------------------------------------
     @staticmethod
     def hybrid_pose(out, prev_motion):

@@ -1,0 +1,82 @@
+"""Sequence driver over the fused pipeline: the analogue of DFVO.main's frame loop (/root/reference/libs/dfvo.py:347-425)
+for one contiguous chunk of a sequence, and the frame-batch data-parallel wrapper around it.
+
+Pair j = (frame j, frame j+1).  A chunk [lo, hi) of pairs needs frames lo .. hi: frame lo is the chunk's 1-frame halo
+(its depth is the PnP fallback's reference depth for pair lo; the reference computes it when frame lo is `cur`, here it
+is recomputed by the rank that owns the chunk -- no activation exchange between ranks).  The nets run `ahead` pairs
+ahead of the solver stage; nothing but the relative poses leaves the device.
+
+RandomState modes (SURVEY hard part 2):
+  "sequential"  one stream seeded once (np.random.seed(cfg.seed), run.py:81-84) and carried from pair to pair -- the
+                reference's behaviour, reproducible only by a single rank walking the whole sequence in order;
+  "per_pair"    the stream is re-seeded with seed ^ (pair index + 1) before every pair, so a pair's result does not depend
+                on which rank tracked it or what came before: the data-parallel mode (documented deviation)."""
+import numpy as np
+import torch
+
+from . import capi
+from . import dist as dmod
+from .pipeline import TrackingPipeline
+
+SLOTS = 4  # DFVO_PIPELINE_SLOTS
+
+
+def track_chunk(pipe, frames, lo, hi, seed=4869, rng_mode="sequential", ahead=3, first_chunk=None, collect=None):
+    """track pairs lo .. hi-1 of `frames` (sequence of device uint8 tensors [H,W,3], indexable by frame number).
+    Returns (rel [n,4,4] cur->ref motions, status [n]); status-1 rows (constant motion) hold the identity and are resolved
+    by dist.compose_trajectory once the previous pair's motion is known."""
+    assert rng_mode in ("sequential", "per_pair")
+    n = hi - lo
+    rel = np.tile(np.eye(4), (n, 1, 1))
+    status = np.zeros(n, np.int64)
+    if n <= 0:
+        return rel, status
+    ahead = max(1, min(ahead, SLOTS - 1))
+    pipe.set_ref_image(frames[lo])  # halo: depth of the chunk's first reference frame
+    if rng_mode == "sequential":
+        pipe.seed(seed)
+    for j in range(lo, min(lo + ahead, hi)):
+        pipe.enqueue_nets(j % SLOTS, frames[j], frames[j + 1])
+        pipe.prefetch_track(j % SLOTS)
+    prev = np.eye(4)
+    for j in range(lo, hi):
+        if j + ahead < hi:
+            pipe.enqueue_nets((j + ahead) % SLOTS, frames[j + ahead], frames[j + ahead + 1])
+            pipe.prefetch_track((j + ahead) % SLOTS)
+        if rng_mode == "per_pair":
+            pipe.seed((seed ^ (j + 1)) & 0xffffffff)
+        out = pipe.track(j % SLOTS)
+        status[j - lo] = out.status
+        if out.status != 1:
+            rel[j - lo], _ = TrackingPipeline.hybrid_pose(out, prev)
+            prev = rel[j - lo]
+        if collect is not None:
+            collect(j, out)
+    pipe.sync()
+    return rel, status
+
+
+def run_sequence(pipe, frames, n_frames, world=1, rank=0, dist=None, seed=4869, rng_mode=None, ahead=3, collect=None):
+    """data-parallel tracking of an n_frames sequence: contiguous chunk per rank (dist.chunk_bounds), ONE all-gather of
+    the relative poses + status words (RCCL when `dist` runs the nccl backend), then the sequential prefix composition
+    that reproduces DFVO.update_global_pose incl. the constant-motion rule (dfvo.py:109-119,157-161).
+    Returns (global poses [n_frames,4,4] camera-to-world, gathered [n_frames-1,17])."""
+    if rng_mode is None:
+        rng_mode = "sequential" if world == 1 else "per_pair"
+    if world > 1 and rng_mode == "sequential":
+        raise ValueError("the sequential numpy RandomState cannot be reproduced frame-parallel; use rng_mode='per_pair'")
+    lo, hi = dmod.chunk_bounds(n_frames - 1, world, rank)
+    rel, status = track_chunk(pipe, frames, lo, hi, seed, rng_mode, ahead, collect=collect)
+    gathered = dmod.allgather_poses(rel, status, world, rank, dist)
+    return dmod.compose_trajectory(gathered), gathered
+
+
+def save_traj(path, poses):
+    """one line per frame: "<idx> r11 r12 r13 tx r21 ... tz" (libs/general/utils.py:329-355 save_traj, format 'kitti')"""
+    with open(path, "w") as f:
+        for i, p in enumerate(poses):
+            f.write(" ".join([str(i)] + [repr(float(v)) for v in np.asarray(p)[:3, :4].reshape(-1)]) + "\n")
+
+
+def frames_to_device(frames_u8):
+    return [torch.from_numpy(np.ascontiguousarray(f)).cuda() for f in frames_u8]

@@ -222,3 +222,302 @@ def rigid_scene(h, w, seed=1, T=None, noise_px=0.05, bad_frac=0.35):
     proc_ref[~((proc_ref < 50) & (proc_ref > 0))] = 0
     return dict(K=K, flow=flow.astype(np.float32), diff=diff.astype(np.float32), depth_cur=proc, depth_ref=proc_ref, R=R,
                 t=tv, scale_true=scale_true)
+
+
+# ==================================================================================================================
+# Coded tunnel world: frames that CARRY their own optical flow and depth, plus network weights that read them out.
+#
+# Random-weight networks give incoherent flow, so with them the nets -> keypoints -> RANSAC data path of
+# libs/dfvo.py:299-345,121-262 can only be fed from outside.  No trained weights / KITTI frames exist in the build
+# environment (no network), hence this construction: a convex rectangular tunnel (closed-form ray casting, no
+# occlusions, forward and backward flow exactly consistent) is rendered into uint8 frames whose colour channels hold
+# dithered CODES of the flow and depth fields, and a handful of channels of otherwise random LiteFlowNet / monodepth2
+# weights are overwritten so that the real layer stack (7x7 conv, stride-2 conv, 1x1 conv, the Subpixel stack with its
+# LeakyReLUs, the Regularization module's softmax-weighted local average; 7x7 stride-2 conv, BatchNorm, skip
+# connection, ELU decoder, sigmoid head) decodes them.  Every kernel of both nets still runs at full cost on dense
+# random weights; only the flow / disparity heads listen to the decoding channels.  Used by the end-to-end tests, the
+# trajectory test and `bench.py --solver-inputs nets`; the torch-CPU oracle runs the same weights on the same frames.
+#
+# Two frame encodings:
+#   "mux"   (image size == flow-net size, i.e. both divisible by 32; e.g. the reference's default 192x640): the 2x2
+#           pixel block under a level-2 feature pixel holds  (R,G)@(0,0) = forward flow to the next frame,
+#           (R,G)@(1,1) = backward flow to the previous frame,  R@(0,1) = frame counter;  B of every pixel = depth.
+#           The Subpixel stack gates "first.fwd if second is the later frame else first.bwd" with exact ReLUs built
+#           from LeakyReLU pairs, so fwd AND bwd flow are the true fields of an arbitrarily long sequence.
+#   "pot"   (any size; the frame goes through the net's bilinear input resize, which spatial multiplexing does not
+#           survive): (R,G) hold a potential x_k with x_k - x_{k+1} = fwd_k / (2 range); the net outputs
+#           2 range (x_first - x_second), i.e. bwd_k(p) = -fwd_k(p) at the same pixel.  x accumulates, so this
+#           encoding is for short sequences with small motion (tests: 4 frames; bench: one pair).
+# ==================================================================================================================
+DEPTH_LOGIT = (-5.0, -1.7)  # disparity logit at B = 0 / 255  ->  depth 70.2 m ... 3.48 m through monodepth2's head
+
+
+def kitti_K(h, w):
+    f = 718.856 * w / 1241.0
+    return np.array([[f, 0, 607.19 * w / 1241.0], [0, f, 185.22 * h / 376.0], [0, 0, 1]])
+
+
+def _depth_code_table():
+    """depth [m] that monodepth2's head (sigmoid -> 1/(0.01 + 9.99 s) * 5.4) yields for each 8-bit code"""
+    code = np.arange(256, dtype=np.float64)
+    logit = DEPTH_LOGIT[0] + (DEPTH_LOGIT[1] - DEPTH_LOGIT[0]) * code / 255.0
+    s = 1.0 / (1.0 + np.exp(-logit))
+    return 5.4 / (0.01 + 9.99 * s)  # strictly decreasing in the code
+
+
+def encode_depth(z):
+    """nearest 8-bit code for a depth map (comparisons against the 256-entry table only)"""
+    tab = _depth_code_table()
+    mid = 0.5 * (tab[1:] + tab[:-1])  # decreasing
+    return (255 - np.searchsorted(mid[::-1], z, side="left")).astype(np.uint8)
+
+
+def crafted_monodepth2_state_dict(seed=4869):
+    """random ResNet18 + decoder whose disparity head reads the blue channel:  logit = L0 + (L1 - L0) B/255.
+    Path: conv1 centre tap (+B, -B) -> BN identity -> ReLU pair -> skip connection into upconv(1,1): (p - n) + 3 > 0
+    (ELU = identity) -> upconv(0,0), nearest x2, upconv(0,1) centre taps -> dispconv -> sigmoid."""
+    sd = monodepth2_state_dict(seed)
+    w = sd['encoder.conv1.weight']
+    w[0:2] = 0
+    w[0, 2, 3, 3] = 1.0
+    w[1, 2, 3, 3] = -1.0
+    for k, v in (('weight', 1.0), ('bias', 0.0), ('running_mean', 0.0), ('running_var', 1.0)):
+        sd['encoder.bn1.' + k][0:2] = v
+    w = sd['decoder.7.conv.conv.weight']  # upconv(1,1): cat(upsampled 32, features[0] 64) -> 32
+    w[0] = 0
+    w[0, 32 + 0, 1, 1] = 1.0
+    w[0, 32 + 1, 1, 1] = -1.0
+    sd['decoder.7.conv.conv.bias'][0] = 3.0
+    for name in ('decoder.8.conv.conv', 'decoder.9.conv.conv'):  # upconv(0,0), upconv(0,1)
+        w = sd[name + '.weight']
+        w[0] = 0
+        w[0, 0, 1, 1] = 1.0
+        sd[name + '.bias'][0] = 0.0
+    bn_scale = 1.0 / math.sqrt(1.0 + 1e-5)  # eval BatchNorm with unit variance
+    a = (DEPTH_LOGIT[1] - DEPTH_LOGIT[0]) * 0.225 / bn_scale
+    b = DEPTH_LOGIT[0] + (DEPTH_LOGIT[1] - DEPTH_LOGIT[0]) * 0.45
+    w = sd['decoder.10.conv.weight']
+    w[:] = 0
+    w[0, 0, 1, 1] = a
+    sd['decoder.10.conv.bias'][0] = b - 3.0 * a
+    return sd
+
+
+def crafted_liteflownet_state_dict(h, w, mode, flow_range=32.0, seed=4869):
+    """random LiteFlowNet whose level-2 flow reads the frame codes (see the block comment above).
+    (h, w) = image size (the output scaling of deep_flow.py:106-129 is folded into the head gain)."""
+    assert mode in ("mux", "pot")
+    sd = liteflownet_state_dict(seed)
+    nh, nw = _net_size(h, w)
+    if mode == "mux":
+        assert (nh, nw) == (h, w), "the multiplexed encoding needs image size == flow-net size"
+    ncode = 5 if mode == "mux" else 2
+
+    def passthrough(name, n, tap):
+        wt, b = sd[name + '.weight'], sd[name + '.bias']
+        wt[:n] = 0
+        b[:n] = 0
+        for c in range(n):
+            wt[c, c, tap, tap] = 1.0
+
+    p = 'moduleFeatures.'
+    passthrough(p + 'moduleOne.0', 2, 3)  # R, G at the centre tap of the 7x7
+    wt, b = sd[p + 'moduleTwo.0.weight'], sd[p + 'moduleTwo.0.bias']  # 3x3 stride 2 pad 1: tap (1,1) = pixel (2i,2j)
+    wt[:ncode] = 0
+    b[:ncode] = 0
+    wt[0, 0, 1, 1] = 1.0
+    wt[1, 1, 1, 1] = 1.0
+    if mode == "mux":
+        wt[2, 0, 2, 2] = 1.0  # R @ (2i+1, 2j+1): backward u
+        wt[3, 1, 2, 2] = 1.0  # G @ (2i+1, 2j+1): backward v
+        wt[4, 0, 1, 2] = 1.0  # R @ (2i, 2j+1): frame counter
+    passthrough(p + 'moduleTwo.2', ncode, 1)
+    passthrough(p + 'moduleTwo.4', ncode, 1)
+    passthrough('moduleSubpixel.0.moduleFeat.0', ncode, 0)
+    # level-2 Matching contributes nothing: flow entering Subpixel is exactly 0 (second features warped by zero flow)
+    sd['moduleMatching.0.moduleUpflow.weight'][:] = 0
+    sd['moduleMatching.0.moduleMain.6.weight'][:] = 0
+    sd['moduleMatching.0.moduleMain.6.bias'][:] = 0
+    ps = 'moduleSubpixel.0.moduleMain.'
+    F, S = 0, 64  # channel offsets of first / second features in cat([first, second, flow])
+    w0, b0 = sd[ps + '0.weight'], sd[ps + '0.bias']
+    w2, b2 = sd[ps + '2.weight'], sd[ps + '2.bias']
+    w4, b4 = sd[ps + '4.weight'], sd[ps + '4.bias']
+    w6, b6 = sd[ps + '6.weight'], sd[ps + '6.bias']
+    r = 1.0 / 0.99  # relu(z) = (leaky(z) + 0.1 leaky(-z)) / 0.99 for slope 0.1
+    if mode == "mux":
+        w0[:6] = 0
+        b0[:6] = 0
+        for c in range(4):
+            w0[c, F + c, 1, 1] = 1.0  # a_u, a_v (first.fwd), b_u, b_v (first.bwd)
+        w0[4, S + 4, 1, 1], w0[4, F + 4, 1, 1] = 255.0, -255.0  # d = +1: second is the later frame
+        w0[5, S + 4, 1, 1], w0[5, F + 4, 1, 1] = -255.0, 255.0
+        w2[:8] = 0
+        b2[:8] = 0
+        for comp in range(2):  # s = relu(d);  z1 = a + s - 1 (selected when s = 1),  z2 = b - s (when s = 0)
+            o = 4 * comp
+            for sign, row in ((1.0, o), (-1.0, o + 1)):
+                w2[row, comp, 1, 1] = sign
+                w2[row, 4, 1, 1], w2[row, 5, 1, 1] = sign * r, sign * 0.1 * r
+                b2[row] = -sign
+            for sign, row in ((1.0, o + 2), (-1.0, o + 3)):
+                w2[row, 2 + comp, 1, 1] = sign
+                w2[row, 4, 1, 1], w2[row, 5, 1, 1] = -sign * r, -sign * 0.1 * r
+        w4[:2] = 0
+        b4[:2] = 0
+        for comp in range(2):  # selected code = relu(z1) + relu(z2) in [0, 1]
+            o = 4 * comp
+            w4[comp, o, 1, 1], w4[comp, o + 1, 1, 1] = r, 0.1 * r
+            w4[comp, o + 2, 1, 1], w4[comp, o + 3, 1, 1] = r, 0.1 * r
+    else:
+        w0[:4] = 0
+        b0[:4] = 0
+        w0[0, F + 0, 1, 1] = w0[1, F + 1, 1, 1] = w0[2, S + 0, 1, 1] = w0[3, S + 1, 1, 1] = 1.0
+        for wt, b in ((w2, b2), (w4, b4)):
+            wt[:4] = 0
+            b[:4] = 0
+            for c in range(4):
+                wt[c, c, 1, 1] = 1.0
+    # head: image-resolution flow [px] = 10 * (W_img / W_level2) * net output  (lite_flow_net.py:322-324, deep_flow.py:106-129)
+    gu = 2.0 * flow_range / (10.0 * w / (nw // 2))
+    gv = 2.0 * flow_range / (10.0 * h / (nh // 2))
+    w6[:] = 0
+    if mode == "mux":
+        w6[0, 0, 3, 3], w6[1, 1, 3, 3] = gu, gv
+        b6[0], b6[1] = -0.5 * gu, -0.5 * gv
+    else:
+        w6[0, 0, 3, 3], w6[0, 2, 3, 3] = gu, -gu
+        w6[1, 1, 3, 3], w6[1, 3, 3, 3] = gv, -gv
+        b6[:] = 0
+    # Regularization: a convex combination of the 7x7 neighbourhood (ScaleX/Y = 1), near-uniform softmax weights
+    pr = 'moduleRegularization.0.'
+    for k in (pr + 'moduleScaleX', pr + 'moduleScaleY'):
+        sd[k + '.weight'][:] = 1.0
+        sd[k + '.bias'][:] = 0.0
+    sd[pr + 'moduleDist.1.weight'] *= 0.02
+    sd[pr + 'moduleDist.1.bias'] *= 0.02
+    return sd
+
+
+def _net_size(h, w):
+    """deep_flow.py:89-105"""
+    hs = [32 * (h // 32), 32 * (h // 32 + 1)]
+    ws = [32 * (w // 32), 32 * (w // 32 + 1)]
+    best, arg = None, None
+    for i in range(4):
+        rr = abs(hs[i // 2] * (1.0 / ws[i % 2]) - h / w)
+        if best is None or rr < best:
+            best, arg = rr, i
+    return hs[arg // 2], ws[arg % 2]
+
+
+def tunnel_poses(n, step=1.0, seed=7):
+    """camera-to-world poses [n,4,4] (KITTI convention: x right, y down, z forward): forward drive with gentle yaw /
+    pitch oscillation and lateral sway, first pose = identity"""
+    k = np.arange(n, dtype=np.float64)
+    yaw = 0.06 * np.sin(k / 11.0) + 0.004 * k / max(n, 1)
+    pitch = 0.008 * np.sin(k / 7.0 + 1.0)
+    x = 1.2 * (np.cos(k / 17.0) - 1.0)
+    y = 0.08 * np.sin(k / 5.0)
+    z = step * k + 0.15 * np.sin(k / 3.0)
+    yaw, pitch = yaw - yaw[0], pitch - pitch[0]
+    y, z = y - y[0], z - z[0]
+    T = np.zeros((n, 4, 4))
+    for i in range(n):
+        cy_, sy_ = math.cos(yaw[i]), math.sin(yaw[i])
+        cp, sp = math.cos(pitch[i]), math.sin(pitch[i])
+        Ry = np.array([[cy_, 0, sy_], [0, 1, 0], [-sy_, 0, cy_]])
+        Rx = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]])
+        T[i, :3, :3] = Ry @ Rx
+        T[i, :3, 3] = [x[i], y[i], z[i]]
+        T[i, 3, 3] = 1
+    return T
+
+
+def tunnel_cast(K, T_wc, py, px, half_width=15.0, cam_height=5.0, ceiling=12.0):
+    """world points hit by the pixel rays (py, px arrays) of camera T_wc in the tunnel |X| <= half_width,
+    -ceiling <= Y <= cam_height (infinite along Z; convex, so every point is visible from every interior camera).
+    Returns (Xw [3, ...], depth = z in the camera frame)."""
+    Kinv = np.linalg.inv(K)
+    d_c = np.stack([Kinv[0, 0] * px + Kinv[0, 2], Kinv[1, 1] * py + Kinv[1, 2], np.ones_like(px)])  # z = 1 rays
+    R, o = T_wc[:3, :3], T_wc[:3, 3]
+    d_w = np.tensordot(R, d_c, axes=(1, 0))
+    tbest = np.full(px.shape, np.inf)
+    for axis, plane in ((0, half_width), (0, -half_width), (1, cam_height), (1, -ceiling)):
+        with np.errstate(divide="ignore", invalid="ignore"):
+            t = (plane - o[axis]) / d_w[axis]
+        t = np.where((t > 0) & np.isfinite(t), t, np.inf)
+        tbest = np.minimum(tbest, t)
+    tbest = np.minimum(tbest, 1e4)  # rays along the tunnel axis
+    Xw = o.reshape(3, *([1] * px.ndim)) + d_w * tbest
+    return Xw, tbest
+
+
+def tunnel_flow(K, T_wc_from, T_wc_to, py, px, **world):
+    """flow (u, v) of the pixels (py, px) of camera `from` into camera `to`, and their depth in `from`"""
+    Xw, z = tunnel_cast(K, T_wc_from, py, px, **world)
+    R, o = T_wc_to[:3, :3], T_wc_to[:3, 3]
+    Xc = np.tensordot(R.T, Xw - o.reshape(3, *([1] * px.ndim)), axes=(1, 0))
+    u = K[0, 0] * Xc[0] / Xc[2] + K[0, 2]
+    v = K[1, 1] * Xc[1] / Xc[2] + K[1, 2]
+    return u - px, v - py, z
+
+
+def coded_tunnel_sequence(h, w, n_frames, mode="mux", flow_range=32.0, step=1.0, seed=7, poses=None, world=None):
+    """uint8 frames [n,h,w,3] of the coded tunnel world + ground truth.
+    Returns dict(frames, poses [n,4,4] camera-to-world, K, mode, flow_range, world)."""
+    world = dict(world or {})
+    K = kitti_K(h, w)
+    T = tunnel_poses(n_frames, step, seed) if poses is None else np.asarray(poses, np.float64)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    nh, nw = _net_size(h, w)
+    frames = np.zeros((n_frames, h, w, 3), np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+
+    def code(v):  # dithered 8-bit code of a value in [0, 1]
+        return np.clip(np.floor(v * 255.0 + rng.random(v.shape)), 0, 255).astype(np.uint8)
+
+    if mode == "mux":
+        assert (nh, nw) == (h, w) and n_frames <= 256
+        h2, w2 = h // 2, w // 2
+        # image position a level-2 pixel stands for once the level-2 flow is resized to the image (align_corners)
+        py = (np.arange(h2, dtype=np.float64) * (h - 1) / (h2 - 1))[:, None] * np.ones((1, w2))
+        px = np.ones((h2, 1)) * (np.arange(w2, dtype=np.float64) * (w - 1) / (w2 - 1))[None, :]
+    else:
+        x_pot = np.full((2, h, w), 0.5)
+    for k in range(n_frames):
+        _, z = tunnel_cast(K, T[k], yy, xx, **world)
+        frames[k, :, :, 2] = encode_depth(z)
+        if mode == "mux":
+            frames[k, :, :, 0:2] = rng.integers(0, 256, (h, w, 2), dtype=np.uint8)  # filler texture
+            if k + 1 < n_frames:
+                u, v, _ = tunnel_flow(K, T[k], T[k + 1], py, px, **world)
+            else:
+                u = v = np.zeros((h2, w2))
+            frames[k, 0::2, 0::2, 0] = code(0.5 + u / (2 * flow_range))
+            frames[k, 0::2, 0::2, 1] = code(0.5 + v / (2 * flow_range))
+            if k > 0:
+                u, v, _ = tunnel_flow(K, T[k], T[k - 1], py, px, **world)
+            else:
+                u = v = np.zeros((h2, w2))
+            frames[k, 1::2, 1::2, 0] = code(0.5 + u / (2 * flow_range))
+            frames[k, 1::2, 1::2, 1] = code(0.5 + v / (2 * flow_range))
+            frames[k, 0::2, 1::2, 0] = k
+        else:
+            frames[k, :, :, 0] = code(x_pot[0])
+            frames[k, :, :, 1] = code(x_pot[1])
+            if k + 1 < n_frames:
+                u, v, _ = tunnel_flow(K, T[k], T[k + 1], yy, xx, **world)
+                x_pot[0] -= u / (2 * flow_range)
+                x_pot[1] -= v / (2 * flow_range)
+    return dict(frames=frames, poses=T, K=K, mode=mode, flow_range=flow_range, world=world)
+
+
+def tunnel_truth(seq, k):
+    """ground-truth forward flow [2,h,w] (frame k -> k+1), backward flow (k+1 -> k) and depth of frame k+1, full resolution"""
+    fr = seq["frames"]
+    h, w = fr.shape[1:3]
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    u, v, _ = tunnel_flow(seq["K"], seq["poses"][k], seq["poses"][k + 1], yy, xx, **seq["world"])
+    ub, vb, z1 = tunnel_flow(seq["K"], seq["poses"][k + 1], seq["poses"][k], yy, xx, **seq["world"])
+    return np.stack([u, v]), np.stack([ub, vb]), z1

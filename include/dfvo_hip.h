@@ -364,6 +364,13 @@ int dfvo_pipeline_track(dfvo_pipeline* p, int slot, const float* d_flow_override
                         const double* d_depth_override, dfvo_track_out* out);
 int dfvo_pipeline_get_flow(dfvo_pipeline* p, int slot, float* h_fwd, float* h_bwd, float* h_diff, float* h_raw_depth,
                            double* h_depth);
+/* inspection (tests, debugging): keypoints selected for `slot` (kp_best of ref / cur, double [n][2], x,y), the E-tracker's
+ * best inlier mask (uint8 [n]; ref_data['inliers'], dfvo.py:179) -- up to `cap` entries, *n_out = the full count -- and the
+ * numpy RandomState the pipeline carries from pair to pair (uint32 key[624] + pos, np.random.get_state() layout) */
+int dfvo_pipeline_get_keypoints(dfvo_pipeline* p, int slot, int cap, double* h_kp_ref, double* h_kp_cur,
+                                uint8_t* h_inliers, int* n_out);
+int dfvo_pipeline_get_rng_state(dfvo_pipeline* p, uint32_t* h_state625);
+int dfvo_pipeline_set_rng_state(dfvo_pipeline* p, const uint32_t* h_state625);
 int dfvo_pipeline_sync(dfvo_pipeline* p);
 double dfvo_pipeline_net_flops(const dfvo_pipeline* p);
 

@@ -11,3 +11,8 @@ smooth_noise = _s.smooth_noise
 image_pair = _s.image_pair
 two_view = _s.two_view
 rigid_scene = _s.rigid_scene
+coded_tunnel_sequence = _s.coded_tunnel_sequence
+crafted_liteflownet_state_dict = _s.crafted_liteflownet_state_dict
+crafted_monodepth2_state_dict = _s.crafted_monodepth2_state_dict
+tunnel_truth = _s.tunnel_truth
+tunnel_cast = _s.tunnel_cast

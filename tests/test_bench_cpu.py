@@ -1,0 +1,119 @@
+"""CPU (gloo, world_size 2): the multi-rank logic of bench.py -- world setup from the torchrun environment, per-rank
+chunks, the single pose all-gather, max-over-ranks timing, rank 0's JSON line (n_gpus, ranks_seen) -- with the device
+pipeline replaced by a stub (no GPU here), and the `--gpus N` self-launch command line."""
+import importlib
+import io
+import json
+import os
+import socket
+import sys
+from contextlib import redirect_stdout
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _Out:
+    def __init__(self, k, seed):
+        self.status, self.scale, self.n_kp, self.good_kp_found = 0, 1.0 + 0.01 * k, 2000, 1
+        self.R = [1, 0, 0, 0, 1, 0, 0, 0, 1]
+        self.t = [0.0, 0.0, float(seed % 7 + 1)]
+
+
+class StubPipeline:
+    """the surface bench.py drives (df-vo_amd/pipeline.py TrackingPipeline), answered on the host"""
+    calls = []
+
+    def __init__(self, H, W, fh, fw, K, fsd, dsd, **opts):
+        self.seed_ = opts.get("seed", 0)
+        self.k = 0
+        self.hybrid_pose = StubPipeline.real.hybrid_pose
+        self.accumulate = StubPipeline.real.accumulate
+
+    def set_ref_image(self, img):
+        StubPipeline.calls.append("ref")
+
+    def enqueue_nets(self, slot, ref, cur, feed=None):
+        assert 0 <= slot < 4
+
+    def prefetch_track(self, slot, *a):
+        pass
+
+    def track(self, slot, *a):
+        self.k += 1
+        return _Out(self.k, self.seed_)
+
+    def sync(self):
+        pass
+
+    def net_flops(self):
+        return 1e9
+
+    def close(self):
+        pass
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), DFVO_BENCH_BACKEND="gloo")
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    pmod = importlib.import_module("df-vo_amd.pipeline")
+    StubPipeline.real = pmod.TrackingPipeline
+    pmod.TrackingPipeline = StubPipeline
+    bench.to_device = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    bench.device_sync = lambda: None
+    buf = io.StringIO()
+    with redirect_stdout(buf):
+        bench.main(["--gpus", str(world), "--steps", "5", "--warmup", "1", "--height", "64", "--width", "96",
+                    "--no-roofline", "--no-cpu-baseline"])
+    q.put((rank, buf.getvalue()))
+
+
+def test_bench_two_ranks_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert outs[1].strip() == ""  # only rank 0 prints
+    line = json.loads(outs[0].strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 5 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["config"]["ranks_seen"] == 2 and line["config"]["gathered_poses"] == 10
+    assert line["unit"] == "frames/s" and line["value"] > 0
+    assert abs(line["value"] - 2 * 5 / (line["ms_per_step"] * 5e-3)) < 1e-2 * line["value"]  # whole-job aggregate
+
+
+def test_bench_gpus_flag_self_launch(monkeypatch):
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    seen = {}
+    import subprocess
+    monkeypatch.setattr(subprocess, "call", lambda cmd: seen.setdefault("cmd", cmd) and 0)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "3"])
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    try:
+        bench.main(["--gpus", "8", "--steps", "3"])
+    except SystemExit as e:
+        assert e.code == 0
+    cmd = seen["cmd"]
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert "--master-addr" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-4:] == ["--gpus", "8", "--steps", "3"] and cmd[-5].endswith("bench.py")

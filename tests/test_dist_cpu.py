@@ -96,3 +96,94 @@ def test_chunk_bounds_cover_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             for a, b in zip(spans, spans[1:]):
                 assert a[1] == b[0]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# sequence.run_sequence (chunk + 1-frame halo driver) under gloo, the device pipeline replaced by a host stub whose
+# result for a pair depends only on (the two frames, the RandomState seed in force) -- as the real pipeline's does
+# ---------------------------------------------------------------------------------------------------------------
+class _StubOut:
+    pass
+
+
+class _StubPipe:
+    def __init__(self):
+        self.slots, self.seed_, self.ref_image, self.log = {}, None, None, []
+
+    def set_ref_image(self, f):
+        self.ref_image = int(f)
+        self.log.append(("ref", int(f)))
+
+    def seed(self, s):
+        self.seed_ = int(s)
+
+    def enqueue_nets(self, slot, ref, cur, feed=None):
+        assert int(cur) == int(ref) + 1
+        self.slots[slot] = (int(ref), int(cur))
+
+    def prefetch_track(self, slot, *a):
+        pass
+
+    def track(self, slot, *a):
+        ref, cur = self.slots[slot]
+        assert self.ref_image is not None and self.ref_image <= ref  # the chunk's halo frame came first
+        rng = np.random.Generator(np.random.PCG64([ref, cur, self.seed_]))
+        o = _StubOut()
+        o.status = 1 if rng.random() < 0.25 else (3 if rng.random() < 0.2 else 0)
+        a = rng.normal(0, 0.02, 3)
+        th = np.linalg.norm(a)
+        k = a / th
+        Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        o.R = list((np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx).reshape(-1))
+        o.t = list(rng.normal(0, 1, 3))
+        o.scale = float(rng.uniform(0.5, 1.5))
+        return o
+
+    def sync(self):
+        pass
+
+
+def _seq_worker(rank, world, port, n_frames, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    smod = importlib.import_module("df-vo_amd.sequence")
+    pipe = _StubPipe()
+    poses, gathered = smod.run_sequence(pipe, list(range(n_frames)), n_frames, world, rank, dist, seed=4869)
+    if rank == 0:
+        q.put((poses, gathered))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_run_sequence_chunks_equal_single_rank_per_pair_seed():
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    smod = importlib.import_module("df-vo_amd.sequence")
+    n_frames = 24
+    want_poses, want_g = smod.run_sequence(_StubPipe(), list(range(n_frames)), n_frames, 1, 0, None, seed=4869,
+                                           rng_mode="per_pair")
+    assert (want_g[:, 16] == 1).any() and (want_g[:, 16] == 3).any()  # constant-motion and PnP rows are exercised
+    for world in (2, 3):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_seq_worker, args=(r, world, port, n_frames, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        poses, g = q.get(timeout=120)
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+        assert np.array_equal(g, want_g) and np.array_equal(poses, want_poses)
+    # the sequential numpy stream cannot be chunked; and a needs-PnP row must not be composed silently
+    import pytest
+    with pytest.raises(ValueError):
+        smod.run_sequence(_StubPipe(), list(range(6)), 6, 2, 0, None, rng_mode="sequential")
+    dmod = importlib.import_module("df-vo_amd.dist")
+    bad = want_g.copy()
+    bad[3, 16] = 2
+    with pytest.raises(ValueError):
+        dmod.compose_trajectory(bad)

@@ -1,0 +1,124 @@
+"""GPU: the product data path with NO overrides -- uint8 frames -> HIP nets -> the nets' own flow / consistency /
+depth -> keypoint selection -> E / PnP RANSAC -> pose (libs/dfvo.py:299-345 then :121-262).
+
+Frames come from the coded tunnel world (df-vo_amd/synthetic.py): they carry their flow and depth fields as colour
+codes and a few channels of otherwise random network weights decode them, so the real layer stacks emit coherent
+rigid-scene flow and depth and `good_kp_found` is true.  Checks per pair, over consecutive pairs with the depth
+roll-over and the numpy RandomState carried along:
+  (1) HIP nets vs the torch-CPU oracle on the same frames (tolerance, absolute pixels / relative depth),
+  (2) the solver stage vs the oracle chain run on the HIP nets' OWN output arrays: keypoints (values and order), inlier
+      mask, R, t, scale, PnP result and the RandomState bit for bit,
+  (3) the recovered motion vs the ground truth of the rendered sequence."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets_torch as O
+from oracle import pipeline_np as P
+from synth import coded_tunnel_sequence, crafted_liteflownet_state_dict, crafted_monodepth2_state_dict, tunnel_truth
+
+pytestmark = pytest.mark.gpu
+
+FLOW_TOL_PX = 2e-3    # |HIP - oracle| on the 376x1241 / 192x640 flow fields, absolute pixels (fp32 summation order)
+DEPTH_TOL_REL = 1e-3
+
+
+def _mods():
+    return importlib.import_module("df-vo_amd.pipeline"), importlib.import_module("df-vo_amd.sequence")
+
+
+@pytest.mark.parametrize("h,w,mode,step", [(192, 640, "mux", 1.0), (376, 1241, "pot", 0.3), (384, 1248, "mux", 1.0)])
+def test_images_to_pose_no_overrides(gpu, h, w, mode, step):
+    pmod, smod = _mods()
+    n_frames = 4
+    seq = coded_tunnel_sequence(h, w, n_frames, mode=mode, step=step)
+    fsd, dsd = crafted_liteflownet_state_dict(h, w, mode), crafted_monodepth2_state_dict()
+    K = seq["K"]
+    pipe = pmod.TrackingPipeline(h, w, 192, 640, K, fsd, dsd, seed=4869)
+    fr = smod.frames_to_device(seq["frames"])
+    # depth of frame 0 exactly as the device computes it (input of the first pair's PnP fallback)
+    pipe.enqueue_nets(3, fr[0], fr[0])
+    pipe.sync()
+    depth_ref = pipe.get_outputs(3)[4]
+    pipe.set_ref_image(fr[0])
+    np.random.seed(4869)
+    modes = []
+    for k in range(n_frames - 1):
+        slot = k % 3
+        pipe.enqueue_nets(slot, fr[k], fr[k + 1])
+        if k == 1:
+            pipe.prefetch_track(slot)  # one pair through the run-ahead path
+        out = pipe.track(slot)
+        fwd, bwd, diff, raw, dep = pipe.get_outputs(slot)
+        kp_ref, kp_cur, inl = pipe.get_keypoints(slot)
+        # (1) nets vs oracle nets
+        ofwd, obwd, odiff = O.flow_inference(fsd, seq["frames"][k], seq["frames"][k + 1])
+        e_flow = max(np.abs(fwd - ofwd).max(), np.abs(bwd - obwd).max())
+        assert e_flow <= FLOW_TOL_PX, "pair %d: |flow HIP - oracle| = %.3e px (max |flow| %.1f px)" % (k, e_flow, np.abs(ofwd).max())
+        oraw, odep = P.frame_depth(dsd, seq["frames"][k + 1])
+        assert np.abs(raw - oraw).max() <= DEPTH_TOL_REL * np.abs(oraw).max()
+        gt_f, gt_b, z1 = tunnel_truth(seq, k)
+        med = float(np.median(np.abs(fwd - gt_f)))
+        assert med < 0.05, "decoded flow is not the rendered scene's flow (median error %.3f px)" % med
+        # (2) solver stage vs the oracle chain on the device's own arrays
+        r = P.solve_pair(fwd, diff, dep, depth_ref, K)
+        assert out.good_kp_found == 1 and r["good_kp_found"], "the no-override path must run with good keypoints"
+        assert out.n_kp == len(r["kp_ref"]) and np.array_equal(kp_ref, r["kp_ref"]) and np.array_equal(kp_cur, r["kp_cur"])
+        R = np.array(out.R[:]).reshape(3, 3)
+        t = np.array(out.t[:]).reshape(3, 1)
+        if r["status"] == "E":
+            assert out.status == 0
+            assert np.array_equal(R, r["E"]["R"]) and np.array_equal(t, r["E"]["t"])
+            assert np.array_equal(inl, np.asarray(r["E"]["inliers"]).reshape(-1).astype(bool))
+            assert out.scale_n_valid == r["scale_diag"]["n_valid"] and abs(out.scale - r["scale"]) <= 1e-9 * abs(r["scale"])
+        else:
+            assert r["status"] == "PnP" and out.status == 3
+            assert out.pnp_n_filtered == len(r["pnp"]["kp1"]) and out.pnp_inliers == r["pnp"]["best_inlier"]
+            assert np.array_equal(R, r["pnp"]["R"]) and np.array_equal(t, r["pnp"]["t"])
+        st_o, st_d = np.random.get_state(), pipe.get_rng_state()
+        assert np.array_equal(st_o[1], st_d[1]) and st_o[2] == st_d[2], "numpy RandomState diverged at pair %d" % k
+        rel, m = pipe.hybrid_pose(out, np.eye(4))
+        assert np.abs(rel - r["pose"]).max() <= 1e-9
+        modes.append(m)
+        # (3) geometry
+        Tgt = np.linalg.inv(seq["poses"][k]) @ seq["poses"][k + 1]
+        assert np.abs(rel[:3, :3] - Tgt[:3, :3]).max() < 2e-3
+        assert np.linalg.norm(rel[:3, 3] - Tgt[:3, 3]) < 0.05 * np.linalg.norm(Tgt[:3, 3])
+        print("%dx%d %s pair %d: %s kp %d inl %d | flow err vs oracle %.2e px, vs truth (median) %.3f px | |t| %.4f (gt %.4f)" % (
+            h, w, mode, k, m, out.n_kp, out.best_inlier_cnt, e_flow, med, np.linalg.norm(rel[:3, 3]), np.linalg.norm(Tgt[:3, 3])))
+        depth_ref = dep  # the current frame's depth rolls over (dfvo.py: ref_data <- cur_data)
+    pipe.close()
+    if mode == "mux":
+        assert "E" in modes  # the E-tracker + depth scale path is the one taken with true fwd/bwd flow
+
+
+def test_chunked_sequence_equals_single_chunk(gpu):
+    """SURVEY 8e on one device: the sequence tracked as 1, 2 and 3 contiguous chunks (each starting from its halo frame via
+    set_ref_image) gives bit-identical relative poses in the per-pair-seed mode, and the composed trajectories agree."""
+    pmod, smod = _mods()
+    dmod = importlib.import_module("df-vo_amd.dist")
+    h, w, n = 192, 640, 9
+    seq = coded_tunnel_sequence(h, w, n, mode="mux", step=1.0, seed=11)
+    pipe = pmod.TrackingPipeline(h, w, 192, 640, seq["K"], crafted_liteflownet_state_dict(h, w, "mux"),
+                                 crafted_monodepth2_state_dict(), seed=4869)
+    fr = smod.frames_to_device(seq["frames"])
+    whole, st_whole = smod.track_chunk(pipe, fr, 0, n - 1, rng_mode="per_pair")
+    assert (st_whole != 1).all()
+    for world in (2, 3):
+        parts = []
+        for rank in range(world):
+            lo, hi = dmod.chunk_bounds(n - 1, world, rank)
+            rel, st = smod.track_chunk(pipe, fr, lo, hi, rng_mode="per_pair")
+            parts.append(dmod.allgather_poses(rel, st, 1, 0))
+        g = np.concatenate(parts, 0)
+        assert np.array_equal(g[:, :16].reshape(-1, 4, 4), whole) and np.array_equal(g[:, 16], st_whole)
+        traj = dmod.compose_trajectory(g)
+        ref = dmod.compose_trajectory(dmod.allgather_poses(whole, st_whole, 1, 0))
+        assert np.array_equal(traj, ref)
+    # the sequential mode differs from the per-pair mode only through the RANSAC sampling: same geometry
+    seq_rel, _ = smod.track_chunk(pipe, fr, 0, n - 1, rng_mode="sequential")
+    for a, b in zip(seq_rel, whole):
+        assert np.linalg.norm(a[:3, 3] - b[:3, 3]) < 0.05 * np.linalg.norm(b[:3, 3])
+    pipe.close()
