@@ -43,7 +43,8 @@ CFG_NAMES = ["conv_igemm_f32<2,2,4,4> 128x128", "conv_igemm_f32<1,4,2,2> 32x128"
              "conv_igemm_f32<2,2,4,2> 128x64", "conv_igemm_f32<4,1,2,2> 128x32", "conv_igemm_f32<4,1,2,1> 128x16",
              "conv_win3_f32<2,2,4,4> (8x16)x128", "conv_win3_f32<2,2,4,2> (8x16)x64", "conv_win3_f32<4,1,2,2> (8x16)x32",
              "conv_win3_f32<1,4,4,2> (4x16)x128", "conv_head_f32<7> 7x7 heads (direct)",
-             "conv_head_f32<5> 5x5 heads (direct)", "conv_head_f32<3> 3x3 heads (direct)"]
+             "conv_head_f32<5> 5x5 heads (direct)", "conv_head_f32<3> 3x3 heads (direct)",
+             "conv_win_f16s (4|8 x 32) x 128|64|32 (f16 hi/lo planes, v_mfma_f32_32x32x16_f16)"]
 
 
 def cpu_baseline_nets(frames, fsd, dsd, K, H, W, n_pairs=3):
@@ -158,7 +159,7 @@ def main(argv=None):
     ap.add_argument("--width", type=int, default=1241)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--conv-precision", default=os.environ.get("DFVO_CONV_PRECISION", "fp32"), choices=["fp32", "bf16x6", "bf16x3"],
+    ap.add_argument("--conv-precision", default=os.environ.get("DFVO_CONV_PRECISION", "fp32"), choices=["fp32", "f16x3", "bf16x6", "bf16x3"],
                     help="fp32 (default, the parity-gated exact path); bf16x6 / bf16x3: opt-in split-precision MFMA modes "
                          "of the 3x3 window layers (DESIGN.md section 3) -- reported in config.conv_precision, never the default")
     ap.add_argument("--solver-inputs", default="nets", choices=["nets", "synthetic"],
@@ -190,6 +191,10 @@ def main(argv=None):
     dev = to_device
     d_feed = None  # the pipeline resizes the current frame itself (device LANCZOS, bit-exact with Pillow)
     popts = dict(seed=4869 ^ rank, e_max_iters=args.e_max_iters, kp_num_bestN=args.kp_bestn)  # per-rank RandomState: DP mode
+    # Everything the host prepares (frames, scenes, weights) first, THEN the pipeline, THEN the device copies of the inputs:
+    # the pair rate depends on the order in which the process creates its HIP streams (133 vs 109 frames/s, exact fp32, same
+    # binary and box: which compute pipes the pipeline's streams share follows their creation order, see
+    # TrackerBuffers::init and DESIGN.md section 5)
     if nets_mode:
         # coded tunnel world: multiplexed encoding when the frame needs no input resize, potential encoding otherwise
         code_mode = "mux" if syn._net_size(H, W) == (H, W) else "pot"
@@ -197,16 +202,17 @@ def main(argv=None):
         K = seq["K"]
         fsd, dsd = syn.crafted_liteflownet_state_dict(H, W, code_mode), syn.crafted_monodepth2_state_dict()
         scenes = None
-        d_frames = [dev(seq["frames"][0]), dev(seq["frames"][1])]
+        h_frames = [seq["frames"][0], seq["frames"][1]]
     else:
         scenes = [syn.rigid_scene(H, W, seed=100 + 7 * rank + i) for i in range(4)]
         K = scenes[0]["K"]
         fsd, dsd = syn.liteflownet_state_dict(4869), syn.monodepth2_state_dict(4869)
-        ref, cur = syn.image_pair(H, W, seed=1 + rank)
-        d_frames = [dev(ref), dev(cur)]
+        h_frames = list(syn.image_pair(H, W, seed=1 + rank))
+    pipe = pmod.TrackingPipeline(H, W, 192, 640, K, fsd, dsd, **popts)
+    d_frames = [dev(f) for f in h_frames]
+    if not nets_mode:
         d_sc = [(dev(s["flow"]), dev(s["diff"]), dev(s["depth_cur"])) for s in scenes]
         d_ref_depth = dev(scenes[0]["depth_ref"])
-    pipe = pmod.TrackingPipeline(H, W, 192, 640, K, fsd, dsd, **popts)
 
     host_t = [0.0, 0.0]  # host seconds inside enqueue_nets / track (DFVO_BENCH_TRACE=1 prints them)
 
@@ -293,9 +299,9 @@ def main(argv=None):
         for _ in range(nprof):
             pipe.enqueue_nets(0, d_frames[0], d_frames[1], d_feed)
             pipe.sync()
-        ms = np.zeros(19)
-        fl = np.zeros(19)
-        ln = np.zeros(19, np.int32)
+        ms = np.zeros(20)
+        fl = np.zeros(20)
+        ln = np.zeros(20, np.int32)
         capi.check(lib.dfvo_conv_profile_end(capi.as_ptr(ms), capi.as_ptr(fl), capi.as_ptr(ln)))
         pipe.set_graph(1)
         dom = int(np.argmax(ms))
@@ -303,7 +309,7 @@ def main(argv=None):
         fam = fl.sum() / (ms.sum() * 1e-3) / 1e12
         # exact fp32: the fp32-MFMA peak.  Opt-in split modes: the window layers issue 4 (bf16x3) / 6 (bf16x6) bf16 products
         # per fp32 product, so the ceiling for USEFUL fp32-equivalent FLOPs is the dense bf16 peak divided by that
-        terms = {"fp32": 0, "bf16x3": 4, "bf16x6": 6}[args.conv_precision]
+        terms = {"fp32": 0, "f16x3": 3, "bf16x3": 4, "bf16x6": 6}[args.conv_precision]
         peak = PEAK_F32_MFMA_TFLOPS if not terms else PEAK_BF16_MFMA_TFLOPS / terms
         roof = {"bound": "mfma", "kernel": CFG_NAMES[dom].replace("conv_win3_f32", "conv_win3_f32" if not terms else "conv_win3_bf16s"),
                 "achieved": round(ach, 2), "peak": round(peak, 1),
@@ -311,7 +317,11 @@ def main(argv=None):
                 "avg_launch_us": round(ms[dom] * 1e3 / max(1, ln[dom]), 2), "launches_per_pair": int(ln[dom] // nprof),
                 "share_of_conv_time": round(float(ms[dom] / ms.sum()), 3),
                 "conv_family_achieved": round(fam, 2), "conv_family_ms_per_pair": round(float(ms.sum() / nprof), 3),
-                "algorithmic_gflop_per_pair": round(net_flops / 1e9, 1)}
+                "algorithmic_gflop_per_pair": round(net_flops / 1e9, 1),
+                "by_config": [{"kernel": CFG_NAMES[i], "ms_per_pair": round(float(ms[i] / nprof), 3),
+                               "launches_per_pair": int(ln[i] // nprof), "gflop_per_pair": round(float(fl[i] / nprof / 1e9), 1),
+                               "tflops": round(float(fl[i] / (ms[i] * 1e-3) / 1e12), 1)}
+                              for i in np.argsort(-ms) if ln[i] > 0]}
     if roof is not None:
         # HBM-side bytes per launch of that kernel from the committed rocprofv3 --pmc passes over this same command
         # (tools/pmc_traffic.py: FETCH_SIZE x2 on gfx950 + WRITE_SIZE); None when no profile matches the kernel
@@ -353,7 +363,9 @@ def main(argv=None):
             "value": round(world * args.steps / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.conv_precision == "fp32" else "f32 accumulate, %s split-bf16 products in the 3x3 window layers (opt-in)" % args.conv_precision,
+            "dtype": {"fp32": "f32", "f16x3": "f32 (f16x3 split products in the 3x3 window layers: two f16 planes per operand = 22 "
+                                                "mantissa bits, three exact products per term, fp32 accumulate; all other layers exact fp32 MFMA)"
+                      }.get(args.conv_precision, "f32 accumulate, %s split-bf16 products in the 3x3 window layers (opt-in)" % args.conv_precision),
             "data": "synthetic",
             "config": {"workload": "%dx%d frame pairs%s (flow net %dx%d batch 2; device LANCZOS resize + depth net 192x640), "
                                    "local_bestN %d keypoints, findHomography + 5x findEssentialMat(%d-iteration budget) + GRIC + "

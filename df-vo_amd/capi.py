@@ -95,6 +95,7 @@ SIGNATURES = {
     "dfvo_memcpy_h2d": (_i, [_vp, _vp, _sz]),
     "dfvo_memcpy_d2h": (_i, [_vp, _vp, _sz]),
     "dfvo_conv2d": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dfvo_set_conv_precision": (_i, [C.c_char_p]),
     "dfvo_conv_profile_begin": (_i, []),
     "dfvo_conv_profile_end": (_i, [_vp, _vp, _vp]),
     "dfvo_correlation": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),

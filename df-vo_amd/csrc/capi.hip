@@ -110,6 +110,12 @@ int dfvo_conv2d(const dfvo_conv_desc* d, const float* d_src0, const float* d_src
         (void)hipFree(db);
         return DFVO_ERR_HIP;
     }
+    if (make_f16s_weights(h_w, d->cout, d->c0, d->c1, d->kh, d->kw, nullptr, &L) != DFVO_OK) {
+        (void)hipFree(dw);
+        (void)hipFree(db);
+        if (L.wsp) (void)hipFree(L.wsp);
+        return DFVO_ERR_HIP;
+    }
     {
         const int hrc = make_head_weights(h_w, d->cout, d->c0, d->c1, d->kh, d->kw, nullptr, &L.wh);
         if (hrc != DFVO_OK) {
@@ -139,10 +145,13 @@ int dfvo_conv2d(const dfvo_conv_desc* d, const float* d_src0, const float* d_src
     (void)hipFree(db);
     if (L.wh) (void)hipFree(L.wh);
     if (L.wsp) (void)hipFree(L.wsp);
+    if (L.wf) (void)hipFree(L.wf);
     if (rc != DFVO_OK) return rc;
     DFVO_HIP_CHECK(e);
     return DFVO_OK;
 }
+
+int dfvo_set_conv_precision(const char* name) { return conv_set_precision(name); }
 
 int dfvo_conv_profile_begin(void) {
     conv_profile_begin();

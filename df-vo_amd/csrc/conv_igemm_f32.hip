@@ -1044,6 +1044,8 @@ int conv_profile_end(double* ms, double* flops, int* launches) {
     return DFVO_OK;
 }
 
+#include "conv_win_f16s.h"
+
 // split-K when the grid cannot fill the chip: partials to p.ws, ordered reduction in a second launch
 static int conv_pick_splits(const ConvParams& p, long long blocks) {
     const long long M = (long long)p.N * p.Ho * p.Wo;
@@ -1241,6 +1243,7 @@ int launch_conv(const ConvParams& p, hipStream_t stream) {
         if (force_cfg == 15 && bn == 128) return launch_win3<1, 4, 4, 2>(p, stream, 15);
         if (force_cfg == 14 && p.cout_pad % 32 == 0) return launch_win3<4, 1, 2, 2>(p, stream, 14);
         const long long tiles8 = (long long)p.N * ((p.Ho + 7) / 8) * ((p.Wo + 15) / 16) * (p.cout_pad / bn);
+        if (p.wf16 && conv_f16s_ok(p)) return launch_f16s(p, stream, 19);  // DFVO_CONV_PRECISION=f16x3
         if (p.wsp && p.wsp_planes == 2) {  // opt-in split-precision modes: same tiles, bf16 MFMAs
             if (bn == 128) return launch_win3<2, 2, 4, 2, 3, 2>(p, stream, 13);
             if (bn == 64) return launch_win3<2, 2, 4, 2, 3, 2>(p, stream, 13);

@@ -1,0 +1,272 @@
+// 3x3 / stride-1 convolution with fp32-class accuracy on the f16 matrix cores (opt-in: DFVO_CONV_PRECISION=f16x3).
+// Included by conv_igemm_f32.hip (same translation unit: shares the epilogue and the per-launch profiling hooks).
+//
+// Every fp32 operand x is split into two f16 planes  x = hi + 2^-11 lo,  hi = f16(x),  lo = f16((x - hi) * 2^11):
+// 22 mantissa bits, the scaled low plane never leaves f16's normal range (an unscaled residue would be subnormal for
+// |x| < 0.125 and lose its bits).  A product keeps three terms,
+//        a b  ~=  ah bh  +  2^-11 (ah bl + al bh)                       (dropped: 2^-22 al bl, an fp32-rounding-sized term)
+// each an EXACT fp32 number (11 x 11 bit mantissas), accumulated in fp32 on v_mfma_f32_32x32x16_f16 in two accumulator
+// sets ("main" and "cross") that the epilogue combines as main + 2^-11 cross.  Against the exact fp32-MFMA path this
+// trades 16 K-passes of 64 FLOP/clk/SIMD for 3 passes of 1024 FLOP/clk/SIMD: 5.3x less matrix-pipe time.
+//
+// Tiling (wave64, 4 waves per workgroup): a workgroup owns TH rows x 32 columns of output pixels x BN output channels.
+// The (TH+2) x 34 input window of one 16-channel chunk is split into planes ONCE, when it is written to LDS
+// (padding / reflection / x2-upsample / two-source concat resolved at that load), pixel stride 80 bytes = 5 sixteen-byte
+// slots: the 16 lanes of every ds_read_b128 service group hit 16 distinct slots.  One MFMA contracts a whole chunk for a
+// 32-channel x 32-pixel block: the weight fragment (A operand: 32 couts x 16 channels) comes straight from L2 in its
+// packed plane layout, fetched one tap ahead into registers; the pixel fragment (B operand: 16 channels x 32 pixels of
+// one window row) is one ds_read_b128 per plane.  A wave holds TC x TR blocks (main + cross: 32 accumulator registers
+// each), the only barrier is the one per chunk (9 taps x 3 TC TR MFMAs of 32 cycles between barriers).
+// The accumulator layout (col = lane & 31 = pixel, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) = cout) gives a lane
+// four consecutive couts of one pixel per register quad: the fp32 kernels' 16-byte vector epilogue is reused as is.
+#pragma once
+// (included inside namespace dfvo)
+
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr float F16S_LO_SCALE = 2048.0f;          // 2^11
+constexpr float F16S_LO_UNSCALE = 1.0f / 2048.0f;
+constexpr float F16S_MAX = 65504.0f;
+
+__device__ __forceinline__ void split_f16_planes(f32x4 x, h16x4* hi, h16x4* lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float v = __builtin_fminf(__builtin_fmaxf(x[e], -F16S_MAX), F16S_MAX);  // saturate instead of inf
+        const _Float16 h = (_Float16)v;  // round to nearest even
+        (*hi)[e] = h;
+        (*lo)[e] = (_Float16)((v - (float)h) * F16S_LO_SCALE);  // v - h is exact in fp32
+    }
+}
+
+template <int WC, int WR, int TC, int TR>
+__global__ __launch_bounds__(256, 2) void conv_win_f16s_kernel(const ConvParams p) {
+    constexpr int TH = WR * TR, TW = 32, WH = TH + 2, WW = TW + 2, PS = 20;  // pixel stride in dwords (80 bytes)
+    constexpr int BN = WC * TC * 32;
+    constexpr int WIN = WH * WW * PS;  // dwords per window buffer
+    constexpr int W_ITEMS = WH * WW * 4;
+    constexpr int W_CNT = (W_ITEMS + 255) / 256;
+    static_assert(WC * WR == 4, "4 waves per block");
+    __shared__ __attribute__((aligned(16))) float lds[2 * WIN];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wc = wave / WR, wr = wave % WR;
+    const int lp = lane & 31, kb = lane >> 5;
+    const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
+    const int nb = gridDim.x;
+    int bid = blockIdx.x;
+    {  // XCD-aware order: each XCD walks a contiguous run of tiles (neighbours share halo rows in its L2)
+        const int q = nb >> 3, r = nb & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int n = bid / (tiles_y * tiles_x);
+    const int trem = bid - n * (tiles_y * tiles_x);
+    const int ty0 = (trem / tiles_x) * TH, tx0 = (trem % tiles_x) * TW;
+    const int n0 = blockIdx.y * BN;
+    const int nchunk0 = (p.G0 + 3) >> 2, nchunk1 = (p.G1 + 3) >> 2, nchunks = nchunk0 + nchunk1;
+
+    // window items of this thread: (pixel, 4-channel group within the chunk)
+    int w_off0[W_CNT], w_off1[W_CNT], w_lds[W_CNT];
+    bool w_ok[W_CNT];
+#pragma unroll
+    for (int r = 0; r < W_CNT; ++r) {
+        const int id = t + 256 * r;
+        const int px = id >> 2, q = id & 3;
+        const int wy = px / WW, wx = px - wy * WW;
+        int iy = ty0 - 1 + wy, ix = tx0 - 1 + wx;
+        bool v = id < W_ITEMS;
+        if (p.pad_mode == PAD_REFLECT) {
+            iy = reflect_idx(iy, p.H);
+            ix = reflect_idx(ix, p.W);
+        }
+        v = v && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        iy = iy < 0 ? 0 : (iy >= p.H ? p.H - 1 : iy);
+        ix = ix < 0 ? 0 : (ix >= p.W ? p.W - 1 : ix);
+        const int sh = p.up0;
+        w_off0[r] = (((n * (p.H >> sh) + (iy >> sh)) * (p.W >> sh) + (ix >> sh)) * p.cs0) + p.co0 + q * 4;
+        w_off1[r] = (((n * p.H + iy) * p.W + ix) * p.cs1) + p.co1 + q * 4;
+        w_ok[r] = v;
+        w_lds[r] = (px < WH * WW ? px : 0) * PS + q * 2;  // hi plane: dwords [0, 8), lo plane: [8, 16) of the pixel
+    }
+    f32x4 rw[W_CNT];
+    bool rwv[W_CNT];
+    auto load_window = [&](int c) {
+        const bool s1 = c >= nchunk0;
+        const int cg0 = s1 ? (c - nchunk0) * 4 : c * 4;
+        const int Gs = s1 ? p.G1 : p.G0;
+        const float* base = s1 ? p.src1 : p.src0;
+#pragma unroll
+        for (int r = 0; r < W_CNT; ++r) {
+            const int q = (t + 256 * r) & 3;
+            const bool v = w_ok[r] && (cg0 + q) < Gs;
+            const int off = (s1 ? w_off1[r] : w_off0[r]) + (v ? cg0 * 4 : -(q * 4));  // masked lanes re-read channel 0
+            rw[r] = *reinterpret_cast<const f32x4*>(base + off);
+            rwv[r] = v;
+        }
+    };
+    auto store_window = [&](float* W) {
+#pragma unroll
+        for (int r = 0; r < W_CNT; ++r)
+            if (t + 256 * r < W_ITEMS) {
+                h16x4 hi, lo;
+                split_f16_planes(rwv[r] ? rw[r] : f32x4{0.f, 0.f, 0.f, 0.f}, &hi, &lo);
+                *reinterpret_cast<h16x4*>(W + w_lds[r]) = hi;
+                *reinterpret_cast<h16x4*>(W + w_lds[r] + 8) = lo;
+            }
+    };
+    // weight fragments: row (cout) = lane & 31 of block tc, k-block = lane >> 5; 64 bytes per (tap, chunk, cout)
+    const unsigned short* wbase = p.wf16 + ((size_t)(n0 + wc * TC * 32 + lp) * 32 + kb * 8);
+    const size_t w_chunk_stride = (size_t)p.wf16_cout_pad * 32;  // halves per (tap, chunk)
+    h16x8 wa[2][TC][2];                                         // [register stage][cout block][plane]
+    auto load_w = [&](int stage, int tap, int c) {
+        const unsigned short* g = wbase + ((size_t)tap * nchunks + c) * w_chunk_stride;
+#pragma unroll
+        for (int i = 0; i < TC; ++i) {
+            wa[stage][i][0] = *reinterpret_cast<const h16x8*>(g + (size_t)i * 32 * 32);
+            wa[stage][i][1] = *reinterpret_cast<const h16x8*>(g + (size_t)i * 32 * 32 + 16);
+        }
+    };
+
+    f32x16 am[TC][TR], ax[TC][TR];
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TR; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) am[i][j][e] = ax[i][j][e] = 0.f;
+
+    load_window(0);
+    load_w(0, 0, 0);
+    store_window(lds);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const float* Wc = lds + (c & 1) * WIN;
+        float* Wn = lds + ((c + 1) & 1) * WIN;
+        const bool next_chunk = c + 1 < nchunks;
+        if (next_chunk) load_window(c + 1);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int cur = tap & 1;  // compile-time register stage (the loop is fully unrolled)
+            if (tap < 8)
+                load_w(cur ^ 1, tap + 1, c);
+            else if (next_chunk)
+                load_w(1, 0, c + 1);  // tap 8 runs from stage 0: the next chunk's first fragments land in stage 1 ...
+            h16x8 xb[TR][2];
+#pragma unroll
+            for (int j = 0; j < TR; ++j) {
+                const float* px = Wc + ((wr * TR + j + ky) * WW + (lp + kx)) * PS + kb * 4;
+                xb[j][0] = *reinterpret_cast<const h16x8*>(px);
+                xb[j][1] = *reinterpret_cast<const h16x8*>(px + 8);
+            }
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TR; ++j) {
+                    ax[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][i][0], xb[j][1], ax[i][j], 0, 0, 0);
+                    ax[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][i][1], xb[j][0], ax[i][j], 0, 0, 0);
+                    am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][i][0], xb[j][0], am[i][j], 0, 0, 0);
+                }
+            if (tap == 4 && next_chunk) store_window(Wn);
+        }
+#pragma unroll
+        for (int i = 0; i < TC; ++i) {  // ... and move to stage 0, where tap 0 expects them (2 TC register-quad copies per chunk)
+            wa[0][i][0] = wa[1][i][0];
+            wa[0][i][1] = wa[1][i][1];
+        }
+        __syncthreads();
+    }
+
+    // epilogue: register quad g of block (i, j) = couts 8 g + 4 kb .. + 3 of the pixel at x = tx0 + lp, row ty0 + wr TR + j
+    const int ox = tx0 + lp;
+    const bool vec_ok = conv_vec_ok(p);
+#pragma unroll
+    for (int j = 0; j < TR; ++j) {
+        const int oy = ty0 + wr * TR + j;
+        if (oy >= p.Ho || ox >= p.Wo) continue;
+        const size_t m = ((size_t)n * p.Ho + oy) * p.Wo + ox;
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col0 = n0 + (wc * TC + i) * 32 + 8 * g + 4 * kb;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = am[i][j][4 * g + e] + F16S_LO_UNSCALE * ax[i][j][4 * g + e];
+                conv_epilogue_quad(p, m, col0, v, vec_ok);
+            }
+    }
+}
+
+static bool conv_f16s_ok(const ConvParams& p) {
+    if (p.kh != 3 || p.kw != 3 || p.stride != 1 || p.pad_h != 1 || p.pad_w != 1) return false;
+    if (p.wf16_cout_pad % 32 != 0 || p.Wo < 24) return false;
+    const long long tiles = (long long)p.N * ((p.Ho + 3) / 4) * ((p.Wo + 31) / 32) * ((p.wf16_cout_pad + 127) / 128);
+    static const long long min_tiles = getenv("DFVO_F16S_MIN_TILES") ? atoll(getenv("DFVO_F16S_MIN_TILES")) : 256;
+    return tiles >= min_tiles;
+}
+
+template <int WC, int WR, int TC, int TR>
+static int launch_f16s_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) {
+    constexpr int TH = WR * TR, BN = WC * TC * 32;
+    const int tiles = p.N * ((p.Ho + TH - 1) / TH) * ((p.Wo + 31) / 32);
+    dim3 grid((unsigned)tiles, (unsigned)(p.wf16_cout_pad / BN), 1);
+    ConvProfEntry pe;
+    if (g_prof) {
+        DFVO_HIP_CHECK(hipEventCreate(&pe.e0));
+        DFVO_HIP_CHECK(hipEventCreate(&pe.e1));
+        pe.cfg = cfg_id;
+        DFVO_HIP_CHECK(hipEventRecord(pe.e0, stream));
+    }
+    hipLaunchKernelGGL((conv_win_f16s_kernel<WC, WR, TC, TR>), grid, dim3(256), 0, stream, p);
+    DFVO_HIP_CHECK(hipGetLastError());
+    if (g_prof) {
+        DFVO_HIP_CHECK(hipEventRecord(pe.e1, stream));
+        pe.flops = p.useful_flops;
+        const int sh[12] = {p.N, p.H, p.W, p.Ho, p.Wo, (p.G0 + p.G1) * 4, p.cout, p.kh, p.stride, (int)grid.x, (int)grid.y, 1};
+        for (int i = 0; i < 12; ++i) pe.shape[i] = sh[i];
+        g_prof->push_back(pe);
+    }
+    return DFVO_OK;
+}
+
+static int launch_f16s(const ConvParams& p, hipStream_t stream, int cfg_id) {
+    const int cp = p.wf16_cout_pad;
+    if (cp % 128 == 0) return launch_f16s_cfg<2, 2, 2, 2>(p, stream, cfg_id);  // 128 couts x (4 x 32) pixels
+    if (cp % 64 == 0) return launch_f16s_cfg<1, 4, 2, 2>(p, stream, cfg_id);   // 64 couts x (8 x 32) pixels
+    return launch_f16s_cfg<1, 4, 1, 2>(p, stream, cfg_id);                      // 32 couts x (8 x 32) pixels
+}
+
+// host side: f32 -> (hi, lo) exactly as split_f16_planes does on the device
+static inline void f16s_split_host(float x, unsigned short* hi, unsigned short* lo) {
+    float v = x < -F16S_MAX ? -F16S_MAX : (x > F16S_MAX ? F16S_MAX : x);
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)((v - (float)h) * F16S_LO_SCALE);
+    memcpy(hi, &h, 2);
+    memcpy(lo, &l, 2);
+}
+
+size_t conv_pack_weights_f16s(const float* w, int cout, int c0, int c1, const float* fold_scale, unsigned short* out) {
+    const int nch0 = (c0 + 15) / 16, nch1 = (c1 + 15) / 16, nch = nch0 + nch1;
+    const int cp = round_up(cout, 32);
+    const size_t total = (size_t)9 * nch * cp * 32;
+    if (!out) return total;
+    memset(out, 0, total * sizeof(unsigned short));
+    const int cin = c0 + c1;
+    for (int tap = 0; tap < 9; ++tap)
+        for (int c = 0; c < nch; ++c)
+            for (int co = 0; co < cout; ++co)
+                for (int k = 0; k < 16; ++k) {
+                    const bool s1 = c >= nch0;
+                    const int ch = s1 ? (c - nch0) * 16 + k : c * 16 + k;
+                    if (ch >= (s1 ? c1 : c0)) continue;
+                    const int ci = s1 ? c0 + ch : ch;
+                    float v = w[((size_t)co * cin + ci) * 9 + tap];
+                    if (fold_scale) v *= fold_scale[co];
+                    unsigned short* o = out + (((size_t)tap * nch + c) * cp + co) * 32;
+                    f16s_split_host(v, o + k, o + 16 + k);
+                }
+    return total;
+}
+

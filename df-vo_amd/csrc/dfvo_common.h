@@ -59,6 +59,10 @@ struct ConvParams {
     const float* wsp;
     size_t wsp_plane;
     int wsp_planes;
+    // f16 hi/lo planes of the weights in the split window kernel's layout (DFVO_CONV_PRECISION=f16x3, 3x3 layers only):
+    // [tap][16-channel chunk][wf16_cout_pad][plane hi, lo][16] halves, see conv_pack_weights_f16s
+    const unsigned short* wf16;
+    int wf16_cout_pad;
     int cout, cout_pad, ksteps;
     // optional residual (added before activation)
     const float* res;
@@ -98,14 +102,17 @@ static inline int conv_cout_pad(int cout, long long M) {
 // weights of a one- / two-channel k x k layer in the order the direct head kernel consumes them:
 // [8-channel chunk (source 0 first, each source rounded up)][kx][4-channel group of the chunk (2)][ky][cout][4]
 void conv_split_weights_bf16(const float* packed, size_t n_floats, int planes, unsigned short* out);
-int conv_split_mode();  // 0 exact fp32 (default), 2 = bf16x3, 3 = bf16x6
+int conv_split_mode();  // 0 exact fp32 (default), 2 = bf16x3, 3 = bf16x6, 4 = f16x3 (f16 hi/lo planes, fp32-class)
+// weights of a 3x3 layer as f16 hi / lo planes for conv_win_f16s_kernel; returns the number of halves written
+// (out may be null to query the size): [tap][chunk][cout_pad32][2][16], chunks = ceil(c0/16) + ceil(c1/16)
+size_t conv_pack_weights_f16s(const float* w_oihw, int cout, int c0, int c1, const float* fold_scale, unsigned short* out);
 size_t conv_head_weight_floats(int cout, int c0, int c1, int k);
 void conv_pack_head_weights(const float* w_oihw, int cout, int c0, int c1, int k, const float* fold_scale, float* out);
 void conv_pack_weights(const float* w_oihw, const float* bias, int cout, int c0, int c1, int kh, int kw,
                        int cout_pad, const float* fold_scale, const float* fold_shift, float* out_w,
                        float* out_b);
 
-constexpr int CONV_NUM_CFGS = 19;  // tile configurations of the implicit-GEMM kernel (profile arrays have this size)
+constexpr int CONV_NUM_CFGS = 20;  // tile configurations of the implicit-GEMM kernel (profile arrays have this size)
 int launch_conv(const ConvParams& p, hipStream_t stream);
 // effective (bm, splits) the launcher would use for p (after clamping the overrides)
 void conv_effective_config(const ConvParams& p, int* bm, int* splits);

@@ -28,6 +28,8 @@ struct ConvLayer {
     float* wsp = nullptr;  // bf16 planes of wp (opt-in split-precision modes, 3x3 layers only)
     size_t wsp_plane = 0;  // dwords per plane
     int wsp_planes = 0;
+    unsigned short* wf = nullptr;  // f16 hi/lo planes for conv_win_f16s_kernel (DFVO_CONV_PRECISION=f16x3, 3x3 layers)
+    int wf_cout_pad = 0;
     float* wh = nullptr;  // head layout (cout <= 2, square 3/5/7 kernels), see conv_pack_head_weights
     int cout = 0, cout_pad = 0, c0 = 0, c1 = 0, kh = 0, kw = 0, ksteps = 0;
     int stride = 1, pad_h = 0, pad_w = 0, pad_mode = PAD_ZERO, act = ACT_NONE;
@@ -50,6 +52,8 @@ void free_conv(ConvLayer* l);
 // uploads the head-layout copy of the weights when the layer qualifies for the direct head kernel (else leaves wh null)
 // uploads the bf16-plane copy of the packed weights when a split-precision mode is on and the layer is 3x3
 int make_split_weights(const std::vector<float>& packed, int kh, int kw, ConvLayer* L);
+int make_f16s_weights(const float* w_oihw, int cout, int c0, int c1, int kh, int kw, const float* scale, ConvLayer* L);
+int conv_set_precision(const char* name);  // fp32 | f16x3 | bf16x6 | bf16x3: applies to layers packed afterwards
 int make_head_weights(const float* w_oihw, int cout, int c0, int c1, int kh, int kw, const float* scale, float** wh);
 
 // while set, run_conv times the candidate tile / split-K configurations of every not-yet-tuned layer on its
@@ -95,6 +99,7 @@ struct FlowNet {
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     float *graph_fwd = nullptr, *graph_bwd = nullptr, *graph_diff = nullptr;
+    const uint8_t *graph_ref = nullptr, *graph_cur = nullptr;
     bool use_graph = true;
     bool tuned_once = false;
 

@@ -73,23 +73,46 @@ int make_conv(const ParamStore& ps, const std::string& wname, const std::string&
     DFVO_HIP_CHECK(hipMemcpy(L->wp, pw.data(), pw.size() * sizeof(float), hipMemcpyHostToDevice));
     DFVO_HIP_CHECK(hipMemcpy(L->bias, pb.data(), pb.size() * sizeof(float), hipMemcpyHostToDevice));
     DFVO_TRY(make_split_weights(pw, L->kh, L->kw, L));
+    DFVO_TRY(make_f16s_weights(w->data.data(), L->cout, c0, c1, L->kh, L->kw, scale, L));
     return make_head_weights(w->data.data(), L->cout, c0, c1, L->kh, L->kw, scale, &L->wh);
 }
 
+static int parse_conv_precision(const char* e) {
+    if (!e || !strcmp(e, "fp32")) return 0;
+    if (!strcmp(e, "bf16x3")) return 2;
+    if (!strcmp(e, "bf16x6")) return 3;
+    if (!strcmp(e, "f16x3")) return 4;
+    return -1;
+}
+static int g_conv_precision = -2;  // -2: not yet read from DFVO_CONV_PRECISION
 int conv_split_mode() {
-    static const int mode = [] {
-        const char* e = getenv("DFVO_CONV_PRECISION");
-        if (!e) return 0;
-        if (!strcmp(e, "bf16x3")) return 2;
-        if (!strcmp(e, "bf16x6")) return 3;
-        return 0;
-    }();
-    return mode;
+    if (g_conv_precision == -2) {
+        const int m = parse_conv_precision(getenv("DFVO_CONV_PRECISION"));
+        g_conv_precision = m < 0 ? 0 : m;
+    }
+    return g_conv_precision;
+}
+int conv_set_precision(const char* name) {
+    const int m = parse_conv_precision(name);
+    DFVO_ARG_CHECK(m >= 0, "dfvo_set_conv_precision: expected fp32 | f16x3 | bf16x6 | bf16x3");
+    g_conv_precision = m;
+    return DFVO_OK;
+}
+
+int make_f16s_weights(const float* w_oihw, int cout, int c0, int c1, int kh, int kw, const float* scale, ConvLayer* L) {
+    if (conv_split_mode() != 4 || kh != 3 || kw != 3) return DFVO_OK;
+    std::vector<unsigned short> wf(conv_pack_weights_f16s(w_oihw, cout, c0, c1, scale, nullptr));
+    conv_pack_weights_f16s(w_oihw, cout, c0, c1, scale, wf.data());
+    DFVO_HIP_CHECK(hipMalloc((void**)&L->wf, wf.size() * sizeof(unsigned short) + 256));
+    DFVO_HIP_CHECK(hipMemcpy(L->wf, wf.data(), wf.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+    L->wf_cout_pad = round_up(cout, 32);
+    return DFVO_OK;
 }
 
 int make_split_weights(const std::vector<float>& packed, int kh, int kw, ConvLayer* L) {
     const int planes = conv_split_mode();
-    if (!planes || kh != 3 || kw != 3) return DFVO_OK;
+    if (planes != 2 && planes != 3) return DFVO_OK;
+    if (kh != 3 || kw != 3) return DFVO_OK;
     std::vector<unsigned short> ps(packed.size() * planes);
     conv_split_weights_bf16(packed.data(), packed.size(), planes, ps.data());
     DFVO_HIP_CHECK(hipMalloc((void**)&L->wsp, ps.size() * sizeof(unsigned short)));
@@ -114,6 +137,8 @@ void free_conv(ConvLayer* l) {
     if (l->bias) (void)hipFree(l->bias);
     if (l->wh) (void)hipFree(l->wh);
     if (l->wsp) (void)hipFree(l->wsp);
+    if (l->wf) (void)hipFree(l->wf);
+    l->wf = nullptr;
     l->wp = l->bias = l->wh = l->wsp = nullptr;
 }
 
@@ -202,6 +227,8 @@ int run_conv(const ConvLayer& L, int N, int H, int W, View s0, int up0, View s1,
     p.wsp = L.wsp;
     p.wsp_plane = L.wsp_plane;
     p.wsp_planes = L.wsp_planes;
+    p.wf16 = L.wf;
+    p.wf16_cout_pad = L.wf_cout_pad;
     p.bias = L.bias;
     p.cout = L.cout;
     p.cout_pad = L.cout_pad;
@@ -599,7 +626,11 @@ int FlowNet::forward(const uint8_t* d_ref, const uint8_t* d_cur, float* d_fwd, f
         set_last_error("FlowNet::forward before finalize");
         return DFVO_ERR_STATE;
     }
-    DFVO_TRY(enqueue_input(d_ref, d_cur));
+    // DFVO_FLOW_GRAPH_INPUT=1: the two frame-reading launches are captured too (one graph launch per pass, but the graph is
+    // re-captured whenever the frame pointers change: only for callers that replay the same buffers)
+    static const bool graph_input = getenv("DFVO_FLOW_GRAPH_INPUT") && atoi(getenv("DFVO_FLOW_GRAPH_INPUT")) != 0;
+    const bool in_graph = graph_input && use_graph && tuned_once && graph_exec && graph_ref == d_ref && graph_cur == d_cur;
+    if (!in_graph) DFVO_TRY(enqueue_input(d_ref, d_cur));
     if (!tuned_once) {  // first call: eager run with the conv autotuner on (sizes are final from here on)
         conv_autotune_scope(true);
         int rc = enqueue(d_fwd, d_bwd, d_diff);
@@ -609,7 +640,8 @@ int FlowNet::forward(const uint8_t* d_ref, const uint8_t* d_cur, float* d_fwd, f
         tuned_once = true;
     }
     if (!use_graph) return enqueue(d_fwd, d_bwd, d_diff);
-    if (graph_exec && (graph_fwd != d_fwd || graph_bwd != d_bwd || graph_diff != d_diff)) {
+    if (graph_exec && (graph_fwd != d_fwd || graph_bwd != d_bwd || graph_diff != d_diff ||
+                       (graph_input && (graph_ref != d_ref || graph_cur != d_cur)))) {
         (void)hipGraphExecDestroy(graph_exec);
         (void)hipGraphDestroy(graph);
         graph_exec = nullptr;
@@ -620,7 +652,8 @@ int FlowNet::forward(const uint8_t* d_ref, const uint8_t* d_cur, float* d_fwd, f
         DFVO_TRY(enqueue(d_fwd, d_bwd, d_diff));
         DFVO_HIP_CHECK(hipStreamSynchronize(stream));
         DFVO_HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-        int rc = enqueue(d_fwd, d_bwd, d_diff);
+        int rc = graph_input ? enqueue_input(d_ref, d_cur) : DFVO_OK;
+        if (rc == DFVO_OK) rc = enqueue(d_fwd, d_bwd, d_diff);
         hipError_t e = hipStreamEndCapture(stream, &graph);
         if (rc != DFVO_OK) return rc;
         DFVO_HIP_CHECK(e);
@@ -628,6 +661,8 @@ int FlowNet::forward(const uint8_t* d_ref, const uint8_t* d_cur, float* d_fwd, f
         graph_fwd = d_fwd;
         graph_bwd = d_bwd;
         graph_diff = d_diff;
+        graph_ref = d_ref;
+        graph_cur = d_cur;
         return DFVO_OK;  // results of the eager run are already in place
     }
     DFVO_HIP_CHECK(hipGraphLaunch(graph_exec, stream));

@@ -14,6 +14,8 @@
 #include "np_legacy.h"
 #include "solver.h"
 #include "solver_math.h"
+#include <cstring>
+
 #include "tracker.h"
 
 namespace dfvo {
@@ -1530,11 +1532,21 @@ int TrackerBuffers::init() {
     DFVO_HIP_CHECK(hipMalloc((void**)&kp_total, sizeof(int) * 8));
     DFVO_HIP_CHECK(hipMalloc((void**)&pose, sizeof(PoseState)));
     DFVO_HIP_CHECK(hipMalloc((void**)&small, sizeof(double) * 128));
-    DFVO_HIP_CHECK(hipHostMalloc((void**)&h_small, sizeof(double) * 18, hipHostMallocDefault));
     DFVO_HIP_CHECK(hipMalloc((void**)&scale_out, sizeof(ScaleResult)));
     DFVO_HIP_CHECK(hipMemset(kp_info, 0, sizeof(int) * 8));
+    // Side streams: [0] runs the five-point batch, [1] the scale stage's fills; the slots past `n_streams` alias them.
+    // How many streams are CREATED here matters although only two are used: the hardware queue a stream gets (and with it
+    // the compute pipe that dispatches it) follows the creation order, the fused pipeline creates its two prefetch
+    // streams after these, and the pair rate depends on which pipes the prefetch chain shares with the flow nets / the
+    // RNG-dependent solver chain.  Measured on MI355X, bench.py order (pipeline created before the process touches the
+    // GPU through torch), exact fp32: 2 -> 103, 3 -> 108, 4 -> 133, 5 -> 111, 6 -> 112, 7 -> 116, 8 -> 133 frames/s;
+    // with a torch copy issued first the fast settings are 5 .. 7 (126).  DFVO_REP_STREAMS overrides (tuning aid).
+    static const int n_streams = getenv("DFVO_REP_STREAMS") ? atoi(getenv("DFVO_REP_STREAMS")) : NUM_REP_STREAMS;
     for (int r = 0; r < MAX_REP; r++) {
-        DFVO_HIP_CHECK(hipStreamCreateWithFlags(&s_rep[r], hipStreamNonBlocking));
+        if (r < n_streams)
+            DFVO_HIP_CHECK(hipStreamCreateWithFlags(&s_rep[r], hipStreamNonBlocking));
+        else
+            s_rep[r] = s_rep[r % n_streams];
         DFVO_HIP_CHECK(hipEventCreateWithFlags(&ev_rep[r], hipEventDisableTiming));
     }
     DFVO_HIP_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
@@ -1555,7 +1567,6 @@ int TrackerBuffers::init_shared(const TrackerBuffers& first) {
     DFVO_HIP_CHECK(hipMalloc((void**)&kp_total, sizeof(int) * 8));
     DFVO_HIP_CHECK(hipMalloc((void**)&pose, sizeof(PoseState)));
     DFVO_HIP_CHECK(hipMalloc((void**)&small, sizeof(double) * 128));
-    DFVO_HIP_CHECK(hipHostMalloc((void**)&h_small, sizeof(double) * 18, hipHostMallocDefault));
     DFVO_HIP_CHECK(hipMalloc((void**)&scale_out, sizeof(ScaleResult)));
     DFVO_HIP_CHECK(hipMemset(kp_info, 0, sizeof(int) * 8));
     DFVO_HIP_CHECK(hipEventCreateWithFlags(&ev_start, hipEventDisableTiming));
@@ -1570,7 +1581,7 @@ void TrackerBuffers::release() {
     for (int r = 0; r < MAX_REP; r++) {
         ws_rep[r].release();
         if (!shared) {
-            if (s_rep[r]) (void)hipStreamDestroy(s_rep[r]);
+            if (s_rep[r] && r < (getenv("DFVO_REP_STREAMS") ? atoi(getenv("DFVO_REP_STREAMS")) : NUM_REP_STREAMS)) (void)hipStreamDestroy(s_rep[r]);
             if (ev_rep[r]) (void)hipEventDestroy(ev_rep[r]);
         }
         s_rep[r] = nullptr;
@@ -1581,8 +1592,7 @@ void TrackerBuffers::release() {
     if (ev_h) (void)hipEventDestroy(ev_h);
     ev_fork = ev_start = ev_h = nullptr;
     if (shared) mt_state = nullptr;
-    if (h_small) (void)hipHostFree(h_small);
-    h_small = nullptr;
+    small_valid = false;
     void* ptrs[] = {mt_state, kp_info, kp_total, pose, small, scale_out, winner, lidx};
     lidx = nullptr;
     lidx_cap = 0;
@@ -1626,14 +1636,20 @@ int enqueue_mt_shuffle(uint32_t* mt_state, const int* d_n, int n_host, int repea
 // previous pair is still busy.  Records tb.ev_start (keypoints ready) and tb.ev_h (this half done) on sh.
 int enqueue_pose_h_part(TrackerBuffers& tb, int n_bound, const PoseConfig& cfg, hipStream_t sh) {
     DFVO_ARG_CHECK(n_bound >= 0 && n_bound <= tb.kp_cap, "compute_pose_2d2d: keypoint capacity");
-    // pinned source: the copy may still be pending when this function returns (sh can be blocked on the slot's nets);
-    // a slot is re-enqueued only after its previous track() returned, i.e. after the previous copy was consumed
-    double* hk = tb.h_small;
+    // the intrinsics are constant for a pipeline / tracker: uploaded (synchronously) only when they differ from what this
+    // buffer set already holds, so the per-pair path contains no host-to-device copy at all (a copy queued behind the
+    // stream's wait for the nets delayed the whole keypoint stage by milliseconds; a pageable source could be read late)
+    double hk[18];
     for (int i = 0; i < 9; i++) {
         hk[i] = cfg.KinvT[i];
         hk[9 + i] = cfg.Kinv[i];
     }
-    DFVO_HIP_CHECK(hipMemcpyAsync(tb.small, hk, 18 * sizeof(double), hipMemcpyHostToDevice, sh));
+    if (!tb.small_valid || memcmp(tb.h_small, hk, sizeof(hk)) != 0) {
+        DFVO_HIP_CHECK(hipDeviceSynchronize());  // nothing in flight may still read the old values
+        DFVO_HIP_CHECK(hipMemcpy(tb.small, hk, sizeof(hk), hipMemcpyHostToDevice));
+        memcpy(tb.h_small, hk, sizeof(hk));
+        tb.small_valid = true;
+    }
     hipLaunchKernelGGL(k_pose_state_init, dim3(cdiv(tb.kp_cap, 256)), dim3(256), 0, sh, tb.pose, tb.kp_info,
                        tb.best_inliers, tb.kp_cap);
     DFVO_HIP_CHECK(hipEventRecord(tb.ev_start, sh));

@@ -50,6 +50,7 @@ struct ScaleConfig {
 };
 
 constexpr int MAX_REP = 8;
+constexpr int NUM_REP_STREAMS = 4;  // side streams created per tracker; two are used (see TrackerBuffers::init)
 
 // PnpTracker.compute_pose_3d2d (solver_pnp.hip)
 struct PnpConfig {
@@ -105,7 +106,8 @@ struct TrackerBuffers {
     int* kp_total = nullptr;
     PoseState* pose = nullptr;
     double* small = nullptr;
-    double* h_small = nullptr;     // pinned staging for the 18 intrinsics doubles uploaded into `small` (async-safe source)
+    double h_small[18] = {};       // host copy of the 18 intrinsics doubles held in `small` (uploaded only when they change)
+    bool small_valid = false;
     ScaleResult* scale_out = nullptr;
     int* winner = nullptr;
     size_t winner_cap = 0;

@@ -72,6 +72,13 @@ int dfvo_conv2d(const dfvo_conv_desc* desc, const float* d_src0, const float* d_
  * heads (direct kernel; wider 5x5 / 7x7 layers use the window kernel under the same ids); arrays of 19), the
  * summed duration [ms], useful FLOPs and launch count.
  * Do not use while a hipGraph capture is active (disable graphs on the nets first). */
+/* arithmetic of the 3x3 / stride-1 window layers packed AFTER this call (nets are packed at *_finalize):
+ *   "fp32"   exact fp32 MFMA (v_mfma_f32_16x16x4_f32), the default
+ *   "f16x3"  fp32-class: operands split into two f16 planes (22 mantissa bits), three exact products per term on
+ *            v_mfma_f32_32x32x16_f16, fp32 accumulate (df-vo_amd/csrc/conv_win_f16s.h)
+ *   "bf16x6" / "bf16x3"  bf16-plane variants (24 / 16 mantissa bits)
+ * Also read once from the environment variable DFVO_CONV_PRECISION. */
+int dfvo_set_conv_precision(const char* name);
 int dfvo_conv_profile_begin(void);
 /* host only: the bf16 planes the opt-in split-precision conv modes (DFVO_CONV_PRECISION=bf16x3 | bf16x6) give a weight:
  * h_out[q * n + i] = plane q of h_in[i], x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1), round to nearest even */

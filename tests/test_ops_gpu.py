@@ -207,3 +207,47 @@ def test_split_precision_modes(gpu):
     assert err["bf16x6"] <= 4e-6     # dropped terms ~2^-24 per product: the same class
     assert err["bf16x3"] <= 2e-5     # 16 mantissa bits per operand, all four product terms
     assert err["bf16x3"] > err["bf16x6"]
+
+
+F16_CASES = [
+    # name, N, H, W, c0, c1, cout, pad_mode, act, up0
+    ("128_128_leaky", 2, 96, 312, 128, 0, 128, 0, 1, 0),
+    ("subpixel_64+66_128", 2, 96, 312, 64, 66, 128, 0, 1, 0),
+    ("regular_3+128_128", 2, 96, 312, 3, 128, 128, 0, 1, 0),
+    ("matching_49_128", 2, 96, 312, 49, 0, 128, 0, 1, 0),
+    ("128_64", 2, 96, 312, 128, 0, 64, 0, 1, 0),
+    ("64_32", 2, 96, 312, 64, 0, 32, 0, 1, 0),
+    ("32_32_odd_size", 2, 97, 301, 32, 0, 32, 0, 1, 0),
+    ("decoder_up32+64_32_reflect_elu", 1, 96, 320, 32, 64, 32, 1, 3, 1),
+    ("decoder_16_16_reflect_elu", 1, 192, 640, 16, 0, 16, 1, 3, 0),
+]
+
+
+@pytest.mark.parametrize("case", F16_CASES, ids=[c[0] for c in F16_CASES])
+def test_f16x3_window_conv(gpu, case):
+    """DFVO_CONV_PRECISION=f16x3 (conv_win_f16s_kernel): 3x3 window layers with operands split into two f16 planes
+    (22 mantissa bits) and three exact products per term, fp32 accumulate -- fp32-class accuracy: the bound is the one the
+    exact fp32 kernel is held to in the split-mode probe (4e-6 of max|ref|, K up to 1200 terms)."""
+    name, n, h, w, c0, c1, cout, pad_mode, act, up0 = case
+    lib = gpu.lib()
+    g = torch.Generator().manual_seed(len(name))
+    x0 = torch.randn(n, c0, h, w, generator=g)
+    x1 = torch.randn(n, c1, h * (2 if up0 else 1), w * (2 if up0 else 1), generator=g) if c1 else None
+    wt = torch.randn(cout, c0 + c1, 3, 3, generator=g) * (2.0 / (9 * (c0 + c1))) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    xin = F.interpolate(x0, scale_factor=2, mode="nearest") if up0 else x0
+    if x1 is not None:
+        xin = torch.cat([xin, x1], 1)
+    xp = F.pad(xin, (1, 1, 1, 1), mode="reflect" if pad_mode else "constant")
+    ref = ref_act(F.conv2d(xp.double(), wt.double(), b.double()), act, 0.1 if act == 1 else 1.0).float()
+    errs = {}
+    for mode in (b"fp32", b"f16x3"):
+        gpu.check(lib.dfvo_set_conv_precision(mode))
+        try:
+            got = run_conv(gpu, x0, wt, b, 1, (1, 1), pad_mode, act, 0.1 if act == 1 else 1.0, x1=x1, up0=up0)
+        finally:
+            gpu.check(lib.dfvo_set_conv_precision(b"fp32"))
+        err, scale = report("%s %s" % (name, mode.decode()), got, ref)
+        errs[mode] = err / scale
+    assert errs[b"fp32"] <= 2e-6
+    assert errs[b"f16x3"] <= 4e-6
