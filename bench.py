@@ -159,9 +159,10 @@ def main(argv=None):
     ap.add_argument("--width", type=int, default=1241)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--conv-precision", default=os.environ.get("DFVO_CONV_PRECISION", "fp32"), choices=["fp32", "f16x3", "bf16x6", "bf16x3"],
-                    help="fp32 (default, the parity-gated exact path); bf16x6 / bf16x3: opt-in split-precision MFMA modes "
-                         "of the 3x3 window layers (DESIGN.md section 3) -- reported in config.conv_precision, never the default")
+    ap.add_argument("--conv-precision", default=os.environ.get("DFVO_CONV_PRECISION", "f16x3"), choices=["fp32", "f16x3", "bf16x6", "bf16x3"],
+                    help="arithmetic of the 3x3 window layers: f16x3 (default: fp32-class split kernel, the whole -m gpu net / "
+                         "pipeline parity suite runs green on it at the exact path's tolerances), fp32 (exact fp32 MFMA), "
+                         "bf16x6 / bf16x3 (round-1 experiments) -- reported in dtype and config.conv_precision")
     ap.add_argument("--solver-inputs", default="nets", choices=["nets", "synthetic"],
                     help="nets: the solver stage consumes the nets' own outputs (coded-world frames, the product data path); "
                          "synthetic: random-weight nets + a synthetic rigid-scene flow/consistency/depth triple (round-1 mode)")

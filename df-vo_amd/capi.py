@@ -109,6 +109,7 @@ SIGNATURES = {
     "dfvo_flownet_destroy": (None, [_vp]),
     "dfvo_flownet_set_param": (_i, [_vp, C.c_char_p, _vp, _i, _ip]),
     "dfvo_flownet_finalize": (_i, [_vp]),
+    "dfvo_flow_target_size": (_i, [_i, _i, _ip, _ip]),
     "dfvo_flownet_net_size": (_i, [_vp, _ip, _ip]),
     "dfvo_flownet_set_graph": (_i, [_vp, _i]),
     "dfvo_flownet_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),

@@ -259,6 +259,11 @@ int dfvo_flownet_finalize(dfvo_flownet* n) {
     DFVO_ARG_CHECK(n, "null net");
     return n->net.finalize();
 }
+int dfvo_flow_target_size(int img_h, int img_w, int* net_h, int* net_w) {
+    DFVO_ARG_CHECK(net_h && net_w && img_h >= 32 && img_w >= 32, "dfvo_flow_target_size: bad argument");
+    flow_target_size(img_h, img_w, net_h, net_w);
+    return DFVO_OK;
+}
 int dfvo_flownet_net_size(const dfvo_flownet* n, int* h, int* w) {
     DFVO_ARG_CHECK(n && h && w, "null argument");
     *h = n->net.H;

@@ -1235,6 +1235,7 @@ int launch_conv(const ConvParams& p, hipStream_t stream) {
         if (p.kh == 5) return p.cout == 2 ? launch_head<5, 2>(p, stream, 17) : launch_head<5, 1>(p, stream, 17);
         return p.cout == 2 ? launch_head<3, 2>(p, stream, 18) : launch_head<3, 1>(p, stream, 18);
     }
+    if (p.wf16 && conv_f16s_ok(p)) return launch_f16s(p, stream, 19);  // f16x3: every 3x3 / stride-1 layer, all map sizes
     if (conv_use_window(p, bn) && p.kh == 7) return launch_win3<4, 1, 2, 1, 7>(p, stream, 16);
     if (conv_use_window(p, bn) && p.kh == 5) return launch_win3<4, 1, 2, 1, 5>(p, stream, 17);
     if (conv_use_window(p, bn)) {
@@ -1243,7 +1244,6 @@ int launch_conv(const ConvParams& p, hipStream_t stream) {
         if (force_cfg == 15 && bn == 128) return launch_win3<1, 4, 4, 2>(p, stream, 15);
         if (force_cfg == 14 && p.cout_pad % 32 == 0) return launch_win3<4, 1, 2, 2>(p, stream, 14);
         const long long tiles8 = (long long)p.N * ((p.Ho + 7) / 8) * ((p.Wo + 15) / 16) * (p.cout_pad / bn);
-        if (p.wf16 && conv_f16s_ok(p)) return launch_f16s(p, stream, 19);  // DFVO_CONV_PRECISION=f16x3
         if (p.wsp && p.wsp_planes == 2) {  // opt-in split-precision modes: same tiles, bf16 MFMAs
             if (bn == 128) return launch_win3<2, 2, 4, 2, 3, 2>(p, stream, 13);
             if (bn == 64) return launch_win3<2, 2, 4, 2, 3, 2>(p, stream, 13);

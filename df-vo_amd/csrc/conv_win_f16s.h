@@ -201,10 +201,20 @@ __global__ __launch_bounds__(256, 2) void conv_win_f16s_kernel(const ConvParams 
 
 static bool conv_f16s_ok(const ConvParams& p) {
     if (p.kh != 3 || p.kw != 3 || p.stride != 1 || p.pad_h != 1 || p.pad_w != 1) return false;
-    if (p.wf16_cout_pad % 32 != 0 || p.Wo < 24) return false;
-    const long long tiles = (long long)p.N * ((p.Ho + 3) / 4) * ((p.Wo + 31) / 32) * ((p.wf16_cout_pad + 127) / 128);
-    static const long long min_tiles = getenv("DFVO_F16S_MIN_TILES") ? atoll(getenv("DFVO_F16S_MIN_TILES")) : 256;
-    return tiles >= min_tiles;
+    if (p.wf16_cout_pad % 32 != 0 || p.Wo < 24 || p.Ho < 4) return false;
+    // small maps stay on the fp32 split-K kernels: with fewer than ~200 of the smallest (32 couts x 4 x 32 px) tiles the
+    // grid cannot fill the chip and the un-split K loop makes the launch longer than the fp32 one (measured: pyramid
+    // levels 5 / 6 and the depth net's inner layers 2-4x slower, level 4 1.5-2x faster)
+    static const long long min_blocks = getenv("DFVO_F16S_MIN_BLOCKS") ? atoll(getenv("DFVO_F16S_MIN_BLOCKS")) : 200;
+    const long long e = (long long)p.N * ((p.Ho + 3) / 4) * ((p.Wo + 31) / 32) * (p.wf16_cout_pad / 32);
+    return e >= min_blocks;
+}
+
+template <int WC, int WR, int TC, int TR>
+static long long f16s_blocks(const ConvParams& p) {
+    constexpr int TH = WR * TR, BN = WC * TC * 32;
+    if (p.wf16_cout_pad % BN != 0) return 0;
+    return (long long)p.N * ((p.Ho + TH - 1) / TH) * ((p.Wo + 31) / 32) * (p.wf16_cout_pad / BN);
 }
 
 template <int WC, int WR, int TC, int TR>
@@ -231,11 +241,18 @@ static int launch_f16s_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) 
     return DFVO_OK;
 }
 
+// Tile choice: the largest tile whose grid still fills the chip (256 CUs x 2 resident workgroups); small maps (pyramid
+// levels 4 .. 6, the depth net's inner layers) fall back to narrower cout blocks / fewer rows so that more CUs get work:
+//   A 128 couts x (4 x 32) px   B 64 x (8 x 32)   C 64 x (4 x 32)   D 32 x (8 x 32)   E 32 x (4 x 32)
 static int launch_f16s(const ConvParams& p, hipStream_t stream, int cfg_id) {
-    const int cp = p.wf16_cout_pad;
-    if (cp % 128 == 0) return launch_f16s_cfg<2, 2, 2, 2>(p, stream, cfg_id);  // 128 couts x (4 x 32) pixels
-    if (cp % 64 == 0) return launch_f16s_cfg<1, 4, 2, 2>(p, stream, cfg_id);   // 64 couts x (8 x 32) pixels
-    return launch_f16s_cfg<1, 4, 1, 2>(p, stream, cfg_id);                      // 32 couts x (8 x 32) pixels
+    static const long long fill = getenv("DFVO_F16S_FILL") ? atoll(getenv("DFVO_F16S_FILL")) : 400;
+    const long long a = f16s_blocks<2, 2, 2, 2>(p), b = f16s_blocks<1, 4, 2, 2>(p), c = f16s_blocks<2, 2, 1, 2>(p),
+                    d = f16s_blocks<1, 4, 1, 2>(p);
+    if (a >= fill) return launch_f16s_cfg<2, 2, 2, 2>(p, stream, cfg_id);
+    if (b >= fill) return launch_f16s_cfg<1, 4, 2, 2>(p, stream, cfg_id);
+    if (c >= fill) return launch_f16s_cfg<2, 2, 1, 2>(p, stream, cfg_id);
+    if (d >= fill) return launch_f16s_cfg<1, 4, 1, 2>(p, stream, cfg_id);
+    return launch_f16s_cfg<1, 4, 1, 1>(p, stream, cfg_id);
 }
 
 // host side: f32 -> (hi, lo) exactly as split_f16_planes does on the device

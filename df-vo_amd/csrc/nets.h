@@ -70,6 +70,9 @@ int run_conv(const ConvLayer& L, int N, int H, int W, View s0, int up0, View s1,
              const DevBuf* splitk_ws = nullptr);
 
 // ------------------------------------------------------------------------------------------------
+// flow-net input size for an image size, exactly as the reference's DeepFlow.get_target_size evaluates (nets.hip)
+void flow_target_size(int h, int w, int* th, int* tw);
+
 struct FlowNet {
     int imgH = 0, imgW = 0;  // cfg image size
     int H = 0, W = 0;        // net size (multiple of 32), deep_flow.py:89-105

@@ -273,27 +273,33 @@ static const float kDbl[7] = {0.f, 0.f, 10.f, 5.f, 2.5f, 1.25f, 0.625f};
 static const int kKer[7] = {0, 0, 7, 5, 5, 3, 3};
 static const int kFeatC[7] = {0, 32, 32, 64, 96, 128, 192};
 
-static void target_size(int h, int w, int* th, int* tw) {
-    // deep_flow.py:89-105
-    const int hs[2] = {32 * (h / 32), 32 * (h / 32 + 1)};
-    const int ws[2] = {32 * (w / 32), 32 * (w / 32 + 1)};
+void flow_target_size(int h, int w, int* th, int* tw) {
+    // deep_flow.py:89-105 as it actually evaluates: `h` and `w` are rebound to the candidate arrays before the aspect
+    // ratios are compared, so entry (i, j) of the compared matrix is |h_i * (1 / w_j) - h_j / w_j| (float64; np.argmin
+    // takes the first minimum in row-major order).  The diagonal is zero up to rounding: (floor, floor) -- 376 x 1241
+    // runs at 352 x 1216 -- unless rounding noise leaves entry [0][0] non-zero (192 x 640 -> 224 x 672).
+    const double hs[2] = {32.0 * (h / 32), 32.0 * (h / 32 + 1)};
+    const double ws[2] = {32.0 * (w / 32), 32.0 * (w / 32 + 1)};
     double best = 1e300;
     int bi = 0;
     for (int i = 0; i < 4; ++i) {
-        const double r = std::fabs((double)hs[i / 2] * (1.0 / (double)ws[i % 2]) - (double)h / (double)w);
+        const volatile double inv = 1.0 / ws[i % 2];          // 1 / w  (rounded)
+        const volatile double prod = hs[i / 2] * inv;         // matmul entry: one rounded product
+        const volatile double quot = hs[i % 2] / ws[i % 2];   // (h / w)[j] broadcast over the rows
+        const double r = std::fabs(prod - quot);
         if (r < best) {
             best = r;
             bi = i;
         }
     }
-    *th = hs[bi / 2];
-    *tw = ws[bi % 2];
+    *th = (int)hs[bi / 2];
+    *tw = (int)ws[bi % 2];
 }
 
 int FlowNet::init(int imgH_, int imgW_, hipStream_t s) {
     imgH = imgH_;
     imgW = imgW_;
-    target_size(imgH, imgW, &H, &W);
+    flow_target_size(imgH, imgW, &H, &W);
     DFVO_ARG_CHECK(H >= 64 && W >= 64, "FlowNet: image too small");
     if (s) {
         stream = s;

@@ -27,12 +27,11 @@ class LiteFlow:
 
     # -- DeepFlow helpers kept for API parity -------------------------------------------------
     def get_target_size(self, h, w):
-        """deep_flow.py:89-105"""
-        hh = 32 * np.array([[math.floor(h / 32), math.floor(h / 32) + 1]])
-        ww = 32 * np.array([[math.floor(w / 32), math.floor(w / 32) + 1]])
-        ratio = np.abs(np.matmul(np.transpose(hh), 1 / ww) - h / w)
-        index = np.argmin(ratio)
-        return hh[0, index // 2], ww[0, index % 2]
+        """deep_flow.py:89-105, evaluated by the library exactly as the reference evaluates it (dfvo_flow_target_size)"""
+        import ctypes as C
+        th, tw = C.c_int(), C.c_int()
+        capi.check(capi.lib().dfvo_flow_target_size(int(h), int(w), C.byref(th), C.byref(tw)))
+        return th.value, tw.value
 
     def initialize_network_model(self, weight_path, finetune):
         """lite_flow.py:32-53: `weight_path` is a torch state_dict file, or an in-memory state_dict"""

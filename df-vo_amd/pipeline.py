@@ -61,11 +61,8 @@ class TrackingPipeline:
 
     @staticmethod
     def _net_size(h, w):
-        import math
-        hh = 32 * np.array([[math.floor(h / 32), math.floor(h / 32) + 1]])
-        ww = 32 * np.array([[math.floor(w / 32), math.floor(w / 32) + 1]])
-        idx = np.argmin(np.abs(np.matmul(np.transpose(hh), 1 / ww) - h / w))
-        return int(hh[0, idx // 2]), int(ww[0, idx % 2])
+        from .synthetic import _net_size
+        return _net_size(h, w)
 
     def close(self):
         if self.h is not None:

@@ -400,15 +400,18 @@ def crafted_liteflownet_state_dict(h, w, mode, flow_range=32.0, seed=4869):
 
 
 def _net_size(h, w):
-    """deep_flow.py:89-105"""
-    hs = [32 * (h // 32), 32 * (h // 32 + 1)]
-    ws = [32 * (w // 32), 32 * (w // 32 + 1)]
+    """flow-net input size as the reference's DeepFlow.get_target_size (deep_flow.py:89-105) really computes it: the
+    function rebinds h, w to the candidate arrays before comparing aspect ratios, so the compared matrix is
+    |h_i * (1/w_j) - h_j / w_j| (float64, first minimum in row-major order): (floor, floor) multiples of 32 unless rounding
+    makes entry [0][0] non-zero -- 376x1241 -> 352x1216, 192x640 -> 224x672, 256x640 / 384x1248 unchanged"""
+    hs = [32.0 * (h // 32), 32.0 * (h // 32 + 1)]
+    ws = [32.0 * (w // 32), 32.0 * (w // 32 + 1)]
     best, arg = None, None
     for i in range(4):
-        rr = abs(hs[i // 2] * (1.0 / ws[i % 2]) - h / w)
+        rr = abs(hs[i // 2] * (1.0 / ws[i % 2]) - hs[i % 2] / ws[i % 2])
         if best is None or rr < best:
             best, arg = rr, i
-    return hs[arg // 2], ws[arg % 2]
+    return int(hs[arg // 2]), int(ws[arg % 2])
 
 
 def tunnel_poses(n, step=1.0, seed=7):
@@ -521,3 +524,26 @@ def tunnel_truth(seq, k):
     u, v, _ = tunnel_flow(seq["K"], seq["poses"][k], seq["poses"][k + 1], yy, xx, **seq["world"])
     ub, vb, z1 = tunnel_flow(seq["K"], seq["poses"][k + 1], seq["poses"][k], yy, xx, **seq["world"])
     return np.stack([u, v]), np.stack([ub, vb]), z1
+
+
+def write_weight_files(dirname, fsd, dsd, feed_h=192, feed_w=640):
+    """the on-disk formats the reference loads: `network-default.pytorch` = a bare LiteFlowNet state_dict
+    (lite_flow.py:45-46); a directory with `encoder.pth` = ResnetEncoder state_dict (keys 'encoder.*', torchvision's unused
+    fc layer and BatchNorm counters included, as a real checkpoint has them) plus the scalar entries 'height' / 'width' /
+    'use_stereo' (monodepth2.py:47-50,70-71) and `depth.pth` = DepthDecoder state_dict (:54-57).
+    Returns (flow weight path, depth weight directory)."""
+    import os
+    ddir = os.path.join(dirname, "depth")
+    os.makedirs(ddir, exist_ok=True)
+    flow_path = os.path.join(dirname, "network-default.pytorch")
+    torch.save({k: v.clone() for k, v in fsd.items()}, flow_path)
+    enc = {k: v.clone() for k, v in dsd.items() if k.startswith("encoder.")}
+    for k in list(enc.keys()):
+        if k.endswith(".running_mean"):
+            enc[k[:-len("running_mean")] + "num_batches_tracked"] = torch.tensor(0, dtype=torch.long)
+    enc["encoder.fc.weight"] = torch.zeros(1000, 512)
+    enc["encoder.fc.bias"] = torch.zeros(1000)
+    enc["height"], enc["width"], enc["use_stereo"] = feed_h, feed_w, True
+    torch.save(enc, os.path.join(ddir, "encoder.pth"))
+    torch.save({k: v.clone() for k, v in dsd.items() if k.startswith("decoder.")}, os.path.join(ddir, "depth.pth"))
+    return flow_path, ddir

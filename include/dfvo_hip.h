@@ -123,6 +123,10 @@ void dfvo_flownet_destroy(dfvo_flownet* net);
  * "aux.linspace_x.<level>" / "aux.linspace_y.<level>" tables (level 2..6). */
 int dfvo_flownet_set_param(dfvo_flownet* net, const char* name, const float* h_data, int ndim, const int* shape);
 int dfvo_flownet_finalize(dfvo_flownet* net);
+/* flow-net input size for an image size (host only, no device needed): DeepFlow.get_target_size (deep_flow.py:89-105) as
+ * the reference really evaluates it -- its rebinding of h / w makes the result (floor, floor) multiples of 32 (KITTI
+ * 376 x 1241 -> 352 x 1216) unless float64 rounding tips it to (ceil, ceil) (192 x 640 -> 224 x 672) */
+int dfvo_flow_target_size(int img_h, int img_w, int* net_h, int* net_w);
 int dfvo_flownet_net_size(const dfvo_flownet* net, int* net_h, int* net_w);
 int dfvo_flownet_set_graph(dfvo_flownet* net, int enable);
 /* device in, device out: ref/cur uint8 [H,W,3]; fwd,bwd float [2,H,W]; diff float [H,W] */

@@ -212,12 +212,16 @@ def liteflownet_forward(sd, first, second, return_levels=False):
 
 
 def get_target_size(h, w):
-    """deep_flow.py:89-105"""
-    hh = 32 * np.array([[math.floor(h / 32), math.floor(h / 32) + 1]])
-    ww = 32 * np.array([[math.floor(w / 32), math.floor(w / 32) + 1]])
-    ratio = np.abs(np.matmul(np.transpose(hh), 1 / ww) - h / w)
+    """deep_flow.py:89-105, statement for statement -- INCLUDING its rebinding of `h` and `w`: by the time the aspect
+    ratio is compared, `h / w` is the element-wise quotient of the two candidate ARRAYS, so the matrix is
+    |h_i * (1/w_j) - h_j / w_j|: its diagonal is zero up to rounding, i.e. the function returns (floor, floor) -- KITTI's
+    376x1241 runs the flow net at 352x1216, not 384x1248 -- unless rounding noise makes entry [0][0] non-zero, in
+    which case (ceil, ceil) wins (192x640 -> 224x672).  Pinned by tests/golden/target_size.npz (reference's own method)."""
+    h = 32 * np.array([[math.floor(h / 32), math.floor(h / 32) + 1]])
+    w = 32 * np.array([[math.floor(w / 32), math.floor(w / 32) + 1]])
+    ratio = np.abs(np.matmul(np.transpose(h), 1 / w) - h / w)
     index = np.argmin(ratio)
-    return int(hh[0, index // 2]), int(ww[0, index % 2])
+    return int(h[0, index // 2]), int(w[0, index % 2])
 
 
 def resize_dense_flow(flow, des_h, des_w):

@@ -28,3 +28,12 @@ def gpu(capi):
     capi.require_gpu()
     assert torch.cuda.is_available(), "torch sees no GPU"
     return capi
+
+
+@pytest.fixture(params=["fp32", "f16x3"])
+def conv_precision(request, gpu):
+    """arithmetic of the 3x3 window layers for every net packed inside the test (dfvo_set_conv_precision): the exact fp32
+    MFMA kernels, and the f16x3 split kernels that bench.py's headline uses -- same tolerances for both"""
+    gpu.check(gpu.lib().dfvo_set_conv_precision(request.param.encode()))
+    yield request.param
+    gpu.check(gpu.lib().dfvo_set_conv_precision(b"fp32"))

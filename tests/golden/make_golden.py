@@ -46,6 +46,29 @@ def apply_compat():
     torch.Tensor.cuda = lambda self, *a, **k: self
     torch.nn.Module.cuda = lambda self, *a, **k: self
     torch.cuda.current_stream = lambda *a, **k: types.SimpleNamespace(cuda_stream=0)
+    torch.cuda.manual_seed = lambda *a, **k: None
+
+    def _is_cuda(d):
+        return (isinstance(d, str) and d.startswith("cuda")) or (isinstance(d, torch.device) and d.type == "cuda")
+    _mto, _tto = torch.nn.Module.to, torch.Tensor.to
+
+    def module_to(self, *a, **k):  # .to(torch.device('cuda')) -> stay on the CPU
+        a = tuple(x for x in a if not _is_cuda(x))
+        k = {kk: v for kk, v in k.items() if not (kk == "device" and _is_cuda(v))}
+        return _mto(self, *a, **k) if (a or k) else self
+
+    def tensor_to(self, *a, **k):
+        a = tuple(x for x in a if not _is_cuda(x))
+        k = {kk: v for kk, v in k.items() if not (kk == "device" and _is_cuda(v))}
+        return _tto(self, *a, **k) if (a or k) else self
+    torch.nn.Module.to = module_to
+    torch.Tensor.to = tensor_to
+    _load = torch.load
+
+    def load_cpu(f, map_location=None, **k):  # torch.load(path, map_location=torch.device('cuda')) -> CPU; old pickles
+        k.setdefault("weights_only", False)
+        return _load(f, map_location="cpu", **k)
+    torch.load = load_cpu
     _gs = F.grid_sample
 
     def grid_sample(input, grid, mode='bilinear', padding_mode='zeros', align_corners=None):
@@ -469,13 +492,157 @@ def golden_lanczos():
     print("wrote lanczos.npz (Pillow %s)" % PIL.__version__)
 
 
+def _stub_matplotlib():
+    try:
+        import matplotlib.pyplot  # noqa: F401
+    except Exception:
+        mpl = types.ModuleType("matplotlib")
+        mpl.pyplot = types.ModuleType("matplotlib.pyplot")
+        sys.modules["matplotlib"] = mpl
+        sys.modules["matplotlib.pyplot"] = mpl.pyplot
+
+
+def kitti_eval_reference(gt, res):
+    """the reference's own KittiEvalOdom methods (tools/evaluation/odometry/kitti_odometry.py:190-245,274-299,445-497 and
+    the reporting arithmetic of :655-683) on two pose lists"""
+    _stub_matplotlib()
+    ko = load_by_path("ref_kitti_odometry", os.path.join(REF, "tools/evaluation/odometry/kitti_odometry.py"))
+    ev = ko.KittiEvalOdom()
+    pg = {i: np.array(p, dtype=np.float64) for i, p in enumerate(gt)}
+    pr = {i: np.array(p, dtype=np.float64) for i, p in enumerate(res)}
+    seq_err = ev.calc_sequence_errors(pg, pr)
+    ave_t, ave_r = ev.compute_overall_err(seq_err)
+    rpe = ev.compute_RPE(pg, pr)
+    return {"seq_err": np.array(seq_err), "t_rel": ave_t * 100, "r_rel": ave_r / np.pi * 180 * 100, "ate": ev.compute_ATE(pg, pr),
+            "rpe_t": float(np.mean(np.asarray(rpe["trans"]))), "rpe_r": float(np.mean(np.asarray(rpe["rot"])) * 180 / np.pi)}
+
+
+def golden_kitti_eval():
+    """kitti_eval.npz: the reference evaluator on (rendered ground truth, oracle trajectory) of tunnel_traj.npz -- pins
+    oracle/kitti_eval.py (tests/test_oracle_eval.py)"""
+    fx = np.load(os.path.join(HERE, "tunnel_traj.npz"))
+    gt, res = fx["gt"], fx["poses"]
+    r = kitti_eval_reference(list(gt), list(res))
+    print("  reference evaluator: t_rel %.4f %%, r_rel %.4f deg/100m, ATE %.3f, RPE %.4f m %.4f deg, %d segments" % (
+        r["t_rel"], r["r_rel"], r["ate"], r["rpe_t"], r["rpe_r"], len(r["seq_err"])))
+    np.savez_compressed(os.path.join(HERE, "kitti_eval.npz"), gt=gt, res=res, **r)
+
+
+TARGET_SIZE_CASES = [(192, 640), (376, 1241), (370, 1226), (375, 1242), (384, 1248), (256, 640), (128, 416), (70, 100), (64, 96),
+                     (960, 1280), (1280, 1920), (480, 640), (320, 1024), (256, 832), (200, 300), (97, 301), (1000, 1000)]
+
+
+def golden_target_size():
+    """target_size.npz: the reference's own DeepFlow.get_target_size (deep_flow.py:89-105) -- whose rebinding of h, w makes
+    it return (floor, floor) multiples of 32, or (ceil, ceil) when float rounding leaves entry [0][0] non-zero"""
+    from oracle import cv2_shim
+    sys.modules["cv2"] = cv2_shim
+    from libs.deep_models.flow.deep_flow import DeepFlow
+    df = DeepFlow.__new__(DeepFlow)
+    out = np.array([[h, w] + [int(v) for v in df.get_target_size(h, w)] for h, w in TARGET_SIZE_CASES])
+    for r in out:
+        print("  %4d x %4d -> %4d x %4d" % tuple(r))
+    np.savez_compressed(os.path.join(HERE, "target_size.npz"), cases=out)
+
+
+def golden_dfvo_main(n_frames=5, h=256, w=640):
+    """dfvo_main.npz: the reference's OWN frame loop -- apis/run.py:76-92 + DFVO.main / deep_model_inference / tracking /
+    update_global_pose (libs/dfvo.py:347-425,299-345,121-262,109-119), its DeepModel / LiteFlow / Monodepth2DepthNet /
+    KeypointSampler / EssTracker / PnpTracker classes, all unmodified, over the third-party shims -- on a coded tunnel
+    sequence, with the crafted weights loaded from files in the reference's on-disk formats through a stub Dataset.
+    Expected values of tests/test_dropin_gpu.py::test_mirrors_reproduce_reference_main_loop and of
+    tests/test_oracle_pipeline.py (which pins oracle/pipeline_np.py to this loop)."""
+    import tempfile
+    from oracle import cv2_shim
+    cv2_shim.imwrite = lambda *a, **k: True
+    sys.modules["cv2"] = cv2_shim
+    _stub_matplotlib()
+    import sklearn.linear_model as lm
+    if not getattr(lm.RANSACRegressor, "_dfvo_compat", False):
+        _RR = lm.RANSACRegressor
+
+        def ransac_regressor_compat(base_estimator=None, **kw):  # sklearn 0.20 spelling
+            return _RR(estimator=base_estimator, **kw)
+        ransac_regressor_compat._dfvo_compat = True
+        lm.RANSACRegressor = ransac_regressor_compat
+    from libs.deep_models.flow.lite_flow_net import correlation as ref_corr
+    ref_corr.FunctionCorrelation = lambda tensorFirst, tensorSecond, intStride: O.correlation(
+        tensorFirst, tensorSecond, intStride)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from synth import coded_tunnel_sequence, crafted_liteflownet_state_dict, crafted_monodepth2_state_dict, write_weight_files
+    seq = coded_tunnel_sequence(h, w, n_frames, mode="mux", step=1.0, seed=31)
+    tmp = tempfile.mkdtemp(prefix="dfvo_golden_")
+    flow_path, depth_dir = write_weight_files(tmp, crafted_liteflownet_state_dict(h, w, "mux"), crafted_monodepth2_state_dict())
+    # configuration exactly as apis/run.py builds it, from the reference's own default file
+    from libs.general.configuration import ConfigLoader
+    cfg = ConfigLoader().merge_cfg([os.path.join(REF, "options/examples/default_configuration.yml")])
+    cfg.dataset = "coded_tunnel"
+    cfg.seq = "00"
+    cfg.image.height, cfg.image.width = h, w
+    cfg.directory.result_dir = os.path.join(tmp, "result")
+    cfg.directory.gt_pose_dir = None
+    cfg.depth.deep_depth.pretrained_model = depth_dir
+    cfg.deep_flow.flow_net_weight = flow_path
+    cfg.visualization.enable = False
+    cfg.no_confirm = True
+    os.makedirs(cfg.directory.result_dir, exist_ok=True)
+    from libs.geometry.camera_modules import Intrinsics
+    from libs import datasets as ref_datasets
+    K = seq["K"]
+
+    class CodedTunnel:
+        """stub of libs/datasets/dataset.py's interface as DFVO uses it"""
+
+        def __init__(self, cfg):
+            self.cfg = cfg
+            self.cam_intrinsics = Intrinsics([K[0, 2], K[1, 2], K[0, 0], K[1, 1]])
+            self.data_dir = {"depth_src": None}
+            self.gt_poses = {i: p for i, p in enumerate(seq["poses"])}
+
+        def __len__(self):
+            return n_frames
+
+        def get_timestamp(self, img_id):
+            return img_id
+
+        def get_image(self, timestamp):
+            return seq["frames"][timestamp].copy()
+
+        def save_result_traj(self, traj_txt, poses):
+            from libs.general.utils import save_traj
+            save_traj(traj_txt, {i: poses[i].pose for i in poses}, format="kitti")
+    ref_datasets.datasets["coded_tunnel"] = CodedTunnel
+    from libs.dfvo import DFVO
+    np.random.seed(cfg.seed)   # apis/run.py:81-84
+    torch.manual_seed(cfg.seed)
+    vo = DFVO(cfg)
+    modes, kps = [], []
+    _tracking = vo.tracking
+
+    def tracking_and_record():
+        _tracking()
+        modes.append(vo.tracking_mode)
+        kps.append(len(vo.ref_data["kp_best"]) if vo.tracking_stage >= 1 and "kp_best" in vo.ref_data else 0)
+    vo.tracking = tracking_and_record
+    vo.main()
+    poses = np.stack([vo.global_poses[i].pose for i in range(n_frames)])
+    st = np.random.get_state()
+    print("  reference DFVO.main:", modes, "kp", kps, "final t", poses[-1][:3, 3])
+    traj = open(os.path.join(cfg.directory.result_dir, "00.txt")).read()
+    np.savez_compressed(os.path.join(HERE, "dfvo_main.npz"), poses=poses, modes=np.array(modes), n_kp=np.array(kps),
+                        rng_after=np.r_[st[1].astype(np.uint32), np.uint32(st[2])], gt=seq["poses"], K=K,
+                        n_frames=n_frames, h=h, w=w, seq_seed=31, traj_txt=np.array(traj))
+
+
 if __name__ == "__main__":
     apply_compat()
     torch.set_num_threads(8)
     which = [a for a in sys.argv[1:] if not a.startswith("--")]
     todo = {"liteflownet": golden_liteflownet, "monodepth2": golden_monodepth2, "kp": golden_kp_selection,
             "gric": golden_gric, "tracker": golden_tracker, "lanczos": golden_lanczos, "sampled": golden_kp_sampled,
-            "tracker_flow": golden_tracker_flow, "rigid": golden_rigid_flow, "bestn": golden_kp_bestn}
+            "tracker_flow": golden_tracker_flow, "rigid": golden_rigid_flow, "bestn": golden_kp_bestn,
+            "kitti_eval": golden_kitti_eval, "dfvo_main": golden_dfvo_main,
+            "target_size": golden_target_size}
     for name, fn in todo.items():
         if not which or name in which:
             print("==", name)

@@ -16,3 +16,4 @@ crafted_liteflownet_state_dict = _s.crafted_liteflownet_state_dict
 crafted_monodepth2_state_dict = _s.crafted_monodepth2_state_dict
 tunnel_truth = _s.tunnel_truth
 tunnel_cast = _s.tunnel_cast
+write_weight_files = _s.write_weight_files

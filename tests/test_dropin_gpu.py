@@ -156,3 +156,98 @@ def test_tracking_loop_over_mirrors_equals_oracle(gpu, selector, validity, scale
         assert np.abs(a - b).max() <= 1e-12, np.abs(a - b).max()
     assert np.array_equal(st_hip[1], st_ref[1]) and st_hip[2] == st_ref[2]
     assert any(np.linalg.norm(p[:3, 3]) > 0.3 for _, p in got)  # the sequence really moved
+
+
+# -----------------------------------------------------------------------------------------------------------------------
+# The mirrors instantiated the way libs/dfvo.py instantiates them (DeepModel(cfg).initialize_models() from weight FILES in the
+# reference's on-disk formats, KeypointSampler(cfg), EssTracker / PnpTracker(cfg, cam_intrinsics)) and driven through the
+# frame loop of DFVO.main; the expected poses / tracking modes come from the REFERENCE's own DFVO.main() on the same frames
+# and weight files (tests/golden/make_golden.py dfvo_main -> dfvo_main.npz; the reference cannot travel to the GPU box).
+# -----------------------------------------------------------------------------------------------------------------------
+def full_cfg(h, w, flow_path, depth_dir):
+    """the keys of options/examples/default_configuration.yml that the hot path reads"""
+    c = make_cfg(h, w)
+    c["dataset"] = "kitti_odom"
+    c["seed"] = 4869
+    c["depth"] = NS(depth_src=None, min_depth=0.0, max_depth=50.0,
+                    deep_depth=NS(network="monodepth2", pretrained_model=depth_dir))
+    c["deep_flow"] = NS(network="liteflow", flow_net_weight=flow_path, forward_backward=True)
+    c["deep_pose"] = NS(enable=False)
+    c["online_finetune"] = NS(enable=False, flow=NS(enable=True), depth=NS(enable=False))
+    c["crop"] = NS(depth_crop=[[0.3, 1], [0, 1]], flow_crop=[[0, 1], [0, 1]])
+    return c
+
+
+def test_mirrors_from_weight_files_reproduce_reference_main_loop(gpu, tmp_path):
+    import os
+    from oracle import cv2_shim
+    from synth import coded_tunnel_sequence, crafted_liteflownet_state_dict, crafted_monodepth2_state_dict, write_weight_files
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dfvo_main.npz"))
+    h, w, n = int(fx["h"]), int(fx["w"]), int(fx["n_frames"])
+    seq = coded_tunnel_sequence(h, w, n, mode="mux", step=1.0, seed=int(fx["seq_seed"]))
+    assert np.array_equal(seq["poses"], fx["gt"])
+    flow_path, depth_dir = write_weight_files(str(tmp_path), crafted_liteflownet_state_dict(h, w, "mux"),
+                                              crafted_monodepth2_state_dict())
+    cfg = full_cfg(h, w, flow_path, depth_dir)
+    dm_mod = importlib.import_module("df-vo_amd.libs.deep_models.deep_models")
+    cam_mod = importlib.import_module("df-vo_amd.libs.geometry.camera_modules")
+    ks_mod = importlib.import_module("df-vo_amd.libs.matching.keypoint_sampler")
+    trk_mod = importlib.import_module("df-vo_amd.libs.tracker")
+    deep_models = dm_mod.DeepModel(cfg)                     # dfvo.py:78-79
+    deep_models.initialize_models()
+    assert deep_models.depth.feed_height == 192 and deep_models.depth.feed_width == 640
+    assert tuple(deep_models.flow.get_target_size(h, w)) == (h, w)
+    K = seq["K"]
+    cam = cam_mod.Intrinsics([K[0, 2], K[1, 2], K[0, 0], K[1, 1]])
+    sampler = ks_mod.KeypointSampler(cfg)                   # dfvo.py:75
+    e_tracker, pnp_tracker = trk_mod.EssTracker(cfg, cam, None), trk_mod.PnpTracker(cfg, cam)   # dfvo.py:100-103
+    SE3 = cam_mod.SE3
+    np.random.seed(cfg.seed)                                # apis/run.py:81-84
+    ref_data, cur_data = {}, {}
+    global_pose = SE3()
+    poses, modes = [], []
+    for img_id in range(n):                                 # dfvo.py:358-404
+        cur_data["id"], cur_data["timestamp"], cur_data["img"] = img_id, img_id, seq["frames"][img_id].copy()
+        # deep_model_inference, dfvo.py:299-345
+        raw = deep_models.forward_depth(imgs=[cur_data["img"]])
+        assert raw.dtype == np.float32 and raw.shape == (192, 640)
+        cur_data["raw_depth"] = cv2_shim.resize(raw, (w, h), interpolation=cv2_shim.INTER_NEAREST)
+        cur_data["depth"] = T.preprocess_depth(cur_data["raw_depth"], cfg.crop.depth_crop, [cfg.depth.min_depth, cfg.depth.max_depth])
+        mode = "Ess. Mat."
+        if img_id >= 1:
+            flows = deep_models.forward_flow(cur_data, ref_data, forward_backward=cfg.deep_flow.forward_backward)
+            kf, kb, kd = (ref_data["id"], cur_data["id"]), (cur_data["id"], ref_data["id"]), (ref_data["id"], cur_data["id"], "diff")
+            assert set(flows) == {kf, kb, kd}
+            assert flows[kf].shape == (2, h, w) and flows[kb].shape == (2, h, w) and flows[kd].shape == (h, w, 1)
+            assert all(v.dtype == np.float32 for v in flows.values())
+            ref_data["flow"], cur_data["flow"], ref_data["flow_diff"] = flows[kf].copy(), flows[kb].copy(), flows[kd].copy()
+            # tracking, dfvo.py:139-262
+            kp_sel = sampler.kp_selection(cur_data, ref_data)
+            assert kp_sel["good_kp_found"]
+            sampler.update_kp_data(cur_data, ref_data, kp_sel)
+            hybrid = SE3()
+            e_out = e_tracker.compute_pose_2d2d(ref_data["kp_best"], cur_data["kp_best"], True)
+            E_pose = e_out["pose"]
+            hybrid.R = E_pose.R
+            scale = -1
+            if np.linalg.norm(E_pose.t) != 0:
+                scale = e_tracker.scale_recovery(cur_data, ref_data, E_pose, False)["scale"]
+                if scale != -1:
+                    hybrid.t = E_pose.t * scale
+            if np.linalg.norm(E_pose.t) == 0 or scale == -1:
+                hybrid = pnp_tracker.compute_pose_3d2d(ref_data["kp_best"], cur_data["kp_best"], ref_data["depth"], True)["pose"]
+                mode = "PnP"
+            global_pose.t = global_pose.R @ hybrid.t + global_pose.t      # update_global_pose, dfvo.py:109-119
+            global_pose.R = global_pose.R @ hybrid.R
+        poses.append(global_pose.pose.copy())
+        modes.append(mode)
+        ref_data = dict(cur_data)                            # update_data, dfvo.py:264-287
+        ref_data["flow"] = cur_data["flow"] = ref_data["flow_diff"] = None
+    poses = np.stack(poses)
+    print("   modes", modes, "| final t (mirrors)", poses[-1][:3, 3], "(reference DFVO.main)", fx["poses"][-1][:3, 3])
+    assert modes == list(fx["modes"])
+    # the nets differ from the reference's torch-CPU nets in fp32 summation order (<= 2e-3 px on the flow), which can move
+    # a keypoint across a threshold and with it the RANSAC samples: poses agree to the solver's noise level, not bit for bit
+    for i in range(n):
+        assert np.abs(poses[i][:3, :3] - fx["poses"][i][:3, :3]).max() < 1e-3
+        assert np.linalg.norm(poses[i][:3, 3] - fx["poses"][i][:3, 3]) < 0.02 * max(1.0, np.linalg.norm(fx["poses"][i][:3, 3]))

@@ -220,14 +220,21 @@ F16_CASES = [
     ("32_32_odd_size", 2, 97, 301, 32, 0, 32, 0, 1, 0),
     ("decoder_up32+64_32_reflect_elu", 1, 96, 320, 32, 64, 32, 1, 3, 1),
     ("decoder_16_16_reflect_elu", 1, 192, 640, 16, 0, 16, 1, 3, 0),
+    ("L4_128_128", 2, 48, 156, 128, 0, 128, 0, 1, 0),
+    ("L4_feat_96_96", 2, 48, 156, 96, 0, 96, 0, 1, 0),
+    ("L5_subpixel_128+130_128", 2, 24, 78, 128, 130, 128, 0, 1, 0),
+    ("L6_subpixel_192+194_128", 2, 12, 39, 192, 194, 128, 0, 1, 0),
+    ("L6_regular_3+192_128", 2, 12, 39, 3, 192, 128, 0, 1, 0),
+    ("resnet_64_64_relu", 1, 48, 160, 64, 0, 64, 0, 2, 0),
+    ("resnet_256_256_relu", 1, 12, 40, 256, 0, 256, 0, 2, 0),
 ]
 
 
 @pytest.mark.parametrize("case", F16_CASES, ids=[c[0] for c in F16_CASES])
 def test_f16x3_window_conv(gpu, case):
     """DFVO_CONV_PRECISION=f16x3 (conv_win_f16s_kernel): 3x3 window layers with operands split into two f16 planes
-    (22 mantissa bits) and three exact products per term, fp32 accumulate -- fp32-class accuracy: the bound is the one the
-    exact fp32 kernel is held to in the split-mode probe (4e-6 of max|ref|, K up to 1200 terms)."""
+    (22 mantissa bits) and three exact products per term, fp32 accumulate -- fp32-class accuracy: the SAME bound as the
+    exact fp32 kernel, 4e-6 of max|ref| (in these cases the split kernel's error is the smaller of the two)."""
     name, n, h, w, c0, c1, cout, pad_mode, act, up0 = case
     lib = gpu.lib()
     g = torch.Generator().manual_seed(len(name))
@@ -249,5 +256,5 @@ def test_f16x3_window_conv(gpu, case):
             gpu.check(lib.dfvo_set_conv_precision(b"fp32"))
         err, scale = report("%s %s" % (name, mode.decode()), got, ref)
         errs[mode] = err / scale
-    assert errs[b"fp32"] <= 2e-6
+    assert errs[b"fp32"] <= 4e-6   # K up to 3500 terms, split-K summation order
     assert errs[b"f16x3"] <= 4e-6

@@ -47,6 +47,19 @@ def test_correlation_orders_agree():
 
 
 def test_target_size():
-    assert O.get_target_size(376, 1241) == (384, 1248)
-    assert O.get_target_size(370, 1226) == (384, 1248)
-    assert O.get_target_size(192, 640) == (192, 640)
+    """DeepFlow.get_target_size as the reference evaluates it (fixture: the reference's own method, make_golden.py
+    target_size): the oracle, the host-side helper and the library's C entry point all reproduce it"""
+    import ctypes as C
+    import importlib
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "target_size.npz"))["cases"]
+    capi = importlib.import_module("df-vo_amd.capi")
+    syn = importlib.import_module("df-vo_amd.synthetic")
+    lib = capi.lib()
+    assert tuple(fx[list(map(tuple, fx[:, :2])).index((376, 1241))][2:]) == (352, 1216)  # KITTI: NOT 384 x 1248
+    assert tuple(fx[list(map(tuple, fx[:, :2])).index((192, 640))][2:]) == (224, 672)   # float64 rounding tips it up
+    for h, w, th, tw in fx:
+        assert O.get_target_size(int(h), int(w)) == (th, tw)
+        assert syn._net_size(int(h), int(w)) == (th, tw)
+        a, b = C.c_int(), C.c_int()
+        capi.check(lib.dfvo_flow_target_size(int(h), int(w), C.byref(a), C.byref(b)))
+        assert (a.value, b.value) == (th, tw)

@@ -21,7 +21,7 @@ def pipe_mod(gpu):
 
 
 @pytest.mark.parametrize("h,w", [(192, 640), (376, 1241)])
-def test_pipeline_tracker_matches_oracle_chain(gpu, pipe_mod, h, w):
+def test_pipeline_tracker_matches_oracle_chain(gpu, conv_precision, pipe_mod, h, w):
     sc = rigid_scene(h, w, seed=3 + h)
     K = sc["K"]
     pipe = pipe_mod.TrackingPipeline(h, w, 192, 640, K, O.liteflownet_state_dict(4869), O.monodepth2_state_dict(4869),
@@ -84,7 +84,7 @@ def test_pipeline_tracker_matches_oracle_chain(gpu, pipe_mod, h, w):
     pipe.close()
 
 
-def test_pipeline_nets_equal_standalone_executors(gpu, pipe_mod):
+def test_pipeline_nets_equal_standalone_executors(gpu, conv_precision, pipe_mod):
     h, w = 192, 640
     lib = gpu.lib()
     fsd, dsd = O.liteflownet_state_dict(4869), O.monodepth2_state_dict(4869)

@@ -1,0 +1,60 @@
+"""GPU: trajectory-level metric.  A 130-frame coded tunnel sequence (df-vo_amd/synthetic.py; ~135 m of
+path, so that the KITTI evaluator's 100 m segments exist) is tracked end to end -- uint8 frames -> HIP nets -> keypoints
+-> E / PnP RANSAC -> poses, no overrides, sequential RandomState as in apis/run.py -- and written in the KITTI trajectory
+format (libs/general/utils.py:329-355).  The same frames through the oracle's frame loop (oracle/pipeline_np.py) gave the
+committed fixture tests/golden/tunnel_traj.npz (build container; tests/golden/make_oracle_fixtures.py).  Both
+trajectories are scored against the rendered ground truth with the evaluator restated in oracle/kitti_eval.py (pinned
+to the reference's tools/evaluation/odometry/kitti_odometry.py by tests/test_oracle_eval.py):
+        |t_rel(HIP) - t_rel(oracle)| <= 0.1 (percentage points),  north_star's trajectory bar."""
+import importlib
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from oracle import kitti_eval as E
+from synth import coded_tunnel_sequence, crafted_liteflownet_state_dict, crafted_monodepth2_state_dict
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tunnel_traj.npz")
+
+
+def test_trajectory_t_rel_within_a_tenth_of_the_oracle(gpu, conv_precision, tmp_path):
+    pmod = importlib.import_module("df-vo_amd.pipeline")
+    smod = importlib.import_module("df-vo_amd.sequence")
+    fx = np.load(GOLD)
+    h, w, n = int(fx["h"]), int(fx["w"]), int(fx["n_frames"])
+    seq = coded_tunnel_sequence(h, w, n, mode="mux", step=1.0, seed=21)
+    crc = zlib.crc32(np.ascontiguousarray(seq["frames"]).tobytes()) & 0xffffffff
+    assert crc == int(fx["frames_crc"]), "the rendered frames differ from the ones the oracle fixture was computed on"
+    assert np.array_equal(seq["poses"], fx["gt"])
+    pipe = pmod.TrackingPipeline(h, w, 192, 640, seq["K"], crafted_liteflownet_state_dict(h, w, "mux"),
+                                 crafted_monodepth2_state_dict(), seed=4869)
+    frames = smod.frames_to_device(seq["frames"])
+    modes = []
+    poses, gathered = smod.run_sequence(pipe, frames, n, collect=lambda j, out: modes.append(int(out.status)))
+    pipe.close()
+    assert poses.shape == (n, 4, 4) and (gathered[:, 16] != 2).all()
+    # KITTI-format round trip (what apis/run.py leaves on disk and kitti_odometry.py:95-118 reads back)
+    path = str(tmp_path / "09.txt")
+    smod.save_traj(path, poses)
+    back = np.array([[float(v) for v in line.split()[1:]] for line in open(path)]).reshape(n, 3, 4)
+    assert np.array_equal(back, poses[:, :3, :])
+    gt = list(seq["poses"])
+    ev = E.evaluate(gt, list(poses))
+    ev_o = {k[5:]: float(fx[k]) for k in fx.files if k.startswith("eval_")}
+    print("   HIP    (%s): t_rel %.4f %%  r_rel %.4f deg/100m  ATE %.3f m  RPE %.4f m / %.4f deg | E %d PnP %d const %d" % (
+        conv_precision, ev["t_rel"], ev["r_rel"], ev["ate"], ev["rpe_t"], ev["rpe_r"], modes.count(0), modes.count(3), modes.count(1)))
+    print("   oracle        : t_rel %.4f %%  r_rel %.4f deg/100m  ATE %.3f m  RPE %.4f m / %.4f deg" % (
+        ev_o["t_rel"], ev_o["r_rel"], ev_o["ate"], ev_o["rpe_t"], ev_o["rpe_r"]))
+    assert len(E.calc_sequence_errors(gt, list(poses))) >= 3, "sequence too short for the 100 m segments"
+    assert abs(ev["t_rel"] - ev_o["t_rel"]) <= 0.1
+    assert abs(ev["r_rel"] - ev_o["r_rel"]) <= 0.05
+    assert ev["t_rel"] < 2.0  # and the tracker really follows the rendered camera
+    # per-pair agreement with the oracle trajectory (different net rounding -> occasionally different keypoints / samples)
+    rel_h = [np.linalg.inv(poses[i]) @ poses[i + 1] for i in range(n - 1)]
+    rel_o = [np.linalg.inv(fx["poses"][i]) @ fx["poses"][i + 1] for i in range(n - 1)]
+    dt = np.array([np.linalg.norm(a[:3, 3] - b[:3, 3]) for a, b in zip(rel_h, rel_o)])
+    print("   per-pair |dt| HIP vs oracle: median %.4f m, max %.4f m" % (np.median(dt), dt.max()))
+    assert np.median(dt) < 0.02
