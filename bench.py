@@ -199,7 +199,9 @@ def main(argv=None):
     if nets_mode:
         # coded tunnel world: multiplexed encoding when the frame needs no input resize, potential encoding otherwise
         code_mode = "mux" if syn._net_size(H, W) == (H, W) else "pot"
-        seq = syn.coded_tunnel_sequence(H, W, 2, mode=code_mode, step=1.0 if code_mode == "mux" else 0.3, seed=7 + rank)
+        # (potential encoding: the sideways drive, for which it yields E-tracked pairs -- tunnel_poses_lateral)
+        seq = syn.coded_tunnel_sequence(H, W, 2, mode=code_mode, step=1.0, seed=7 + rank,
+                                        poses=None if code_mode == "mux" else syn.tunnel_poses_lateral(2, 0.4))
         K = seq["K"]
         fsd, dsd = syn.crafted_liteflownet_state_dict(H, W, code_mode), syn.crafted_monodepth2_state_dict()
         scenes = None

@@ -437,6 +437,19 @@ def tunnel_poses(n, step=1.0, seed=7):
     return T
 
 
+def tunnel_poses_lateral(n, step=0.4):
+    """sideways drive (x by `step`, z by step / 4 per frame, slight yaw): on the tunnel's floor and ceiling the depth does not
+    change along the flow direction, so forward and backward flow agree at the SAME pixel -- the motion for which the
+    "pot" encoding (bwd(p) = -fwd(p)) passes the consistency check where parallax is large, and the E-tracker is accepted"""
+    T = np.tile(np.eye(4), (n, 1, 1))
+    for k in range(n):
+        yaw = 0.004 * k
+        c, s_ = math.cos(yaw), math.sin(yaw)
+        T[k, :3, :3] = np.array([[c, 0, s_], [0, 1, 0], [-s_, 0, c]])
+        T[k, :3, 3] = [step * k, 0.02 * k, 0.25 * step * k]
+    return T
+
+
 def tunnel_cast(K, T_wc, py, px, half_width=15.0, cam_height=5.0, ceiling=12.0):
     """world points hit by the pixel rays (py, px arrays) of camera T_wc in the tunnel |X| <= half_width,
     -ceiling <= Y <= cam_height (infinite along Z; convex, so every point is visible from every interior camera).

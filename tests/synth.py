@@ -17,3 +17,4 @@ crafted_monodepth2_state_dict = _s.crafted_monodepth2_state_dict
 tunnel_truth = _s.tunnel_truth
 tunnel_cast = _s.tunnel_cast
 write_weight_files = _s.write_weight_files
+tunnel_poses_lateral = _s.tunnel_poses_lateral
