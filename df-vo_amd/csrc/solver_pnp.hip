@@ -367,10 +367,10 @@ __global__ __launch_bounds__(256) void k_pnp_refine(const PBatch B) {
         s_flag = (W[2] / W[1] < 1e-3 || np < 4) ? 1 : 0;
     }
     __syncthreads();
-    if (s_flag) {  // planar object points: initialisation branch not implemented (status -2, like the oracle)
-        if (t == 0) out->status = -2;
-        return;
-    }
+    const bool planar = s_flag != 0;  // coplanar object points: the LM starts from the accepted RANSAC model (as the oracle's
+                                      // cv3_find_extrinsic_guess does; OpenCV's homography initialisation is not restated)
+    if (planar && t < 6) s_param[t] = (R.models + (size_t)R.state->best_iter * 6)[t];
+    __syncthreads();
     // ---- DLT: LL = L^T L, L = 2 rows per point; lane t < 78 owns upper-triangle entry (la, lb)
     int la = 0, lb = 0;
     if (t < 78) {
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(256) void k_pnp_refine(const PBatch B) {
         lb = la + rem;
     }
     acc = 0;
-    for (int c0 = 0; c0 < np; c0 += PR_CHUNK) {
+    for (int c0 = 0; c0 < np && !planar; c0 += PR_CHUNK) {
         const int cnt = load_chunk(c0);
         __syncthreads();
         if (t < cnt) {
@@ -398,12 +398,12 @@ __global__ __launch_bounds__(256) void k_pnp_refine(const PBatch B) {
         if (t < 78) acc = pr_acc_two(s_buf, cnt, la, lb, 12 + la, 12 + lb, acc);
         __syncthreads();
     }
-    if (t < 78) {
+    if (t < 78 && !planar) {
         s_LL[la * 12 + lb] = acc;
         s_LL[lb * 12 + la] = acc;
     }
     __syncthreads();
-    if (t == 0) sm::pnp_dlt_finish(s_LL, s_param, s_ws);
+    if (t == 0 && !planar) sm::pnp_dlt_finish(s_LL, s_param, s_ws);
     __syncthreads();
     // ---- CvLevMarq(6 parameters, 2 np residuals, 20 iterations, FLT_EPSILON)
     int ja = 0, jb = 0;  // lane t < 21: JtJ entry (ja, jb)

@@ -64,6 +64,8 @@ int cv3_solve_pnp_ransac(const double* obj, const double* img, int n, const doub
 void cv3_solve_pnp_epnp_f32(const double* K, const float* obj, const float* img, int n, double* rvec, double* tvec);
 void cv3_epnp(const double* K, const double* pws, const double* us, int n, double* R_out, double* t_out);
 int cv3_find_extrinsic(const double* M, const double* m, int n, const double* K, double* rvec, double* tvec, int* stats);
+int cv3_find_extrinsic_guess(const double* M, const double* m, int n, const double* K, const double* planar_guess,
+                             double* rvec, double* tvec, int* stats);
 double cv3_det_sin(double x);
 double cv3_det_cos(double x);
 double cv3_det_acos(double x);

@@ -14,8 +14,9 @@
  *    double arithmetic, < 1 ulp from libm) instead of the platform libm;
  *  - CvLevMarq::step's lambda = exp(lambdaLg10 * log(10.)) is read from a table of the 33 possible values as
  *    glibc evaluates them (tests/test_oracle_pnp.py re-derives the table with math.exp).
- * One unimplemented branch: cvFindExtrinsicCameraParams2's planar initialisation (object points coplanar,
- * W[2]/W[1] < 1e-3) -- cv3_solve_pnp_ransac returns -2 when the final refinement meets it.
+ * One replaced branch: cvFindExtrinsicCameraParams2's planar initialisation (object points coplanar, W[2]/W[1] < 1e-3;
+ * OpenCV: homography of the in-plane coordinates) -- the LM then starts from the RANSAC model instead, see
+ * cv3_find_extrinsic_guess.
  */
 #include <float.h>
 #include <math.h>
@@ -838,6 +839,17 @@ static void lm_step(const double* JtJ, const double* JtErr, int lambdaLg10, cons
 /* cvFindExtrinsicCameraParams2(useExtrinsicGuess = false) on double points M [n][3], m [n][2].
  * Returns 1, or -2 for the (unimplemented) planar initialisation.  stats (optional): [0] LM iterations */
 int cv3_find_extrinsic(const double* M, const double* m, int n, const double* K, double* rvec, double* tvec, int* stats) {
+    return cv3_find_extrinsic_guess(M, m, n, K, NULL, rvec, tvec, stats);
+}
+
+/* as above; `planar_guess` (rvec | tvec, may be NULL) is the start of the Levenberg-Marquardt iteration when the object
+ * points are coplanar.  DEVIATION (documented in DESIGN.md section 4, made on the device as well): OpenCV initialises the
+ * planar case from a homography (cvFindHomography on the in-plane coordinates); this build starts the same LM from the
+ * model solvePnPRansac's RANSAC stage accepted (EPnP on five points, already within the inlier threshold of every
+ * inlier).  Both starts lie in the basin of the same reprojection minimum; the result is that minimum to the LM's
+ * termination tolerance (FLT_EPSILON relative parameter change), not bit-identical to OpenCV's iterate sequence. */
+int cv3_find_extrinsic_guess(const double* M, const double* m, int n, const double* K, const double* planar_guess,
+                             double* rvec, double* tvec, int* stats) {
     const double fx = K[0], fy = K[4], cx = K[2], cy = K[5], ifx = 1. / fx, ify = 1. / fy;
     double* mn = (double*)malloc(sizeof(double) * 2 * (size_t)n);
     for (int i = 0; i < n; i++) { /* cvUndistortPoints, no distortion, R = P = identity */
@@ -854,11 +866,14 @@ int cv3_find_extrinsic(const double* M, const double* m, int n, const double* K,
     mul_transposed_ata(M, n, 3, Mc, MM);
     svd_square_t(MM, 3, W, NULL, V);
     double param[6];
-    if (W[2] / W[1] < 1e-3 || n < 4) {
+    const int planar = W[2] / W[1] < 1e-3 || n < 4;
+    if (planar && !planar_guess) {
         free(mn);
         return -2;
     }
-    {
+    if (planar) {
+        for (int i = 0; i < 6; i++) param[i] = planar_guess[i];
+    } else {
         double* L = (double*)malloc(sizeof(double) * 24 * (size_t)n);
         for (int i = 0; i < n; i++) {
             double* Lr = L + i * 24;
@@ -1012,7 +1027,7 @@ int cv3_solve_pnp_ransac(const double* obj, const double* img, int n, const doub
                 for (int j = 0; j < 2; j++) ii[np * 2 + j] = ipoints[i * 2 + j];
                 np++;
             }
-        rc = cv3_find_extrinsic(oi, ii, np, K, rvec, tvec, NULL);
+        rc = cv3_find_extrinsic_guess(oi, ii, np, K, model, rvec, tvec, NULL);
         if (rc == 1)
             for (int i = 0; i < n; i++)
                 if (mask[i]) inliers[(*n_inliers)++] = i;

@@ -136,3 +136,54 @@ def test_pnp_tracker_class_pose(gpu):
     assert np.array_equal(state_hip, np_state())  # the global numpy stream advanced exactly as in the reference
     assert np.abs(res["pose"].pose - ref["pose"]).max() <= 1e-12  # Frobenius bar of the contract is 1e-4
     assert np.array_equal(res["kp1"], ref["kp1"]) and np.array_equal(res["kp2"], ref["kp2"])
+
+
+def planar_case(seed, h=376, w=1241, n=1200, relief=0.02):
+    """keypoints whose valid depths lie on the ground plane up to `relief` (relative; a road-only view): the inlier object
+    points of solvePnPRansac are coplanar in cvFindExtrinsicCameraParams2's sense (W[2] / W[1] ~ 1e-6 << 1e-3) and it takes
+    its planar branch.  With relief = 0 the five-point EPnP hypotheses themselves degenerate (OpenCV does not special-case
+    coplanar control points): the consensus set is a handful of points and the pose meaningless."""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    with np.errstate(divide="ignore"):
+        depth = np.where(yy > K[1, 2] + 12, 1.65 * K[1, 1] / (yy - K[1, 2]), 0.0)  # plane Y = 1.65
+    depth = depth * (1.0 + relief * np.sin(xx / 40.0) * np.cos(yy / 9.0))
+    pick = rng.choice(h * w, n, replace=False)
+    kp1 = np.stack([pick % w, pick // w], 1).astype(np.float64)
+    d = depth[kp1[:, 1].astype(int), kp1[:, 0].astype(int)]
+    d_safe = np.where(d > 0, d, 10.0)
+    X = np.stack([(kp1[:, 0] - K[0, 2]) / K[0, 0] * d_safe, (kp1[:, 1] - K[1, 2]) / K[1, 1] * d_safe, d_safe], 1)
+    rv = np.array([0.002, -0.01, 0.001])
+    th = np.linalg.norm(rv)
+    kx = rv / th
+    Kx = np.array([[0, -kx[2], kx[1]], [kx[2], 0, -kx[0]], [-kx[1], kx[0], 0]])
+    R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+    t = np.array([0.02, -0.01, 0.7])
+    Xc = X @ R.T + t
+    kp2 = np.stack([Xc[:, 0] / Xc[:, 2] * K[0, 0] + K[0, 2], Xc[:, 1] / Xc[:, 2] * K[1, 1] + K[1, 2]], 1)
+    kp2 += rng.normal(0, 0.15, kp2.shape)
+    return np.ascontiguousarray(kp1), np.ascontiguousarray(kp2), np.ascontiguousarray(depth), R, t
+
+
+@pytest.mark.parametrize("seed", [51, 52])
+def test_compute_pose_3d2d_coplanar_object_points(gpu, trk, seed):
+    """the planar case no longer aborts: the refinement starts from the accepted RANSAC model on both sides (documented
+    deviation from OpenCV's homography initialisation, oracle/cv3_pnp.c cv3_find_extrinsic_guess) -- device == oracle bit
+    for bit, and the pose is the right one"""
+    kp1, kp2, depth, R_true, t_true = planar_case(seed)
+    np.random.seed(99 + seed)
+    out, keep, state_after = run_hip(gpu, trk, kp1, kp2, depth)
+    np.random.seed(99 + seed)
+    ref = T.compute_pose_3d2d(kp1, kp2, depth, K, 0.0, 50.0, 5, 100, 1.0)
+    assert out.found == 1 and out.status != -2 and out.best_inliers == ref["best_inlier"] > 400
+    assert np.array_equal(np.array(out.R[:]).reshape(3, 3), ref["R"])
+    assert np.array_equal(np.array(out.tvec[:]).reshape(3, 1), ref["t"])
+    assert np.array_equal(state_after, np_state())
+    assert np.abs(ref["R"] - R_true).max() < 2e-3 and np.abs(ref["t"].ravel() - t_true).max() < 5e-2
+    # exactly coplanar points: degenerate EPnP hypotheses, a meaningless pose -- but no abort, and the same consensus size
+    kp1, kp2, depth, _, _ = planar_case(seed, relief=0.0)
+    np.random.seed(7 + seed)
+    out, keep, state_after = run_hip(gpu, trk, kp1, kp2, depth)
+    np.random.seed(7 + seed)
+    ref = T.compute_pose_3d2d(kp1, kp2, depth, K, 0.0, 50.0, 5, 100, 1.0)
+    assert out.status != -2 and out.n_filtered == len(ref["kp1"]) and np.array_equal(state_after, np_state())
