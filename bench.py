@@ -326,17 +326,21 @@ def main(argv=None):
                                "tflops": round(float(fl[i] / (ms[i] * 1e-3) / 1e12), 1)}
                               for i in np.argsort(-ms) if ln[i] > 0]}
     if roof is not None:
-        # HBM-side bytes per launch of that kernel from the committed rocprofv3 --pmc passes over this same command
-        # (tools/pmc_traffic.py: FETCH_SIZE x2 on gfx950 + WRITE_SIZE); None when no profile matches the kernel
+        # HBM-side bytes per launch of that kernel: hardware counters cannot be read from inside the process, so they come
+        # from the committed rocprofv3 --pmc passes over this same command (tools/r2_pmc.sh -> tools/pmc_traffic.py:
+        # FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes); None when no committed profile holds the kernel
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "r1z_pmc_bench.json")))["kernels"]
-            key = CFG_NAMES[dom].split(" ")[0].replace("conv_igemm_f32<", "conv_igemm_f32_kernel<").replace(
-                "conv_win3_f32<", "conv_win_f32_kernel<").replace("conv_win_f32<", "conv_win_f32_kernel<")
+            pmc_file = "r2b_pmc_bench.json"
+            prof = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["kernels"]
+            key = {19: "conv_win_f16s_kernel<"}.get(dom) or CFG_NAMES[dom].split(" ")[0].replace(
+                "conv_igemm_f32<", "conv_igemm_f32_kernel<").replace("conv_win3_f32<", "conv_win_f32_kernel<").replace(
+                "conv_win_f32<", "conv_win_f32_kernel<")
             cand = [k for k in prof if k.replace(" ", "").startswith(key.rstrip(">").replace(" ", ""))]
             if cand:
-                roof["traffic"] = round(prof[cand[0]]["hbm_bytes_per_dispatch"])
-                roof["traffic_unit"] = "bytes per launch (rocprofv3 PMC, profiles/r1z_pmc_bench.json)"
-        except (OSError, KeyError, ValueError):
+                nd = sum(prof[k]["dispatches"] for k in cand)
+                roof["traffic"] = round(sum(prof[k]["hbm_bytes_per_dispatch"] * prof[k]["dispatches"] for k in cand) / nd)
+                roof["traffic_unit"] = "bytes per launch, mean over %d profiled launches (rocprofv3 PMC, profiles/%s)" % (nd, pmc_file)
+        except (OSError, KeyError, ValueError, ZeroDivisionError):
             pass
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

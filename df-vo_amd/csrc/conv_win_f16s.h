@@ -66,59 +66,56 @@ __global__ __launch_bounds__(256, 2) void conv_win_f16s_kernel(const ConvParams 
     const int n0 = blockIdx.y * BN;
     const int nchunk0 = (p.G0 + 3) >> 2, nchunk1 = (p.G1 + 3) >> 2, nchunks = nchunk0 + nchunk1;
 
-    // window items of this thread: (pixel, 4-channel group within the chunk)
-    int w_off0[W_CNT], w_off1[W_CNT], w_lds[W_CNT];
-    bool w_ok[W_CNT];
-#pragma unroll
-    for (int r = 0; r < W_CNT; ++r) {
-        const int id = t + 256 * r;
-        const int px = id >> 2, q = id & 3;
-        const int wy = px / WW, wx = px - wy * WW;
-        int iy = ty0 - 1 + wy, ix = tx0 - 1 + wx;
-        bool v = id < W_ITEMS;
-        if (p.pad_mode == PAD_REFLECT) {
-            iy = reflect_idx(iy, p.H);
-            ix = reflect_idx(ix, p.W);
-        }
-        v = v && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        iy = iy < 0 ? 0 : (iy >= p.H ? p.H - 1 : iy);
-        ix = ix < 0 ? 0 : (ix >= p.W ? p.W - 1 : ix);
-        const int sh = p.up0;
-        w_off0[r] = (((n * (p.H >> sh) + (iy >> sh)) * (p.W >> sh) + (ix >> sh)) * p.cs0) + p.co0 + q * 4;
-        w_off1[r] = (((n * p.H + iy) * p.W + ix) * p.cs1) + p.co1 + q * 4;
-        w_ok[r] = v;
-        w_lds[r] = (px < WH * WW ? px : 0) * PS + q * 2;  // hi plane: dwords [0, 8), lo plane: [8, 16) of the pixel
-    }
+    // window items of this thread: (pixel, 4-channel group within the chunk).  Their addresses are recomputed at every chunk
+    // (a few dozen integer operations against 27 TC TR MFMAs) instead of living in 4 W_CNT registers for the whole kernel:
+    // the accumulators and the weight ring need the register file
     f32x4 rw[W_CNT];
-    bool rwv[W_CNT];
+    unsigned rwv = 0;  // bit r: item r holds real data (inside the image, channel group exists)
     auto load_window = [&](int c) {
         const bool s1 = c >= nchunk0;
         const int cg0 = s1 ? (c - nchunk0) * 4 : c * 4;
         const int Gs = s1 ? p.G1 : p.G0;
         const float* base = s1 ? p.src1 : p.src0;
+        const int sh = s1 ? 0 : p.up0;
+        const int cs = s1 ? p.cs1 : p.cs0, co = s1 ? p.co1 : p.co0;
+        rwv = 0;
 #pragma unroll
         for (int r = 0; r < W_CNT; ++r) {
-            const int q = (t + 256 * r) & 3;
-            const bool v = w_ok[r] && (cg0 + q) < Gs;
-            const int off = (s1 ? w_off1[r] : w_off0[r]) + (v ? cg0 * 4 : -(q * 4));  // masked lanes re-read channel 0
-            rw[r] = *reinterpret_cast<const f32x4*>(base + off);
-            rwv[r] = v;
+            const int id = t + 256 * r;
+            const int px = id >> 2, q = id & 3;
+            const int wy = px / WW, wx = px - wy * WW;
+            int iy = ty0 - 1 + wy, ix = tx0 - 1 + wx;
+            bool v = id < W_ITEMS && (cg0 + q) < Gs;
+            if (p.pad_mode == PAD_REFLECT) {
+                iy = reflect_idx(iy, p.H);
+                ix = reflect_idx(ix, p.W);
+            }
+            v = v && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            iy = iy < 0 ? 0 : (iy >= p.H ? p.H - 1 : iy);
+            ix = ix < 0 ? 0 : (ix >= p.W ? p.W - 1 : ix);
+            const int off = (((n * (p.H >> sh) + (iy >> sh)) * (p.W >> sh) + (ix >> sh)) * cs) + co + (v ? (cg0 + q) * 4 : 0);
+            rw[r] = *reinterpret_cast<const f32x4*>(base + off);  // masked lanes re-read channel group 0 of a valid pixel
+            rwv |= (v ? 1u : 0u) << r;
         }
     };
     auto store_window = [&](float* W) {
 #pragma unroll
-        for (int r = 0; r < W_CNT; ++r)
-            if (t + 256 * r < W_ITEMS) {
+        for (int r = 0; r < W_CNT; ++r) {
+            const int id = t + 256 * r;
+            if (id < W_ITEMS) {
                 h16x4 hi, lo;
-                split_f16_planes(rwv[r] ? rw[r] : f32x4{0.f, 0.f, 0.f, 0.f}, &hi, &lo);
-                *reinterpret_cast<h16x4*>(W + w_lds[r]) = hi;
-                *reinterpret_cast<h16x4*>(W + w_lds[r] + 8) = lo;
+                split_f16_planes(((rwv >> r) & 1u) ? rw[r] : f32x4{0.f, 0.f, 0.f, 0.f}, &hi, &lo);
+                float* dst = W + (id >> 2) * PS + (id & 3) * 2;  // hi plane: dwords [0, 8), lo plane: [8, 16) of the pixel
+                *reinterpret_cast<h16x4*>(dst) = hi;
+                *reinterpret_cast<h16x4*>(dst + 8) = lo;
             }
+        }
     };
     // weight fragments: row (cout) = lane & 31 of block tc, k-block = lane >> 5; 64 bytes per (tap, chunk, cout)
     const unsigned short* wbase = p.wf16 + ((size_t)(n0 + wc * TC * 32 + lp) * 32 + kb * 8);
     const size_t w_chunk_stride = (size_t)p.wf16_cout_pad * 32;  // halves per (tap, chunk)
-    h16x8 wa[2][TC][2];                                         // [register stage][cout block][plane]
+    h16x8 wa[2][TC][2];  // [register stage][cout block][plane]: fetched one tap ahead (a ring of three, two taps ahead, does
+                         // not fit: 128 accumulator + 48 ring + 16 pixel-fragment + window staging registers spill at 256)
     auto load_w = [&](int stage, int tap, int c) {
         const unsigned short* g = wbase + ((size_t)tap * nchunks + c) * w_chunk_stride;
 #pragma unroll
@@ -160,14 +157,22 @@ __global__ __launch_bounds__(256, 2) void conv_win_f16s_kernel(const ConvParams 
                 xb[j][0] = *reinterpret_cast<const h16x8*>(px);
                 xb[j][1] = *reinterpret_cast<const h16x8*>(px + 8);
             }
+            // the three product terms block by block per term: consecutive MFMAs never target the same accumulator
 #pragma unroll
             for (int i = 0; i < TC; ++i)
 #pragma unroll
-                for (int j = 0; j < TR; ++j) {
+                for (int j = 0; j < TR; ++j)
                     ax[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][i][0], xb[j][1], ax[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TR; ++j)
                     ax[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][i][1], xb[j][0], ax[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TR; ++j)
                     am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][i][0], xb[j][0], am[i][j], 0, 0, 0);
-                }
             if (tap == 4 && next_chunk) store_window(Wn);
         }
 #pragma unroll

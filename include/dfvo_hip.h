@@ -385,6 +385,11 @@ int dfvo_pipeline_set_rng_state(dfvo_pipeline* p, const uint32_t* h_state625);
 int dfvo_pipeline_sync(dfvo_pipeline* p);
 double dfvo_pipeline_net_flops(const dfvo_pipeline* p);
 
+/* Not exported here: the per-sequence pose all-gather of SURVEY.md section 8e ("dfvo_allgather_poses").  It moves 136
+ * bytes per frame once per chunk and runs through the process group the host already owns (torch.distributed: RCCL on
+ * GPUs, gloo in the CPU tests) -- df-vo_amd/dist.py:allgather_poses, df-vo_amd/sequence.py:run_sequence.  A C caller
+ * composes trajectories from dfvo_track_out exactly as dist.compose_trajectory does (dfvo.py:109-119,157-161). */
+
 #ifdef __cplusplus
 }
 #endif
