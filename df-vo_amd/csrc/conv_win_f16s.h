@@ -9,7 +9,7 @@
 // sets ("main" and "cross") that the epilogue combines as main + 2^-11 cross.  Against the exact fp32-MFMA path this
 // trades 16 K-passes of 64 FLOP/clk/SIMD for 3 passes of 1024 FLOP/clk/SIMD: 5.3x less matrix-pipe time.
 //
-// Tiling (wave64, 4 waves per workgroup): a workgroup owns TH rows x 32 columns of output pixels x BN output channels.
+// Tiling (wave64, 4 or 8 waves per workgroup): a workgroup owns TH rows x 32 columns of output pixels x BN output channels.
 // The (TH+2) x 34 input window of one 16-channel chunk is split into planes ONCE, when it is written to LDS
 // (padding / reflection / x2-upsample / two-source concat resolved at that load), pixel stride 80 bytes = 5 sixteen-byte
 // slots: the 16 lanes of every ds_read_b128 service group hit 16 distinct slots.  One MFMA contracts a whole chunk for a
@@ -41,13 +41,14 @@ __device__ __forceinline__ void split_f16_planes(f32x4 x, h16x4* hi, h16x4* lo) 
 }
 
 template <int WC, int WR, int TC, int TR>
-__global__ __launch_bounds__(256, 2) void conv_win_f16s_kernel(const ConvParams p) {
+__global__ __launch_bounds__(64 * WC * WR, 2) void conv_win_f16s_kernel(const ConvParams p) {
+    constexpr int NT = 64 * WC * WR;  // 4 or 8 waves per workgroup
     constexpr int TH = WR * TR, TW = 32, WH = TH + 2, WW = TW + 2, PS = 20;  // pixel stride in dwords (80 bytes)
     constexpr int BN = WC * TC * 32;
     constexpr int WIN = WH * WW * PS;  // dwords per window buffer
     constexpr int W_ITEMS = WH * WW * 4;
-    constexpr int W_CNT = (W_ITEMS + 255) / 256;
-    static_assert(WC * WR == 4, "4 waves per block");
+    constexpr int W_CNT = (W_ITEMS + NT - 1) / NT;
+    static_assert(WC * WR == 4 || WC * WR == 8, "4 or 8 waves per block");
     __shared__ __attribute__((aligned(16))) float lds[2 * WIN];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -65,6 +66,7 @@ __global__ __launch_bounds__(256, 2) void conv_win_f16s_kernel(const ConvParams 
     const int ty0 = (trem / tiles_x) * TH, tx0 = (trem % tiles_x) * TW;
     const int n0 = blockIdx.y * BN;
     const int nchunk0 = (p.G0 + 3) >> 2, nchunk1 = (p.G1 + 3) >> 2, nchunks = nchunk0 + nchunk1;
+    const bool nt = p.force_splits == -7;  // (experiment switch, see launch_f16s)
 
     // window items of this thread: (pixel, 4-channel group within the chunk).  Their addresses are recomputed at every chunk
     // (a few dozen integer operations against 27 TC TR MFMAs) instead of living in 4 W_CNT registers for the whole kernel:
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256, 2) void conv_win_f16s_kernel(const ConvParams 
         rwv = 0;
 #pragma unroll
         for (int r = 0; r < W_CNT; ++r) {
-            const int id = t + 256 * r;
+            const int id = t + NT * r;
             const int px = id >> 2, q = id & 3;
             const int wy = px / WW, wx = px - wy * WW;
             int iy = ty0 - 1 + wy, ix = tx0 - 1 + wx;
@@ -94,14 +96,17 @@ __global__ __launch_bounds__(256, 2) void conv_win_f16s_kernel(const ConvParams 
             iy = iy < 0 ? 0 : (iy >= p.H ? p.H - 1 : iy);
             ix = ix < 0 ? 0 : (ix >= p.W ? p.W - 1 : ix);
             const int off = (((n * (p.H >> sh) + (iy >> sh)) * (p.W >> sh) + (ix >> sh)) * cs) + co + (v ? (cg0 + q) * 4 : 0);
-            rw[r] = *reinterpret_cast<const f32x4*>(base + off);  // masked lanes re-read channel group 0 of a valid pixel
+            // masked lanes re-read channel group 0 of a valid pixel.  Streaming (non-temporal) policy: the activations pass
+            // through once, the layer's weights are re-read by every workgroup and should keep the L2
+            rw[r] = nt ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + off))
+                       : *reinterpret_cast<const f32x4*>(base + off);
             rwv |= (v ? 1u : 0u) << r;
         }
     };
     auto store_window = [&](float* W) {
 #pragma unroll
         for (int r = 0; r < W_CNT; ++r) {
-            const int id = t + 256 * r;
+            const int id = t + NT * r;
             if (id < W_ITEMS) {
                 h16x4 hi, lo;
                 split_f16_planes(((rwv >> r) & 1u) ? rw[r] : f32x4{0.f, 0.f, 0.f, 0.f}, &hi, &lo);
@@ -150,6 +155,9 @@ __global__ __launch_bounds__(256, 2) void conv_win_f16s_kernel(const ConvParams 
                 load_w(cur ^ 1, tap + 1, c);
             else if (next_chunk)
                 load_w(1, 0, c + 1);  // tap 8 runs from stage 0: the next chunk's first fragments land in stage 1 ...
+            // keep the fetch HERE: left alone, the scheduler sinks these loads below the tap's last MFMA (it then needs one
+            // register set instead of two) and the L2 round trip is exposed at every tap -- measured 30 % matrix-pipe busy
+            __builtin_amdgcn_sched_barrier(0);
             h16x8 xb[TR][2];
 #pragma unroll
             for (int j = 0; j < TR; ++j) {
@@ -234,7 +242,7 @@ static int launch_f16s_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) 
         pe.cfg = cfg_id;
         DFVO_HIP_CHECK(hipEventRecord(pe.e0, stream));
     }
-    hipLaunchKernelGGL((conv_win_f16s_kernel<WC, WR, TC, TR>), grid, dim3(256), 0, stream, p);
+    hipLaunchKernelGGL((conv_win_f16s_kernel<WC, WR, TC, TR>), grid, dim3(64 * WC * WR), 0, stream, p);
     DFVO_HIP_CHECK(hipGetLastError());
     if (g_prof) {
         DFVO_HIP_CHECK(hipEventRecord(pe.e1, stream));
@@ -246,14 +254,28 @@ static int launch_f16s_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) 
     return DFVO_OK;
 }
 
-// Tile choice: the largest tile whose grid still fills the chip (256 CUs x 2 resident workgroups); small maps (pyramid
-// levels 4 .. 6, the depth net's inner layers) fall back to narrower cout blocks / fewer rows so that more CUs get work:
-//   A 128 couts x (4 x 32) px   B 64 x (8 x 32)   C 64 x (4 x 32)   D 32 x (8 x 32)   E 32 x (4 x 32)
-static int launch_f16s(const ConvParams& p, hipStream_t stream, int cfg_id) {
+// Tile choice: the largest tile whose grid still fills the chip; small maps (pyramid level 4, the depth net's outer layers)
+// fall back to narrower cout blocks / fewer rows so that more CUs get work:
+//   A' 128 couts x (4 x 32) px, waves 4 x 1   A 128 x (4 x 32), waves 2 x 2   B 64 x (8 x 32)   C 64 x (4 x 32)
+//   D 32 x (8 x 32)   E 32 x (4 x 32)   (F / G: 8-wave tiles with twice the rows, opt-in)
+static int launch_f16s(const ConvParams& p_in, hipStream_t stream, int cfg_id) {
+    ConvParams p = p_in;
+    static const int nt_mode = getenv("DFVO_F16S_NT") ? atoi(getenv("DFVO_F16S_NT")) : 0;
+    p.force_splits = nt_mode ? -7 : 0;  // force_splits is unused by this kernel: carries the streaming-load experiment switch
     static const long long fill = getenv("DFVO_F16S_FILL") ? atoll(getenv("DFVO_F16S_FILL")) : 400;
+    // 8-wave tiles (twice the pixels per workgroup = half the weight re-reads from L2): measured neutral, off by default
+    static const long long fill8 = getenv("DFVO_F16S_FILL8") ? atoll(getenv("DFVO_F16S_FILL8")) : (1LL << 40);
+    const long long f = f16s_blocks<2, 4, 2, 2>(p), g = f16s_blocks<1, 8, 2, 2>(p);
     const long long a = f16s_blocks<2, 2, 2, 2>(p), b = f16s_blocks<1, 4, 2, 2>(p), c = f16s_blocks<2, 2, 1, 2>(p),
                     d = f16s_blocks<1, 4, 1, 2>(p);
+    // 128-cout layers: one 32-cout block per wave x four rows (A').  Every weight fragment is then fetched by exactly one wave
+    // (the 2 x 2 arrangement loads each fragment twice); the pixel fragments, read from LDS, are the shared operand: +6 %.
+    // (DFVO_F16S_VARIANT=0 restores the 2 x 2 arrangement.)
+    static const int variant = getenv("DFVO_F16S_VARIANT") ? atoi(getenv("DFVO_F16S_VARIANT")) : 1;
+    if (variant == 1 && f16s_blocks<4, 1, 1, 4>(p) >= fill) return launch_f16s_cfg<4, 1, 1, 4>(p, stream, cfg_id);
+    if (f >= fill8) return launch_f16s_cfg<2, 4, 2, 2>(p, stream, cfg_id);
     if (a >= fill) return launch_f16s_cfg<2, 2, 2, 2>(p, stream, cfg_id);
+    if (g >= fill8) return launch_f16s_cfg<1, 8, 2, 2>(p, stream, cfg_id);
     if (b >= fill) return launch_f16s_cfg<1, 4, 2, 2>(p, stream, cfg_id);
     if (c >= fill) return launch_f16s_cfg<2, 2, 1, 2>(p, stream, cfg_id);
     if (d >= fill) return launch_f16s_cfg<1, 4, 1, 2>(p, stream, cfg_id);
