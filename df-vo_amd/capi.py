@@ -39,7 +39,8 @@ class Pose2d2dOut(C.Structure):
 
 class ScaleCfg(C.Structure):
     _fields_ = [("cx", C.c_double), ("cy", C.c_double), ("fx", C.c_double), ("fy", C.c_double),
-                ("min_samples", C.c_int), ("max_trials", C.c_int), ("stop_prob", C.c_double), ("thre", C.c_double)]
+                ("min_samples", C.c_int), ("max_trials", C.c_int), ("stop_prob", C.c_double), ("thre", C.c_double),
+                ("method", C.c_int)]
 
 
 class Pose3d2dCfg(C.Structure):
@@ -104,6 +105,7 @@ SIGNATURES = {
     "dfvo_split_bf16_planes": (_i, [_vp, _i, _i, _vp]),
     "dfvo_lanczos_coeffs": (_i, [_i, _i, _vp, _vp, _i, _ip]),
     "dfvo_resize_lanczos_u8": (_i, [_vp, _i, _i, _vp, _i, _i, _vp]),
+    "dfvo_resize_linear_u8": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp]),
     "dfvo_resize_bilinear": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "dfvo_flownet_create": (_i, [_i, _i, _vp, C.POINTER(_vp)]),
     "dfvo_flownet_destroy": (None, [_vp]),
@@ -138,6 +140,7 @@ SIGNATURES = {
     "dfvo_tracker_set_rng_state": (_i, [_vp, _vp]),
     "dfvo_tracker_get_rng_state": (_i, [_vp, _vp]),
     "dfvo_kp_local_bestn": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _ip, _ip]),
+    "dfvo_kp_local_bestn_ex": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _ip, _ip]),
     "dfvo_kp_sampled": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
     "dfvo_kp_bestn": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "dfvo_kp_rigid_flow": (_i, [_vp, _vp, _vp, _vp, _i, _i, C.POINTER(RigidKpCfg), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

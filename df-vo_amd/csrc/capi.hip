@@ -411,6 +411,9 @@ int dfvo_resize_lanczos_u8(const uint8_t* d_src, int H, int W, uint8_t* d_dst, i
     DFVO_HIP_CHECK(e);
     return DFVO_OK;
 }
+int dfvo_resize_linear_u8(const uint8_t* d_src, int H, int W, int C, uint8_t* d_dst, int out_h, int out_w, void* stream) {
+    return enqueue_resize_linear_u8(d_src, H, W, C, d_dst, out_h, out_w, (hipStream_t)stream);
+}
 double dfvo_depthnet_last_flops(const dfvo_depthnet* n) { return n ? n->net.flops_last : 0.0; }
 int dfvo_depthnet_sync(dfvo_depthnet* n) {
     DFVO_ARG_CHECK(n, "null net");

@@ -182,8 +182,17 @@ int dfvo_tracker_get_rng_state(dfvo_tracker* t, uint32_t* h) {
 int dfvo_kp_local_bestn(dfvo_tracker* t, const float* h_flow, const float* h_diff, int H, int W, int num_row,
                         int num_col, int num_bestN, float thre, double* h_kp1, double* h_kp2, int* n_out,
                         int* good_kp_found) {
+    return dfvo_kp_local_bestn_ex(t, h_flow, h_diff, H, W, num_row, num_col, num_bestN, thre, DFVO_KP_SCORE_FLOW, h_kp1, h_kp2,
+                                  n_out, good_kp_found);
+}
+
+int dfvo_kp_local_bestn_ex(dfvo_tracker* t, const float* h_flow, const float* h_diff, int H, int W, int num_row,
+                           int num_col, int num_bestN, float thre, int score_method, double* h_kp1, double* h_kp2,
+                           int* n_out, int* good_kp_found) {
     DFVO_ARG_CHECK(t && h_flow && h_diff && h_kp1 && h_kp2 && n_out && good_kp_found && H > 0 && W > 0,
                    "dfvo_kp_local_bestn: bad argument");
+    DFVO_ARG_CHECK(score_method == DFVO_KP_SCORE_FLOW || score_method == DFVO_KP_SCORE_FLOW_RATIO,
+                   "dfvo_kp_local_bestn_ex: score_method must be DFVO_KP_SCORE_FLOW or DFVO_KP_SCORE_FLOW_RATIO");
     const size_t px = (size_t)H * W;
     if (px > t->flow_cap) {
         if (t->d_flow) (void)hipFree(t->d_flow);
@@ -194,7 +203,7 @@ int dfvo_kp_local_bestn(dfvo_tracker* t, const float* h_flow, const float* h_dif
     }
     DFVO_HIP_CHECK(hipMemcpyAsync(t->d_flow, h_flow, sizeof(float) * 2 * px, hipMemcpyHostToDevice, t->stream));
     DFVO_HIP_CHECK(hipMemcpyAsync(t->d_diff, h_diff, sizeof(float) * px, hipMemcpyHostToDevice, t->stream));
-    int rc = enqueue_local_bestn(t->tb, t->d_flow, t->d_diff, H, W, num_row, num_col, num_bestN, thre, t->stream);
+    int rc = enqueue_local_bestn(t->tb, t->d_flow, t->d_diff, H, W, num_row, num_col, num_bestN, thre, t->stream, score_method);
     if (rc != DFVO_OK) return rc;
     int info[3];
     DFVO_HIP_CHECK(hipMemcpyAsync(info, t->tb.kp_info, sizeof(info), hipMemcpyDeviceToHost, t->stream));
@@ -367,7 +376,8 @@ int dfvo_compute_pose_2d2d(dfvo_tracker* t, const double* h_kp_ref, const double
         pc.KinvT[i] = cfg->KinvT[i];
         pc.Kinv[i] = cfg->Kinv[i];
     }
-    DFVO_ARG_CHECK(cfg->validity_method == DFVO_VALIDITY_GRIC || cfg->validity_method == DFVO_VALIDITY_FLOW,
+    DFVO_ARG_CHECK(cfg->validity_method == DFVO_VALIDITY_GRIC || cfg->validity_method == DFVO_VALIDITY_FLOW ||
+                       cfg->validity_method == DFVO_VALIDITY_HOMO_RATIO,
                    "dfvo_compute_pose_2d2d: unknown validity_method");
     pc.validity = cfg->validity_method;
     pc.validity_thre = cfg->validity_thre;
@@ -382,7 +392,7 @@ int dfvo_compute_pose_2d2d(dfvo_tracker* t, const double* h_kp_ref, const double
     out->n = ps.n;
     out->best_inlier_cnt = ps.best_cnt;
     out->num_valid = ps.num_valid;
-    out->major_valid = (cfg->validity_method == DFVO_VALIDITY_FLOW ? n >= 5 : n > 10) ? ps.major_valid : 0;
+    out->major_valid = (cfg->validity_method == DFVO_VALIDITY_GRIC ? n > 10 : n >= 5) ? ps.major_valid : 0;
     out->cheirality = ps.cheirality;
     out->h_found = ps.h_found;
     out->h_gric = ps.h_gric;
@@ -419,6 +429,9 @@ int dfvo_find_scale_from_depth(dfvo_tracker* t, const double* h_kp1, const doubl
     sc.max_trials = cfg->max_trials;
     sc.stop_prob = cfg->stop_prob;
     sc.thre = cfg->thre;
+    DFVO_ARG_CHECK(cfg->method == DFVO_SCALE_DEPTH_RATIO || cfg->method == DFVO_SCALE_ABS_DIFF,
+                   "dfvo_find_scale_from_depth: unknown method");
+    sc.method = cfg->method;
     rc = enqueue_find_scale(t->tb, n, t->d_small, t->d_depth, H, W, sc, t->stream);
     if (rc != DFVO_OK) return rc;
     ScaleResult sr;

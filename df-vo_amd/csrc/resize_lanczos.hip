@@ -165,4 +165,62 @@ int LanczosResizer::enqueue(const uint8_t* d_src, uint8_t* d_dst, hipStream_t s)
     return DFVO_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// cv2.resize(img, (w, h)) of the loaded uint8 frame (/root/reference/libs/general/utils.py:51; default INTER_LINEAR).
+// OpenCV 3.4.3 imgproc/src/resize.cpp (third party, restated): scale = 1 / (dst / src); coefficient per output sample
+// f = float((d + 0.5) * scale - 0.5), s = floor(f), f -= s, 11-bit fixed point saturate_cast<short>((1 - f, f) * 2048)
+// (half to even); columns clamp to (0, f = 0) / (W - 1, f = 0), rows clip to [0, H - 1] keeping their weights;
+// horizontal S[s] a0 + S[s + 1] a1 in int, vertical (((b0 (r0 >> 4)) >> 16) + ((b1 (r1 >> 4)) >> 16) + 2) >> 2.
+// Exact 2 x 2 decimation takes INTER_AREA's fast path (a + b + c + d + 2) >> 2.  One thread per output pixel: the
+// coefficients cost a handful of instructions, so no tables are kept; HBM-bound (reads <= 4 source pixels per output,
+// neighbouring threads share them through L1/L2).
+__device__ __forceinline__ void linear_coef_u8(int d, double scale, int* s_out, int* c0, int* c1, float* f_out) {
+    float f = (float)__dsub_rn(__dmul_rn((double)d + 0.5, scale), 0.5);
+    const int s = (int)floorf(f);
+    f = __fsub_rn(f, (float)s);
+    *s_out = s;
+    *f_out = f;
+    *c0 = (int)rintf(__fmul_rn(__fsub_rn(1.f, f), 2048.f));
+    *c1 = (int)rintf(__fmul_rn(f, 2048.f));
+}
+
+__global__ __launch_bounds__(256) void k_resize_linear_u8(const uint8_t* __restrict__ src, int H, int W, int C,
+                                                           uint8_t* __restrict__ dst, int oh, int ow, double scale_x,
+                                                           double scale_y, int area2) {
+    const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y * blockDim.y + threadIdx.y;
+    if (dx >= ow || dy >= oh) return;
+    uint8_t* o = dst + ((size_t)dy * ow + dx) * C;
+    if (area2) {
+        const uint8_t* p = src + ((size_t)(2 * dy) * W + 2 * dx) * C;
+        const size_t row = (size_t)W * C;
+        for (int c = 0; c < C; ++c) o[c] = (uint8_t)((p[c] + p[C + c] + p[row + c] + p[row + C + c] + 2) >> 2);
+        return;
+    }
+    int sx, a0, a1, sy, b0, b1;
+    float f;
+    linear_coef_u8(dx, scale_x, &sx, &a0, &a1, &f);
+    if (sx < 0) sx = 0, a0 = 2048, a1 = 0;
+    if (sx >= W - 1) sx = W - 1, a0 = 2048, a1 = 0;
+    linear_coef_u8(dy, scale_y, &sy, &b0, &b1, &f);
+    const int y0 = sy < 0 ? 0 : (sy < H ? sy : H - 1), y1 = sy + 1 < 0 ? 0 : (sy + 1 < H ? sy + 1 : H - 1);
+    const int sx1 = sx + 1 < W ? sx + 1 : sx;
+    const uint8_t *r0 = src + (size_t)y0 * W * C, *r1 = src + (size_t)y1 * W * C;
+    for (int c = 0; c < C; ++c) {
+        const int h0 = r0[sx * C + c] * a0 + r0[sx1 * C + c] * a1;
+        const int h1 = r1[sx * C + c] * a0 + r1[sx1 * C + c] * a1;
+        o[c] = (uint8_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
+    }
+}
+
+int enqueue_resize_linear_u8(const uint8_t* d_src, int H, int W, int C, uint8_t* d_dst, int oh, int ow, hipStream_t s) {
+    DFVO_ARG_CHECK(d_src && d_dst && H > 0 && W > 0 && oh > 0 && ow > 0 && C >= 1 && C <= 4, "resize_linear_u8: bad argument");
+    volatile double inv_x = (double)ow / (double)W, inv_y = (double)oh / (double)H;  // cv::resize: inv_scale = dsize / ssize
+    const double scale_x = 1.0 / inv_x, scale_y = 1.0 / inv_y;                       // hal::resize: scale = 1 / inv_scale
+    const int area2 = (std::fabs(scale_x - 2.0) < 2.220446049250313e-16 && std::fabs(scale_y - 2.0) < 2.220446049250313e-16) ? 1 : 0;
+    hipLaunchKernelGGL(k_resize_linear_u8, dim3(cdiv(ow, 64), cdiv(oh, 4)), dim3(64, 4), 0, s, d_src, H, W, C, d_dst, oh, ow,
+                       scale_x, scale_y, area2);
+    DFVO_HIP_CHECK(hipGetLastError());
+    return DFVO_OK;
+}
+
 }  // namespace dfvo

@@ -30,6 +30,11 @@ __device__ __forceinline__ int wave_sum_i(int v) {
     return v;
 }
 
+__device__ __forceinline__ double wave_sum_d(double v) {
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
 // ================================================================================================
 // keypoint selection
 // ================================================================================================
@@ -706,8 +711,18 @@ int enqueue_kp_sampled(const float* d_flow, int H, int W, int y0, int y1, int x0
     return DFVO_OK;
 }
 
+// score_method 'flow_ratio' (kp_selection.py:137-141,155): mask and score are flow_diff / |flow| per pixel, float32 as numpy
+// evaluates it -- np.linalg.norm over the 2-vector = sqrt(x*x + y*y) with separately rounded products and sum
+__global__ void k_flow_ratio(const float* __restrict__ flow, const float* __restrict__ diff, int px, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= px) return;
+    const float fx = flow[i], fy = flow[px + i];
+    const float xx = __fmul_rn(fx, fx), yy = __fmul_rn(fy, fy);
+    out[i] = __fdiv_rn(diff[i], __fsqrt_rn(__fadd_rn(xx, yy)));
+}
+
 int enqueue_local_bestn(TrackerBuffers& tb, const float* d_flow, const float* d_diff, int H, int W, int num_row,
-                        int num_col, int num_bestN, float thre, hipStream_t s) {
+                        int num_col, int num_bestN, float thre, hipStream_t s, int score_method) {
     const int cells = num_row * num_col;
     DFVO_ARG_CHECK(cells > 0 && cells <= 1024 && H < 65536 && W < 65536, "local_bestN: grid too large");
     const int n_best = num_bestN / cells;  // math.floor(N / (rows*cols))
@@ -729,7 +744,17 @@ int enqueue_local_bestn(TrackerBuffers& tb, const float* d_flow, const float* d_
     if (int rc_lds = ensure_dyn_lds((const void*)k_kp_cell, lds)) return rc_lds;
     DFVO_HIP_CHECK(hipMemsetAsync(tb.kp_total, 0, sizeof(int), s));
     hipLaunchKernelGGL(k_kp_count, dim3(cdiv(H * W, 256)), dim3(256), 0, s, d_diff, H * W, thre, tb.kp_total);
-    hipLaunchKernelGGL(k_kp_cell, dim3(cells), dim3(256), lds, s, d_diff, H, W, num_row, num_col, thre, n_best, cap,
+    const float* d_key = d_diff;  // what the cells threshold and rank: the consistency map, or its ratio to the flow magnitude
+    if (score_method == 1) {
+        if ((size_t)H * W > tb.ratio_cap) {
+            if (tb.ratio_map) (void)hipFree(tb.ratio_map);
+            tb.ratio_cap = (size_t)H * W;
+            DFVO_HIP_CHECK(hipMalloc((void**)&tb.ratio_map, sizeof(float) * tb.ratio_cap));
+        }
+        hipLaunchKernelGGL(k_flow_ratio, dim3(cdiv(H * W, 256)), dim3(256), 0, s, d_flow, d_diff, H * W, tb.ratio_map);
+        d_key = tb.ratio_map;
+    }
+    hipLaunchKernelGGL(k_kp_cell, dim3(cells), dim3(256), lds, s, d_key, H, W, num_row, num_col, thre, n_best, cap,
                        tb.cell_count, tb.cell_sel, tb.lidx, par);
     // thresholds exactly as the python float comparisons: count < N*0.1 ; regions < rows*cols*0.1
     const int min_total = (int)ceil((double)num_bestN * 0.1);
@@ -1193,12 +1218,19 @@ struct RepBatch {
 __global__ __launch_bounds__(256) void k_rep_update_all(PoseState* ps, const RansacState* hst, const double* __restrict__ h_gric,
                                                          const RepBatch B, const double* __restrict__ e_gric,
                                                          const int* __restrict__ perm, int perm_stride,
-                                                         uint8_t* __restrict__ best_inliers, int repeat) {
+                                                         uint8_t* __restrict__ best_inliers, int repeat,
+                                                         int by_ratio, double ratio_thre) {
+    // by_ratio (validity.method 'homo_ratio', E_tracker.py:186-194,243-250): a repeat is valid while
+    // H_inliers.sum() / (H_inliers.sum() + inliers.sum()) < thre (0 / 0 = nan compares false, like numpy);
+    // h_gric then carries the homography's inlier count and rep_gric[] the ratios
     __shared__ int s_take;
     const int n = ps->n;
     if (threadIdx.x == 0) {
         ps->h_found = hst->found;
-        ps->h_gric = hst->found ? *h_gric : INFINITY;
+        if (by_ratio)
+            ps->h_gric = hst->found ? (double)hst->max_good : 0.0;  // no model: OpenCV returns an all-zero mask
+        else
+            ps->h_gric = hst->found ? *h_gric : INFINITY;
     }
     __syncthreads();
     for (int rep = 0; rep < repeat; ++rep) {
@@ -1206,10 +1238,18 @@ __global__ __launch_bounds__(256) void k_rep_update_all(PoseState* ps, const Ran
             const RansacState* est = B.st[rep];
             const int found = est->found;
             const int cnt = found ? est->max_good : 0;
-            const bool valid = found && (ps->h_gric > e_gric[rep]);
+            bool valid;
+            double crit;
+            if (by_ratio) {
+                crit = ps->h_gric / (ps->h_gric + (double)cnt);
+                valid = crit < ratio_thre;
+            } else {
+                crit = found ? e_gric[rep] : INFINITY;
+                valid = found && (ps->h_gric > e_gric[rep]);
+            }
             ps->rep_cnt[rep] = cnt;
             ps->rep_valid[rep] = valid ? 1 : 0;
-            ps->rep_gric[rep] = found ? e_gric[rep] : INFINITY;
+            ps->rep_gric[rep] = crit;
             ps->num_valid += valid ? 1 : 0;
             s_take = (found && cnt > ps->best_cnt) ? 1 : 0;
             if (s_take) {
@@ -1333,7 +1373,8 @@ __global__ void k_scale_triangulate(const int* __restrict__ n_ptr, const double*
 __global__ __launch_bounds__(256) void k_scale_ratios(const int* __restrict__ n_ptr, const double* __restrict__ z2,
                                                        const int* __restrict__ pix, const int* __restrict__ winner,
                                                        const double* __restrict__ depth, double* __restrict__ ratios,
-                                                       int* __restrict__ n_valid) {
+                                                       int* __restrict__ n_valid, double* __restrict__ tri_list,
+                                                       double* __restrict__ pred_list) {
     // single block: n <= a few thousand.  rank = number of valid entries with a smaller pixel index.
     extern __shared__ int s_pix[];
     const int n = *n_ptr;
@@ -1356,6 +1397,10 @@ __global__ __launch_bounds__(256) void k_scale_ratios(const int* __restrict__ n_
         int rank = 0;
         for (int j = 0; j < n; j++) rank += (s_pix[j] >= 0 && s_pix[j] < p) ? 1 : 0;
         ratios[rank] = z2[i] / depth[p];
+        if (tri_list) {  // ransac.method 'abs_diff': the regression runs on the two depths themselves
+            tri_list[rank] = z2[i];
+            pred_list[rank] = depth[p];
+        }
         local++;
     }
     const int s = wave_sum_i(local);
@@ -1364,8 +1409,11 @@ __global__ __launch_bounds__(256) void k_scale_ratios(const int* __restrict__ n_
 
 // sklearn RANSACRegressor(LinearRegression(fit_intercept=False), min_samples, max_trials, stop_probability,
 // residual_threshold).fit(ratio.reshape(-1,1), ones) -> estimator_.coef_[0,0]; one 256-thread block.
+// yv != nullptr (ransac.method 'abs_diff', E_tracker.py:631-635): .fit(depth_tri, depth_pred) -- the same loop with a
+// general target: least squares through the origin sum(xy)/sum(xx), residual |y - x coef|, and the tie-break score is
+// the real r2_score of the inlier set (1 - ss_res / ss_tot; constant target: 1 when ss_res == 0, else 0).
 __global__ __launch_bounds__(256) void k_scale_ransac(uint32_t* __restrict__ mt_state, const double* __restrict__ x,
-                                                       const int* __restrict__ n_valid, int min_valid, int min_samples,
+                                                       const double* __restrict__ yv, const int* __restrict__ n_valid, int min_valid, int min_samples,
                                                        int max_trials, double stop_prob, double thr,
                                                        uint8_t* __restrict__ inl_a, uint8_t* __restrict__ inl_b,
                                                        int* __restrict__ scratch, ScaleResult* __restrict__ out,
@@ -1373,6 +1421,7 @@ __global__ __launch_bounds__(256) void k_scale_ransac(uint32_t* __restrict__ mt_
     __shared__ sm::Mt19937 s;
     __shared__ double s_coef;
     __shared__ int s_cnt[4], s_nz[4];
+    __shared__ double s_red[3][4];
     __shared__ int s_ctl;  // 0 continue, 1 stop
     __shared__ int s_best_is_a;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -1406,7 +1455,7 @@ __global__ __launch_bounds__(256) void k_scale_ransac(uint32_t* __restrict__ mt_
             // LinearRegression(fit_intercept=False) on (x_subset, ones): least squares through the origin
             double sx = 0, sxx = 0;
             for (int k = 0; k < min_samples; k++) {
-                sx += x[idx[k]];
+                sx += x[idx[k]] * (yv ? yv[idx[k]] : 1.0);
                 sxx += x[idx[k]] * x[idx[k]];
             }
             s_coef = sx / sxx;
@@ -1415,27 +1464,54 @@ __global__ __launch_bounds__(256) void k_scale_ransac(uint32_t* __restrict__ mt_
         const double coef = s_coef;
         uint8_t* cur = best_is_a ? inl_b : inl_a;  // write the candidate mask into the non-best buffer
         int c = 0, nz = 0;
+        double sy = 0;
         for (int i = t; i < n; i += 256) {
             const double pred = x[i] * coef;
-            const double r = fabs(1.0 - pred);
+            const double yi = yv ? yv[i] : 1.0;
+            const double r = fabs(yi - pred);
             const int f = r <= thr ? 1 : 0;
             cur[i] = (uint8_t)f;
             c += f;
-            nz += (f && (1.0 - pred) != 0.0) ? 1 : 0;  // r2_score numerator != 0 on the inlier set
+            nz += (f && (yi - pred) != 0.0) ? 1 : 0;  // r2_score numerator != 0 on the inlier set
+            if (f) sy += yi;
         }
         c = wave_sum_i(c);
         nz = wave_sum_i(nz);
+        if (yv) sy = wave_sum_d(sy);
         if (lane == 0) {
             s_cnt[wave] = c;
             s_nz[wave] = nz;
+            s_red[0][wave] = sy;
         }
         __syncthreads();
         const int n_in = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
         const int nzs = s_nz[0] + s_nz[1] + s_nz[2] + s_nz[3];
+        const double mean_y = (s_red[0][0] + s_red[0][1] + s_red[0][2] + s_red[0][3]) / (double)n_in;
         __syncthreads();
         if (n_in < n_inliers_best) continue;  // n_skips_no_inliers_
         // r2_score with constant y_true: 1.0 when the residual sum is zero, else 0.0
-        const double score = nzs == 0 ? 1.0 : 0.0;
+        double score = nzs == 0 ? 1.0 : 0.0;
+        if (yv) {
+            double res = 0, tot = 0;
+            for (int i = t; i < n; i += 256)
+                if (cur[i]) {
+                    const double d = yv[i] - x[i] * coef, e = yv[i] - mean_y;
+                    res += d * d;
+                    tot += e * e;
+                }
+            res = wave_sum_d(res);
+            tot = wave_sum_d(tot);
+            if (lane == 0) {
+                s_red[1][wave] = res;
+                s_red[2][wave] = tot;
+            }
+            __syncthreads();
+            res = s_red[1][0] + s_red[1][1] + s_red[1][2] + s_red[1][3];
+            tot = s_red[2][0] + s_red[2][1] + s_red[2][2] + s_red[2][3];
+            __syncthreads();
+            if (tot != 0.0) score = 1.0 - res / tot;  // else: the constant-target rule above (force_finite)
+        }
+        if (n_in < 2) score = NAN;  // r2_score of fewer than two samples: nan, which loses no comparison below
         if (n_in == n_inliers_best && score < score_best) continue;
         n_inliers_best = n_in;
         score_best = score;
@@ -1468,7 +1544,7 @@ __global__ __launch_bounds__(256) void k_scale_ransac(uint32_t* __restrict__ mt_
             double sx = 0, sxx = 0;
             for (int i = 0; i < n; i++)
                 if (best[i]) {
-                    sx += x[i];
+                    sx += x[i] * (yv ? yv[i] : 1.0);
                     sxx += x[i] * x[i];
                 }
             scale = sx / sxx;
@@ -1509,7 +1585,7 @@ int TrackerBuffers::ensure_kp(int cap, int cells, int n_best) {
     DFVO_HIP_CHECK(hipMalloc((void**)&cell_sel, sizeof(int) * sel_cap));
     DFVO_HIP_CHECK(hipMalloc((void**)&z2, sizeof(double) * kp_cap));
     DFVO_HIP_CHECK(hipMalloc((void**)&pix, sizeof(int) * kp_cap));
-    DFVO_HIP_CHECK(hipMalloc((void**)&ratios, sizeof(double) * kp_cap));
+    DFVO_HIP_CHECK(hipMalloc((void**)&ratios, sizeof(double) * kp_cap * 3));  // ratio | triangulated | CNN depth lists
     DFVO_HIP_CHECK(hipMalloc((void**)&inl_a, kp_cap + 8));
     DFVO_HIP_CHECK(hipMalloc((void**)&inl_b, kp_cap + 8));
     DFVO_HIP_CHECK(hipMalloc((void**)&scratch, sizeof(int) * (kp_cap + 8)));
@@ -1593,6 +1669,9 @@ void TrackerBuffers::release() {
     ev_fork = ev_start = ev_h = nullptr;
     if (shared) mt_state = nullptr;
     small_valid = false;
+    if (ratio_map) (void)hipFree(ratio_map);
+    ratio_map = nullptr;
+    ratio_cap = 0;
     void* ptrs[] = {mt_state, kp_info, kp_total, pose, small, scale_out, winner, lidx};
     lidx = nullptr;
     lidx_cap = 0;
@@ -1662,9 +1741,11 @@ int enqueue_pose_h_part(TrackerBuffers& tb, int n_bound, const PoseConfig& cfg, 
     }
     // ---- homography + GRIC-H (kp_cur -> kp_ref); with 10 or fewer keypoints the result is never consumed
     // (E_tracker.py:196) and with fewer than 5 the chain marks itself "no model"
-    int rc = enqueue_find_homography(tb.ws_h, tb.kp_cur, tb.kp_ref, n_bound, 1.0, 2000, 0.99, sh, tb.kp_info);
+    // homo_ratio: the same call with ransacReprojThreshold 0.2, only its inlier count is used (E_tracker.py:188-194)
+    int rc = enqueue_find_homography(tb.ws_h, tb.kp_cur, tb.kp_ref, n_bound, cfg.validity == 2 ? 0.2 : 1.0, 2000, 0.99, sh,
+                                     tb.kp_info);
     if (rc != DFVO_OK) return rc;
-    {
+    if (cfg.validity != 2) {
         GricFusedBatch GH;
         for (int r = 0; r < MAX_E_BATCH; ++r) GH.M[r] = tb.ws_h.out;
         hipLaunchKernelGGL(k_gric_fused, dim3(1), dim3(256), 0, sh, GH, 1, tb.small, tb.small + 9, tb.kp_info, tb.kp_cur,
@@ -1681,9 +1762,10 @@ int enqueue_pose_e_part(TrackerBuffers& tb, int n_host, const PoseConfig& cfg, h
     DFVO_ARG_CHECK(n_host >= 0 && n_host <= tb.kp_cap, "compute_pose_2d2d: keypoint capacity");
     DFVO_ARG_CHECK(cfg.repeat >= 1 && cfg.repeat <= MAX_REP, "compute_pose_2d2d: repeat out of range");
     DFVO_HIP_CHECK(hipStreamWaitEvent(s, tb.ev_h, 0));
-    const bool by_flow = cfg.validity == 1;
-    // GRIC: only when more than 10 keypoints (E_tracker.py:196); flow: whenever the five-point solver has its 5 points
-    if (by_flow ? n_host >= 5 : n_host > 10) {
+    const bool by_flow = cfg.validity == 1, by_ratio = cfg.validity == 2;
+    // GRIC: only when more than 10 keypoints (E_tracker.py:196); flow / homo_ratio: whenever the five-point solver has
+    // its 5 points
+    if (by_flow || by_ratio ? n_host >= 5 : n_host > 10) {
         const int nb = cdiv(n_host, 256);
         const int cap = tb.kp_cap;
         hipStream_t sr = tb.s_rep[0];
@@ -1712,7 +1794,7 @@ int enqueue_pose_e_part(TrackerBuffers& tb, int n_host, const PoseConfig& cfg, h
                 if (rc != DFVO_OK) return rc;
                 hipLaunchKernelGGL(k_copy_double, dim3(1), dim3(1), 0, sr, tb.small + 19 + rep, tb.ws_h.out + 16 + 12);
             }
-        } else {
+        } else if (!by_ratio) {
             GricFusedBatch GE;
             for (int rep = 0; rep < MAX_E_BATCH; ++rep) GE.M[rep] = rep < cfg.repeat ? tb.ws_rep[rep].out : nullptr;
             hipLaunchKernelGGL(k_gric_fused, dim3(R), dim3(256), 0, sr, GE, 0, tb.small, tb.small + 9, tb.kp_info, tb.pa, tb.pb,
@@ -1732,7 +1814,8 @@ int enqueue_pose_e_part(TrackerBuffers& tb, int n_host, const PoseConfig& cfg, h
                                    tb.small + 19, tb.perm, cap + 8, tb.best_inliers, cfg.repeat);
             else
                 hipLaunchKernelGGL(k_rep_update_all, dim3(1), dim3(256), 0, s, tb.pose, tb.ws_h.state, tb.small + 18, RB,
-                                   tb.small + 19, tb.perm, cap + 8, tb.best_inliers, cfg.repeat);
+                                   tb.small + 19, tb.perm, cap + 8, tb.best_inliers, cfg.repeat, by_ratio ? 1 : 0,
+                                   cfg.validity_thre);
         }
         // recoverPose(best_E, kp_cur, kp_ref): always enqueued, consumed only when major_valid; its last kernel also
         // writes the pose bookkeeping and (fused pipeline) the inverse pose for the scale stage
@@ -1789,11 +1872,14 @@ int enqueue_find_scale(TrackerBuffers& tb, int n_host, const double* d_T21, cons
         DFVO_HIP_CHECK(hipMemsetAsync(tb.kp_total + 4, 0, sizeof(int), s));
     }
     const int nb = cdiv(n_host > 0 ? n_host : 1, 256);
+    const bool abs_diff = cfg.method == 1;
     hipLaunchKernelGGL(k_scale_triangulate, dim3(nb), dim3(256), 0, s, tb.kp_info, tb.kp_ref, tb.kp_cur, d_T21, cfg.cx,
                        cfg.cy, cfg.fx, cfg.fy, H, W, tb.z2, tb.pix, tb.winner);
     hipLaunchKernelGGL(k_scale_ratios, dim3(1), dim3(256), sizeof(int) * (size_t)(n_host > 0 ? n_host : 1), s, tb.kp_info,
-                       tb.z2, tb.pix, tb.winner, d_depth, tb.ratios, tb.kp_total + 4);
-    hipLaunchKernelGGL(k_scale_ransac, dim3(1), dim3(256), 0, s, tb.mt_state, tb.ratios, tb.kp_total + 4, 10,
+                       tb.z2, tb.pix, tb.winner, d_depth, tb.ratios, tb.kp_total + 4, abs_diff ? tb.ratios + tb.kp_cap : nullptr,
+                       abs_diff ? tb.ratios + 2 * (size_t)tb.kp_cap : nullptr);
+    hipLaunchKernelGGL(k_scale_ransac, dim3(1), dim3(256), 0, s, tb.mt_state, abs_diff ? tb.ratios + tb.kp_cap : tb.ratios,
+                       abs_diff ? tb.ratios + 2 * (size_t)tb.kp_cap : (const double*)nullptr, tb.kp_total + 4, 10,
                        cfg.min_samples, cfg.max_trials, cfg.stop_prob, cfg.thre, tb.inl_a, tb.inl_b, tb.scratch,
                        tb.scale_out, d_gate);
     DFVO_HIP_CHECK(hipGetLastError());

@@ -39,14 +39,16 @@ struct PoseConfig {
     int repeat;
     int max_iters;
     double KinvT[9], Kinv[9];
-    int validity = 0;           // e_tracker.validity.method: 0 GRIC, 1 flow (E_tracker.py:182-185, 243-250)
-    double validity_thre = 0;   // flow: mean keypoint displacement [px] above which the pair is tracked at all
+    int validity = 0;           // e_tracker.validity.method: 0 GRIC, 1 flow, 2 homo_ratio (E_tracker.py:182-194, 243-250)
+    double validity_thre = 0;   // flow: mean keypoint displacement [px] above which the pair is tracked at all;
+                                // homo_ratio: a repeat is valid while H inliers / (H + E inliers) stays below it
 };
 
 struct ScaleConfig {
     double cx, cy, fx, fy;
     int min_samples, max_trials;
     double stop_prob, thre;
+    int method = 0;  // scale_recovery.ransac.method: 0 depth_ratio, 1 abs_diff (E_tracker.py:626-635)
 };
 
 constexpr int MAX_REP = 8;
@@ -113,6 +115,8 @@ struct TrackerBuffers {
     size_t winner_cap = 0;
     unsigned short* lidx = nullptr;
     size_t lidx_cap = 0;
+    float* ratio_map = nullptr;  // flow_diff / |flow| per pixel (local_bestN score_method 'flow_ratio')
+    size_t ratio_cap = 0;
     // keypoint-sized buffers
     double *kp_ref = nullptr, *kp_cur = nullptr, *pa = nullptr, *pb = nullptr, *res = nullptr, *z2 = nullptr,
            *ratios = nullptr;
@@ -128,8 +132,9 @@ struct TrackerBuffers {
     void release();
 };
 
+// score_method: 0 'flow' (the consistency map itself), 1 'flow_ratio' (map / |flow|), kp_selection.py:137-141,151-156
 int enqueue_local_bestn(TrackerBuffers& tb, const float* d_flow, const float* d_diff, int H, int W, int num_row,
-                        int num_col, int num_bestN, float thre, hipStream_t s);
+                        int num_col, int num_bestN, float thre, hipStream_t s, int score_method = 0);
 // bestN_flow_kp (kp_selection.py:33-71): whole-image argpartition
 struct BestNBuffers {
     float* key_base = nullptr;   // keys carried along with the index array, with slack on either side

@@ -17,8 +17,9 @@ class KeypointSampler:
         if ks.sampled_kp.enable:  # keypoint_sampler.py:29-36
             self.kps['uniform'] = self.generate_kp_samples(img_h=self.cfg.image.height, img_w=self.cfg.image.width,
                                                            crop=self.cfg.crop.flow_crop, N=ks.sampled_kp.num_kp)
-        if ks.local_bestN.enable and ks.local_bestN.score_method != "flow":
-            raise NotImplementedError("local_bestN.score_method '%s'" % ks.local_bestN.score_method)
+        if ks.local_bestN.enable and ks.local_bestN.score_method not in ("flow", "flow_ratio"):
+            raise NotImplementedError("local_bestN.score_method '%s' (flow_depth needs depth_consistency: Experiment Ver. only)"
+                                      % ks.local_bestN.score_method)
         if ks.depth_consistency.enable:
             raise NotImplementedError("depth_consistency is experiment-only in the reference (out of scope)")
 
@@ -84,9 +85,10 @@ class KeypointSampler:
         kp1 = np.zeros((nmax, 2))
         kp2 = np.zeros((nmax, 2))
         n, good = C.c_int(), C.c_int()
-        capi.check(capi.lib().dfvo_kp_local_bestn(_ctx.tracker(), capi.as_ptr(flow), capi.as_ptr(diff.reshape(h, w)), h,
-                                                  w, int(c.num_row), int(c.num_col), nmax, float(c.thre),
-                                                  capi.as_ptr(kp1), capi.as_ptr(kp2), C.byref(n), C.byref(good)))
+        score = {"flow": 0, "flow_ratio": 1}[c.score_method]
+        capi.check(capi.lib().dfvo_kp_local_bestn_ex(_ctx.tracker(), capi.as_ptr(flow), capi.as_ptr(diff.reshape(h, w)), h,
+                                                     w, int(c.num_row), int(c.num_col), nmax, float(c.thre), score,
+                                                     capi.as_ptr(kp1), capi.as_ptr(kp2), C.byref(n), C.byref(good)))
         if not good.value:
             print("Cannot find enough good keypoints!")
             outputs['good_kp_found'] = False

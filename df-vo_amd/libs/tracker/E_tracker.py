@@ -12,6 +12,10 @@ from ..geometry.camera_modules import SE3
 from . import _ctx, rigid_kp
 
 
+VALIDITY_METHODS = {"GRIC": 0, "flow": 1, "homo_ratio": 2}   # include/dfvo_hip.h DFVO_VALIDITY_*
+SCALE_METHODS = {"depth_ratio": 0, "abs_diff": 1}             # DFVO_SCALE_*
+
+
 class EssTracker:
     def __init__(self, cfg, cam_intrinsics, timers):
         self.cfg = cfg
@@ -24,9 +28,9 @@ class EssTracker:
     def compute_pose_2d2d(self, kp_ref, kp_cur, is_iterative):
         """E_tracker.py:154-307 -> {'pose': SE3 (cur -> ref), 'inliers': bool [N]}"""
         valid_cfg = self.cfg.e_tracker.validity
-        if valid_cfg.method not in ("GRIC", "flow"):
-            raise NotImplementedError("e_tracker.validity.method '%s': GRIC and flow run on the device "
-                                      "(homo_ratio appears in no shipped configuration)" % valid_cfg.method)
+        if valid_cfg.method not in VALIDITY_METHODS:
+            raise NotImplementedError("e_tracker.validity.method '%s' (the reference knows GRIC, flow, homo_ratio)"
+                                      % valid_cfg.method)
         K = np.asarray(self.cam_intrinsics.mat, dtype=np.float64)
         repeat = int(self.cfg.e_tracker.ransac.repeat) if is_iterative else 3
         kp_ref = np.ascontiguousarray(kp_ref, dtype=np.float64)
@@ -35,8 +39,8 @@ class EssTracker:
         cfg = capi.Pose2d2dCfg(fx=float(self.cam_intrinsics.fx), cx=float(self.cam_intrinsics.cx),
                                cy=float(self.cam_intrinsics.cy),
                                reproj_thre=float(self.cfg.e_tracker.ransac.reproj_thre), repeat=repeat,
-                               max_iters=self.max_iters, validity_method=1 if valid_cfg.method == "flow" else 0,
-                               validity_thre=float(valid_cfg.thre) if valid_cfg.method == "flow" else 0.0)
+                               max_iters=self.max_iters, validity_method=VALIDITY_METHODS[valid_cfg.method],
+                               validity_thre=0.0 if valid_cfg.method == "GRIC" else float(valid_cfg.thre))
         KinvT, Kinv = np.linalg.inv(K.T), np.linalg.inv(K)
         for i in range(9):
             cfg.KinvT[i] = KinvT.flat[i]
@@ -110,9 +114,9 @@ class EssTracker:
         return self.find_scale_from_depth(ref_data[src], cur_data[src], E_pose.inv_pose, cur_data['depth'])
 
     def find_scale_from_depth(self, kp1, kp2, T_21, depth2):
-        """E_tracker.py:571-643 (ransac.method 'depth_ratio')"""
+        """E_tracker.py:571-643 (ransac.method 'depth_ratio' or 'abs_diff')"""
         rc = self.cfg.scale_recovery.ransac
-        if rc.method != "depth_ratio":
+        if rc.method not in SCALE_METHODS:
             raise NotImplementedError("scale_recovery.ransac.method '%s'" % rc.method)
         kp1 = np.ascontiguousarray(kp1, dtype=np.float64)
         kp2 = np.ascontiguousarray(kp2, dtype=np.float64)
@@ -122,7 +126,7 @@ class EssTracker:
         cam = self.cam_intrinsics
         scfg = capi.ScaleCfg(cx=float(cam.cx), cy=float(cam.cy), fx=float(cam.fx), fy=float(cam.fy),
                              min_samples=int(rc.min_samples), max_trials=int(rc.max_trials),
-                             stop_prob=float(rc.stop_prob), thre=float(rc.thre))
+                             stop_prob=float(rc.stop_prob), thre=float(rc.thre), method=SCALE_METHODS[rc.method])
         scale = C.c_double()
         info = np.zeros(4, np.int32)
         if self.timers is not None:

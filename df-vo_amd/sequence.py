@@ -80,3 +80,20 @@ def save_traj(path, poses):
 
 def frames_to_device(frames_u8):
     return [torch.from_numpy(np.ascontiguousarray(f)).cuda() for f in frames_u8]
+
+
+def image_to_device(img_u8, h, w, crop=None):
+    """the tail of read_image (/root/reference/libs/general/utils.py:46-51) on the device: the decoded RGB frame is uploaded
+    as it is, optionally cropped ([[y0, y1], [x0, x1]] fractions) and resized to the configured (h, w) with cv2.resize's
+    default 8-bit INTER_LINEAR arithmetic (dfvo_resize_linear_u8).  Returns a device uint8 tensor [h, w, 3]."""
+    img = np.ascontiguousarray(img_u8)
+    if crop is not None:
+        ih, iw = img.shape[:2]
+        y0, y1 = int(ih * crop[0][0]), int(ih * crop[0][1])
+        x0, x1 = int(iw * crop[1][0]), int(iw * crop[1][1])
+        img = np.ascontiguousarray(img[y0:y1, x0:x1])
+    src = torch.from_numpy(img).cuda()
+    dst = torch.empty((h, w, img.shape[2]), dtype=torch.uint8, device="cuda")
+    capi.check(capi.lib().dfvo_resize_linear_u8(src.data_ptr(), img.shape[0], img.shape[1], img.shape[2], dst.data_ptr(), h, w,
+                                                torch.cuda.current_stream().cuda_stream))
+    return dst

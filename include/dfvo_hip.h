@@ -109,6 +109,11 @@ int dfvo_resize_lanczos_u8(const uint8_t* d_src, int H, int W, uint8_t* d_dst, i
  * sample, count), h_coeffs [out_size][*ksize] 22-bit coefficients (coeff_cap ints available) -- Pillow's
  * precompute_coeffs + normalize_coeffs_8bpc */
 int dfvo_lanczos_coeffs(int in_size, int out_size, int* h_bounds, int* h_coeffs, int coeff_cap, int* ksize);
+/* uint8 [H,W,C] (C <= 4) -> uint8 [out_h,out_w,C] = cv2.resize(img, (out_w, out_h)) with the default INTER_LINEAR, the
+ * resize of the loaded frame to the configured size in read_image (libs/general/utils.py:51): OpenCV 3.4.3's 11-bit
+ * fixed-point bilinear arithmetic (exact 2 x 2 decimation: its (a + b + c + d + 2) >> 2 area path).  Asynchronous on
+ * `stream`. */
+int dfvo_resize_linear_u8(const uint8_t* d_src, int H, int W, int C, uint8_t* d_dst, int out_h, int out_w, void* stream);
 int dfvo_resize_bilinear(const float* d_src, int N, int H, int W, int C, float* d_dst, int Ho, int Wo,
                          int align_corners, void* stream);
 
@@ -208,6 +213,14 @@ int dfvo_tracker_get_rng_state(dfvo_tracker* trk, uint32_t* h_state625);
 int dfvo_kp_local_bestn(dfvo_tracker* trk, const float* h_flow, const float* h_diff, int H, int W, int num_row,
                         int num_col, int num_bestN, float thre, double* h_kp1, double* h_kp2, int* n_out,
                         int* good_kp_found);
+/* same with cfg.kp_selection.local_bestN.score_method (kp_selection.py:137-141,151-156): 'flow' thresholds and ranks the
+ * consistency map itself (what dfvo_kp_local_bestn does), 'flow_ratio' the map divided by the flow magnitude per pixel
+ * (float32, numpy's evaluation order); the "enough good pixels" rule stays on the map itself (kp_selection.py:121) */
+#define DFVO_KP_SCORE_FLOW 0
+#define DFVO_KP_SCORE_FLOW_RATIO 1
+int dfvo_kp_local_bestn_ex(dfvo_tracker* trk, const float* h_flow, const float* h_diff, int H, int W, int num_row,
+                           int num_col, int num_bestN, float thre, int score_method, double* h_kp1, double* h_kp2,
+                           int* n_out, int* good_kp_found);
 /* bestN_flow_kp (kp_selection.py:33-71, ablation_correspondences_best_n.yml): the num_bestN pixels of the whole image
  * with the least forward-backward inconsistency, in np.argpartition(flow_diff[flow_diff >= 0], num_bestN)[:num_bestN]
  * order (numpy's scalar introselect).  *n_out = num_bestN, or 0 when the image has no more than num_bestN candidates
@@ -246,9 +259,13 @@ int dfvo_kp_rigid_flow(dfvo_tracker* trk, const float* h_flow, const float* h_fl
  * displacement exceeds validity_thre (else identity and no RandomState draw); a repeat is valid when the cheirality
  * count of recoverPose(E_rep) exceeds 10 % of the keypoints, and it can only become the best model above 5 %
  * (out: h_gric = the mean displacement, rep_gric[] = the per-repeat cheirality counts).
+ * DFVO_VALIDITY_HOMO_RATIO (E_tracker.py:186-194,243-250): findHomography with ransacReprojThreshold 0.2; a repeat is
+ * valid while H_inliers.sum() / (H_inliers.sum() + inliers.sum()) < validity_thre (out: h_gric = the homography's
+ * inlier count, rep_gric[] = the ratios; fewer than 5 keypoints, where the reference raises: identity).
  * Consumes the tracker's RandomState for the shuffles. */
 #define DFVO_VALIDITY_GRIC 0
 #define DFVO_VALIDITY_FLOW 1
+#define DFVO_VALIDITY_HOMO_RATIO 2
 typedef struct dfvo_pose2d2d_cfg {
     double fx, cx, cy;       /* focal = fx, principal point (E_tracker.py:231-239) */
     double reproj_thre;      /* e_tracker.ransac.reproj_thre */
@@ -256,8 +273,8 @@ typedef struct dfvo_pose2d2d_cfg {
     int max_iters;           /* 1000 = OpenCV 3.4.3 */
     double KinvT[9];         /* np.linalg.inv(K.T) */
     double Kinv[9];          /* np.linalg.inv(K)   */
-    int validity_method;     /* e_tracker.validity.method: DFVO_VALIDITY_GRIC / DFVO_VALIDITY_FLOW */
-    double validity_thre;    /* e_tracker.validity.thre (flow only) */
+    int validity_method;     /* e_tracker.validity.method: DFVO_VALIDITY_GRIC / _FLOW / _HOMO_RATIO */
+    double validity_thre;    /* e_tracker.validity.thre (flow, homo_ratio) */
 } dfvo_pose2d2d_cfg;
 typedef struct dfvo_pose2d2d_out {
     double R[9], t[3];       /* pose cur -> ref (identity / zero when rejected) */
@@ -272,11 +289,16 @@ int dfvo_compute_pose_2d2d(dfvo_tracker* trk, const double* h_kp_ref, const doub
 /* EssTracker.find_scale_from_depth (E_tracker.py:571-643): triangulate (ops_3d.py:44-67), scatter to a
  * sparse depth map (ops_3d.py:15-41), depth ratios on valid pixels, sklearn RANSACRegressor on them.
  * h_T21 4x4; h_depth double [H,W].  *scale = -1 when fewer than 11 valid ratios.
+ * method DFVO_SCALE_DEPTH_RATIO: .fit(depth_ratio, ones); DFVO_SCALE_ABS_DIFF: .fit(depth_tri, depth_pred)
+ * (scale_recovery.ransac.method, E_tracker.py:626-635).
  * h_info[4] = {n_valid, n_trials, n_inliers, status}.  Consumes the tracker's RandomState. */
+#define DFVO_SCALE_DEPTH_RATIO 0
+#define DFVO_SCALE_ABS_DIFF 1
 typedef struct dfvo_scale_cfg {
     double cx, cy, fx, fy;
     int min_samples, max_trials;
     double stop_prob, thre;
+    int method;              /* DFVO_SCALE_DEPTH_RATIO / DFVO_SCALE_ABS_DIFF */
 } dfvo_scale_cfg;
 int dfvo_find_scale_from_depth(dfvo_tracker* trk, const double* h_kp1, const double* h_kp2, int n,
                                const double* h_T21, const double* h_depth, int H, int W, const dfvo_scale_cfg* cfg,

@@ -166,9 +166,13 @@ def Rodrigues(src):
 
 
 def resize(src, dsize, interpolation=INTER_LINEAR):
-    """nearest-neighbour only (dfvo.py:314-317): sx = min(floor(x * src_w / dst_w), src_w - 1)"""
-    assert interpolation == INTER_NEAREST, "oracle cv2 shim implements INTER_NEAREST only"
+    """cv2.resize as the reference calls it: INTER_NEAREST on the depth map (dfvo.py:314-317) and the default
+    INTER_LINEAR on the loaded uint8 frame (utils.py:51)"""
     src = np.asarray(src)
+    if interpolation == INTER_LINEAR:
+        return resize_linear_u8(src, dsize)
+    assert interpolation == INTER_NEAREST, "oracle cv2 shim implements INTER_NEAREST and 8-bit INTER_LINEAR"
+    # nearest: sx = min(floor(x * src_w / dst_w), src_w - 1)
     w, h = dsize
     sh, sw = src.shape[:2]
     ifx = 1.0 / (float(w) / sw)
@@ -176,3 +180,48 @@ def resize(src, dsize, interpolation=INTER_LINEAR):
     xs = np.minimum(np.floor(np.arange(w) * ifx).astype(np.int64), sw - 1)
     ys = np.minimum(np.floor(np.arange(h) * ify).astype(np.int64), sh - 1)
     return src[ys][:, xs]
+
+
+def _linear_axis_u8(n_src, n_dst, scale):
+    """OpenCV 3.4.3 imgproc/src/resize.cpp, hal::resize, the coefficient loops of the generic path for CV_8U +
+    INTER_LINEAR: f = float((d + 0.5) * scale - 0.5), s = floor(f), f -= s (float); the 11-bit fixed-point pair
+    saturate_cast<short>((1 - f, f) * 2048) (cvRound: half to even).  Returns s (unclamped) and the [n_dst, 2] table."""
+    d = np.arange(n_dst, dtype=np.float64)
+    f = ((d + 0.5) * scale - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = f - s.astype(np.float32)
+    return s, f
+
+
+def resize_linear_u8(src, dsize):
+    """cv2.resize(src, (w, h)) for uint8 [H,W] / [H,W,C], interpolation INTER_LINEAR (restated from OpenCV 3.4.3's
+    resize.cpp; the IPP branch is skipped there for 8-bit linear, "does not match OpenCV exactly"):
+      * scale = 1 / (dst / src) per axis (double);
+      * exactly 2 x 2 decimation switches to INTER_AREA's fast path: (a + b + c + d + 2) >> 2;
+      * otherwise columns: s < 0 -> (0, f = 0); s >= W - 1 -> (W - 1, f = 0); rows are clipped to [0, H - 1] with
+        their weights unchanged; horizontal pass S[s] * a0 + S[s + 1] * a1 (int, 2048 = 1.0), vertical pass
+        (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2."""
+    src = np.asarray(src)
+    assert src.dtype == np.uint8, "8-bit only (the reference resizes the frame right after cv2.imread)"
+    w, h = int(dsize[0]), int(dsize[1])
+    sh, sw = src.shape[:2]
+    img = src.reshape(sh, sw, -1).astype(np.int64)
+    scale_x, scale_y = 1.0 / (float(w) / sw), 1.0 / (float(h) / sh)
+    eps = np.finfo(np.float64).eps
+    if abs(scale_x - 2) < eps and abs(scale_y - 2) < eps:
+        out = (img[0:2 * h:2, 0:2 * w:2] + img[0:2 * h:2, 1:2 * w:2] + img[1:2 * h:2, 0:2 * w:2] + img[1:2 * h:2, 1:2 * w:2] + 2) >> 2
+        return out.astype(np.uint8).reshape((h, w) + src.shape[2:])
+    sx, fx = _linear_axis_u8(sw, w, scale_x)
+    lo, hi = sx < 0, sx >= sw - 1
+    fx = np.where(lo | hi, np.float32(0), fx)
+    sx = np.where(lo, 0, np.where(hi, sw - 1, sx))
+    a0 = np.rint((np.float32(1) - fx) * np.float32(2048)).astype(np.int64)
+    a1 = np.rint(fx * np.float32(2048)).astype(np.int64)
+    sy, fy = _linear_axis_u8(sh, h, scale_y)
+    b0 = np.rint((np.float32(1) - fy) * np.float32(2048)).astype(np.int64)
+    b1 = np.rint(fy * np.float32(2048)).astype(np.int64)
+    y0, y1 = np.clip(sy, 0, sh - 1), np.clip(sy + 1, 0, sh - 1)
+    sx1 = np.minimum(sx + 1, sw - 1)  # a1 == 0 wherever this clamps
+    rows = img[:, sx] * a0[None, :, None] + img[:, sx1] * a1[None, :, None]         # [H, w, C]
+    out = (((b0[:, None, None] * (rows[y0] >> 4)) >> 16) + ((b1[:, None, None] * (rows[y1] >> 4)) >> 16) + 2) >> 2
+    return out.astype(np.uint8).reshape((h, w) + src.shape[2:])

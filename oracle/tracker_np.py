@@ -133,8 +133,9 @@ def image_grid(h, w):
     return np.transpose(np.stack([xv, yv]), (1, 2, 0))
 
 
-def local_bestN(flow, flow_diff, num_bestN=2000, num_row=10, num_col=10, thre=0.1, argpartition=argpartition_c):
-    """kp_selection.py:74-200 with score_method 'flow', depth consistency disabled.
+def local_bestN(flow, flow_diff, num_bestN=2000, num_row=10, num_col=10, thre=0.1, argpartition=argpartition_c,
+                score_method="flow"):
+    """kp_selection.py:74-200 with score_method 'flow' or 'flow_ratio' (:137-141,151-156), depth consistency disabled.
     flow [2,H,W] f32, flow_diff [H,W,1] f32 -> dict(good_kp_found, kp1_best [1,N,2], kp2_best [1,N,2])"""
     h, w, _ = flow_diff.shape
     kp1 = np.expand_dims(image_grid(h, w), 0)
@@ -151,6 +152,10 @@ def local_bestN(flow, flow_diff, num_bestN=2000, num_row=10, num_col=10, thre=0.
             x0 = [int(h / num_row * row), int(w / num_col * col)]
             x1 = [int(h / num_row * (row + 1)) - 1, int(w / num_col * (col + 1)) - 1]
             tile = diff[:, x0[0]:x1[0], x0[1]:x1[1]].copy()
+            if score_method == "flow_ratio":
+                tmp_flow = np.transpose(np.expand_dims(flow[:, x0[0]:x1[0], x0[1]:x1[1]], 0), (0, 2, 3, 1))
+                with np.errstate(divide="ignore", invalid="ignore"):
+                    tile = tile / np.linalg.norm(tmp_flow, axis=3, keepdims=True)
             where = np.where(tile < thre)
             num_to_pick = min(n_best, len(where[0]))
             if num_to_pick != 0:
@@ -374,6 +379,8 @@ def compute_pose_2d2d(kp_ref, kp_cur, K, reproj_thre=0.2, repeat=5, max_iters=10
     Consumes np.random (global RandomState).  Returns dict(R, t, inliers, and diagnostics)."""
     if validity == "flow":
         return _compute_pose_2d2d_flow(kp_ref, kp_cur, K, reproj_thre, repeat, max_iters, validity_thre)
+    if validity == "homo_ratio":
+        return _compute_pose_2d2d_homo_ratio(kp_ref, kp_cur, K, reproj_thre, repeat, max_iters, validity_thre)
     assert validity == "GRIC"
     fx, cx, cy = K[0, 0], K[0, 2], K[1, 2]
     n = kp_ref.shape[0]
@@ -469,6 +476,50 @@ def _compute_pose_2d2d_flow(kp_ref, kp_cur, K, reproj_thre, repeat, max_iters, t
     return out
 
 
+def _compute_pose_2d2d_homo_ratio(kp_ref, kp_cur, K, reproj_thre, repeat, max_iters, thre):
+    """E_tracker.py:186-194 (findHomography, ransacReprojThreshold 0.2), :243-250 (per repeat: the share of homography
+    inliers among homography + essential inliers below `thre`), :276-300 (unchanged ending)"""
+    fx, cx, cy = K[0, 0], K[0, 2], K[1, 2]
+    n = kp_ref.shape[0]
+    R, t = np.eye(3), np.zeros((3, 1))
+    best_cnt = 0
+    best_inliers = np.ones((n, 1)) == 1
+    diag = {"rep_inliers": [], "rep_valid": [], "rep_ratio": [], "num_valid": 0, "major_valid": False, "cheirality": 0}
+    H, H_inl = cv2.findHomography(kp_cur, kp_ref, method=cv2.RANSAC, confidence=0.99, ransacReprojThreshold=0.2)
+    diag["h_inliers"] = int(H_inl.sum())
+    best_E = None
+    num_valid = 0
+    for _ in range(repeat):
+        new_list = np.arange(0, n, 1)
+        np.random.shuffle(new_list)
+        a, b = kp_cur.copy()[new_list], kp_ref.copy()[new_list]
+        E, inl = cv2.findEssentialMat(a, b, focal=fx, pp=(cx, cy), method=cv2.RANSAC, prob=0.99,
+                                      threshold=reproj_thre, maxIters=max_iters)
+        with np.errstate(invalid="ignore"):
+            ratio = H_inl.sum() / (H_inl.sum() + inl.sum())
+        valid_case = ratio < thre
+        diag["rep_inliers"].append(int(inl.sum()))
+        diag["rep_valid"].append(bool(valid_case))
+        diag["rep_ratio"].append(float(ratio))
+        if inl.sum() > best_cnt:
+            best_E, best_cnt = E, inl.sum()
+            revert = np.zeros_like(new_list)
+            for cnt, i in enumerate(new_list):
+                revert[i] = cnt
+            best_inliers = inl[list(revert)]
+        num_valid += valid_case * 1
+    diag["num_valid"] = int(num_valid)
+    if num_valid > (repeat / 2):
+        diag["major_valid"] = True
+        good, Rr, tr, _ = cv2.recoverPose(best_E, kp_cur, kp_ref, focal=fx, pp=(cx, cy))
+        diag["cheirality"] = int(good)
+        if good > n * 0.1:
+            R, t = Rr, tr
+    out = {"R": R, "t": t, "inliers": best_inliers[:, 0] == 1, "best_inlier_cnt": int(best_cnt)}
+    out.update(diag)
+    return out
+
+
 def convert_sparse3D_to_depth(kp, XYZ, height, width):
     """ops_3d.py:15-41"""
     depth = np.zeros((height, width))
@@ -491,8 +542,8 @@ def triangulation(kp1, kp2, T_1w, T_2w):
 
 
 def find_scale_from_depth(kp1, kp2, T_21, depth2, K, min_samples=3, max_trials=100, stop_prob=0.99, thre=0.1,
-                          diag=None):
-    """E_tracker.py:571-643 with ransac.method == 'depth_ratio'.  Consumes np.random through sklearn."""
+                          diag=None, method="depth_ratio"):
+    """E_tracker.py:571-643 with ransac.method 'depth_ratio' or 'abs_diff'.  Consumes np.random through sklearn."""
     from sklearn import linear_model
     fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
     img_h, img_w = depth2.shape
@@ -514,7 +565,11 @@ def find_scale_from_depth(kp1, kp2, T_21, depth2, K, min_samples=3, max_trials=1
         ransac = linear_model.RANSACRegressor(estimator=linear_model.LinearRegression(fit_intercept=False),
                                               min_samples=min_samples, max_trials=max_trials,
                                               stop_probability=stop_prob, residual_threshold=thre)
-        ransac.fit(ratio.reshape(-1, 1), np.ones((ratio.shape[0], 1)))
+        if method == "depth_ratio":
+            ransac.fit(ratio.reshape(-1, 1), np.ones((ratio.shape[0], 1)))
+        else:
+            assert method == "abs_diff"
+            ransac.fit(tri[valid].reshape(-1, 1), depth2[valid].reshape(-1, 1))
         if diag is not None:
             diag["n_trials"] = int(ransac.n_trials_)
             diag["n_inliers"] = int(ransac.inlier_mask_.sum())

@@ -176,7 +176,40 @@ def golden_kp_selection():
             print("  kp", tag, res["kp1_best"].shape)
         else:
             print("  kp", tag, "not enough keypoints")
+    # score_method 'flow_ratio' (kp_selection.py:137-141,155): mask and score = flow_diff / |flow|; thresholds scaled so that
+    # the ratio (diff ~ U[0, 0.1 / frac], |flow| ~ 3 sigma Rayleigh) leaves a mix of full and sparse cells
+    cfg.kp_selection.local_bestN.score_method = "flow_ratio"
+    for tag, (h, w, seed, frac, thre) in {"ra": (192, 640, 21, 0.6, 0.02), "rb": (376, 1241, 22, 0.35, 0.01),
+                                          "rc": (100, 130, 23, 0.05, 0.02)}.items():
+        diff, flow = kp_case(h, w, seed, frac)
+        flow[:, 5:9, 7:30] = 0  # zero flow: the ratio is inf (nan where the map is 0 too) -- never selected
+        diff[6, 10:14, 0] = 0
+        cfg.kp_selection.local_bestN.thre = thre
+        x = np.linspace(0, w - 1, w)
+        y = np.linspace(0, h - 1, h)
+        xv, yv = np.meshgrid(x, y)
+        kp1 = np.expand_dims(np.transpose(np.stack([xv, yv]), (1, 2, 0)), 0)
+        kp2 = kp1 + np.transpose(np.expand_dims(flow, 0), (0, 2, 3, 1))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            res = kps.local_bestN(kp1=kp1, kp2=kp2, ref_data={"flow_diff": diff, "flow": flow}, cfg=cfg,
+                                  outputs={"good_kp_found": True})
+        out[tag + "_spec"] = np.array([h, w, seed, frac, thre])
+        out[tag + "_good"] = np.array(res["good_kp_found"])
+        if res["good_kp_found"]:
+            out[tag + "_kp1"] = res["kp1_best"]
+            out[tag + "_kp2"] = res["kp2_best"]
+            print("  kp flow_ratio", tag, res["kp1_best"].shape)
+        else:
+            print("  kp flow_ratio", tag, "not enough keypoints")
     np.savez_compressed(os.path.join(HERE, "local_bestN.npz"), **out)
+
+
+def kp_ratio_case(h, w, seed, frac):
+    """inputs of the flow_ratio fixtures: kp_case + a patch of zero flow / zero consistency (also imported by the tests)"""
+    diff, flow = kp_case(h, w, seed, frac)
+    flow[:, 5:9, 7:30] = 0
+    diff[6, 10:14, 0] = 0
+    return diff, flow
 
 
 def golden_kp_sampled():
@@ -374,6 +407,90 @@ def golden_tracker_flow():
         out[tag + "_rng_after"] = np.r_[st[1].astype(np.uint32), np.uint32(st[2])]
         print("  tracker(flow)", tag, "inliers", int(res["inliers"].sum()), "t", res["pose"].t.ravel())
     np.savez_compressed(os.path.join(HERE, "e_tracker_flow.npz"), **out)
+
+
+def variant_case(tag):
+    """inputs of the e_tracker_variants fixtures (also imported by the tests): tracker_case with a CNN depth that agrees
+    with the geometry (true depth of view 2 x 1.25, 2 % noise, a fifth of the pixels arbitrary); case 'p': a planar
+    scene (keypoints related by a homography) -- the homography explains as many matches as the essential matrix"""
+    seed, n, of, noise = {"a": (71, 2000, 0.3, 0.15), "b": (72, 1500, 0.5, 0.25), "p": (73, 2000, 0.2, 0.05),
+                          "d": (74, 2000, 0.97, 0.2)}[tag]
+    c = tracker_case(seed, n, of, noise)
+    r = np.random.Generator(np.random.PCG64(seed))
+    X = np.stack([r.uniform(-20, 20, n), r.uniform(-3, 3, n), r.uniform(5, 60, n)], 1)  # two_view's points
+    z2 = ((c["R"] @ X.T).T + c["t"])[:, 2]
+    g = np.random.Generator(np.random.PCG64(seed + 1000))
+    zs = z2 * 1.25 * (1 + g.normal(0, 0.02, n))
+    wild = g.random(n) < 0.2
+    zs[wild] = g.uniform(5, 60, int(wild.sum()))
+    h, w = c["depth_cur"].shape
+    kp_ref, kp_cur = c["kp_ref"], c["kp_cur"]
+    if tag == "p":
+        Hm = np.array([[1.02, 0.01, 6.0], [-0.004, 1.015, 2.0], [1e-5, -2e-5, 1.0]])
+        q = (Hm @ np.c_[kp_ref, np.ones(n)].T).T
+        kp_cur = q[:, :2] / q[:, 2:] + g.normal(0, noise, (n, 2))
+        kp_cur[c["outliers"]] = np.stack([g.uniform(0, w, int(c["outliers"].sum())),
+                                          g.uniform(0, h, int(c["outliers"].sum()))], 1)
+        kp_cur = np.ascontiguousarray(kp_cur)
+    depth = np.zeros((h, w))
+    ix, iy = kp_cur[:, 0].astype(int), kp_cur[:, 1].astype(int)
+    ok = (ix >= 0) & (ix < w) & (iy >= 0) & (iy < h)
+    depth[iy[ok], ix[ok]] = zs[ok]
+    return dict(seed=seed, kp_ref=kp_ref, kp_cur=kp_cur, K=c["K"], depth_cur=depth)
+
+
+def golden_tracker_variants():
+    """the reference's EssTracker with e_tracker.validity.method 'homo_ratio' and scale_recovery.ransac.method
+    'abs_diff' (neither is in a shipped configuration; E_tracker.py:186-194,243-250,631-635) over the cv2 shim"""
+    from oracle import cv2_shim
+    sys.modules["cv2"] = cv2_shim
+    import sklearn.linear_model as lm
+    if not getattr(lm.RANSACRegressor, "_dfvo_compat", False):
+        _RR = lm.RANSACRegressor
+
+        def ransac_regressor_compat(base_estimator=None, **kw):  # sklearn 0.20 spelling: base_estimator=
+            return _RR(estimator=base_estimator, **kw)
+        ransac_regressor_compat._dfvo_compat = True
+        lm.RANSACRegressor = ransac_regressor_compat
+    try:
+        import matplotlib.pyplot  # noqa: F401
+    except Exception:
+        mpl = types.ModuleType("matplotlib")
+        mpl.pyplot = types.ModuleType("matplotlib.pyplot")
+        sys.modules["matplotlib"] = mpl
+        sys.modules["matplotlib.pyplot"] = mpl.pyplot
+    from easydict import EasyDict
+    from libs.tracker.E_tracker import EssTracker
+    from libs.general.timer import Timer
+    from libs.geometry.camera_modules import Intrinsics
+    cfg = EasyDict({
+        "kp_selection": {"rigid_flow_kp": {"enable": False}},
+        "e_tracker": {"ransac": {"reproj_thre": 0.2, "repeat": 5}, "validity": {"method": "homo_ratio", "thre": 0.4},
+                      "kp_src": "kp_best", "iterative_kp": {"enable": False}},
+        "scale_recovery": {"method": "simple", "kp_src": "kp_best", "iterative_kp": {"enable": False, "kp_src": "kp_depth"},
+                           "ransac": {"method": "abs_diff", "min_samples": 3, "max_trials": 100, "stop_prob": 0.99,
+                                      "thre": 0.1}},
+        "image": {"height": 376, "width": 1241}})
+    out = {}
+    for tag in "abpd":
+        c = variant_case(tag)
+        K = c["K"]
+        cam = Intrinsics([K[0, 2], K[1, 2], K[0, 0], K[1, 1]])
+        trk = EssTracker(cfg, cam, Timer())
+        np.random.seed(4869 + c["seed"])
+        res = trk.compute_pose_2d2d(c["kp_ref"], c["kp_cur"], True)
+        pose = res["pose"]
+        out[tag + "_pose"] = pose.pose.copy()
+        out[tag + "_inliers"] = res["inliers"].copy()
+        scale = -2.0
+        if np.linalg.norm(pose.t) != 0:
+            scale = trk.scale_recovery({"kp_best": c["kp_cur"], "depth": c["depth_cur"]}, {"kp_best": c["kp_ref"]}, pose,
+                                       False)["scale"]
+        out[tag + "_scale"] = np.array(float(scale))
+        st = np.random.get_state()
+        out[tag + "_rng_after"] = np.r_[st[1].astype(np.uint32), np.uint32(st[2])]
+        print("  tracker(homo_ratio, abs_diff)", tag, "inliers", int(res["inliers"].sum()), "t", pose.t.ravel(), "scale", scale)
+    np.savez_compressed(os.path.join(HERE, "e_tracker_variants.npz"), **out)
 
 
 RIGID_CASES = {"a": (192, 640, 61, "opt_flow"), "b": (192, 640, 62, "rigid_flow"), "c": (120, 200, 63, "opt_flow")}
@@ -642,7 +759,7 @@ if __name__ == "__main__":
             "gric": golden_gric, "tracker": golden_tracker, "lanczos": golden_lanczos, "sampled": golden_kp_sampled,
             "tracker_flow": golden_tracker_flow, "rigid": golden_rigid_flow, "bestn": golden_kp_bestn,
             "kitti_eval": golden_kitti_eval, "dfvo_main": golden_dfvo_main,
-            "target_size": golden_target_size}
+            "target_size": golden_target_size, "tracker_variants": golden_tracker_variants}
     for name, fn in todo.items():
         if not which or name in which:
             print("==", name)

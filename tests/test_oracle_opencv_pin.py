@@ -48,3 +48,9 @@ def test_oracle_equals_opencv_343_on_the_dumped_cases():
         assert np.abs(rvec.ravel() - fx[p + "pnp_rvec"].ravel()).max() <= 1e-9
         assert np.abs(tvec.ravel() - fx[p + "pnp_tvec"].ravel()).max() <= 1e-9
         assert np.abs(cv2.Rodrigues(fx[p + "pnp_rvec"])[0] - fx[p + "rod"]).max() <= 1e-12
+    for ri in range(int(fx["n_resize"]) if "n_resize" in fx.files else 0):
+        seed, h, w, oh, ow = [int(v) for v in fx["r%d_spec" % ri]]
+        img = fx["r%d_img" % ri]
+        assert np.array_equal(cv2.resize(img, (ow, oh)), fx["r%d_linear" % ri]), "resize case %d: 8-bit INTER_LINEAR" % ri
+        assert np.array_equal(cv2.resize(img[..., 0].astype(np.float32), (ow, oh), interpolation=cv2.INTER_NEAREST),
+                              fx["r%d_nearest" % ri]), "resize case %d: INTER_NEAREST" % ri

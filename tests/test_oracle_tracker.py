@@ -57,6 +57,22 @@ def test_local_bestN_matches_reference_fixture():
             assert np.array_equal(res["kp2_best"], g[tag + "_kp2"]), tag
 
 
+def test_local_bestN_flow_ratio_matches_reference_fixture():
+    from golden.make_golden import kp_ratio_case
+    g = np.load(os.path.join(G, "local_bestN.npz"))
+    n_good = 0
+    for tag in ("ra", "rb", "rc"):
+        h, w, seed, frac, thre = g[tag + "_spec"]
+        diff, flow = kp_ratio_case(h, w, seed, frac)
+        res = T.local_bestN(flow, diff, thre=float(thre), score_method="flow_ratio")
+        assert bool(res["good_kp_found"]) == bool(g[tag + "_good"])
+        if res["good_kp_found"]:
+            n_good += 1
+            assert np.array_equal(res["kp1_best"], g[tag + "_kp1"]), tag
+            assert np.array_equal(res["kp2_best"], g[tag + "_kp2"]), tag
+    assert n_good >= 2
+
+
 def test_gric_matches_reference_fixture():
     g = np.load(os.path.join(G, "gric.npz"))
     f = T.fundamental_residual(g["F"], g["kp1"], g["kp2"])
@@ -83,6 +99,31 @@ def test_e_tracker_matches_reference_fixture():
             assert abs(scale - float(g[tag + "_scale"])) <= 1e-12 * abs(scale), tag
         st = np.random.get_state()
         assert np.array_equal(np.r_[st[1].astype(np.uint32), np.uint32(st[2])], g[tag + "_rng_after"]), tag
+
+
+def test_e_tracker_homo_ratio_and_abs_diff_match_reference_fixture():
+    """e_tracker.validity.method 'homo_ratio' + scale_recovery.ransac.method 'abs_diff' (E_tracker.py:186-194,243-250,
+    631-635): poses, masks, scale and the RandomState afterwards; case p (planar scene) is rejected by the ratio"""
+    from golden.make_golden import variant_case
+    g = np.load(os.path.join(G, "e_tracker_variants.npz"))
+    rejected = 0
+    for tag in "abpd":
+        c = variant_case(tag)
+        np.random.seed(4869 + c["seed"])
+        res = T.compute_pose_2d2d(c["kp_ref"], c["kp_cur"], c["K"], validity="homo_ratio", validity_thre=0.4)
+        pose = g[tag + "_pose"]
+        assert np.array_equal(res["inliers"], g[tag + "_inliers"]), tag
+        assert np.array_equal(res["R"], pose[:3, :3]) and np.array_equal(res["t"], pose[:3, 3:]), tag
+        if np.linalg.norm(res["t"]) != 0:
+            scale = T.find_scale_from_depth(c["kp_ref"], c["kp_cur"], np.linalg.inv(pose), c["depth_cur"], c["K"],
+                                            method="abs_diff")
+            assert abs(scale - float(g[tag + "_scale"])) <= 1e-12 * abs(scale), tag
+        else:
+            rejected += 1
+            assert float(g[tag + "_scale"]) == -2.0
+        st = np.random.get_state()
+        assert np.array_equal(np.r_[st[1].astype(np.uint32), np.uint32(st[2])], g[tag + "_rng_after"]), tag
+    assert rejected == 1
 
 
 def flow_case(g, tag):

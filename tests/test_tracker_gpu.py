@@ -67,6 +67,26 @@ def test_local_bestn_bit_exact(gpu, trk, h, w, seed, frac):
         assert np.array_equal(kp2[:n.value], ref["kp2_best"][0])
 
 
+@pytest.mark.parametrize("h,w,seed,frac,thre", [(192, 640, 21, 0.6, 0.02), (376, 1241, 22, 0.35, 0.01), (100, 130, 23, 0.05, 0.02),
+                                                 (376, 1241, 24, 0.35, 0.003)])
+def test_local_bestn_flow_ratio_bit_exact(gpu, trk, h, w, seed, frac, thre):
+    """cfg.kp_selection.local_bestN.score_method 'flow_ratio' (dfvo_kp_local_bestn_ex): values and order against the oracle
+    (pinned to the reference's kp_selection.py fixture), including pixels with zero flow (ratio inf / nan: never selected)"""
+    from golden.make_golden import kp_ratio_case
+    diff, flow = kp_ratio_case(h, w, seed, frac)
+    ref = T.local_bestN(flow, diff, thre=thre, score_method="flow_ratio")
+    kp1, kp2 = np.zeros((2000, 2)), np.zeros((2000, 2))
+    n, good = C.c_int(), C.c_int()
+    gpu.check(gpu.lib().dfvo_kp_local_bestn_ex(trk, gpu.as_ptr(np.ascontiguousarray(flow)),
+                                               gpu.as_ptr(np.ascontiguousarray(diff[..., 0])), h, w, 10, 10, 2000, thre, 1,
+                                               gpu.as_ptr(kp1), gpu.as_ptr(kp2), C.byref(n), C.byref(good)))
+    assert bool(good.value) == bool(ref["good_kp_found"])
+    if ref["good_kp_found"]:
+        assert n.value == ref["kp1_best"].shape[1]
+        assert np.array_equal(kp1[:n.value], ref["kp1_best"][0])
+        assert np.array_equal(kp2[:n.value], ref["kp2_best"][0])
+
+
 @pytest.mark.parametrize("h,w,seed,levels", [(376, 1241, 41, 8), (376, 1241, 42, 64), (192, 640, 43, 3), (376, 1241, 44, 1000)])
 def test_local_bestn_heavy_ties(gpu, trk, h, w, seed, levels):
     """quantised consistency maps: most candidates of a cell tie with the pivot, which drives the workgroup-parallel
@@ -227,6 +247,55 @@ def test_compute_pose_2d2d_flow_validity(gpu, trk, tag):
     assert np.array_equal(R, ref["R"]) and np.array_equal(t, ref["t"])
     assert np.array_equal(R, pose[:3, :3]) and np.array_equal(t, pose[:3, 3:])
     assert np.array_equal(pull_rng(gpu, trk), np_state()), "RandomState diverged"
+    assert np.array_equal(pull_rng(gpu, trk), g[tag + "_rng_after"])
+
+
+@pytest.mark.parametrize("tag", list("abpd"))
+def test_compute_pose_2d2d_homo_ratio_and_abs_diff_scale(gpu, trk, tag):
+    """e_tracker.validity.method 'homo_ratio' and scale_recovery.ransac.method 'abs_diff' (E_tracker.py:186-194,243-250,
+    631-635) against the reference fixture and the oracle: pose, inlier mask, per-repeat counts / ratios bit-exact, the
+    least-squares scale to 1e-12 (sklearn goes through LAPACK), RandomState afterwards identical"""
+    import os
+    from golden.make_golden import variant_case
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "e_tracker_variants.npz"))
+    c = variant_case(tag)
+    kp_ref, kp_cur, K = c["kp_ref"], c["kp_cur"], c["K"]
+    np.random.seed(4869 + c["seed"])
+    push_rng(gpu, trk)
+    ref = T.compute_pose_2d2d(kp_ref, kp_cur, K, validity="homo_ratio", validity_thre=0.4)
+    out, inl = _pose2d2d(gpu, trk, kp_ref, kp_cur, K, validity_method=2, validity_thre=0.4)
+    R = np.array(out.R[:]).reshape(3, 3)
+    t = np.array(out.t[:]).reshape(3, 1)
+    print("homo_ratio %s: H inliers %d | oracle reps %s ratio %s valid %s | hip reps %s ratio %s valid %s" % (
+        tag, ref["h_inliers"], ref["rep_inliers"], np.round(ref["rep_ratio"], 4), ref["rep_valid"],
+        list(out.rep_inliers[:5]), np.round(out.rep_gric[:5], 4), list(out.rep_valid[:5])))
+    assert out.h_gric == ref["h_inliers"]
+    assert list(out.rep_inliers[:5]) == ref["rep_inliers"]
+    assert list(out.rep_gric[:5]) == ref["rep_ratio"]
+    assert [bool(v) for v in out.rep_valid[:5]] == ref["rep_valid"]
+    pose = g[tag + "_pose"]
+    assert np.array_equal(inl, ref["inliers"]) and np.array_equal(inl, g[tag + "_inliers"])
+    assert np.array_equal(R, ref["R"]) and np.array_equal(t, ref["t"])
+    assert np.array_equal(R, pose[:3, :3]) and np.array_equal(t, pose[:3, 3:])
+    assert np.array_equal(pull_rng(gpu, trk), np_state()), "RandomState diverged"
+    if np.linalg.norm(t) != 0:
+        T21 = np.linalg.inv(pose)
+        diag = {}
+        s_ref = T.find_scale_from_depth(kp_ref, kp_cur, T21, c["depth_cur"], K, diag=diag, method="abs_diff")
+        h, w = c["depth_cur"].shape
+        scfg = gpu.ScaleCfg(cx=K[0, 2], cy=K[1, 2], fx=K[0, 0], fy=K[1, 1], min_samples=3, max_trials=100, stop_prob=0.99,
+                            thre=0.1, method=1)
+        scale = C.c_double()
+        info = np.zeros(4, np.int32)
+        gpu.check(gpu.lib().dfvo_find_scale_from_depth(trk, gpu.as_ptr(kp_ref), gpu.as_ptr(kp_cur), kp_ref.shape[0],
+                                                       gpu.as_ptr(np.ascontiguousarray(T21)), gpu.as_ptr(c["depth_cur"]), h, w,
+                                                       C.byref(scfg), C.byref(scale), gpu.as_ptr(info)))
+        print("abs_diff scale: oracle %.15g (valid %s trials %s inliers %s) | hip %.15g info %s" % (
+            s_ref, diag.get("n_valid"), diag.get("n_trials"), diag.get("n_inliers"), scale.value, info.tolist()))
+        assert info[0] == diag["n_valid"] and info[1] == diag["n_trials"] and info[2] == diag["n_inliers"]
+        assert abs(scale.value - s_ref) <= 1e-12 * abs(s_ref)
+        assert abs(scale.value - float(g[tag + "_scale"])) <= 1e-12 * abs(s_ref)
+        assert np.array_equal(pull_rng(gpu, trk), np_state()), "RandomState diverged after scale recovery"
     assert np.array_equal(pull_rng(gpu, trk), g[tag + "_rng_after"])
 
 

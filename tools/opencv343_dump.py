@@ -46,6 +46,10 @@ def two_view(n, out_frac, noise, seed, w=1241, h=376):
 CASES = [(2000, 0.3, 0.15, 31), (2000, 0.6, 0.3, 32), (600, 0.2, 0.1, 33), (2000, 0.97, 0.2, 34), (200, 0.0, 0.05, 35), (40, 0.1, 0.2, 36)]
 
 
+RESIZE_CASES = [(1, 376, 1241, 192, 640), (2, 370, 1226, 192, 640), (3, 96, 128, 48, 64), (4, 60, 80, 130, 210),
+                (5, 480, 640, 256, 320)]
+
+
 def main(out_path):
     import cv2
     if not cv2.__version__.startswith("3.4.3"):
@@ -76,6 +80,14 @@ def main(out_path):
         out[p + "pnp_ok"], out[p + "pnp_rvec"], out[p + "pnp_tvec"] = np.array(bool(ok)), rvec, tvec
         out[p + "pnp_inliers"] = inl if inl is not None else np.zeros((0, 1), np.int32)
         out[p + "rod"] = cv2.Rodrigues(rvec)[0]
+    # utils.py:51 (read_image): cv2.resize(img, (w, h)) of the uint8 frame, default INTER_LINEAR; dfvo.py:314-317 nearest
+    out["n_resize"] = len(RESIZE_CASES)
+    for ri, (seed, h, w, oh, ow) in enumerate(RESIZE_CASES):
+        img = np.random.Generator(np.random.PCG64(seed)).integers(0, 256, (h, w, 3), dtype=np.uint8)
+        out["r%d_spec" % ri] = np.array([seed, h, w, oh, ow])
+        out["r%d_img" % ri] = img
+        out["r%d_linear" % ri] = cv2.resize(img, (ow, oh))
+        out["r%d_nearest" % ri] = cv2.resize(img[..., 0].astype(np.float32), (ow, oh), interpolation=cv2.INTER_NEAREST)
     # cv::RNG: not exposed in Python; findEssentialMat's subset stream is exercised through the masks above
     np.savez_compressed(out_path, **out)
     print("wrote", out_path, "with OpenCV", cv2.__version__)
