@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64 * WC * WR, 2) void conv_win_f16s_kernel(const Co
     const int ty0 = (trem / tiles_x) * TH, tx0 = (trem % tiles_x) * TW;
     const int n0 = blockIdx.y * BN;
     const int nchunk0 = (p.G0 + 3) >> 2, nchunk1 = (p.G1 + 3) >> 2, nchunks = nchunk0 + nchunk1;
-    const bool nt = p.force_splits == -7;  // (experiment switch, see launch_f16s)
+    const bool nt = (p.force_splits & 1) != 0;  // (experiment switch, see launch_f16s)
 
     // window items of this thread: (pixel, 4-channel group within the chunk).  Their addresses are recomputed at every chunk
     // (a few dozen integer operations against 27 TC TR MFMAs) instead of living in 4 W_CNT registers for the whole kernel:
@@ -116,17 +116,25 @@ __global__ __launch_bounds__(64 * WC * WR, 2) void conv_win_f16s_kernel(const Co
             }
         }
     };
-    // weight fragments: row (cout) = lane & 31 of block tc, k-block = lane >> 5; 64 bytes per (tap, chunk, cout)
-    const unsigned short* wbase = p.wf16 + ((size_t)(n0 + wc * TC * 32 + lp) * 32 + kb * 8);
+    // weight fragments: row (cout) = lane & 31 of block tc, k-block = lane >> 5.  Packed per (tap, chunk, 32-cout block) as
+    // [plane][k-block][cout][8 halves]: the 64 lanes of one load instruction read 1 KB of consecutive bytes, lane l its
+    // 16 bytes at 16 l (a [cout][plane][k] order made every lane quad touch four different 64-byte segments)
+    const unsigned short* wbase = p.wf16 + ((size_t)(n0 + wc * TC * 32) * 32 + (kb * 32 + lp) * 8);
     const size_t w_chunk_stride = (size_t)p.wf16_cout_pad * 32;  // halves per (tap, chunk)
-    h16x8 wa[2][TC][2];  // [register stage][cout block][plane]: fetched one tap ahead (a ring of three, two taps ahead, does
-                         // not fit: 128 accumulator + 48 ring + 16 pixel-fragment + window staging registers spill at 256)
+    // [register stage][cout block][plane].  Memory operations retire in order (one vmcnt): waiting for a weight fragment also
+    // waits for every older load, so the window loads of the next chunk -- HBM latency -- get exactly as many taps of slack
+    // as the fragments are fetched ahead.  One cout block per wave (TC == 1) leaves room for a ring of three = two taps ahead
+    // (9 taps = 3 turns of the ring: the stage of a tap is a compile-time constant and nothing is copied at the chunk end);
+    // TC == 2 keeps two stages, one tap ahead (a third would spill: 128 accumulator + 48 ring + 16 pixel-fragment +
+    // window staging registers)
+    constexpr int R = TC == 1 ? 3 : 2;
+    h16x8 wa[R][TC][2];
     auto load_w = [&](int stage, int tap, int c) {
         const unsigned short* g = wbase + ((size_t)tap * nchunks + c) * w_chunk_stride;
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
             wa[stage][i][0] = *reinterpret_cast<const h16x8*>(g + (size_t)i * 32 * 32);
-            wa[stage][i][1] = *reinterpret_cast<const h16x8*>(g + (size_t)i * 32 * 32 + 16);
+            wa[stage][i][1] = *reinterpret_cast<const h16x8*>(g + (size_t)i * 32 * 32 + 512);
         }
     };
 
@@ -140,21 +148,28 @@ __global__ __launch_bounds__(64 * WC * WR, 2) void conv_win_f16s_kernel(const Co
 
     load_window(0);
     load_w(0, 0, 0);
+    if (R == 3) load_w(1, 1, 0);
     store_window(lds);
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
         const float* Wc = lds + (c & 1) * WIN;
         float* Wn = lds + ((c + 1) & 1) * WIN;
         const bool next_chunk = c + 1 < nchunks;
-        if (next_chunk) load_window(c + 1);
+        const int c_next = c + 1;
+        if (next_chunk) load_window(c_next);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - ky * 3;
-            const int cur = tap & 1;  // compile-time register stage (the loop is fully unrolled)
-            if (tap < 8)
+            const int cur = R == 3 ? tap % 3 : (tap & 1);  // compile-time register stage (the loop is fully unrolled)
+            if (R == 3) {
+                if (tap < 7)
+                    load_w((tap + 2) % 3, tap + 2, c);
+                else if (next_chunk)
+                    load_w((tap + 2) % 3, tap - 7, c_next);
+            } else if (tap < 8)
                 load_w(cur ^ 1, tap + 1, c);
             else if (next_chunk)
-                load_w(1, 0, c + 1);  // tap 8 runs from stage 0: the next chunk's first fragments land in stage 1 ...
+                load_w(1, 0, c_next);  // tap 8 runs from stage 0: the next chunk's first fragments land in stage 1 ...
             // keep the fetch HERE: left alone, the scheduler sinks these loads below the tap's last MFMA (it then needs one
             // register set instead of two) and the L2 round trip is exposed at every tap -- measured 30 % matrix-pipe busy
             __builtin_amdgcn_sched_barrier(0);
@@ -183,11 +198,12 @@ __global__ __launch_bounds__(64 * WC * WR, 2) void conv_win_f16s_kernel(const Co
                     am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][i][0], xb[j][0], am[i][j], 0, 0, 0);
             if (tap == 4 && next_chunk) store_window(Wn);
         }
+        if (R == 2)
 #pragma unroll
-        for (int i = 0; i < TC; ++i) {  // ... and move to stage 0, where tap 0 expects them (2 TC register-quad copies per chunk)
-            wa[0][i][0] = wa[1][i][0];
-            wa[0][i][1] = wa[1][i][1];
-        }
+            for (int i = 0; i < TC; ++i) {  // ... and move to stage 0, where tap 0 expects them (2 TC register-quad copies per chunk)
+                wa[0][i][0] = wa[1][i][0];
+                wa[0][i][1] = wa[1][i][1];
+            }
         __syncthreads();
     }
 
@@ -261,7 +277,7 @@ static int launch_f16s_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) 
 static int launch_f16s(const ConvParams& p_in, hipStream_t stream, int cfg_id) {
     ConvParams p = p_in;
     static const int nt_mode = getenv("DFVO_F16S_NT") ? atoi(getenv("DFVO_F16S_NT")) : 0;
-    p.force_splits = nt_mode ? -7 : 0;  // force_splits is unused by this kernel: carries the streaming-load experiment switch
+    p.force_splits = nt_mode ? 1 : 0;  // force_splits is unused by this kernel: carries the streaming-load experiment switch
     static const long long fill = getenv("DFVO_F16S_FILL") ? atoll(getenv("DFVO_F16S_FILL")) : 400;
     // 8-wave tiles (twice the pixels per workgroup = half the weight re-reads from L2): measured neutral, off by default
     static const long long fill8 = getenv("DFVO_F16S_FILL8") ? atoll(getenv("DFVO_F16S_FILL8")) : (1LL << 40);
@@ -308,8 +324,9 @@ size_t conv_pack_weights_f16s(const float* w, int cout, int c0, int c1, const fl
                     const int ci = s1 ? c0 + ch : ch;
                     float v = w[((size_t)co * cin + ci) * 9 + tap];
                     if (fold_scale) v *= fold_scale[co];
-                    unsigned short* o = out + (((size_t)tap * nch + c) * cp + co) * 32;
-                    f16s_split_host(v, o + k, o + 16 + k);
+                    // [tap][chunk][cout / 32][plane][k / 8][cout % 32][k % 8]
+                    unsigned short* o = out + (((size_t)tap * nch + c) * cp + (co & ~31)) * 32 + ((k >> 3) * 32 + (co & 31)) * 8 + (k & 7);
+                    f16s_split_host(v, o, o + 512);
                 }
     return total;
 }

@@ -2,6 +2,7 @@
 // Activations are NHWC float32; "cs" = floats per pixel of the underlying
 // buffer, "co" = channel offset of the view inside the pixel.
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
@@ -60,7 +61,7 @@ struct ConvParams {
     size_t wsp_plane;
     int wsp_planes;
     // f16 hi/lo planes of the weights in the split window kernel's layout (DFVO_CONV_PRECISION=f16x3, 3x3 layers only):
-    // [tap][16-channel chunk][wf16_cout_pad][plane hi, lo][16] halves, see conv_pack_weights_f16s
+    // [tap][16-channel chunk][wf16_cout_pad / 32][plane hi, lo][k / 8][32 couts][8] halves, see conv_pack_weights_f16s
     const unsigned short* wf16;
     int wf16_cout_pad;
     int cout, cout_pad, ksteps;
@@ -84,6 +85,20 @@ struct ConvParams {
 
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Stream priorities (tuning aid, off by default).  The solver stage is a chain of ~40 dependent launches of one or a few
+// workgroups racing against net kernels that keep every CU full, so raising its streams' priority looked promising;
+// measured on MI355X (bench.py, 60 pairs) it is neutral for the chain's own stream and costs 3-9 % for the others:
+// DFVO_SOLVER_PRIORITY bit mask -> 0: 231.7 frames/s, 1: 231.7, 2: 225.4, 3: 222.8, 4: 214.2, 8 (nets lowest): 212.3.
+static inline hipError_t create_solver_stream(hipStream_t* s, int which = 1) {
+    // which: 1 the RNG-ordered chain's stream, 2 its side streams, 4 the prefetch streams, 8 a net stream (lowest priority)
+    static const int mask = getenv("DFVO_SOLVER_PRIORITY") ? atoi(getenv("DFVO_SOLVER_PRIORITY")) : 0;
+    if (!(mask & which)) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    int least = 0, greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (e != hipSuccess) return e;
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, which == 8 ? least : greatest);
+}
 
 // number of K-steps (16 k-values = 4 groups of 4 channels) for a conv
 static inline int conv_ksteps(int kh, int kw, int c0, int c1) {

@@ -72,9 +72,8 @@ int dfvo_pipeline_create(const dfvo_pipeline_cfg* cfg, dfvo_pipeline** out) {
         delete p;
         return rc;
     };
-    if (hipStreamCreateWithFlags(&p->s_flow, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&p->s_depth, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&p->s_trk, hipStreamNonBlocking) != hipSuccess) {
+    if (create_solver_stream(&p->s_flow, 8) != hipSuccess || create_solver_stream(&p->s_depth, 8) != hipSuccess ||
+        create_solver_stream(&p->s_trk) != hipSuccess) {
         dfvo::set_last_error("dfvo_pipeline_create: hipStreamCreate failed (no GPU?)");
         return fail(DFVO_ERR_HIP);
     }
@@ -91,7 +90,7 @@ int dfvo_pipeline_create(const dfvo_pipeline_cfg* cfg, dfvo_pipeline** out) {
     if (p->flow_instances < 1) p->flow_instances = 1;
     if (p->flow_instances > DFVO_PIPELINE_SLOTS) p->flow_instances = DFVO_PIPELINE_SLOTS;
     for (int i = 0; i + 1 < p->flow_instances; ++i) {
-        if (hipStreamCreateWithFlags(&p->s_flow_x[i], hipStreamNonBlocking) != hipSuccess) return fail(DFVO_ERR_HIP);
+        if (create_solver_stream(&p->s_flow_x[i], 8) != hipSuccess) return fail(DFVO_ERR_HIP);
         rc = p->flow_x[i].init(p->H, p->W, p->s_flow_x[i]);
         if (rc != DFVO_OK) return fail(rc);
     }
@@ -107,7 +106,7 @@ int dfvo_pipeline_create(const dfvo_pipeline_cfg* cfg, dfvo_pipeline** out) {
         if (rc != DFVO_OK) return fail(rc);
     }
     for (int i = 0; i < 2; i++)
-        if (hipStreamCreateWithFlags(&p->s_pre[i], hipStreamNonBlocking) != hipSuccess) return fail(DFVO_ERR_HIP);
+        if (create_solver_stream(&p->s_pre[i], 4) != hipSuccess) return fail(DFVO_ERR_HIP);
     for (int i = 0; i < DFVO_PIPELINE_SLOTS; i++) {
         if (hipEventCreateWithFlags(&p->e_pre[i], hipEventDisableTiming) != hipSuccess ||
             hipHostMalloc((void**)&p->h_info[i], 4 * sizeof(int), hipHostMallocDefault) != hipSuccess)

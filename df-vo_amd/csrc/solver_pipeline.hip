@@ -1620,7 +1620,7 @@ int TrackerBuffers::init() {
     static const int n_streams = getenv("DFVO_REP_STREAMS") ? atoi(getenv("DFVO_REP_STREAMS")) : NUM_REP_STREAMS;
     for (int r = 0; r < MAX_REP; r++) {
         if (r < n_streams)
-            DFVO_HIP_CHECK(hipStreamCreateWithFlags(&s_rep[r], hipStreamNonBlocking));
+            DFVO_HIP_CHECK(create_solver_stream(&s_rep[r], 2));
         else
             s_rep[r] = s_rep[r % n_streams];
         DFVO_HIP_CHECK(hipEventCreateWithFlags(&ev_rep[r], hipEventDisableTiming));

@@ -20,6 +20,8 @@ LAYERS = [("L2 128->128", 2, 192, 624, 128, 0, 128), ("L2 64+66->128", 2, 192, 6
           ("L2 49->128", 2, 192, 624, 49, 0, 128), ("L2 128->64", 2, 192, 624, 128, 0, 64), ("L2 64->64", 2, 192, 624, 64, 0, 64),
           ("L2 64->32", 2, 192, 624, 64, 0, 32), ("L2 32->32", 2, 192, 624, 32, 0, 32), ("L3 128->128", 2, 96, 312, 128, 0, 128),
           ("L3 128->64", 2, 96, 312, 128, 0, 64), ("L4 128->128", 2, 48, 156, 128, 0, 128)]
+if os.environ.get("ONLY"):
+    LAYERS = [l for l in LAYERS if l[0] == os.environ["ONLY"]]
 g = torch.Generator().manual_seed(1)
 for name, n, h, w, c0, c1, cout in LAYERS:
     x0 = torch.randn(n, c0, h, w, generator=g)

@@ -26,6 +26,17 @@ def main():
     for k in range(3):
         pipe.enqueue_nets(k % 4, d_ref, d_cur, d_feed)
     pipe.sync()
+    if os.environ.get("SAMPLE"):  # shader clock / power while the loop below runs (rocm-smi from a side thread)
+        import subprocess
+        import threading
+
+        def sample():
+            time.sleep(1.5)
+            for _ in range(6):
+                out = subprocess.run("rocm-smi --showclocks --showpower 2>&1 | grep -i 'sclk\\|Power (W)' | tr '\n' ' '",
+                                     shell=True, capture_output=True, text=True).stdout
+                print("  smi:", " ".join(out.split()), flush=True)
+        threading.Thread(target=sample, daemon=True).start()
     t0 = time.perf_counter()
     for k in range(n):
         pipe.enqueue_nets(k % 4, d_ref, d_cur, d_feed)
