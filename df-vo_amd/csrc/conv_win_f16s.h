@@ -73,48 +73,52 @@ __global__ __launch_bounds__(64 * WC * WR, 2) void conv_win_f16s_kernel(const Co
     // the accumulators and the weight ring need the register file
     f32x4 rw[W_CNT];
     unsigned rwv = 0;  // bit r: item r holds real data (inside the image, channel group exists)
-    auto load_window = [&](int c) {
+    // One item per tap: item r of the next chunk is loaded at tap r and written to LDS (split into planes) at tap
+    // 9 - W_CNT + r, so that the ~30 VALU instructions of a split sit in the shadow of that tap's MFMAs instead of all
+    // W_CNT splits queueing up at one tap, and every load has at least three taps to arrive.
+    auto load_window_item = [&](int c, int r) {
         const bool s1 = c >= nchunk0;
         const int cg0 = s1 ? (c - nchunk0) * 4 : c * 4;
         const int Gs = s1 ? p.G1 : p.G0;
         const float* base = s1 ? p.src1 : p.src0;
         const int sh = s1 ? 0 : p.up0;
         const int cs = s1 ? p.cs1 : p.cs0, co = s1 ? p.co1 : p.co0;
-        rwv = 0;
-#pragma unroll
-        for (int r = 0; r < W_CNT; ++r) {
-            const int id = t + NT * r;
-            const int px = id >> 2, q = id & 3;
-            const int wy = px / WW, wx = px - wy * WW;
-            int iy = ty0 - 1 + wy, ix = tx0 - 1 + wx;
-            bool v = id < W_ITEMS && (cg0 + q) < Gs;
-            if (p.pad_mode == PAD_REFLECT) {
-                iy = reflect_idx(iy, p.H);
-                ix = reflect_idx(ix, p.W);
-            }
-            v = v && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            iy = iy < 0 ? 0 : (iy >= p.H ? p.H - 1 : iy);
-            ix = ix < 0 ? 0 : (ix >= p.W ? p.W - 1 : ix);
-            const int off = (((n * (p.H >> sh) + (iy >> sh)) * (p.W >> sh) + (ix >> sh)) * cs) + co + (v ? (cg0 + q) * 4 : 0);
-            // masked lanes re-read channel group 0 of a valid pixel.  Streaming (non-temporal) policy: the activations pass
-            // through once, the layer's weights are re-read by every workgroup and should keep the L2
-            rw[r] = nt ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + off))
-                       : *reinterpret_cast<const f32x4*>(base + off);
-            rwv |= (v ? 1u : 0u) << r;
+        const int id = t + NT * r;
+        const int px = id >> 2, q = id & 3;
+        const int wy = px / WW, wx = px - wy * WW;
+        int iy = ty0 - 1 + wy, ix = tx0 - 1 + wx;
+        bool v = id < W_ITEMS && (cg0 + q) < Gs;
+        if (p.pad_mode == PAD_REFLECT) {
+            iy = reflect_idx(iy, p.H);
+            ix = reflect_idx(ix, p.W);
         }
+        v = v && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        iy = iy < 0 ? 0 : (iy >= p.H ? p.H - 1 : iy);
+        ix = ix < 0 ? 0 : (ix >= p.W ? p.W - 1 : ix);
+        const int off = (((n * (p.H >> sh) + (iy >> sh)) * (p.W >> sh) + (ix >> sh)) * cs) + co + (v ? (cg0 + q) * 4 : 0);
+        // masked lanes re-read channel group 0 of a valid pixel.  Streaming (non-temporal) policy: the activations pass
+        // through once, the layer's weights are re-read by every workgroup and should keep the L2
+        rw[r] = nt ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + off))
+                   : *reinterpret_cast<const f32x4*>(base + off);
+        rwv = (rwv & ~(1u << r)) | ((v ? 1u : 0u) << r);
+    };
+    auto store_window_item = [&](float* W, int r) {
+        const int id = t + NT * r;
+        if (id < W_ITEMS) {
+            h16x4 hi, lo;
+            split_f16_planes(((rwv >> r) & 1u) ? rw[r] : f32x4{0.f, 0.f, 0.f, 0.f}, &hi, &lo);
+            float* dst = W + (id >> 2) * PS + (id & 3) * 2;  // hi plane: dwords [0, 8), lo plane: [8, 16) of the pixel
+            *reinterpret_cast<h16x4*>(dst) = hi;
+            *reinterpret_cast<h16x4*>(dst + 8) = lo;
+        }
+    };
+    auto load_window = [&](int c) {
+#pragma unroll
+        for (int r = 0; r < W_CNT; ++r) load_window_item(c, r);
     };
     auto store_window = [&](float* W) {
 #pragma unroll
-        for (int r = 0; r < W_CNT; ++r) {
-            const int id = t + NT * r;
-            if (id < W_ITEMS) {
-                h16x4 hi, lo;
-                split_f16_planes(((rwv >> r) & 1u) ? rw[r] : f32x4{0.f, 0.f, 0.f, 0.f}, &hi, &lo);
-                float* dst = W + (id >> 2) * PS + (id & 3) * 2;  // hi plane: dwords [0, 8), lo plane: [8, 16) of the pixel
-                *reinterpret_cast<h16x4*>(dst) = hi;
-                *reinterpret_cast<h16x4*>(dst + 8) = lo;
-            }
-        }
+        for (int r = 0; r < W_CNT; ++r) store_window_item(W, r);
     };
     // weight fragments: row (cout) = lane & 31 of block tc, k-block = lane >> 5.  Packed per (tap, chunk, 32-cout block) as
     // [plane][k-block][cout][8 halves]: the 64 lanes of one load instruction read 1 KB of consecutive bytes, lane l its
@@ -156,7 +160,8 @@ __global__ __launch_bounds__(64 * WC * WR, 2) void conv_win_f16s_kernel(const Co
         float* Wn = lds + ((c + 1) & 1) * WIN;
         const bool next_chunk = c + 1 < nchunks;
         const int c_next = c + 1;
-        if (next_chunk) load_window(c_next);
+        constexpr bool SPREAD = W_CNT <= 6;  // (always, with the tiles instantiated below)
+        if (next_chunk && !SPREAD) load_window(c_next);
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap - ky * 3;
@@ -170,6 +175,7 @@ __global__ __launch_bounds__(64 * WC * WR, 2) void conv_win_f16s_kernel(const Co
                 load_w(cur ^ 1, tap + 1, c);
             else if (next_chunk)
                 load_w(1, 0, c_next);  // tap 8 runs from stage 0: the next chunk's first fragments land in stage 1 ...
+            if (SPREAD && next_chunk && tap < W_CNT) load_window_item(c_next, tap);
             // keep the fetch HERE: left alone, the scheduler sinks these loads below the tap's last MFMA (it then needs one
             // register set instead of two) and the L2 round trip is exposed at every tap -- measured 30 % matrix-pipe busy
             __builtin_amdgcn_sched_barrier(0);
@@ -196,7 +202,11 @@ __global__ __launch_bounds__(64 * WC * WR, 2) void conv_win_f16s_kernel(const Co
 #pragma unroll
                 for (int j = 0; j < TR; ++j)
                     am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][i][0], xb[j][0], am[i][j], 0, 0, 0);
-            if (tap == 4 && next_chunk) store_window(Wn);
+            if (SPREAD) {
+                if (next_chunk && tap >= 9 - W_CNT) store_window_item(Wn, tap - (9 - W_CNT));
+            } else if (tap == 4 && next_chunk) {
+                store_window(Wn);
+            }
         }
         if (R == 2)
 #pragma unroll
