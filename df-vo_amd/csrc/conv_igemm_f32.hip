@@ -76,6 +76,49 @@ __device__ __forceinline__ bool conv_vec_ok(const ConvParams& p) {
     return (((p.dst_cs | p.dst_co) & 3) == 0) && (!p.res || (((p.res_cs | p.res_co) & 3) == 0));
 }
 
+// Split-K finish inside the contracting kernel.  After a workgroup has written its partial tile to the workspace it draws
+// a ticket for that tile; whoever draws the last one (all z-slices are then written) reduces the partials and runs the
+// epilogue.  The sum runs over the slices in slice order -- the order of conv_splitk_epilogue -- so the result does not
+// depend on which workgroup happens to be last.
+// The z-slices of a tile run on different XCDs, whose L2s are not coherent with each other.  A release / acquire fence
+// pair would be the textbook handoff, but at device scope it writes back and invalidates the whole L2 -- measured: the
+// nets 2x slower, every concurrent kernel pays.  Instead the partials themselves travel with device-scope relaxed atomic
+// stores / loads (write-through, L2-bypassing accesses), the writer drains them (vmcnt 0) before its ticket, and the
+// ticket is a relaxed device-scope RMW.  The winner leaves the counter at zero for the next launch.
+__device__ __forceinline__ void splitk_store(float* dst, f32x4 v) {
+    union {
+        float f[4];
+        unsigned long long u[2];
+    } c;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c.f[e] = v[e];
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst), c.u[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst) + 1, c.u[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ f32x4 splitk_load(const float* src) {
+    union {
+        float f[4];
+        unsigned long long u[2];
+    } c;
+    c.u[0] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(src), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    c.u[1] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(src) + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return f32x4{c.f[0], c.f[1], c.f[2], c.f[3]};
+}
+// Every thread of the workgroup must call this, after its splitk_store()s.
+__device__ __forceinline__ bool splitk_last_arriver(const ConvParams& p, unsigned tile) {
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's write-through stores have been acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned prev = __hip_atomic_fetch_add(&p.tile_flags[tile], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = prev + 1 == gridDim.z ? 1 : 0;
+        if (last) __hip_atomic_store(&p.tile_flags[tile], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = last;
+    }
+    __syncthreads();
+    return s_last != 0;
+}
+
 // k-group table entry built once per block in LDS: which tap / source / channel offset a k-group is
 struct KGroup {
     uint32_t tap;  // ky | kx << 8 | valid << 16 | src << 17
@@ -266,10 +309,29 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int m = m0 + wm * TM * 16 + i * 16 + li;
-                if (m < M) *reinterpret_cast<f32x4*>(wsz + (size_t)m * p.cout_pad + col0) = acc[i][j];
+                if (m >= M) continue;
+                if (p.tile_flags)
+                    splitk_store(wsz + (size_t)m * p.cout_pad + col0, acc[i][j]);
+                else
+                    *reinterpret_cast<f32x4*>(wsz + (size_t)m * p.cout_pad + col0) = acc[i][j];
             }
         }
-        return;
+        if (!p.tile_flags) return;  // reduced by conv_splitk_epilogue
+        if (!splitk_last_arriver(p, blockIdx.y * gridDim.x + blockIdx.x)) return;
+        const size_t zs = (size_t)M * p.cout_pad;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col0 = n0 + wn * TN * 16 + j * 16 + kq * 4;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = m0 + wm * TM * 16 + i * 16 + li;
+                if (m >= M) continue;
+                const float* w0 = p.ws + (size_t)m * p.cout_pad + col0;
+                f32x4 v = splitk_load(w0);
+                for (int z = 1; z < (int)gridDim.z; ++z) v += splitk_load(w0 + z * zs);
+                acc[i][j] = v;
+            }
+        }
     }
     const bool vec_ok = conv_vec_ok(p);
 #pragma unroll
@@ -457,11 +519,30 @@ __global__ __launch_bounds__(256) void conv_win_f32_kernel(const ConvParams p) {
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int oy = ty0 + wm * TM + i;
-                if (oy < p.Ho && ox < p.Wo)
-                    *reinterpret_cast<f32x4*>(wsz + (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.cout_pad + col0) = acc[i][j];
+                if (oy >= p.Ho || ox >= p.Wo) continue;
+                float* wd = wsz + (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.cout_pad + col0;
+                if (p.tile_flags)
+                    splitk_store(wd, acc[i][j]);
+                else
+                    *reinterpret_cast<f32x4*>(wd) = acc[i][j];
             }
         }
-        return;
+        if (!p.tile_flags) return;  // reduced by conv_splitk_epilogue
+        if (!splitk_last_arriver(p, blockIdx.y * gridDim.x + blockIdx.x)) return;
+        const size_t zs = Mtot * p.cout_pad;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col0 = n0 + wn * TN * 16 + j * 16 + kq * 4;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int oy = ty0 + wm * TM + i;
+                if (oy >= p.Ho || ox >= p.Wo) continue;
+                const float* w0 = p.ws + (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.cout_pad + col0;
+                f32x4 v = splitk_load(w0);
+                for (int z = 1; z < (int)gridDim.z; ++z) v += splitk_load(w0 + z * zs);
+                acc[i][j] = v;
+            }
+        }
     }
     const bool vec_ok = conv_vec_ok(p);
 #pragma unroll
@@ -1085,9 +1166,12 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) {
         pe.flops = 0;
         DFVO_HIP_CHECK(hipEventRecord(pe.e0, stream));
     }
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<WM, WN, TM, TN>), grid, dim3(256), 0, stream, p);
+    ConvParams pk = p;  // in-kernel split-K finish when the tiles have tickets (else: second launch below)
+    const bool fused = splits > 1 && pk.tile_flags && (long long)grid.x * grid.y <= pk.tile_flags_n;
+    if (!fused) pk.tile_flags = nullptr;
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<WM, WN, TM, TN>), grid, dim3(256), 0, stream, pk);
     DFVO_HIP_CHECK(hipGetLastError());
-    if (splits > 1) {
+    if (splits > 1 && !fused) {
         const int cols = p.dst_zero_to > p.cout ? p.dst_zero_to : p.cout;
         const long long total = M * cols;
         hipLaunchKernelGGL(conv_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p, splits);
@@ -1134,12 +1218,15 @@ static int launch_win3(const ConvParams& p, hipStream_t stream, int cfg_id) {
         pe.cfg = cfg_id;
         DFVO_HIP_CHECK(hipEventRecord(pe.e0, stream));
     }
+    ConvParams pk = p;  // in-kernel split-K finish (exact fp32 kernel) when the tiles have tickets
+    const bool fused = NPL == 0 && splits > 1 && pk.tile_flags && blocks <= pk.tile_flags_n;
+    if (!fused) pk.tile_flags = nullptr;
     if constexpr (NPL == 0)
-        hipLaunchKernelGGL((conv_win_f32_kernel<WM, WN, TM, TN, KS>), grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((conv_win_f32_kernel<WM, WN, TM, TN, KS>), grid, dim3(256), 0, stream, pk);
     else
-        hipLaunchKernelGGL((conv_win_bf16s_kernel<WM, WN, TM, TN, KS, NPL>), grid, dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((conv_win_bf16s_kernel<WM, WN, TM, TN, KS, NPL>), grid, dim3(256), 0, stream, pk);
     DFVO_HIP_CHECK(hipGetLastError());
-    if (splits > 1) {
+    if (splits > 1 && !fused) {
         const int cols = p.dst_zero_to > p.cout ? p.dst_zero_to : p.cout;
         const long long total = M * cols;
         hipLaunchKernelGGL(conv_splitk_epilogue, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p, splits);

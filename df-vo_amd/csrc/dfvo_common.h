@@ -77,6 +77,10 @@ struct ConvParams {
     // split-K workspace (optional): partial accumulators [splits][M][cout_pad]
     float* ws;
     size_t ws_floats;
+    // split-K tickets (optional, zero between launches): one counter per output tile.  With them the workgroup that writes
+    // a tile's last partial also reduces and finishes the tile -- no second launch (see splitk_last_arriver)
+    unsigned* tile_flags;
+    int tile_flags_n;
     // 2 * MACs of the unpadded convolution (bookkeeping for the bench's roofline leg; not read on device)
     double useful_flops;
     // launch overrides chosen by the per-layer autotuner (0 = heuristic): M tile rows, split-K factor

@@ -197,6 +197,8 @@ static int autotune_conv(const ConvLayer& L, ConvParams p, hipStream_t s) {
     return DFVO_OK;
 }
 
+constexpr int SPLITK_TICKETS = 4096;  // split-K never runs with 600 or more tiles (conv_pick_splits)
+
 int run_conv(const ConvLayer& L, int N, int H, int W, View s0, int up0, View s1, const float* res, int res_cs,
              int res_co, float* dst, int dst_cs, int dst_co, int dst_zero_to, hipStream_t s, double* flops,
              const DevBuf* splitk_ws) {
@@ -244,6 +246,16 @@ int run_conv(const ConvLayer& L, int N, int H, int W, View s0, int up0, View s1,
     p.dst_zero_to = dst_zero_to;
     p.ws = splitk_ws ? splitk_ws->p : nullptr;
     p.ws_floats = splitk_ws ? splitk_ws->n : 0;
+    p.tile_flags = nullptr;
+    p.tile_flags_n = 0;
+    if (splitk_ws && splitk_ws->n > (size_t)(2 * SPLITK_TICKETS)) {  // the tail of the (zero-filled) workspace holds the tickets
+        static const bool fused = !(getenv("DFVO_SPLITK_FUSED") && atoi(getenv("DFVO_SPLITK_FUSED")) == 0);
+        p.ws_floats = splitk_ws->n - SPLITK_TICKETS;
+        if (fused) {
+            p.tile_flags = reinterpret_cast<unsigned*>(splitk_ws->p + p.ws_floats);
+            p.tile_flags_n = SPLITK_TICKETS;
+        }
+    }
     p.useful_flops = 2.0 * (double)N * p.Ho * p.Wo * L.macs_per_pixel();
     if (flops) *flops += p.useful_flops;
     if (g_conv_autotune && !L.tuned) DFVO_TRY(autotune_conv(L, p, s));

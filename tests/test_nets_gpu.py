@@ -81,6 +81,52 @@ def test_flownet_vs_oracle(gpu, conv_precision, h, w):
     _flow_gate("flow diff %dx%d %s" % (h, w, conv_precision), diff, odiff[..., 0], tol=4e-3)
 
 
+_SPLITK_AB = r"""
+import ctypes as C, importlib, sys, numpy as np, torch
+sys.path.insert(0, %(tests)r); sys.path.insert(0, %(root)r)
+from oracle import nets_torch as O
+from synth import image_pair
+import test_nets_gpu as T
+capi = importlib.import_module("df-vo_amd.capi")
+lib = capi.lib()
+h, w = 192, 640
+sd = O.liteflownet_state_dict(4869)
+ref_img, cur_img = image_pair(h, w, seed=77)
+net, nh, nw = T.make_flownet(capi, h, w, sd)
+out = {}
+for rep in range(3):
+    fwd, bwd, diff = np.zeros((2, h, w), np.float32), np.zeros((2, h, w), np.float32), np.zeros((h, w), np.float32)
+    capi.check(lib.dfvo_flownet_forward_host(net, capi.as_ptr(ref_img), capi.as_ptr(cur_img), capi.as_ptr(fwd), capi.as_ptr(bwd),
+                                             capi.as_ptr(diff)))
+    out["fwd%%d" %% rep], out["bwd%%d" %% rep], out["diff%%d" %% rep] = fwd, bwd, diff
+dsd = O.monodepth2_state_dict(4869)
+np.savez(%(out)r, **out)
+"""
+
+
+def test_splitk_in_kernel_finish_equals_two_launch_reduction(gpu, tmp_path):
+    """the split-K layers (pyramid levels 3-6) reduced by the last-arriving workgroup inside the contracting kernel
+    (tile tickets) against the separate ordered-reduction launch (DFVO_SPLITK_FUSED=0): same slice order, so the flow
+    fields are identical bit for bit, and repeated passes reproduce themselves (no ordering race)"""
+    import os
+    import subprocess
+    import sys
+    tests = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+    for fused in ("0", "1"):
+        out = str(tmp_path / ("splitk_%s.npz" % fused))
+        env = dict(os.environ, DFVO_SPLITK_FUSED=fused, DFVO_CONV_PRECISION="fp32")
+        code = _SPLITK_AB % {"tests": tests, "root": os.path.dirname(tests), "out": out}
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[fused] = np.load(out)
+    for k in ("fwd", "bwd", "diff"):
+        for rep in (1, 2):
+            assert np.array_equal(res["1"][k + "0"], res["1"]["%s%d" % (k, rep)]), "fused finish not repeatable: %s" % k
+        assert np.array_equal(res["0"][k + "0"], res["1"][k + "0"]), "fused finish differs from the two-launch reduction: %s" % k
+    assert np.abs(res["1"]["fwd0"]).max() > 0.1
+
+
 def test_flownet_graph_replay_is_identical(gpu):
     lib = gpu.lib()
     h, w = 128, 224
