@@ -330,7 +330,7 @@ def main(argv=None):
         # from the committed rocprofv3 --pmc passes over this same command (tools/r2_pmc.sh -> tools/pmc_traffic.py:
         # FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes); None when no committed profile holds the kernel
         try:
-            pmc_file = "r2b_pmc_bench.json"
+            pmc_file = "r2c_pmc_bench.json"
             prof = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["kernels"]
             key = {19: "conv_win_f16s_kernel<"}.get(dom) or CFG_NAMES[dom].split(" ")[0].replace(
                 "conv_igemm_f32<", "conv_igemm_f32_kernel<").replace("conv_win3_f32<", "conv_win_f32_kernel<").replace(

@@ -318,18 +318,19 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
         }
         if (!p.tile_flags) return;  // reduced by conv_splitk_epilogue
         if (!splitk_last_arriver(p, blockIdx.y * gridDim.x + blockIdx.x)) return;
+        // slice by slice, all fragments of the thread per slice: the TM x TN loads of a slice are in flight together (they
+        // bypass the L2: microseconds each), every element still accumulates its slices in ascending order
         const size_t zs = (size_t)M * p.cout_pad;
+        for (int z = 0; z < (int)gridDim.z; ++z) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col0 = n0 + wn * TN * 16 + j * 16 + kq * 4;
+            for (int j = 0; j < TN; ++j) {
+                const int col0 = n0 + wn * TN * 16 + j * 16 + kq * 4;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int m = m0 + wm * TM * 16 + i * 16 + li;
-                if (m >= M) continue;
-                const float* w0 = p.ws + (size_t)m * p.cout_pad + col0;
-                f32x4 v = splitk_load(w0);
-                for (int z = 1; z < (int)gridDim.z; ++z) v += splitk_load(w0 + z * zs);
-                acc[i][j] = v;
+                for (int i = 0; i < TM; ++i) {
+                    const int m = m0 + wm * TM * 16 + i * 16 + li;
+                    const f32x4 v = splitk_load(p.ws + z * zs + (size_t)(m < M ? m : 0) * p.cout_pad + col0);
+                    acc[i][j] = z == 0 ? v : acc[i][j] + v;
+                }
             }
         }
     }
@@ -530,17 +531,18 @@ __global__ __launch_bounds__(256) void conv_win_f32_kernel(const ConvParams p) {
         if (!p.tile_flags) return;  // reduced by conv_splitk_epilogue
         if (!splitk_last_arriver(p, blockIdx.y * gridDim.x + blockIdx.x)) return;
         const size_t zs = Mtot * p.cout_pad;
+        const int oxc = ox < p.Wo ? ox : p.Wo - 1;
+        for (int z = 0; z < (int)gridDim.z; ++z) {  // (same order as in conv_igemm_f32_kernel)
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col0 = n0 + wn * TN * 16 + j * 16 + kq * 4;
+            for (int j = 0; j < TN; ++j) {
+                const int col0 = n0 + wn * TN * 16 + j * 16 + kq * 4;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int oy = ty0 + wm * TM + i;
-                if (oy >= p.Ho || ox >= p.Wo) continue;
-                const float* w0 = p.ws + (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.cout_pad + col0;
-                f32x4 v = splitk_load(w0);
-                for (int z = 1; z < (int)gridDim.z; ++z) v += splitk_load(w0 + z * zs);
-                acc[i][j] = v;
+                for (int i = 0; i < TM; ++i) {
+                    const int oy = ty0 + wm * TM + i;
+                    const int oyc = oy < p.Ho ? oy : p.Ho - 1;
+                    const f32x4 v = splitk_load(p.ws + z * zs + (((size_t)n * p.Ho + oyc) * p.Wo + oxc) * p.cout_pad + col0);
+                    acc[i][j] = z == 0 ? v : acc[i][j] + v;
+                }
             }
         }
     }

@@ -94,6 +94,25 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 // workgroups racing against net kernels that keep every CU full, so raising its streams' priority looked promising;
 // measured on MI355X (bench.py, 60 pairs) it is neutral for the chain's own stream and costs 3-9 % for the others:
 // DFVO_SOLVER_PRIORITY bit mask -> 0: 231.7 frames/s, 1: 231.7, 2: 225.4, 3: 222.8, 4: 214.2, 8 (nets lowest): 212.3.
+// Net streams with a few CUs left out (DFVO_NET_CU_RESERVE = CUs per 32-CU mask word, i.e. per XCD; default 0 = none), so
+// that the solver chain's small workgroups always find an idle CU (tuning aid).  Measured: 1 / 2 / 4 reserved CUs per
+// XCD -> 211.7 / 210.1 / 208.8 frames/s against 236.1 without; the chain's latency under load (3.75 ms, 2.1 ms with
+// the nets idle) did not move, so free CU slots are not what it waits for.
+static inline hipError_t create_net_stream(hipStream_t* s) {
+    static const int reserve = getenv("DFVO_NET_CU_RESERVE") ? atoi(getenv("DFVO_NET_CU_RESERVE")) : 0;
+    if (reserve <= 0 || reserve >= 32) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    hipDeviceProp_t prop;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return e;
+    const int words = (prop.multiProcessorCount + 31) / 32;
+    uint32_t mask[16];
+    for (int i = 0; i < 16; ++i) mask[i] = i < words ? ~((1u << reserve) - 1u) : 0u;
+    return hipExtStreamCreateWithCUMask(s, (uint32_t)(words < 16 ? words : 16), mask);
+}
+
 static inline hipError_t create_solver_stream(hipStream_t* s, int which = 1) {
     // which: 1 the RNG-ordered chain's stream, 2 its side streams, 4 the prefetch streams, 8 a net stream (lowest priority)
     static const int mask = getenv("DFVO_SOLVER_PRIORITY") ? atoi(getenv("DFVO_SOLVER_PRIORITY")) : 0;

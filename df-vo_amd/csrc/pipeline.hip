@@ -31,6 +31,7 @@ struct dfvo_pipeline {
     // (dfvo_pipeline_prefetch_track): two streams used alternately, per-slot completion event and pinned keypoint info
     hipStream_t s_pre[2] = {nullptr, nullptr};
     hipEvent_t e_pre[DFVO_PIPELINE_SLOTS] = {};
+    hipEvent_t e_ref = nullptr;  // reference depth of the first frame written (dfvo_pipeline_set_ref_image / _set_ref_depth)
     int* h_info[DFVO_PIPELINE_SLOTS] = {};
     bool prefetched[DFVO_PIPELINE_SLOTS] = {};
     hipStream_t s_flow = nullptr, s_depth = nullptr, s_trk = nullptr;
@@ -72,7 +73,7 @@ int dfvo_pipeline_create(const dfvo_pipeline_cfg* cfg, dfvo_pipeline** out) {
         delete p;
         return rc;
     };
-    if (create_solver_stream(&p->s_flow, 8) != hipSuccess || create_solver_stream(&p->s_depth, 8) != hipSuccess ||
+    if (create_net_stream(&p->s_flow) != hipSuccess || create_net_stream(&p->s_depth) != hipSuccess ||
         create_solver_stream(&p->s_trk) != hipSuccess) {
         dfvo::set_last_error("dfvo_pipeline_create: hipStreamCreate failed (no GPU?)");
         return fail(DFVO_ERR_HIP);
@@ -90,7 +91,7 @@ int dfvo_pipeline_create(const dfvo_pipeline_cfg* cfg, dfvo_pipeline** out) {
     if (p->flow_instances < 1) p->flow_instances = 1;
     if (p->flow_instances > DFVO_PIPELINE_SLOTS) p->flow_instances = DFVO_PIPELINE_SLOTS;
     for (int i = 0; i + 1 < p->flow_instances; ++i) {
-        if (create_solver_stream(&p->s_flow_x[i], 8) != hipSuccess) return fail(DFVO_ERR_HIP);
+        if (create_net_stream(&p->s_flow_x[i]) != hipSuccess) return fail(DFVO_ERR_HIP);
         rc = p->flow_x[i].init(p->H, p->W, p->s_flow_x[i]);
         if (rc != DFVO_OK) return fail(rc);
     }
@@ -103,6 +104,12 @@ int dfvo_pipeline_create(const dfvo_pipeline_cfg* cfg, dfvo_pipeline** out) {
     if (rc != DFVO_OK) return fail(rc);
     for (int i = 1; i < DFVO_PIPELINE_SLOTS; i++) {
         rc = p->tbs[i].init_shared(p->tbs[0]);
+        if (rc != DFVO_OK) return fail(rc);
+    }
+    // the PnP fallback's buffers at their final size: grown lazily they would be freed and re-allocated (hipFree waits for
+    // the whole device) whenever a pair with more keypoints than any before takes the fallback
+    if (cfg->kp_num_bestN > 0 && cfg->pnp_iters > 0) {
+        rc = p->pnp.ensure(cfg->kp_num_bestN + 8, cfg->pnp_iters);
         if (rc != DFVO_OK) return fail(rc);
     }
     for (int i = 0; i < 2; i++)
@@ -155,6 +162,7 @@ void dfvo_pipeline_destroy(dfvo_pipeline* p) {
         if (p->s_pre[i]) (void)hipStreamDestroy(p->s_pre[i]);
     for (int i = 0; i < DFVO_PIPELINE_SLOTS; i++) {
         if (p->e_pre[i]) (void)hipEventDestroy(p->e_pre[i]);
+        if (i == 0 && p->e_ref) (void)hipEventDestroy(p->e_ref);
         if (p->h_info[i]) (void)hipHostFree(p->h_info[i]);
     }
     for (int i = 0; i < DFVO_PIPELINE_SLOTS; i++) {
@@ -267,7 +275,11 @@ int dfvo_pipeline_set_ref_depth(dfvo_pipeline* p, const uint8_t* d_feed, const d
         const int x0 = (int)(p->W * c.depth_crop[2]), x1 = (int)(p->W * c.depth_crop[3]);
         P_TRY(launch_depth_post(p->depth_small, p->feedH, p->feedW, p->H, p->W, y0, y1, x0, x1, (float)c.min_depth,
                                 (float)c.max_depth, p->ref_raw, p->ref_depth, p->s_depth));
-        DFVO_HIP_CHECK(hipStreamSynchronize(p->s_depth));
+        // not waited for on the host: the solver stream (PnP fallback reads the reference depth, the roll-over writes it)
+        // is ordered behind it on the device, the depth stream runs its later passes in order anyway
+        if (!p->e_ref) DFVO_HIP_CHECK(hipEventCreateWithFlags(&p->e_ref, hipEventDisableTiming));
+        DFVO_HIP_CHECK(hipEventRecord(p->e_ref, p->s_depth));
+        DFVO_HIP_CHECK(hipStreamWaitEvent(p->s_trk, p->e_ref, 0));
     }
     p->has_ref_depth = true;
     return DFVO_OK;
