@@ -327,7 +327,7 @@ def main(argv=None):
                               for i in np.argsort(-ms) if ln[i] > 0]}
     if roof is not None:
         # HBM-side bytes per launch of that kernel: hardware counters cannot be read from inside the process, so they come
-        # from the committed rocprofv3 --pmc passes over this same command (tools/r2_pmc.sh -> tools/pmc_traffic.py:
+        # from the committed rocprofv3 --pmc passes over this same command (tools/r2c_profile.sh -> tools/pmc_traffic.py:
         # FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes); None when no committed profile holds the kernel
         try:
             pmc_file = "r2c_pmc_bench.json"

@@ -116,6 +116,22 @@ static inline hipError_t create_net_stream(hipStream_t* s) {
 static inline hipError_t create_solver_stream(hipStream_t* s, int which = 1) {
     // which: 1 the RNG-ordered chain's stream, 2 its side streams, 4 the prefetch streams, 8 a net stream (lowest priority)
     static const int mask = getenv("DFVO_SOLVER_PRIORITY") ? atoi(getenv("DFVO_SOLVER_PRIORITY")) : 0;
+    // DFVO_SOLVER_CU_ONLY (bit mask over `which`) together with DFVO_NET_CU_RESERVE = k: those solver streams may only use
+    // the k CUs per XCD that the nets leave out (measured: 211-213 frames/s, the chain's latency under load unchanged)
+    static const int cu_only = getenv("DFVO_SOLVER_CU_ONLY") ? atoi(getenv("DFVO_SOLVER_CU_ONLY")) : 0;
+    static const int reserve = getenv("DFVO_NET_CU_RESERVE") ? atoi(getenv("DFVO_NET_CU_RESERVE")) : 0;
+    if ((cu_only & which) && reserve > 0 && reserve < 32) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        e = hipGetDeviceProperties(&prop, dev);
+        if (e != hipSuccess) return e;
+        const int words = (prop.multiProcessorCount + 31) / 32;
+        uint32_t m[16];
+        for (int i = 0; i < 16; ++i) m[i] = i < words ? ((1u << reserve) - 1u) : 0u;
+        return hipExtStreamCreateWithCUMask(s, (uint32_t)(words < 16 ? words : 16), m);
+    }
     if (!(mask & which)) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
     int least = 0, greatest = 0;
     hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
