@@ -349,7 +349,10 @@ int dfvo_pipeline_track(dfvo_pipeline* p, int slot, const float* d_flow_override
     hipStream_t s = p->s_trk;
     TrackerBuffers& tb = p->tbs[slot];
     static const bool trace = getenv("DFVO_TRACK_TRACE") != nullptr;  // host-side phase timing (tuning aid)
-    static double tr_acc[4] = {0, 0, 0, 0};
+    static double tr_acc[4] = {0, 0, 0, 0}, tr_dev[3] = {0, 0, 0};
+    static int tr_dev_n = 0;
+    if (trace && !tb.ev_t[0])
+        for (int i = 0; i < 4; i++) DFVO_HIP_CHECK(hipEventCreate(&tb.ev_t[i]));
     static int tr_n = 0;
     const auto tr0 = std::chrono::steady_clock::now();
     auto tr_ms = [&](std::chrono::steady_clock::time_point a) {
@@ -387,6 +390,7 @@ int dfvo_pipeline_track(dfvo_pipeline* p, int slot, const float* d_flow_override
     sc.thre = c.scale_thre;
     const double* depth = d_depth_override ? d_depth_override : p->proc_depth[slot];
     P_TRY(enqueue_find_scale(tb, n, p->d_T21, depth, p->H, p->W, sc, s, tb.pose, true));
+    if (tb.ev_t[3]) DFVO_HIP_CHECK(hipEventRecord(tb.ev_t[3], s));
     const double tr_enq = tr_ms(tr0);
     PoseState ps;
     ScaleResult sr;
@@ -438,6 +442,21 @@ int dfvo_pipeline_track(dfvo_pipeline* p, int slot, const float* d_flow_override
     P_TRY(roll_ref_depth(p, slot, d_depth_override));
     DFVO_HIP_CHECK(hipStreamSynchronize(s));
     if (trace) {
+        float d01 = 0, d12 = 0, d23 = 0;  // device time of the chain's three segments (valid when the pair took the E path)
+        if (n > 10 && hipEventElapsedTime(&d01, tb.ev_t[0], tb.ev_t[1]) == hipSuccess &&
+            hipEventElapsedTime(&d12, tb.ev_t[1], tb.ev_t[2]) == hipSuccess &&
+            hipEventElapsedTime(&d23, tb.ev_t[2], tb.ev_t[3]) == hipSuccess) {
+            tr_dev[0] += d01;
+            tr_dev[1] += d12;
+            tr_dev[2] += d23;
+            tr_dev_n++;
+        }
+        if (tr_dev_n == 20) {
+            fprintf(stderr, "track device ms: shuffles + five-point batch %.3f | bookkeeping + recoverPose %.3f | scale %.3f\n",
+                    tr_dev[0] / 20, tr_dev[1] / 20, tr_dev[2] / 20);
+            tr_dev[0] = tr_dev[1] = tr_dev[2] = 0;
+            tr_dev_n = 0;
+        }
         tr_acc[0] += tr_kp;
         tr_acc[1] += tr_enq;
         tr_acc[2] += tr_ms(tr0);

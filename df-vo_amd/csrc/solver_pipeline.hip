@@ -1667,6 +1667,10 @@ void TrackerBuffers::release() {
     if (ev_start) (void)hipEventDestroy(ev_start);
     if (ev_h) (void)hipEventDestroy(ev_h);
     ev_fork = ev_start = ev_h = nullptr;
+    for (int i = 0; i < 4; i++) {
+        if (ev_t[i]) (void)hipEventDestroy(ev_t[i]);
+        ev_t[i] = nullptr;
+    }
     if (shared) mt_state = nullptr;
     small_valid = false;
     if (ratio_map) (void)hipFree(ratio_map);
@@ -1773,6 +1777,7 @@ int enqueue_pose_e_part(TrackerBuffers& tb, int n_host, const PoseConfig& cfg, h
         // flow: the shuffles (and with them np.random) only run behind an open gate: their count is gate[0] = n or 0
         const int* d_n = by_flow ? tb.kp_total + 5 : tb.kp_info;
         DFVO_HIP_CHECK(hipStreamWaitEvent(sr, by_flow ? tb.ev_h : tb.ev_start, 0));
+        if (tb.ev_t[0]) DFVO_HIP_CHECK(hipEventRecord(tb.ev_t[0], sr));
         int rc = enqueue_mt_shuffle(tb.mt_state, d_n, n_host, cfg.repeat, cap + 8, tb.perm, sr);
         if (rc != DFVO_OK) return rc;
         hipLaunchKernelGGL(k_permute_points, dim3(nb, R), dim3(256), 0, sr, d_n, tb.perm, cap + 8, tb.kp_cur,
@@ -1800,6 +1805,7 @@ int enqueue_pose_e_part(TrackerBuffers& tb, int n_host, const PoseConfig& cfg, h
             hipLaunchKernelGGL(k_gric_fused, dim3(R), dim3(256), 0, sr, GE, 0, tb.small, tb.small + 9, tb.kp_info, tb.pa, tb.pb,
                                2 * cap, 0.8, 5, 3, tb.small + 19);
         }
+        if (tb.ev_t[1]) DFVO_HIP_CHECK(hipEventRecord(tb.ev_t[1], sr));
         DFVO_HIP_CHECK(hipEventRecord(tb.ev_rep[0], sr));
         DFVO_HIP_CHECK(hipStreamWaitEvent(s, tb.ev_rep[0], 0));
         {
@@ -1825,6 +1831,7 @@ int enqueue_pose_e_part(TrackerBuffers& tb, int n_host, const PoseConfig& cfg, h
         rc = enqueue_recover_pose(tb.ws_rep[0], (const double*)((const char*)tb.pose + offsetof(PoseState, best_E)),
                                   tb.kp_cur, tb.kp_ref, n_host, cfg.fx, cfg.cx, cfg.cy, s, fin);
         if (rc != DFVO_OK) return rc;
+        if (tb.ev_t[2]) DFVO_HIP_CHECK(hipEventRecord(tb.ev_t[2], s));
     }
     DFVO_HIP_CHECK(hipGetLastError());
     return DFVO_OK;

@@ -102,6 +102,9 @@ struct TrackerBuffers {
     hipStream_t s_rep[MAX_REP] = {};
     hipEvent_t ev_rep[MAX_REP] = {};
     hipEvent_t ev_fork = nullptr, ev_start = nullptr, ev_h = nullptr;
+    // DFVO_TRACK_TRACE: device-side timestamps of the RNG-ordered chain (start of the shuffles, end of the five-point batch,
+    // end of recoverPose, end of the scale stage); null unless tracing
+    hipEvent_t ev_t[4] = {nullptr, nullptr, nullptr, nullptr};
     bool shared = false;  // streams / events / RandomState borrowed from another TrackerBuffers (see share_from)
     uint32_t* mt_state = nullptr;  // numpy RandomState: key[624], pos
     int* kp_info = nullptr;        // [n, good_kp_found, regions]
