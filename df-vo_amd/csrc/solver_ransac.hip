@@ -206,6 +206,65 @@ __global__ __launch_bounds__(64) void k_e_stage3(const EBatch B, int it0, int it
     if (active && root == 0) nmodels[it] = __popc(grp_mask);
 }
 
+// (Opt-in experiment, see enqueue_find_essential_batch.)  The three per-hypothesis stages in one launch (the
+// RandomState-ordered chain of the fused pipeline pays for every dependent launch): four hypotheses per 64-thread block.  Stage 1 and the polynomial are serial chains per hypothesis
+// and run on the first lane of each 16-lane group -- a wave with four active lanes has the latency of a full one, and
+// there are wave slots to spare -- stage 3 then uses all sixteen lanes of the group, one root per lane, exactly as
+// k_e_stage3 does.  Same device functions, same operands: bit-identical to the three-launch sequence.
+__global__ __launch_bounds__(64) void k_e_hyp(const EBatch B, int it0, int it1) {
+    __shared__ double s_ws[4 * E_STAGE1_STRIDE];
+    const ERep& R = B.r[blockIdx.y];
+    const RansacState* st = R.state;
+    double* ws = R.ws;
+    int* ok = R.ok;
+    double* models = R.models;
+    int* nmodels = R.nmodels;
+    const int grp = threadIdx.x >> 4, root = threadIdx.x & 15;
+    const int it = it0 + blockIdx.x * 4 + grp;
+    if (st->done) return;  // uniform over the block
+    const bool active = it < it1;
+    if (active && root == 0) {
+        const int* idx = B.idx;
+        const double *p1 = R.norm_a, *p2 = R.norm_b;
+        double q1[10], q2[10];
+        for (int i = 0; i < 5; i++) {
+            const int k = idx[it * 5 + i];
+            q1[i * 2] = p1[k * 2];
+            q1[i * 2 + 1] = p1[k * 2 + 1];
+            q2[i * 2] = p2[k * 2];
+            q2[i * 2 + 1] = p2[k * 2 + 1];
+        }
+        double* w = ws + (size_t)it * E_WS;  // [EE 36 | b 39 | c 11 | roots 20]
+        const int good = sm::five_point_stage1_ws(q1, q2, w, w + 36, w + 75, s_ws + grp * E_STAGE1_STRIDE) ? 1 : 0;
+        ok[it] = good;
+        if (good) {
+            double c[11], rre[10], rim[10];
+            for (int i = 0; i < 11; i++) c[i] = w[75 + i];
+            sm::solve_poly10(c, rre, rim);
+            for (int i = 0; i < 10; i++) {
+                w[86 + i] = rre[i];
+                w[96 + i] = rim[i];
+            }
+        }
+    }
+    __syncthreads();  // the group's lanes read what its first lane wrote (global memory, same workgroup)
+    bool valid = false;
+    double Ev[9];
+    if (active && root < 10 && ok[it]) {
+        const double* w = ws + (size_t)it * E_WS;
+        valid = sm::five_point_root_to_E(w, w + 36, w[86 + root], w[96 + root], Ev);
+    }
+    const unsigned long long m = __ballot(valid);
+    const unsigned grp_mask = (unsigned)((m >> (grp * 16)) & 0xffffull);
+    if (valid) {
+        const int slot = __popc(grp_mask & ((1u << root) - 1u));
+        double* dst = models + (size_t)it * 90 + slot * 9;
+#pragma unroll
+        for (int k = 0; k < 9; k++) dst[k] = Ev[k];
+    }
+    if (active && root == 0) nmodels[it] = __popc(grp_mask);
+}
+
 // one wavefront per hypothesis: Sampson error of every correspondence under each of its models
 __global__ __launch_bounds__(256) void k_e_score(const EBatch B, int it0, int it1, int n, float thr2) {
     __shared__ double sE[4][90];
@@ -350,9 +409,17 @@ int enqueue_find_essential_batch(RansacWorkspace* w, const double* const* d_pts1
             if (it1 <= it0) continue;
             const int nh = it1 - it0;
             hipLaunchKernelGGL(k_e_subsets, dim3(1), dim3(1), 0, s, B, n, it0, it1);
-            hipLaunchKernelGGL(k_e_stage1, dim3(cdiv(nh, E_STAGE1_LANES), R), dim3(E_STAGE1_LANES), 0, s, B, it0, it1);
-            hipLaunchKernelGGL(k_e_poly, dim3(cdiv(nh, 64), R), dim3(64), 0, s, B, it0, it1);
-            hipLaunchKernelGGL(k_e_stage3, dim3(cdiv(nh, 4), R), dim3(64), 0, s, B, it0, it1);
+            // DFVO_E_FUSED=1: k_e_hyp instead of the three launches.  Measured in the default bench: the five-point batch
+            // gets 0.14 ms shorter under load (2.46 vs 2.60 ms) but the pair rate drops, 223.8 vs 236.8 frames/s -- 800
+            // quarter-filled waves that live 1.3 ms each take more from the nets than two launches cost.  Off.
+            static const bool fused = getenv("DFVO_E_FUSED") && atoi(getenv("DFVO_E_FUSED")) != 0;
+            if (fused) {
+                hipLaunchKernelGGL(k_e_hyp, dim3(cdiv(nh, 4), R), dim3(64), 0, s, B, it0, it1);
+            } else {
+                hipLaunchKernelGGL(k_e_stage1, dim3(cdiv(nh, E_STAGE1_LANES), R), dim3(E_STAGE1_LANES), 0, s, B, it0, it1);
+                hipLaunchKernelGGL(k_e_poly, dim3(cdiv(nh, 64), R), dim3(64), 0, s, B, it0, it1);
+                hipLaunchKernelGGL(k_e_stage3, dim3(cdiv(nh, 4), R), dim3(64), 0, s, B, it0, it1);
+            }
             hipLaunchKernelGGL(k_e_score, dim3(cdiv(nh, 4), R), dim3(256), 0, s, B, it0, it1, n, thr2);
             hipLaunchKernelGGL(k_e_replay, dim3(R), dim3(1), 0, s, B, it0, it1, n, prob);
         }
