@@ -265,6 +265,97 @@ __global__ __launch_bounds__(64) void k_e_hyp(const EBatch B, int it0, int it1) 
     if (active && root == 0) nmodels[it] = __popc(grp_mask);
 }
 
+// Two launches instead of four for the hypothesis stages, without thinning the waves: stage 1 and the polynomial are both
+// one-lane-per-hypothesis chains and share k_e_stage1's 16-lane workgroups (k_e_stage1_poly); stage 3's output -- the
+// models of a hypothesis -- is exactly what the scoring wave of that hypothesis stages in LDS, so the first sixteen lanes
+// of the scoring wave compute it in place (k_e_stage3_score).  Same device functions, same operands, same results.
+__global__ __launch_bounds__(E_STAGE1_LANES) void k_e_stage1_poly(const EBatch B, int it0, int it1) {
+    __shared__ double s_ws[E_STAGE1_LANES * E_STAGE1_STRIDE];
+    const ERep& R = B.r[blockIdx.y];
+    const RansacState* st = R.state;
+    const int* idx = B.idx;
+    const double *p1 = R.norm_a, *p2 = R.norm_b;
+    double* ws = R.ws;
+    int* ok = R.ok;
+    const int it = it0 + blockIdx.x * E_STAGE1_LANES + threadIdx.x;
+    if (st->done || it >= it1) return;
+    double q1[10], q2[10];
+    for (int i = 0; i < 5; i++) {
+        const int k = idx[it * 5 + i];
+        q1[i * 2] = p1[k * 2];
+        q1[i * 2 + 1] = p1[k * 2 + 1];
+        q2[i * 2] = p2[k * 2];
+        q2[i * 2 + 1] = p2[k * 2 + 1];
+    }
+    double* w = ws + (size_t)it * E_WS;  // [EE 36 | b 39 | c 11 | roots 20]
+    const int good = sm::five_point_stage1_ws(q1, q2, w, w + 36, w + 75, s_ws + threadIdx.x * E_STAGE1_STRIDE) ? 1 : 0;
+    ok[it] = good;
+    if (!good) return;
+    double c[11], rre[10], rim[10];
+    for (int i = 0; i < 11; i++) c[i] = w[75 + i];
+    sm::solve_poly10(c, rre, rim);
+    for (int i = 0; i < 10; i++) {
+        w[86 + i] = rre[i];
+        w[96 + i] = rim[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_e_stage3_score(const EBatch B, int it0, int it1, int n, float thr2) {
+    __shared__ double sE[4][90];
+    const ERep& R = B.r[blockIdx.y];
+    const RansacState* st = R.state;
+    const double* ws = R.ws;
+    const int* ok = R.ok;
+    double* models = R.models;
+    int* nmodels = R.nmodels;
+    const double *p1 = R.norm_a, *p2 = R.norm_b;
+    int* counts = R.counts;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int it = it0 + blockIdx.x * 4 + wave;
+    const bool active = !st->done && it < it1;
+    // stage 3: one root per lane on the wave's first sixteen lanes, survivors compacted in root order
+    bool valid = false;
+    double Ev[9];
+    if (active && lane < 10 && ok[it]) {
+        const double* w = ws + (size_t)it * E_WS;
+        valid = sm::five_point_root_to_E(w, w + 36, w[86 + lane], w[96 + lane], Ev);
+    }
+    const unsigned mask = (unsigned)(__ballot(valid) & 0xffffull);
+    const int nm = active ? __popc(mask) : 0;
+    if (valid) {
+        const int slot = __popc(mask & ((1u << lane) - 1u));
+        double* dst = models + (size_t)it * 90 + slot * 9;
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            dst[k] = Ev[k];
+            sE[wave][slot * 9 + k] = Ev[k];
+        }
+    }
+    if (active && lane == 0) nmodels[it] = nm;
+    __syncthreads();
+    if (nm <= 0) return;
+    int cnt[10];
+#pragma unroll
+    for (int m = 0; m < 10; m++) cnt[m] = 0;
+    for (int i = lane; i < n; i += 64) {
+        const double x1 = p1[i * 2], y1 = p1[i * 2 + 1], x2 = p2[i * 2], y2 = p2[i * 2 + 1];
+#pragma unroll
+        for (int m = 0; m < 10; m++) {
+            if (m < nm) {
+                const float e = sm::essential_error(&sE[wave][m * 9], x1, y1, x2, y2);
+                cnt[m] += (e <= thr2) ? 1 : 0;
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 10; m++) {
+        if (m < nm) {
+            const int s = wave_sum(cnt[m]);
+            if (lane == 0) counts[it * 10 + m] = s;
+        }
+    }
+}
+
 // one wavefront per hypothesis: Sampson error of every correspondence under each of its models
 __global__ __launch_bounds__(256) void k_e_score(const EBatch B, int it0, int it1, int n, float thr2) {
     __shared__ double sE[4][90];
@@ -412,8 +503,17 @@ int enqueue_find_essential_batch(RansacWorkspace* w, const double* const* d_pts1
             // DFVO_E_FUSED=1: k_e_hyp instead of the three launches.  Measured in the default bench: the five-point batch
             // gets 0.14 ms shorter under load (2.46 vs 2.60 ms) but the pair rate drops, 223.8 vs 236.8 frames/s -- 800
             // quarter-filled waves that live 1.3 ms each take more from the nets than two launches cost.  Off.
-            static const bool fused = getenv("DFVO_E_FUSED") && atoi(getenv("DFVO_E_FUSED")) != 0;
-            if (fused) {
+            static const int fused = getenv("DFVO_E_FUSED") ? atoi(getenv("DFVO_E_FUSED")) : 0;
+            // 2: (stage 1 + polynomial), (stage 3 + scoring) -- the batch 0.21 ms shorter under load (2.37 vs 2.58 ms), the
+            // pair rate unchanged (235.9 vs 234.3 frames/s): the time reappears in the wait for the homography half, i.e.
+            // the pair rate is set by the nets under contention, not by this chain.  Off, like 1.
+            if (fused == 2) {
+                hipLaunchKernelGGL(k_e_stage1_poly, dim3(cdiv(nh, E_STAGE1_LANES), R), dim3(E_STAGE1_LANES), 0, s, B, it0, it1);
+                hipLaunchKernelGGL(k_e_stage3_score, dim3(cdiv(nh, 4), R), dim3(256), 0, s, B, it0, it1, n, thr2);
+                hipLaunchKernelGGL(k_e_replay, dim3(R), dim3(1), 0, s, B, it0, it1, n, prob);
+                continue;
+            }
+            if (fused == 1) {
                 hipLaunchKernelGGL(k_e_hyp, dim3(cdiv(nh, 4), R), dim3(64), 0, s, B, it0, it1);
             } else {
                 hipLaunchKernelGGL(k_e_stage1, dim3(cdiv(nh, E_STAGE1_LANES), R), dim3(E_STAGE1_LANES), 0, s, B, it0, it1);
