@@ -119,7 +119,10 @@ static inline hipError_t create_solver_stream(hipStream_t* s, int which = 1) {
     // DFVO_SOLVER_CU_ONLY (bit mask over `which`) together with DFVO_NET_CU_RESERVE = k: those solver streams may only use
     // the k CUs per XCD that the nets leave out (measured: 211-213 frames/s, the chain's latency under load unchanged)
     static const int cu_only = getenv("DFVO_SOLVER_CU_ONLY") ? atoi(getenv("DFVO_SOLVER_CU_ONLY")) : 0;
-    static const int reserve = getenv("DFVO_NET_CU_RESERVE") ? atoi(getenv("DFVO_NET_CU_RESERVE")) : 0;
+    // (DFVO_SOLVER_CU_K = k confines them to k CUs per XCD while the nets keep all CUs)
+    static const int reserve = getenv("DFVO_SOLVER_CU_K")      ? atoi(getenv("DFVO_SOLVER_CU_K"))
+                               : getenv("DFVO_NET_CU_RESERVE") ? atoi(getenv("DFVO_NET_CU_RESERVE"))
+                                                               : 0;
     if ((cu_only & which) && reserve > 0 && reserve < 32) {
         hipDeviceProp_t prop;
         int dev = 0;
