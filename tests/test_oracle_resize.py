@@ -70,3 +70,10 @@ def test_exact_half_size_is_the_2x2_mean():
 def test_nearest_still_served():
     d = np.arange(12, dtype=np.float32).reshape(3, 4)
     assert np.array_equal(cv2.resize(d, (8, 6), interpolation=cv2.INTER_NEAREST), d.repeat(2, 0).repeat(2, 1))
+
+
+def test_known_answer_two_pixels_to_four():
+    """cv2.resize(np.array([[0, 255]], np.uint8), (4, 1)) is [[0, 64, 191, 255]] in every OpenCV 3.x / 4.x (the textbook
+    example of its half-pixel-centre convention and of the 11-bit fixed point: 63.75 and 191.25 round to 64 and 191)"""
+    assert cv2.resize(np.array([[0, 255]], np.uint8), (4, 1)).tolist() == [[0, 64, 191, 255]]
+    assert cv2.resize(np.array([[0], [255]], np.uint8), (1, 4)).ravel().tolist() == [0, 64, 191, 255]
