@@ -97,6 +97,7 @@ SIGNATURES = {
     "dfvo_memcpy_d2h": (_i, [_vp, _vp, _sz]),
     "dfvo_conv2d": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dfvo_set_conv_precision": (_i, [C.c_char_p]),
+    "dfvo_f16s_overflow_count": (_i, [C.POINTER(C.c_ulonglong), _i]),
     "dfvo_conv_profile_begin": (_i, []),
     "dfvo_conv_profile_end": (_i, [_vp, _vp, _vp]),
     "dfvo_correlation": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
@@ -207,6 +208,13 @@ def check(rc):
 def require_gpu():
     if lib().dfvo_device_count() < 1:
         raise DfvoError("no HIP device visible: the DF-VO hot path has no CPU fallback")
+
+
+def f16s_overflow_count(reset=False):
+    """events (threads / packed weights) that hit the +-65504 saturation of the f16x3 split since the last reset"""
+    n = C.c_ulonglong(0)
+    check(lib().dfvo_f16s_overflow_count(C.byref(n), int(bool(reset))))
+    return int(n.value)
 
 
 def as_ptr(a):

@@ -152,6 +152,7 @@ int dfvo_conv2d(const dfvo_conv_desc* d, const float* d_src0, const float* d_src
 }
 
 int dfvo_set_conv_precision(const char* name) { return conv_set_precision(name); }
+int dfvo_f16s_overflow_count(unsigned long long* h_count, int reset) { return conv_f16s_overflow_count(h_count, reset); }
 
 int dfvo_conv_profile_begin(void) {
     conv_profile_begin();

@@ -30,7 +30,16 @@ constexpr float F16S_LO_SCALE = 2048.0f;          // 2^11
 constexpr float F16S_LO_UNSCALE = 1.0f / 2048.0f;
 constexpr float F16S_MAX = 65504.0f;
 
-__device__ __forceinline__ void split_f16_planes(f32x4 x, h16x4* hi, h16x4* lo) {
+// Saturation is not silent: every kernel that splits activations keeps the running max |x| of what it split (two
+// v_max3_f32 per four elements) and bumps g_f16s_clamped once per thread that saw a value beyond f16's range;
+// dfvo_f16s_overflow_count() reads it (the -m gpu net tests assert zero after every f16x3 test).
+__device__ unsigned int g_f16s_clamped = 0;
+__device__ __forceinline__ void f16s_report_clamp(float amax) {
+    if (amax > F16S_MAX) atomicAdd(&g_f16s_clamped, 1u);  // (NaN compares false: NaNs propagate through the planes instead)
+}
+__device__ __forceinline__ void split_f16_planes(f32x4 x, h16x4* hi, h16x4* lo, float& amax) {
+    amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(x[0]), __builtin_fabsf(x[1])));
+    amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(x[2]), __builtin_fabsf(x[3])));
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const float v = __builtin_fminf(__builtin_fmaxf(x[e], -F16S_MAX), F16S_MAX);  // saturate instead of inf
@@ -72,6 +81,7 @@ __global__ __launch_bounds__(64 * WC * WR, 2) void conv_win_f16s_kernel(const Co
     // (a few dozen integer operations against 27 TC TR MFMAs) instead of living in 4 W_CNT registers for the whole kernel:
     // the accumulators and the weight ring need the register file
     f32x4 rw[W_CNT];
+    float amax = 0.f;  // max |x| over everything this thread split (saturation report)
     unsigned rwv = 0;  // bit r: item r holds real data (inside the image, channel group exists)
     // One item per tap: item r of the next chunk is loaded at tap r and written to LDS (split into planes) at tap
     // 9 - W_CNT + r, so that the ~30 VALU instructions of a split sit in the shadow of that tap's MFMAs instead of all
@@ -106,7 +116,7 @@ __global__ __launch_bounds__(64 * WC * WR, 2) void conv_win_f16s_kernel(const Co
         const int id = t + NT * r;
         if (id < W_ITEMS) {
             h16x4 hi, lo;
-            split_f16_planes(((rwv >> r) & 1u) ? rw[r] : f32x4{0.f, 0.f, 0.f, 0.f}, &hi, &lo);
+            split_f16_planes(((rwv >> r) & 1u) ? rw[r] : f32x4{0.f, 0.f, 0.f, 0.f}, &hi, &lo, amax);
             float* dst = W + (id >> 2) * PS + (id & 3) * 2;  // hi plane: dwords [0, 8), lo plane: [8, 16) of the pixel
             *reinterpret_cast<h16x4*>(dst) = hi;
             *reinterpret_cast<h16x4*>(dst + 8) = lo;
@@ -217,6 +227,7 @@ __global__ __launch_bounds__(64 * WC * WR, 2) void conv_win_f16s_kernel(const Co
         __syncthreads();
     }
 
+    f16s_report_clamp(amax);
     // epilogue: register quad g of block (i, j) = couts 8 g + 4 kb .. + 3 of the pixel at x = tx0 + lp, row ty0 + wr TR + j
     const int ox = tx0 + lp;
     const bool vec_ok = conv_vec_ok(p);
@@ -309,12 +320,27 @@ static int launch_f16s(const ConvParams& p_in, hipStream_t stream, int cfg_id) {
 }
 
 // host side: f32 -> (hi, lo) exactly as split_f16_planes does on the device
+static unsigned long long g_f16s_clamped_host = 0;  // weights beyond f16's range at pack time (same report as the device counter)
 static inline void f16s_split_host(float x, unsigned short* hi, unsigned short* lo) {
     float v = x < -F16S_MAX ? -F16S_MAX : (x > F16S_MAX ? F16S_MAX : x);
+    if (v != x && x == x) ++g_f16s_clamped_host;
     const _Float16 h = (_Float16)v;
     const _Float16 l = (_Float16)((v - (float)h) * F16S_LO_SCALE);
     memcpy(hi, &h, 2);
     memcpy(lo, &l, 2);
+}
+
+// number of threads (activations) + weights (pack time) that hit the +-65504 saturation of the hi plane since the last reset
+int conv_f16s_overflow_count(unsigned long long* n, int reset) {
+    unsigned int dev = 0;
+    DFVO_HIP_CHECK(hipMemcpyFromSymbol(&dev, HIP_SYMBOL(g_f16s_clamped), sizeof(dev)));
+    if (n) *n = (unsigned long long)dev + g_f16s_clamped_host;
+    if (reset) {
+        const unsigned int zero = 0;
+        DFVO_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_f16s_clamped), &zero, sizeof(zero)));
+        g_f16s_clamped_host = 0;
+    }
+    return DFVO_OK;
 }
 
 size_t conv_pack_weights_f16s(const float* w, int cout, int c0, int c1, const float* fold_scale, unsigned short* out) {

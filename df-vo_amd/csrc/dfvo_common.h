@@ -163,6 +163,7 @@ int conv_split_mode();  // 0 exact fp32 (default), 2 = bf16x3, 3 = bf16x6, 4 = f
 // weights of a 3x3 layer as f16 hi / lo planes for conv_win_f16s_kernel; returns the number of halves written
 // (out may be null to query the size): [tap][chunk][cout_pad32][2][16], chunks = ceil(c0/16) + ceil(c1/16)
 size_t conv_pack_weights_f16s(const float* w_oihw, int cout, int c0, int c1, const float* fold_scale, unsigned short* out);
+int conv_f16s_overflow_count(unsigned long long* n, int reset);  // saturation report of the f16x3 split (conv_win_f16s.h)
 size_t conv_head_weight_floats(int cout, int c0, int c1, int k);
 void conv_pack_head_weights(const float* w_oihw, int cout, int c0, int c1, int k, const float* fold_scale, float* out);
 void conv_pack_weights(const float* w_oihw, const float* bias, int cout, int c0, int c1, int kh, int kw,

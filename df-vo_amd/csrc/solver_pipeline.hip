@@ -1617,7 +1617,7 @@ int TrackerBuffers::init() {
     // RNG-dependent solver chain.  Measured on MI355X, bench.py order (pipeline created before the process touches the
     // GPU through torch), exact fp32: 2 -> 103, 3 -> 108, 4 -> 133, 5 -> 111, 6 -> 112, 7 -> 116, 8 -> 133 frames/s;
     // with a torch copy issued first the fast settings are 5 .. 7 (126).  DFVO_REP_STREAMS overrides (tuning aid).
-    static const int n_streams = getenv("DFVO_REP_STREAMS") ? atoi(getenv("DFVO_REP_STREAMS")) : NUM_REP_STREAMS;
+    const int n_streams = rep_stream_count();
     for (int r = 0; r < MAX_REP; r++) {
         if (r < n_streams)
             DFVO_HIP_CHECK(create_solver_stream(&s_rep[r], 2));
@@ -1657,7 +1657,7 @@ void TrackerBuffers::release() {
     for (int r = 0; r < MAX_REP; r++) {
         ws_rep[r].release();
         if (!shared) {
-            if (s_rep[r] && r < (getenv("DFVO_REP_STREAMS") ? atoi(getenv("DFVO_REP_STREAMS")) : NUM_REP_STREAMS)) (void)hipStreamDestroy(s_rep[r]);
+            if (s_rep[r] && r < rep_stream_count()) (void)hipStreamDestroy(s_rep[r]);
             if (ev_rep[r]) (void)hipEventDestroy(ev_rep[r]);
         }
         s_rep[r] = nullptr;

@@ -94,6 +94,12 @@ def image_to_device(img_u8, h, w, crop=None):
         img = np.ascontiguousarray(img[y0:y1, x0:x1])
     src = torch.from_numpy(img).cuda()
     dst = torch.empty((h, w, img.shape[2]), dtype=torch.uint8, device="cuda")
+    stream = torch.cuda.current_stream()
     capi.check(capi.lib().dfvo_resize_linear_u8(src.data_ptr(), img.shape[0], img.shape[1], img.shape[2], dst.data_ptr(), h, w,
-                                                torch.cuda.current_stream().cuda_stream))
+                                                stream.cuda_stream))
+    # Ordering contract for device frames handed to TrackingPipeline.enqueue_nets / set_ref_image: the pipeline reads them
+    # on its OWN non-blocking streams, which are not ordered behind torch's current stream -- a frame must be complete
+    # before it is handed over.  The upload + resize are therefore drained here (frames_to_device's .cuda() copy is
+    # synchronous for pageable host memory already).
+    stream.synchronize()
     return dst

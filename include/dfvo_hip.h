@@ -79,6 +79,10 @@ int dfvo_conv2d(const dfvo_conv_desc* desc, const float* d_src0, const float* d_
  *   "bf16x6" / "bf16x3"  bf16-plane variants (24 / 16 mantissa bits)
  * Also read once from the environment variable DFVO_CONV_PRECISION. */
 int dfvo_set_conv_precision(const char* name);
+/* f16x3 saturation report: the hi plane of the split is f16, so |x| > 65504 is clamped.  Every splitting kernel counts the
+ * threads that saw such an activation, the packer the weights; *h_count = events since the last reset (0 = nothing was
+ * ever clamped, i.e. the f16x3 result is the 22-bit split of the true operands).  reset != 0 clears the counter. */
+int dfvo_f16s_overflow_count(unsigned long long* h_count, int reset);
 int dfvo_conv_profile_begin(void);
 /* host only: the bf16 planes the opt-in split-precision conv modes (DFVO_CONV_PRECISION=bf16x3 | bf16x6) give a weight:
  * h_out[q * n + i] = plane q of h_in[i], x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1), round to nearest even */
@@ -373,6 +377,11 @@ int dfvo_pipeline_set_graph(dfvo_pipeline* p, int enable);   /* hipGraph replay 
 /* number of output slots: the host may run the nets this many pairs ahead of the solver stage (the nets of pairs
  * k+1 .. k+3 queue up behind each other on their streams while dfvo_pipeline_track(k) blocks the host) */
 #define DFVO_PIPELINE_SLOTS 4
+/* Ordering contract for every device frame handed to the three calls below: they are ASYNCHRONOUS and read the frame on
+ * the pipeline's own non-blocking HIP streams.  (1) The frame must be complete when the call is made -- work still queued
+ * on another stream (e.g. a resize on the caller's stream) is not waited for.  (2) The frame must stay unchanged, and
+ * allocated, until dfvo_pipeline_track() of that slot has returned (enqueue_nets) / until dfvo_pipeline_sync() or the
+ * first dfvo_pipeline_track() after the call has returned (set_ref_depth, set_ref_image). */
 /* enqueue both nets for one pair into `slot` (0 .. DFVO_PIPELINE_SLOTS-1); returns at once.  d_* uint8 device images:
  * ref/cur [img_h,img_w,3], cur_feed [feed_h,feed_w,3] (the PIL-LANCZOS resized current frame) or NULL: the current frame
  * is then resized on the device (dfvo_resize_lanczos_u8's arithmetic) ahead of the depth net */

@@ -33,19 +33,21 @@ def frame_depth(dsd, img_u8, feed_hw=(192, 640), depth_range=(0.0, 50.0)):
     return raw, T.preprocess_depth(raw, DEPTH_CROP, list(depth_range))
 
 
-def solve_pair(fwd, diff, depth_cur, depth_ref, K):
+def solve_pair(fwd, diff, depth_cur, depth_ref, K, num_bestN=2000, e_max_iters=1000):
     """dfvo.py:147-250 on given net outputs.  Consumes np.random exactly as the reference does.
+    `num_bestN` = kp_selection.local_bestN.num_bestN of the configuration (kp_selection.py:74-200); `e_max_iters` = the
+    findEssentialMat hypothesis budget (1000 is OpenCV 3.4.3's fixed value; BASELINE config 5 asks for 8192).
     Returns dict(status 'E' | 'PnP' | 'constant_motion', pose 4x4 cur->ref or None, + stage results for bit comparisons)."""
     if diff.ndim == 2:
         diff = diff[..., None]
     out = {"status": "constant_motion", "pose": None}
-    kp = T.local_bestN(fwd, diff)
+    kp = T.local_bestN(fwd, diff, num_bestN=num_bestN)
     out["good_kp_found"] = bool(kp["good_kp_found"])
     if not kp["good_kp_found"]:
         return out
     kp1, kp2 = kp["kp1_best"][0], kp["kp2_best"][0]
     out["kp_ref"], out["kp_cur"] = kp1, kp2
-    res = T.compute_pose_2d2d(kp1, kp2, K)
+    res = T.compute_pose_2d2d(kp1, kp2, K, max_iters=e_max_iters)
     out["E"] = res
     scale = -1
     if np.linalg.norm(res["t"]) != 0:  # dfvo.py:184-222

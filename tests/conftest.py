@@ -35,5 +35,10 @@ def conv_precision(request, gpu):
     """arithmetic of the 3x3 window layers for every net packed inside the test (dfvo_set_conv_precision): the exact fp32
     MFMA kernels, and the f16x3 split kernels that bench.py's headline uses -- same tolerances for both"""
     gpu.check(gpu.lib().dfvo_set_conv_precision(request.param.encode()))
+    gpu.f16s_overflow_count(reset=True)
     yield request.param
     gpu.check(gpu.lib().dfvo_set_conv_precision(b"fp32"))
+    # the f16x3 split saturates at +-65504 (conv_win_f16s.h): never silently -- no activation or weight of any net in
+    # the suite may have been clamped
+    clamped = gpu.f16s_overflow_count(reset=True)
+    assert clamped == 0, "f16x3: %d activations / weights were clamped to +-65504" % clamped
