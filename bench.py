@@ -44,7 +44,10 @@ CFG_NAMES = ["conv_igemm_f32<2,2,4,4> 128x128", "conv_igemm_f32<1,4,2,2> 32x128"
              "conv_win3_f32<2,2,4,4> (8x16)x128", "conv_win3_f32<2,2,4,2> (8x16)x64", "conv_win3_f32<4,1,2,2> (8x16)x32",
              "conv_win3_f32<1,4,4,2> (4x16)x128", "conv_head_f32<7> 7x7 heads (direct)",
              "conv_head_f32<5> 5x5 heads (direct)", "conv_head_f32<3> 3x3 heads (direct)",
-             "conv_win_f16s (4|8 x 32) x 128|64|32 (f16 hi/lo planes, v_mfma_f32_32x32x16_f16)"]
+             "conv_win_f16s (4|8 x 32) x 128|64|32 (f16 hi/lo planes, v_mfma_f32_32x32x16_f16)",
+             "conv_gemm_f16s streaming (1x1, k x 1, stride 2, 7x7 layers; 32 px x 32|64 couts per wave, f16 hi/lo planes)",
+             "conv_gemm_f16s K-sliced (small maps: pyramid levels 5-6, depth net inner layers; in-workgroup ordered reduction)",
+             "(unused)", "(unused)"]
 
 
 def cpu_baseline_nets(frames, fsd, dsd, K, H, W, n_pairs=3):
@@ -302,9 +305,9 @@ def main(argv=None):
         for _ in range(nprof):
             pipe.enqueue_nets(0, d_frames[0], d_frames[1], d_feed)
             pipe.sync()
-        ms = np.zeros(20)
-        fl = np.zeros(20)
-        ln = np.zeros(20, np.int32)
+        ms = np.zeros(24)
+        fl = np.zeros(24)
+        ln = np.zeros(24, np.int32)
         capi.check(lib.dfvo_conv_profile_end(capi.as_ptr(ms), capi.as_ptr(fl), capi.as_ptr(ln)))
         pipe.set_graph(1)
         dom = int(np.argmax(ms))
@@ -313,6 +316,8 @@ def main(argv=None):
         # exact fp32: the fp32-MFMA peak.  Opt-in split modes: the window layers issue 4 (bf16x3) / 6 (bf16x6) bf16 products
         # per fp32 product, so the ceiling for USEFUL fp32-equivalent FLOPs is the dense bf16 peak divided by that
         terms = {"fp32": 0, "f16x3": 3, "bf16x3": 4, "bf16x6": 6}[args.conv_precision]
+        if terms and dom < 19 and args.conv_precision == "f16x3":
+            terms = 0  # a kernel of the exact fp32 family dominates although the window layers run split: price it as fp32
         peak = PEAK_F32_MFMA_TFLOPS if not terms else PEAK_BF16_MFMA_TFLOPS / terms
         roof = {"bound": "mfma", "kernel": CFG_NAMES[dom].replace("conv_win3_f32", "conv_win3_f32" if not terms else "conv_win3_bf16s"),
                 "achieved": round(ach, 2), "peak": round(peak, 1),
@@ -332,7 +337,7 @@ def main(argv=None):
         try:
             pmc_file = "r2c_pmc_bench.json"
             prof = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["kernels"]
-            key = {19: "conv_win_f16s_kernel<"}.get(dom) or CFG_NAMES[dom].split(" ")[0].replace(
+            key = {19: "conv_win_f16s_kernel<", 20: "conv_gemm_f16s_kernel<", 21: "conv_gemm_f16s_kernel<"}.get(dom) or CFG_NAMES[dom].split(" ")[0].replace(
                 "conv_igemm_f32<", "conv_igemm_f32_kernel<").replace("conv_win3_f32<", "conv_win_f32_kernel<").replace(
                 "conv_win_f32<", "conv_win_f32_kernel<")
             cand = [k for k in prof if k.replace(" ", "").startswith(key.rstrip(">").replace(" ", ""))]

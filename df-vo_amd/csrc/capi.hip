@@ -116,6 +116,13 @@ int dfvo_conv2d(const dfvo_conv_desc* d, const float* d_src0, const float* d_src
         if (L.wsp) (void)hipFree(L.wsp);
         return DFVO_ERR_HIP;
     }
+    if (make_f16g_weights(h_w, d->cout, d->c0, d->c1, d->kh, d->kw, nullptr, &L) != DFVO_OK) {
+        (void)hipFree(dw);
+        (void)hipFree(db);
+        if (L.wsp) (void)hipFree(L.wsp);
+        if (L.wf) (void)hipFree(L.wf);
+        return DFVO_ERR_HIP;
+    }
     {
         const int hrc = make_head_weights(h_w, d->cout, d->c0, d->c1, d->kh, d->kw, nullptr, &L.wh);
         if (hrc != DFVO_OK) {
@@ -146,6 +153,8 @@ int dfvo_conv2d(const dfvo_conv_desc* d, const float* d_src0, const float* d_src
     if (L.wh) (void)hipFree(L.wh);
     if (L.wsp) (void)hipFree(L.wsp);
     if (L.wf) (void)hipFree(L.wf);
+    if (L.wg) (void)hipFree(L.wg);
+    if (L.gtab) (void)hipFree(L.gtab);
     if (rc != DFVO_OK) return rc;
     DFVO_HIP_CHECK(e);
     return DFVO_OK;

@@ -1128,6 +1128,7 @@ int conv_profile_end(double* ms, double* flops, int* launches) {
 }
 
 #include "conv_win_f16s.h"
+#include "conv_gemm_f16s.h"
 
 // split-K when the grid cannot fill the chip: partials to p.ws, ordered reduction in a second launch
 static int conv_pick_splits(const ConvParams& p, long long blocks) {
@@ -1324,7 +1325,8 @@ int launch_conv(const ConvParams& p, hipStream_t stream) {
         if (p.kh == 5) return p.cout == 2 ? launch_head<5, 2>(p, stream, 17) : launch_head<5, 1>(p, stream, 17);
         return p.cout == 2 ? launch_head<3, 2>(p, stream, 18) : launch_head<3, 1>(p, stream, 18);
     }
-    if (p.wf16 && conv_f16s_ok(p)) return launch_f16s(p, stream, 19);  // f16x3: every 3x3 / stride-1 layer, all map sizes
+    if (p.wf16 && conv_f16s_ok(p)) return launch_f16s(p, stream, 19);  // f16x3: the 3x3 / stride-1 layers whose map fills the chip
+    if (conv_f16g_ok(p)) return launch_f16g(p, stream);  // f16x3: everything else (small maps, 1x1, k x 1, stride 2, 7x7)
     if (conv_use_window(p, bn) && p.kh == 7) return launch_win3<4, 1, 2, 1, 7>(p, stream, 16);
     if (conv_use_window(p, bn) && p.kh == 5) return launch_win3<4, 1, 2, 1, 5>(p, stream, 17);
     if (conv_use_window(p, bn)) {

@@ -30,19 +30,22 @@ constexpr float F16S_LO_SCALE = 2048.0f;          // 2^11
 constexpr float F16S_LO_UNSCALE = 1.0f / 2048.0f;
 constexpr float F16S_MAX = 65504.0f;
 
-// Saturation is not silent: every kernel that splits activations keeps the running max |x| of what it split (two
-// v_max3_f32 per four elements) and bumps g_f16s_clamped once per thread that saw a value beyond f16's range;
-// dfvo_f16s_overflow_count() reads it (the -m gpu net tests assert zero after every f16x3 test).
+// |x| > 65504 does not fit the hi plane.  It is neither clamped (a silently wrong product) nor ignored: the conversion
+// yields +-inf, which propagates as inf / NaN into the layer's output, and every kernel that splits activations keeps the
+// running max |x| of what it split (one v_max3_f32 per two elements -- cheaper than the clamp it replaces) and bumps
+// g_f16s_clamped once per thread that saw such a value; dfvo_f16s_overflow_count() reads it (the -m gpu tests assert
+// zero after every f16x3 test).
 __device__ unsigned int g_f16s_clamped = 0;
 __device__ __forceinline__ void f16s_report_clamp(float amax) {
-    if (amax > F16S_MAX) atomicAdd(&g_f16s_clamped, 1u);  // (NaN compares false: NaNs propagate through the planes instead)
+    if (amax > F16S_MAX) atomicAdd(&g_f16s_clamped, 1u);
 }
 __device__ __forceinline__ void split_f16_planes(f32x4 x, h16x4* hi, h16x4* lo, float& amax) {
-    amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(x[0]), __builtin_fabsf(x[1])));
-    amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(x[2]), __builtin_fabsf(x[3])));
+    // (spelled as instructions: fmaxf() drags a canonicalising v_max per operand along, 7 instructions instead of 2)
+    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(x[0]), "v"(x[1]));
+    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(x[2]), "v"(x[3]));
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const float v = __builtin_fminf(__builtin_fmaxf(x[e], -F16S_MAX), F16S_MAX);  // saturate instead of inf
+        const float v = x[e];
         const _Float16 h = (_Float16)v;  // round to nearest even
         (*hi)[e] = h;
         (*lo)[e] = (_Float16)((v - (float)h) * F16S_LO_SCALE);  // v - h is exact in fp32

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
 
 #include "../../include/dfvo_hip.h"
 
@@ -64,6 +65,12 @@ struct ConvParams {
     // [tap][16-channel chunk][wf16_cout_pad / 32][plane hi, lo][k / 8][32 couts][8] halves, see conv_pack_weights_f16s
     const unsigned short* wf16;
     int wf16_cout_pad;
+    // f16 hi/lo planes in k-group order for the generic split kernel (conv_gemm_f16s.h; every layer in f16x3 mode):
+    // [16-k step][wf16g_cout_pad / 32][plane][k / 8][32 couts][8] halves + the layer's k-group table (4 words per step)
+    const unsigned short* wf16g;
+    int wf16g_cout_pad;
+    const uint32_t* f16g_tab;
+    int f16g_steps;
     int cout, cout_pad, ksteps;
     // optional residual (added before activation)
     const float* res;
@@ -164,13 +171,16 @@ int conv_split_mode();  // 0 exact fp32 (default), 2 = bf16x3, 3 = bf16x6, 4 = f
 // (out may be null to query the size): [tap][chunk][cout_pad32][2][16], chunks = ceil(c0/16) + ceil(c1/16)
 size_t conv_pack_weights_f16s(const float* w_oihw, int cout, int c0, int c1, const float* fold_scale, unsigned short* out);
 int conv_f16s_overflow_count(unsigned long long* n, int reset);  // saturation report of the f16x3 split (conv_win_f16s.h)
+void conv_build_f16g_table(int c0, int c1, int kh, int kw, std::vector<uint32_t>* tab);
+size_t conv_pack_weights_f16g(const float* w_oihw, int cout, int c0, int c1, int kh, int kw, const float* fold_scale,
+                              unsigned short* out);
 size_t conv_head_weight_floats(int cout, int c0, int c1, int k);
 void conv_pack_head_weights(const float* w_oihw, int cout, int c0, int c1, int k, const float* fold_scale, float* out);
 void conv_pack_weights(const float* w_oihw, const float* bias, int cout, int c0, int c1, int kh, int kw,
                        int cout_pad, const float* fold_scale, const float* fold_shift, float* out_w,
                        float* out_b);
 
-constexpr int CONV_NUM_CFGS = 20;  // tile configurations of the implicit-GEMM kernel (profile arrays have this size)
+constexpr int CONV_NUM_CFGS = 24;  // tile configurations of the implicit-GEMM kernel (profile arrays have this size)
 int launch_conv(const ConvParams& p, hipStream_t stream);
 // effective (bm, splits) the launcher would use for p (after clamping the overrides)
 void conv_effective_config(const ConvParams& p, int* bm, int* splits);

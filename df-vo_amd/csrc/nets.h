@@ -30,6 +30,9 @@ struct ConvLayer {
     int wsp_planes = 0;
     unsigned short* wf = nullptr;  // f16 hi/lo planes for conv_win_f16s_kernel (DFVO_CONV_PRECISION=f16x3, 3x3 layers)
     int wf_cout_pad = 0;
+    unsigned short* wg = nullptr;  // f16 hi/lo planes in k-group order for conv_gemm_f16s_kernel (f16x3 mode, every layer)
+    uint32_t* gtab = nullptr;      // its k-group table
+    int wg_cout_pad = 0, g_steps = 0;
     float* wh = nullptr;  // head layout (cout <= 2, square 3/5/7 kernels), see conv_pack_head_weights
     int cout = 0, cout_pad = 0, c0 = 0, c1 = 0, kh = 0, kw = 0, ksteps = 0;
     int stride = 1, pad_h = 0, pad_w = 0, pad_mode = PAD_ZERO, act = ACT_NONE;
@@ -53,6 +56,7 @@ void free_conv(ConvLayer* l);
 // uploads the bf16-plane copy of the packed weights when a split-precision mode is on and the layer is 3x3
 int make_split_weights(const std::vector<float>& packed, int kh, int kw, ConvLayer* L);
 int make_f16s_weights(const float* w_oihw, int cout, int c0, int c1, int kh, int kw, const float* scale, ConvLayer* L);
+int make_f16g_weights(const float* w_oihw, int cout, int c0, int c1, int kh, int kw, const float* scale, ConvLayer* L);
 int conv_set_precision(const char* name);  // fp32 | f16x3 | bf16x6 | bf16x3: applies to layers packed afterwards
 int make_head_weights(const float* w_oihw, int cout, int c0, int c1, int kh, int kw, const float* scale, float** wh);
 

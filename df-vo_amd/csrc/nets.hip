@@ -74,6 +74,7 @@ int make_conv(const ParamStore& ps, const std::string& wname, const std::string&
     DFVO_HIP_CHECK(hipMemcpy(L->bias, pb.data(), pb.size() * sizeof(float), hipMemcpyHostToDevice));
     DFVO_TRY(make_split_weights(pw, L->kh, L->kw, L));
     DFVO_TRY(make_f16s_weights(w->data.data(), L->cout, c0, c1, L->kh, L->kw, scale, L));
+    DFVO_TRY(make_f16g_weights(w->data.data(), L->cout, c0, c1, L->kh, L->kw, scale, L));
     return make_head_weights(w->data.data(), L->cout, c0, c1, L->kh, L->kw, scale, &L->wh);
 }
 
@@ -109,6 +110,21 @@ int make_f16s_weights(const float* w_oihw, int cout, int c0, int c1, int kh, int
     return DFVO_OK;
 }
 
+int make_f16g_weights(const float* w_oihw, int cout, int c0, int c1, int kh, int kw, const float* scale, ConvLayer* L) {
+    if (conv_split_mode() != 4 || kh > 31 || kw > 31) return DFVO_OK;
+    std::vector<unsigned short> wg(conv_pack_weights_f16g(w_oihw, cout, c0, c1, kh, kw, scale, nullptr));
+    conv_pack_weights_f16g(w_oihw, cout, c0, c1, kh, kw, scale, wg.data());
+    std::vector<uint32_t> tab;
+    conv_build_f16g_table(c0, c1, kh, kw, &tab);
+    DFVO_HIP_CHECK(hipMalloc((void**)&L->wg, wg.size() * sizeof(unsigned short) + 256));
+    DFVO_HIP_CHECK(hipMemcpy(L->wg, wg.data(), wg.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
+    DFVO_HIP_CHECK(hipMalloc((void**)&L->gtab, tab.size() * sizeof(uint32_t) + 256));
+    DFVO_HIP_CHECK(hipMemcpy(L->gtab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    L->wg_cout_pad = round_up(cout, 32);
+    L->g_steps = (int)(tab.size() / 4);
+    return DFVO_OK;
+}
+
 int make_split_weights(const std::vector<float>& packed, int kh, int kw, ConvLayer* L) {
     const int planes = conv_split_mode();
     if (planes != 2 && planes != 3) return DFVO_OK;
@@ -138,7 +154,11 @@ void free_conv(ConvLayer* l) {
     if (l->wh) (void)hipFree(l->wh);
     if (l->wsp) (void)hipFree(l->wsp);
     if (l->wf) (void)hipFree(l->wf);
+    if (l->wg) (void)hipFree(l->wg);
+    if (l->gtab) (void)hipFree(l->gtab);
     l->wf = nullptr;
+    l->wg = nullptr;
+    l->gtab = nullptr;
     l->wp = l->bias = l->wh = l->wsp = nullptr;
 }
 
@@ -231,6 +251,10 @@ int run_conv(const ConvLayer& L, int N, int H, int W, View s0, int up0, View s1,
     p.wsp_planes = L.wsp_planes;
     p.wf16 = L.wf;
     p.wf16_cout_pad = L.wf_cout_pad;
+    p.wf16g = L.wg;
+    p.wf16g_cout_pad = L.wg_cout_pad;
+    p.f16g_tab = L.gtab;
+    p.f16g_steps = L.g_steps;
     p.bias = L.bias;
     p.cout = L.cout;
     p.cout_pad = L.cout_pad;

@@ -79,15 +79,17 @@ int dfvo_conv2d(const dfvo_conv_desc* desc, const float* d_src0, const float* d_
  *   "bf16x6" / "bf16x3"  bf16-plane variants (24 / 16 mantissa bits)
  * Also read once from the environment variable DFVO_CONV_PRECISION. */
 int dfvo_set_conv_precision(const char* name);
-/* f16x3 saturation report: the hi plane of the split is f16, so |x| > 65504 is clamped.  Every splitting kernel counts the
- * threads that saw such an activation, the packer the weights; *h_count = events since the last reset (0 = nothing was
- * ever clamped, i.e. the f16x3 result is the 22-bit split of the true operands).  reset != 0 clears the counter. */
+/* f16x3 range report: the hi plane of the split is f16, so an activation with |x| > 65504 does not fit -- it becomes
+ * +-inf and propagates as inf / NaN into the layer's output (never a silently clamped product).  Every splitting kernel
+ * counts the threads that saw such an activation, the packer the weights (those are clamped, and counted);
+ * *h_count = events since the last reset (0 = the f16x3 result is the 22-bit split of the true operands everywhere).
+ * reset != 0 clears the counter. */
 int dfvo_f16s_overflow_count(unsigned long long* h_count, int reset);
 int dfvo_conv_profile_begin(void);
 /* host only: the bf16 planes the opt-in split-precision conv modes (DFVO_CONV_PRECISION=bf16x3 | bf16x6) give a weight:
  * h_out[q * n + i] = plane q of h_in[i], x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1), round to nearest even */
 int dfvo_split_bf16_planes(const float* h_in, int n, int planes, uint16_t* h_out);
-int dfvo_conv_profile_end(double* h_ms19, double* h_flops19, int* h_launches19);
+int dfvo_conv_profile_end(double* h_ms24, double* h_flops24, int* h_launches24);
 
 /* correlation.py:38-106,281-340 (_FunctionCorrelation.forward) followed by leaky_relu(slope)
  * (lite_flow_net.py:145,148).  NHWC inputs [N,H,W,C]; output [N,ceil(H/s),ceil(W/s),52], 49 used.

@@ -88,7 +88,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
-def test_conv(gpu, case):
+def test_conv(gpu, conv_precision, case):
     name, n, h, w, c0, c1, cout, kh, kw, stride, pad, pad_mode, act, up0, use_res = case
     g = torch.Generator().manual_seed(hash(name) % 10000)
     x0 = torch.randn(n, c0, h, w, generator=g)

@@ -34,9 +34,9 @@ def main():
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
     for _ in range(2):
         capi.check(lib.dfvo_conv2d(C.byref(desc), p(x0), p(x1), capi.as_ptr(w), capi.as_ptr(b), None, p(dst), None))
-    ms = np.zeros(20)
-    fl = np.zeros(20)
-    ln = np.zeros(20, np.int32)
+    ms = np.zeros(24)
+    fl = np.zeros(24)
+    ln = np.zeros(24, np.int32)
     capi.check(lib.dfvo_conv_profile_begin())
     for _ in range(IT):
         capi.check(lib.dfvo_conv2d(C.byref(desc), p(x0), p(x1), capi.as_ptr(w), capi.as_ptr(b), None, p(dst), None))

@@ -37,7 +37,7 @@ for name, n, h, w, c0, c1, cout in LAYERS:
         for rep in range(3):
             capi.check(lib.dfvo_conv_profile_begin())
             outs[mode] = run_conv(capi, x0, wt, b, 1, (1, 1), 0, 1, 0.1, x1=x1)
-            ms, fl, ln = np.zeros(20), np.zeros(20), np.zeros(20, np.int32)
+            ms, fl, ln = np.zeros(24), np.zeros(24), np.zeros(24, np.int32)
             capi.check(lib.dfvo_conv_profile_end(capi.as_ptr(ms), capi.as_ptr(fl), capi.as_ptr(ln)))
             best = min(best, ms.sum())
         line += " | %s %7.1f us %6.1f TF/s (cfg %d)" % (mode.decode(), best * 1e3, gf / best, int(np.argmax(ms)))
