@@ -28,9 +28,8 @@ static inline uint32_t f16g_entry(int ky, int kx, int valid, int src, int choff)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(4))) const u32x4 cu32x4;
 
-template <int WP, int KSP, int TC>
+template <int WP, int KSP, int TC, int PF = 3>  // PF: register ring, loads of step s + PF are issued when step s has been consumed
 __global__ __launch_bounds__(64 * WP * KSP) void conv_gemm_f16s_kernel(const ConvParams p) {
-    constexpr int PF = 3;  // register ring: loads of step s + PF are issued when step s has been consumed
     extern __shared__ __attribute__((aligned(16))) float f16g_red[];  // [WP][KSP][TC][16][64] partial blocks (KSP > 1)
 
     const int t = threadIdx.x, lane = t & 63;
@@ -249,13 +248,13 @@ static bool conv_f16g_ok(const ConvParams& p) {
     return true;
 }
 
-template <int WP, int KSP, int TC>
+template <int WP, int KSP, int TC, int PF = 3>
 static int launch_f16g_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) {
     const long long M = (long long)p.N * p.Ho * p.Wo;
     dim3 grid((unsigned)((M + 32 * WP - 1) / (32 * WP)), (unsigned)(p.wf16g_cout_pad / (32 * TC)), 1);
     const size_t lds = KSP > 1 ? (size_t)WP * KSP * TC * 16 * 64 * sizeof(float) : 0;
     if (lds > 48 * 1024)
-        if (int rc_lds = ensure_dyn_lds((const void*)conv_gemm_f16s_kernel<WP, KSP, TC>, lds)) return rc_lds;
+        if (int rc_lds = ensure_dyn_lds((const void*)conv_gemm_f16s_kernel<WP, KSP, TC, PF>, lds)) return rc_lds;
     ConvProfEntry pe;
     if (g_prof) {
         DFVO_HIP_CHECK(hipEventCreate(&pe.e0));
@@ -263,7 +262,7 @@ static int launch_f16g_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) 
         pe.cfg = cfg_id;
         DFVO_HIP_CHECK(hipEventRecord(pe.e0, stream));
     }
-    hipLaunchKernelGGL((conv_gemm_f16s_kernel<WP, KSP, TC>), grid, dim3(64 * WP * KSP), lds, stream, p);
+    hipLaunchKernelGGL((conv_gemm_f16s_kernel<WP, KSP, TC, PF>), grid, dim3(64 * WP * KSP), lds, stream, p);
     DFVO_HIP_CHECK(hipGetLastError());
     if (g_prof) {
         DFVO_HIP_CHECK(hipEventRecord(pe.e1, stream));
@@ -282,10 +281,15 @@ static int launch_f16g(const ConvParams& p, hipStream_t stream) {
     const long long M = (long long)p.N * p.Ho * p.Wo;
     const long long mblocks = (M + 31) / 32;
     const int nblk = p.wf16g_cout_pad / 32;
-    const bool tc2 = (nblk % 2) == 0;
-    const long long tiles = mblocks * (tc2 ? nblk / 2 : nblk);
     static const int force_ksp = getenv("DFVO_F16G_KSP") ? atoi(getenv("DFVO_F16G_KSP")) : 0;
     static const long long target = getenv("DFVO_F16G_WAVES") ? atoll(getenv("DFVO_F16G_WAVES")) : 2048;
+    static const int deep = getenv("DFVO_F16G_PF") ? atoi(getenv("DFVO_F16G_PF")) : 3;  // 5: deeper ring for the K-sliced shapes
+    // two cout blocks per wave only while that still leaves enough (pixel block, cout pair) tiles to fill the chip with
+    // at most eight K slices; tiny maps with many couts (the depth net's 6 x 20 / 12 x 40 layers: the launch is one pass
+    // over megabytes of weights) take one block per wave and up to 16 slices -- more waves, more loads in flight
+    bool tc2 = (nblk % 2) == 0;
+    if (tc2 && mblocks * (nblk / 2) * 8 * 2 < target && p.f16g_steps >= 64) tc2 = false;
+    const long long tiles = mblocks * (tc2 ? nblk / 2 : nblk);
     int ksp = 1;
     // (16 slices only with one cout block per wave: a 1024-thread workgroup leaves 128 registers per lane)
     while (ksp < (tc2 ? 8 : 16) && tiles * ksp * 2 <= target && p.f16g_steps >= 4 * ksp * 2) ksp *= 2;
@@ -295,15 +299,15 @@ static int launch_f16g(const ConvParams& p, hipStream_t stream) {
         switch (ksp) {
             case 1: return launch_f16g_cfg<4, 1, 2>(p, stream, cfg);
             case 2: return launch_f16g_cfg<2, 2, 2>(p, stream, cfg);
-            case 4: return launch_f16g_cfg<1, 4, 2>(p, stream, cfg);
-            default: return launch_f16g_cfg<1, 8, 2>(p, stream, cfg);
+            case 4: return deep == 5 ? launch_f16g_cfg<1, 4, 2, 5>(p, stream, cfg) : launch_f16g_cfg<1, 4, 2>(p, stream, cfg);
+            default: return deep == 5 ? launch_f16g_cfg<1, 8, 2, 5>(p, stream, cfg) : launch_f16g_cfg<1, 8, 2>(p, stream, cfg);
         }
     }
     switch (ksp) {
         case 1: return launch_f16g_cfg<4, 1, 1>(p, stream, cfg);
         case 2: return launch_f16g_cfg<2, 2, 1>(p, stream, cfg);
-        case 4: return launch_f16g_cfg<1, 4, 1>(p, stream, cfg);
-        case 8: return launch_f16g_cfg<1, 8, 1>(p, stream, cfg);
+        case 4: return deep == 5 ? launch_f16g_cfg<1, 4, 1, 5>(p, stream, cfg) : launch_f16g_cfg<1, 4, 1>(p, stream, cfg);
+        case 8: return deep == 5 ? launch_f16g_cfg<1, 8, 1, 5>(p, stream, cfg) : launch_f16g_cfg<1, 8, 1>(p, stream, cfg);
         default: return launch_f16g_cfg<1, 16, 1>(p, stream, cfg);
     }
 }

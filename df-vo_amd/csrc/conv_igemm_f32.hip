@@ -24,6 +24,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 namespace dfvo {
@@ -1129,6 +1131,7 @@ int conv_profile_end(double* ms, double* flops, int* launches) {
 
 #include "conv_win_f16s.h"
 #include "conv_gemm_f16s.h"
+#include "conv_win_f16s2.h"
 
 // split-K when the grid cannot fill the chip: partials to p.ws, ordered reduction in a second launch
 static int conv_pick_splits(const ConvParams& p, long long blocks) {
@@ -1325,7 +1328,10 @@ int launch_conv(const ConvParams& p, hipStream_t stream) {
         if (p.kh == 5) return p.cout == 2 ? launch_head<5, 2>(p, stream, 17) : launch_head<5, 1>(p, stream, 17);
         return p.cout == 2 ? launch_head<3, 2>(p, stream, 18) : launch_head<3, 1>(p, stream, 18);
     }
-    if (p.wf16 && conv_f16s_ok(p)) return launch_f16s(p, stream, 19);  // f16x3: the 3x3 / stride-1 layers whose map fills the chip
+    if (p.wf16 && conv_f16s_ok(p)) {  // f16x3: the 3x3 / stride-1 layers whose map fills the chip
+        const int rc2 = launch_f16s2(p, stream, 19);  // one-wave-per-SIMD skeleton where the grid is large enough
+        return rc2 >= 0 ? rc2 : launch_f16s(p, stream, 19);
+    }
     if (conv_f16g_ok(p)) return launch_f16g(p, stream);  // f16x3: everything else (small maps, 1x1, k x 1, stride 2, 7x7)
     if (conv_use_window(p, bn) && p.kh == 7) return launch_win3<4, 1, 2, 1, 7>(p, stream, 16);
     if (conv_use_window(p, bn) && p.kh == 5) return launch_win3<4, 1, 2, 1, 5>(p, stream, 17);

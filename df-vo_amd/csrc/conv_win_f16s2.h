@@ -1,0 +1,273 @@
+// conv_win_f16s_kernel, second skeleton: ONE wave per SIMD with a large register tile, software-pipelined.
+//
+// What the first skeleton (conv_win_f16s.h) could not do inside 256 registers at two waves per SIMD: hold the pixel
+// fragments of the NEXT tap while the current tap's MFMAs run.  Its waves issue their eight ds_read_b128 just in time, wait,
+// then issue 12 MFMAs (384 cycles); the matrix pipe of a SIMD idles whenever both of its waves sit in that phase together
+// (counters, profiles/r2c_pmc_f16s_L2_128x128.txt: 41.6 % busy; a memory-free loop of that shape: 46 % of peak).
+// Here a wave owns (32 TC) couts x TR rows x 32 pixels with TC x TR up to 2 x 4: 24 MFMAs (768 cycles) per tap against 4
+// weight-fragment loads and 8 pixel-fragment reads, the 2 x TC x TR x 16 accumulator registers in AGPRs, and
+//   * the pixel fragments of tap t + 1 are read from LDS while the MFMAs of tap t issue (two register sets),
+//   * the weight fragments of tap t + 2 are requested from L2 at tap t (ring of three, as before),
+//   * the window items of the next chunk are loaded and split one per tap (as before),
+// so the only exposed latencies are the first pixel-fragment read after the per-chunk barrier and the barrier itself
+// (once per 9 taps = 216 MFMAs).  One 4-wave workgroup per CU (512 registers per lane: __launch_bounds__(256, 1)).
+// Same arithmetic, window layout, weight packing and epilogue as conv_win_f16s_kernel.
+#pragma once
+// (included inside namespace dfvo, after conv_win_f16s.h)
+
+template <class F, int... T>
+__device__ __forceinline__ void f16s2_static_for_impl(F&& f, std::integer_sequence<int, T...>) {
+    (f(std::integral_constant<int, T>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void f16s2_static_for(F&& f) {  // f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>)
+    f16s2_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+template <int WC, int WR, int TC, int TR>
+__global__ __launch_bounds__(64 * WC * WR, 1) void conv_win_f16s2_kernel(const ConvParams p) {
+    constexpr int NT = 64 * WC * WR;
+    constexpr int TH = WR * TR, TW = 32, WH = TH + 2, WW = TW + 2, PS = 20;  // pixel stride in dwords (80 bytes)
+    constexpr int BN = WC * TC * 32;
+    constexpr int WIN = (WH * WW + 1) * PS;  // + one pixel slot that absorbs the stores of the items beyond the window
+    constexpr int W_ITEMS = WH * WW * 4;
+    constexpr int W_CNT = (W_ITEMS + NT - 1) / NT;
+    static_assert(W_CNT <= 9, "one window item per tap");
+    static_assert(WC * WR == 4, "4 waves per block");
+    __shared__ __attribute__((aligned(16))) float lds[2 * WIN];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wc = wave / WR, wr = wave % WR;
+    const int lp = lane & 31, kb = lane >> 5;
+    const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
+    const int nb = gridDim.x;
+    int bid = blockIdx.x;
+    {  // XCD-aware order: each XCD walks a contiguous run of tiles (neighbours share halo rows in its L2)
+        const int q = nb >> 3, r = nb & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
+    const int n = bid / (tiles_y * tiles_x);
+    const int trem = bid - n * (tiles_y * tiles_x);
+    const int ty0 = (trem / tiles_x) * TH, tx0 = (trem % tiles_x) * TW;
+    const int n0 = blockIdx.y * BN;
+    const int nchunk0 = (p.G0 + 3) >> 2, nchunk1 = (p.G1 + 3) >> 2, nchunks = nchunk0 + nchunk1;
+
+    // window items of this thread: (pixel, 4-channel group q = t & 3 of the chunk).  Their pixel offsets inside both sources
+    // are computed ONCE (the register file has room at one wave per SIMD): what is left per chunk is one add and one
+    // compare per item -- in the first skeleton the per-item address arithmetic and the kernarg re-loads it drags along
+    // (SGPR pressure) sat between the taps' MFMA groups, where nothing covers them.
+    f32x4 rw[W_CNT];
+    float amax = 0.f;
+    unsigned rwv = 0;
+    int w_off0[W_CNT], w_off1[W_CNT];
+    unsigned w_ok = 0;
+    const int wq = t & 3;  // (NT is a multiple of 4: every item of a thread has the same channel group)
+#pragma unroll
+    for (int r = 0; r < W_CNT; ++r) {
+        const int id = t + NT * r;
+        const int px = id >> 2;
+        const int wy = px / WW, wx = px - wy * WW;
+        int iy = ty0 - 1 + wy, ix = tx0 - 1 + wx;
+        bool v = id < W_ITEMS;
+        if (p.pad_mode == PAD_REFLECT) {
+            iy = reflect_idx(iy, p.H);
+            ix = reflect_idx(ix, p.W);
+        }
+        v = v && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        iy = iy < 0 ? 0 : (iy >= p.H ? p.H - 1 : iy);
+        ix = ix < 0 ? 0 : (ix >= p.W ? p.W - 1 : ix);
+        const int sh = p.up0;
+        w_off0[r] = (((n * (p.H >> sh) + (iy >> sh)) * (p.W >> sh) + (ix >> sh)) * p.cs0) + p.co0;
+        w_off1[r] = (((n * p.H + iy) * p.W + ix) * p.cs1) + p.co1;
+        w_ok |= (v ? 1u : 0u) << r;
+    }
+    const int G0 = __builtin_amdgcn_readfirstlane(p.G0), G1 = __builtin_amdgcn_readfirstlane(p.G1);
+    auto load_window_item = [&](int c, int r) {
+        const bool s1 = c >= nchunk0;
+        const int cg = (s1 ? (c - nchunk0) * 4 : c * 4) + wq;
+        const bool v = ((w_ok >> r) & 1u) && cg < (s1 ? G1 : G0);
+        const float* base = s1 ? p.src1 : p.src0;
+        const int off = (s1 ? w_off1[r] : w_off0[r]) + (v ? cg * 4 : 0);  // masked lanes re-read channel group 0
+        rw[r] = *reinterpret_cast<const f32x4*>(base + off);
+        rwv = (rwv & ~(1u << r)) | ((v ? 1u : 0u) << r);
+    };
+    auto store_window_item = [&](float* W, int r) {
+        const int id = t + NT * r;
+        const int px = (id >> 2) < WH * WW ? (id >> 2) : WH * WW;  // (no branch: out-of-window items land in the spare slot)
+        h16x4 hi, lo;
+        split_f16_planes(((rwv >> r) & 1u) ? rw[r] : f32x4{0.f, 0.f, 0.f, 0.f}, &hi, &lo, amax);
+        float* dst = W + px * PS + wq * 2;
+        *reinterpret_cast<h16x4*>(dst) = hi;
+        *reinterpret_cast<h16x4*>(dst + 8) = lo;
+    };
+    const unsigned short* wbase = p.wf16 + ((size_t)(n0 + wc * TC * 32) * 32 + (kb * 32 + lp) * 8);
+    const size_t w_chunk_stride = (size_t)p.wf16_cout_pad * 32;  // halves per (tap, chunk)
+    h16x8 wa[3][TC][2];
+    auto load_w = [&](int stage, int tap, int c) {
+        const unsigned short* g = wbase + ((size_t)tap * nchunks + c) * w_chunk_stride;
+#pragma unroll
+        for (int i = 0; i < TC; ++i) {
+            wa[stage][i][0] = *reinterpret_cast<const h16x8*>(g + (size_t)i * 32 * 32);
+            wa[stage][i][1] = *reinterpret_cast<const h16x8*>(g + (size_t)i * 32 * 32 + 512);
+        }
+    };
+    h16x8 xb[2][TR][2];
+    auto read_x = [&](const float* Wc, int set, int tap) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+        for (int j = 0; j < TR; ++j) {
+            const float* px = Wc + ((wr * TR + j + ky) * WW + (lp + kx)) * PS + kb * 4;
+            xb[set][j][0] = *reinterpret_cast<const h16x8*>(px);
+            xb[set][j][1] = *reinterpret_cast<const h16x8*>(px + 8);
+        }
+    };
+
+    f32x16 am[TC][TR], ax[TC][TR];
+#pragma unroll
+    for (int i = 0; i < TC; ++i)
+#pragma unroll
+        for (int j = 0; j < TR; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) am[i][j][e] = ax[i][j][e] = 0.f;
+
+#pragma unroll
+    for (int r = 0; r < W_CNT; ++r) load_window_item(0, r);
+    load_w(0, 0, 0);
+    load_w(1, 1, 0);
+#pragma unroll
+    for (int r = 0; r < W_CNT; ++r) store_window_item(lds, r);
+    __syncthreads();
+    // one chunk = 9 taps, branch-free, so that the whole chunk is one scheduling region and the interleave below is what
+    // the hardware sees.  The last chunk prefetches itself again (window into the idle buffer, first two weight
+    // fragments) instead of running a second, prefetch-free copy of the loop body: a second instantiation gets its own
+    // register assignment and pays ~280 v_accvgpr moves to get there.
+    constexpr bool next_chunk = true;
+    for (int c = 0; c < nchunks; ++c) {
+        const float* Wc = lds + (c & 1) * WIN;
+        float* Wn = lds + ((c + 1) & 1) * WIN;
+        const int c_next = c + 1 < nchunks ? c + 1 : c;
+        read_x(Wc, 0, 0);
+        f16s2_static_for<9>([&](auto tap_c) {
+            constexpr int tap = decltype(tap_c)::value;
+            constexpr int cur = tap % 3, xs = tap & 1;
+            if (tap < 7)
+                load_w((tap + 2) % 3, tap + 2, c);
+            else if (next_chunk)
+                load_w((tap + 2) % 3, tap - 7, c_next);
+            if (next_chunk && tap < W_CNT) load_window_item(c_next, tap);
+            __builtin_amdgcn_sched_barrier(0);  // the requests stay ahead of the tap's arithmetic
+            if (tap < 8) read_x(Wc, xs ^ 1, tap + 1);
+            constexpr int ST0 = 9 - W_CNT;
+            if (next_chunk && tap >= ST0) store_window_item(Wn, tap - ST0);
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TR; ++j)
+                    ax[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][i][0], xb[xs][j][1], ax[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TR; ++j)
+                    ax[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][i][1], xb[xs][j][0], ax[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TC; ++i)
+#pragma unroll
+                for (int j = 0; j < TR; ++j)
+                    am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][i][0], xb[xs][j][0], am[i][j], 0, 0, 0);
+            // interleave: the next tap's pixel-fragment reads one per MFMA first, then the window item's split (about 30
+            // VALU instructions) two per MFMA, its two LDS writes last -- everything inside the shadow of the tap's MFMAs
+            constexpr int NM = 3 * TC * TR, NR = tap < 8 ? 2 * TR : 0;
+#pragma unroll
+            for (int k = 0; k < NM; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                if (k < NR)
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                else if (next_chunk && tap >= ST0)
+                    __builtin_amdgcn_sched_group_barrier(0x2, NM - NR >= 16 ? 2 : 4, 0);
+            }
+            if (next_chunk && tap >= ST0) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        __syncthreads();
+    }
+    f16s_report_clamp(amax);
+
+    const int ox = tx0 + lp;
+    const bool vec_ok = conv_vec_ok(p);
+#pragma unroll
+    for (int j = 0; j < TR; ++j) {
+        const int oy = ty0 + wr * TR + j;
+        if (oy >= p.Ho || ox >= p.Wo) continue;
+        const size_t m = ((size_t)n * p.Ho + oy) * p.Wo + ox;
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col0 = n0 + (wc * TC + i) * 32 + 8 * g + 4 * kb;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = am[i][j][4 * g + e] + F16S_LO_UNSCALE * ax[i][j][4 * g + e];
+                conv_epilogue_quad(p, m, col0, v, vec_ok);
+            }
+    }
+}
+
+template <int WC, int WR, int TC, int TR>
+static long long f16s2_blocks(const ConvParams& p) {
+    constexpr int TH = WR * TR, BN = WC * TC * 32;
+    if (p.wf16_cout_pad % BN != 0) return 0;
+    return (long long)p.N * ((p.Ho + TH - 1) / TH) * ((p.Wo + 31) / 32) * (p.wf16_cout_pad / BN);
+}
+
+template <int WC, int WR, int TC, int TR>
+static int launch_f16s2_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) {
+    constexpr int TH = WR * TR, BN = WC * TC * 32;
+    const int tiles = p.N * ((p.Ho + TH - 1) / TH) * ((p.Wo + 31) / 32);
+    dim3 grid((unsigned)tiles, (unsigned)(p.wf16_cout_pad / BN), 1);
+    ConvProfEntry pe;
+    if (g_prof) {
+        DFVO_HIP_CHECK(hipEventCreate(&pe.e0));
+        DFVO_HIP_CHECK(hipEventCreate(&pe.e1));
+        pe.cfg = cfg_id;
+        DFVO_HIP_CHECK(hipEventRecord(pe.e0, stream));
+    }
+    hipLaunchKernelGGL((conv_win_f16s2_kernel<WC, WR, TC, TR>), grid, dim3(64 * WC * WR), 0, stream, p);
+    DFVO_HIP_CHECK(hipGetLastError());
+    if (g_prof) {
+        DFVO_HIP_CHECK(hipEventRecord(pe.e1, stream));
+        pe.flops = p.useful_flops;
+        const int sh[12] = {p.N, p.H, p.W, p.Ho, p.Wo, (p.G0 + p.G1) * 4, p.cout, p.kh, p.stride, (int)grid.x, (int)grid.y, 2};
+        for (int i = 0; i < 12; ++i) pe.shape[i] = sh[i];
+        g_prof->push_back(pe);
+    }
+    return DFVO_OK;
+}
+
+// Tile choice for the one-wave-per-SIMD skeleton (one workgroup per CU): the rows per tile that minimise
+// rounds x rows for the layer's grid among the instantiated shapes.  Returns -1 when the layer should stay on the first
+// skeleton (small grids: fewer than ~200 workgroups cannot fill the chip at one workgroup per CU).
+static int launch_f16s2(const ConvParams& p, hipStream_t stream, int cfg_id) {
+    static const int mode = getenv("DFVO_F16S_V2") ? atoi(getenv("DFVO_F16S_V2")) : 0;
+    if (!mode) return -1;
+    const int ncu = 256;
+    auto cost = [&](long long blocks, int rows) { return blocks <= 0 ? (1LL << 60) : ((blocks + ncu - 1) / ncu) * rows; };
+    if (p.wf16_cout_pad % 128 == 0) {
+        const long long b4 = f16s2_blocks<2, 2, 2, 4>(p), b3 = f16s2_blocks<2, 2, 2, 3>(p), b2 = f16s2_blocks<2, 2, 2, 2>(p);
+        if (b2 < 200) return -1;
+        const long long c4 = cost(b4, 8), c3 = cost(b3, 6), c2 = cost(b2, 4) * 11 / 10;  // (small tiles: fewer MFMAs per load)
+        if ((mode & 2) || (c4 <= c3 && c4 <= c2)) return launch_f16s2_cfg<2, 2, 2, 4>(p, stream, cfg_id);
+        if (c3 <= c2) return launch_f16s2_cfg<2, 2, 2, 3>(p, stream, cfg_id);
+        return launch_f16s2_cfg<2, 2, 2, 2>(p, stream, cfg_id);
+    }
+    if (p.wf16_cout_pad % 64 == 0) {
+        const long long b3 = f16s2_blocks<1, 4, 2, 3>(p), b2 = f16s2_blocks<1, 4, 2, 2>(p);
+        if (b2 < 200) return -1;
+        if ((mode & 2) || cost(b3, 12) <= cost(b2, 8)) return launch_f16s2_cfg<1, 4, 2, 3>(p, stream, cfg_id);
+        return launch_f16s2_cfg<1, 4, 2, 2>(p, stream, cfg_id);
+    }
+    const long long b3 = f16s2_blocks<1, 4, 1, 3>(p), b2 = f16s2_blocks<1, 4, 1, 2>(p);
+    if (b2 < 200) return -1;
+    if ((mode & 2) || cost(b3, 12) <= cost(b2, 8)) return launch_f16s2_cfg<1, 4, 1, 3>(p, stream, cfg_id);
+    return launch_f16s2_cfg<1, 4, 1, 2>(p, stream, cfg_id);
+}
