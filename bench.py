@@ -2,7 +2,8 @@
 """bench.py -- KITTI-sized frame pairs per second through the DF-VO tracking hot path on MI355X.
 
 One step = one frame pair (1241x376): monodepth2 depth + LiteFlowNet forward/backward flow + consistency
-(HIP fp32-MFMA nets), local_bestN keypoint selection, homography + 5 x five-point RANSAC + GRIC +
+(HIP nets: f16x3 split products on the f16 matrix cores by default, fp32-class; `exact_fp32` in the same JSON line is the
+all-fp32-MFMA path timed in the same run), local_bestN keypoint selection, homography + 5 x five-point RANSAC + GRIC +
 recoverPose, depth-ratio scale RANSAC (PnP fallback where the reference takes it), pose out.  Inputs (the two uint8
 frames) are resident in HBM before the timed region; the Pillow-exact LANCZOS resize of the depth input runs on the
 device inside it.
@@ -16,7 +17,16 @@ solver stage fed a synthetic rigid-scene flow / consistency / depth triple of th
 
     python bench.py [--gpus N --steps K --warmup W]
 N > 1: one process per GPU over RCCL.  Under torch.distributed.run (WORLD_SIZE set) this process is one rank; run
-directly, bench.py re-launches itself under torch.distributed.run with N ranks on 127.0.0.1.
+directly, bench.py re-launches itself under torch.distributed.run with N ranks on 127.0.0.1.  The N ranks track ONE
+sequence of N x K pairs: contiguous chunk per rank from its 1-frame halo (df-vo_amd/sequence.py run_sequence), one
+all-gather of the relative poses, prefix composition on every rank; rank 0 then re-tracks the whole sequence alone
+(outside the timed region) and checks the gathered poses bit for bit.
+
+--surface mirrors   times the drop-in class surface instead of the fused pipeline object: DeepModel / KeypointSampler /
+                    EssTracker / PnpTracker built from weight FILES, host numpy arrays in and out, the frame loop of
+                    DFVO.main, torch touching the GPU first; per-stage ms under the reference's Timer keys.
+--frames host       frames arrive in pinned host memory: each pair's new frame is uploaded on a copy stream inside the
+                    timed region, overlapped with the nets of the pairs in flight (default: frames resident in HBM).
 
 Prints ONE JSON line on rank 0 (contract in the task description; `roofline` and `cpu_baseline` added).
 """
@@ -37,6 +47,21 @@ SLOTS = 4  # DFVO_PIPELINE_SLOTS
 PREFETCH = os.environ.get("DFVO_BENCH_PREFETCH", "1") != "0"  # RNG-independent solver half enqueued behind the nets
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: FP32 matrix (f32 in / f32 acc)
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # same table: BF16 MFMA dense (only used for the opt-in split-precision modes)
+PMC_FILE = "r3_pmc_bench.json"  # committed rocprofv3 --pmc passes over the default command (tools/r3_profile.sh)
+
+
+def kernel_source_digest():
+    """digest of the conv kernel sources: ties a committed PMC profile to the build it was taken on"""
+    import hashlib
+    h = hashlib.sha1()
+    for f in ("conv_igemm_f32.hip", "conv_win_f16s.h", "conv_win_f16s2.h", "conv_gemm_f16s.h"):
+        try:
+            h.update(open(os.path.join(ROOT, "df-vo_amd", "csrc", f), "rb").read())
+        except OSError:
+            pass
+    return h.hexdigest()[:12]
+
+
 CFG_NAMES = ["conv_igemm_f32<2,2,4,4> 128x128", "conv_igemm_f32<1,4,2,2> 32x128", "conv_igemm_f32<4,1,4,4> 256x64",
              "conv_igemm_f32<2,2,2,2> 64x64", "conv_igemm_f32<4,1,4,2> 256x32", "conv_igemm_f32<2,2,2,1> 64x32",
              "conv_igemm_f32<4,1,4,1> 256x16", "conv_igemm_f32<4,1,1,1> 64x16", "conv_igemm_f32<1,4,4,2> 64x128",
@@ -153,6 +178,124 @@ def device_sync():
     torch.cuda.synchronize()
 
 
+def run_mirrors(args, syn, capi, h_frames, K, fsd, dsd, code_mode):
+    """--surface mirrors: the frame loop of DFVO.main (/root/reference/libs/dfvo.py:347-425: deep_model_inference :299-345,
+    tracking :121-262, update_global_pose :109-119) over the drop-in classes exactly as libs/dfvo.py instantiates them --
+    DeepModel(cfg).initialize_models() from weight FILES in the reference's on-disk formats, KeypointSampler(cfg),
+    EssTracker / PnpTracker(cfg, cam_intrinsics) -- with host numpy arrays in and out of every call (2 x 1.4 MB H2D +
+    9.8 MB D2H per pair, synchronous), the library's default exact-fp32 nets unless --conv-precision says otherwise, and
+    torch touching the GPU before the library creates its streams (as apis/run.py's imports do).  Per-stage host times
+    under the reference's Timer keys (libs/general/timer.py; dfvo.py:146-246,305-335)."""
+    import tempfile
+    import torch
+    torch.zeros(8, device="cuda").sum().item()  # the caller used the GPU first
+    cfg_mod = importlib.import_module("df-vo_amd.default_cfg")
+    dm_mod = importlib.import_module("df-vo_amd.libs.deep_models.deep_models")
+    cam_mod = importlib.import_module("df-vo_amd.libs.geometry.camera_modules")
+    ks_mod = importlib.import_module("df-vo_amd.libs.matching.keypoint_sampler")
+    trk_mod = importlib.import_module("df-vo_amd.libs.tracker")
+    H, W = args.height, args.width
+    tmp = tempfile.mkdtemp(prefix="dfvo_bench_")
+    flow_path, depth_dir = syn.write_weight_files(tmp, fsd, dsd)
+    cfg = cfg_mod.default_configuration(H, W, flow_path, depth_dir)
+    deep_models = dm_mod.DeepModel(cfg)
+    deep_models.initialize_models()
+    cam = cam_mod.Intrinsics([K[0, 2], K[1, 2], K[0, 0], K[1, 1]])
+    sampler = ks_mod.KeypointSampler(cfg)
+    e_tracker, pnp_tracker = trk_mod.EssTracker(cfg, cam, None), trk_mod.PnpTracker(cfg, cam)
+    SE3 = cam_mod.SE3
+    np.random.seed(cfg.seed)
+    keys = ["depth_cnn", "flow_cnn", "kp_sel", "E-tracker", "scale_recovery", "pnp", "deep_inference", "tracking", "DF-VO"]
+    acc = {k: 0.0 for k in keys}
+    fh, fw = deep_models.depth.feed_height, deep_models.depth.feed_width
+    ys = np.minimum(np.floor(np.arange(H) * (fh / float(H))).astype(np.int64), fh - 1)  # cv2.resize INTER_NEAREST, dfvo.py:314-317
+    xs = np.minimum(np.floor(np.arange(W) * (fw / float(W))).astype(np.int64), fw - 1)
+    y0, y1 = int(H * cfg.crop.depth_crop[0][0]), int(H * cfg.crop.depth_crop[0][1])
+    x0, x1 = int(W * cfg.crop.depth_crop[1][0]), int(W * cfg.crop.depth_crop[1][1])
+    crop_mask = np.zeros((H, W))
+    crop_mask[y0:y1, x0:x1] = 1
+    ref_data, cur_data = {}, {}
+    global_pose = SE3()
+    modes = []
+    n_frames = args.warmup + args.steps + 1
+    t_begin = None
+    for img_id in range(n_frames):
+        if img_id == args.warmup + 1:  # frame 0 only gets its depth; `warmup` untimed pairs, then `steps` timed ones
+            acc = {k: 0.0 for k in keys}
+            modes = []
+            t_begin = time.perf_counter()
+        tf0 = time.perf_counter()
+        cur_data["id"], cur_data["timestamp"], cur_data["img"] = img_id, img_id, h_frames[img_id % 2]
+        t0 = time.perf_counter()
+        raw = deep_models.forward_depth(imgs=[cur_data["img"]])
+        cur_data["raw_depth"] = raw[ys][:, xs]
+        d = cur_data["raw_depth"]
+        cur_data["depth"] = d * (crop_mask * ((d < cfg.depth.max_depth) * (d > cfg.depth.min_depth)))  # preprocess_depth, utils.py:89-114
+        t1 = time.perf_counter()
+        acc["depth_cnn"] += t1 - t0
+        if img_id >= 1:
+            flows = deep_models.forward_flow(cur_data, ref_data, forward_backward=cfg.deep_flow.forward_backward)
+            ref_data["flow"] = flows[(ref_data["id"], cur_data["id"])].copy()        # dfvo.py:330-333
+            cur_data["flow"] = flows[(cur_data["id"], ref_data["id"])].copy()
+            ref_data["flow_diff"] = flows[(ref_data["id"], cur_data["id"], "diff")].copy()
+            t2 = time.perf_counter()
+            acc["flow_cnn"] += t2 - t1
+            acc["deep_inference"] += t2 - t0
+            kp_sel = sampler.kp_selection(cur_data, ref_data)
+            t3 = time.perf_counter()
+            acc["kp_sel"] += t3 - t2
+            mode = "Constant motion"
+            hybrid = SE3()
+            if kp_sel["good_kp_found"]:
+                sampler.update_kp_data(cur_data, ref_data, kp_sel)
+                mode = "Ess. Mat."
+                e_out = e_tracker.compute_pose_2d2d(ref_data["kp_best"], cur_data["kp_best"], True)
+                E_pose = e_out["pose"]
+                hybrid.R = E_pose.R
+                t4 = time.perf_counter()
+                acc["E-tracker"] += t4 - t3
+                scale = -1
+                if np.linalg.norm(E_pose.t) != 0:
+                    scale = e_tracker.scale_recovery(cur_data, ref_data, E_pose, False)["scale"]
+                    if scale != -1:
+                        hybrid.t = E_pose.t * scale
+                t5 = time.perf_counter()
+                acc["scale_recovery"] += t5 - t4
+                if np.linalg.norm(E_pose.t) == 0 or scale == -1:
+                    hybrid = pnp_tracker.compute_pose_3d2d(ref_data["kp_best"], cur_data["kp_best"], ref_data["depth"], True)["pose"]
+                    mode = "PnP"
+                    acc["pnp"] += time.perf_counter() - t5
+            global_pose.t = global_pose.R @ hybrid.t + global_pose.t
+            global_pose.R = global_pose.R @ hybrid.R
+            acc["tracking"] += time.perf_counter() - t2
+            modes.append(mode)
+        else:
+            acc["deep_inference"] += t1 - t0
+        ref_data = dict(cur_data)
+        ref_data["flow"] = cur_data["flow"] = ref_data["flow_diff"] = None
+        acc["DF-VO"] += time.perf_counter() - tf0
+    capi.check(capi.lib().dfvo_sync_device())
+    dt = time.perf_counter() - t_begin
+    net_h, net_w = syn._net_size(H, W)
+    line = {
+        "metric": "KITTI-odom frames/sec (DF-VO per-pair tracking hot path: monodepth2 + LiteFlowNet fwd/bwd + "
+                  "kp selection + E/H RANSAC + scale)",
+        "value": round(args.steps / dt, 3), "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.conv_precision == "fp32" else "f32 (%s split products)" % args.conv_precision, "data": "synthetic",
+        "config": {"workload": "%dx%d frame pairs (flow net %dx%d batch 2; depth net 192x640) through the drop-in class surface: "
+                               "DeepModel.forward_depth / forward_flow, KeypointSampler.kp_selection, EssTracker.compute_pose_2d2d / "
+                               "scale_recovery, PnpTracker.compute_pose_3d2d built from weight files; host numpy arrays in and out of "
+                               "every call, synchronous; torch touched the GPU first" % (W, H, net_h, net_w),
+                   "surface": "mirrors", "conv_precision": args.conv_precision,
+                   "solver_inputs": "the nets' own outputs, coded tunnel-world frames, '%s' encoding, ping-pong" % code_mode,
+                   "tracked_by_E": modes.count("Ess. Mat."), "tracked_by_PnP": modes.count("PnP"),
+                   "constant_motion": modes.count("Constant motion")},
+        "stage_ms_per_pair": {k: round(v / args.steps * 1e3, 3) for k, v in acc.items()},
+        "roofline": None, "cpu_baseline": None}
+    print(json.dumps(line))
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -171,6 +314,11 @@ def main(argv=None):
                          "synthetic: random-weight nets + a synthetic rigid-scene flow/consistency/depth triple (round-1 mode)")
     ap.add_argument("--e-max-iters", type=int, default=1000, help="findEssentialMat hypothesis budget (config 5: 8192)")
     ap.add_argument("--kp-bestn", type=int, default=2000, help="kp_selection.local_bestN.num_bestN (config 5: 20000)")
+    ap.add_argument("--surface", default="fused", choices=["fused", "mirrors"],
+                    help="fused: the dfvo_pipeline_* object (default); mirrors: the reference's class surface over host arrays")
+    ap.add_argument("--frames", default="device", choices=["device", "host"],
+                    help="host: pinned host frames, H2D on a copy stream inside the timed region")
+    ap.add_argument("--no-exact-leg", action="store_true", help="skip the second timed leg in exact fp32 (exact_fp32 in the JSON line)")
     args = ap.parse_args(argv)
     os.environ["DFVO_CONV_PRECISION"] = args.conv_precision  # read once by the library when the layers are packed
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -192,9 +340,10 @@ def main(argv=None):
 
     H, W = args.height, args.width
     nets_mode = args.solver_inputs == "nets"
+    smod = importlib.import_module("df-vo_amd.sequence") if world > 1 else None
     dev = to_device
     d_feed = None  # the pipeline resizes the current frame itself (device LANCZOS, bit-exact with Pillow)
-    popts = dict(seed=4869 ^ rank, e_max_iters=args.e_max_iters, kp_num_bestN=args.kp_bestn)  # per-rank RandomState: DP mode
+    popts = dict(seed=4869, e_max_iters=args.e_max_iters, kp_num_bestN=args.kp_bestn)
     # Everything the host prepares (frames, scenes, weights) first, THEN the pipeline, THEN the device copies of the inputs:
     # the pair rate depends on the order in which the process creates its HIP streams (133 vs 109 frames/s, exact fp32, same
     # binary and box: which compute pipes the pipeline's streams share follows their creation order, see
@@ -203,49 +352,94 @@ def main(argv=None):
         # coded tunnel world: multiplexed encoding when the frame needs no input resize, potential encoding otherwise
         code_mode = "mux" if syn._net_size(H, W) == (H, W) else "pot"
         # (potential encoding: the sideways drive, for which it yields E-tracked pairs -- tunnel_poses_lateral)
-        seq = syn.coded_tunnel_sequence(H, W, 2, mode=code_mode, step=1.0, seed=7 + rank,
+        seq = syn.coded_tunnel_sequence(H, W, 2, mode=code_mode, step=1.0, seed=7,
                                         poses=None if code_mode == "mux" else syn.tunnel_poses_lateral(2, 0.4))
         K = seq["K"]
         fsd, dsd = syn.crafted_liteflownet_state_dict(H, W, code_mode), syn.crafted_monodepth2_state_dict()
         scenes = None
         h_frames = [seq["frames"][0], seq["frames"][1]]
     else:
-        scenes = [syn.rigid_scene(H, W, seed=100 + 7 * rank + i) for i in range(4)]
+        if world > 1:
+            raise SystemExit("bench.py: --gpus N tracks one sequence through the product data path (--solver-inputs nets)")
+        scenes = [syn.rigid_scene(H, W, seed=100 + i) for i in range(4)]
         K = scenes[0]["K"]
         fsd, dsd = syn.liteflownet_state_dict(4869), syn.monodepth2_state_dict(4869)
-        h_frames = list(syn.image_pair(H, W, seed=1 + rank))
+        h_frames = list(syn.image_pair(H, W, seed=1))
+
+    if args.surface == "mirrors":
+        if world > 1 or not nets_mode:
+            raise SystemExit("bench.py: --surface mirrors is a single-GPU mode over the product data path")
+        return run_mirrors(args, syn, capi, h_frames, K, fsd, dsd, code_mode)
+
     pipe = pmod.TrackingPipeline(H, W, 192, 640, K, fsd, dsd, **popts)
     d_frames = [dev(f) for f in h_frames]
     if not nets_mode:
         d_sc = [(dev(s["flow"]), dev(s["diff"]), dev(s["depth_cur"])) for s in scenes]
         d_ref_depth = dev(scenes[0]["depth_ref"])
+    host_frames = args.frames == "host" and on_gpu
+    if host_frames:
+        # frames arrive in pinned host memory; the new frame of every pair is uploaded on a copy stream while the nets of
+        # the pairs in flight run.  Ring of device buffers: a buffer is rewritten SLOTS + 3 frames later, long after the
+        # nets of the last pair that read it have finished (track() of that pair has returned before the upload is issued)
+        ring = [torch.empty_like(d_frames[0]) for _ in range(SLOTS + 3)]
+        h_pinned = [torch.from_numpy(np.ascontiguousarray(f)).pin_memory() for f in h_frames]
+        copy_stream = torch.cuda.Stream()
+        pending = {}
+
+        def upload(fidx):
+            buf = ring[fidx % len(ring)]
+            with torch.cuda.stream(copy_stream):
+                buf.copy_(h_pinned[fidx % 2], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(copy_stream)
+            pending[fidx] = ev
+
+        def frame_on_device(fidx):  # ordering contract of enqueue_nets: the frame is complete when it is handed over
+            ev = pending.pop(fidx, None)
+            if ev is not None:
+                ev.synchronize()
+            return ring[fidx % len(ring)]
 
     host_t = [0.0, 0.0]  # host seconds inside enqueue_nets / track (DFVO_BENCH_TRACE=1 prints them)
+    t_track = []         # completion time of every track() of the last run (steady-state rate)
 
-    def run(n):
+    def run(p, n):
         """software pipeline: the nets of pairs k+1, k+2 are enqueued before the solver stage of pair k blocks the host"""
         g = np.eye(4)
         prev = np.eye(4)
         rel_all = np.zeros((n, 4, 4))
         status = np.zeros(n, np.int64)
+        del t_track[:]
         if n == 0:
             return rel_all, status
-        if nets_mode:
-            pipe.set_ref_image(d_frames[0])  # depth of the first reference frame (PnP fallback input), from the frame itself
+        if host_frames:
+            pending.clear()
+            upload(0)
+            upload(1)
+            p.set_ref_image(frame_on_device(0))
+        elif nets_mode:
+            p.set_ref_image(d_frames[0])  # depth of the first reference frame (PnP fallback input), from the frame itself
         else:
-            pipe.set_ref_depth(depth=d_ref_depth)
+            p.set_ref_depth(depth=d_ref_depth)
         # nets run `ahead` pairs ahead of the solver stage (<= SLOTS - 1): with 3, each of the two flow-net instances always
         # has its next pair queued behind the current one while track(k) blocks the host
         ahead = int(os.environ.get("DFVO_BENCH_AHEAD", "3"))
+
         def feed(j):  # nets of pair j, then the RNG-independent half of its solver stage right behind them
-            if nets_mode:  # ping-pong A->B, B->A: every pair (and the rolled-over reference depth) is consistent
-                pipe.enqueue_nets(j % SLOTS, d_frames[j % 2], d_frames[1 - j % 2], d_feed)
+            if host_frames:
+                upload(j + 2)  # the frame the NEXT feed needs: its upload overlaps this pair's nets
+                p.enqueue_nets(j % SLOTS, frame_on_device(j), frame_on_device(j + 1), d_feed)
                 if PREFETCH:
-                    pipe.prefetch_track(j % SLOTS)
+                    p.prefetch_track(j % SLOTS)
                 return
-            pipe.enqueue_nets(j % SLOTS, d_frames[0], d_frames[1], d_feed)
+            if nets_mode:  # ping-pong A->B, B->A: every pair (and the rolled-over reference depth) is consistent
+                p.enqueue_nets(j % SLOTS, d_frames[j % 2], d_frames[1 - j % 2], d_feed)
+                if PREFETCH:
+                    p.prefetch_track(j % SLOTS)
+                return
+            p.enqueue_nets(j % SLOTS, d_frames[0], d_frames[1], d_feed)
             if PREFETCH:
-                pipe.prefetch_track(j % SLOTS, d_sc[j % len(d_sc)][0], d_sc[j % len(d_sc)][1])
+                p.prefetch_track(j % SLOTS, d_sc[j % len(d_sc)][0], d_sc[j % len(d_sc)][1])
 
         for j in range(min(ahead, n)):
             feed(j)
@@ -255,45 +449,74 @@ def main(argv=None):
                 feed(k + ahead)
             t_b = time.perf_counter()
             if nets_mode:
-                out = pipe.track(k % SLOTS)  # no overrides: keypoints / RANSAC / scale / PnP on the nets' own outputs
+                out = p.track(k % SLOTS)  # no overrides: keypoints / RANSAC / scale / PnP on the nets' own outputs
             else:
                 f, dd, dp = d_sc[k % len(d_sc)]
-                out = pipe.track(k % SLOTS, f, dd, dp)  # E-tracker, or the PnP fallback when its pose is rejected
+                out = p.track(k % SLOTS, f, dd, dp)  # E-tracker, or the PnP fallback when its pose is rejected
+            t_c = time.perf_counter()
+            t_track.append(t_c)
             host_t[0] += t_b - t_a
-            host_t[1] += time.perf_counter() - t_b
-            rel, _ = pipe.hybrid_pose(out, prev)
+            host_t[1] += t_c - t_b
+            rel, _ = p.hybrid_pose(out, prev)
             prev = rel
-            g = pipe.accumulate(g, rel)
+            g = p.accumulate(g, rel)
             rel_all[k] = rel
             status[k] = out.status
-        pipe.sync()
+        p.sync()
         return rel_all, status
 
-    run(args.warmup)
-    if dist is not None:
+    class PingPong:  # the sequence A, B, A, B, ... as an indexable of device frames
+        def __getitem__(self, i):
+            return d_frames[i % 2]
+
+    seq_check = None
+    if world == 1:
+        run(pipe, args.warmup)
+        device_sync()
+        host_t[0] = host_t[1] = 0.0
+        t0 = time.perf_counter()
+        rel_all, status = run(pipe, args.steps)
+        device_sync()
+        dt = time.perf_counter() - t0
+        if os.environ.get("DFVO_BENCH_TRACE"):
+            sys.stderr.write("host ms/pair: enqueue_nets %.3f  track %.3f\n" % (host_t[0] * 1e3 / args.steps,
+                                                                                host_t[1] * 1e3 / args.steps))
+        gathered = dmod.allgather_poses(rel_all, status, 1, 0)
+        n_total = args.steps
+    else:
+        # ONE sequence of world x steps pairs (ping-pong frames), contiguous chunk per rank from its 1-frame halo, per-pair
+        # RandomState (df-vo_amd/sequence.py), ONE all-gather of pose + status rows, prefix composition on every rank
+        n_total = world * args.steps
+        frames = PingPong()
+        smod.track_chunk(pipe, frames, 0, args.warmup, rng_mode="per_pair")
         dist.barrier()
-    device_sync()
-    host_t[0] = host_t[1] = 0.0
-    t0 = time.perf_counter()
-    rel_all, status = run(args.steps)
-    if os.environ.get("DFVO_BENCH_TRACE"):
-        sys.stderr.write("host ms/pair: enqueue_nets %.3f  track %.3f\n" % (host_t[0] * 1e3 / args.steps,
-                                                                            host_t[1] * 1e3 / args.steps))
-    gathered = dmod.allgather_poses(rel_all, status, world, rank, dist, "cuda" if on_gpu else "cpu")  # one RCCL all-gather of the chunk's poses
-    if (status == 2).any():
-        raise SystemExit("bench.py: a pair needed the PnP fallback without a reference depth")
-    device_sync()
-    if dist is not None:
+        device_sync()
+        t0 = time.perf_counter()
+        traj, gathered = smod.run_sequence(pipe, frames, n_total + 1, world, rank, dist, rng_mode="per_pair")
+        device_sync()
         dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
+        dt = time.perf_counter() - t0
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        status = gathered[:, 16].astype(np.int64)
+        if rank == 0 and on_gpu:  # outside the timed region: the same sequence tracked by this rank alone
+            rel1, st1 = smod.track_chunk(pipe, frames, 0, n_total, rng_mode="per_pair")
+            same = bool(np.array_equal(rel1.reshape(n_total, 16)[st1 != 1], gathered[:, :16][st1 != 1]) and np.array_equal(st1, status))
+            seq_check = {"pairs": int(n_total), "equal_to_single_rank_run": same,
+                         "trajectory_end": [round(float(v), 4) for v in traj[-1][:3, 3]]}
+            if not same:
+                raise SystemExit("bench.py: the gathered poses of the %d-rank run differ from the single-rank run" % world)
+    if (status == 2).any():
+        raise SystemExit("bench.py: a pair needed the PnP fallback without a reference depth")
     net_flops = pipe.net_flops()
+    ahead = int(os.environ.get("DFVO_BENCH_AHEAD", "3"))
+    steady = None
+    if world == 1 and len(t_track) > ahead + 2:  # pairs after the first `ahead` (pipeline filled): the sustained rate
+        steady = (len(t_track) - ahead) / (t_track[-1] - t_track[ahead - 1])
 
     roof = None
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and world == 1 and not args.no_roofline:
         # per-launch durations of the conv kernel family, HIP events on the launch streams, graphs off
         # (one pair in flight at a time here: overlapping passes would stretch each other's launches)
         pipe.set_graph(0)
@@ -313,8 +536,8 @@ def main(argv=None):
         dom = int(np.argmax(ms))
         ach = fl[dom] / (ms[dom] * 1e-3) / 1e12
         fam = fl.sum() / (ms.sum() * 1e-3) / 1e12
-        # exact fp32: the fp32-MFMA peak.  Opt-in split modes: the window layers issue 4 (bf16x3) / 6 (bf16x6) bf16 products
-        # per fp32 product, so the ceiling for USEFUL fp32-equivalent FLOPs is the dense bf16 peak divided by that
+        # exact fp32: the fp32-MFMA peak.  Split modes: 3 (f16x3) / 4 (bf16x3) / 6 (bf16x6) half-precision products per
+        # fp32 product, so the ceiling for USEFUL fp32-equivalent FLOPs is the dense f16 / bf16 peak divided by that
         terms = {"fp32": 0, "f16x3": 3, "bf16x3": 4, "bf16x6": 6}[args.conv_precision]
         if terms and dom < 19 and args.conv_precision == "f16x3":
             terms = 0  # a kernel of the exact fp32 family dominates although the window layers run split: price it as fp32
@@ -330,33 +553,57 @@ def main(argv=None):
                                "launches_per_pair": int(ln[i] // nprof), "gflop_per_pair": round(float(fl[i] / nprof / 1e9), 1),
                                "tflops": round(float(fl[i] / (ms[i] * 1e-3) / 1e12), 1)}
                               for i in np.argsort(-ms) if ln[i] > 0]}
-    if roof is not None:
         # HBM-side bytes per launch of that kernel: hardware counters cannot be read from inside the process, so they come
-        # from the committed rocprofv3 --pmc passes over this same command (tools/r2c_profile.sh -> tools/pmc_traffic.py:
-        # FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes); None when no committed profile holds the kernel
+        # from the committed rocprofv3 --pmc passes over this same command (tools/r3_profile.sh -> tools/pmc_traffic.py:
+        # FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes); None when no committed profile holds the kernel.  The
+        # profile records the library build it was taken on: a stale file is reported as such, not silently used.
         try:
-            pmc_file = "r2c_pmc_bench.json"
-            prof = json.load(open(os.path.join(ROOT, "profiles", pmc_file)))["kernels"]
-            key = {19: "conv_win_f16s_kernel<", 20: "conv_gemm_f16s_kernel<", 21: "conv_gemm_f16s_kernel<"}.get(dom) or CFG_NAMES[dom].split(" ")[0].replace(
+            prof_all = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))
+            prof = prof_all["kernels"]
+            key = {19: "conv_win_f16s", 20: "conv_gemm_f16s_kernel<", 21: "conv_gemm_f16s_kernel<"}.get(dom) or CFG_NAMES[dom].split(" ")[0].replace(
                 "conv_igemm_f32<", "conv_igemm_f32_kernel<").replace("conv_win3_f32<", "conv_win_f32_kernel<").replace(
                 "conv_win_f32<", "conv_win_f32_kernel<")
             cand = [k for k in prof if k.replace(" ", "").startswith(key.rstrip(">").replace(" ", ""))]
             if cand:
                 nd = sum(prof[k]["dispatches"] for k in cand)
                 roof["traffic"] = round(sum(prof[k]["hbm_bytes_per_dispatch"] * prof[k]["dispatches"] for k in cand) / nd)
-                roof["traffic_unit"] = "bytes per launch, mean over %d profiled launches (rocprofv3 PMC, profiles/%s)" % (nd, pmc_file)
+                roof["traffic_unit"] = "bytes per launch, mean over %d profiled launches (rocprofv3 PMC, profiles/%s)" % (nd, PMC_FILE)
+                src_now = kernel_source_digest()
+                if prof_all.get("kernel_source_digest") not in (None, src_now):
+                    roof["traffic_stale"] = "profile taken on kernel sources %s, this build is %s" % (prof_all.get("kernel_source_digest"), src_now)
         except (OSError, KeyError, ValueError, ZeroDivisionError):
             pass
+
+    exact = None
+    if rank == 0 and world == 1 and not args.no_exact_leg and args.conv_precision != "fp32" and nets_mode and on_gpu:
+        # the same workload with every layer on the exact fp32-MFMA kernels: a second pipeline (the precision is fixed when
+        # the layers are packed), same warm-up and step count, timed the same way
+        pipe.close()
+        pipe = None
+        capi.check(capi.lib().dfvo_set_conv_precision(b"fp32"))
+        pipe_x = pmod.TrackingPipeline(H, W, 192, 640, K, fsd, dsd, **popts)
+        run(pipe_x, args.warmup)
+        device_sync()
+        tx = time.perf_counter()
+        _, st_x = run(pipe_x, args.steps)
+        device_sync()
+        dtx = time.perf_counter() - tx
+        exact = {"value": round(args.steps / dtx, 3), "unit": "frames/s", "ms_per_step": round(dtx / args.steps * 1e3, 3),
+                 "dtype": "f32 (every layer on v_mfma_f32_16x16x4_f32: f32 in, f32 accumulate)",
+                 "tracked_by_E": int((st_x == 0).sum()), "tracked_by_PnP": int((st_x == 3).sum())}
+        pipe_x.close()
+        capi.check(capi.lib().dfvo_set_conv_precision(args.conv_precision.encode()))
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         base = cpu_baseline_nets(seq["frames"], fsd, dsd, K, H, W) if nets_mode else cpu_baseline(syn, H, W, scenes)
     seen = ranks_seen(dist, world, rank, local_rank, torch)
-    pipe.close()
+    if pipe is not None:
+        pipe.close()
 
     if rank == 0:
         n_e = int((status == 0).sum())
         if roof is not None:
-            roof["whole_pair_tflops"] = round(net_flops * world * args.steps / dt / 1e12, 2)  # issued net FLOPs / timed wall time
+            roof["whole_pair_tflops"] = round(net_flops * n_total / dt / 1e12, 2)  # issued net FLOPs / timed wall time
             roof["note"] = ("achieved/frac: the conv tile configuration with the largest time share, per-launch HIP-event "
                             "durations, graphs off, ONE pair in flight (conv_family_ms_per_pair sums those and exceeds "
                             "ms_per_step, whose timed region overlaps two flow-net instances and the solver stage); "
@@ -372,11 +619,11 @@ def main(argv=None):
         line = {
             "metric": "KITTI-odom frames/sec (DF-VO per-pair tracking hot path: monodepth2 + LiteFlowNet fwd/bwd + "
                       "kp selection + E/H RANSAC + scale)",
-            "value": round(world * args.steps / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "value": round(n_total / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "f16x3": "f32 (f16x3 split products in the 3x3 window layers: two f16 planes per operand = 22 "
-                                                "mantissa bits, three exact products per term, fp32 accumulate; all other layers exact fp32 MFMA)"
+            "dtype": {"fp32": "f32", "f16x3": "f32 (f16x3 split products: two f16 planes per operand = 22 mantissa bits, three exact "
+                                                "products per term, fp32 accumulate; direct one- / two-channel heads exact fp32)"
                       }.get(args.conv_precision, "f32 accumulate, %s split-bf16 products in the 3x3 window layers (opt-in)" % args.conv_precision),
             "data": "synthetic",
             "config": {"workload": "%dx%d frame pairs%s (flow net %dx%d batch 2; device LANCZOS resize + depth net 192x640), "
@@ -385,11 +632,18 @@ def main(argv=None):
                                    "reference takes it" % (W, H, " (KITTI seq-09 size)" if (H, W) == (376, 1241) else "", net_h,
                                                            net_w, args.kp_bestn, args.e_max_iters),
                        "conv_precision": args.conv_precision, "frames_per_gpu": args.steps,
-                       "parallelism": "frame-batch DP x%d, one all-gather of poses" % world,
+                       "frames": "pinned host memory, uploaded on a copy stream inside the timed region" if host_frames else "resident in HBM",
+                       "parallelism": ("one sequence of %d pairs, contiguous chunk + 1-frame halo per rank, per-pair RandomState, one "
+                                       "all-gather of poses, prefix composition" % n_total) if world > 1 else
+                                      "single rank, sequential RandomState (the reference's mode)",
                        "solver_inputs": si,
                        "tracked_by_E": n_e, "tracked_by_PnP": int((status == 3).sum()),
                        "constant_motion": int((status == 1).sum()), "gathered_poses": int(gathered.shape[0]),
                        "ranks_seen": len(set(r[0] for r in seen)), "devices_seen": len(set((r[1], r[2], r[3]) for r in seen))},
+            "steady_state": None if steady is None else {"value": round(steady, 3), "unit": "frames/s",
+                                                         "note": "pairs after the first %d (nets running ahead of the solver "
+                                                                 "stage), host clock at the return of track()" % ahead},
+            "exact_fp32": exact, "sequence_check": seq_check,
             "roofline": roof, "cpu_baseline": base}
         print(json.dumps(line))
     if dist is not None:

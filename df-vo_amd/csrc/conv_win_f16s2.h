@@ -24,7 +24,9 @@ __device__ __forceinline__ void f16s2_static_for(F&& f) {  // f(integral_constan
     f16s2_static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-template <int WC, int WR, int TC, int TR>
+// SKIP: timing-only ablation (wrong results), compile-time so that the instructions really disappear: bit 0 no weight loads
+// inside the loop, bit 1 no pixel-fragment reads inside the loop, bit 2 no window loads / splits / stores inside the loop
+template <int WC, int WR, int TC, int TR, int SKIP = 0>
 __global__ __launch_bounds__(64 * WC * WR, 1) void conv_win_f16s2_kernel(const ConvParams p) {
     constexpr int NT = 64 * WC * WR;
     constexpr int TH = WR * TR, TW = 32, WH = TH + 2, WW = TW + 2, PS = 20;  // pixel stride in dwords (80 bytes)
@@ -83,7 +85,11 @@ __global__ __launch_bounds__(64 * WC * WR, 1) void conv_win_f16s2_kernel(const C
         w_ok |= (v ? 1u : 0u) << r;
     }
     const int G0 = __builtin_amdgcn_readfirstlane(p.G0), G1 = __builtin_amdgcn_readfirstlane(p.G1);
-    auto load_window_item = [&](int c, int r) {
+    // timing-only ablations (DFVO_F16S2_ABL, wrong results): bit 0 = every window load re-reads chunk 0 (cache hits instead
+    // of HBM / Infinity Cache), bit 1 = every weight fragment is (tap 0, chunk 0) -- same instruction stream either way
+    const int abl = __builtin_amdgcn_readfirstlane(p.force_splits);
+    auto load_window_item = [&](int c_in, int r) {
+        const int c = (abl & 1) ? 0 : c_in;
         const bool s1 = c >= nchunk0;
         const int cg = (s1 ? (c - nchunk0) * 4 : c * 4) + wq;
         const bool v = ((w_ok >> r) & 1u) && cg < (s1 ? G1 : G0);
@@ -105,7 +111,7 @@ __global__ __launch_bounds__(64 * WC * WR, 1) void conv_win_f16s2_kernel(const C
     const size_t w_chunk_stride = (size_t)p.wf16_cout_pad * 32;  // halves per (tap, chunk)
     h16x8 wa[3][TC][2];
     auto load_w = [&](int stage, int tap, int c) {
-        const unsigned short* g = wbase + ((size_t)tap * nchunks + c) * w_chunk_stride;
+        const unsigned short* g = wbase + ((abl & 2) ? (size_t)0 : ((size_t)tap * nchunks + c) * w_chunk_stride);
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
             wa[stage][i][0] = *reinterpret_cast<const h16x8*>(g + (size_t)i * 32 * 32);
@@ -147,19 +153,22 @@ __global__ __launch_bounds__(64 * WC * WR, 1) void conv_win_f16s2_kernel(const C
         const float* Wc = lds + (c & 1) * WIN;
         float* Wn = lds + ((c + 1) & 1) * WIN;
         const int c_next = c + 1 < nchunks ? c + 1 : c;
-        read_x(Wc, 0, 0);
+        if (!(SKIP & 2) || c == 0) read_x(Wc, 0, 0);
+        if ((SKIP & 2) && c == 0) read_x(Wc, 1, 1);
         f16s2_static_for<9>([&](auto tap_c) {
             constexpr int tap = decltype(tap_c)::value;
             constexpr int cur = tap % 3, xs = tap & 1;
-            if (tap < 7)
-                load_w((tap + 2) % 3, tap + 2, c);
-            else if (next_chunk)
-                load_w((tap + 2) % 3, tap - 7, c_next);
-            if (next_chunk && tap < W_CNT) load_window_item(c_next, tap);
+            if (!(SKIP & 1)) {
+                if (tap < 7)
+                    load_w((tap + 2) % 3, tap + 2, c);
+                else if (next_chunk)
+                    load_w((tap + 2) % 3, tap - 7, c_next);
+            }
+            if (!(SKIP & 4) && next_chunk && tap < W_CNT) load_window_item(c_next, tap);
             __builtin_amdgcn_sched_barrier(0);  // the requests stay ahead of the tap's arithmetic
-            if (tap < 8) read_x(Wc, xs ^ 1, tap + 1);
+            if (!(SKIP & 2) && tap < 8) read_x(Wc, xs ^ 1, tap + 1);
             constexpr int ST0 = 9 - W_CNT;
-            if (next_chunk && tap >= ST0) store_window_item(Wn, tap - ST0);
+            if (!(SKIP & 4) && next_chunk && tap >= ST0) store_window_item(Wn, tap - ST0);
 #pragma unroll
             for (int i = 0; i < TC; ++i)
 #pragma unroll
@@ -220,7 +229,7 @@ static long long f16s2_blocks(const ConvParams& p) {
     return (long long)p.N * ((p.Ho + TH - 1) / TH) * ((p.Wo + 31) / 32) * (p.wf16_cout_pad / BN);
 }
 
-template <int WC, int WR, int TC, int TR>
+template <int WC, int WR, int TC, int TR, int SKIP = 0>
 static int launch_f16s2_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) {
     constexpr int TH = WR * TR, BN = WC * TC * 32;
     const int tiles = p.N * ((p.Ho + TH - 1) / TH) * ((p.Wo + 31) / 32);
@@ -232,7 +241,10 @@ static int launch_f16s2_cfg(const ConvParams& p, hipStream_t stream, int cfg_id)
         pe.cfg = cfg_id;
         DFVO_HIP_CHECK(hipEventRecord(pe.e0, stream));
     }
-    hipLaunchKernelGGL((conv_win_f16s2_kernel<WC, WR, TC, TR>), grid, dim3(64 * WC * WR), 0, stream, p);
+    static const int abl = getenv("DFVO_F16S2_ABL") ? atoi(getenv("DFVO_F16S2_ABL")) : 0;
+    ConvParams pk = p;
+    pk.force_splits = abl;  // (unused by this kernel otherwise)
+    hipLaunchKernelGGL((conv_win_f16s2_kernel<WC, WR, TC, TR, SKIP>), grid, dim3(64 * WC * WR), 0, stream, pk);
     DFVO_HIP_CHECK(hipGetLastError());
     if (g_prof) {
         DFVO_HIP_CHECK(hipEventRecord(pe.e1, stream));
@@ -252,6 +264,18 @@ static int launch_f16s2(const ConvParams& p, hipStream_t stream, int cfg_id) {
     if (!mode) return -1;
     const int ncu = 256;
     auto cost = [&](long long blocks, int rows) { return blocks <= 0 ? (1LL << 60) : ((blocks + ncu - 1) / ncu) * rows; };
+    static const int skip = getenv("DFVO_F16S2_SKIP") ? atoi(getenv("DFVO_F16S2_SKIP")) : 0;
+    if (skip && p.wf16_cout_pad % 128 == 0) {  // timing-only ablations of the 128-cout x 6-row shape
+        switch (skip) {
+            case 1: return launch_f16s2_cfg<2, 2, 2, 3, 1>(p, stream, cfg_id);
+            case 2: return launch_f16s2_cfg<2, 2, 2, 3, 2>(p, stream, cfg_id);
+            case 4: return launch_f16s2_cfg<2, 2, 2, 3, 4>(p, stream, cfg_id);
+            case 3: return launch_f16s2_cfg<2, 2, 2, 3, 3>(p, stream, cfg_id);
+            case 5: return launch_f16s2_cfg<2, 2, 2, 3, 5>(p, stream, cfg_id);
+            case 6: return launch_f16s2_cfg<2, 2, 2, 3, 6>(p, stream, cfg_id);
+            default: return launch_f16s2_cfg<2, 2, 2, 3, 7>(p, stream, cfg_id);
+        }
+    }
     if (p.wf16_cout_pad % 128 == 0) {
         const long long b4 = f16s2_blocks<2, 2, 2, 4>(p), b3 = f16s2_blocks<2, 2, 2, 3>(p), b2 = f16s2_blocks<2, 2, 2, 2>(p);
         if (b2 < 200) return -1;

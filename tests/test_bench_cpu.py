@@ -1,6 +1,7 @@
-"""CPU (gloo, world_size 2): the multi-rank logic of bench.py -- world setup from the torchrun environment, per-rank
-chunks, the single pose all-gather, max-over-ranks timing, rank 0's JSON line (n_gpus, ranks_seen) -- with the device
-pipeline replaced by a stub (no GPU here), and the `--gpus N` self-launch command line."""
+"""CPU (gloo, world_size 2): the multi-rank logic of bench.py -- world setup from the torchrun environment, ONE sequence
+of world x steps pairs tracked as contiguous chunks from each rank's halo frame (df-vo_amd/sequence.py run_sequence), the
+single pose all-gather, max-over-ranks timing, rank 0's JSON line (n_gpus, ranks_seen) -- with the device pipeline replaced
+by a stub (no GPU here), and the `--gpus N` self-launch command line."""
 import importlib
 import io
 import json
@@ -38,11 +39,12 @@ class StubPipeline:
     def __init__(self, H, W, fh, fw, K, fsd, dsd, **opts):
         self.seed_ = opts.get("seed", 0)
         self.k = 0
-        self.hybrid_pose = StubPipeline.real.hybrid_pose
-        self.accumulate = StubPipeline.real.accumulate
 
     def set_ref_image(self, img):
         StubPipeline.calls.append("ref")
+
+    def seed(self, seed):  # per-pair RandomState of the data-parallel mode (df-vo_amd/sequence.py)
+        self.seed_ = seed
 
     def enqueue_nets(self, slot, ref, cur, feed=None):
         assert 0 <= slot < 4
@@ -70,7 +72,8 @@ def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     bench = importlib.import_module("bench")
     pmod = importlib.import_module("df-vo_amd.pipeline")
-    StubPipeline.real = pmod.TrackingPipeline
+    StubPipeline.hybrid_pose = staticmethod(pmod.TrackingPipeline.hybrid_pose)  # (host-side helpers of the real class)
+    StubPipeline.accumulate = staticmethod(pmod.TrackingPipeline.accumulate)
     pmod.TrackingPipeline = StubPipeline
     bench.to_device = lambda a: torch.from_numpy(np.ascontiguousarray(a))
     bench.device_sync = lambda: None
@@ -96,7 +99,7 @@ def test_bench_two_ranks_gloo():
     assert outs[1].strip() == ""  # only rank 0 prints
     line = json.loads(outs[0].strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["steps"] == 5 and line["warmup"] == 1 and line["scaling"] == "weak"
-    assert line["config"]["ranks_seen"] == 2 and line["config"]["gathered_poses"] == 10
+    assert line["config"]["ranks_seen"] == 2 and line["config"]["gathered_poses"] == 10  # every rank composed all 10 pairs
     assert line["unit"] == "frames/s" and line["value"] > 0
     assert abs(line["value"] - 2 * 5 / (line["ms_per_step"] * 5e-3)) < 1e-2 * line["value"]  # whole-job aggregate
 

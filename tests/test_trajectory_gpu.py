@@ -23,7 +23,8 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tunne
 # Gates of the from-images accounting, set from the first measured run of round 3 (printed line "FROM-IMAGES ..."); a
 # regression of the nets' agreement with torch-CPU shows up here before it shows up in t_rel
 MIN_IDENTICAL_KP_PAIRS = {"fp32": 0, "f16x3": 0}
-MAX_MEDIAN_DT_F = 2e-2
+MAX_MEDIAN_DT_F = 1e-2   # measured 5.3e-3 (fp32) / 6.1e-3 (f16x3): RANSAC sampling noise on a 1 m step
+MAX_DT_F = 6e-2          # measured max 3.5e-2 / 2.8e-2
 
 
 def _from_images_accounting(fx, precision, n, rel, status, kps):
@@ -36,7 +37,7 @@ def _from_images_accounting(fx, precision, n, rel, status, kps):
     for mode, key in (("sequential", "seq"), ("per_pair", "pp")):
         mask_bits = np.unpackbits(fx[key + "_mask"])
         same_kp = same_mask = same_kp_count = 0
-        moved = []
+        moved, overlap = [], []
         dF = np.zeros(n - 1)
         for j in range(n - 1):
             kr, kc, inl = kps[mode][j]
@@ -46,18 +47,24 @@ def _from_images_accounting(fx, precision, n, rel, status, kps):
             same_kp_count += len(kr) == len(xy)
             if len(kr) == len(xy):
                 moved.append(int((kr != xy).any(1).sum()))
+            # as SETS of reference pixels (the order inside a cell is introselect's, which any rank change reshuffles)
+            a = set(map(tuple, kr.astype(np.int64)))
+            overlap.append(len(a & set(map(tuple, xy.astype(np.int64)))) / max(1, len(a)))
             okp_full = okp and np.array_equal(kc, cur)
             same_kp += okp_full
             same_mask += bool(okp_full and np.array_equal(inl, mask_bits[off[j]:off[j + 1]].astype(bool)))
             assert (status[mode][j] == 0) == (str(fx[key + "_status"][j]) == "E"), "pair %d: tracking branch differs" % j
             dF[j] = np.linalg.norm(rel[mode][j] - fx[key + "_rel"][j])
         print("FROM-IMAGES 130-frame %s RandomState (%s): of %d pairs | identical keypoint set (values+order) %d | identical "
-              "inlier mask %d | same keypoint count %d, keypoints at another pixel per pair: median %d max %d of ~2000 | "
-              "||dT||_F <= 1e-4: %d, <= 1e-3: %d, <= 1e-2: %d; median %.2e max %.2e" % (
+              "inlier mask %d | same keypoint count %d, list positions holding another pixel: median %d max %d of ~2000, "
+              "keypoints shared as a set: median %.1f %% min %.1f %% | ||dT||_F <= 1e-4: %d, <= 1e-3: %d, <= 1e-2: %d; "
+              "median %.2e max %.2e" % (
                   mode, precision, n - 1, same_kp, same_mask, same_kp_count, np.median(moved) if moved else -1,
-                  max(moved) if moved else -1, (dF <= 1e-4).sum(), (dF <= 1e-3).sum(), (dF <= 1e-2).sum(), np.median(dF), dF.max()))
+                  max(moved) if moved else -1, 100 * np.median(overlap), 100 * min(overlap),
+                  (dF <= 1e-4).sum(), (dF <= 1e-3).sum(), (dF <= 1e-2).sum(), np.median(dF), dF.max()))
         assert same_kp >= MIN_IDENTICAL_KP_PAIRS[precision]
-        assert np.median(dF) <= MAX_MEDIAN_DT_F
+        assert same_kp_count == n - 1
+        assert np.median(dF) <= MAX_MEDIAN_DT_F and dF.max() <= MAX_DT_F
 
 
 def test_trajectory_t_rel_within_a_tenth_of_the_oracle(gpu, conv_precision, tmp_path):
