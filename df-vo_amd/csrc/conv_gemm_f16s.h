@@ -162,17 +162,15 @@ __global__ __launch_bounds__(64 * WP * KSP) void conv_gemm_f16s_kernel(const Con
 
     // combine the two accumulator sets; with KSP > 1 the partial blocks of a pixel block meet in LDS and are added in slice
     // order by the wave that finishes the register quad
-    const bool vec_ok = conv_vec_ok(p);
     if (KSP == 1) {
+        ConvEpi<4 * TC> epi;
+        conv_epi_init(p, epi, [&](int q) { return n0 + (q >> 2) * 32 + 8 * (q & 3) + 4 * kb; });
+        conv_epi_row(p, epi, (size_t)(vm ? m : 0), vm, [&](int q) {
+            f32x4 v;
 #pragma unroll
-        for (int i = 0; i < TC; ++i)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = am[i][4 * g + e] + F16S_LO_UNSCALE * ax[i][4 * g + e];
-                if (vm) conv_epilogue_quad(p, (size_t)m, n0 + i * 32 + 8 * g + 4 * kb, v, vec_ok);
-            }
+            for (int e = 0; e < 4; ++e) v[e] = am[q >> 2][4 * (q & 3) + e] + F16S_LO_UNSCALE * ax[q >> 2][4 * (q & 3) + e];
+            return v;
+        });
         return;
     }
     float* const mine = f16g_red + (size_t)((wp * KSP + wk) * TC) * 16 * 64;
@@ -181,15 +179,32 @@ __global__ __launch_bounds__(64 * WP * KSP) void conv_gemm_f16s_kernel(const Con
 #pragma unroll
         for (int e = 0; e < 16; ++e) mine[(i * 16 + e) * 64 + lane] = am[i][e] + F16S_LO_UNSCALE * ax[i][e];
     __syncthreads();
+    const bool vec_ok = conv_vec_ok(p);
     for (int q = wk; q < 4 * TC; q += KSP) {
         const int i = q >> 2, g = q & 3;
+        const int col0 = n0 + i * 32 + 8 * g + 4 * kb;
+        // (the quad's bias / residual requested before the LDS sum, consumed after it)
+        const bool fastq = vec_ok && col0 + 3 < p.cout;
+        f32x4 b = {0.f, 0.f, 0.f, 0.f}, r = {0.f, 0.f, 0.f, 0.f};
+        if (fastq) {
+            b = *reinterpret_cast<const f32x4*>(p.bias + col0);
+            if (p.res && vm) r = *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.res_cs + p.res_co + col0);
+        }
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         for (int z = 0; z < KSP; ++z) {
             const float* src = f16g_red + (size_t)((wp * KSP + z) * TC + i) * 16 * 64 + (4 * g) * 64 + lane;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = z == 0 ? src[e * 64] : v[e] + src[e * 64];
         }
-        if (vm) conv_epilogue_quad(p, (size_t)m, n0 + i * 32 + 8 * g + 4 * kb, v, vec_ok);
+        if (!vm) continue;
+        if (fastq) {
+            f32x4 x = v + b + r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = apply_act(x[e], p.act, p.act_param);
+            *reinterpret_cast<f32x4*>(p.dst + (size_t)m * p.dst_cs + p.dst_co + col0) = x;
+        } else {
+            conv_epilogue_quad(p, (size_t)m, col0, v, vec_ok);
+        }
     }
 }
 

@@ -78,6 +78,79 @@ __device__ __forceinline__ bool conv_vec_ok(const ConvParams& p) {
     return (((p.dst_cs | p.dst_co) & 3) == 0) && (!p.res || (((p.res_cs | p.res_co) & 3) == 0));
 }
 
+
+// ---- batched epilogue of the f16x3 kernels --------------------------------------------------------------------------
+// conv_epilogue_quad() interleaves, per quad, a bias (and residual) LOAD with the quad's STORE.  Stores count on vmcnt on
+// this architecture, so the wait for each bias value drains every store issued before it: 16-24 quads per wave become
+// 16-24 serialised store round trips (measured on the level-2 layers: 40 us of a 213 us launch at two workgroups per CU,
+// 111 us of 283 us at one -- the intercept of launch time over the number of channel chunks).  Here the bias quads of the
+// wave's couts are loaded ONCE before the first store, the residual quads of a group of four are loaded together, and the
+// stores go out back to back.  LeakyReLU / ReLU / none are one select-and-multiply with a per-layer slope; ELU is the
+// second instantiation.  Quads that are not fully inside [0, cout) or not 16-byte aligned, and sigmoid layers, fall back
+// to conv_epilogue_quad (wave-uniform decision).
+template <int NQ>
+struct ConvEpi {
+    f32x4 b[NQ];
+    int col0[NQ];
+    float slope;  // LeakyReLU a / ReLU 0 / none 1 as one formula: v > 0 ? v : v * slope
+    bool fast;    // every quad of every lane of the wave takes the vector path
+};
+// col0_of(q): first cout of quad q for this lane
+template <int NQ, class ColOf>
+__device__ __forceinline__ void conv_epi_init(const ConvParams& p, ConvEpi<NQ>& c, ColOf col0_of) {
+    bool ok = conv_vec_ok(p) && p.act != ACT_SIGMOID;  // (sigmoid: the one- / two-channel heads, never vector quads)
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        c.col0[q] = col0_of(q);
+        ok = ok && (c.col0[q] + 3 < p.cout);
+    }
+    c.fast = __all(ok ? 1 : 0) != 0;
+    c.slope = p.act == ACT_LEAKY ? p.act_param : (p.act == ACT_RELU ? 0.f : 1.f);
+    if (c.fast) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) c.b[q] = *reinterpret_cast<const f32x4*>(p.bias + c.col0[q]);
+    }
+}
+template <bool ELU, int NQ, class Get>
+__device__ __forceinline__ void conv_epi_row_act(const ConvParams& p, const ConvEpi<NQ>& c, size_t m, Get get) {
+    float* d = p.dst + m * p.dst_cs + p.dst_co;
+    constexpr int GQ = NQ < 4 ? NQ : 4;  // quads per group: a group's residual loads together, its stores back to back
+#pragma unroll
+    for (int q0 = 0; q0 < NQ; q0 += GQ) {
+        f32x4 r[GQ];
+        if (p.res) {
+            const float* rp = p.res + m * p.res_cs + p.res_co;
+#pragma unroll
+            for (int q = 0; q < GQ; ++q) r[q] = *reinterpret_cast<const f32x4*>(rp + c.col0[q0 + q]);
+        }
+#pragma unroll
+        for (int q = 0; q < GQ; ++q) {
+            f32x4 x = get(q0 + q) + c.b[q0 + q];
+            if (p.res) x += r[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = ELU ? (x[e] > 0.f ? x[e] : p.act_param * expm1f(x[e])) : (x[e] > 0.f ? x[e] : x[e] * c.slope);
+            *reinterpret_cast<f32x4*>(d + c.col0[q0 + q]) = x;
+        }
+    }
+}
+// one output pixel (linear index m) x NQ quads; get(q) = the accumulated quad; `valid` false = the lane has no pixel here
+template <int NQ, class Get>
+__device__ __forceinline__ void conv_epi_row(const ConvParams& p, const ConvEpi<NQ>& c, size_t m, bool valid, Get get) {
+    if (!c.fast) {
+        if (valid) {
+            const bool vec_ok = conv_vec_ok(p);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) conv_epilogue_quad(p, m, c.col0[q], get(q), vec_ok);
+        }
+        return;
+    }
+    if (!valid) return;
+    if (p.act == ACT_ELU)  // wave-uniform
+        conv_epi_row_act<true, NQ>(p, c, m, get);
+    else
+        conv_epi_row_act<false, NQ>(p, c, m, get);
+}
+
 // Split-K finish inside the contracting kernel.  After a workgroup has written its partial tile to the workspace it draws
 // a ticket for that tile; whoever draws the last one (all z-slices are then written) reduces the partials and runs the
 // epilogue.  The sum runs over the slices in slice order -- the order of conv_splitk_epilogue -- so the result does not
@@ -336,15 +409,12 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvParams p)
             }
         }
     }
-    const bool vec_ok = conv_vec_ok(p);
+    ConvEpi<TN> epi;  // bias of the wave's couts loaded once, a pixel's stores back to back (see conv_epi_row)
+    conv_epi_init(p, epi, [&](int j) { return n0 + wn * TN * 16 + j * 16 + kq * 4; });
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + wm * TM * 16 + i * 16 + li;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {  // inner: the 64-byte runs of one pixel row back to back
-            const int col0 = n0 + wn * TN * 16 + j * 16 + kq * 4;
-            if (m < M) conv_epilogue_quad(p, (size_t)m, col0, acc[i][j], vec_ok);
-        }
+        conv_epi_row(p, epi, (size_t)(m < M ? m : 0), m < M, [&](int j) { return acc[i][j]; });
     }
 }
 
@@ -548,15 +618,13 @@ __global__ __launch_bounds__(256) void conv_win_f32_kernel(const ConvParams p) {
             }
         }
     }
-    const bool vec_ok = conv_vec_ok(p);
+    ConvEpi<TN> epi;  // bias of the wave's couts loaded once, a pixel's stores back to back (see conv_epi_row)
+    conv_epi_init(p, epi, [&](int j) { return n0 + wn * TN * 16 + j * 16 + kq * 4; });
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int oy = ty0 + wm * TM + i;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {  // inner: the 64-byte runs of one pixel back to back
-            const int col0 = n0 + wn * TN * 16 + j * 16 + kq * 4;
-            if (oy < p.Ho && ox < p.Wo) conv_epilogue_quad(p, ((size_t)n * p.Ho + oy) * p.Wo + ox, col0, acc[i][j], vec_ok);
-        }
+        const bool valid = oy < p.Ho && ox < p.Wo;
+        conv_epi_row(p, epi, valid ? ((size_t)n * p.Ho + oy) * p.Wo + ox : 0, valid, [&](int j) { return acc[i][j]; });
     }
 }
 
@@ -792,15 +860,13 @@ __global__ __launch_bounds__(256) void conv_win_bf16s_kernel(const ConvParams p)
         }
         return;
     }
-    const bool vec_ok = conv_vec_ok(p);
+    ConvEpi<TN> epi;  // bias of the wave's couts loaded once, a pixel's stores back to back (see conv_epi_row)
+    conv_epi_init(p, epi, [&](int j) { return n0 + wn * TN * 16 + j * 16 + kq * 4; });
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int oy = ty0 + wm * TM + i;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {  // inner: the 64-byte runs of one pixel back to back
-            const int col0 = n0 + wn * TN * 16 + j * 16 + kq * 4;
-            if (oy < p.Ho && ox < p.Wo) conv_epilogue_quad(p, ((size_t)n * p.Ho + oy) * p.Wo + ox, col0, acc[i][j], vec_ok);
-        }
+        const bool valid = oy < p.Ho && ox < p.Wo;
+        conv_epi_row(p, epi, valid ? ((size_t)n * p.Ho + oy) * p.Wo + ox : 0, valid, [&](int j) { return acc[i][j]; });
     }
 }
 

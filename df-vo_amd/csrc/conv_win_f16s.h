@@ -232,23 +232,21 @@ __global__ __launch_bounds__(64 * WC * WR, 2) void conv_win_f16s_kernel(const Co
 
     f16s_report_clamp(amax);
     // epilogue: register quad g of block (i, j) = couts 8 g + 4 kb .. + 3 of the pixel at x = tx0 + lp, row ty0 + wr TR + j
+    // (bias loaded once for the wave's couts, a row's stores back to back: conv_epi_row)
     const int ox = tx0 + lp;
-    const bool vec_ok = conv_vec_ok(p);
+    ConvEpi<4 * TC> epi;
+    conv_epi_init(p, epi, [&](int q) { return n0 + (wc * TC + (q >> 2)) * 32 + 8 * (q & 3) + 4 * kb; });
 #pragma unroll
     for (int j = 0; j < TR; ++j) {
         const int oy = ty0 + wr * TR + j;
-        if (oy >= p.Ho || ox >= p.Wo) continue;
-        const size_t m = ((size_t)n * p.Ho + oy) * p.Wo + ox;
+        const bool valid = oy < p.Ho && ox < p.Wo;
+        const size_t m = valid ? ((size_t)n * p.Ho + oy) * p.Wo + ox : 0;
+        conv_epi_row(p, epi, m, valid, [&](int q) {
+            f32x4 v;
 #pragma unroll
-        for (int i = 0; i < TC; ++i)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int col0 = n0 + (wc * TC + i) * 32 + 8 * g + 4 * kb;
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = am[i][j][4 * g + e] + F16S_LO_UNSCALE * ax[i][j][4 * g + e];
-                conv_epilogue_quad(p, m, col0, v, vec_ok);
-            }
+            for (int e = 0; e < 4; ++e) v[e] = am[q >> 2][j][4 * (q & 3) + e] + F16S_LO_UNSCALE * ax[q >> 2][j][4 * (q & 3) + e];
+            return v;
+        });
     }
 }
 

@@ -203,22 +203,19 @@ __global__ __launch_bounds__(64 * WC * WR, 1) void conv_win_f16s2_kernel(const C
     f16s_report_clamp(amax);
 
     const int ox = tx0 + lp;
-    const bool vec_ok = conv_vec_ok(p);
+    ConvEpi<4 * TC> epi;
+    conv_epi_init(p, epi, [&](int q) { return n0 + (wc * TC + (q >> 2)) * 32 + 8 * (q & 3) + 4 * kb; });
 #pragma unroll
     for (int j = 0; j < TR; ++j) {
         const int oy = ty0 + wr * TR + j;
-        if (oy >= p.Ho || ox >= p.Wo) continue;
-        const size_t m = ((size_t)n * p.Ho + oy) * p.Wo + ox;
+        const bool valid = oy < p.Ho && ox < p.Wo;
+        const size_t m = valid ? ((size_t)n * p.Ho + oy) * p.Wo + ox : 0;
+        conv_epi_row(p, epi, m, valid, [&](int q) {
+            f32x4 v;
 #pragma unroll
-        for (int i = 0; i < TC; ++i)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int col0 = n0 + (wc * TC + i) * 32 + 8 * g + 4 * kb;
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = am[i][j][4 * g + e] + F16S_LO_UNSCALE * ax[i][j][4 * g + e];
-                conv_epilogue_quad(p, m, col0, v, vec_ok);
-            }
+            for (int e = 0; e < 4; ++e) v[e] = am[q >> 2][j][4 * (q & 3) + e] + F16S_LO_UNSCALE * ax[q >> 2][j][4 * (q & 3) + e];
+            return v;
+        });
     }
 }
 
@@ -260,7 +257,10 @@ static int launch_f16s2_cfg(const ConvParams& p, hipStream_t stream, int cfg_id)
 // rounds x rows for the layer's grid among the instantiated shapes.  Returns -1 when the layer should stay on the first
 // skeleton (small grids: fewer than ~200 workgroups cannot fill the chip at one workgroup per CU).
 static int launch_f16s2(const ConvParams& p, hipStream_t stream, int cfg_id) {
-    static const int mode = getenv("DFVO_F16S_V2") ? atoi(getenv("DFVO_F16S_V2")) : 0;
+    // default on: per layer the two skeletons are within 2 % of each other (tools/bench_f16s_v2.py), inside the pipeline the
+    // one-wave-per-SIMD one gives +3 % pairs/s (half the resident net waves next to the solver's kernels).
+    // DFVO_F16S_V2=0 restores the first skeleton everywhere.
+    static const int mode = getenv("DFVO_F16S_V2") ? atoi(getenv("DFVO_F16S_V2")) : 1;
     if (!mode) return -1;
     const int ncu = 256;
     auto cost = [&](long long blocks, int rows) { return blocks <= 0 ? (1LL << 60) : ((blocks + ncu - 1) / ncu) * rows; };
@@ -277,11 +277,11 @@ static int launch_f16s2(const ConvParams& p, hipStream_t stream, int cfg_id) {
         }
     }
     if (p.wf16_cout_pad % 128 == 0) {
-        const long long b4 = f16s2_blocks<2, 2, 2, 4>(p), b3 = f16s2_blocks<2, 2, 2, 3>(p), b2 = f16s2_blocks<2, 2, 2, 2>(p);
+        // (an 8-row tile -- 256 accumulator registers -- does not fit: the allocator spills inside the tap loop)
+        const long long b3 = f16s2_blocks<2, 2, 2, 3>(p), b2 = f16s2_blocks<2, 2, 2, 2>(p);
         if (b2 < 200) return -1;
-        const long long c4 = cost(b4, 8), c3 = cost(b3, 6), c2 = cost(b2, 4) * 11 / 10;  // (small tiles: fewer MFMAs per load)
-        if ((mode & 2) || (c4 <= c3 && c4 <= c2)) return launch_f16s2_cfg<2, 2, 2, 4>(p, stream, cfg_id);
-        if (c3 <= c2) return launch_f16s2_cfg<2, 2, 2, 3>(p, stream, cfg_id);
+        const long long c3 = cost(b3, 6), c2 = cost(b2, 4) * 11 / 10;  // (small tiles: fewer MFMAs per load)
+        if ((mode & 2) || c3 <= c2) return launch_f16s2_cfg<2, 2, 2, 3>(p, stream, cfg_id);
         return launch_f16s2_cfg<2, 2, 2, 2>(p, stream, cfg_id);
     }
     if (p.wf16_cout_pad % 64 == 0) {
