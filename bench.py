@@ -371,6 +371,8 @@ def main(argv=None):
             raise SystemExit("bench.py: --surface mirrors is a single-GPU mode over the product data path")
         return run_mirrors(args, syn, capi, h_frames, K, fsd, dsd, code_mode)
 
+    if os.environ.get("DFVO_BENCH_TORCH_FIRST") and on_gpu:  # (A/B aid: the caller used the GPU through torch before the library)
+        torch.zeros(1 << 20, device="cuda").sum().item()
     pipe = pmod.TrackingPipeline(H, W, 192, 640, K, fsd, dsd, **popts)
     d_frames = [dev(f) for f in h_frames]
     if not nets_mode:

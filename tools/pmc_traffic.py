@@ -35,8 +35,16 @@ def main():
         write = 1024.0 * sw / nw if nw else 0.0
         out[k] = {"dispatches": nf or nw, "fetch_bytes_per_dispatch": fetch, "write_bytes_per_dispatch": write,
                   "hbm_bytes_per_dispatch": fetch + write}
+    digest = None
+    try:  # ties the profile to the kernel sources it was taken on (bench.py reports a stale profile as such)
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        digest = bench.kernel_source_digest()
+    except Exception:
+        pass
     json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE (separate passes) over bench.py; FETCH_SIZE x2 (gfx950), KB -> bytes",
-               "kernels": out}, open(sys.argv[3], "w"), indent=1)
+               "kernel_source_digest": digest, "kernels": out}, open(sys.argv[3], "w"), indent=1)
     top = sorted(out.items(), key=lambda kv: -kv[1]["hbm_bytes_per_dispatch"] * kv[1]["dispatches"])[:8]
     for k, v in top:
         print("%-50s n=%5d  %.1f MB/dispatch" % (k, v["dispatches"], v["hbm_bytes_per_dispatch"] / 1e6))
