@@ -37,12 +37,18 @@ __global__ __launch_bounds__(64 * WP * KSP) void conv_gemm_f16s_kernel(const Con
     const int wp = wave / KSP, wk = wave % KSP;
     const int lp = lane & 31, kb = lane >> 5;
     const int M = p.N * p.Ho * p.Wo;
+    // one-dimensional grid, XCD-aware: each XCD walks a contiguous run of logical ids, and the cout tile is the FASTEST
+    // index inside a run -- the workgroups that read the same pixel block (one per cout tile) are neighbours on one XCD,
+    // so the activations are fetched from HBM once and served to the other cout tiles by that XCD's L2
     const int nb = gridDim.x;
     int bid = blockIdx.x;
-    {  // XCD-aware order: each XCD walks a contiguous run of pixel blocks
+    {
         const int q = nb >> 3, r = nb & 7, xcd = bid & 7, k = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
     }
+    const int ny = p.wf16g_cout_pad / (32 * TC);
+    const int ytile = bid % ny;
+    bid /= ny;
     const int m = (bid * WP + wp) * 32 + lp;
     const bool vm = m < M;
     int iy0, ix0, nimg;
@@ -54,7 +60,7 @@ __global__ __launch_bounds__(64 * WP * KSP) void conv_gemm_f16s_kernel(const Con
         iy0 = oy * p.stride - p.pad_h;
         ix0 = ox * p.stride - p.pad_w;
     }
-    const int n0 = blockIdx.y * (32 * TC);
+    const int n0 = ytile * (32 * TC);
     // K slice of this wave
     const int S = p.f16g_steps;
     const int per = (S + KSP - 1) / KSP;
@@ -266,7 +272,7 @@ static bool conv_f16g_ok(const ConvParams& p) {
 template <int WP, int KSP, int TC, int PF = 3>
 static int launch_f16g_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) {
     const long long M = (long long)p.N * p.Ho * p.Wo;
-    dim3 grid((unsigned)((M + 32 * WP - 1) / (32 * WP)), (unsigned)(p.wf16g_cout_pad / (32 * TC)), 1);
+    dim3 grid((unsigned)(((M + 32 * WP - 1) / (32 * WP)) * (p.wf16g_cout_pad / (32 * TC))), 1, 1);
     const size_t lds = KSP > 1 ? (size_t)WP * KSP * TC * 16 * 64 * sizeof(float) : 0;
     if (lds > 48 * 1024)
         if (int rc_lds = ensure_dyn_lds((const void*)conv_gemm_f16s_kernel<WP, KSP, TC, PF>, lds)) return rc_lds;
@@ -282,7 +288,7 @@ static int launch_f16g_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) 
     if (g_prof) {
         DFVO_HIP_CHECK(hipEventRecord(pe.e1, stream));
         pe.flops = p.useful_flops;
-        const int sh[12] = {p.N, p.H, p.W, p.Ho, p.Wo, (p.G0 + p.G1) * 4, p.cout, p.kh, p.stride, (int)grid.x, (int)grid.y, KSP};
+        const int sh[12] = {p.N, p.H, p.W, p.Ho, p.Wo, (p.G0 + p.G1) * 4, p.cout, p.kh, p.stride, (int)grid.x, TC, KSP};
         for (int i = 0; i < 12; ++i) pe.shape[i] = sh[i];
         g_prof->push_back(pe);
     }
@@ -298,31 +304,40 @@ static int launch_f16g(const ConvParams& p, hipStream_t stream) {
     const int nblk = p.wf16g_cout_pad / 32;
     static const int force_ksp = getenv("DFVO_F16G_KSP") ? atoi(getenv("DFVO_F16G_KSP")) : 0;
     static const long long target = getenv("DFVO_F16G_WAVES") ? atoll(getenv("DFVO_F16G_WAVES")) : 2048;
-    static const int deep = getenv("DFVO_F16G_PF") ? atoi(getenv("DFVO_F16G_PF")) : 3;  // 5: deeper ring for the K-sliced shapes
-    // two cout blocks per wave only while that still leaves enough (pixel block, cout pair) tiles to fill the chip with
-    // at most eight K slices; tiny maps with many couts (the depth net's 6 x 20 / 12 x 40 layers: the launch is one pass
-    // over megabytes of weights) take one block per wave and up to 16 slices -- more waves, more loads in flight
+    // DFVO_F16G_PF=8 (A/B): eight-stage ring + one cout block per wave + twice the waves on the K-sliced shapes, so that a
+    // wave's whole K slice is in flight at once.  Measured: WORSE (K-sliced layers 1.24 vs 1.10 ms per pair, 225 vs 230
+    // pairs/s) -- more waves contending, not fewer round trips, is what the small layers feel.  Default: three stages.
+    static const int deep = getenv("DFVO_F16G_PF") ? atoi(getenv("DFVO_F16G_PF")) : 3;
+    // DFVO_F16G_STREAM_TC1=1 (A/B): streaming shapes with one cout block per wave (120 registers, four waves per SIMD)
+    static const int stream_tc1 = getenv("DFVO_F16G_STREAM_TC1") ? atoi(getenv("DFVO_F16G_STREAM_TC1")) : 0;
+    // two cout blocks per wave (a pixel fragment, whose split costs the VALU work, feeds both) only while that still leaves
+    // enough (pixel block, cout pair) tiles to fill the chip with at most eight K slices; tiny maps with many couts (the
+    // depth net's 6 x 20 / 12 x 40 layers: the launch is one pass over megabytes of weights) take one block per wave and up
+    // to 16 slices -- more waves, more loads in flight
     bool tc2 = (nblk % 2) == 0;
     if (tc2 && mblocks * (nblk / 2) * 8 * 2 < target && p.f16g_steps >= 64) tc2 = false;
-    const long long tiles = mblocks * (tc2 ? nblk / 2 : nblk);
+    if (deep == 8) tc2 = false;
+    long long tiles = mblocks * (tc2 ? nblk / 2 : nblk);
+    const long long tgt = deep == 8 ? 2 * target : target;
     int ksp = 1;
     // (16 slices only with one cout block per wave: a 1024-thread workgroup leaves 128 registers per lane)
-    while (ksp < (tc2 ? 8 : 16) && tiles * ksp * 2 <= target && p.f16g_steps >= 4 * ksp * 2) ksp *= 2;
+    while (ksp < (tc2 ? 8 : 16) && tiles * ksp * 2 <= tgt && p.f16g_steps >= 4 * ksp * 2) ksp *= 2;
     if (force_ksp == 1 || force_ksp == 2 || force_ksp == 4 || force_ksp == 8) ksp = force_ksp;
+    if (ksp == 1 && stream_tc1) tc2 = false;
     const int cfg = ksp == 1 ? 20 : 21;  // profile rows: 20 streaming (KSP = 1), 21 K-sliced small maps
     if (tc2) {
         switch (ksp) {
             case 1: return launch_f16g_cfg<4, 1, 2>(p, stream, cfg);
             case 2: return launch_f16g_cfg<2, 2, 2>(p, stream, cfg);
-            case 4: return deep == 5 ? launch_f16g_cfg<1, 4, 2, 5>(p, stream, cfg) : launch_f16g_cfg<1, 4, 2>(p, stream, cfg);
-            default: return deep == 5 ? launch_f16g_cfg<1, 8, 2, 5>(p, stream, cfg) : launch_f16g_cfg<1, 8, 2>(p, stream, cfg);
+            case 4: return launch_f16g_cfg<1, 4, 2>(p, stream, cfg);
+            default: return launch_f16g_cfg<1, 8, 2>(p, stream, cfg);
         }
     }
     switch (ksp) {
         case 1: return launch_f16g_cfg<4, 1, 1>(p, stream, cfg);
         case 2: return launch_f16g_cfg<2, 2, 1>(p, stream, cfg);
-        case 4: return deep == 5 ? launch_f16g_cfg<1, 4, 1, 5>(p, stream, cfg) : launch_f16g_cfg<1, 4, 1>(p, stream, cfg);
-        case 8: return deep == 5 ? launch_f16g_cfg<1, 8, 1, 5>(p, stream, cfg) : launch_f16g_cfg<1, 8, 1>(p, stream, cfg);
-        default: return launch_f16g_cfg<1, 16, 1>(p, stream, cfg);
+        case 4: return deep == 8 ? launch_f16g_cfg<1, 4, 1, 8>(p, stream, cfg) : launch_f16g_cfg<1, 4, 1>(p, stream, cfg);
+        case 8: return deep == 8 ? launch_f16g_cfg<1, 8, 1, 8>(p, stream, cfg) : launch_f16g_cfg<1, 8, 1>(p, stream, cfg);
+        default: return deep == 8 ? launch_f16g_cfg<1, 16, 1, 4>(p, stream, cfg) : launch_f16g_cfg<1, 16, 1>(p, stream, cfg);
     }
 }

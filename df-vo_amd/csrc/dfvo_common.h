@@ -149,6 +149,17 @@ static inline hipError_t create_solver_stream(hipStream_t* s, int which = 1) {
     return hipStreamCreateWithPriority(s, hipStreamNonBlocking, which == 8 ? least : greatest);
 }
 
+// candidate streams classified by the dispatch pipe that serves them (stream_pool.hip)
+struct StreamPool {
+    std::vector<hipStream_t> s;
+    std::vector<int> group;  // pipe group of s[i] (streams of one group slow each other's dispatch), -1 unknown
+    int ngroups = 0;         // 0: the probe failed, use creation order
+    int create(int n);
+    hipStream_t take(int group);  // removes a stream of that group from the pool (nullptr when none is left)
+    int count(int group) const;
+    void release();               // destroys what was not taken
+};
+
 // number of K-steps (16 k-values = 4 groups of 4 channels) for a conv
 static inline int conv_ksteps(int kh, int kw, int c0, int c1) {
     int G = cdiv(c0, 4) + cdiv(c1, 4);

@@ -4,10 +4,12 @@
 // (tracking): the host-side glue of the reference (cv2.resize nearest, preprocess_depth, dict passing)
 // becomes device kernels; the pose composition stays on the host (dfvo.py:109-119).
 #include "../../include/dfvo_hip.h"
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 
 #include "nets.h"
 #include "ops.h"
@@ -73,8 +75,36 @@ int dfvo_pipeline_create(const dfvo_pipeline_cfg* cfg, dfvo_pipeline** out) {
         delete p;
         return rc;
     };
-    if (create_net_stream(&p->s_flow) != hipSuccess || create_net_stream(&p->s_depth) != hipSuccess ||
-        create_solver_stream(&p->s_trk) != hipSuccess) {
+    // Streams by dispatch pipe (stream_pool.hip): twelve candidates, classified by measurement; pipe A / B: one flow-net
+    // instance each, pipe C: the depth net + the two run-ahead homography chains, pipe D: the RandomState-ordered chain and
+    // its two side streams, alone.  Falls back to creation order when the probe is off (DFVO_STREAM_PROBE=0), when one of
+    // the stream experiments of dfvo_common.h is active, or when the probe does not find four groups of three.
+    hipStream_t pool_rep[2] = {nullptr, nullptr}, pool_pre[2] = {nullptr, nullptr}, pool_fx = nullptr;
+    {
+        static const bool probe = !(getenv("DFVO_STREAM_PROBE") && atoi(getenv("DFVO_STREAM_PROBE")) == 0) &&
+                                  !getenv("DFVO_NET_CU_RESERVE") && !getenv("DFVO_SOLVER_PRIORITY") && !getenv("DFVO_SOLVER_CU_ONLY");
+        StreamPool pool;
+        if (probe && pool.create(12) == DFVO_OK && pool.ngroups >= 4) {
+            int g[4] = {-1, -1, -1, -1}, ng = 0;  // the four largest groups, largest first
+            std::vector<int> order;
+            for (int i = 0; i < pool.ngroups; ++i) order.push_back(i);
+            std::sort(order.begin(), order.end(), [&](int a, int b) { return pool.count(a) > pool.count(b); });
+            for (int i = 0; i < 4; ++i) g[ng++] = order[i];
+            if (pool.count(g[0]) >= 3 && pool.count(g[1]) >= 3 && pool.count(g[2]) >= 1 && pool.count(g[3]) >= 1) {
+                p->s_trk = pool.take(g[0]);
+                pool_rep[0] = pool.take(g[0]);
+                pool_rep[1] = pool.take(g[0]);
+                p->s_depth = pool.take(g[1]);
+                pool_pre[0] = pool.take(g[1]);
+                pool_pre[1] = pool.take(g[1]);
+                p->s_flow = pool.take(g[2]);
+                pool_fx = pool.take(g[3]);
+            }
+        }
+        pool.release();
+    }
+    if (!p->s_trk && (create_net_stream(&p->s_flow) != hipSuccess || create_net_stream(&p->s_depth) != hipSuccess ||
+                      create_solver_stream(&p->s_trk) != hipSuccess)) {
         dfvo::set_last_error("dfvo_pipeline_create: hipStreamCreate failed (no GPU?)");
         return fail(DFVO_ERR_HIP);
     }
@@ -91,7 +121,12 @@ int dfvo_pipeline_create(const dfvo_pipeline_cfg* cfg, dfvo_pipeline** out) {
     if (p->flow_instances < 1) p->flow_instances = 1;
     if (p->flow_instances > DFVO_PIPELINE_SLOTS) p->flow_instances = DFVO_PIPELINE_SLOTS;
     for (int i = 0; i + 1 < p->flow_instances; ++i) {
-        if (create_net_stream(&p->s_flow_x[i]) != hipSuccess) return fail(DFVO_ERR_HIP);
+        if (i == 0 && pool_fx) {
+            p->s_flow_x[0] = pool_fx;
+            pool_fx = nullptr;
+        } else if (create_net_stream(&p->s_flow_x[i]) != hipSuccess) {
+            return fail(DFVO_ERR_HIP);
+        }
         rc = p->flow_x[i].init(p->H, p->W, p->s_flow_x[i]);
         if (rc != DFVO_OK) return fail(rc);
     }
@@ -100,7 +135,8 @@ int dfvo_pipeline_create(const dfvo_pipeline_cfg* cfg, dfvo_pipeline** out) {
     p->depth.min_depth = cfg->net_min_depth;
     p->depth.max_depth = cfg->net_max_depth;
     p->depth.baseline_mult = cfg->baseline_mult;
-    rc = p->tbs[0].init();
+    if (pool_fx) (void)hipStreamDestroy(pool_fx);  // (DFVO_FLOW_INSTANCES=1)
+    rc = p->tbs[0].init(pool_rep[0], pool_rep[1]);
     if (rc != DFVO_OK) return fail(rc);
     for (int i = 1; i < DFVO_PIPELINE_SLOTS; i++) {
         rc = p->tbs[i].init_shared(p->tbs[0]);
@@ -112,8 +148,12 @@ int dfvo_pipeline_create(const dfvo_pipeline_cfg* cfg, dfvo_pipeline** out) {
         rc = p->pnp.ensure(cfg->kp_num_bestN + 8, cfg->pnp_iters);
         if (rc != DFVO_OK) return fail(rc);
     }
-    for (int i = 0; i < 2; i++)
-        if (create_solver_stream(&p->s_pre[i], 4) != hipSuccess) return fail(DFVO_ERR_HIP);
+    for (int i = 0; i < 2; i++) {
+        if (pool_pre[i])
+            p->s_pre[i] = pool_pre[i];
+        else if (create_solver_stream(&p->s_pre[i], 4) != hipSuccess)
+            return fail(DFVO_ERR_HIP);
+    }
     for (int i = 0; i < DFVO_PIPELINE_SLOTS; i++) {
         if (hipEventCreateWithFlags(&p->e_pre[i], hipEventDisableTiming) != hipSuccess ||
             hipHostMalloc((void**)&p->h_info[i], 4 * sizeof(int), hipHostMallocDefault) != hipSuccess)

@@ -1602,7 +1602,7 @@ void TrackerBuffers::release_kp() {
     kp_cap = sel_cap = 0;
 }
 
-int TrackerBuffers::init() {
+int TrackerBuffers::init(hipStream_t rep0, hipStream_t rep1) {
     DFVO_HIP_CHECK(hipMalloc((void**)&mt_state, sizeof(uint32_t) * 640));
     DFVO_HIP_CHECK(hipMalloc((void**)&kp_info, sizeof(int) * 8));
     DFVO_HIP_CHECK(hipMalloc((void**)&kp_total, sizeof(int) * 8));
@@ -1617,9 +1617,14 @@ int TrackerBuffers::init() {
     // RNG-dependent solver chain.  Measured on MI355X, bench.py order (pipeline created before the process touches the
     // GPU through torch), exact fp32: 2 -> 103, 3 -> 108, 4 -> 133, 5 -> 111, 6 -> 112, 7 -> 116, 8 -> 133 frames/s;
     // with a torch copy issued first the fast settings are 5 .. 7 (126).  DFVO_REP_STREAMS overrides (tuning aid).
-    const int n_streams = rep_stream_count();
+    // (The fused pipeline no longer depends on this: it measures which streams share a pipe and passes rep0 / rep1 in,
+    // stream_pool.hip.)
+    const int n_streams = rep0 ? 2 : rep_stream_count();
+    n_rep_owned = n_streams;
     for (int r = 0; r < MAX_REP; r++) {
-        if (r < n_streams)
+        if (rep0 && r < 2)
+            s_rep[r] = r == 0 ? rep0 : (rep1 ? rep1 : rep0);
+        else if (r < n_streams)
             DFVO_HIP_CHECK(create_solver_stream(&s_rep[r], 2));
         else
             s_rep[r] = s_rep[r % n_streams];
@@ -1657,7 +1662,7 @@ void TrackerBuffers::release() {
     for (int r = 0; r < MAX_REP; r++) {
         ws_rep[r].release();
         if (!shared) {
-            if (s_rep[r] && r < rep_stream_count()) (void)hipStreamDestroy(s_rep[r]);
+            if (s_rep[r] && r < n_rep_owned && !(r == 1 && s_rep[1] == s_rep[0])) (void)hipStreamDestroy(s_rep[r]);
             if (ev_rep[r]) (void)hipEventDestroy(ev_rep[r]);
         }
         s_rep[r] = nullptr;

@@ -1,0 +1,104 @@
+// Pipe-aware stream assignment for the fused pipeline.
+//
+// The command processor dispatches compute queues through four PIPES; a HIP stream's hardware queue -- and with it its
+// pipe -- follows the order in which the PROCESS created its streams (queue index mod 4: tools/ubench/queue_probe.hip,
+// profiles/r3i_queue_probe.txt).  Two busy streams on one pipe slow each other's dispatch: a chain of 60 dependent
+// empty kernels takes 100 us alone or next to a busy stream on another pipe, 240-280 us next to a busy stream on its own
+// pipe.  The pipeline's pair rate is set by exactly such a chain (the RandomState-ordered solver chain: ~40 dependent
+// launches per pair), so which streams it shares a pipe with decides 172 vs 250 pairs/s on the same binary -- and that
+// depended on whether the caller had touched the GPU (created streams) before dfvo_pipeline_create
+// (profiles/r3h_torch_first_ab.txt).  Creation order is not something a library can control; so the pool below creates
+// its candidates, MEASURES which of them share a pipe (the same probe as the microbenchmark, ~10 ms once per pipeline),
+// and hands the roles out by pipe: the two flow-net instances a pipe each, the depth net and the run-ahead homography
+// chains a third, the RandomState-ordered chain and its side streams the fourth, alone.
+#include "dfvo_common.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+
+namespace dfvo {
+
+__global__ void k_pool_spin(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+__global__ void k_pool_empty() {}
+
+static float chain_us(hipStream_t s, hipEvent_t e0, hipEvent_t e1, int n) {
+    if (hipEventRecord(e0, s) != hipSuccess) return -1.f;
+    for (int k = 0; k < n; ++k) hipLaunchKernelGGL(k_pool_empty, dim3(1), dim3(64), 0, s);
+    if (hipEventRecord(e1, s) != hipSuccess || hipEventSynchronize(e1) != hipSuccess) return -1.f;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return -1.f;
+    return ms * 1e3f;
+}
+
+int StreamPool::create(int n) {
+    release();
+    s.resize(n, nullptr);
+    group.assign(n, -1);
+    for (int i = 0; i < n; ++i) DFVO_HIP_CHECK(hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking));
+    hipEvent_t e0, e1;
+    DFVO_HIP_CHECK(hipEventCreate(&e0));
+    DFVO_HIP_CHECK(hipEventCreate(&e1));
+    for (int i = 0; i < n; ++i) hipLaunchKernelGGL(k_pool_empty, dim3(1), dim3(64), 0, s[i]);
+    DFVO_HIP_CHECK(hipDeviceSynchronize());
+    const int CH = 40;
+    std::vector<float> base(n);
+    for (int i = 0; i < n; ++i) base[i] = chain_us(s[i], e0, e1, CH);
+    ngroups = 0;
+    bool ok = true;
+    for (int a = 0; a < n && ok; ++a) {
+        if (group[a] >= 0) continue;
+        group[a] = ngroups;
+        for (int b = a + 1; b < n; ++b) {
+            if (group[b] >= 0) continue;
+            // stream a busy for ~0.6 ms (30 x 20 us, wall_clock64 ticks at 100 MHz), the chain on b inside that window
+            for (int k = 0; k < 30; ++k) hipLaunchKernelGGL(k_pool_spin, dim3(1), dim3(64), 0, s[a], 2000LL);
+            const float t = chain_us(s[b], e0, e1, CH);
+            if (hipStreamSynchronize(s[a]) != hipSuccess || t < 0.f || base[b] <= 0.f) {
+                ok = false;
+                break;
+            }
+            if (t > 1.6f * base[b]) group[b] = ngroups;
+        }
+        ++ngroups;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    DFVO_HIP_CHECK(hipGetLastError());
+    if (!ok) ngroups = 0;
+    if (getenv("DFVO_STREAM_PROBE_VERBOSE")) {
+        fprintf(stderr, "dfvo stream pool: %d streams, %d pipe groups:", n, ngroups);
+        for (int i = 0; i < n; ++i) fprintf(stderr, " %d", group[i]);
+        fprintf(stderr, "\n");
+    }
+    return DFVO_OK;
+}
+
+hipStream_t StreamPool::take(int g) {
+    for (size_t i = 0; i < s.size(); ++i)
+        if (s[i] && group[i] == g) {
+            hipStream_t r = s[i];
+            s[i] = nullptr;
+            return r;
+        }
+    return nullptr;
+}
+
+int StreamPool::count(int g) const {
+    int c = 0;
+    for (size_t i = 0; i < s.size(); ++i) c += (s[i] && group[i] == g) ? 1 : 0;
+    return c;
+}
+
+void StreamPool::release() {
+    for (auto& q : s)
+        if (q) (void)hipStreamDestroy(q);
+    s.clear();
+    group.clear();
+    ngroups = 0;
+}
+
+}  // namespace dfvo

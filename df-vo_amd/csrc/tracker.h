@@ -109,6 +109,7 @@ struct TrackerBuffers {
     RansacWorkspace ws_h, ws_e;          // ws_e: stand-alone findEssentialMat / recoverPose calls
     RansacWorkspace ws_rep[MAX_REP];     // one workspace per repeated findEssentialMat (run concurrently)
     hipStream_t s_rep[MAX_REP] = {};
+    int n_rep_owned = 0;  // s_rep[0 .. n_rep_owned) are distinct streams this object destroys
     hipEvent_t ev_rep[MAX_REP] = {};
     hipEvent_t ev_fork = nullptr, ev_start = nullptr, ev_h = nullptr;
     // DFVO_TRACK_TRACE: device-side timestamps of the RNG-ordered chain (start of the shuffles, end of the five-point batch,
@@ -135,7 +136,8 @@ struct TrackerBuffers {
     int *perm = nullptr, *cell_count = nullptr, *cell_sel = nullptr, *pix = nullptr, *scratch = nullptr;
     uint8_t *best_inliers = nullptr, *inl_a = nullptr, *inl_b = nullptr;
     int kp_cap = 0, sel_cap = 0;
-    int init();
+    // rep0 / rep1: side streams chosen by the caller (the fused pipeline hands out streams by dispatch pipe); null = create
+    int init(hipStream_t rep0 = nullptr, hipStream_t rep1 = nullptr);
     // second and further buffer sets of the fused pipeline: own keypoint / RANSAC workspaces, but the numpy
     // RandomState and the (serialised anyway) RNG-side streams and events of `first`
     int init_shared(const TrackerBuffers& first);
