@@ -96,6 +96,8 @@ SIGNATURES = {
     "dfvo_memcpy_h2d": (_i, [_vp, _vp, _sz]),
     "dfvo_memcpy_d2h": (_i, [_vp, _vp, _sz]),
     "dfvo_conv2d": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dfvo_compose_trajectory": (_i, [_vp, _i, _vp, _vp, C.POINTER(_i)]),
+    "dfvo_compose_trajectory_device": (_i, [_vp, _i, _vp, _vp, C.POINTER(_i), _vp]),
     "dfvo_set_conv_precision": (_i, [C.c_char_p]),
     "dfvo_f16s_overflow_count": (_i, [C.POINTER(C.c_ulonglong), _i]),
     "dfvo_conv_profile_begin": (_i, []),

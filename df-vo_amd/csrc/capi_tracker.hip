@@ -493,4 +493,39 @@ int dfvo_compute_pose_3d2d(dfvo_tracker* t, const double* h_kp1, const double* h
     return DFVO_OK;
 }
 
+
+// rows / first / poses on the DEVICE (e.g. the output of the RCCL all-gather); *h_bad_row = first status-2 row or -1
+int dfvo_compose_trajectory_device(const double* d_rows, int n, const double* d_first, double* d_poses, int* h_bad_row,
+                                   void* stream) {
+    DFVO_ARG_CHECK(n >= 0 && d_poses && h_bad_row, "dfvo_compose_trajectory_device: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    int* d_bad = nullptr;
+    DFVO_HIP_CHECK(hipMalloc((void**)&d_bad, sizeof(int)));
+    int rc = enqueue_compose_trajectory(d_rows, n, d_first, d_poses, d_bad, s);
+    hipError_t e = hipStreamSynchronize(s);
+    if (rc == DFVO_OK && e == hipSuccess) e = hipMemcpy(h_bad_row, d_bad, sizeof(int), hipMemcpyDeviceToHost);
+    (void)hipFree(d_bad);
+    if (rc != DFVO_OK) return rc;
+    DFVO_HIP_CHECK(e);
+    return DFVO_OK;
+}
+
+// host arrays in and out
+int dfvo_compose_trajectory(const double* h_rows, int n, const double* h_first, double* h_poses, int* h_bad_row) {
+    DFVO_ARG_CHECK(n >= 0 && h_poses && h_bad_row && (n == 0 || h_rows), "dfvo_compose_trajectory: bad argument");
+    double *d_rows = nullptr, *d_first = nullptr, *d_poses = nullptr;
+    DFVO_HIP_CHECK(hipMalloc((void**)&d_rows, sizeof(double) * 17 * (size_t)(n > 0 ? n : 1)));
+    DFVO_HIP_CHECK(hipMalloc((void**)&d_poses, sizeof(double) * 16 * (size_t)(n + 1)));
+    if (h_first) DFVO_HIP_CHECK(hipMalloc((void**)&d_first, sizeof(double) * 16));
+    hipError_t e = n ? hipMemcpy(d_rows, h_rows, sizeof(double) * 17 * (size_t)n, hipMemcpyHostToDevice) : hipSuccess;
+    if (e == hipSuccess && h_first) e = hipMemcpy(d_first, h_first, sizeof(double) * 16, hipMemcpyHostToDevice);
+    int rc = e == hipSuccess ? dfvo_compose_trajectory_device(d_rows, n, d_first, d_poses, h_bad_row, nullptr) : DFVO_ERR_HIP;
+    if (rc == DFVO_OK) e = hipMemcpy(h_poses, d_poses, sizeof(double) * 16 * (size_t)(n + 1), hipMemcpyDeviceToHost);
+    (void)hipFree(d_rows);
+    (void)hipFree(d_poses);
+    if (d_first) (void)hipFree(d_first);
+    if (rc != DFVO_OK) return rc;
+    DFVO_HIP_CHECK(e);
+    return DFVO_OK;
+}
 }  // extern "C"

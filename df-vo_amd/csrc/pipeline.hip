@@ -90,7 +90,30 @@ int dfvo_pipeline_create(const dfvo_pipeline_cfg* cfg, dfvo_pipeline** out) {
             for (int i = 0; i < pool.ngroups; ++i) order.push_back(i);
             std::sort(order.begin(), order.end(), [&](int a, int b) { return pool.count(a) > pool.count(b); });
             for (int i = 0; i < 4; ++i) g[ng++] = order[i];
-            if (pool.count(g[0]) >= 3 && pool.count(g[1]) >= 3 && pool.count(g[2]) >= 1 && pool.count(g[3]) >= 1) {
+            // role -> pipe.  Layout 0 (default, measured best): the RandomState-ordered chain and its side streams alone on
+            // one pipe.  DFVO_STREAM_LAYOUT = 1 .. 3: other placements of the side / run-ahead streams (A/B).
+            static const int layout = getenv("DFVO_STREAM_LAYOUT") ? atoi(getenv("DFVO_STREAM_LAYOUT")) : 0;
+            //                         trk rep0 rep1 depth pre0 pre1 flow flow_x
+            // Measured (profiles/r3k_layouts.txt): 0 -> 266 pairs/s; 1 / 2 / 3 (a run-ahead homography chain on a flow net's
+            // pipe) -> 178-194: the long single-workgroup kernels of that chain hold up the dispatch of the flow net's
+            // hundred short launches per pass.
+            static const int L[6][8] = {{0, 0, 0, 1, 1, 1, 2, 3},
+                                        {0, 0, 0, 1, 2, 3, 2, 3},
+                                        {0, 1, 1, 1, 2, 3, 2, 3},
+                                        {0, 0, 1, 1, 2, 3, 2, 3},
+                                        {0, 0, 0, 2, 1, 1, 2, 3},
+                                        {0, 0, 0, 3, 1, 1, 2, 3}};
+            const int* R = L[layout >= 0 && layout < 6 ? layout : 0];
+            if (pool.count(g[0]) >= 3 && pool.count(g[1]) >= 3 && pool.count(g[2]) >= 3 && pool.count(g[3]) >= 3) {
+                p->s_trk = pool.take(g[R[0]]);
+                pool_rep[0] = pool.take(g[R[1]]);
+                pool_rep[1] = pool.take(g[R[2]]);
+                p->s_depth = pool.take(g[R[3]]);
+                pool_pre[0] = pool.take(g[R[4]]);
+                pool_pre[1] = pool.take(g[R[5]]);
+                p->s_flow = pool.take(g[R[6]]);
+                pool_fx = pool.take(g[R[7]]);
+            } else if (pool.count(g[0]) >= 3 && pool.count(g[1]) >= 3 && pool.count(g[2]) >= 1 && pool.count(g[3]) >= 1) {
                 p->s_trk = pool.take(g[0]);
                 pool_rep[0] = pool.take(g[0]);
                 pool_rep[1] = pool.take(g[0]);

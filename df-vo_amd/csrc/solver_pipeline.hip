@@ -1898,4 +1898,78 @@ int enqueue_find_scale(TrackerBuffers& tb, int n_host, const double* d_T21, cons
     return DFVO_OK;
 }
 
+// ================================================================================================
+// Trajectory composition: DFVO.update_global_pose (dfvo.py:109-119) over a whole gathered
+// sequence in ONE launch -- rows [n][17] = relative pose (4x4 row major) | status word; status 1 (constant motion,
+// dfvo.py:157-161) reuses the previous pair's relative motion.  The recurrence is sequential by definition
+// (t_w += R_w t ; R_w = R_w R, in that order, no re-association): one lane walks it, rows staged through LDS by the rest of
+// the wave.  Where this pays: the N-rank run, whose gathered rows already sit in HBM after the RCCL all-gather -- the
+// composed poses come back with one copy instead of n x 136-byte rows + a Python loop.
+// bad[0] = index of the first row with status 2 (needs PnP but had no reference depth), -1 if none.
+// ================================================================================================
+__global__ __launch_bounds__(64) void k_compose_trajectory(const double* __restrict__ rows, int n, const double* __restrict__ first,
+                                                            double* __restrict__ poses, int* __restrict__ bad) {
+    __shared__ double s_rows[64 * 17];
+    const int lane = threadIdx.x;
+    double g[16], prev[16];
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            g[i] = first ? first[i] : ((i % 5) == 0 ? 1.0 : 0.0);
+            prev[i] = (i % 5) == 0 ? 1.0 : 0.0;
+            poses[i] = g[i];
+        }
+        bad[0] = -1;
+    }
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int cnt = n - c0 < 64 ? n - c0 : 64;
+        for (int i = lane; i < cnt * 17; i += 64) s_rows[i] = rows[(size_t)c0 * 17 + i];
+        __syncthreads();
+        if (lane == 0) {
+            for (int k = 0; k < cnt; ++k) {
+                const double* r = s_rows + k * 17;
+                const int st = (int)r[16];
+                if (st == 2 && bad[0] < 0) bad[0] = c0 + k;
+                double rel[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) rel[i] = st == 1 ? prev[i] : r[i];
+                double nt[3], nR[9];
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    double a = 0.0;  // (R_w @ t)[i], terms in column order, then + t_w[i]
+#pragma unroll
+                    for (int j = 0; j < 3; j++) a += g[i * 4 + j] * rel[j * 4 + 3];
+                    nt[i] = a + g[i * 4 + 3];
+#pragma unroll
+                    for (int c = 0; c < 3; c++) {
+                        double b = 0.0;
+#pragma unroll
+                        for (int j = 0; j < 3; j++) b += g[i * 4 + j] * rel[j * 4 + c];
+                        nR[i * 3 + c] = b;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    g[i * 4 + 3] = nt[i];
+#pragma unroll
+                    for (int c = 0; c < 3; c++) g[i * 4 + c] = nR[i * 3 + c];
+                }
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    prev[i] = rel[i];
+                    poses[(size_t)(c0 + k + 1) * 16 + i] = g[i];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+int enqueue_compose_trajectory(const double* d_rows, int n, const double* d_first, double* d_poses, int* d_bad, hipStream_t s) {
+    DFVO_ARG_CHECK(n >= 0 && d_poses && d_bad && (n == 0 || d_rows), "compose_trajectory: bad argument");
+    hipLaunchKernelGGL(k_compose_trajectory, dim3(1), dim3(64), 0, s, d_rows, n, d_first, d_poses, d_bad);
+    DFVO_HIP_CHECK(hipGetLastError());
+    return DFVO_OK;
+}
+
 }  // namespace dfvo

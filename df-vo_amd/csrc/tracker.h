@@ -185,6 +185,8 @@ int enqueue_mt_seed(TrackerBuffers& tb, uint32_t seed, hipStream_t s);
 // d_T21 (optional): 16 doubles that receive the inverse of the accepted pose (input of the scale stage)
 int enqueue_compute_pose_2d2d(TrackerBuffers& tb, int n_host, const PoseConfig& cfg, hipStream_t s,
                               double* d_T21 = nullptr);
+// update_global_pose over a gathered sequence in one launch (rows [n][17] -> poses [n+1][16]); d_bad[0] = first status-2 row or -1
+int enqueue_compose_trajectory(const double* d_rows, int n, const double* d_first, double* d_poses, int* d_bad, hipStream_t s);
 int enqueue_pose_h_part(TrackerBuffers& tb, int n_bound, const PoseConfig& cfg, hipStream_t sh);
 int enqueue_pose_e_part(TrackerBuffers& tb, int n_host, const PoseConfig& cfg, hipStream_t s, double* d_T21);
 int enqueue_mt_shuffle(uint32_t* mt_state, const int* d_n, int n_host, int repeat, int perm_stride, int* perm,

@@ -38,6 +38,37 @@ def allgather_poses(rel, status, world, rank, dist=None, backend_device="cuda"):
     return np.concatenate([b[:c].cpu().numpy() for b, c in zip(bufs, counts)], 0)
 
 
+def compose_trajectory_device(gathered, first_pose=None):
+    """compose_trajectory in ONE device launch (dfvo_compose_trajectory[_device], csrc/solver_pipeline.hip): `gathered` is
+    the [n,17] pose | status array -- a numpy array, or a CUDA tensor (the RCCL all-gather's output: nothing but the
+    composed poses then crosses PCIe).  Same recurrence, same order of operations as the host loop below; numpy's 3x3
+    products may fuse multiply-adds where the kernel does not, so the two agree to rounding (<= 1e-12), not bit for bit."""
+    import ctypes as C
+    from . import capi
+    lib = capi.lib()
+    bad = C.c_int(-1)
+    fp = None if first_pose is None else np.ascontiguousarray(first_pose, np.float64)
+    if hasattr(gathered, "is_cuda") and gathered.is_cuda:
+        import torch
+        g = gathered.contiguous().double()
+        n = g.shape[0]
+        out = torch.empty((n + 1, 4, 4), dtype=torch.float64, device=g.device)
+        first = None if fp is None else torch.from_numpy(fp).to(g.device)
+        torch.cuda.current_stream().synchronize()  # the library launches on the null stream
+        capi.check(lib.dfvo_compose_trajectory_device(C.c_void_p(g.data_ptr()), n, None if first is None else C.c_void_p(first.data_ptr()),
+                                                      C.c_void_p(out.data_ptr()), C.byref(bad), None))
+        poses = out.cpu().numpy()
+    else:
+        g = np.ascontiguousarray(gathered, np.float64)
+        n = g.shape[0]
+        poses = np.zeros((n + 1, 4, 4))
+        capi.check(lib.dfvo_compose_trajectory(capi.as_ptr(g), n, None if fp is None else capi.as_ptr(fp), capi.as_ptr(poses), C.byref(bad)))
+    if bad.value >= 0:
+        raise ValueError("compose_trajectory: pair %d needs the PnP fallback but had no reference depth; start every chunk "
+                         "with TrackingPipeline.set_ref_image(first frame of the chunk)" % bad.value)
+    return poses
+
+
 def compose_trajectory(gathered, first_pose=None):
     """sequential prefix composition over all gathered pairs -> global poses [n+1,4,4].
     status 1 (constant motion) reuses the previous pair's relative motion, as the reference does."""

@@ -56,10 +56,13 @@ def track_chunk(pipe, frames, lo, hi, seed=4869, rng_mode="sequential", ahead=3,
     return rel, status
 
 
-def run_sequence(pipe, frames, n_frames, world=1, rank=0, dist=None, seed=4869, rng_mode=None, ahead=3, collect=None):
+def run_sequence(pipe, frames, n_frames, world=1, rank=0, dist=None, seed=4869, rng_mode=None, ahead=3, collect=None,
+                 compose="host"):
     """data-parallel tracking of an n_frames sequence: contiguous chunk per rank (dist.chunk_bounds), ONE all-gather of
     the relative poses + status words (RCCL when `dist` runs the nccl backend), then the sequential prefix composition
     that reproduces DFVO.update_global_pose incl. the constant-motion rule (dfvo.py:109-119,157-161).
+    compose: "host" = the numpy recurrence of dist.compose_trajectory (the reference's own operations), "device" = the same
+    recurrence in one launch (dist.compose_trajectory_device; agrees to rounding).
     Returns (global poses [n_frames,4,4] camera-to-world, gathered [n_frames-1,17])."""
     if rng_mode is None:
         rng_mode = "sequential" if world == 1 else "per_pair"
@@ -68,14 +71,15 @@ def run_sequence(pipe, frames, n_frames, world=1, rank=0, dist=None, seed=4869, 
     lo, hi = dmod.chunk_bounds(n_frames - 1, world, rank)
     rel, status = track_chunk(pipe, frames, lo, hi, seed, rng_mode, ahead, collect=collect)
     gathered = dmod.allgather_poses(rel, status, world, rank, dist)
-    return dmod.compose_trajectory(gathered), gathered
+    traj = dmod.compose_trajectory_device(gathered) if compose == "device" else dmod.compose_trajectory(gathered)
+    return traj, gathered
 
 
 def save_traj(path, poses):
-    """one line per frame: "<idx> r11 r12 r13 tx r21 ... tz" (libs/general/utils.py:329-355 save_traj, format 'kitti')"""
-    with open(path, "w") as f:
-        for i, p in enumerate(poses):
-            f.write(" ".join([str(i)] + [repr(float(v)) for v in np.asarray(p)[:3, :4].reshape(-1)]) + "\n")
+    """one line per frame: "<idx> r11 r12 r13 tx r21 ... tz" (libs/general/utils.py:329-355 save_traj, format 'kitti');
+    the batched writer of df-vo_amd/evaluation.py"""
+    from .evaluation import save_traj as _save
+    _save(path, poses)
 
 
 def frames_to_device(frames_u8):

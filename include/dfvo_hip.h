@@ -418,6 +418,16 @@ int dfvo_pipeline_set_rng_state(dfvo_pipeline* p, const uint32_t* h_state625);
 int dfvo_pipeline_sync(dfvo_pipeline* p);
 double dfvo_pipeline_net_flops(const dfvo_pipeline* p);
 
+/* DFVO.update_global_pose (dfvo.py:109-119: t_w += R_w t, then R_w = R_w R) over a whole gathered sequence in ONE launch,
+ * constant-motion rows included (dfvo.py:157-161: a row with status 1 reuses the previous pair's relative motion).
+ * rows [n][17] = relative pose cur -> ref (4x4 row major) | status (the layout of dist.allgather_poses); first [16] = pose
+ * of frame 0 (NULL: identity); poses [n+1][16] out.  *h_bad_row = index of the first status-2 row (a pair that needed the
+ * PnP fallback but had no reference depth), -1 when there is none.  The _device variant takes device pointers (the
+ * gathered rows are already in HBM after the RCCL all-gather) and a HIP stream. */
+int dfvo_compose_trajectory(const double* h_rows, int n, const double* h_first, double* h_poses, int* h_bad_row);
+int dfvo_compose_trajectory_device(const double* d_rows, int n, const double* d_first, double* d_poses, int* h_bad_row,
+                                   void* stream);
+
 /* Not exported here: the per-sequence pose all-gather of SURVEY.md section 8e ("dfvo_allgather_poses").  It moves 136
  * bytes per frame once per chunk and runs through the process group the host already owns (torch.distributed: RCCL on
  * GPUs, gloo in the CPU tests) -- df-vo_amd/dist.py:allgather_poses, df-vo_amd/sequence.py:run_sequence.  A C caller

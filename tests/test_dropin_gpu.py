@@ -257,3 +257,37 @@ def test_mirrors_from_weight_files_reproduce_reference_main_loop(gpu, tmp_path):
     for i in range(n):
         assert np.abs(poses[i][:3, :3] - fx["poses"][i][:3, :3]).max() < 1e-3
         assert np.linalg.norm(poses[i][:3, 3] - fx["poses"][i][:3, 3]) < 0.02 * max(1.0, np.linalg.norm(fx["poses"][i][:3, 3]))
+
+
+def test_trajectory_composition_on_the_device(gpu):
+    """update_global_pose over a gathered sequence in one launch (dfvo_compose_trajectory) against the host
+    loop of dist.compose_trajectory -- E / PnP rows, constant-motion rows (status 1: the previous motion is reused, also
+    when several follow each other and at row 0), a non-identity first pose, host arrays and a CUDA tensor; a status-2 row
+    is refused with the row index"""
+    import torch
+    dmod = importlib.import_module("df-vo_amd.dist")
+    rng = np.random.Generator(np.random.PCG64(11))
+    n = 301
+    rows = np.zeros((n, 17))
+    for i in range(n):
+        w = rng.normal(0, 0.01, 3)
+        th = np.linalg.norm(w)
+        Kx = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+        R = np.eye(3) + np.sin(th) / th * Kx + (1 - np.cos(th)) / th ** 2 * Kx @ Kx
+        T = np.eye(4)
+        T[:3, :3], T[:3, 3] = R, rng.normal(0, 0.5, 3) + [0, 0, 1.0]
+        rows[i, :16] = T.reshape(-1)
+    rows[[0, 7, 8, 9, 100], 16] = 1       # constant motion (row 0: the identity "previous" motion)
+    rows[[20, 21], 16] = 3                # PnP rows compose like E rows
+    first = np.eye(4)
+    first[:3, 3] = [1.0, -2.0, 3.0]
+    for fp in (None, first):
+        want = dmod.compose_trajectory(rows, fp)
+        got_h = dmod.compose_trajectory_device(rows, fp)
+        got_d = dmod.compose_trajectory_device(torch.from_numpy(rows).cuda(), fp)
+        assert got_h.shape == want.shape == (n + 1, 4, 4)
+        assert np.array_equal(got_h, got_d)
+        assert np.abs(got_h - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
+    rows[50, 16] = 2
+    with pytest.raises(ValueError, match="pair 50"):
+        dmod.compose_trajectory_device(rows)
