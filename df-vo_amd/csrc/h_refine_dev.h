@@ -1,0 +1,601 @@
+// Device code shared by the homography refinement of findHomography (k_h_refine, solver_ransac.hip) and the planar
+// initialisation of cvFindExtrinsicCameraParams2 (k_pnp_refine, solver_pnp.hip): the cooperative Jacobi eigen solver and
+// the "refit on the inliers + Levenberg-Marquardt" block, one 256-thread workgroup, one lane per sequentially-summed
+// accumulator (same rounding as the CPU loops of oracle/cv3_calib3d.c: h_run_kernel / h_refine_lm).
+#pragma once
+#include <cfloat>
+
+#include "solver_math.h"
+
+namespace dfvo {
+
+// ------------------------------------------------------------------------------------------------
+// Jacobi eigen decomposition run by ONE WAVEFRONT on a matrix in LDS (same arithmetic, element for element, as
+// sm::jacobi_eigen_ws: the rotation sequence is data dependent and stays sequential, but inside a rotation the
+// pivot search is a (value, scan order) max-reduction over <= 16 lanes, the element pairs of the two rows/columns
+// are rotated one per lane, and the four pivot-table rescans run on four lanes).  ~10x the single-lane rate.
+// ------------------------------------------------------------------------------------------------
+#define WAVE_LDS_SYNC()                                          \
+    do {                                                         \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   \
+        __builtin_amdgcn_wave_barrier();                         \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   \
+    } while (0)
+
+template <int N>
+__device__ void jacobi_eigen_coop(double* A, double* W, double* V, int* ind, int lane) {
+    const double eps = DBL_EPSILON;
+    int *indR = ind, *indC = ind + N;
+    auto scan_row = [&](int k) {  // first maximum of |A[k][i]|, i > k
+        int m = k + 1;
+        double mv = fabs(A[N * k + m]);
+        for (int i = k + 2; i < N; i++) {
+            const double val = fabs(A[N * k + i]);
+            if (mv < val) mv = val, m = i;
+        }
+        return m;
+    };
+    auto scan_col = [&](int k) {  // first maximum of |A[i][k]|, i < k
+        int m = 0;
+        double mv = fabs(A[k]);
+        for (int i = 1; i < k; i++) {
+            const double val = fabs(A[N * i + k]);
+            if (mv < val) mv = val, m = i;
+        }
+        return m;
+    };
+    for (int idx = lane; idx < N * N; idx += 64) V[idx] = (idx / N == idx % N) ? 1. : 0.;
+    if (lane < N) {
+        W[lane] = A[(N + 1) * lane];
+        if (lane < N - 1) indR[lane] = scan_row(lane);
+        if (lane > 0) indC[lane] = scan_col(lane);
+    }
+    WAVE_LDS_SYNC();
+    const int maxIters = N * N * 30;
+    for (int iters = 0; iters < maxIters; iters++) {
+        // pivot candidates in the sequential scan order: rows 0..N-2 (via indR), then columns 1..N-1 (via indC)
+        double val = -1.;
+        int ck = 0, cl = 0, ord = lane;
+        if (lane < N - 1) {
+            ck = lane;
+            cl = indR[lane];
+            val = fabs(A[N * ck + cl]);
+        } else if (lane < 2 * N - 2) {
+            cl = lane - (N - 1) + 1;
+            ck = indC[cl];
+            val = fabs(A[N * ck + cl]);
+        }
+#pragma unroll
+        for (int sh = 8; sh >= 1; sh >>= 1) {
+            const double ov = __shfl_xor(val, sh, 64);
+            const int oo = __shfl_xor(ord, sh, 64);
+            if (ov > val || (ov == val && oo < ord)) {
+                val = ov;
+                ord = oo;
+            }
+        }
+        ord = __shfl(ord, 0, 64);  // lanes 0..15 agree; broadcast to the rest of the wave
+        const int k = __shfl(ck, ord, 64), l = __shfl(cl, ord, 64);
+        const double p = A[N * k + l];
+        if (fabs(p) <= eps) break;
+        const double y = (W[l] - W[k]) * 0.5;
+        double t = fabs(y) + sm::hypot_p(p, y);
+        double sn = sm::hypot_p(p, t);
+        const double c = t / sn;
+        sn = p / sn;
+        t = (p / t) * p;
+        if (y < 0) sn = -sn, t = -t;
+        WAVE_LDS_SYNC();  // every lane has read W[k], W[l], A[k][l]
+        if (lane == 0) {
+            A[N * k + l] = 0;
+            W[k] -= t;
+            W[l] += t;
+        }
+        if (lane < N) {
+            const int i = lane;
+            double a0, b0;
+            if (i < k) {
+                a0 = A[N * i + k], b0 = A[N * i + l];
+                A[N * i + k] = a0 * c - b0 * sn;
+                A[N * i + l] = a0 * sn + b0 * c;
+            } else if (i > k && i < l) {
+                a0 = A[N * k + i], b0 = A[N * i + l];
+                A[N * k + i] = a0 * c - b0 * sn;
+                A[N * i + l] = a0 * sn + b0 * c;
+            } else if (i > l) {
+                a0 = A[N * k + i], b0 = A[N * l + i];
+                A[N * k + i] = a0 * c - b0 * sn;
+                A[N * l + i] = a0 * sn + b0 * c;
+            }
+            a0 = V[N * k + i], b0 = V[N * l + i];
+            V[N * k + i] = a0 * c - b0 * sn;
+            V[N * l + i] = a0 * sn + b0 * c;
+        }
+        WAVE_LDS_SYNC();
+        if (lane == 0 && k < N - 1) indR[k] = scan_row(k);
+        if (lane == 1 && k > 0) indC[k] = scan_col(k);
+        if (lane == 2 && l < N - 1) indR[l] = scan_row(l);
+        if (lane == 3 && l > 0) indC[l] = scan_col(l);
+        WAVE_LDS_SYNC();
+    }
+    if (lane == 0) {  // descending selection sort of the eigenvalues with their vectors
+        for (int k = 0; k < N - 1; k++) {
+            int m = k;
+            for (int i = k + 1; i < N; i++)
+                if (W[m] < W[i]) m = i;
+            if (k != m) {
+                double t = W[m];
+                W[m] = W[k];
+                W[k] = t;
+                for (int i = 0; i < N; i++) {
+                    t = V[N * m + i];
+                    V[N * m + i] = V[N * k + i];
+                    V[N * k + i] = t;
+                }
+            }
+        }
+    }
+    WAVE_LDS_SYNC();
+}
+
+// ------------------------------------------------------------------------------------------------
+// post-RANSAC refinement on the inliers (findHomography tail): one 256-thread block.
+//   * ordered (ballot) compaction of the inlier indices,
+//   * least-squares refit: every LtL entry / centroid / scale is a sequential sum over the inliers in
+//     index order, so ONE LANE OWNS ONE ACCUMULATOR (45 + 4 lanes) -> same rounding as the CPU loop;
+//     the per-point terms are produced 256 points at a time by all threads into LDS,
+//   * Levenberg-Marquardt (<= 10 iterations): residuals and the two Jacobian rows of 256 points per chunk
+//     in parallel into LDS, then J^T J (36 unique entries), J^T r (8), |r|^2 and |r|_inf again one lane
+//     per accumulator over the chunk; the 8x8 eigen-solve on lane 0.
+// ------------------------------------------------------------------------------------------------
+struct HRefineShared {
+    double buf[256 * 18];  // per-point Lx|Ly (refit) or J rows (16) + r (2) (LM)
+    float pts[256 * 4];    // Mx My mx my of the chunk
+    int wave_cnt[4];
+    int base;
+};
+
+__device__ __forceinline__ void h_chunk_points(HRefineShared& sh, const float* src, const float* dst, const int* cidx,
+                                               int c0, int np) {
+    const int t = threadIdx.x;
+    if (c0 + t < np) {
+        const int p = cidx[c0 + t];
+        sh.pts[t * 4 + 0] = src[p * 2];
+        sh.pts[t * 4 + 1] = src[p * 2 + 1];
+        sh.pts[t * 4 + 2] = dst[p * 2];
+        sh.pts[t * 4 + 3] = dst[p * 2 + 1];
+    }
+}
+
+// residuals (and Jacobian rows) of the chunk at parameters h into sh.buf: [t*18 + 0..7] row a, [8..15] row b,
+// [16],[17] residuals
+__device__ __forceinline__ void h_chunk_lm(HRefineShared& sh, const float* pts, const double* h, int cnt, bool with_j) {
+    const int t = threadIdx.x;
+    if (t >= cnt) return;
+    const double Mx = pts[t * 4], My = pts[t * 4 + 1];
+    double ww = h[6] * Mx + h[7] * My + 1.;
+    ww = fabs(ww) > DBL_EPSILON ? 1. / ww : 0;
+    const double xi = (h[0] * Mx + h[1] * My + h[2]) * ww;
+    const double yi = (h[3] * Mx + h[4] * My + h[5]) * ww;
+    double* o = sh.buf + t * 18;
+    o[16] = xi - pts[t * 4 + 2];
+    o[17] = yi - pts[t * 4 + 3];
+    if (with_j) {
+        o[0] = Mx * ww;
+        o[1] = My * ww;
+        o[2] = ww;
+        o[3] = o[4] = o[5] = 0.;
+        o[6] = -Mx * ww * xi;
+        o[7] = -My * ww * xi;
+        o[8] = o[9] = o[10] = 0.;
+        o[11] = Mx * ww;
+        o[12] = My * ww;
+        o[13] = ww;
+        o[14] = -Mx * ww * yi;
+        o[15] = -My * ww * yi;
+    }
+}
+
+// Sequential (reference-order) sums over the points of a chunk.  The products are independent, only the adds
+// form the chain; batches of 8 points are loaded and multiplied first so the LDS latency is paid once per batch.
+constexpr int H_UNROLL = 8;
+// a += o[i0]*o[i1]; a += o[i2]*o[i3]   per point
+__device__ __forceinline__ double seq_acc_two(const double* buf, int cnt, int i0, int i1, int i2, int i3, double a) {
+    int k = 0;
+    for (; k + H_UNROLL <= cnt; k += H_UNROLL) {
+        double p0[H_UNROLL], p1[H_UNROLL];
+#pragma unroll
+        for (int u = 0; u < H_UNROLL; ++u) {
+            const double* o = buf + (k + u) * 18;
+            p0[u] = o[i0] * o[i1];
+            p1[u] = o[i2] * o[i3];
+        }
+#pragma unroll
+        for (int u = 0; u < H_UNROLL; ++u) {
+            a += p0[u];
+            a += p1[u];
+        }
+    }
+    for (; k < cnt; k++) {
+        const double* o = buf + k * 18;
+        a += o[i0] * o[i1];
+        a += o[i2] * o[i3];
+    }
+    return a;
+}
+// a += o[i0]*o[i1] + o[i2]*o[i3]   per point
+// a += o[i0]*o[i1]   per point: the form used for accumulators one of whose two Jacobian rows is structurally zero
+// (the homography Jacobian rows are [* * * 0 0 0 * *] and [0 0 0 * * * * *]): the skipped term is an exact +-0
+// product, and x + (+-0) == x for every x the running sum can hold (it starts at +0 and can never become -0)
+__device__ __forceinline__ double seq_acc_one(const double* buf, int cnt, int i0, int i1, double a) {
+    int k = 0;
+    for (; k + H_UNROLL <= cnt; k += H_UNROLL) {
+        double p0[H_UNROLL];
+#pragma unroll
+        for (int u = 0; u < H_UNROLL; ++u) {
+            const double* o = buf + (k + u) * 18;
+            p0[u] = o[i0] * o[i1];
+        }
+#pragma unroll
+        for (int u = 0; u < H_UNROLL; ++u) a += p0[u];
+    }
+    for (; k < cnt; k++) {
+        const double* o = buf + k * 18;
+        a += o[i0] * o[i1];
+    }
+    return a;
+}
+__device__ __forceinline__ double seq_acc_pair(const double* buf, int cnt, int i0, int i1, int i2, int i3, double a) {
+    int k = 0;
+    for (; k + H_UNROLL <= cnt; k += H_UNROLL) {
+        double p[H_UNROLL];
+#pragma unroll
+        for (int u = 0; u < H_UNROLL; ++u) {
+            const double* o = buf + (k + u) * 18;
+            p[u] = o[i0] * o[i1] + o[i2] * o[i3];
+        }
+#pragma unroll
+        for (int u = 0; u < H_UNROLL; ++u) a += p[u];
+    }
+    for (; k < cnt; k++) {
+        const double* o = buf + k * 18;
+        a += o[i0] * o[i1] + o[i2] * o[i3];
+    }
+    return a;
+}
+// |r|^2 in groups of two points (four residual rows), the order the oracle's norm loop uses
+__device__ __forceinline__ double seq_acc_sq(const double* buf, int cnt, double a) {
+    int k = 0;
+    for (; k + H_UNROLL <= cnt; k += H_UNROLL) {
+        double p[H_UNROLL / 2];
+#pragma unroll
+        for (int u = 0; u < H_UNROLL / 2; ++u) {
+            const double v0 = buf[(k + 2 * u) * 18 + 16], v1 = buf[(k + 2 * u) * 18 + 17];
+            const double v2 = buf[(k + 2 * u + 1) * 18 + 16], v3 = buf[(k + 2 * u + 1) * 18 + 17];
+            p[u] = v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
+        }
+#pragma unroll
+        for (int u = 0; u < H_UNROLL / 2; ++u) a += p[u];
+    }
+    for (; k + 1 < cnt; k += 2) {
+        const double v0 = buf[k * 18 + 16], v1 = buf[k * 18 + 17];
+        const double v2 = buf[(k + 1) * 18 + 16], v3 = buf[(k + 1) * 18 + 17];
+        a += v0 * v0 + v1 * v1 + v2 * v2 + v3 * v3;
+    }
+    for (; k < cnt; k++) {  // only at the very end of the inlier list (chunks hold an even count otherwise)
+        const double v0 = buf[k * 18 + 16], v1 = buf[k * 18 + 17];
+        a += v0 * v0;
+        a += v1 * v1;
+    }
+    return a;
+}
+
+__device__ double seq_dot8(const double* a, const double* b) {
+    double r = 0;
+    r += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+    r += a[4] * b[4] + a[5] * b[5] + a[6] * b[6] + a[7] * b[7];
+    return r;
+}
+
+// everything the refit + LM block keeps in LDS besides HRefineShared
+struct HRefineWork {
+    double h[9], x[8], xd[8], d[8], v[8], A[64], D[8], norm[8], LtL[81];
+    double S, Sd, rinf, lambda, lc;
+    double Ap[64], eig[2 * 81 + 2 * 9];  // lane 0's dense 8x8 / 9x9 work (LDS, not scratch)
+    int flag;
+};
+
+// cv::findHomography's tail on `np` point pairs: the normalised DLT over all of them (HomographyEstimatorCallback::
+// runKernel), then the Levenberg-Marquardt refinement (<= 10 iterations).  chunk_pts(c0) returns the points
+// [c0, c0 + 256) as Mx My mx my floats (and may synchronise the workgroup).  When the DLT rejects the point set
+// (degenerate scales) the model is H_fallback.  All 256 threads must call; the result is in w.x[0..7] (h[8] = w.h[8]).
+// refine_on_reject: run the LM from H_fallback even when the DLT rejected the points (findHomography's RANSAC tail calls
+// runKernel and the LM unconditionally); false = leave H_fallback as the answer (cv::findHomography method 0 returns
+// an empty matrix there, which cvFindHomography turns into zeros).
+template <class ChunkPts>
+__device__ __forceinline__ void h_refit_refine_block(HRefineShared& sh, HRefineWork& w, int np, ChunkPts chunk_pts,
+                                                     const double* H_fallback, bool refine_on_reject = true) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    double* const s_h = w.h;
+    double* const s_x = w.x;
+    double* const s_xd = w.xd;
+    double* const s_d = w.d;
+    double* const s_v = w.v;
+    double* const s_A = w.A;
+    double* const s_D = w.D;
+    double* const s_norm = w.norm;
+    double* const s_LtL = w.LtL;
+    double* const s_Ap = w.Ap;
+    double* const s_eig = w.eig;
+    double& s_S = w.S;
+    double& s_Sd = w.Sd;
+    double& s_rinf = w.rinf;
+    double& s_lambda = w.lambda;
+    double& s_lc = w.lc;
+    int& s_flag = w.flag;
+    const double* const H_io = H_fallback;
+    // ---- refit: centroids (4 sequential sums), then scales (4 sequential sums)
+    double acc = 0;
+    for (int c0 = 0; c0 < np; c0 += 256) {
+        const int cnt = np - c0 < 256 ? np - c0 : 256;
+        const float* cp = chunk_pts(c0);
+        if (t < 4) {  // 0: cm.x 1: cm.y 2: cM.x 3: cM.y
+            const int comp = t < 2 ? 2 + t : t - 2;
+            int k = 0;
+            for (; k + 8 <= cnt; k += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = cp[(k + u) * 4 + comp];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u];
+            }
+            for (; k < cnt; k++) acc += cp[k * 4 + comp];
+        }
+        __syncthreads();
+    }
+    if (t < 4) s_norm[t] = acc / np;
+    __syncthreads();
+    acc = 0;
+    for (int c0 = 0; c0 < np; c0 += 256) {
+        const int cnt = np - c0 < 256 ? np - c0 : 256;
+        const float* cp = chunk_pts(c0);
+        if (t < 4) {
+            const int comp = t < 2 ? 2 + t : t - 2;
+            const double c = s_norm[t];
+            int k = 0;
+            for (; k + 8 <= cnt; k += 8) {
+                double v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = fabs(cp[(k + u) * 4 + comp] - c);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u];
+            }
+            for (; k < cnt; k++) acc += fabs(cp[k * 4 + comp] - c);
+        }
+        __syncthreads();
+    }
+    if (t < 4) s_norm[4 + t] = acc;
+    __syncthreads();
+    sm::HNorm hn;
+    hn.cmx = s_norm[0];
+    hn.cmy = s_norm[1];
+    hn.cMx = s_norm[2];
+    hn.cMy = s_norm[3];
+    const bool degenerate = fabs(s_norm[4]) < DBL_EPSILON || fabs(s_norm[5]) < DBL_EPSILON ||
+                            fabs(s_norm[6]) < DBL_EPSILON || fabs(s_norm[7]) < DBL_EPSILON;
+    if (!degenerate) {
+        hn.smx = np / s_norm[4];
+        hn.smy = np / s_norm[5];
+        hn.sMx = np / s_norm[6];
+        hn.sMy = np / s_norm[7];
+        int lj = 0, lk = 0;
+        if (t < 45) {  // lane t owns upper-triangular entry (lj, lk)
+            int rem = t;
+            while (rem >= 9 - lj) {
+                rem -= 9 - lj;
+                lj++;
+            }
+            lk = lj + rem;
+        }
+        acc = 0;
+        for (int c0 = 0; c0 < np; c0 += 256) {
+            const int cnt = np - c0 < 256 ? np - c0 : 256;
+            const float* cp = chunk_pts(c0);
+            if (t < cnt) {
+                const double x = (cp[t * 4 + 2] - hn.cmx) * hn.smx, y = (cp[t * 4 + 3] - hn.cmy) * hn.smy;
+                const double X = (cp[t * 4 + 0] - hn.cMx) * hn.sMx, Y = (cp[t * 4 + 1] - hn.cMy) * hn.sMy;
+                double* o = sh.buf + t * 18;
+                o[0] = X; o[1] = Y; o[2] = 1; o[3] = 0; o[4] = 0; o[5] = 0; o[6] = -x * X; o[7] = -x * Y; o[8] = -x;
+                o[9] = 0; o[10] = 0; o[11] = 0; o[12] = X; o[13] = Y; o[14] = 1; o[15] = -y * X; o[16] = -y * Y; o[17] = -y;
+            }
+            __syncthreads();
+            if (t < 45) acc = seq_acc_pair(sh.buf, cnt, lj, lk, 9 + lj, 9 + lk, acc);
+            __syncthreads();
+        }
+        if (t < 81) s_LtL[t] = 0;
+        __syncthreads();
+        if (t < 45) s_LtL[lj * 9 + lk] = acc;
+        __syncthreads();
+        if (t < 81) {  // symmetric completion, then the 9 x 9 eigen decomposition on wave 0
+            const int j = t / 9, k = t % 9;
+            if (k < j) s_LtL[t] = s_LtL[k * 9 + j];
+        }
+        __syncthreads();
+        if (wave == 0) jacobi_eigen_coop<9>(s_LtL, s_eig, s_eig + 9, reinterpret_cast<int*>(s_eig + 90), lane);
+        __syncthreads();
+        if (t == 0) sm::homography_denormalise(hn, s_eig + 9 + 72, s_h);
+    } else if (t == 0) {
+        for (int i = 0; i < 9; i++) s_h[i] = H_io[i];
+    }
+    __syncthreads();
+    if (degenerate && !refine_on_reject) {
+        if (t < 8) s_x[t] = s_h[t];
+        __syncthreads();
+        return;
+    }
+    // ---- Levenberg-Marquardt on the 8 free parameters
+    if (t < 8) s_x[t] = s_h[t];
+    __syncthreads();
+    // accumulator roles: t < 36 -> JtJ(i,j); 64..71 -> Jtr(i); 128 -> |r|^2 (4-row groups); 192 -> |r|_inf
+    int ai = 0, aj = 0;
+    if (t < 36) {
+        int rem = t;
+        while (rem >= 8 - ai) {
+            rem -= 8 - ai;
+            ai++;
+        }
+        aj = ai + rem;
+    }
+    auto full_pass = [&](const double* h) {  // residuals + Jacobian at h -> s_A, s_v, s_S, s_rinf
+        double a = 0;
+        for (int c0 = 0; c0 < np; c0 += 256) {
+            const int cnt = np - c0 < 256 ? np - c0 : 256;
+            const float* cp = chunk_pts(c0);
+            h_chunk_lm(sh, cp, h, cnt, true);
+            __syncthreads();
+            if (t < 36) {
+                // row a is non-zero in columns {0,1,2,6,7}, row b in {3,4,5,6,7}
+                const bool ua = (ai < 3 || ai > 5) && (aj < 3 || aj > 5), ub = ai >= 3 && aj >= 3;
+                if (ua && ub)
+                    a = seq_acc_two(sh.buf, cnt, ai, aj, 8 + ai, 8 + aj, a);
+                else if (ua)
+                    a = seq_acc_one(sh.buf, cnt, ai, aj, a);
+                else if (ub)
+                    a = seq_acc_one(sh.buf, cnt, 8 + ai, 8 + aj, a);
+            } else if (t >= 64 && t < 72) {
+                const int i = t - 64;
+                if (i < 3)
+                    a = seq_acc_one(sh.buf, cnt, i, 16, a);
+                else if (i < 6)
+                    a = seq_acc_one(sh.buf, cnt, 8 + i, 17, a);
+                else
+                    a = seq_acc_two(sh.buf, cnt, i, 16, 8 + i, 17, a);
+            } else if (t == 128) {
+                a = seq_acc_sq(sh.buf, cnt, a);
+            } else if (t == 192) {
+                int k = 0;
+                for (; k + 8 <= cnt; k += 8) {
+                    double v[16];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        v[2 * u] = fabs(sh.buf[(k + u) * 18 + 16]);
+                        v[2 * u + 1] = fabs(sh.buf[(k + u) * 18 + 17]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) a = a > v[u] ? a : v[u];
+                }
+                for (; k < cnt; k++) {
+                    const double v0 = fabs(sh.buf[k * 18 + 16]), v1 = fabs(sh.buf[k * 18 + 17]);
+                    a = a > v0 ? a : v0;
+                    a = a > v1 ? a : v1;
+                }
+            }
+            __syncthreads();
+        }
+        if (t < 36) {
+            s_A[ai * 8 + aj] = a;
+            s_A[aj * 8 + ai] = a;
+        } else if (t >= 64 && t < 72) {
+            s_v[t - 64] = a;
+        } else if (t == 128) {
+            s_S = a;
+        } else if (t == 192) {
+            s_rinf = a;
+        }
+        __syncthreads();
+    };
+    auto residual_pass = [&](const double* h) {  // |r(h)|^2 -> s_Sd
+        double a = 0;
+        for (int c0 = 0; c0 < np; c0 += 256) {
+            const int cnt = np - c0 < 256 ? np - c0 : 256;
+            const float* cp = chunk_pts(c0);
+            h_chunk_lm(sh, cp, h, cnt, false);
+            __syncthreads();
+            if (t == 128) a = seq_acc_sq(sh.buf, cnt, a);
+            __syncthreads();
+        }
+        if (t == 128) s_Sd = a;
+        __syncthreads();
+    };
+    full_pass(s_x);
+    if (t < 8) s_D[t] = s_A[t * 8 + t];
+    if (t == 0) {
+        s_lambda = 1;
+        s_lc = 0.75;
+    }
+    __syncthreads();
+    const double Rlo = 0.25, Rhi = 0.75;
+    const double epsx = FLT_EPSILON, epsf = FLT_EPSILON;
+    int iter = 0;
+    for (;;) {
+        if (t < 64) s_Ap[t] = s_A[t];
+        __syncthreads();
+        if (t < 8) s_Ap[t * 8 + t] += s_lambda * s_D[t];
+        __syncthreads();
+        // solve(Ap, v, d, DECOMP_EIG): eigen decomposition on wave 0 (in place), back-substitution on lane 0
+        if (wave == 0) jacobi_eigen_coop<8>(s_Ap, s_eig + 64, s_eig, reinterpret_cast<int*>(s_eig + 72), lane);
+        __syncthreads();
+        if (t == 0) {
+            sm::svbksb_eig_vec<8>(s_eig + 64, s_eig, s_v, s_d);
+            for (int i = 0; i < 8; i++) s_xd[i] = s_x[i] - s_d[i];
+        }
+        __syncthreads();
+        residual_pass(s_xd);
+        if (t == 0) {
+            const double Sd = s_Sd;
+            double temp_d[8], d[8], v[8];
+            for (int i = 0; i < 8; i++) {
+                d[i] = s_d[i];
+                v[i] = s_v[i];
+            }
+            for (int i = 0; i < 8; i++) {
+                double sacc = 0;
+                for (int k = 0; k < 8; k++) sacc += s_A[i * 8 + k] * d[k];
+                temp_d[i] = sacc * -1. + v[i] * 2.;
+            }
+            const double dS = seq_dot8(d, temp_d);
+            const double S = s_S;
+            const double R = (S - Sd) / (fabs(dS) > DBL_EPSILON ? dS : 1);
+            double lambda = s_lambda, lc = s_lc;
+            if (R > Rhi) {
+                lambda *= 0.5;
+                if (lambda < lc) lambda = 0;
+            } else if (R < Rlo) {
+                const double tt = seq_dot8(d, v);
+                double nu = (Sd - S) / (fabs(tt) > DBL_EPSILON ? tt : 1) + 2;
+                nu = nu > 2. ? nu : 2.;
+                nu = nu < 10. ? nu : 10.;
+                if (lambda == 0) {
+                    double* Ai = s_Ap;
+                    sm::invert_eig_ws<8>(s_A, Ai, s_eig);
+                    double maxval = DBL_EPSILON;
+                    for (int i = 0; i < 8; i++) maxval = maxval > fabs(Ai[i * 8 + i]) ? maxval : fabs(Ai[i * 8 + i]);
+                    lambda = lc = 1. / maxval;
+                    nu *= 0.5;
+                }
+                lambda *= nu;
+            }
+            s_lambda = lambda;
+            s_lc = lc;
+            s_flag = Sd < S ? 1 : 0;
+        }
+        __syncthreads();
+        if (s_flag) {
+            if (t < 8) {
+                const double tx = s_x[t];
+                s_x[t] = s_xd[t];
+                s_xd[t] = tx;
+            }
+            __syncthreads();
+            full_pass(s_x);  // refreshes A, v, S (= Sd) and |r|_inf
+        }
+        iter++;
+        double dinf = 0;
+        for (int i = 0; i < 8; i++) dinf = dinf > fabs(s_d[i]) ? dinf : fabs(s_d[i]);
+        const bool proceed = iter < 10 && dinf >= epsx && s_rinf >= epsf;
+        __syncthreads();
+        if (!proceed) break;
+    }
+}
+
+}  // namespace dfvo

@@ -13,6 +13,7 @@
 // Built with -ffp-contract=off.
 #include <cstring>
 
+#include "h_refine_dev.h"  // the homography refit + LM block (planar initialisation)
 #include "pnp_math.h"
 #include "ransac_dev.h"
 #include "tracker.h"
@@ -367,9 +368,86 @@ __global__ __launch_bounds__(256) void k_pnp_refine(const PBatch B) {
         s_flag = (W[2] / W[1] < 1e-3 || np < 4) ? 1 : 0;
     }
     __syncthreads();
-    const bool planar = s_flag != 0;  // coplanar object points: the LM starts from the accepted RANSAC model (as the oracle's
-                                      // cv3_find_extrinsic_guess does; OpenCV's homography initialisation is not restated)
-    if (planar && t < 6) s_param[t] = (R.models + (size_t)R.state->best_iter * 6)[t];
+    const bool planar = s_flag != 0;
+    if (planar) {
+        // Coplanar object points: cvFindExtrinsicCameraParams2's planar initialisation (calibration.cpp; oracle:
+        // cv3_find_extrinsic_guess).  The points are rotated into their principal plane (R_transform = V^T of the SVD above,
+        // made right-handed; T_transform = -R_transform Mc), cvFindHomography (method 0: DLT over all inliers + LM,
+        // h_refit_refine_block -- the block findHomography's own tail runs on) maps the in-plane coordinates to the
+        // normalised image points, and the pose is read off H.  The LDS of the row buffer is free at this point.
+        __shared__ double s_pl[12 + 9];  // R_transform | T_transform | zero matrix (the model of a rejected point set)
+        HRefineShared& hs = *reinterpret_cast<HRefineShared*>(s_buf);
+        HRefineWork& hw = *reinterpret_cast<HRefineWork*>(s_buf + 5200);
+        static_assert(sizeof(HRefineShared) <= 5200 * sizeof(double) && 5200 * sizeof(double) + sizeof(HRefineWork) <= sizeof(s_buf),
+                      "the homography block does not fit the row buffer");
+        if (t == 0) {
+            const double* V = s_ws + 12;  // V^T: rows are the right singular vectors
+            double Rt[9];
+            for (int i = 0; i < 9; i++) Rt[i] = V[i];
+            if (V[2] * V[2] + V[5] * V[5] < 1e-10) {
+                for (int i = 0; i < 9; i++) Rt[i] = 0.;
+                Rt[0] = Rt[4] = Rt[8] = 1.;
+            }
+            if (sm::det3(Rt) < 0)
+                for (int i = 0; i < 9; i++) Rt[i] *= -1.;
+            for (int i = 0; i < 9; i++) s_pl[i] = Rt[i];
+            for (int i = 0; i < 3; i++) s_pl[9 + i] = (Rt[i * 3] * s_Mc[0] + Rt[i * 3 + 1] * s_Mc[1] + Rt[i * 3 + 2] * s_Mc[2]) * -1.;
+            for (int i = 0; i < 9; i++) s_pl[12 + i] = 0.;
+        }
+        __syncthreads();
+        auto plane_pts = [&](int c0) -> const float* {  // (in-plane x, y | normalised image point) of inliers [c0, c0 + 256)
+            const int cnt = load_chunk(c0);
+            __syncthreads();
+            if (t < cnt) {
+                const double X = s_pts[t * 5], Y = s_pts[t * 5 + 1], Z = s_pts[t * 5 + 2];
+                const double Mx = s_pl[0] * X + s_pl[1] * Y + s_pl[2] * Z + s_pl[9];
+                const double My = s_pl[3] * X + s_pl[4] * Y + s_pl[5] * Z + s_pl[10];
+                hs.pts[t * 4 + 0] = (float)Mx;
+                hs.pts[t * 4 + 1] = (float)My;
+                hs.pts[t * 4 + 2] = (float)(((double)s_pts[t * 5 + 3] - cx) * ifx);
+                hs.pts[t * 4 + 3] = (float)(((double)s_pts[t * 5 + 4] - cy) * ify);
+            }
+            __syncthreads();
+            return hs.pts;
+        };
+        h_refit_refine_block(hs, hw, np, plane_pts, s_pl + 12, /*refine_on_reject=*/false);
+        __syncthreads();
+        if (t == 0) {
+            double h[9];
+            for (int i = 0; i < 8; i++) h[i] = hw.x[i];
+            h[8] = hw.h[8];
+            bool finite = true;
+            for (int i = 0; i < 9; i++) finite = finite && isfinite(h[i]);
+            double Rm[9], tt[3] = {0., 0., 0.};
+            if (finite) {
+                const double h1n = sqrt(h[0] * h[0] + h[3] * h[3] + h[6] * h[6]);
+                const double h2n = sqrt(h[1] * h[1] + h[4] * h[4] + h[7] * h[7]);
+                const double s1 = 1. / (h1n > DBL_EPSILON ? h1n : DBL_EPSILON), s2 = 1. / (h2n > DBL_EPSILON ? h2n : DBL_EPSILON);
+                const double s3 = 2. / (h1n + h2n > DBL_EPSILON ? h1n + h2n : DBL_EPSILON);
+                for (int i = 0; i < 3; i++) {
+                    h[i * 3] *= s1;
+                    h[i * 3 + 1] *= s2;
+                    tt[i] = h[i * 3 + 2] * s3;
+                }
+                h[2] = h[3] * h[7] - h[6] * h[4];
+                h[5] = h[6] * h[1] - h[0] * h[7];
+                h[8] = h[0] * h[4] - h[3] * h[1];
+                double r3[3], Hr[9];
+                sm::rodrigues_m2v(h, r3, s_ws);
+                sm::rodrigues_v2m(r3, Hr, nullptr);
+                const double* Rt = s_pl;
+                const double* Tt = s_pl + 9;
+                for (int i = 0; i < 3; i++) tt[i] = (Hr[i * 3] * Tt[0] + Hr[i * 3 + 1] * Tt[1] + Hr[i * 3 + 2] * Tt[2]) + tt[i];
+                for (int i = 0; i < 3; i++)
+                    for (int j = 0; j < 3; j++) Rm[i * 3 + j] = Hr[i * 3] * Rt[j] + Hr[i * 3 + 1] * Rt[3 + j] + Hr[i * 3 + 2] * Rt[6 + j];
+            } else {
+                for (int i = 0; i < 9; i++) Rm[i] = 0.;
+                Rm[0] = Rm[4] = Rm[8] = 1.;
+            }
+            sm::rodrigues_m2v(Rm, s_param, s_ws);
+            for (int i = 0; i < 3; i++) s_param[3 + i] = tt[i];
+        }
+    }
     __syncthreads();
     // ---- DLT: LL = L^T L, L = 2 rows per point; lane t < 78 owns upper-triangle entry (la, lb)
     int la = 0, lb = 0;

@@ -788,6 +788,26 @@ static int h_refine_lm(const float* M, const float* m, int count, double* h8, in
     return iter;
 }
 
+/* cv::findHomography(src, dst, method = 0): the normalised DLT over ALL points, then (n > 4) the Levenberg-Marquardt
+ * refinement -- what cvFindHomography does for cvFindExtrinsicCameraParams2's planar initialisation (calibration.cpp).
+ * The points are converted to CV_32F first, as findHomography does.  Returns 0 (H zeroed, as the C wrapper leaves it) when
+ * the kernel rejects the point set. */
+int cv3_find_homography_lsq(const double* pts1, const double* pts2, int n, double* H) {
+    float* src = (float*)malloc(sizeof(float) * 2 * (size_t)n);
+    float* dst = (float*)malloc(sizeof(float) * 2 * (size_t)n);
+    for (int i = 0; i < 2 * n; i++) {
+        src[i] = (float)pts1[i];
+        dst[i] = (float)pts2[i];
+    }
+    int ok = n >= 4 && h_run_kernel(NULL, src, dst, n, H) > 0;
+    if (ok && n > 4) h_refine_lm(src, dst, n, H, 10);
+    if (!ok)
+        for (int i = 0; i < 9; i++) H[i] = 0;
+    free(src);
+    free(dst);
+    return ok;
+}
+
 int cv3_find_homography(const double* pts1, const double* pts2, int n, double ransac_thr, int max_iters,
                         double confidence, double* H, unsigned char* mask) {
     if (n < 4) return 0;

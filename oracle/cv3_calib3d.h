@@ -46,6 +46,7 @@ int cv3_recover_pose(const double* E, const double* pts1, const double* pts2, in
                      double ppy, double* R, double* t, unsigned char* mask);
 
 /* cv::findHomography(points1, points2, RANSAC, thr, mask, maxIters, confidence); H[9]; returns 1/0 */
+int cv3_find_homography_lsq(const double* pts1, const double* pts2, int n, double* H);
 int cv3_find_homography(const double* pts1, const double* pts2, int n, double ransac_thr, int max_iters,
                         double confidence, double* H, unsigned char* mask);
 

@@ -14,9 +14,8 @@
  *    double arithmetic, < 1 ulp from libm) instead of the platform libm;
  *  - CvLevMarq::step's lambda = exp(lambdaLg10 * log(10.)) is read from a table of the 33 possible values as
  *    glibc evaluates them (tests/test_oracle_pnp.py re-derives the table with math.exp).
- * One replaced branch: cvFindExtrinsicCameraParams2's planar initialisation (object points coplanar, W[2]/W[1] < 1e-3;
- * OpenCV: homography of the in-plane coordinates) -- the LM then starts from the RANSAC model instead, see
- * cv3_find_extrinsic_guess.
+ * (Round 3: cvFindExtrinsicCameraParams2's planar initialisation -- object points coplanar, W[2]/W[1] < 1e-3 -- is
+ * restated as well, see cv3_find_extrinsic_guess; rounds 1-2 started the LM from the RANSAC model there.)
  */
 #include <float.h>
 #include <math.h>
@@ -837,17 +836,18 @@ static void lm_step(const double* JtJ, const double* JtErr, int lambdaLg10, cons
 }
 
 /* cvFindExtrinsicCameraParams2(useExtrinsicGuess = false) on double points M [n][3], m [n][2].
- * Returns 1, or -2 for the (unimplemented) planar initialisation.  stats (optional): [0] LM iterations */
+ * Returns 1.  stats (optional): [0] LM iterations */
 int cv3_find_extrinsic(const double* M, const double* m, int n, const double* K, double* rvec, double* tvec, int* stats) {
     return cv3_find_extrinsic_guess(M, m, n, K, NULL, rvec, tvec, stats);
 }
 
-/* as above; `planar_guess` (rvec | tvec, may be NULL) is the start of the Levenberg-Marquardt iteration when the object
- * points are coplanar.  DEVIATION (documented in DESIGN.md section 4, made on the device as well): OpenCV initialises the
- * planar case from a homography (cvFindHomography on the in-plane coordinates); this build starts the same LM from the
- * model solvePnPRansac's RANSAC stage accepted (EPnP on five points, already within the inlier threshold of every
- * inlier).  Both starts lie in the basin of the same reprojection minimum; the result is that minimum to the LM's
- * termination tolerance (FLT_EPSILON relative parameter change), not bit-identical to OpenCV's iterate sequence. */
+/* as above.  Round 3: the planar initialisation is restated too (calibration.cpp, the `W[2]/W[1] < 1e-3` branch): object
+ * points rotated into their principal plane (R_transform = V^T of the covariance's SVD, made right-handed; T_transform =
+ * -R_transform Mc), cvFindHomography (method 0: normalised DLT over all points + LM) between the in-plane coordinates
+ * and the normalised image points, H's first two columns normalised, third = their cross product, the rotation
+ * orthonormalised by a Rodrigues round trip, t = H T_transform + h3 * 2 / (|h1| + |h2|), R = H R_transform.
+ * `planar_guess` is kept for callers that want the old behaviour (start the LM from a given rvec | tvec instead); NULL
+ * = OpenCV's initialisation. */
 int cv3_find_extrinsic_guess(const double* M, const double* m, int n, const double* K, const double* planar_guess,
                              double* rvec, double* tvec, int* stats) {
     const double fx = K[0], fy = K[4], cx = K[2], cy = K[5], ifx = 1. / fx, ify = 1. / fy;
@@ -868,10 +868,57 @@ int cv3_find_extrinsic_guess(const double* M, const double* m, int n, const doub
     double param[6];
     const int planar = W[2] / W[1] < 1e-3 || n < 4;
     if (planar && !planar_guess) {
-        free(mn);
-        return -2;
-    }
-    if (planar) {
+        /* R_transform = matV (CV_SVD_V_T: rows are the right singular vectors) */
+        double Rt[9];
+        memcpy(Rt, V, sizeof(Rt));
+        if (V[2] * V[2] + V[5] * V[5] < 1e-10) {
+            memset(Rt, 0, sizeof(Rt));
+            Rt[0] = Rt[4] = Rt[8] = 1.;
+        }
+        if (cv3_det3(Rt) < 0)
+            for (int i = 0; i < 9; i++) Rt[i] *= -1.;
+        double Tt[3]; /* cvGEMM(R_transform, Mc, -1, 0, 0, T_transform, CV_GEMM_B_T) */
+        for (int i = 0; i < 3; i++) Tt[i] = (Rt[i * 3] * Mc[0] + Rt[i * 3 + 1] * Mc[1] + Rt[i * 3 + 2] * Mc[2]) * -1.;
+        double* Mxy = (double*)malloc(sizeof(double) * 2 * (size_t)n);
+        for (int i = 0; i < n; i++) {
+            const double* src = M + i * 3;
+            Mxy[i * 2] = Rt[0] * src[0] + Rt[1] * src[1] + Rt[2] * src[2] + Tt[0];
+            Mxy[i * 2 + 1] = Rt[3] * src[0] + Rt[4] * src[1] + Rt[5] * src[2] + Tt[1];
+        }
+        double h[9];
+        cv3_find_homography_lsq(Mxy, mn, n, h);
+        free(Mxy);
+        int finite = 1;
+        for (int i = 0; i < 9; i++) finite = finite && isfinite(h[i]);
+        double R[9], tt[3] = {0, 0, 0};
+        if (finite) {
+            const double h1n = sqrt(h[0] * h[0] + h[3] * h[3] + h[6] * h[6]);
+            const double h2n = sqrt(h[1] * h[1] + h[4] * h[4] + h[7] * h[7]);
+            const double s1 = 1. / (h1n > DBL_EPSILON ? h1n : DBL_EPSILON), s2 = 1. / (h2n > DBL_EPSILON ? h2n : DBL_EPSILON);
+            const double s3 = 2. / (h1n + h2n > DBL_EPSILON ? h1n + h2n : DBL_EPSILON);
+            for (int i = 0; i < 3; i++) {
+                h[i * 3] *= s1;
+                h[i * 3 + 1] *= s2;
+                tt[i] = h[i * 3 + 2] * s3;
+            }
+            /* _h3 = _h1 x _h2 */
+            h[2] = h[3] * h[7] - h[6] * h[4];
+            h[5] = h[6] * h[1] - h[0] * h[7];
+            h[8] = h[0] * h[4] - h[3] * h[1];
+            double r3[3], Hr[9];
+            cv3_rodrigues_m2v(h, r3);
+            cv3_rodrigues_v2m(r3, Hr);
+            for (int i = 0; i < 3; i++) /* cvMatMulAdd(H, T_transform, t, t) */
+                tt[i] = (Hr[i * 3] * Tt[0] + Hr[i * 3 + 1] * Tt[1] + Hr[i * 3 + 2] * Tt[2]) + tt[i];
+            for (int i = 0; i < 3; i++) /* cvMatMul(H, R_transform, R) */
+                for (int j = 0; j < 3; j++) R[i * 3 + j] = Hr[i * 3] * Rt[j] + Hr[i * 3 + 1] * Rt[3 + j] + Hr[i * 3 + 2] * Rt[6 + j];
+        } else {
+            memset(R, 0, sizeof(R));
+            R[0] = R[4] = R[8] = 1.;
+        }
+        cv3_rodrigues_m2v(R, param);
+        for (int i = 0; i < 3; i++) param[3 + i] = tt[i];
+    } else if (planar) {
         for (int i = 0; i < 6; i++) param[i] = planar_guess[i];
     } else {
         double* L = (double*)malloc(sizeof(double) * 24 * (size_t)n);
@@ -1027,7 +1074,7 @@ int cv3_solve_pnp_ransac(const double* obj, const double* img, int n, const doub
                 for (int j = 0; j < 2; j++) ii[np * 2 + j] = ipoints[i * 2 + j];
                 np++;
             }
-        rc = cv3_find_extrinsic_guess(oi, ii, np, K, model, rvec, tvec, NULL);
+        rc = cv3_find_extrinsic_guess(oi, ii, np, K, NULL, rvec, tvec, NULL); /* (planar inliers: OpenCV's homography initialisation) */
         if (rc == 1)
             for (int i = 0; i < n; i++)
                 if (mask[i]) inliers[(*n_inliers)++] = i;

@@ -1,6 +1,8 @@
 // TEST-ONLY host build of df-vo_amd/csrc/solver_math.h (the per-lane device functions of the HIP
 // solvers) so that their arithmetic can be checked bit-for-bit against the C oracle on a machine
 // without a GPU.  Never linked into libdfvo_hip.so; the product has no CPU path.
+#include <cmath>
+
 #include "../../df-vo_amd/csrc/solver_math.h"
 
 extern "C" {
@@ -54,7 +56,122 @@ float hh_pnp_error(const double* rvec, const double* tvec, const double* K4, con
     return sm::pnp_error(R, tvec, K4, obj, img);
 }
 // the flow of the refinement kernel (k_pnp_refine) written sequentially on the host with the same lane functions:
-// centroid / covariance planarity test, DLT initialisation, CvLevMarq loop.  Returns 1, or -2 (planar).
+// centroid / covariance planarity test, DLT (or, for coplanar points, homography) initialisation, CvLevMarq loop.
+// cv::findHomography(method 0) for the planar branch: the lane functions the device block is built from
+// (sm::homography_kernel, the eigen solvers) driven by the sequential LMSolver loop
+static void hh_homography_lsq(const float* M, const float* m, int n, double* H) {
+    if (!sm::homography_kernel(M, m, n, H)) {
+        for (int i = 0; i < 9; i++) H[i] = 0;
+        return;
+    }
+    if (n <= 4) return;
+    const int lx = 8, rows = 2 * n;
+    double x[8], xd[8], d[8], v[8], A[64], Ap[64], D[8];
+    double* r = new double[rows];
+    double* rd = new double[rows];
+    double* J = new double[(size_t)rows * 8];
+    auto compute = [&](const double* h, double* err, double* Jo) {
+        for (int i = 0; i < n; i++) {
+            const double Mx = M[i * 2], My = M[i * 2 + 1];
+            double ww = h[6] * Mx + h[7] * My + 1.;
+            ww = fabs(ww) > DBL_EPSILON ? 1. / ww : 0;
+            const double xi = (h[0] * Mx + h[1] * My + h[2]) * ww, yi = (h[3] * Mx + h[4] * My + h[5]) * ww;
+            err[i * 2] = xi - m[i * 2];
+            err[i * 2 + 1] = yi - m[i * 2 + 1];
+            if (Jo) {
+                double* Jp = Jo + (size_t)i * 16;
+                Jp[0] = Mx * ww; Jp[1] = My * ww; Jp[2] = ww; Jp[3] = Jp[4] = Jp[5] = 0.; Jp[6] = -Mx * ww * xi; Jp[7] = -My * ww * xi;
+                Jp[8] = Jp[9] = Jp[10] = 0.; Jp[11] = Mx * ww; Jp[12] = My * ww; Jp[13] = ww; Jp[14] = -Mx * ww * yi; Jp[15] = -My * ww * yi;
+            }
+        }
+    };
+    auto nsq = [](const double* a, int cnt) {
+        double s = 0;
+        int i = 0;
+        for (; i <= cnt - 4; i += 4) s += a[i] * a[i] + a[i + 1] * a[i + 1] + a[i + 2] * a[i + 2] + a[i + 3] * a[i + 3];
+        for (; i < cnt; i++) s += a[i] * a[i];
+        return s;
+    };
+    auto dot8 = [](const double* a, const double* b) {
+        double q = 0;
+        q += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+        q += a[4] * b[4] + a[5] * b[5] + a[6] * b[6] + a[7] * b[7];
+        return q;
+    };
+    auto normal = [&]() {
+        for (int i = 0; i < lx; i++)
+            for (int j = i; j < lx; j++) {
+                double q = 0;
+                for (int k = 0; k < rows; k++) q += J[(size_t)k * lx + i] * J[(size_t)k * lx + j];
+                A[i * lx + j] = A[j * lx + i] = q;
+            }
+        for (int i = 0; i < lx; i++) {
+            double q = 0;
+            for (int k = 0; k < rows; k++) q += J[(size_t)k * lx + i] * r[k];
+            v[i] = q;
+        }
+    };
+    for (int i = 0; i < 8; i++) x[i] = H[i];
+    compute(x, r, J);
+    double S = nsq(r, rows);
+    normal();
+    for (int i = 0; i < lx; i++) D[i] = A[i * lx + i];
+    double lambda = 1, lc = 0.75;
+    int iter = 0;
+    for (;;) {
+        for (int i = 0; i < 64; i++) Ap[i] = A[i];
+        for (int i = 0; i < lx; i++) Ap[i * lx + i] += lambda * D[i];
+        sm::solve_eig<8>(Ap, v, d);
+        for (int i = 0; i < lx; i++) xd[i] = x[i] - d[i];
+        compute(xd, rd, nullptr);
+        const double Sd = nsq(rd, rows);
+        double temp_d[8];
+        for (int i = 0; i < lx; i++) {
+            double q = 0;
+            for (int k = 0; k < lx; k++) q += A[i * lx + k] * d[k];
+            temp_d[i] = q * -1. + v[i] * 2.;
+        }
+        const double dS = dot8(d, temp_d);
+        const double Rr = (S - Sd) / (fabs(dS) > DBL_EPSILON ? dS : 1);
+        if (Rr > 0.75) {
+            lambda *= 0.5;
+            if (lambda < lc) lambda = 0;
+        } else if (Rr < 0.25) {
+            const double tq = dot8(d, v);
+            double nu = (Sd - S) / (fabs(tq) > DBL_EPSILON ? tq : 1) + 2;
+            nu = nu > 2. ? nu : 2.;
+            nu = nu < 10. ? nu : 10.;
+            if (lambda == 0) {
+                sm::invert_eig<8>(A, Ap);
+                double maxval = DBL_EPSILON;
+                for (int i = 0; i < lx; i++) maxval = maxval > fabs(Ap[i * lx + i]) ? maxval : fabs(Ap[i * lx + i]);
+                lambda = lc = 1. / maxval;
+                nu *= 0.5;
+            }
+            lambda *= nu;
+        }
+        if (Sd < S) {
+            S = Sd;
+            for (int i = 0; i < 8; i++) {
+                const double tx = x[i];
+                x[i] = xd[i];
+                xd[i] = tx;
+            }
+            compute(x, r, J);
+            normal();
+        }
+        iter++;
+        double dinf = 0, rinf = 0;
+        for (int i = 0; i < lx; i++) dinf = dinf > fabs(d[i]) ? dinf : fabs(d[i]);
+        for (int i = 0; i < rows; i++) rinf = rinf > fabs(r[i]) ? rinf : fabs(r[i]);
+        if (!(iter < 10 && dinf >= FLT_EPSILON && rinf >= FLT_EPSILON)) break;
+    }
+    for (int i = 0; i < 8; i++) H[i] = x[i];
+    delete[] r;
+    delete[] rd;
+    delete[] J;
+}
+
 int hh_find_extrinsic(const double* M, const double* m, int n, const double* K4, double* rvec, double* tvec) {
     const double ifx = 1. / K4[0], ify = 1. / K4[1];
     double Mc[3] = {0, 0, 0};
@@ -70,8 +187,62 @@ int hh_find_extrinsic(const double* M, const double* m, int n, const double* K4,
             MM[i * 3 + j] = MM[j * 3 + i] = s;
         }
     sm::svd_square_t<3>(MM, W, ut, V);
-    if (W[2] / W[1] < 1e-3 || n < 4) return -2;
+    const bool planar = W[2] / W[1] < 1e-3 || n < 4;
+    double param[6], ws[sm::PNP_DLT_WS];
+    if (planar) {  // cvFindExtrinsicCameraParams2's planar initialisation, as k_pnp_refine does it
+        double Rt[9];
+        for (int i = 0; i < 9; i++) Rt[i] = V[i];
+        if (V[2] * V[2] + V[5] * V[5] < 1e-10) {
+            for (int i = 0; i < 9; i++) Rt[i] = 0.;
+            Rt[0] = Rt[4] = Rt[8] = 1.;
+        }
+        if (sm::det3(Rt) < 0)
+            for (int i = 0; i < 9; i++) Rt[i] *= -1.;
+        double Tt[3];
+        for (int i = 0; i < 3; i++) Tt[i] = (Rt[i * 3] * Mc[0] + Rt[i * 3 + 1] * Mc[1] + Rt[i * 3 + 2] * Mc[2]) * -1.;
+        float* Mf = new float[2 * n];
+        float* mf = new float[2 * n];
+        for (int i = 0; i < n; i++) {
+            const double X = M[i * 3], Y = M[i * 3 + 1], Z = M[i * 3 + 2];
+            Mf[i * 2] = (float)(Rt[0] * X + Rt[1] * Y + Rt[2] * Z + Tt[0]);
+            Mf[i * 2 + 1] = (float)(Rt[3] * X + Rt[4] * Y + Rt[5] * Z + Tt[1]);
+            mf[i * 2] = (float)((m[i * 2] - K4[2]) * ifx);
+            mf[i * 2 + 1] = (float)((m[i * 2 + 1] - K4[3]) * ify);
+        }
+        double h[9];
+        hh_homography_lsq(Mf, mf, n, h);
+        delete[] Mf;
+        delete[] mf;
+        bool finite = true;
+        for (int i = 0; i < 9; i++) finite = finite && std::isfinite(h[i]);
+        double Rm[9], tt[3] = {0., 0., 0.};
+        if (finite) {
+            const double h1n = sqrt(h[0] * h[0] + h[3] * h[3] + h[6] * h[6]), h2n = sqrt(h[1] * h[1] + h[4] * h[4] + h[7] * h[7]);
+            const double s1 = 1. / (h1n > DBL_EPSILON ? h1n : DBL_EPSILON), s2 = 1. / (h2n > DBL_EPSILON ? h2n : DBL_EPSILON);
+            const double s3 = 2. / (h1n + h2n > DBL_EPSILON ? h1n + h2n : DBL_EPSILON);
+            for (int i = 0; i < 3; i++) {
+                h[i * 3] *= s1;
+                h[i * 3 + 1] *= s2;
+                tt[i] = h[i * 3 + 2] * s3;
+            }
+            h[2] = h[3] * h[7] - h[6] * h[4];
+            h[5] = h[6] * h[1] - h[0] * h[7];
+            h[8] = h[0] * h[4] - h[3] * h[1];
+            double r3[3], Hr[9];
+            sm::rodrigues_m2v(h, r3, ws);
+            sm::rodrigues_v2m(r3, Hr, nullptr);
+            for (int i = 0; i < 3; i++) tt[i] = (Hr[i * 3] * Tt[0] + Hr[i * 3 + 1] * Tt[1] + Hr[i * 3 + 2] * Tt[2]) + tt[i];
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 3; j++) Rm[i * 3 + j] = Hr[i * 3] * Rt[j] + Hr[i * 3 + 1] * Rt[3 + j] + Hr[i * 3 + 2] * Rt[6 + j];
+        } else {
+            for (int i = 0; i < 9; i++) Rm[i] = 0.;
+            Rm[0] = Rm[4] = Rm[8] = 1.;
+        }
+        sm::rodrigues_m2v(Rm, param, ws);
+        for (int i = 0; i < 3; i++) param[3 + i] = tt[i];
+    }
     double LL[144];
+    if (!planar) {
     for (int a = 0; a < 12; a++)
         for (int b = a; b < 12; b++) {
             double s = 0;
@@ -87,8 +258,8 @@ int hh_find_extrinsic(const double* M, const double* m, int n, const double* K4,
             }
             LL[a * 12 + b] = LL[b * 12 + a] = s;
         }
-    double param[6], ws[sm::PNP_DLT_WS];
     sm::pnp_dlt_finish(LL, param, ws);
+    }
     double JtJ[36], JtErr[6], prev[6], lmws[sm::PNP_LM_WS];
     double prevErrNorm = DBL_MAX, errNorm = 0;
     int lambdaLg10 = -3, iters = 0;

@@ -48,6 +48,23 @@ def test_oracle_equals_opencv_343_on_the_dumped_cases():
         assert np.abs(rvec.ravel() - fx[p + "pnp_rvec"].ravel()).max() <= 1e-9
         assert np.abs(tvec.ravel() - fx[p + "pnp_tvec"].ravel()).max() <= 1e-9
         assert np.abs(cv2.Rodrigues(fx[p + "pnp_rvec"])[0] - fx[p + "rod"]).max() <= 1e-12
+    for pi in range(int(fx["n_planar"]) if "n_planar" in fx.files else 0):  # coplanar object points: the homography initialisation
+        p = "p%d_" % pi
+        X, x2, K = fx[p + "X"], fx[p + "x2"], fx[p + "K"]
+        ok, rvec, tvec, inl = cv2.solvePnPRansac(objectPoints=X, imagePoints=x2, cameraMatrix=K, distCoeffs=None,
+                                                 iterationsCount=100, reprojectionError=1)
+        assert bool(ok) == bool(fx[p + "pnp_ok"])
+        assert np.array_equal(np.asarray(inl).ravel(), fx[p + "pnp_inliers"].ravel()), "planar case %d: solvePnPRansac inliers" % pi
+        assert np.abs(rvec.ravel() - fx[p + "pnp_rvec"].ravel()).max() <= 1e-9
+        assert np.abs(tvec.ravel() - fx[p + "pnp_tvec"].ravel()).max() <= 1e-9
+    if "five_idx" in fx.files:  # count == modelPoints: the five-point kernel's FIRST model, on 40 five-tuples of case 0
+        x1, x2, K = fx["c0_x1"], fx["c0_x2"], fx["c0_K"]
+        for ti, idx in enumerate(fx["five_idx"]):
+            E5, _ = cv2.findEssentialMat(x2[idx], x1[idx], focal=K[0, 0], pp=(K[0, 2], K[1, 2]), method=cv2.RANSAC, prob=0.99, threshold=0.2)
+            want = fx["five_E_%d" % ti]
+            assert (E5 is None or E5.size == 0) == (want.size == 0), "five-tuple %d: model count" % ti
+            if want.size:
+                assert np.abs(np.asarray(E5)[:3] - want[:3]).max() <= 1e-9, "five-tuple %d: first essential matrix" % ti
     for ri in range(int(fx["n_resize"]) if "n_resize" in fx.files else 0):
         seed, h, w, oh, ow = [int(v) for v in fx["r%d_spec" % ri]]
         img = fx["r%d_img" % ri]

@@ -131,18 +131,27 @@ def test_lane_refinement_flow_matches_oracle(hh, cv3):
         assert rc_h == rc_o == 1
         assert np.array_equal(r_h, r_o) and np.array_equal(t_h, t_o)  # bit-exact
         assert np.abs(r_o - rv).max() < 2e-3 and np.abs(t_o - t).max() < 3e-2
-    # coplanar object points take the (unimplemented) planar branch on both sides
-    X, uv, rv, t, out = scene(14, n=50, outliers=0.0)
-    X[:, 2] = 10.0
-    r_h, t_h = np.zeros(3), np.zeros(3)
-    assert hh.hh_find_extrinsic(_p(X), _p(np.ascontiguousarray(uv)), 50, _p(K4), _p(r_h), _p(t_h)) == -2
-    assert cv3.cv3_find_extrinsic(_p(X), _p(np.ascontiguousarray(uv)), 50, _p(K), _p(r_h), _p(t_h), None) == -2
+    # coplanar object points: cvFindExtrinsicCameraParams2's planar initialisation (homography of the in-plane coordinates),
+    # lane functions vs oracle bit for bit, and the pose is the true one (the points really lie on a plane; uv is their image)
+    for seed, tilt in ((14, 0.0), (15, 0.3)):
+        X, uv, rv, t, out = scene(seed, n=200, outliers=0.0, noise=0.2)
+        X[:, 2] = 10.0 + tilt * X[:, 0]
+        R0 = cv2_shim.Rodrigues(rv)[0]
+        Xc = X @ R0.T + t
+        uv = Xc[:, :2] / Xc[:, 2:] * [K[0, 0], K[1, 1]] + [K[0, 2], K[1, 2]]
+        Xd = np.ascontiguousarray(X.astype(np.float32).astype(np.float64))
+        ud = np.ascontiguousarray(uv.astype(np.float32).astype(np.float64))
+        r_h, t_h, r_o, t_o = np.zeros(3), np.zeros(3), np.zeros(3), np.zeros(3)
+        assert hh.hh_find_extrinsic(_p(Xd), _p(ud), len(Xd), _p(K4), _p(r_h), _p(t_h)) == 1
+        assert cv3.cv3_find_extrinsic(_p(Xd), _p(ud), len(Xd), _p(K), _p(r_o), _p(t_o), None) == 1
+        assert np.array_equal(r_h, r_o) and np.array_equal(t_h, t_o)  # bit-exact
+        assert np.abs(r_o - rv).max() < 1e-4 and np.abs(t_o - t).max() < 1e-3
 
 
 def test_oracle_solve_pnp_ransac_on_coplanar_points_reaches_the_reprojection_minimum():
-    """object points on one plane: cvFindExtrinsicCameraParams2's planar branch.  The restatement starts the LM from the
-    RANSAC model there (cv3_find_extrinsic_guess) instead of OpenCV's homography initialisation; the answer must be the
-    reprojection-error minimum over the inliers (scipy, independent)."""
+    """object points on one plane: cvFindExtrinsicCameraParams2's planar branch (round 3: OpenCV's homography
+    initialisation restated; rounds 1-2 started the LM from the RANSAC model).  The answer must be the reprojection-error
+    minimum over the inliers (scipy, independent)."""
     from scipy.optimize import least_squares
     rng = np.random.default_rng(8)
     n = 400

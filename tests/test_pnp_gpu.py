@@ -167,20 +167,17 @@ def planar_case(seed, h=376, w=1241, n=1200, relief=0.02):
 
 @pytest.mark.parametrize("seed", [51, 52])
 def test_compute_pose_3d2d_coplanar_object_points(gpu, trk, seed):
-    """the planar case no longer aborts: the refinement starts from the accepted RANSAC model on both sides (documented
-    deviation from OpenCV's homography initialisation, oracle/cv3_pnp.c cv3_find_extrinsic_guess) -- device == oracle to
-    1e-8, and the pose is the right one"""
+    """the planar case: cvFindExtrinsicCameraParams2's homography initialisation (round 3: restated on both sides --
+    oracle/cv3_pnp.c cv3_find_extrinsic_guess, k_pnp_refine) -- device == oracle BIT FOR BIT (the refinement no longer
+    consumes the RANSAC model's last bits, only its inlier mask), and the pose is the right one"""
     kp1, kp2, depth, R_true, t_true = planar_case(seed)
     np.random.seed(99 + seed)
     out, keep, state_after = run_hip(gpu, trk, kp1, kp2, depth)
     np.random.seed(99 + seed)
     ref = T.compute_pose_3d2d(kp1, kp2, depth, K, 0.0, 50.0, 5, 100, 1.0)
     assert out.found == 1 and out.status != -2 and out.best_inliers == ref["best_inlier"] > 400
-    # the consensus set and the RandomState are bit-exact; the refined pose agrees to 1e-8 (contract: 1e-4 Frobenius) but
-    # not bit for bit: the LM starts from the RANSAC MODEL here, whose last bits differ between device and oracle (in
-    # every other path only the model's inlier mask is consumed, which is what the bit-exact tests pin)
-    assert np.abs(np.array(out.R[:]).reshape(3, 3) - ref["R"]).max() <= 1e-8
-    assert np.abs(np.array(out.tvec[:]).reshape(3, 1) - ref["t"]).max() <= 1e-8
+    assert np.array_equal(np.array(out.R[:]).reshape(3, 3), ref["R"])
+    assert np.array_equal(np.array(out.tvec[:]).reshape(3, 1), ref["t"])
     assert np.array_equal(state_after, np_state())
     assert np.abs(ref["R"] - R_true).max() < 2e-3 and np.abs(ref["t"].ravel() - t_true).max() < 5e-2
     # exactly coplanar points: degenerate EPnP hypotheses, a meaningless pose -- but no abort, and the same consensus size

@@ -46,6 +46,29 @@ def two_view(n, out_frac, noise, seed, w=1241, h=376):
 CASES = [(2000, 0.3, 0.15, 31), (2000, 0.6, 0.3, 32), (600, 0.2, 0.1, 33), (2000, 0.97, 0.2, 34), (200, 0.0, 0.05, 35), (40, 0.1, 0.2, 36)]
 
 
+def planar_view(n, seed, tilt, noise=0.2, w=1241, h=376):
+    """object points on one plane (a road / wall seen obliquely): solvePnPRansac's refinement takes
+    cvFindExtrinsicCameraParams2's planar initialisation (W[2] / W[1] < 1e-3)"""
+    r = np.random.Generator(np.random.PCG64(seed))
+    f = 718.856 * w / 1241.0
+    K = np.array([[f, 0, 607.19 * w / 1241.0], [0, f, 185.22 * h / 376.0], [0, 0, 1]])
+    X = np.stack([r.uniform(-15, 15, n), np.full(n, 1.65), r.uniform(6, 45, n)], 1)
+    X[:, 1] += tilt * X[:, 0]
+    wv = np.array([0.003, -0.015, 0.002])
+    th = np.linalg.norm(wv)
+    k = wv / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+    t = np.array([0.04, -0.02, 0.9])
+    X2 = (R @ X.T).T + t
+    x2 = (K @ X2.T).T
+    x2 = x2[:, :2] / x2[:, 2:] + r.normal(0, noise, (n, 2))
+    return np.ascontiguousarray(X), np.ascontiguousarray(x2), K
+
+
+PLANAR_CASES = [(400, 41, 0.0), (400, 42, 0.25), (60, 43, 0.1)]
+
+
 RESIZE_CASES = [(1, 376, 1241, 192, 640), (2, 370, 1226, 192, 640), (3, 96, 128, 48, 64), (4, 60, 80, 130, 210),
                 (5, 480, 640, 256, 320)]
 
@@ -80,6 +103,30 @@ def main(out_path):
         out[p + "pnp_ok"], out[p + "pnp_rvec"], out[p + "pnp_tvec"] = np.array(bool(ok)), rvec, tvec
         out[p + "pnp_inliers"] = inl if inl is not None else np.zeros((0, 1), np.int32)
         out[p + "rod"] = cv2.Rodrigues(rvec)[0]
+    # coplanar object points: the homography initialisation of cvFindExtrinsicCameraParams2 (calibration.cpp) behind
+    # solvePnPRansac (pnp_tracker.py:98-105); and cv2.solvePnP(ITERATIVE) alone on the same points (no RANSAC in front)
+    out["n_planar"] = len(PLANAR_CASES)
+    for pi, (n, seed, tilt) in enumerate(PLANAR_CASES):
+        X, x2, K = planar_view(n, seed, tilt)
+        p = "p%d_" % pi
+        out[p + "X"], out[p + "x2"], out[p + "K"] = X, x2, K
+        ok, rvec, tvec, inl = cv2.solvePnPRansac(objectPoints=X, imagePoints=x2, cameraMatrix=K, distCoeffs=None,
+                                                 iterationsCount=100, reprojectionError=1)
+        out[p + "pnp_ok"], out[p + "pnp_rvec"], out[p + "pnp_tvec"] = np.array(bool(ok)), rvec, tvec
+        out[p + "pnp_inliers"] = inl if inl is not None else np.zeros((0, 1), np.int32)
+        Xf, xf = X.astype(np.float32).astype(np.float64), x2.astype(np.float32).astype(np.float64)
+        ok2, rv2, tv2 = cv2.solvePnP(Xf, xf, K, None, flags=cv2.SOLVEPNP_ITERATIVE)
+        out[p + "it_ok"], out[p + "it_rvec"], out[p + "it_tvec"] = np.array(bool(ok2)), rv2, tv2
+    # five points exactly (count == modelPoints: the registrator returns the kernel's first model) and the five-tuples of
+    # case 0 on which the restated five-point solver leaves the largest constraint residual (tests/test_oracle_opencv_
+    # properties.py): findEssentialMat on those five correspondences alone answers whether OpenCV's solver does the same
+    x1, x2, X, K = two_view(2000, 0.3, 0.15, 31)
+    r5 = np.random.Generator(np.random.PCG64(77))
+    tuples = [r5.choice(2000, 5, replace=False) for _ in range(40)]
+    out["five_idx"] = np.array(tuples)
+    for ti, idx in enumerate(tuples):
+        E5, m5 = cv2.findEssentialMat(x2[idx], x1[idx], focal=K[0, 0], pp=(K[0, 2], K[1, 2]), method=cv2.RANSAC, prob=0.99, threshold=0.2)
+        out["five_E_%d" % ti] = E5 if E5 is not None else np.zeros((0, 3))
     # utils.py:51 (read_image): cv2.resize(img, (w, h)) of the uint8 frame, default INTER_LINEAR; dfvo.py:314-317 nearest
     out["n_resize"] = len(RESIZE_CASES)
     for ri, (seed, h, w, oh, ow) in enumerate(RESIZE_CASES):
