@@ -447,14 +447,16 @@ def main(argv=None):
             feed(j)
         for k in range(n):
             t_a = time.perf_counter()
+            # the RandomState-ordered chain of pair k is enqueued first, the nets of pair k + ahead while it runs
+            if nets_mode:
+                p.track_begin(k % SLOTS)  # no overrides: keypoints / RANSAC / scale / PnP on the nets' own outputs
+            else:
+                f, dd, dp = d_sc[k % len(d_sc)]
+                p.track_begin(k % SLOTS, f, dd, dp)  # E-tracker, or the PnP fallback when its pose is rejected
             if k + ahead < n:
                 feed(k + ahead)
             t_b = time.perf_counter()
-            if nets_mode:
-                out = p.track(k % SLOTS)  # no overrides: keypoints / RANSAC / scale / PnP on the nets' own outputs
-            else:
-                f, dd, dp = d_sc[k % len(d_sc)]
-                out = p.track(k % SLOTS, f, dd, dp)  # E-tracker, or the PnP fallback when its pose is rejected
+            out = p.track_end(k % SLOTS)
             t_c = time.perf_counter()
             t_track.append(t_c)
             host_t[0] += t_b - t_a

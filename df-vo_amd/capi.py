@@ -157,6 +157,8 @@ SIGNATURES = {
     "dfvo_pipeline_set_graph": (_i, [_vp, _i]),
     "dfvo_pipeline_enqueue_nets": (_i, [_vp, _i, _vp, _vp, _vp]),
     "dfvo_pipeline_track": (_i, [_vp, _i, _vp, _vp, _vp, C.POINTER(TrackOut)]),
+    "dfvo_pipeline_track_begin": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "dfvo_pipeline_track_end": (_i, [_vp, _i, C.POINTER(TrackOut)]),
     "dfvo_pipeline_set_ref_depth": (_i, [_vp, _vp, _vp]),
     "dfvo_pipeline_set_ref_image": (_i, [_vp, _vp]),
     "dfvo_pipeline_prefetch_track": (_i, [_vp, _i, _vp, _vp]),

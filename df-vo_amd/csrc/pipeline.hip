@@ -36,6 +36,11 @@ struct dfvo_pipeline {
     hipEvent_t e_ref = nullptr;  // reference depth of the first frame written (dfvo_pipeline_set_ref_image / _set_ref_depth)
     int* h_info[DFVO_PIPELINE_SLOTS] = {};
     bool prefetched[DFVO_PIPELINE_SLOTS] = {};
+    // dfvo_pipeline_track_begin / _end: results of the RandomState-ordered chain land in pinned host memory behind e_res
+    void* h_res[DFVO_PIPELINE_SLOTS] = {};   // PoseState | ScaleResult
+    hipEvent_t e_res[DFVO_PIPELINE_SLOTS] = {};
+    int begun_n[DFVO_PIPELINE_SLOTS] = {};   // -1: no chain pending, -2: pending pair had no good keypoints, else keypoint count
+    const double* begun_depth_override[DFVO_PIPELINE_SLOTS] = {};
     hipStream_t s_flow = nullptr, s_depth = nullptr, s_trk = nullptr;
     hipEvent_t e_flow[DFVO_PIPELINE_SLOTS] = {}, e_depth[DFVO_PIPELINE_SLOTS] = {};
     // per-slot outputs of the nets
@@ -179,8 +184,11 @@ int dfvo_pipeline_create(const dfvo_pipeline_cfg* cfg, dfvo_pipeline** out) {
     }
     for (int i = 0; i < DFVO_PIPELINE_SLOTS; i++) {
         if (hipEventCreateWithFlags(&p->e_pre[i], hipEventDisableTiming) != hipSuccess ||
-            hipHostMalloc((void**)&p->h_info[i], 4 * sizeof(int), hipHostMallocDefault) != hipSuccess)
+            hipEventCreateWithFlags(&p->e_res[i], hipEventDisableTiming) != hipSuccess ||
+            hipHostMalloc((void**)&p->h_info[i], 4 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void**)&p->h_res[i], sizeof(PoseState) + sizeof(ScaleResult), hipHostMallocDefault) != hipSuccess)
             return fail(DFVO_ERR_HIP);
+        p->begun_n[i] = -1;
     }
     const size_t px = (size_t)p->H * p->W;
     for (int i = 0; i < DFVO_PIPELINE_SLOTS; i++) {
@@ -225,6 +233,8 @@ void dfvo_pipeline_destroy(dfvo_pipeline* p) {
         if (p->s_pre[i]) (void)hipStreamDestroy(p->s_pre[i]);
     for (int i = 0; i < DFVO_PIPELINE_SLOTS; i++) {
         if (p->e_pre[i]) (void)hipEventDestroy(p->e_pre[i]);
+        if (p->e_res[i]) (void)hipEventDestroy(p->e_res[i]);
+        if (p->h_res[i]) (void)hipHostFree(p->h_res[i]);
         if (i == 0 && p->e_ref) (void)hipEventDestroy(p->e_ref);
         if (p->h_info[i]) (void)hipHostFree(p->h_info[i]);
     }
@@ -405,36 +415,27 @@ int dfvo_pipeline_prefetch_track(dfvo_pipeline* p, int slot, const float* d_flow
     return DFVO_OK;
 }
 
-int dfvo_pipeline_track(dfvo_pipeline* p, int slot, const float* d_flow_override, const float* d_diff_override,
-                        const double* d_depth_override, dfvo_track_out* out) {
-    DFVO_ARG_CHECK(p && out && (slot >= 0 && slot < DFVO_PIPELINE_SLOTS), "dfvo_pipeline_track: bad argument");
+// First half of dfvo_pipeline_track: waits for the slot's keypoint stage, enqueues the RandomState-ordered chain (shuffles,
+// 5 x five-point RANSAC, GRIC, recoverPose, scale recovery) and the copy of its results into pinned host memory, returns.
+// The host is then free to enqueue the next pairs' nets while the chain runs (dfvo_pipeline_track_end collects).
+int dfvo_pipeline_track_begin(dfvo_pipeline* p, int slot, const float* d_flow_override, const float* d_diff_override,
+                              const double* d_depth_override) {
+    DFVO_ARG_CHECK(p && (slot >= 0 && slot < DFVO_PIPELINE_SLOTS), "dfvo_pipeline_track_begin: bad argument");
+    DFVO_ARG_CHECK(p->begun_n[slot] == -1, "dfvo_pipeline_track_begin: the slot's previous pair was not collected (track_end)");
     const dfvo_pipeline_cfg& c = p->cfg;
     hipStream_t s = p->s_trk;
     TrackerBuffers& tb = p->tbs[slot];
-    static const bool trace = getenv("DFVO_TRACK_TRACE") != nullptr;  // host-side phase timing (tuning aid)
-    static double tr_acc[4] = {0, 0, 0, 0}, tr_dev[3] = {0, 0, 0};
-    static int tr_dev_n = 0;
+    static const bool trace = getenv("DFVO_TRACK_TRACE") != nullptr;
     if (trace && !tb.ev_t[0])
         for (int i = 0; i < 4; i++) DFVO_HIP_CHECK(hipEventCreate(&tb.ev_t[i]));
-    static int tr_n = 0;
-    const auto tr0 = std::chrono::steady_clock::now();
-    auto tr_ms = [&](std::chrono::steady_clock::time_point a) {
-        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
-    };
-    memset(out, 0, sizeof(*out));
-    for (int i = 0; i < 3; i++) out->R[i * 4] = 1.0;
     P_TRY(enqueue_scale_prepare(tb, p->H, p->W));  // side stream: the scale stage's fills leave the dependent chain
     if (!p->prefetched[slot]) P_TRY(enqueue_pre_part(p, slot, d_flow_override, d_diff_override, p->s_pre[slot & 1]));
     p->prefetched[slot] = false;
     DFVO_HIP_CHECK(hipEventSynchronize(p->e_pre[slot]));  // keypoint info is in pinned host memory now
     const int* info = p->h_info[slot];
-    const double tr_kp = tr_ms(tr0);
-    out->n_kp = info[0];
-    out->good_kp_found = info[1];
+    p->begun_depth_override[slot] = d_depth_override;
     if (!info[1]) {
-        out->status = DFVO_TRACK_CONSTANT_MOTION;
-        P_TRY(roll_ref_depth(p, slot, d_depth_override));
-        DFVO_HIP_CHECK(hipStreamSynchronize(s));
+        p->begun_n[slot] = -2;
         return DFVO_OK;
     }
     const int n = info[0];
@@ -454,12 +455,50 @@ int dfvo_pipeline_track(dfvo_pipeline* p, int slot, const float* d_flow_override
     const double* depth = d_depth_override ? d_depth_override : p->proc_depth[slot];
     P_TRY(enqueue_find_scale(tb, n, p->d_T21, depth, p->H, p->W, sc, s, tb.pose, true));
     if (tb.ev_t[3]) DFVO_HIP_CHECK(hipEventRecord(tb.ev_t[3], s));
-    const double tr_enq = tr_ms(tr0);
+    char* hr = (char*)p->h_res[slot];
+    DFVO_HIP_CHECK(hipMemcpyAsync(hr, tb.pose, sizeof(PoseState), hipMemcpyDeviceToHost, s));
+    DFVO_HIP_CHECK(hipMemcpyAsync(hr + sizeof(PoseState), tb.scale_out, sizeof(ScaleResult), hipMemcpyDeviceToHost, s));
+    DFVO_HIP_CHECK(hipEventRecord(p->e_res[slot], s));
+    p->begun_n[slot] = n;
+    return DFVO_OK;
+}
+
+// Second half: waits for the chain's results, runs the PnP fallback where the reference takes it (dfvo.py:225-250; decided
+// on the host, so the NEXT pair's chain must not be begun before this returns -- it consumes the same RandomState), rolls
+// the reference depth over.
+int dfvo_pipeline_track_end(dfvo_pipeline* p, int slot, dfvo_track_out* out) {
+    DFVO_ARG_CHECK(p && out && (slot >= 0 && slot < DFVO_PIPELINE_SLOTS), "dfvo_pipeline_track_end: bad argument");
+    DFVO_ARG_CHECK(p->begun_n[slot] != -1, "dfvo_pipeline_track_end: no pair pending in this slot (track_begin)");
+    const dfvo_pipeline_cfg& c = p->cfg;
+    hipStream_t s = p->s_trk;
+    TrackerBuffers& tb = p->tbs[slot];
+    static const bool trace = getenv("DFVO_TRACK_TRACE") != nullptr;  // host-side phase timing (tuning aid)
+    static double tr_acc[2] = {0, 0}, tr_dev[3] = {0, 0, 0};
+    static int tr_dev_n = 0, tr_n = 0;
+    const auto tr0 = std::chrono::steady_clock::now();
+    auto tr_ms = [&](std::chrono::steady_clock::time_point a) {
+        return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - a).count();
+    };
+    const int n = p->begun_n[slot];
+    const double* d_depth_override = p->begun_depth_override[slot];
+    p->begun_n[slot] = -1;
+    memset(out, 0, sizeof(*out));
+    for (int i = 0; i < 3; i++) out->R[i * 4] = 1.0;
+    const int* info = p->h_info[slot];
+    out->n_kp = info[0];
+    out->good_kp_found = info[1];
+    if (n == -2) {
+        out->status = DFVO_TRACK_CONSTANT_MOTION;
+        P_TRY(roll_ref_depth(p, slot, d_depth_override));
+        DFVO_HIP_CHECK(hipStreamSynchronize(s));
+        return DFVO_OK;
+    }
+    DFVO_HIP_CHECK(hipEventSynchronize(p->e_res[slot]));
+    const double tr_wait = tr_ms(tr0);
     PoseState ps;
     ScaleResult sr;
-    DFVO_HIP_CHECK(hipMemcpyAsync(&ps, tb.pose, sizeof(ps), hipMemcpyDeviceToHost, s));
-    DFVO_HIP_CHECK(hipMemcpyAsync(&sr, tb.scale_out, sizeof(sr), hipMemcpyDeviceToHost, s));
-    DFVO_HIP_CHECK(hipStreamSynchronize(s));
+    memcpy(&ps, p->h_res[slot], sizeof(ps));
+    memcpy(&sr, (const char*)p->h_res[slot] + sizeof(PoseState), sizeof(sr));
     for (int i = 0; i < 9; i++) out->R[i] = ps.R[i];
     for (int i = 0; i < 3; i++) out->t[i] = ps.t[i];
     out->best_inlier_cnt = ps.best_cnt;
@@ -489,8 +528,7 @@ int dfvo_pipeline_track(dfvo_pipeline* p, int slot, const float* d_flow_override
             PnpResult pr;
             DFVO_HIP_CHECK(hipMemcpyAsync(&pr, p->pnp.result, sizeof(pr), hipMemcpyDeviceToHost, s));
             DFVO_HIP_CHECK(hipStreamSynchronize(s));
-            DFVO_ARG_CHECK(pr.status != -2, "dfvo_pipeline_track: PnP met coplanar object points (planar initialisation "
-                                            "of cvFindExtrinsicCameraParams2 is not implemented)");
+            DFVO_ARG_CHECK(pr.status >= 0, "dfvo_pipeline_track: the PnP fallback reported an internal error");
             for (int i = 0; i < 9; i++) out->R[i] = pr.R[i];
             for (int i = 0; i < 3; i++) out->t[i] = pr.tvec[i];
             out->scale = 1.0;
@@ -502,8 +540,8 @@ int dfvo_pipeline_track(dfvo_pipeline* p, int slot, const float* d_flow_override
     } else {
         out->status = DFVO_TRACK_E;
     }
+    // the roll-over copy is ordered on s_trk ahead of anything the next pair enqueues there: no host wait needed
     P_TRY(roll_ref_depth(p, slot, d_depth_override));
-    DFVO_HIP_CHECK(hipStreamSynchronize(s));
     if (trace) {
         float d01 = 0, d12 = 0, d23 = 0;  // device time of the chain's three segments (valid when the pair took the E path)
         if (n > 10 && hipEventElapsedTime(&d01, tb.ev_t[0], tb.ev_t[1]) == hipSuccess &&
@@ -520,15 +558,22 @@ int dfvo_pipeline_track(dfvo_pipeline* p, int slot, const float* d_flow_override
             tr_dev[0] = tr_dev[1] = tr_dev[2] = 0;
             tr_dev_n = 0;
         }
-        tr_acc[0] += tr_kp;
-        tr_acc[1] += tr_enq;
-        tr_acc[2] += tr_ms(tr0);
+        tr_acc[0] += tr_wait;
+        tr_acc[1] += tr_ms(tr0);
         if (++tr_n % 20 == 0) {
-            fprintf(stderr, "track host ms: kp stage done %.3f | all enqueued %.3f | total %.3f\n", tr_acc[0] / 20, tr_acc[1] / 20,
-                    tr_acc[2] / 20);
-            tr_acc[0] = tr_acc[1] = tr_acc[2] = 0;
+            fprintf(stderr, "track_end host ms: waited for the chain %.3f | total %.3f\n", tr_acc[0] / 20, tr_acc[1] / 20);
+            tr_acc[0] = tr_acc[1] = 0;
         }
     }
+    return DFVO_OK;
+}
+
+int dfvo_pipeline_track(dfvo_pipeline* p, int slot, const float* d_flow_override, const float* d_diff_override,
+                        const double* d_depth_override, dfvo_track_out* out) {
+    DFVO_ARG_CHECK(p && out && (slot >= 0 && slot < DFVO_PIPELINE_SLOTS), "dfvo_pipeline_track: bad argument");
+    P_TRY(dfvo_pipeline_track_begin(p, slot, d_flow_override, d_diff_override, d_depth_override));
+    P_TRY(dfvo_pipeline_track_end(p, slot, out));
+    DFVO_HIP_CHECK(hipStreamSynchronize(p->s_trk));  // (synchronous, as documented: the roll-over copy included)
     return DFVO_OK;
 }
 

@@ -93,6 +93,17 @@ class TrackingPipeline:
         capi.check(self.lib.dfvo_pipeline_track(self.h, slot, p(flow), p(diff), p(depth), C.byref(out)))
         return out
 
+    def track_begin(self, slot, flow=None, diff=None, depth=None):
+        """first half of track(): enqueues the RandomState-ordered chain of `slot` and returns; the host can feed the nets of
+        the pairs ahead while it runs.  Pair k + 1 must not be begun before track_end(k) returned."""
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        capi.check(self.lib.dfvo_pipeline_track_begin(self.h, slot, p(flow), p(diff), p(depth)))
+
+    def track_end(self, slot):
+        out = capi.TrackOut()
+        capi.check(self.lib.dfvo_pipeline_track_end(self.h, slot, C.byref(out)))
+        return out
+
     def set_ref_depth(self, d_feed=None, depth=None):
         """depth of the first reference frame: the uint8 feed image (runs the depth net) or a processed depth map"""
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None

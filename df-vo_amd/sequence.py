@@ -40,12 +40,13 @@ def track_chunk(pipe, frames, lo, hi, seed=4869, rng_mode="sequential", ahead=3,
         pipe.prefetch_track(j % SLOTS)
     prev = np.eye(4)
     for j in range(lo, hi):
+        if rng_mode == "per_pair":
+            pipe.seed((seed ^ (j + 1)) & 0xffffffff)
+        pipe.track_begin(j % SLOTS)  # the chain of pair j runs while the host feeds the nets of pair j + ahead
         if j + ahead < hi:
             pipe.enqueue_nets((j + ahead) % SLOTS, frames[j + ahead], frames[j + ahead + 1])
             pipe.prefetch_track((j + ahead) % SLOTS)
-        if rng_mode == "per_pair":
-            pipe.seed((seed ^ (j + 1)) & 0xffffffff)
-        out = pipe.track(j % SLOTS)
+        out = pipe.track_end(j % SLOTS)
         status[j - lo] = out.status
         if out.status != 1:
             rel[j - lo], _ = TrackingPipeline.hybrid_pose(out, prev)

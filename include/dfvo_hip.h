@@ -406,6 +406,14 @@ int dfvo_pipeline_prefetch_track(dfvo_pipeline* p, int slot, const float* d_flow
  * map [H,W] / processed depth [H,W] double that feed the solver stage (used by bench.py). Synchronous. */
 int dfvo_pipeline_track(dfvo_pipeline* p, int slot, const float* d_flow_override, const float* d_diff_override,
                         const double* d_depth_override, dfvo_track_out* out);
+/* The same in two halves, so that the host can enqueue the nets of the pairs ahead while the chain of this pair runs:
+ * _begin waits for the slot's keypoint stage and enqueues the RandomState-ordered chain + the copy of its results into
+ * pinned host memory; _end waits for them, runs the PnP fallback where the reference takes it and rolls the reference
+ * depth over.  Pairs must be begun and ended in order, and pair k + 1 must not be begun before pair k was ended (the PnP
+ * fallback of pair k consumes the RandomState ahead of pair k + 1's shuffles).  dfvo_pipeline_track = _begin + _end. */
+int dfvo_pipeline_track_begin(dfvo_pipeline* p, int slot, const float* d_flow_override, const float* d_diff_override,
+                              const double* d_depth_override);
+int dfvo_pipeline_track_end(dfvo_pipeline* p, int slot, dfvo_track_out* out);
 int dfvo_pipeline_get_flow(dfvo_pipeline* p, int slot, float* h_fwd, float* h_bwd, float* h_diff, float* h_raw_depth,
                            double* h_depth);
 /* inspection (tests, debugging): keypoints selected for `slot` (kp_best of ref / cur, double [n][2], x,y), the E-tracker's

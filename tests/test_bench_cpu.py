@@ -56,6 +56,12 @@ class StubPipeline:
         self.k += 1
         return _Out(self.k, self.seed_)
 
+    def track_begin(self, slot, *a):
+        self.k += 1
+
+    def track_end(self, slot):
+        return _Out(self.k, self.seed_)
+
     def sync(self):
         pass
 

@@ -139,6 +139,13 @@ class _StubPipe:
         o.scale = float(rng.uniform(0.5, 1.5))
         return o
 
+    def track_begin(self, slot, *a):  # (the result of a pair is fixed by what is in force when its chain is enqueued)
+        self.pending = getattr(self, "pending", {})
+        self.pending[slot] = self.track(slot)
+
+    def track_end(self, slot):
+        return self.pending.pop(slot)
+
     def sync(self):
         pass
 
