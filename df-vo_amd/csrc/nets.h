@@ -103,18 +103,28 @@ struct FlowNet {
     DevBuf splitk;          // split-K partial sums of the small-grid convs (own buffer: the nets run on separate streams)
     DevBuf out_fwd, out_bwd, out_diff;
     double flops_last = 0.0;  // useful conv+corr FLOPs of the last forward (2*MAC)
-    hipGraph_t graph = nullptr;
+    // ... of its parts: Features on both frames / on the current frame alone (carried mode) / everything behind them
+    double flops_feat2 = 0.0, flops_feat1 = 0.0, flops_levels = 0.0;
+    hipGraph_t graph = nullptr;            // the levels
     hipGraphExec_t graph_exec = nullptr;
     float *graph_fwd = nullptr, *graph_bwd = nullptr, *graph_diff = nullptr;
-    const uint8_t *graph_ref = nullptr, *graph_cur = nullptr;
+    hipGraph_t graph_feat[2] = {nullptr, nullptr};  // [0] Features of both frames, [1] carry + Features of the current frame
+    hipGraphExec_t graph_feat_exec[2] = {nullptr, nullptr};
+    const FlowNet* graph_carry_src = nullptr;
+    hipEvent_t e_feat = nullptr;  // recorded behind the feature stage of every pass (the carry source of the next pair)
     bool use_graph = true;
     bool tuned_once = false;
 
     int init(int imgH, int imgW, hipStream_t s);
     int finalize();
-    int forward(const uint8_t* d_ref, const uint8_t* d_cur, float* d_fwd, float* d_bwd, float* d_diff);
+    int forward(const uint8_t* d_ref, const uint8_t* d_cur, float* d_fwd, float* d_bwd, float* d_diff,
+                const FlowNet* carry_from = nullptr);
     int enqueue_input(const uint8_t* d_ref, const uint8_t* d_cur);  // uint8 frames -> level-1 net input (not captured)
-    int enqueue(float* d_fwd, float* d_bwd, float* d_diff);         // everything after that (captured into the graph)
+    int enqueue_features(int n0, int N, double* fl);
+    int enqueue_features_both();
+    int enqueue_carry(const FlowNet& src);
+    int enqueue_levels(float* d_fwd, float* d_bwd, float* d_diff);
+    int enqueue(float* d_fwd, float* d_bwd, float* d_diff);  // Features of both frames + levels
     void destroy();
 };
 

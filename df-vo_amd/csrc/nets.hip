@@ -4,6 +4,8 @@
 // depth/monodepth2/{resnet_encoder.py:87-98, depth_decoder.py:17-65, monodepth2.py:91-139}.
 #include "nets.h"
 
+#include <array>
+#include <mutex>
 #include <cstdlib>
 #include <utility>
 
@@ -172,7 +174,25 @@ void conv_autotune_scope(bool on) {
     g_conv_autotune = on && enabled;
 }
 
+// Tuning results are shared by every layer of the same shape in the process (the two flow-net instances of a pipeline, a
+// second pipeline): the choice is timing-based, and a different K-split changes the summation order -- the instances of
+// one net must not disagree about a layer, or a pair's flow would depend on which instance ran it.
+static std::mutex g_tune_mu;
+static std::map<std::array<int, 15>, std::pair<int, int>> g_tune_cache;
+
 static int autotune_conv(const ConvLayer& L, ConvParams p, hipStream_t s) {
+    const std::array<int, 15> key = {p.N, p.H, p.W, p.G0, p.G1, p.cout, p.kh, p.kw, p.stride, p.pad_h, p.pad_w, p.pad_mode, p.up0, p.act,
+                                       (L.wf ? 1 : 0) | (L.wg ? 2 : 0) | (L.wsp ? 4 : 0) | (L.wh ? 8 : 0)};  // (which kernel families the layer can use)
+    {
+        std::lock_guard<std::mutex> lk(g_tune_mu);
+        auto it = g_tune_cache.find(key);
+        if (it != g_tune_cache.end()) {
+            L.tune_bm = it->second.first;
+            L.tune_splits = it->second.second;
+            L.tuned = true;
+            return DFVO_OK;
+        }
+    }
     const long long M = (long long)p.N * p.Ho * p.Wo;
     const int bn = conv_pick_bn(p.cout, M);
     const int bms128[3] = {128, 64, 32}, bms[3] = {256, 128, 64};
@@ -214,6 +234,10 @@ static int autotune_conv(const ConvLayer& L, ConvParams p, hipStream_t s) {
     L.tune_bm = best_bm;
     L.tune_splits = best_sp;
     L.tuned = true;
+    {
+        std::lock_guard<std::mutex> lk(g_tune_mu);
+        g_tune_cache[key] = {best_bm, best_sp};
+    }
     return DFVO_OK;
 }
 
@@ -533,45 +557,74 @@ int FlowNet::finalize() {
 int FlowNet::enqueue_input(const uint8_t* d_ref, const uint8_t* d_cur) {
     // batch sample 0 = ref, sample 1 = cur: "first" = X[n], "second" = X[1-n]  (lite_flow.py:108-110)
     const size_t img_px = (size_t)H * W;
-    DFVO_TRY(launch_img_u8_to_flow_input(d_ref, imgH, imgW, img[1].p, H, W, stream));
+    if (d_ref) DFVO_TRY(launch_img_u8_to_flow_input(d_ref, imgH, imgW, img[1].p, H, W, stream));
     DFVO_TRY(launch_img_u8_to_flow_input(d_cur, imgH, imgW, img[1].p + img_px * 4, H, W, stream));
     return DFVO_OK;
 }
 
+// image pyramid + Features (lite_flow_net.py:78-86, 307-309) of the batch samples [n0, n0 + N): N = 2 for a pair whose
+// frames are both new, n0 = 1 / N = 1 for the current frame alone when the reference frame's pyramids were carried over
+// from the previous pair (enqueue_carry).  Temporaries borrowed from level-2/3/4 scratch.  (Callers: one frame per call,
+// see enqueue_features_both.)
+int FlowNet::enqueue_features(int n0, int N, double* fl) {
+    hipStream_t s = stream;
+    const View none{nullptr, 0, 0};
+    auto im = [&](int l) { return img[l].p + (size_t)n0 * lh[l] * lw[l] * 4; };
+    auto ft = [&](int l) { return feat[l].p + (size_t)n0 * lh[l] * lw[l] * lc[l]; };
+    for (int l = 2; l <= 6; ++l) DFVO_TRY(launch_resize_bilinear(im(l - 1), N, lh[l - 1], lw[l - 1], 4, im(l), lh[l], lw[l], 0, s));
+    Level& L2 = lv[2];
+    Level& L3 = lv[3];
+    Level& L4 = lv[4];
+    DFVO_TRY(run_conv(feat_convs[0], N, lh[1], lw[1], View{im(1), 4, 0}, 0, none, nullptr, 0, 0, ft(1), 32, 0, 0, s, fl, &splitk));
+    DFVO_TRY(run_conv(feat_convs[1], N, lh[1], lw[1], View{ft(1), 32, 0}, 0, none, nullptr, 0, 0, L2.x32.p, 32, 0, 0, s, fl, &splitk));
+    DFVO_TRY(run_conv(feat_convs[2], N, lh[2], lw[2], View{L2.x32.p, 32, 0}, 0, none, nullptr, 0, 0, L2.x32b.p, 32, 0, 0, s, fl, &splitk));
+    DFVO_TRY(run_conv(feat_convs[3], N, lh[2], lw[2], View{L2.x32b.p, 32, 0}, 0, none, nullptr, 0, 0, ft(2), 32, 0, 0, s, fl, &splitk));
+    DFVO_TRY(run_conv(feat_convs[4], N, lh[2], lw[2], View{ft(2), 32, 0}, 0, none, nullptr, 0, 0, L3.x64.p, 64, 0, 0, s, fl, &splitk));
+    DFVO_TRY(run_conv(feat_convs[5], N, lh[3], lw[3], View{L3.x64.p, 64, 0}, 0, none, nullptr, 0, 0, ft(3), 64, 0, 0, s, fl, &splitk));
+    DFVO_TRY(run_conv(feat_convs[6], N, lh[3], lw[3], View{ft(3), 64, 0}, 0, none, nullptr, 0, 0, L4.x128.p, 96, 0, 0, s, fl, &splitk));
+    DFVO_TRY(run_conv(feat_convs[7], N, lh[4], lw[4], View{L4.x128.p, 96, 0}, 0, none, nullptr, 0, 0, ft(4), 96, 0, 0, s, fl, &splitk));
+    DFVO_TRY(run_conv(feat_convs[8], N, lh[4], lw[4], View{ft(4), 96, 0}, 0, none, nullptr, 0, 0, ft(5), 128, 0, 0, s, fl, &splitk));
+    DFVO_TRY(run_conv(feat_convs[9], N, lh[5], lw[5], View{ft(5), 128, 0}, 0, none, nullptr, 0, 0, ft(6), 192, 0, 0, s, fl, &splitk));
+    return DFVO_OK;
+}
+
+// The reference frame of this pair is the current frame of the pair `src` ran last (src may be this net): its image and
+// feature pyramids (batch sample 1 there) become batch sample 0 here -- 21 MB of device copies instead of 15 GFLOP of
+// convolutions.  The caller orders this stream behind src.e_feat.
+int FlowNet::enqueue_carry(const FlowNet& src) {
+    DFVO_ARG_CHECK(src.H == H && src.W == W && src.finalized, "FlowNet::enqueue_carry: nets of different sizes");
+    for (int l = 1; l <= 6; ++l) {
+        const size_t ni = (size_t)lh[l] * lw[l] * 4, nf = (size_t)lh[l] * lw[l] * lc[l];
+        DFVO_HIP_CHECK(hipMemcpyAsync(img[l].p, src.img[l].p + ni, ni * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        if (l >= 2) DFVO_HIP_CHECK(hipMemcpyAsync(feat[l].p, src.feat[l].p + nf, nf * sizeof(float), hipMemcpyDeviceToDevice, stream));
+    }
+    return DFVO_OK;
+}
+
 int FlowNet::enqueue(float* d_fwd, float* d_bwd, float* d_diff) {
+    DFVO_TRY(enqueue_features_both());
+    return enqueue_levels(d_fwd, d_bwd, d_diff);
+}
+
+// Both frames through Features, ONE FRAME PER LAUNCH: the tile / K-split configuration of a launch depends on its batch
+// size and a different K-split changes the summation order, so a frame's pyramids must come out of the same single-frame
+// launches whether they are computed for this pair or were carried over from the previous one -- a sequence's flow is then
+// bit-identical in both modes (tests/test_pipeline_gpu.py), and a chunk boundary of the data-parallel mode leaves no trace.
+int FlowNet::enqueue_features_both() {
+    double fl = 0.0;
+    DFVO_TRY(enqueue_features(0, 1, &fl));
+    flops_feat1 = fl;
+    DFVO_TRY(enqueue_features(1, 1, &fl));
+    flops_feat2 = fl;
+    return DFVO_OK;
+}
+
+// everything behind the feature pyramids: matching / sub-pixel / regularisation per level, output resize + consistency
+int FlowNet::enqueue_levels(float* d_fwd, float* d_bwd, float* d_diff) {
     const int N = 2;
     hipStream_t s = stream;
     double fl = 0.0;
     const View none{nullptr, 0, 0};
-    // image pyramid (lite_flow_net.py:307-309)
-    for (int l = 2; l <= 6; ++l)
-        DFVO_TRY(launch_resize_bilinear(img[l - 1].p, N, lh[l - 1], lw[l - 1], 4, img[l].p, lh[l], lw[l], 0, s));
-    // Features (lite_flow_net.py:78-86); temporaries borrowed from level-2/3/4 scratch
-    {
-        Level& L2 = lv[2];
-        Level& L3 = lv[3];
-        Level& L4 = lv[4];
-        DFVO_TRY(run_conv(feat_convs[0], N, lh[1], lw[1], View{img[1].p, 4, 0}, 0, none, nullptr, 0, 0, feat[1].p, 32, 0,
-                          0, s, &fl, &splitk));
-        DFVO_TRY(run_conv(feat_convs[1], N, lh[1], lw[1], View{feat[1].p, 32, 0}, 0, none, nullptr, 0, 0, L2.x32.p, 32,
-                          0, 0, s, &fl, &splitk));
-        DFVO_TRY(run_conv(feat_convs[2], N, lh[2], lw[2], View{L2.x32.p, 32, 0}, 0, none, nullptr, 0, 0, L2.x32b.p, 32,
-                          0, 0, s, &fl, &splitk));
-        DFVO_TRY(run_conv(feat_convs[3], N, lh[2], lw[2], View{L2.x32b.p, 32, 0}, 0, none, nullptr, 0, 0, feat[2].p, 32,
-                          0, 0, s, &fl, &splitk));
-        DFVO_TRY(run_conv(feat_convs[4], N, lh[2], lw[2], View{feat[2].p, 32, 0}, 0, none, nullptr, 0, 0, L3.x64.p, 64,
-                          0, 0, s, &fl, &splitk));
-        DFVO_TRY(run_conv(feat_convs[5], N, lh[3], lw[3], View{L3.x64.p, 64, 0}, 0, none, nullptr, 0, 0, feat[3].p, 64,
-                          0, 0, s, &fl, &splitk));
-        DFVO_TRY(run_conv(feat_convs[6], N, lh[3], lw[3], View{feat[3].p, 64, 0}, 0, none, nullptr, 0, 0, L4.x128.p, 96,
-                          0, 0, s, &fl, &splitk));
-        DFVO_TRY(run_conv(feat_convs[7], N, lh[4], lw[4], View{L4.x128.p, 96, 0}, 0, none, nullptr, 0, 0, feat[4].p, 96,
-                          0, 0, s, &fl, &splitk));
-        DFVO_TRY(run_conv(feat_convs[8], N, lh[4], lw[4], View{feat[4].p, 96, 0}, 0, none, nullptr, 0, 0, feat[5].p,
-                          128, 0, 0, s, &fl, &splitk));
-        DFVO_TRY(run_conv(feat_convs[9], N, lh[5], lw[5], View{feat[5].p, 128, 0}, 0, none, nullptr, 0, 0, feat[6].p,
-                          192, 0, 0, s, &fl, &splitk));
-    }
     const float* flow_prev = nullptr;
     for (int l = 6; l >= 2; --l) {
         Level& L = lv[l];
@@ -659,21 +712,40 @@ int FlowNet::enqueue(float* d_fwd, float* d_bwd, float* d_diff) {
     }
     // lite_flow_net.py:322-324 (x 20*0.5^1 for the level-2 map) + resize + consistency
     DFVO_TRY(launch_flow_post(lv[2].flow.p, 4, 0, lh[2], lw[2], 10.0f, imgH, imgW, d_fwd, d_bwd, d_diff, s));
-    flops_last = fl;
+    flops_levels = fl;
+    flops_last = flops_feat2 + flops_levels;
     return DFVO_OK;
 }
 
-int FlowNet::forward(const uint8_t* d_ref, const uint8_t* d_cur, float* d_fwd, float* d_bwd, float* d_diff) {
+// One stream capture -> instantiated graph (re-captured by the callers when the pointers baked into it change)
+template <class F>
+static int capture_graph(hipStream_t stream, hipGraph_t* g, hipGraphExec_t* ge, F&& body) {
+    if (*ge) (void)hipGraphExecDestroy(*ge);
+    if (*g) (void)hipGraphDestroy(*g);
+    *ge = nullptr;
+    *g = nullptr;
+    DFVO_HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+    const int rc = body();
+    const hipError_t e = hipStreamEndCapture(stream, g);
+    if (rc != DFVO_OK) return rc;
+    DFVO_HIP_CHECK(e);
+    DFVO_HIP_CHECK(hipGraphInstantiate(ge, *g, nullptr, nullptr, 0));
+    return DFVO_OK;
+}
+
+// carry_from != nullptr: the reference frame is the current frame of carry_from's last pass (d_ref is not read): its
+// pyramids are copied over and only the current frame runs through Features.  Bit-identical to the full pass
+// (enqueue_features_both).
+int FlowNet::forward(const uint8_t* d_ref, const uint8_t* d_cur, float* d_fwd, float* d_bwd, float* d_diff,
+                     const FlowNet* carry_from) {
     if (!finalized) {
         set_last_error("FlowNet::forward before finalize");
         return DFVO_ERR_STATE;
     }
-    // DFVO_FLOW_GRAPH_INPUT=1: the two frame-reading launches are captured too (one graph launch per pass, but the graph is
-    // re-captured whenever the frame pointers change: only for callers that replay the same buffers)
-    static const bool graph_input = getenv("DFVO_FLOW_GRAPH_INPUT") && atoi(getenv("DFVO_FLOW_GRAPH_INPUT")) != 0;
-    const bool in_graph = graph_input && use_graph && tuned_once && graph_exec && graph_ref == d_ref && graph_cur == d_cur;
-    if (!in_graph) DFVO_TRY(enqueue_input(d_ref, d_cur));
+    DFVO_ARG_CHECK(d_cur && (d_ref || carry_from), "FlowNet::forward: null frame");
+    if (!e_feat) DFVO_HIP_CHECK(hipEventCreateWithFlags(&e_feat, hipEventDisableTiming));
     if (!tuned_once) {  // first call: eager run with the conv autotuner on (sizes are final from here on)
+        DFVO_TRY(enqueue_input(d_ref, d_cur));  // (timing run: a carried first pass measures on a zero reference frame)
         conv_autotune_scope(true);
         int rc = enqueue(d_fwd, d_bwd, d_diff);
         conv_autotune_scope(false);
@@ -681,39 +753,60 @@ int FlowNet::forward(const uint8_t* d_ref, const uint8_t* d_cur, float* d_fwd, f
         DFVO_HIP_CHECK(hipStreamSynchronize(stream));
         tuned_once = true;
     }
-    if (!use_graph) return enqueue(d_fwd, d_bwd, d_diff);
-    if (graph_exec && (graph_fwd != d_fwd || graph_bwd != d_bwd || graph_diff != d_diff ||
-                       (graph_input && (graph_ref != d_ref || graph_cur != d_cur)))) {
-        (void)hipGraphExecDestroy(graph_exec);
-        (void)hipGraphDestroy(graph);
-        graph_exec = nullptr;
-        graph = nullptr;
+    if (carry_from && carry_from != this) DFVO_HIP_CHECK(hipStreamWaitEvent(stream, carry_from->e_feat, 0));
+    DFVO_TRY(enqueue_input(carry_from ? nullptr : d_ref, d_cur));
+    auto features = [&]() -> int {
+        if (!carry_from) return enqueue_features_both();
+        double fl = 0.0;
+        DFVO_TRY(enqueue_carry(*carry_from));
+        return enqueue_features(1, 1, &fl);
+    };
+    if (!use_graph) {
+        DFVO_TRY(features());
+        DFVO_HIP_CHECK(hipEventRecord(e_feat, stream));
+        DFVO_TRY(enqueue_levels(d_fwd, d_bwd, d_diff));
+        flops_last = (carry_from ? flops_feat1 : flops_feat2) + flops_levels;
+        return DFVO_OK;
     }
-    if (!graph_exec) {
-        // run once eagerly (configures function attributes), then capture
-        DFVO_TRY(enqueue(d_fwd, d_bwd, d_diff));
+    // two graphs per pass -- [carry +] Features | levels -- with e_feat between them: the other flow-net instance carries
+    // this pass's current-frame pyramids into the next pair as soon as they exist
+    const int fi = carry_from ? 1 : 0;
+    if (!graph_feat_exec[fi] || (carry_from && graph_carry_src != carry_from)) {
+        DFVO_TRY(features());  // eagerly once (configures function attributes), then captured
         DFVO_HIP_CHECK(hipStreamSynchronize(stream));
-        DFVO_HIP_CHECK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-        int rc = graph_input ? enqueue_input(d_ref, d_cur) : DFVO_OK;
-        if (rc == DFVO_OK) rc = enqueue(d_fwd, d_bwd, d_diff);
-        hipError_t e = hipStreamEndCapture(stream, &graph);
-        if (rc != DFVO_OK) return rc;
-        DFVO_HIP_CHECK(e);
-        DFVO_HIP_CHECK(hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0));
+        DFVO_TRY(capture_graph(stream, &graph_feat[fi], &graph_feat_exec[fi], features));
+        if (carry_from) graph_carry_src = carry_from;
+    } else {
+        DFVO_HIP_CHECK(hipGraphLaunch(graph_feat_exec[fi], stream));
+    }
+    DFVO_HIP_CHECK(hipEventRecord(e_feat, stream));
+    if (!graph_exec || graph_fwd != d_fwd || graph_bwd != d_bwd || graph_diff != d_diff) {
+        DFVO_TRY(enqueue_levels(d_fwd, d_bwd, d_diff));
+        DFVO_HIP_CHECK(hipStreamSynchronize(stream));
+        DFVO_TRY(capture_graph(stream, &graph, &graph_exec, [&]() { return enqueue_levels(d_fwd, d_bwd, d_diff); }));
         graph_fwd = d_fwd;
         graph_bwd = d_bwd;
         graph_diff = d_diff;
-        graph_ref = d_ref;
-        graph_cur = d_cur;
-        return DFVO_OK;  // results of the eager run are already in place
+    } else {
+        DFVO_HIP_CHECK(hipGraphLaunch(graph_exec, stream));
     }
-    DFVO_HIP_CHECK(hipGraphLaunch(graph_exec, stream));
+    flops_last = (carry_from ? flops_feat1 : flops_feat2) + flops_levels;
     return DFVO_OK;
 }
 
 void FlowNet::destroy() {
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (graph) (void)hipGraphDestroy(graph);
+    for (int i = 0; i < 2; ++i) {
+        if (graph_feat_exec[i]) (void)hipGraphExecDestroy(graph_feat_exec[i]);
+        if (graph_feat[i]) (void)hipGraphDestroy(graph_feat[i]);
+        graph_feat_exec[i] = nullptr;
+        graph_feat[i] = nullptr;
+    }
+    graph_exec = nullptr;
+    graph = nullptr;
+    if (e_feat) (void)hipEventDestroy(e_feat);
+    e_feat = nullptr;
     for (auto& c : feat_convs) free_conv(&c);
     for (int l = 1; l <= 6; ++l) {
         img[l].release();

@@ -58,6 +58,7 @@ struct dfvo_pipeline {
     bool has_ref_depth = false;
     dfvo_pipeline_cfg cfg;
     bool nets_ready = false;
+    const FlowNet* last_flow = nullptr;  // the instance that ran the previous pair (carry source of a d_ref == NULL call)
 };
 
 #define P_TRY(expr)                     \
@@ -306,8 +307,10 @@ int dfvo_pipeline_seed(dfvo_pipeline* p, uint32_t seed) {
 
 int dfvo_pipeline_enqueue_nets(dfvo_pipeline* p, int slot, const uint8_t* d_ref, const uint8_t* d_cur,
                                const uint8_t* d_cur_feed) {
-    DFVO_ARG_CHECK(p && p->nets_ready && (slot >= 0 && slot < DFVO_PIPELINE_SLOTS) && d_ref && d_cur,
+    DFVO_ARG_CHECK(p && p->nets_ready && (slot >= 0 && slot < DFVO_PIPELINE_SLOTS) && d_cur,
                    "dfvo_pipeline_enqueue_nets: bad argument");
+    DFVO_ARG_CHECK(d_ref || p->last_flow, "dfvo_pipeline_enqueue_nets: d_ref == NULL (reference frame = the previous call's "
+                                          "current frame) needs a previous call");
     const size_t px = (size_t)p->H * p->W;
     // depth of the current frame (dfvo.py:305-319); without a caller-resized frame the LANCZOS resize of
     // deep_models.py:195-199 runs here, ahead of the net on its stream
@@ -326,7 +329,10 @@ int dfvo_pipeline_enqueue_nets(dfvo_pipeline* p, int slot, const uint8_t* d_ref,
     const int inst = slot % p->flow_instances;
     FlowNet& fn = inst == 0 ? p->flow : p->flow_x[inst - 1];
     hipStream_t sf = fn.stream;
-    P_TRY(fn.forward(d_ref, d_cur, fn.out_fwd.p, fn.out_bwd.p, fn.out_diff.p));  // frame pointers may change per pair (not captured)
+    // frame pointers may change per pair (not captured).  d_ref == NULL: the image / feature pyramids of the reference frame
+    // are carried over from the pass that saw it as its current frame (the other flow-net instance, normally)
+    P_TRY(fn.forward(d_ref, d_cur, fn.out_fwd.p, fn.out_bwd.p, fn.out_diff.p, d_ref ? nullptr : p->last_flow));
+    p->last_flow = &fn;
     DFVO_HIP_CHECK(hipMemcpyAsync(p->fwd[slot], fn.out_fwd.p, 2 * px * sizeof(float), hipMemcpyDeviceToDevice, sf));
     DFVO_HIP_CHECK(hipMemcpyAsync(p->bwd[slot], fn.out_bwd.p, 2 * px * sizeof(float), hipMemcpyDeviceToDevice, sf));
     DFVO_HIP_CHECK(hipMemcpyAsync(p->diff[slot], fn.out_diff.p, px * sizeof(float), hipMemcpyDeviceToDevice, sf));

@@ -77,7 +77,9 @@ class TrackingPipeline:
 
     def enqueue_nets(self, slot, d_ref, d_cur, d_feed=None):
         """device uint8 tensors (torch.cuda): ref/cur [H,W,3]; feed [feed_h,feed_w,3] = the LANCZOS-resized current
-        frame, or None to have the pipeline resize d_cur on the device"""
+        frame, or None to have the pipeline resize d_cur on the device.
+        d_ref=None: the reference frame is the current frame of the previous enqueue_nets call -- the flow net carries that
+        frame's image / feature pyramids over instead of running Features on it again (sequences)."""
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
         capi.check(self.lib.dfvo_pipeline_enqueue_nets(self.h, slot, p(d_ref), p(d_cur), p(d_feed)))
 

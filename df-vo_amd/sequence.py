@@ -21,7 +21,8 @@ from .pipeline import TrackingPipeline
 SLOTS = 4  # DFVO_PIPELINE_SLOTS
 
 
-def track_chunk(pipe, frames, lo, hi, seed=4869, rng_mode="sequential", ahead=3, first_chunk=None, collect=None):
+def track_chunk(pipe, frames, lo, hi, seed=4869, rng_mode="sequential", ahead=3, first_chunk=None, collect=None,
+                carry_features=True):
     """track pairs lo .. hi-1 of `frames` (sequence of device uint8 tensors [H,W,3], indexable by frame number).
     Returns (rel [n,4,4] cur->ref motions, status [n]); status-1 rows (constant motion) hold the identity and are resolved
     by dist.compose_trajectory once the previous pair's motion is known."""
@@ -35,17 +36,22 @@ def track_chunk(pipe, frames, lo, hi, seed=4869, rng_mode="sequential", ahead=3,
     pipe.set_ref_image(frames[lo])  # halo: depth of the chunk's first reference frame
     if rng_mode == "sequential":
         pipe.seed(seed)
-    for j in range(lo, min(lo + ahead, hi)):
-        pipe.enqueue_nets(j % SLOTS, frames[j], frames[j + 1])
+    # carry_features: only the chunk's first pair hands both frames to the flow net; from then on the reference frame's image
+    # / feature pyramids are the ones the previous pair computed for it as its current frame (ref = None)
+
+    def feed(j):
+        pipe.enqueue_nets(j % SLOTS, None if (carry_features and j > lo) else frames[j], frames[j + 1])
         pipe.prefetch_track(j % SLOTS)
+
+    for j in range(lo, min(lo + ahead, hi)):
+        feed(j)
     prev = np.eye(4)
     for j in range(lo, hi):
         if rng_mode == "per_pair":
             pipe.seed((seed ^ (j + 1)) & 0xffffffff)
         pipe.track_begin(j % SLOTS)  # the chain of pair j runs while the host feeds the nets of pair j + ahead
         if j + ahead < hi:
-            pipe.enqueue_nets((j + ahead) % SLOTS, frames[j + ahead], frames[j + ahead + 1])
-            pipe.prefetch_track((j + ahead) % SLOTS)
+            feed(j + ahead)
         out = pipe.track_end(j % SLOTS)
         status[j - lo] = out.status
         if out.status != 1:

@@ -386,7 +386,12 @@ int dfvo_pipeline_set_graph(dfvo_pipeline* p, int enable);   /* hipGraph replay 
  * first dfvo_pipeline_track() after the call has returned (set_ref_depth, set_ref_image). */
 /* enqueue both nets for one pair into `slot` (0 .. DFVO_PIPELINE_SLOTS-1); returns at once.  d_* uint8 device images:
  * ref/cur [img_h,img_w,3], cur_feed [feed_h,feed_w,3] (the PIL-LANCZOS resized current frame) or NULL: the current frame
- * is then resized on the device (dfvo_resize_lanczos_u8's arithmetic) ahead of the depth net */
+ * is then resized on the device (dfvo_resize_lanczos_u8's arithmetic) ahead of the depth net.
+ * d_ref == NULL (sequences): the reference frame is the current frame of the previous dfvo_pipeline_enqueue_nets call.
+ * LiteFlowNet's image pyramid and Features (lite_flow_net.py:78-86, 307-309) are functions of one frame each; the
+ * reference's model call runs them on both frames of every pair, i.e. twice per frame of a sequence.  Here the pyramids
+ * the previous pass computed for that frame are carried over (device copies, ordered by an event between the flow-net
+ * instances) and only the new frame runs through Features: same values, 15 GFLOP less per pair at KITTI size. */
 int dfvo_pipeline_enqueue_nets(dfvo_pipeline* p, int slot, const uint8_t* d_ref, const uint8_t* d_cur,
                                const uint8_t* d_cur_feed);
 /* depth of the very first reference frame (dfvo.py computes the depth of every frame as it becomes `cur`; the first

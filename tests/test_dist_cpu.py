@@ -109,6 +109,7 @@ class _StubOut:
 class _StubPipe:
     def __init__(self):
         self.slots, self.seed_, self.ref_image, self.log = {}, None, None, []
+        self.last_cur = None
 
     def set_ref_image(self, f):
         self.ref_image = int(f)
@@ -118,7 +119,11 @@ class _StubPipe:
         self.seed_ = int(s)
 
     def enqueue_nets(self, slot, ref, cur, feed=None):
+        if ref is None:  # carried mode: the reference frame is the previous call's current frame
+            assert self.last_cur is not None
+            ref = self.last_cur
         assert int(cur) == int(ref) + 1
+        self.last_cur = int(cur)
         self.slots[slot] = (int(ref), int(cur))
 
     def prefetch_track(self, slot, *a):

@@ -113,3 +113,44 @@ def test_pipeline_nets_equal_standalone_executors(gpu, conv_precision, pipe_mod)
     assert np.array_equal(raw, want_raw)
     want = T.preprocess_depth(want_raw, [[0.3, 1], [0, 1]], [0, 50])
     assert np.array_equal(dep, want)
+
+
+@pytest.mark.parametrize("h,w,instances", [(192, 640, "2"), (376, 1241, "2"), (192, 640, "1")])
+def test_feature_carry_equals_recomputed_features(gpu, conv_precision, pipe_mod, h, w, instances, monkeypatch):
+    """enqueue_nets(ref=None): the reference frame's image / feature pyramids come from the previous pass (the other flow-net
+    instance with two instances, the same one with one) instead of a second Features run: forward / backward flow and the
+    consistency map of the pair must be what the full pass on the same two frames gives, bit for bit (Features always runs
+    one frame per launch, and the instances share their layer configurations: nets.hip enqueue_features_both, autotune_conv)."""
+    monkeypatch.setenv("DFVO_FLOW_INSTANCES", instances)
+    fsd, dsd = O.liteflownet_state_dict(4869), O.monodepth2_state_dict(4869)
+    K = rigid_scene(64, 64, seed=1)["K"]
+    pipe = pipe_mod.TrackingPipeline(h, w, 192, 640, K, fsd, dsd)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    a, b = image_pair(h, w, seed=31)
+    c, e = image_pair(h, w, seed=32)
+    frames = [d(x) for x in (a, b, c, e)]
+    carried, full = [], []
+    pipe.enqueue_nets(0, frames[0], frames[1])  # a sequence: first pair full, then carried, slot (= instance) alternating
+    for j in (1, 2):
+        pipe.enqueue_nets(j, None, frames[j + 1])
+    pipe.sync()
+    for j in (1, 2):
+        carried.append(pipe.get_outputs(j)[:3])
+    for j in (1, 2):  # the same pairs with both frames handed over
+        pipe.enqueue_nets(j, frames[j], frames[j + 1])
+        pipe.sync()
+        full.append(pipe.get_outputs(j)[:3])
+    # and carried again after full passes (the carry source is whichever instance ran last)
+    pipe.enqueue_nets(3, None, frames[0])
+    pipe.sync()
+    again = pipe.get_outputs(3)[:3]
+    pipe.enqueue_nets(0, frames[3], frames[0])
+    pipe.sync()
+    again_full = pipe.get_outputs(0)[:3]
+    pipe.close()
+    worst = 0.0
+    for got, want in zip(carried + [again], full + [again_full]):
+        for g, wnt in zip(got, want):
+            worst = max(worst, float(np.abs(g - wnt).max()))
+    print("feature carry vs recomputed: max |diff| %.3g px (0 = bit-identical)" % worst)
+    assert worst == 0.0

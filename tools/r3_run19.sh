@@ -1,0 +1,10 @@
+#!/bin/bash
+# round 3, GPU call 19: the reference frame's pyramids carried over from the previous pair: parity + rate
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out; export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_pipeline_gpu.py -q -m gpu -x -s -k "carry" 2>&1 | grep -E "carry|passed|failed|Error|error" | tail -12 | tee gpurun_out/r3s_carry.txt
+timeout 1500 python -m pytest tests/test_e2e_gpu.py tests/test_pipeline_gpu.py tests/test_trajectory_gpu.py tests/test_dropin_gpu.py -q -m gpu -x 2>&1 | grep -v amdgpu.ids | tail -4 | tee -a gpurun_out/r3s_carry.txt
+for i in 1 2; do
+  timeout 300 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-roofline --no-exact-leg 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('carried', d['value'], d['ms_per_step'], 'steady', d['steady_state']['value'], d['config']['tracked_by_E'], d['config']['tracked_by_PnP'], '| recomputed', d['features_recomputed'])"
+done | tee -a gpurun_out/r3s_carry.txt
