@@ -15,6 +15,10 @@
 #pragma once
 // (included inside namespace dfvo, after conv_win_f16s.h)
 
+#ifndef F16S2_LATE
+#define F16S2_LATE 1
+#endif
+
 template <class F, int... T>
 __device__ __forceinline__ void f16s2_static_for_impl(F&& f, std::integer_sequence<int, T...>) {
     (f(std::integral_constant<int, T>{}), ...);
@@ -85,17 +89,23 @@ __global__ __launch_bounds__(64 * WC * WR, 1) void conv_win_f16s2_kernel(const C
         w_ok |= (v ? 1u : 0u) << r;
     }
     const int G0 = __builtin_amdgcn_readfirstlane(p.G0), G1 = __builtin_amdgcn_readfirstlane(p.G1);
-    // timing-only ablations (DFVO_F16S2_ABL, wrong results): bit 0 = every window load re-reads chunk 0 (cache hits instead
-    // of HBM / Infinity Cache), bit 1 = every weight fragment is (tap 0, chunk 0) -- same instruction stream either way
-    const int abl = __builtin_amdgcn_readfirstlane(p.force_splits);
-    auto load_window_item = [&](int c_in, int r) {
-        const int c = (abl & 1) ? 0 : c_in;
-        const bool s1 = c >= nchunk0;
-        const int cg = (s1 ? (c - nchunk0) * 4 : c * 4) + wq;
-        const bool v = ((w_ok >> r) & 1u) && cg < (s1 ? G1 : G0);
-        const float* base = s1 ? p.src1 : p.src0;
-        const int off = (s1 ? w_off1[r] : w_off0[r]) + (v ? cg * 4 : 0);  // masked lanes re-read channel group 0
-        rw[r] = *reinterpret_cast<const f32x4*>(base + off);
+    // per-chunk uniforms of the window prefetch (which source, which 4-channel group, whether it exists): set once per chunk
+    // by set_chunk(), so that the taps' requests are plain loads -- no uniform branch inside the 9-tap scheduling region
+    bool ch_s1 = false, ch_v = true;
+    int ch_cg4 = 0;
+    const float* ch_base = p.src0;
+    auto set_chunk = [&](int c_in) {
+        const int c = c_in;
+        ch_s1 = c >= nchunk0;
+        const int cg = (ch_s1 ? (c - nchunk0) * 4 : c * 4) + wq;
+        ch_v = cg < (ch_s1 ? G1 : G0);
+        ch_cg4 = ch_v ? cg * 4 : 0;  // masked lanes re-read channel group 0
+        ch_base = ch_s1 ? p.src1 : p.src0;
+    };
+    auto load_window_item = [&](int r) {
+        const bool v = ((w_ok >> r) & 1u) && ch_v;
+        const int off = (ch_s1 ? w_off1[r] : w_off0[r]) + (((w_ok >> r) & 1u) ? ch_cg4 : 0);
+        rw[r] = *reinterpret_cast<const f32x4*>(ch_base + off);
         rwv = (rwv & ~(1u << r)) | ((v ? 1u : 0u) << r);
     };
     auto store_window_item = [&](float* W, int r) {
@@ -111,14 +121,23 @@ __global__ __launch_bounds__(64 * WC * WR, 1) void conv_win_f16s2_kernel(const C
     const size_t w_chunk_stride = (size_t)p.wf16_cout_pad * 32;  // halves per (tap, chunk)
     h16x8 wa[3][TC][2];
     auto load_w = [&](int stage, int tap, int c) {
-        const unsigned short* g = wbase + ((abl & 2) ? (size_t)0 : ((size_t)tap * nchunks + c) * w_chunk_stride);
+        const unsigned short* g = wbase + ((size_t)tap * nchunks + c) * w_chunk_stride;
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
             wa[stage][i][0] = *reinterpret_cast<const h16x8*>(g + (size_t)i * 32 * 32);
             wa[stage][i][1] = *reinterpret_cast<const h16x8*>(g + (size_t)i * 32 * 32 + 512);
         }
     };
+    auto load_w_piece = [&](int stage, int tap, int c, int piece) {  // piece = cout tile * 2 + plane
+        const unsigned short* g = wbase + ((size_t)tap * nchunks + c) * w_chunk_stride;
+        wa[stage][piece >> 1][piece & 1] = *reinterpret_cast<const h16x8*>(g + (size_t)(piece >> 1) * 32 * 32 + (piece & 1) * 512);
+    };
     h16x8 xb[2][TR][2];
+    auto read_x_piece = [&](const float* Wc, int set, int tap, int piece) {  // piece = row tile * 2 + plane
+        const int ky = tap / 3, kx = tap - ky * 3, j = piece >> 1;
+        const float* px = Wc + ((wr * TR + j + ky) * WW + (lp + kx)) * PS + kb * 4;
+        xb[set][j][piece & 1] = *reinterpret_cast<const h16x8*>(px + (piece & 1) * 8);
+    };
     auto read_x = [&](const float* Wc, int set, int tap) {
         const int ky = tap / 3, kx = tap - ky * 3;
 #pragma unroll
@@ -137,8 +156,9 @@ __global__ __launch_bounds__(64 * WC * WR, 1) void conv_win_f16s2_kernel(const C
 #pragma unroll
             for (int e = 0; e < 16; ++e) am[i][j][e] = ax[i][j][e] = 0.f;
 
+    set_chunk(0);
 #pragma unroll
-    for (int r = 0; r < W_CNT; ++r) load_window_item(0, r);
+    for (int r = 0; r < W_CNT; ++r) load_window_item(r);
     load_w(0, 0, 0);
     load_w(1, 1, 0);
 #pragma unroll
@@ -153,49 +173,89 @@ __global__ __launch_bounds__(64 * WC * WR, 1) void conv_win_f16s2_kernel(const C
         const float* Wc = lds + (c & 1) * WIN;
         float* Wn = lds + ((c + 1) & 1) * WIN;
         const int c_next = c + 1 < nchunks ? c + 1 : c;
+        set_chunk(c_next);
         if (!(SKIP & 2) || c == 0) read_x(Wc, 0, 0);
         if ((SKIP & 2) && c == 0) read_x(Wc, 1, 1);
         f16s2_static_for<9>([&](auto tap_c) {
             constexpr int tap = decltype(tap_c)::value;
             constexpr int cur = tap % 3, xs = tap & 1;
-            if (!(SKIP & 1)) {
-                if (tap < 7)
-                    load_w((tap + 2) % 3, tap + 2, c);
-                else if (next_chunk)
-                    load_w((tap + 2) % 3, tap - 7, c_next);
-            }
-            if (!(SKIP & 4) && next_chunk && tap < W_CNT) load_window_item(c_next, tap);
-            __builtin_amdgcn_sched_barrier(0);  // the requests stay ahead of the tap's arithmetic
-            if (!(SKIP & 2) && tap < 8) read_x(Wc, xs ^ 1, tap + 1);
             constexpr int ST0 = 9 - W_CNT;
-            if (!(SKIP & 4) && next_chunk && tap >= ST0) store_window_item(Wn, tap - ST0);
-#pragma unroll
-            for (int i = 0; i < TC; ++i)
-#pragma unroll
-                for (int j = 0; j < TR; ++j)
-                    ax[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][i][0], xb[xs][j][1], ax[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < TC; ++i)
-#pragma unroll
-                for (int j = 0; j < TR; ++j)
-                    ax[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][i][1], xb[xs][j][0], ax[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < TC; ++i)
-#pragma unroll
-                for (int j = 0; j < TR; ++j)
-                    am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][i][0], xb[xs][j][0], am[i][j], 0, 0, 0);
-            // interleave: the next tap's pixel-fragment reads one per MFMA first, then the window item's split (about 30
-            // VALU instructions) two per MFMA, its two LDS writes last -- everything inside the shadow of the tap's MFMAs
             constexpr int NM = 3 * TC * TR, NR = tap < 8 ? 2 * TR : 0;
+            // MFMA k of the tap: product set g = k / (TC * TR) (0: hi x lo, 1: lo x hi -> cross sums, 2: hi x hi -> main sums)
+            auto mfma = [&](int k) {
+                const int g = k / (TC * TR), i = (k % (TC * TR)) / TR, j = k % TR;
+                if (g == 0)
+                    ax[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][i][0], xb[xs][j][1], ax[i][j], 0, 0, 0);
+                else if (g == 1)
+                    ax[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][i][1], xb[xs][j][0], ax[i][j], 0, 0, 0);
+                else
+                    am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][i][0], xb[xs][j][0], am[i][j], 0, 0, 0);
+            };
+            if (F16S2_LATE) {
+                // One request per MFMA, each fenced into that MFMA's shadow (the compiler hoists free-standing loads to the
+                // top of the region whatever the group hints say): first the next tap's pixel fragments from LDS, then the
+                // weight fragments of tap + 2 and one window item of the next chunk from global memory -- they are
+                // consumed two taps / one chunk later -- so that nothing but the split of the window item is left between
+                // the taps' MFMA groups.
+                constexpr int NV = ((SKIP & 1) ? 0 : 2 * TC) + ((!(SKIP & 4) && tap < W_CNT) ? 1 : 0);
+                constexpr int NF = NR + NV < NM ? NR + NV : NM;  // fenced slots
+                f16s2_static_for<NF>([&](auto k_c) {
+                    constexpr int k = decltype(k_c)::value;
+                    mfma(k);
+                    constexpr int per = NF > 0 ? (NR + NV + NF - 1) / NF : 1;  // requests per slot (1 unless the tile has few MFMAs)
 #pragma unroll
-            for (int k = 0; k < NM; ++k) {
-                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                if (k < NR)
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                else if (next_chunk && tap >= ST0)
-                    __builtin_amdgcn_sched_group_barrier(0x2, NM - NR >= 16 ? 2 : 4, 0);
+                    for (int u = 0; u < per; ++u) {
+                        const int q = k * per + u;
+                        if (q < NR) {
+                            if (!(SKIP & 2)) read_x_piece(Wc, xs ^ 1, tap + 1, q);
+                        } else if (q < NR + NV) {
+                            const int v = q - NR;
+                            if (!(SKIP & 1) && v < 2 * TC) {
+                                if (tap < 7)
+                                    load_w_piece((tap + 2) % 3, tap + 2, c, v);
+                                else
+                                    load_w_piece((tap + 2) % 3, tap - 7, c_next, v);
+                            } else if (!(SKIP & 4) && tap < W_CNT) {
+                                load_window_item(tap);
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+                if (!(SKIP & 4) && tap >= ST0) store_window_item(Wn, tap - ST0);
+#pragma unroll
+                for (int k = NF; k < NM; ++k) mfma(k);
+#pragma unroll
+                for (int k = NF; k < NM; ++k) {  // the window item's split (about 30 VALU instructions), its two LDS writes last
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                    if (tap >= ST0) __builtin_amdgcn_sched_group_barrier(0x2, NM - NF >= 16 ? 2 : 4, 0);
+                }
+                if (tap >= ST0) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+            } else {
+                if (!(SKIP & 1)) {
+                    if (tap < 7)
+                        load_w((tap + 2) % 3, tap + 2, c);
+                    else if (next_chunk)
+                        load_w((tap + 2) % 3, tap - 7, c_next);
+                }
+                if (!(SKIP & 4) && next_chunk && tap < W_CNT) load_window_item(tap);
+                __builtin_amdgcn_sched_barrier(0);  // the requests stay ahead of the tap's arithmetic
+                if (!(SKIP & 2) && tap < 8) read_x(Wc, xs ^ 1, tap + 1);
+                if (!(SKIP & 4) && next_chunk && tap >= ST0) store_window_item(Wn, tap - ST0);
+#pragma unroll
+                for (int k = 0; k < NM; ++k) mfma(k);
+                // interleave: the next tap's pixel-fragment reads one per MFMA first, then the window item's split (about 30
+                // VALU instructions) two per MFMA, its two LDS writes last -- everything inside the shadow of the tap's MFMAs
+#pragma unroll
+                for (int k = 0; k < NM; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                    if (k < NR)
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    else if (next_chunk && tap >= ST0)
+                        __builtin_amdgcn_sched_group_barrier(0x2, NM - NR >= 16 ? 2 : 4, 0);
+                }
+                if (next_chunk && tap >= ST0) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
             }
-            if (next_chunk && tap >= ST0) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
             __builtin_amdgcn_sched_barrier(0);
         });
         __syncthreads();
@@ -238,10 +298,7 @@ static int launch_f16s2_cfg(const ConvParams& p, hipStream_t stream, int cfg_id)
         pe.cfg = cfg_id;
         DFVO_HIP_CHECK(hipEventRecord(pe.e0, stream));
     }
-    static const int abl = getenv("DFVO_F16S2_ABL") ? atoi(getenv("DFVO_F16S2_ABL")) : 0;
-    ConvParams pk = p;
-    pk.force_splits = abl;  // (unused by this kernel otherwise)
-    hipLaunchKernelGGL((conv_win_f16s2_kernel<WC, WR, TC, TR, SKIP>), grid, dim3(64 * WC * WR), 0, stream, pk);
+    hipLaunchKernelGGL((conv_win_f16s2_kernel<WC, WR, TC, TR, SKIP>), grid, dim3(64 * WC * WR), 0, stream, p);
     DFVO_HIP_CHECK(hipGetLastError());
     if (g_prof) {
         DFVO_HIP_CHECK(hipEventRecord(pe.e1, stream));
@@ -264,18 +321,6 @@ static int launch_f16s2(const ConvParams& p, hipStream_t stream, int cfg_id) {
     if (!mode) return -1;
     const int ncu = 256;
     auto cost = [&](long long blocks, int rows) { return blocks <= 0 ? (1LL << 60) : ((blocks + ncu - 1) / ncu) * rows; };
-    static const int skip = getenv("DFVO_F16S2_SKIP") ? atoi(getenv("DFVO_F16S2_SKIP")) : 0;
-    if (skip && p.wf16_cout_pad % 128 == 0) {  // timing-only ablations of the 128-cout x 6-row shape
-        switch (skip) {
-            case 1: return launch_f16s2_cfg<2, 2, 2, 3, 1>(p, stream, cfg_id);
-            case 2: return launch_f16s2_cfg<2, 2, 2, 3, 2>(p, stream, cfg_id);
-            case 4: return launch_f16s2_cfg<2, 2, 2, 3, 4>(p, stream, cfg_id);
-            case 3: return launch_f16s2_cfg<2, 2, 2, 3, 3>(p, stream, cfg_id);
-            case 5: return launch_f16s2_cfg<2, 2, 2, 3, 5>(p, stream, cfg_id);
-            case 6: return launch_f16s2_cfg<2, 2, 2, 3, 6>(p, stream, cfg_id);
-            default: return launch_f16s2_cfg<2, 2, 2, 3, 7>(p, stream, cfg_id);
-        }
-    }
     if (p.wf16_cout_pad % 128 == 0) {
         // (an 8-row tile -- 256 accumulator registers -- does not fit: the allocator spills inside the tap loop)
         const long long b3 = f16s2_blocks<2, 2, 2, 3>(p), b2 = f16s2_blocks<2, 2, 2, 2>(p);

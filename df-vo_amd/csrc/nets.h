@@ -105,9 +105,12 @@ struct FlowNet {
     double flops_last = 0.0;  // useful conv+corr FLOPs of the last forward (2*MAC)
     // ... of its parts: Features on both frames / on the current frame alone (carried mode) / everything behind them
     double flops_feat2 = 0.0, flops_feat1 = 0.0, flops_levels = 0.0;
-    hipGraph_t graph = nullptr;            // the levels
-    hipGraphExec_t graph_exec = nullptr;
-    float *graph_fwd = nullptr, *graph_bwd = nullptr, *graph_diff = nullptr;
+    struct LevelsGraph {  // the levels, captured per output buffer set
+        hipGraph_t g = nullptr;
+        hipGraphExec_t exec = nullptr;
+        float *fwd = nullptr, *bwd = nullptr, *diff = nullptr;
+    } lv_graphs[4];
+    int lv_graph_next = 0;
     hipGraph_t graph_feat[2] = {nullptr, nullptr};  // [0] Features of both frames, [1] carry + Features of the current frame
     hipGraphExec_t graph_feat_exec[2] = {nullptr, nullptr};
     const FlowNet* graph_carry_src = nullptr;

@@ -593,11 +593,24 @@ int FlowNet::enqueue_features(int n0, int N, double* fl) {
 // convolutions.  The caller orders this stream behind src.e_feat.
 int FlowNet::enqueue_carry(const FlowNet& src) {
     DFVO_ARG_CHECK(src.H == H && src.W == W && src.finalized, "FlowNet::enqueue_carry: nets of different sizes");
+    const float* from[12];
+    float* to[12];
+    size_t cnt[12];
+    int n = 0;
     for (int l = 1; l <= 6; ++l) {
         const size_t ni = (size_t)lh[l] * lw[l] * 4, nf = (size_t)lh[l] * lw[l] * lc[l];
-        DFVO_HIP_CHECK(hipMemcpyAsync(img[l].p, src.img[l].p + ni, ni * sizeof(float), hipMemcpyDeviceToDevice, stream));
-        if (l >= 2) DFVO_HIP_CHECK(hipMemcpyAsync(feat[l].p, src.feat[l].p + nf, nf * sizeof(float), hipMemcpyDeviceToDevice, stream));
+        from[n] = src.img[l].p + ni;
+        to[n] = img[l].p;
+        cnt[n++] = ni;
+        if (l >= 2) {
+            from[n] = src.feat[l].p + nf;
+            to[n] = feat[l].p;
+            cnt[n++] = nf;
+        }
     }
+    static const bool one_launch = !(getenv("DFVO_CARRY_ONE_LAUNCH") && atoi(getenv("DFVO_CARRY_ONE_LAUNCH")) == 0);
+    if (one_launch) return launch_copy_segments(from, to, cnt, n, stream);  // (eleven copy nodes cost eleven dispatches)
+    for (int i = 0; i < n; ++i) DFVO_HIP_CHECK(hipMemcpyAsync(to[i], from[i], cnt[i] * sizeof(float), hipMemcpyDeviceToDevice, stream));
     return DFVO_OK;
 }
 
@@ -780,31 +793,38 @@ int FlowNet::forward(const uint8_t* d_ref, const uint8_t* d_cur, float* d_fwd, f
         DFVO_HIP_CHECK(hipGraphLaunch(graph_feat_exec[fi], stream));
     }
     DFVO_HIP_CHECK(hipEventRecord(e_feat, stream));
-    if (!graph_exec || graph_fwd != d_fwd || graph_bwd != d_bwd || graph_diff != d_diff) {
+    // one levels graph per output buffer set (the fused pipeline hands over its per-slot buffers: no copies behind the pass)
+    LevelsGraph* lg = nullptr;
+    for (auto& g : lv_graphs)
+        if (g.exec && g.fwd == d_fwd && g.bwd == d_bwd && g.diff == d_diff) lg = &g;
+    if (!lg) {
+        lg = &lv_graphs[lv_graph_next];
+        lv_graph_next = (lv_graph_next + 1) % 4;
         DFVO_TRY(enqueue_levels(d_fwd, d_bwd, d_diff));
         DFVO_HIP_CHECK(hipStreamSynchronize(stream));
-        DFVO_TRY(capture_graph(stream, &graph, &graph_exec, [&]() { return enqueue_levels(d_fwd, d_bwd, d_diff); }));
-        graph_fwd = d_fwd;
-        graph_bwd = d_bwd;
-        graph_diff = d_diff;
+        DFVO_TRY(capture_graph(stream, &lg->g, &lg->exec, [&]() { return enqueue_levels(d_fwd, d_bwd, d_diff); }));
+        lg->fwd = d_fwd;
+        lg->bwd = d_bwd;
+        lg->diff = d_diff;
     } else {
-        DFVO_HIP_CHECK(hipGraphLaunch(graph_exec, stream));
+        DFVO_HIP_CHECK(hipGraphLaunch(lg->exec, stream));
     }
     flops_last = (carry_from ? flops_feat1 : flops_feat2) + flops_levels;
     return DFVO_OK;
 }
 
 void FlowNet::destroy() {
-    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
-    if (graph) (void)hipGraphDestroy(graph);
+    for (auto& g : lv_graphs) {
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        if (g.g) (void)hipGraphDestroy(g.g);
+        g = LevelsGraph();
+    }
     for (int i = 0; i < 2; ++i) {
         if (graph_feat_exec[i]) (void)hipGraphExecDestroy(graph_feat_exec[i]);
         if (graph_feat[i]) (void)hipGraphDestroy(graph_feat[i]);
         graph_feat_exec[i] = nullptr;
         graph_feat[i] = nullptr;
     }
-    graph_exec = nullptr;
-    graph = nullptr;
     if (e_feat) (void)hipEventDestroy(e_feat);
     e_feat = nullptr;
     for (auto& c : feat_convs) free_conv(&c);

@@ -45,6 +45,15 @@ int launch_maxpool3x3s2(const float* src, int N, int H, int W, int C, float* dst
 // outputs fwd[2,H,W], bwd[2,H,W] planar and diff[H,W] = || fwd - grid_sample(-bwd, pix+fwd) ||.
 int launch_flow_post(const float* netflow, int fcs, int fco, int h, int w, float scale, int H, int W, float* fwd,
                      float* bwd, float* diff, hipStream_t s);
+// up to 12 device-to-device copies (float counts multiples of 4, 16-byte aligned) in ONE launch
+struct CopySegs {
+    const float* src[12];
+    float* dst[12];
+    unsigned n4[12];      // float4 elements per segment
+    unsigned start[13];   // first workgroup of each segment (prefix sums), start[n] = grid size
+    int n;
+};
+int launch_copy_segments(const float* const* src, float* const* dst, const size_t* floats, int n, hipStream_t s);
 // monodepth2 tail: sigmoid disp -> depth = mult/(min_disp + (max_disp-min_disp)*disp); monodepth2.py:108-139
 int launch_disp_to_depth(const float* disp, int dcs, int dco, int n, float min_disp, float disp_range,
                          float mult, float* depth, hipStream_t s);

@@ -558,6 +558,44 @@ int launch_flow_post(const float* netflow, int fcs, int fco, int h, int w, float
     return DFVO_OK;
 }
 
+// several contiguous device-to-device copies in one launch (the flow net's pyramid carry-over: eleven copy nodes in a graph
+// cost eleven dispatches of ~5 us each on the net's stream; this is one)
+constexpr int COPY_SEG_F4_PER_BLOCK = 256 * 4;
+__global__ __launch_bounds__(256) void k_copy_segments(const CopySegs S) {
+    int seg = 0;
+#pragma unroll 1
+    while (seg + 1 < S.n && blockIdx.x >= S.start[seg + 1]) ++seg;
+    const float4* __restrict__ src = reinterpret_cast<const float4*>(S.src[seg]);
+    float4* __restrict__ dst = reinterpret_cast<float4*>(S.dst[seg]);
+    const unsigned base = (blockIdx.x - S.start[seg]) * COPY_SEG_F4_PER_BLOCK + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const unsigned i = base + u * 256;
+        if (i < S.n4[seg]) dst[i] = src[i];
+    }
+}
+
+int launch_copy_segments(const float* const* src, float* const* dst, const size_t* floats, int n, hipStream_t s) {
+    DFVO_ARG_CHECK(n >= 1 && n <= 12, "launch_copy_segments: 1 .. 12 segments");
+    CopySegs S = {};
+    S.n = n;
+    unsigned blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        DFVO_ARG_CHECK(floats[i] % 4 == 0 && ((uintptr_t)src[i] & 15) == 0 && ((uintptr_t)dst[i] & 15) == 0,
+                       "launch_copy_segments: segments must be 16-byte aligned multiples of 4 floats");
+        S.src[i] = src[i];
+        S.dst[i] = dst[i];
+        S.n4[i] = (unsigned)(floats[i] / 4);
+        S.start[i] = blocks;
+        blocks += (S.n4[i] + COPY_SEG_F4_PER_BLOCK - 1) / COPY_SEG_F4_PER_BLOCK;
+    }
+    S.start[n] = blocks;
+    if (blocks == 0) return DFVO_OK;
+    hipLaunchKernelGGL(k_copy_segments, dim3(blocks), dim3(256), 0, s, S);
+    DFVO_HIP_CHECK(hipGetLastError());
+    return DFVO_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // depth tail
 // ---------------------------------------------------------------------------------------------

@@ -331,11 +331,17 @@ int dfvo_pipeline_enqueue_nets(dfvo_pipeline* p, int slot, const uint8_t* d_ref,
     hipStream_t sf = fn.stream;
     // frame pointers may change per pair (not captured).  d_ref == NULL: the image / feature pyramids of the reference frame
     // are carried over from the pass that saw it as its current frame (the other flow-net instance, normally)
-    P_TRY(fn.forward(d_ref, d_cur, fn.out_fwd.p, fn.out_bwd.p, fn.out_diff.p, d_ref ? nullptr : p->last_flow));
+    // DFVO_FLOW_DIRECT_OUT=1: the net writes the slot's buffers itself (one levels graph per slot, no copies behind the pass)
+    static const bool direct = getenv("DFVO_FLOW_DIRECT_OUT") && atoi(getenv("DFVO_FLOW_DIRECT_OUT")) != 0;
+    if (direct) {
+        P_TRY(fn.forward(d_ref, d_cur, p->fwd[slot], p->bwd[slot], p->diff[slot], d_ref ? nullptr : p->last_flow));
+    } else {
+        P_TRY(fn.forward(d_ref, d_cur, fn.out_fwd.p, fn.out_bwd.p, fn.out_diff.p, d_ref ? nullptr : p->last_flow));
+        DFVO_HIP_CHECK(hipMemcpyAsync(p->fwd[slot], fn.out_fwd.p, 2 * px * sizeof(float), hipMemcpyDeviceToDevice, sf));
+        DFVO_HIP_CHECK(hipMemcpyAsync(p->bwd[slot], fn.out_bwd.p, 2 * px * sizeof(float), hipMemcpyDeviceToDevice, sf));
+        DFVO_HIP_CHECK(hipMemcpyAsync(p->diff[slot], fn.out_diff.p, px * sizeof(float), hipMemcpyDeviceToDevice, sf));
+    }
     p->last_flow = &fn;
-    DFVO_HIP_CHECK(hipMemcpyAsync(p->fwd[slot], fn.out_fwd.p, 2 * px * sizeof(float), hipMemcpyDeviceToDevice, sf));
-    DFVO_HIP_CHECK(hipMemcpyAsync(p->bwd[slot], fn.out_bwd.p, 2 * px * sizeof(float), hipMemcpyDeviceToDevice, sf));
-    DFVO_HIP_CHECK(hipMemcpyAsync(p->diff[slot], fn.out_diff.p, px * sizeof(float), hipMemcpyDeviceToDevice, sf));
     DFVO_HIP_CHECK(hipEventRecord(p->e_flow[slot], sf));
     return DFVO_OK;
 }

@@ -158,12 +158,12 @@ __global__ __launch_bounds__(E_STAGE1_LANES) void k_e_stage1(const EBatch B, int
     ok[it] = sm::five_point_stage1_ws(q1, q2, w, w + 36, w + 75, s_ws + threadIdx.x * E_STAGE1_STRIDE) ? 1 : 0;
 }
 
-__global__ __launch_bounds__(64) void k_e_poly(const EBatch B, int it0, int it1) {
+__global__ __launch_bounds__(256) void k_e_poly(const EBatch B, int it0, int it1) {
     const ERep& R = B.r[blockIdx.y];
     const RansacState* st = R.state;
     double* ws = R.ws;
     const int* ok = R.ok;
-    const int it = it0 + blockIdx.x * 64 + threadIdx.x;
+    const int it = it0 + blockIdx.x * blockDim.x + threadIdx.x;
     if (st->done || it >= it1) return;
     if (!ok[it]) return;
     double* w = ws + (size_t)it * E_WS;
@@ -518,7 +518,14 @@ int enqueue_find_essential_batch(RansacWorkspace* w, const double* const* d_pts1
                 hipLaunchKernelGGL(k_e_hyp, dim3(cdiv(nh, 4), R), dim3(64), 0, s, B, it0, it1);
             } else {
                 hipLaunchKernelGGL(k_e_stage1, dim3(cdiv(nh, E_STAGE1_LANES), R), dim3(E_STAGE1_LANES), 0, s, B, it0, it1);
-                hipLaunchKernelGGL(k_e_poly, dim3(cdiv(nh, 64), R), dim3(64), 0, s, B, it0, it1);
+                // one lane per hypothesis, 0.5 ms per wave (cv::solvePoly's 300 sweeps).  DFVO_E_POLY_BLOCK = 128 / 256 packs two /
+                // four of those waves into one workgroup, i.e. onto the SIMDs of ONE compute unit instead of different ones (a
+                // resident foreign wave keeps the nets' one-wave-per-SIMD window workgroups off its whole compute unit):
+                // measured, 64 / 128 / 256 -> 276.8 / 277.4 / 277.0 pairs/s (profiles/r3t_poly_block_ab.txt): not what
+                // couples the solver stage to the nets.
+                static const int poly_block = getenv("DFVO_E_POLY_BLOCK") ? atoi(getenv("DFVO_E_POLY_BLOCK")) : 64;
+                const int pb = poly_block == 256 || poly_block == 128 ? poly_block : 64;
+                hipLaunchKernelGGL(k_e_poly, dim3(cdiv(nh, pb), R), dim3(pb), 0, s, B, it0, it1);
                 hipLaunchKernelGGL(k_e_stage3, dim3(cdiv(nh, 4), R), dim3(64), 0, s, B, it0, it1);
             }
             hipLaunchKernelGGL(k_e_score, dim3(cdiv(nh, 4), R), dim3(256), 0, s, B, it0, it1, n, thr2);
