@@ -99,6 +99,7 @@ SIGNATURES = {
     "dfvo_compose_trajectory": (_i, [_vp, _i, _vp, _vp, C.POINTER(_i)]),
     "dfvo_compose_trajectory_device": (_i, [_vp, _i, _vp, _vp, C.POINTER(_i), _vp]),
     "dfvo_set_conv_precision": (_i, [C.c_char_p]),
+    "dfvo_set_sklearn_compat": (_i, [C.c_char_p]),
     "dfvo_f16s_overflow_count": (_i, [C.POINTER(C.c_ulonglong), _i]),
     "dfvo_conv_profile_begin": (_i, []),
     "dfvo_conv_profile_end": (_i, [_vp, _vp, _vp]),
@@ -170,6 +171,7 @@ SIGNATURES = {
     "dfvo_pipeline_net_flops": (_d, [_vp]),
     "dfvo_find_scale_from_depth": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, C.POINTER(ScaleCfg), C.POINTER(_d), _vp]),
     "dfvo_compute_pose_3d2d": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, C.POINTER(Pose3d2dCfg), C.POINTER(Pose3d2dOut), _vp]),
+    "dfvo_ransac_regressor": (_i, [_vp, _vp, _vp, _i, C.POINTER(ScaleCfg), C.POINTER(_d), _vp]),
 }
 
 
@@ -212,6 +214,12 @@ def check(rc):
 def require_gpu():
     if lib().dfvo_device_count() < 1:
         raise DfvoError("no HIP device visible: the DF-VO hot path has no CPU fallback")
+
+
+def set_sklearn_compat(version):
+    """which scikit-learn the scale-recovery RANSAC reproduces where versions differ ("0.20.3": the reference's pin and the
+    library default; pass sklearn.__version__ to match an installed one)"""
+    check(lib().dfvo_set_sklearn_compat(str(version).encode()))
 
 
 def f16s_overflow_count(reset=False):

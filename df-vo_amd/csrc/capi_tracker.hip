@@ -404,6 +404,8 @@ int dfvo_compute_pose_2d2d(dfvo_tracker* t, const double* h_kp_ref, const double
     return DFVO_OK;
 }
 
+int dfvo_set_sklearn_compat(const char* version) { return dfvo::set_sklearn_compat(version); }
+
 int dfvo_find_scale_from_depth(dfvo_tracker* t, const double* h_kp1, const double* h_kp2, int n, const double* h_T21,
                                const double* h_depth, int H, int W, const dfvo_scale_cfg* cfg, double* scale,
                                int* h_info) {
@@ -438,6 +440,37 @@ int dfvo_find_scale_from_depth(dfvo_tracker* t, const double* h_kp1, const doubl
     DFVO_HIP_CHECK(hipMemcpyAsync(&sr, t->tb.scale_out, sizeof(sr), hipMemcpyDeviceToHost, t->stream));
     DFVO_HIP_CHECK(hipStreamSynchronize(t->stream));
     *scale = sr.scale;
+    if (h_info) {
+        h_info[0] = sr.n_valid;
+        h_info[1] = sr.n_trials;
+        h_info[2] = sr.n_inliers;
+        h_info[3] = sr.status;
+    }
+    return DFVO_OK;
+}
+
+int dfvo_ransac_regressor(dfvo_tracker* t, const double* h_x, const double* h_y, int n, const dfvo_scale_cfg* cfg,
+                          double* coef, int* h_info) {
+    DFVO_ARG_CHECK(t && h_x && cfg && coef && n >= 1, "dfvo_ransac_regressor: bad argument");
+    DFVO_ARG_CHECK(cfg->min_samples >= 1 && cfg->min_samples <= 8, "dfvo_ransac_regressor: min_samples in [1,8]");
+    int rc = t->tb.ensure_kp(n > 16 ? n : 16, 1, 1);
+    if (rc != DFVO_OK) return rc;
+    DFVO_HIP_CHECK(hipMemcpyAsync(t->tb.ratios, h_x, sizeof(double) * n, hipMemcpyHostToDevice, t->stream));
+    if (h_y)
+        DFVO_HIP_CHECK(hipMemcpyAsync(t->tb.ratios + t->tb.kp_cap, h_y, sizeof(double) * n, hipMemcpyHostToDevice, t->stream));
+    ScaleConfig sc;
+    sc.cx = sc.cy = sc.fx = sc.fy = 0;
+    sc.min_samples = cfg->min_samples;
+    sc.max_trials = cfg->max_trials;
+    sc.stop_prob = cfg->stop_prob;
+    sc.thre = cfg->thre;
+    sc.method = h_y ? 1 : 0;
+    rc = enqueue_ransac_regressor(t->tb, n, h_y == nullptr, sc, t->stream);
+    if (rc != DFVO_OK) return rc;
+    ScaleResult sr;
+    DFVO_HIP_CHECK(hipMemcpyAsync(&sr, t->tb.scale_out, sizeof(sr), hipMemcpyDeviceToHost, t->stream));
+    DFVO_HIP_CHECK(hipStreamSynchronize(t->stream));
+    *coef = sr.scale;
     if (h_info) {
         h_info[0] = sr.n_valid;
         h_info[1] = sr.n_trials;

@@ -18,6 +18,8 @@
 
 #include "tracker.h"
 
+#include <atomic>
+
 namespace dfvo {
 
 __device__ __forceinline__ int wave_sum_i(int v) {
@@ -1417,7 +1419,7 @@ __global__ __launch_bounds__(256) void k_scale_ransac(uint32_t* __restrict__ mt_
                                                        int max_trials, double stop_prob, double thr,
                                                        uint8_t* __restrict__ inl_a, uint8_t* __restrict__ inl_b,
                                                        int* __restrict__ scratch, ScaleResult* __restrict__ out,
-                                                       const PoseState* __restrict__ gate) {
+                                                       const PoseState* __restrict__ gate, int r2_nan_below_two) {
     __shared__ sm::Mt19937 s;
     __shared__ double s_coef;
     __shared__ int s_cnt[4], s_nz[4];
@@ -1511,7 +1513,10 @@ __global__ __launch_bounds__(256) void k_scale_ransac(uint32_t* __restrict__ mt_
             __syncthreads();
             if (tot != 0.0) score = 1.0 - res / tot;  // else: the constant-target rule above (force_finite)
         }
-        if (n_in < 2) score = NAN;  // r2_score of fewer than two samples: nan, which loses no comparison below
+        // sklearn >= 0.22: r2_score of fewer than two samples is nan, which loses no comparison below.  scikit-learn 0.20.3
+        // (the reference's pin, envs/requirement.yml:233) has no such rule: one sample is a constant target, scored 1.0 /
+        // 0.0 by the rule above.  dfvo_set_sklearn_compat selects (default: the reference's pin).
+        if (r2_nan_below_two && n_in < 2) score = NAN;
         if (n_in == n_inliers_best && score < score_best) continue;
         n_inliers_best = n_in;
         score_best = score;
@@ -1868,6 +1873,32 @@ int enqueue_scale_prepare(TrackerBuffers& tb, int H, int W) {
     return DFVO_OK;
 }
 
+// which scikit-learn the depth-ratio RANSAC reproduces where the versions differ (dfvo_set_sklearn_compat)
+std::atomic<int> g_sklearn_r2_nan_below_two{0};
+int set_sklearn_compat(const char* version) {
+    DFVO_ARG_CHECK(version, "dfvo_set_sklearn_compat: null version");
+    int major = 0, minor = 0;
+    DFVO_ARG_CHECK(sscanf(version, "%d.%d", &major, &minor) == 2, "dfvo_set_sklearn_compat: expected \"<major>.<minor>[...]\"");
+    // r2_score's "fewer than two samples -> nan" rule exists from scikit-learn 0.22 on
+    g_sklearn_r2_nan_below_two.store((major > 0 || minor >= 22) ? 1 : 0);
+    return DFVO_OK;
+}
+
+// sklearn.linear_model.RANSACRegressor(LinearRegression(fit_intercept=False), min_samples, max_trials, stop_probability,
+// residual_threshold).fit(x[:, None], y) on raw arrays already in tb.ratios (x at [0, n), y at [kp_cap, kp_cap + n), or
+// d_y_is_ones: y = 1): the regression stage of find_scale_from_depth on its own (no "more than 10 valid points" gate)
+int enqueue_ransac_regressor(TrackerBuffers& tb, int n, bool y_is_ones, const ScaleConfig& cfg, hipStream_t s) {
+    DFVO_ARG_CHECK(n >= 1 && n <= tb.kp_cap, "ransac_regressor: capacity");
+    DFVO_HIP_CHECK(hipMemcpyAsync(tb.kp_total + 4, &n, sizeof(int), hipMemcpyHostToDevice, s));
+    DFVO_HIP_CHECK(hipStreamSynchronize(s));  // (n is a stack value)
+    hipLaunchKernelGGL(k_scale_ransac, dim3(1), dim3(256), 0, s, tb.mt_state, tb.ratios,
+                       y_is_ones ? (const double*)nullptr : tb.ratios + tb.kp_cap, tb.kp_total + 4, -1, cfg.min_samples,
+                       cfg.max_trials, cfg.stop_prob, cfg.thre, tb.inl_a, tb.inl_b, tb.scratch, tb.scale_out,
+                       (const PoseState*)nullptr, g_sklearn_r2_nan_below_two.load());
+    DFVO_HIP_CHECK(hipGetLastError());
+    return DFVO_OK;
+}
+
 int enqueue_find_scale(TrackerBuffers& tb, int n_host, const double* d_T21, const double* d_depth, int H, int W,
                        const ScaleConfig& cfg, hipStream_t s, const PoseState* d_gate, bool prepared) {
     DFVO_ARG_CHECK(n_host >= 0 && n_host <= tb.kp_cap, "find_scale: keypoint capacity");
@@ -1893,7 +1924,7 @@ int enqueue_find_scale(TrackerBuffers& tb, int n_host, const double* d_T21, cons
     hipLaunchKernelGGL(k_scale_ransac, dim3(1), dim3(256), 0, s, tb.mt_state, abs_diff ? tb.ratios + tb.kp_cap : tb.ratios,
                        abs_diff ? tb.ratios + 2 * (size_t)tb.kp_cap : (const double*)nullptr, tb.kp_total + 4, 10,
                        cfg.min_samples, cfg.max_trials, cfg.stop_prob, cfg.thre, tb.inl_a, tb.inl_b, tb.scratch,
-                       tb.scale_out, d_gate);
+                       tb.scale_out, d_gate, g_sklearn_r2_nan_below_two.load());
     DFVO_HIP_CHECK(hipGetLastError());
     return DFVO_OK;
 }

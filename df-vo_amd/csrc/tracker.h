@@ -198,5 +198,7 @@ int enqueue_compute_pose_3d2d(PnpBuffers& pb, uint32_t* mt_state, const double* 
 int enqueue_find_scale(TrackerBuffers& tb, int n_host, const double* d_T21, const double* d_depth, int H, int W,
                        const ScaleConfig& cfg, hipStream_t s, const PoseState* d_gate = nullptr, bool prepared = false);
 int enqueue_scale_prepare(TrackerBuffers& tb, int H, int W);
+int enqueue_ransac_regressor(TrackerBuffers& tb, int n, bool y_is_ones, const ScaleConfig& cfg, hipStream_t s);
+int set_sklearn_compat(const char* version);  // "0.20" (the reference's pin, default) | "0.22" and later
 
 }  // namespace dfvo

@@ -79,6 +79,12 @@ int dfvo_conv2d(const dfvo_conv_desc* desc, const float* d_src0, const float* d_
  *   "bf16x6" / "bf16x3"  bf16-plane variants (24 / 16 mantissa bits)
  * Also read once from the environment variable DFVO_CONV_PRECISION. */
 int dfvo_set_conv_precision(const char* name);
+/* Which scikit-learn the scale-recovery RANSAC (sklearn.linear_model.RANSACRegressor, E_tracker.py:618-636) reproduces
+ * where the versions differ: r2_score of a one-sample consensus set is nan from 0.22 on (every later trial with the same
+ * inlier count then wins), 1.0 / 0.0 in 0.20.3 -- the version the reference pins (envs/requirement.yml:233) and the
+ * default here.  version: "<major>.<minor>[.patch]" of the scikit-learn to reproduce (process-wide, takes effect with the
+ * next scale recovery). */
+int dfvo_set_sklearn_compat(const char* version);
 /* f16x3 range report: the hi plane of the split is f16, so an activation with |x| > 65504 does not fit -- it becomes
  * +-inf and propagates as inf / NaN into the layer's output (never a silently clamped product).  Every splitting kernel
  * counts the threads that saw such an activation, the packer the weights (those are clamped, and counted);
@@ -309,6 +315,13 @@ typedef struct dfvo_scale_cfg {
 int dfvo_find_scale_from_depth(dfvo_tracker* trk, const double* h_kp1, const double* h_kp2, int n,
                                const double* h_T21, const double* h_depth, int H, int W, const dfvo_scale_cfg* cfg,
                                double* scale, int* h_info);
+/* The regression stage on its own -- sklearn.linear_model.RANSACRegressor(LinearRegression(fit_intercept=False),
+ * min_samples, max_trials, stop_probability, residual_threshold).fit(x[:, None], y) as E_tracker.py:618-636 builds it --
+ * on raw host arrays: h_x [n], h_y [n] or NULL for y = 1 (the depth-ratio case).  Consumes the tracker's RandomState as
+ * sklearn consumes np.random.  coef: estimator_.coef_[0, 0]; h_info as above (status -1: "RANSAC could not find a valid
+ * consensus set", where sklearn raises ValueError).  cfg->cx .. fy and method are not read. */
+int dfvo_ransac_regressor(dfvo_tracker* trk, const double* h_x, const double* h_y, int n, const dfvo_scale_cfg* cfg,
+                          double* coef, int* h_info);
 
 /* PnpTracker.compute_pose_3d2d (pnp_tracker.py:45-125): masks (kp2 inside the image, depth_1[int(kp1)] != 0 and
  * in (min_depth, max_depth)), unprojection_kp (ops_3d.py:70-94), `repeat` x [np.random.shuffle +

@@ -27,6 +27,10 @@ def gpu(capi):
     import torch
     capi.require_gpu()
     assert torch.cuda.is_available(), "torch sees no GPU"
+    # the oracle's scale recovery runs the INSTALLED scikit-learn; the library defaults to the reference's pin (0.20.3),
+    # which differs in one degenerate rule (tests/test_tracker_gpu.py::test_scale_recovery_sklearn_versions covers both)
+    import sklearn
+    capi.set_sklearn_compat(sklearn.__version__)
     return capi
 
 

@@ -18,6 +18,8 @@ def run():
     from oracle import nets_torch as O
     from oracle import tracker_np as T
     capi.require_gpu()
+    import sklearn
+    capi.set_sklearn_compat(sklearn.__version__)  # the checker below runs the installed scikit-learn (library default: 0.20.3, the reference's pin)
     h, w = 128, 416
     sc = syn.rigid_scene(h, w, seed=9)
     fsd, dsd = syn.liteflownet_state_dict(4869), syn.monodepth2_state_dict(4869)

@@ -6,6 +6,8 @@ last bits between numpy and the device library), the final least-squares scale (
 LAPACK gelsd)."""
 import ctypes as C
 
+import warnings
+
 import numpy as np
 import pytest
 
@@ -201,6 +203,112 @@ def test_scale_recovery_small_populations(gpu, trk):
             assert info[1] == diag["n_trials"] and info[2] == diag["n_inliers"]
             assert abs(scale.value - s_ref) <= 1e-12 * abs(s_ref)
         assert np.array_equal(pull_rng(gpu, trk), np_state())
+
+
+def test_scale_recovery_sklearn_versions(gpu, trk):
+    """dfvo_set_sklearn_compat: a residual threshold so tight that consensus sets of ONE sample occur -- r2_score of one
+    sample is nan in the installed scikit-learn (>= 0.22) and 1.0 / 0.0 in 0.20.3, the reference's pin.  Device vs the
+    installed RANSACRegressor with the matching r2_score (oracle/sklearn_compat.py), both rules: trial count, inlier count,
+    coefficient, RandomState.  (The two rules only part ways when a one-sample consensus set has an exactly zero residual
+    -- score 1.0 instead of 0.0 / nan -- which none of 360 random cases reached; tests/test_oracle_sklearn_compat.py shows
+    the difference on a crafted input.)"""
+    import sklearn
+    from oracle.sklearn_compat import r2_score_like
+    lib = gpu.lib()
+    results = {}
+    try:
+        for version in ("0.20.3", sklearn.__version__):
+            gpu.set_sklearn_compat(version)
+            for seed, n, thre in ((51, 60, 2e-3), (52, 200, 1e-3), (53, 400, 5e-4), (54, 30, 1e-3), (55, 20, 3e-3), (56, 14, 1e-3)):
+                c = tracker_case(seed, n, 0.1, 0.05)
+                K = c["K"]
+                pose = np.eye(4)
+                pose[:3, :3] = c["R"]
+                pose[:3, 3] = c["t"]
+                T21 = np.ascontiguousarray(pose)
+                np.random.seed(seed)
+                push_rng(gpu, trk)
+                diag = {}
+                raised = False
+                with r2_score_like(version), warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    try:
+                        s_ref = T.find_scale_from_depth(c["kp_ref"], c["kp_cur"], T21, c["depth_cur"], K, diag=diag, thre=thre)
+                    except ValueError:  # "RANSAC could not find a valid consensus set"
+                        raised = True
+                scfg = gpu.ScaleCfg(cx=K[0, 2], cy=K[1, 2], fx=K[0, 0], fy=K[1, 1], min_samples=3, max_trials=100,
+                                    stop_prob=0.99, thre=thre)
+                scale = C.c_double()
+                info = np.zeros(4, np.int32)
+                h, w = c["depth_cur"].shape
+                gpu.check(lib.dfvo_find_scale_from_depth(trk, gpu.as_ptr(c["kp_ref"]), gpu.as_ptr(c["kp_cur"]), n,
+                                                         gpu.as_ptr(T21), gpu.as_ptr(np.ascontiguousarray(c["depth_cur"])),
+                                                         h, w, C.byref(scfg), C.byref(scale), gpu.as_ptr(info)))
+                print("sklearn %s seed %d: oracle %s %s | hip %.12g %s" % (
+                    version, seed, "raised" if raised else "%.12g" % s_ref, {k: v for k, v in diag.items() if k != "ratios"},
+                    scale.value, info.tolist()))
+                assert np.array_equal(pull_rng(gpu, trk), np_state())
+                if raised:
+                    assert info[3] == -1
+                    continue
+                assert info[0] == diag["n_valid"]
+                if s_ref == -1:
+                    assert scale.value == -1
+                else:
+                    assert info[1] == diag["n_trials"] and info[2] == diag["n_inliers"]
+                    assert abs(scale.value - s_ref) <= 1e-12 * abs(s_ref)
+                results[(version, seed)] = (scale.value, int(info[1]), int(info[2]))
+    finally:
+        gpu.set_sklearn_compat(sklearn.__version__)
+    one_sample = [k for k, v in results.items() if v[2] == 1]
+    print("results with a one-sample consensus set:", one_sample)
+    assert one_sample, "no case ended on a one-sample consensus set: the test does not reach the rule"
+
+
+def test_ransac_regressor_one_sample_consensus_rule(gpu, trk):
+    """dfvo_ransac_regressor on the crafted input of tests/test_oracle_sklearn_compat.py (zeros, isolated powers of two, two
+    small values; y = 1): one-sample consensus sets with exactly zero and with non-zero residuals alternate, so the r2_score
+    rule of scikit-learn 0.20.3 (1.0 / 0.0) and of >= 0.22 (nan) pick different final sets on half of the seeds.  The
+    device follows dfvo_set_sklearn_compat, bit for bit: coefficient, inlier count, trial count, RandomState."""
+    import sklearn
+    from sklearn import linear_model
+    from oracle.sklearn_compat import r2_score_like
+    lib = gpu.lib()
+    x = np.array([0.0] * 6 + [4.0, 64.0, 1024.0, 16384.0] + [0.5, 0.25])
+    got = {}
+    try:
+        for version in ("0.20.3", sklearn.__version__):
+            gpu.set_sklearn_compat(version)
+            for seed in range(30):
+                np.random.seed(seed)
+                push_rng(gpu, trk)
+                r = linear_model.RANSACRegressor(estimator=linear_model.LinearRegression(fit_intercept=False), min_samples=3,
+                                                 max_trials=40, stop_probability=0.99, residual_threshold=0.3)
+                want = None
+                with r2_score_like(version), warnings.catch_warnings():
+                    warnings.simplefilter("ignore")
+                    try:
+                        r.fit(x.reshape(-1, 1), np.ones((x.shape[0], 1)))
+                        want = (float(r.estimator_.coef_[0, 0]), int(r.n_trials_), int(r.inlier_mask_.sum()))
+                    except ValueError:
+                        pass
+                scfg = gpu.ScaleCfg(cx=0, cy=0, fx=1, fy=1, min_samples=3, max_trials=40, stop_prob=0.99, thre=0.3)
+                coef = C.c_double()
+                info = np.zeros(4, np.int32)
+                gpu.check(lib.dfvo_ransac_regressor(trk, gpu.as_ptr(x), None, x.shape[0], C.byref(scfg), C.byref(coef),
+                                                    gpu.as_ptr(info)))
+                assert np.array_equal(pull_rng(gpu, trk), np_state()), (version, seed)
+                if want is None:
+                    assert info[3] == -1, (version, seed)
+                else:
+                    assert (coef.value, int(info[1]), int(info[2])) == want, (version, seed, coef.value, info.tolist(), want)
+                got[(version, seed)] = want
+    finally:
+        gpu.set_sklearn_compat(sklearn.__version__)
+    differ = [s for s in range(30) if got[("0.20.3", s)] != got[(sklearn.__version__, s)]]
+    print("seeds on which the two scikit-learn rules end on different consensus sets:", differ)
+    major, minor = (int(v) for v in sklearn.__version__.split(".")[:2])
+    assert differ or not (major > 0 or minor >= 22)
 
 
 def _pose2d2d(gpu, trk, kp_ref, kp_cur, K, **kw):
