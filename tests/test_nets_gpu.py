@@ -127,6 +127,55 @@ def test_splitk_in_kernel_finish_equals_two_launch_reduction(gpu, tmp_path):
     assert np.abs(res["1"]["fwd0"]).max() > 0.1
 
 
+_SPLITK_LOAD = """
+import importlib, sys, zlib
+import numpy as np, torch
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(tests)r)
+importlib.import_module("df-vo_amd")
+pmod = importlib.import_module("df-vo_amd.pipeline")
+smod = importlib.import_module("df-vo_amd.sequence")
+from oracle import nets_torch as O
+from synth import image_pair, rigid_scene
+h, w = 192, 640
+K = rigid_scene(64, 64, seed=1)["K"]
+pipe = pmod.TrackingPipeline(h, w, 192, 640, K, O.liteflownet_state_dict(4869), O.monodepth2_state_dict(4869), seed=4869)
+frames = []
+for i in range(5):
+    a, b = image_pair(h, w, seed=100 + i)
+    frames += [a, b]
+frames = [torch.from_numpy(np.ascontiguousarray(f)).cuda() for f in frames]
+crc = []
+def collect(j, out):
+    fwd, bwd, diff, raw, dep = pipe.get_outputs(j %% 4)
+    crc.append([zlib.crc32(fwd.tobytes()), zlib.crc32(bwd.tobytes()), zlib.crc32(diff.tobytes()), zlib.crc32(raw.tobytes())])
+for rep in range(2):  # two flow-net instances, the depth net and the solver stage of the pairs behind run concurrently
+    smod.track_chunk(pipe, frames, 0, len(frames) - 1, collect=collect)
+pipe.close()
+np.save(%(out)r, np.array(crc, np.int64))
+"""
+
+
+def test_splitk_in_kernel_finish_under_pipeline_load(gpu, tmp_path):
+    """the same A/B inside the fused pipeline in exact fp32: two flow-net instances three pairs ahead, the depth net and the
+    solver stages on their own streams while the split-K layers hand their partials over across XCDs -- flow / depth of
+    every pair of two passes over a 10-frame sequence, fused finish vs the separate reduction launch, CRC-equal"""
+    import os
+    import subprocess
+    import sys
+    tests = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+    for fused in ("0", "1"):
+        out = str(tmp_path / ("splitk_load_%s.npy" % fused))
+        env = dict(os.environ, DFVO_SPLITK_FUSED=fused, DFVO_CONV_PRECISION="fp32")
+        code = _SPLITK_LOAD % {"tests": tests, "root": os.path.dirname(tests), "out": out}
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[fused] = np.load(out)
+    assert res["0"].shape == (18, 4)
+    assert np.array_equal(res["0"], res["1"]), "fused split-K finish differs under load: rows %s" % np.nonzero((res["0"] != res["1"]).any(1))[0]
+    assert np.array_equal(res["1"][:9], res["1"][9:]), "second pass over the sequence differs from the first"
+
+
 def test_flownet_graph_replay_is_identical(gpu):
     lib = gpu.lib()
     h, w = 128, 224
