@@ -384,10 +384,133 @@ __global__ __launch_bounds__(256) void k_correlation(const float* __restrict__ f
     }
 }
 
+// Register-tiled form for C % 32 == 0 (every level of the flow net).  Same staging, pixel stride C + 4 floats (16-byte
+// aligned pixel vectors; consecutive pixels 1 bank-quad apart: conflict-free ds_read_b128 for lanes along x).  A thread
+// owns TWO vertically adjacent output pixels x the seven vertical displacements of one horizontal displacement: the eight
+// second-image vectors it reads serve 14 (pixel, displacement) items -- 10 b128 reads per 56 FMAs instead of 112 b32
+// reads.  Summation order of the reference kernel kept exactly: per item 32 partial sums over c = j, j + 32, ...
+// (fmaf chains from 0), added in order j = 0 .. 31 -- four consecutive j per 16-byte read.
+template <int K32>  // C / 32
+__global__ __launch_bounds__(256) void k_correlation_rt(const float* __restrict__ f1, int cs1, int co1,
+                                                         const float* __restrict__ f2, int cs2, int co2, int swap2,
+                                                         int N, int H, int W, int stride, int Ho, int Wo, int TH, int TW,
+                                                         float* __restrict__ dst, int dcs, float slope) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int C = 32 * K32, P = C + 4, C4 = C / 4;
+    const int HW2 = TW + 6, HH2 = TH + 6;
+    float* s1 = smem;                 // [TH*TW][P]
+    float* s2 = smem + TH * TW * P;   // [HH2*HW2][P]
+    const int n = blockIdx.z;
+    const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
+    const int n2 = swap2 ? (N - 1 - n) : n;
+    for (int it = threadIdx.x; it < TH * TW * C4; it += 256) {
+        const int c = it % C4, pp = it / C4;
+        const int py = pp / TW, px = pp - py * TW;
+        const int oy = oy0 + py, ox = ox0 + px;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (oy < Ho && ox < Wo)
+            v = *reinterpret_cast<const f32x4*>(f1 + ((size_t)(n * H + oy * stride) * W + ox * stride) * cs1 + co1 + c * 4);
+        *reinterpret_cast<f32x4*>(s1 + pp * P + c * 4) = v;
+    }
+    for (int it = threadIdx.x; it < HH2 * HW2 * C4; it += 256) {
+        const int c = it % C4, pp = it / C4;
+        const int py = pp / HW2, px = pp - py * HW2;
+        const int sy = oy0 + py - 3, sx = ox0 + px - 3;  // coordinates on the stride-subsampled grid
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (sy >= 0 && sy < Ho && sx >= 0 && sx < Wo)
+            v = *reinterpret_cast<const f32x4*>(f2 + ((size_t)(n2 * H + sy * stride) * W + sx * stride) * cs2 + co2 + c * 4);
+        *reinterpret_cast<f32x4*>(s2 + pp * P + c * 4) = v;
+    }
+    __syncthreads();
+    const int units = TW * 7 * (TH / 2);
+    const int u = threadIdx.x;
+    if (u >= units) return;
+    const int px = u % TW, r = u / TW, dx = r % 7, yp = r / 7;
+    const int py = 2 * yp;
+    const float* a0 = s1 + (py * TW + px) * P;
+    const float* a1 = a0 + TW * P;
+    const float* b = s2 + (py * HW2 + px + dx) * P;  // rows py .. py + 7 of the halo tile, column px + dx
+    float tot0[7], tot1[7];
+#pragma unroll
+    for (int d = 0; d < 7; ++d) tot0[d] = tot1[d] = 0.f;
+#pragma unroll 1
+    for (int g = 0; g < 8; ++g) {  // partial sums j = 4g .. 4g + 3
+        f32x4 p0[7], p1[7];
+#pragma unroll
+        for (int d = 0; d < 7; ++d) p0[d] = p1[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < K32; ++k) {
+            const int c = 4 * g + 32 * k;
+            const f32x4 A0 = *reinterpret_cast<const f32x4*>(a0 + c);
+            const f32x4 A1 = *reinterpret_cast<const f32x4*>(a1 + c);
+            f32x4 B[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) B[i] = *reinterpret_cast<const f32x4*>(b + i * HW2 * P + c);
+#pragma unroll
+            for (int d = 0; d < 7; ++d)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    p0[d][e] = fmaf(A0[e], B[d][e], p0[d][e]);
+                    p1[d][e] = fmaf(A1[e], B[d + 1][e], p1[d][e]);
+                }
+        }
+#pragma unroll
+        for (int d = 0; d < 7; ++d)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                tot0[d] += p0[d][e];
+                tot1[d] += p1[d][e];
+            }
+    }
+    const float invC = (float)C;
+    const int ox = ox0 + px;
+    if (ox >= Wo) return;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int oy = oy0 + py + q;
+        if (oy >= Ho) continue;
+        float* o = dst + ((size_t)(n * Ho + oy) * Wo + ox) * dcs + dx;
+#pragma unroll
+        for (int d = 0; d < 7; ++d) {
+            float v = (q ? tot1[d] : tot0[d]) / invC;
+            v = v > 0.f ? v : v * slope;
+            o[d * 7] = v;  // displacement index tc = dy * 7 + dx
+        }
+    }
+}
+
+template <int K32>
+static int launch_correlation_rt(const float* f1, int cs1, int co1, const float* f2, int cs2, int co2, int swap2, int N,
+                                 int H, int W, int stride, float* dst, int dcs, float slope, hipStream_t s) {
+    constexpr int C = 32 * K32, P = C + 4;
+    const int Ho = cdiv(H, stride), Wo = cdiv(W, stride);
+    int TH = 8, TW = 8;
+    if ((size_t)(TH * TW + (TH + 6) * (TW + 6)) * P * sizeof(float) > 150 * 1024) TH = 4;
+    const size_t lds = (size_t)(TH * TW + (TH + 6) * (TW + 6)) * P * sizeof(float);
+    DFVO_ARG_CHECK(lds <= 160 * 1024, "correlation: channel count too large for the LDS tile");
+    if (int rc_lds = ensure_dyn_lds((const void*)k_correlation_rt<K32>, lds)) return rc_lds;
+    dim3 grid(cdiv(Wo, TW), cdiv(Ho, TH), N);
+    hipLaunchKernelGGL(k_correlation_rt<K32>, grid, dim3(256), lds, s, f1, cs1, co1, f2, cs2, co2, swap2, N, H, W, stride, Ho,
+                       Wo, TH, TW, dst, dcs, slope);
+    DFVO_HIP_CHECK(hipGetLastError());
+    return DFVO_OK;
+}
+
 int launch_correlation(const float* f1, int cs1, int co1, const float* f2, int cs2, int co2, int swap2, int N,
                        int H, int W, int C, int stride, float* dst, int dcs, float slope, hipStream_t s) {
     DFVO_ARG_CHECK(C % 4 == 0 && cs1 % 4 == 0 && cs2 % 4 == 0 && co1 % 4 == 0 && co2 % 4 == 0,
                    "correlation: alignment");
+    static const bool rt = !(getenv("DFVO_CORR_RT") && atoi(getenv("DFVO_CORR_RT")) == 0);
+    if (rt && C % 32 == 0 && C >= 32 && C <= 192) {
+        switch (C / 32) {
+            case 1: return launch_correlation_rt<1>(f1, cs1, co1, f2, cs2, co2, swap2, N, H, W, stride, dst, dcs, slope, s);
+            case 2: return launch_correlation_rt<2>(f1, cs1, co1, f2, cs2, co2, swap2, N, H, W, stride, dst, dcs, slope, s);
+            case 3: return launch_correlation_rt<3>(f1, cs1, co1, f2, cs2, co2, swap2, N, H, W, stride, dst, dcs, slope, s);
+            case 4: return launch_correlation_rt<4>(f1, cs1, co1, f2, cs2, co2, swap2, N, H, W, stride, dst, dcs, slope, s);
+            case 6: return launch_correlation_rt<6>(f1, cs1, co1, f2, cs2, co2, swap2, N, H, W, stride, dst, dcs, slope, s);
+            default: break;
+        }
+    }
     const int Ho = cdiv(H, stride), Wo = cdiv(W, stride);
     int TH = 8, TW = 8;
     if (C > 64) { TH = 4; TW = 8; }
