@@ -6,6 +6,7 @@
 namespace dfvo {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 static inline unsigned grid1d(long long n, int block) { return (unsigned)((n + block - 1) / block); }
 
@@ -565,10 +566,70 @@ __global__ void k_reg_head(const float* __restrict__ dist, int dist_cs, int k, c
     dst[pix * dcs + dco + 1] = (ay + by) * div;
 }
 
+// The same head with the pixel's distance vector read ONCE, as 16-byte loads into registers (a thread's k*k values are
+// contiguous and consecutive pixels are adjacent: the first form read them twice, four bytes at a time at a 208-byte lane
+// stride), the two flow components of a neighbour as one 8-byte load.  Same operations in the same order.
+template <int K>
+__global__ __launch_bounds__(256) void k_reg_head_v(const float* __restrict__ dist, int dist_cs, const float* __restrict__ flow,
+                                                     int fcs, int fco, const float* __restrict__ wx, float bx,
+                                                     const float* __restrict__ wy, float by, int N, int H, int W,
+                                                     float* __restrict__ dst, int dcs, int dco) {
+    constexpr int KK = K * K, KK4 = (KK + 3) / 4, R = (K - 1) / 2;
+    const long long pix = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= (long long)N * H * W) return;
+    const int x = (int)(pix % W);
+    const long long row = pix / W;
+    const int y = (int)(row % H);
+    const int n = (int)(row / H);
+    float v[KK4 * 4];
+    const f32x4* d4 = reinterpret_cast<const f32x4*>(dist + pix * dist_cs);
+#pragma unroll
+    for (int i = 0; i < KK4; ++i) {
+        const f32x4 q = d4[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[4 * i + e] = -(q[e] * q[e]);
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < KK; ++c) m = fmaxf(m, v[c]);
+    float se = 0.f, ax = 0.f, ay = 0.f;
+#pragma unroll
+    for (int c = 0; c < KK; ++c) {
+        const float e = expf(v[c] - m);
+        se += e;
+        const int ky = c / K, kx = c - ky * K;
+        const int yy = y + ky - R, xx = x + kx - R;
+        float ux = 0.f, uy = 0.f;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+            const f32x2 f = *reinterpret_cast<const f32x2*>(flow + ((size_t)(n * H + yy) * W + xx) * fcs + fco);
+            ux = f[0];
+            uy = f[1];
+        }
+        ax += wx[c] * (e * ux);
+        ay += wy[c] * (e * uy);
+    }
+    const float div = 1.f / se;
+    *reinterpret_cast<f32x2*>(dst + pix * dcs + dco) = f32x2{(ax + bx) * div, (ay + by) * div};
+}
+
 int launch_reg_head(const float* dist, int dist_cs, int k, const float* flow, int fcs, int fco, const float* wx,
                     float bx, const float* wy, float by, int N, int H, int W, float* dst, int dcs, int dco,
                     hipStream_t s) {
-    hipLaunchKernelGGL(k_reg_head, dim3(grid1d((long long)N * H * W, 256)), dim3(256), 0, s, dist, dist_cs, k, flow,
+    static const bool vec = !(getenv("DFVO_REG_HEAD_V") && atoi(getenv("DFVO_REG_HEAD_V")) == 0);
+    const dim3 grid(grid1d((long long)N * H * W, 256));
+    const bool aligned = dist_cs % 4 == 0 && ((uintptr_t)dist & 15) == 0 && dist_cs >= ((k * k + 3) & ~3) && fcs % 2 == 0 &&
+                         fco % 2 == 0 && ((uintptr_t)flow & 7) == 0 && dcs % 2 == 0 && dco % 2 == 0 && ((uintptr_t)dst & 7) == 0;
+    if (vec && aligned && (k == 3 || k == 5 || k == 7)) {
+        if (k == 3)
+            hipLaunchKernelGGL(k_reg_head_v<3>, grid, dim3(256), 0, s, dist, dist_cs, flow, fcs, fco, wx, bx, wy, by, N, H, W, dst, dcs, dco);
+        else if (k == 5)
+            hipLaunchKernelGGL(k_reg_head_v<5>, grid, dim3(256), 0, s, dist, dist_cs, flow, fcs, fco, wx, bx, wy, by, N, H, W, dst, dcs, dco);
+        else
+            hipLaunchKernelGGL(k_reg_head_v<7>, grid, dim3(256), 0, s, dist, dist_cs, flow, fcs, fco, wx, bx, wy, by, N, H, W, dst, dcs, dco);
+        DFVO_HIP_CHECK(hipGetLastError());
+        return DFVO_OK;
+    }
+    hipLaunchKernelGGL(k_reg_head, grid, dim3(256), 0, s, dist, dist_cs, k, flow,
                        fcs, fco, wx, bx, wy, by, N, H, W, dst, dcs, dco);
     DFVO_HIP_CHECK(hipGetLastError());
     return DFVO_OK;

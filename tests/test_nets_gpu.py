@@ -127,6 +127,28 @@ def test_splitk_in_kernel_finish_equals_two_launch_reduction(gpu, tmp_path):
     assert np.abs(res["1"]["fwd0"]).max() > 0.1
 
 
+@pytest.mark.parametrize("knob", ["DFVO_REG_HEAD_V", "DFVO_CORR_RT"])
+def test_rewritten_kernels_leave_the_flow_bit_identical(gpu, tmp_path, knob):
+    """the register-tiled correlation kernel (DFVO_CORR_RT) and the vectorised regularisation head (DFVO_REG_HEAD_V) keep
+    the operation order of the kernels they replace: the whole flow net's output with the knob off / on, bit for bit"""
+    import os
+    import subprocess
+    import sys
+    tests = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+    for on in ("0", "1"):
+        out = str(tmp_path / ("%s_%s.npz" % (knob, on)))
+        env = dict(os.environ, DFVO_CONV_PRECISION="fp32")
+        env[knob] = on
+        code = _SPLITK_AB % {"tests": tests, "root": os.path.dirname(tests), "out": out}
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[on] = np.load(out)
+    for k in ("fwd0", "bwd0", "diff0"):
+        assert np.array_equal(res["0"][k], res["1"][k]), "%s changes %s" % (knob, k)
+    assert np.abs(res["1"]["fwd0"]).max() > 0.1
+
+
 _SPLITK_LOAD = """
 import importlib, sys, zlib
 import numpy as np, torch
