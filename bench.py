@@ -331,7 +331,14 @@ def main(argv=None):
     import torch
     rank, world, local_rank, dist = world_setup(args, torch)
     on_gpu = dist is None or dist.get_backend() == "nccl"  # (gloo: CPU test of the multi-rank logic, tests/test_bench_cpu.py)
-    if world == 1:
+    # DFVO_BENCH_ONE_DEVICE=1 (verification aid for 1-GPU boxes): every rank drives device 0 with its own pipeline, collectives
+    # over gloo on host tensors -- the chunk / halo / gather / compose logic and the single-rank equality check run on real
+    # pipelines; only RCCL itself is left out
+    one_device = world > 1 and os.environ.get("DFVO_BENCH_ONE_DEVICE") == "1" and torch.cuda.is_available()
+    if one_device:
+        on_gpu = True
+        local_rank = 0
+    if world == 1 or one_device:
         torch.cuda.set_device(0)
 
     pkg = importlib.import_module("df-vo_amd")  # noqa: F841
@@ -510,7 +517,7 @@ def main(argv=None):
         device_sync()
         dist.barrier()
         dt = time.perf_counter() - t0
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if on_gpu else "cpu")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
         status = gathered[:, 16].astype(np.int64)
