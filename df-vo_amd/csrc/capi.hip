@@ -145,8 +145,13 @@ int dfvo_conv2d(const dfvo_conv_desc* d, const float* d_src0, const float* d_src
     L.pad_mode = d->pad_mode;
     L.act = d->act;
     L.act_param = d->act_param;
+    // split-K workspace + tile tickets (as the nets own one each): process-wide, calls are serialised by the sync below
+    static DevBuf conv2d_ws;
+    static std::mutex conv2d_mu;
+    std::lock_guard<std::mutex> conv2d_lock(conv2d_mu);
+    if (!conv2d_ws.p && conv2d_ws.alloc((size_t)4 << 20) != DFVO_OK) conv2d_ws.p = nullptr;
     int rc = run_conv(L, d->N, d->H, d->W, View{d_src0, d->cs0, d->co0}, d->up0, View{d_src1, d->cs1, d->co1}, d_res,
-                      d->res_cs, d->res_co, d_dst, d->dst_cs, d->dst_co, 0, s, nullptr);
+                      d->res_cs, d->res_co, d_dst, d->dst_cs, d->dst_co, 0, s, nullptr, conv2d_ws.p ? &conv2d_ws : nullptr);
     hipError_t e = hipStreamSynchronize(s);
     (void)hipFree(dw);
     (void)hipFree(db);

@@ -61,10 +61,14 @@ __global__ __launch_bounds__(64 * WP * KSP) void conv_gemm_f16s_kernel(const Con
         ix0 = ox * p.stride - p.pad_w;
     }
     const int n0 = ytile * (32 * TC);
-    // K slice of this wave
+    // K slice of this wave.  gridDim.z > 1 (small maps that cannot fill the chip with their tiles x KSP waves): the K range
+    // is first divided over gridDim.z WORKGROUPS; their partial blocks meet in the split-K workspace and are added in
+    // workgroup order by the last one to arrive (tile tickets: splitk_last_arriver of conv_igemm_f32.hip) -- deterministic
+    // like the in-workgroup sum, and the launch streams its weights through gridDim.z times as many compute units.
     const int S = p.f16g_steps;
-    const int per = (S + KSP - 1) / KSP;
-    const int s0 = wk * per;
+    const int nz = __builtin_amdgcn_readfirstlane((int)gridDim.z), zb = __builtin_amdgcn_readfirstlane((int)blockIdx.z);
+    const int per = (S + KSP * nz - 1) / (KSP * nz);
+    const int s0 = (zb * KSP + wk) * per < S ? (zb * KSP + wk) * per : S;
     const int s1 = s0 + per < S ? s0 + per : S;
 
     // Everything the gather needs from the parameter block lives in SGPRs for the whole kernel.  (Left to itself the
@@ -186,6 +190,23 @@ __global__ __launch_bounds__(64 * WP * KSP) void conv_gemm_f16s_kernel(const Con
         for (int e = 0; e < 16; ++e) mine[(i * 16 + e) * 64 + lane] = am[i][e] + F16S_LO_UNSCALE * ax[i][e];
     __syncthreads();
     const bool vec_ok = conv_vec_ok(p);
+    const unsigned tile = blockIdx.x;
+    bool finish = true;
+    if (nz > 1) {  // hand the workgroup's partial block over, then only the last workgroup of the tile goes on
+        float* const wsb = p.ws + ((size_t)(tile * nz + zb) * (WP * 4 * TC)) * 256;
+        for (int q = wk; q < 4 * TC; q += KSP) {
+            const int i = q >> 2, g = q & 3;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            for (int z = 0; z < KSP; ++z) {
+                const float* src = f16g_red + (size_t)((wp * KSP + z) * TC + i) * 16 * 64 + (4 * g) * 64 + lane;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = z == 0 ? src[e * 64] : v[e] + src[e * 64];
+            }
+            splitk_store(wsb + ((size_t)(wp * 4 * TC + q) * 64 + lane) * 4, v);
+        }
+        finish = splitk_last_arriver(p, tile);
+    }
+    if (!finish) return;
     for (int q = wk; q < 4 * TC; q += KSP) {
         const int i = q >> 2, g = q & 3;
         const int col0 = n0 + i * 32 + 8 * g + 4 * kb;
@@ -197,10 +218,17 @@ __global__ __launch_bounds__(64 * WP * KSP) void conv_gemm_f16s_kernel(const Con
             if (p.res && vm) r = *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.res_cs + p.res_co + col0);
         }
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        for (int z = 0; z < KSP; ++z) {
-            const float* src = f16g_red + (size_t)((wp * KSP + z) * TC + i) * 16 * 64 + (4 * g) * 64 + lane;
+        if (nz > 1) {
+            for (int z = 0; z < nz; ++z) {
+                const f32x4 x = splitk_load(p.ws + ((size_t)(tile * nz + z) * (WP * 4 * TC) + (wp * 4 * TC + q)) * 256 + lane * 4);
+                v = z == 0 ? x : v + x;
+            }
+        } else {
+            for (int z = 0; z < KSP; ++z) {
+                const float* src = f16g_red + (size_t)((wp * KSP + z) * TC + i) * 16 * 64 + (4 * g) * 64 + lane;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = z == 0 ? src[e * 64] : v[e] + src[e * 64];
+                for (int e = 0; e < 4; ++e) v[e] = z == 0 ? src[e * 64] : v[e] + src[e * 64];
+            }
         }
         if (!vm) continue;
         if (fastq) {
@@ -270,9 +298,14 @@ static bool conv_f16g_ok(const ConvParams& p) {
 }
 
 template <int WP, int KSP, int TC, int PF = 3>
-static int launch_f16g_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) {
+static int launch_f16g_cfg(const ConvParams& p, hipStream_t stream, int cfg_id, int nz = 1) {
     const long long M = (long long)p.N * p.Ho * p.Wo;
     dim3 grid((unsigned)(((M + 32 * WP - 1) / (32 * WP)) * (p.wf16g_cout_pad / (32 * TC))), 1, 1);
+    // cross-workgroup K split (KSP > 1 shapes only): needs the split-K workspace and tickets of the net
+    if (KSP == 1 || !p.tile_flags || !p.ws || (long long)grid.x > p.tile_flags_n ||
+        (size_t)grid.x * nz * (WP * 4 * TC) * 256 > p.ws_floats)
+        nz = 1;
+    grid.z = (unsigned)nz;
     const size_t lds = KSP > 1 ? (size_t)WP * KSP * TC * 16 * 64 * sizeof(float) : 0;
     if (lds > 48 * 1024)
         if (int rc_lds = ensure_dyn_lds((const void*)conv_gemm_f16s_kernel<WP, KSP, TC, PF>, lds)) return rc_lds;
@@ -288,7 +321,7 @@ static int launch_f16g_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) 
     if (g_prof) {
         DFVO_HIP_CHECK(hipEventRecord(pe.e1, stream));
         pe.flops = p.useful_flops;
-        const int sh[12] = {p.N, p.H, p.W, p.Ho, p.Wo, (p.G0 + p.G1) * 4, p.cout, p.kh, p.stride, (int)grid.x, TC, KSP};
+        const int sh[12] = {p.N, p.H, p.W, p.Ho, p.Wo, (p.G0 + p.G1) * 4, p.cout, p.kh, p.stride, (int)grid.x, TC, KSP * 100 + nz};
         for (int i = 0; i < 12; ++i) pe.shape[i] = sh[i];
         g_prof->push_back(pe);
     }
@@ -324,20 +357,32 @@ static int launch_f16g(const ConvParams& p, hipStream_t stream) {
     while (ksp < (tc2 ? 8 : 16) && tiles * ksp * 2 <= tgt && p.f16g_steps >= 4 * ksp * 2) ksp *= 2;
     if (force_ksp == 1 || force_ksp == 2 || force_ksp == 4 || force_ksp == 8) ksp = force_ksp;
     if (ksp == 1 && stream_tc1) tc2 = false;
+    // K divided over workgroups as well while the tiles alone leave compute units idle (the depth net's 6 x 20 / 12 x 40
+    // layers, pyramid levels 5 / 6: 64 .. 120 tiles on 256 CUs) and every wave keeps at least three steps.
+    // DFVO_F16G_NZ: 0 = off (DEFAULT), -1 = this rule, 2 / 4 = forced.  Measured (profiles/r3af_nz_ab.txt): the K-sliced
+    // launches get 7 % shorter one pass at a time (1.20 -> 1.12 ms per pair) and the pair rate DROPS 1.3 % (280.5 -> 276.8,
+    // three alternations): these launches are latency chains, not bandwidth per compute unit, and twice the workgroups
+    // take slots from the window kernels of the other streams.
+    static const int force_nz = getenv("DFVO_F16G_NZ") ? atoi(getenv("DFVO_F16G_NZ")) : 0;
+    int nz = 1;
+    if (ksp > 1)
+        while (nz < 4 && tiles * nz * 2 <= 320 && p.f16g_steps >= ksp * nz * 2 * 3) nz *= 2;
+    if (force_nz == 0) nz = 1;
+    if ((force_nz == 2 || force_nz == 4) && ksp > 1) nz = force_nz;
     const int cfg = ksp == 1 ? 20 : 21;  // profile rows: 20 streaming (KSP = 1), 21 K-sliced small maps
     if (tc2) {
         switch (ksp) {
             case 1: return launch_f16g_cfg<4, 1, 2>(p, stream, cfg);
-            case 2: return launch_f16g_cfg<2, 2, 2>(p, stream, cfg);
-            case 4: return launch_f16g_cfg<1, 4, 2>(p, stream, cfg);
-            default: return launch_f16g_cfg<1, 8, 2>(p, stream, cfg);
+            case 2: return launch_f16g_cfg<2, 2, 2>(p, stream, cfg, nz);
+            case 4: return launch_f16g_cfg<1, 4, 2>(p, stream, cfg, nz);
+            default: return launch_f16g_cfg<1, 8, 2>(p, stream, cfg, nz);
         }
     }
     switch (ksp) {
         case 1: return launch_f16g_cfg<4, 1, 1>(p, stream, cfg);
-        case 2: return launch_f16g_cfg<2, 2, 1>(p, stream, cfg);
-        case 4: return deep == 8 ? launch_f16g_cfg<1, 4, 1, 8>(p, stream, cfg) : launch_f16g_cfg<1, 4, 1>(p, stream, cfg);
-        case 8: return deep == 8 ? launch_f16g_cfg<1, 8, 1, 8>(p, stream, cfg) : launch_f16g_cfg<1, 8, 1>(p, stream, cfg);
-        default: return deep == 8 ? launch_f16g_cfg<1, 16, 1, 4>(p, stream, cfg) : launch_f16g_cfg<1, 16, 1>(p, stream, cfg);
+        case 2: return launch_f16g_cfg<2, 2, 1>(p, stream, cfg, nz);
+        case 4: return deep == 8 ? launch_f16g_cfg<1, 4, 1, 8>(p, stream, cfg, nz) : launch_f16g_cfg<1, 4, 1>(p, stream, cfg, nz);
+        case 8: return deep == 8 ? launch_f16g_cfg<1, 8, 1, 8>(p, stream, cfg, nz) : launch_f16g_cfg<1, 8, 1>(p, stream, cfg, nz);
+        default: return deep == 8 ? launch_f16g_cfg<1, 16, 1, 4>(p, stream, cfg, nz) : launch_f16g_cfg<1, 16, 1>(p, stream, cfg, nz);
     }
 }

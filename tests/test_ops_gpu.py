@@ -62,6 +62,10 @@ CASES = [
     ("dec_refl_up_cat_elu", 1, 12, 20, 128, 128, 128, 3, 3, 1, (1, 1), 1, 3, 1, False),
     ("dec_refl_sigmoid_16_1", 1, 32, 48, 16, 0, 1, 3, 3, 1, (1, 1), 1, 4, 0, False),
     ("resnet_512_small", 1, 6, 20, 512, 0, 512, 3, 3, 1, (1, 1), 0, 2, 0, True),
+    # small maps whose K range is divided over workgroups as well (conv_gemm_f16s.h, gridDim.z > 1) in f16x3 mode
+    ("resnet_256_12x40", 1, 12, 40, 256, 0, 256, 3, 3, 1, (1, 1), 0, 2, 0, True),
+    ("flow_L5_128_11x38", 2, 11, 38, 128, 0, 128, 3, 3, 1, (1, 1), 0, 1, 0, False),
+    ("flow_L6_192_6x19_cat", 2, 6, 19, 192, 52, 128, 3, 3, 1, (1, 1), 0, 1, 0, False),
     ("big_M_128_128", 2, 96, 160, 128, 0, 128, 3, 3, 1, (1, 1), 0, 1, 0, False),
     ("big_M_64_32", 2, 96, 160, 64, 0, 32, 3, 3, 1, (1, 1), 0, 1, 0, False),
     ("big_M_32_2_5x5", 2, 96, 160, 32, 0, 2, 5, 5, 1, (2, 2), 0, 0, 0, True),
