@@ -262,3 +262,19 @@ def test_f16x3_window_conv(gpu, case):
         errs[mode] = err / scale
     assert errs[b"fp32"] <= 4e-6   # K up to 3500 terms, split-K summation order
     assert errs[b"f16x3"] <= 4e-6
+
+
+@pytest.mark.gpu
+def test_conv_small_maps_with_k_divided_over_workgroups(gpu):
+    """DFVO_F16G_NZ=-1 (off by default: slower inside the pipeline): the small-map cases again with the K range divided over
+    workgroups and handed over through the split-K workspace -- the environment switch is read once per process, hence a
+    child pytest over exactly those cases"""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, DFVO_F16G_NZ="-1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
+                        "test_conv and (resnet_512_small or resnet_256_12x40 or flow_L5 or flow_L6 or 192_out or dec_refl_up_cat_elu)"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert "14 passed" in r.stdout, r.stdout[-500:]  # seven cases x two precisions
