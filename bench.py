@@ -526,8 +526,8 @@ def main(argv=None):
             same = bool(np.array_equal(rel1.reshape(n_total, 16)[st1 != 1], gathered[:, :16][st1 != 1]) and np.array_equal(st1, status))
             seq_check = {"pairs": int(n_total), "equal_to_single_rank_run": same,
                          "trajectory_end": [round(float(v), 4) for v in traj[-1][:3, 3]]}
-            if not same:  # reported, not fatal: the line still carries the measured rate (exact-fp32 layers are autotuned by
-                # timing per process, and a different K-split on another rank changes a flow by rounding)
+            if not same:  # reported, not fatal: the line still carries the measured rate (with DFVO_CONV_AUTOTUNE=1 the layer
+                # configurations are timing-based per process, and a different K-split on another rank changes a flow by rounding)
                 seq_check["max_abs_pose_diff"] = float(np.abs(rel1.reshape(n_total, 16) - gathered[:, :16]).max())
                 sys.stderr.write("bench.py: the gathered poses of the %d-rank run differ from the single-rank run\n" % world)
     if (status == 2).any():
