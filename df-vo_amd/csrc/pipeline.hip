@@ -331,6 +331,11 @@ int dfvo_pipeline_enqueue_nets(dfvo_pipeline* p, int slot, const uint8_t* d_ref,
     hipStream_t sf = fn.stream;
     // frame pointers may change per pair (not captured).  d_ref == NULL: the image / feature pyramids of the reference frame
     // are carried over from the pass that saw it as its current frame (the other flow-net instance, normally)
+    // Whatever this pass is (carried or not), it overwrites this instance's pyramids: the previous pass -- normally on the
+    // OTHER instance -- may still be copying them (its carry-over reads this instance's current-frame pyramids), so this
+    // stream is ordered behind that pass's feature stage.  A carried pass waits for the same event anyway; a full pass
+    // enqueued right behind a carried one without a sync in between would otherwise race with that copy.
+    if (p->last_flow && p->last_flow != &fn && p->last_flow->e_feat) DFVO_HIP_CHECK(hipStreamWaitEvent(sf, p->last_flow->e_feat, 0));
     // DFVO_FLOW_DIRECT_OUT=1: the net writes the slot's buffers itself (one levels graph per slot, no copies behind the pass)
     static const bool direct = getenv("DFVO_FLOW_DIRECT_OUT") && atoi(getenv("DFVO_FLOW_DIRECT_OUT")) != 0;
     if (direct) {

@@ -147,6 +147,17 @@ def test_feature_carry_equals_recomputed_features(gpu, conv_precision, pipe_mod,
     pipe.enqueue_nets(0, frames[3], frames[0])
     pipe.sync()
     again_full = pipe.get_outputs(0)[:3]
+    # a full pass enqueued right behind a carried one, no sync in between: it overwrites the pyramids the carried pass
+    # (other instance) is still copying from unless the pipeline orders it behind that pass's feature stage
+    for rep in range(3):
+        pipe.enqueue_nets(0, frames[0], frames[1])
+        pipe.enqueue_nets(1, None, frames[2])
+        pipe.enqueue_nets(2, frames[2], frames[3])
+        pipe.sync()
+        carried.append(pipe.get_outputs(1)[:3])
+        full.append(full[0])
+        carried.append(pipe.get_outputs(2)[:3])
+        full.append(full[1])
     pipe.close()
     worst = 0.0
     for got, want in zip(carried + [again], full + [again_full]):
