@@ -41,6 +41,7 @@ struct dfvo_pipeline {
     hipEvent_t e_res[DFVO_PIPELINE_SLOTS] = {};
     int begun_n[DFVO_PIPELINE_SLOTS] = {};   // -1: no chain pending, -2: pending pair had no good keypoints, else keypoint count
     const double* begun_depth_override[DFVO_PIPELINE_SLOTS] = {};
+    int pending_slot = -1;  // the one pair begun and not yet collected (the chains consume ONE RandomState, in pair order)
     hipStream_t s_flow = nullptr, s_depth = nullptr, s_trk = nullptr;
     hipEvent_t e_flow[DFVO_PIPELINE_SLOTS] = {}, e_depth[DFVO_PIPELINE_SLOTS] = {};
     // per-slot outputs of the nets
@@ -439,6 +440,8 @@ int dfvo_pipeline_track_begin(dfvo_pipeline* p, int slot, const float* d_flow_ov
                               const double* d_depth_override) {
     DFVO_ARG_CHECK(p && (slot >= 0 && slot < DFVO_PIPELINE_SLOTS), "dfvo_pipeline_track_begin: bad argument");
     DFVO_ARG_CHECK(p->begun_n[slot] == -1, "dfvo_pipeline_track_begin: the slot's previous pair was not collected (track_end)");
+    DFVO_ARG_CHECK(p->pending_slot == -1, "dfvo_pipeline_track_begin: another pair is begun and not yet collected -- the PnP decision "
+                                          "of track_end (RandomState draws) comes before the next pair's chain");
     const dfvo_pipeline_cfg& c = p->cfg;
     hipStream_t s = p->s_trk;
     TrackerBuffers& tb = p->tbs[slot];
@@ -453,6 +456,7 @@ int dfvo_pipeline_track_begin(dfvo_pipeline* p, int slot, const float* d_flow_ov
     p->begun_depth_override[slot] = d_depth_override;
     if (!info[1]) {
         p->begun_n[slot] = -2;
+        p->pending_slot = slot;
         return DFVO_OK;
     }
     const int n = info[0];
@@ -477,6 +481,7 @@ int dfvo_pipeline_track_begin(dfvo_pipeline* p, int slot, const float* d_flow_ov
     DFVO_HIP_CHECK(hipMemcpyAsync(hr + sizeof(PoseState), tb.scale_out, sizeof(ScaleResult), hipMemcpyDeviceToHost, s));
     DFVO_HIP_CHECK(hipEventRecord(p->e_res[slot], s));
     p->begun_n[slot] = n;
+    p->pending_slot = slot;
     return DFVO_OK;
 }
 
@@ -499,6 +504,7 @@ int dfvo_pipeline_track_end(dfvo_pipeline* p, int slot, dfvo_track_out* out) {
     const int n = p->begun_n[slot];
     const double* d_depth_override = p->begun_depth_override[slot];
     p->begun_n[slot] = -1;
+    p->pending_slot = -1;
     memset(out, 0, sizeof(*out));
     for (int i = 0; i < 3; i++) out->R[i * 4] = 1.0;
     const int* info = p->h_info[slot];

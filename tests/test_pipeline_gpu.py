@@ -165,3 +165,25 @@ def test_feature_carry_equals_recomputed_features(gpu, conv_precision, pipe_mod,
             worst = max(worst, float(np.abs(g - wnt).max()))
     print("feature carry vs recomputed: max |diff| %.3g px (0 = bit-identical)" % worst)
     assert worst == 0.0
+
+
+def test_track_begin_refuses_a_second_pending_pair(gpu, pipe_mod):
+    """track_begin(k + 1) before track_end(k) would put pair k + 1's RandomState draws ahead of pair k's PnP decision: refused"""
+    h, w = 192, 640
+    sc = rigid_scene(h, w, seed=5)
+    pipe = pipe_mod.TrackingPipeline(h, w, 192, 640, sc["K"], O.liteflownet_state_dict(4869), O.monodepth2_state_dict(4869), seed=1)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    ref, cur = image_pair(h, w, seed=11)
+    dref, dcur = d(ref), d(cur)
+    dflow, ddiff, ddepth = d(sc["flow"]), d(sc["diff"]), d(sc["depth_cur"])
+    pipe.set_ref_depth(depth=d(sc["depth_ref"]))
+    pipe.enqueue_nets(0, dref, dcur)
+    pipe.enqueue_nets(1, dcur, dref)
+    pipe.track_begin(0, dflow, ddiff, ddepth)
+    with pytest.raises(gpu.DfvoError, match="not yet collected"):
+        pipe.track_begin(1, dflow, ddiff, ddepth)
+    out0 = pipe.track_end(0)
+    pipe.track_begin(1, dflow, ddiff, ddepth)
+    out1 = pipe.track_end(1)
+    assert out0.status in (0, 3) and out1.status in (0, 3)
+    pipe.close()
