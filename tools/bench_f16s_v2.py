@@ -28,6 +28,18 @@ for name, n, h, w, c0, c1, cout in LAYERS:
     x0 = torch.randn(n, c0, h, w, generator=g)
     x1 = torch.randn(n, c1, h, w, generator=g) if c1 else None
     wt = torch.randn(cout, c0 + c1, 3, 3, generator=g) * 0.05
+    # OPERANDS=zero_x / zero_all / const (timing only): the same instruction stream on operands that toggle fewer wires --
+    # what the launch time owes to the power limit rather than to its schedule
+    mode = os.environ.get("OPERANDS", "random")
+    if mode in ("zero_x", "zero_all"):
+        x0 = torch.zeros_like(x0)
+        x1 = torch.zeros_like(x1) if x1 is not None else None
+    if mode == "zero_all":
+        wt = torch.zeros_like(wt)
+    if mode == "const":
+        x0 = torch.full_like(x0, 0.5)
+        x1 = torch.full_like(x1, 0.5) if x1 is not None else None
+        wt = torch.full_like(wt, 0.25)
     b = torch.zeros(cout)
     gf = 2.0 * n * h * w * 9 * (c0 + c1) * cout / 1e9
     best = 1e9
@@ -40,4 +52,4 @@ for name, n, h, w, c0, c1, cout in LAYERS:
     if not name.startswith("c5"):
         tot += best
     print("%-16s %6.1f GF %8.1f us %6.1f TF/s-eq  crc %08x" % (name, gf, best * 1e3, gf / best, zlib.crc32(out.numpy().tobytes()) & 0xffffffff), flush=True)
-print("V2=%s sum of the KITTI layers %.1f us" % (os.environ.get("DFVO_F16S_V2", "0"), tot * 1e3))
+print("V2=%s operands %s: sum of the KITTI layers %.1f us" % (os.environ.get("DFVO_F16S_V2", "1"), os.environ.get("OPERANDS", "random"), tot * 1e3))
