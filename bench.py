@@ -509,11 +509,11 @@ def main(argv=None):
         # RandomState (df-vo_amd/sequence.py), ONE all-gather of pose + status rows, prefix composition on every rank
         n_total = world * args.steps
         frames = PingPong()
-        smod.track_chunk(pipe, frames, 0, args.warmup, rng_mode="per_pair")
+        smod.track_chunk(pipe, frames, 0, args.warmup, rng_mode="per_pair", carry_features=carry[0])
         dist.barrier()
         device_sync()
         t0 = time.perf_counter()
-        traj, gathered = smod.run_sequence(pipe, frames, n_total + 1, world, rank, dist, rng_mode="per_pair")
+        traj, gathered = smod.run_sequence(pipe, frames, n_total + 1, world, rank, dist, rng_mode="per_pair", carry_features=carry[0])
         device_sync()
         dist.barrier()
         dt = time.perf_counter() - t0
@@ -522,7 +522,7 @@ def main(argv=None):
         dt = float(tmax.item())
         status = gathered[:, 16].astype(np.int64)
         if rank == 0 and on_gpu:  # outside the timed region: the same sequence tracked by this rank alone
-            rel1, st1 = smod.track_chunk(pipe, frames, 0, n_total, rng_mode="per_pair")
+            rel1, st1 = smod.track_chunk(pipe, frames, 0, n_total, rng_mode="per_pair", carry_features=carry[0])
             same = bool(np.array_equal(rel1.reshape(n_total, 16)[st1 != 1], gathered[:, :16][st1 != 1]) and np.array_equal(st1, status))
             seq_check = {"pairs": int(n_total), "equal_to_single_rank_run": same,
                          "trajectory_end": [round(float(v), 4) for v in traj[-1][:3, 3]]}

@@ -64,7 +64,7 @@ def track_chunk(pipe, frames, lo, hi, seed=4869, rng_mode="sequential", ahead=3,
 
 
 def run_sequence(pipe, frames, n_frames, world=1, rank=0, dist=None, seed=4869, rng_mode=None, ahead=3, collect=None,
-                 compose="host"):
+                 compose="host", carry_features=True):
     """data-parallel tracking of an n_frames sequence: contiguous chunk per rank (dist.chunk_bounds), ONE all-gather of
     the relative poses + status words (RCCL when `dist` runs the nccl backend), then the sequential prefix composition
     that reproduces DFVO.update_global_pose incl. the constant-motion rule (dfvo.py:109-119,157-161).
@@ -76,7 +76,7 @@ def run_sequence(pipe, frames, n_frames, world=1, rank=0, dist=None, seed=4869, 
     if world > 1 and rng_mode == "sequential":
         raise ValueError("the sequential numpy RandomState cannot be reproduced frame-parallel; use rng_mode='per_pair'")
     lo, hi = dmod.chunk_bounds(n_frames - 1, world, rank)
-    rel, status = track_chunk(pipe, frames, lo, hi, seed, rng_mode, ahead, collect=collect)
+    rel, status = track_chunk(pipe, frames, lo, hi, seed, rng_mode, ahead, collect=collect, carry_features=carry_features)
     gathered = dmod.allgather_poses(rel, status, world, rank, dist)
     traj = dmod.compose_trajectory_device(gathered) if compose == "device" else dmod.compose_trajectory(gathered)
     return traj, gathered
