@@ -92,6 +92,9 @@ struct FlowNet {
     std::vector<ConvLayer> feat_convs;  // 12 convs of Features
     struct Level {
         ConvLayer m_feat, m_main[4], s_feat, s_main[4], r_feat, r_main[6], r_dist[2];
+        ConvLayer feat3;  // level 2: m_feat | s_feat | r_feat as one 1x1 convolution (32 -> 256)
+        DevBuf f3;
+        bool has_feat3 = false;
         bool has_mfeat = false, has_upflow = false, has_upcorr = false, has_rfeat = false, dist_sep = false;
         DevBuf upflow_w, upcorr_w, scale_wx, scale_wy;
         float scale_bx = 0.f, scale_by = 0.f;

@@ -503,6 +503,34 @@ int FlowNet::finalize() {
             leaky(L.r_feat, 0, 0);
             DFVO_TRY(L.rfeat.alloc(px * 128));
         }
+        // Level 2: the three 1x1 `moduleFeat` convolutions of Matching / Subpixel / Regularization (32 -> 64, 64, 128, all
+        // LeakyReLU 0.1) read the same feature map: one 32 -> 256 launch into one buffer, read back as channel views.  Every
+        // output channel keeps its own dot product over the same K order: bit-identical (tests/test_nets_gpu.py).  Opt-in
+        // (DFVO_FLOW_FUSE_FEAT=1): two launches and 13.6 MB of reads fewer per pass, pair rate 286.4 vs 288.0 without it over
+        // three alternations (profiles/r3am_fuse_feat_ab.txt) -- no gain to show for a second code path by default.
+        static const bool fuse_feat = getenv("DFVO_FLOW_FUSE_FEAT") && atoi(getenv("DFVO_FLOW_FUSE_FEAT")) != 0;
+        if (fuse_feat && L.has_mfeat && L.has_rfeat) {
+            const char* mods[3] = {"moduleMatching", "moduleSubpixel", "moduleRegularization"};
+            ParamStore cat;
+            HostTensor wt, bt;
+            for (int i = 0; i < 3; ++i) {
+                const HostTensor* w = params.get(lvl_name(mods[i], l, "moduleFeat.0.weight"));
+                const HostTensor* b = params.get(lvl_name(mods[i], l, "moduleFeat.0.bias"));
+                DFVO_ARG_CHECK(w && b && w->shape.size() == 4 && w->shape[1] == C && w->shape[2] == 1 && w->shape[3] == 1,
+                               "moduleFeat weights of level 2");
+                wt.data.insert(wt.data.end(), w->data.begin(), w->data.end());
+                bt.data.insert(bt.data.end(), b->data.begin(), b->data.end());
+            }
+            wt.shape = {(int)(wt.data.size() / C), C, 1, 1};
+            bt.shape = {(int)bt.data.size()};
+            DFVO_ARG_CHECK(wt.shape[0] == 256 && bt.shape[0] == 256, "moduleFeat weights of level 2: 64 + 64 + 128 outputs");
+            cat.t["w"] = wt;
+            cat.t["b"] = bt;
+            DFVO_TRY(make_conv(cat, "w", "b", C, 0, M, nullptr, nullptr, &L.feat3));
+            leaky(L.feat3, 0, 0);
+            DFVO_TRY(L.f3.alloc(px * 256));
+            L.has_feat3 = true;
+        }
         const int rc0[6] = {3, 128, 128, 64, 64, 32}, rc1[6] = {Cr, 0, 0, 0, 0, 0};
         for (int i = 0; i < 6; ++i) {
             const std::string idx = std::to_string(2 * i);
@@ -649,7 +677,15 @@ int FlowNet::enqueue_levels(float* d_fwd, float* d_bwd, float* d_diff) {
         // ------------------------------ Matching (lite_flow_net.py:132-152)
         const float* mf = feat[l].p;
         const float* sf = feat[l].p;
-        if (L.has_mfeat) {
+        const float* rf = feat[l].p;
+        int mcs = Cm, mco = 0, scs = Cm, sco = 0, rcs = Cr, rco = 0;  // channel stride / offset of the three views
+        if (L.has_feat3) {
+            DFVO_TRY(run_conv(L.feat3, N, h, w, View{feat[l].p, C, 0}, 0, none, nullptr, 0, 0, L.f3.p, 256, 0, 0, s, &fl, &splitk));
+            mf = sf = rf = L.f3.p;
+            mcs = scs = rcs = 256;
+            sco = 64;
+            rco = 128;
+        } else if (L.has_mfeat) {
             DFVO_TRY(run_conv(L.m_feat, N, h, w, View{feat[l].p, C, 0}, 0, none, nullptr, 0, 0, L.mfeat.p, 64, 0, 0, s,
                               &fl, &splitk));
             DFVO_TRY(run_conv(L.s_feat, N, h, w, View{feat[l].p, C, 0}, 0, none, nullptr, 0, 0, L.sfeat.p, 64, 0, 0, s,
@@ -660,11 +696,11 @@ int FlowNet::enqueue_levels(float* d_fwd, float* d_bwd, float* d_diff) {
         const int stride = L.has_upcorr ? 2 : 1;
         if (flow_prev) {
             DFVO_TRY(launch_deconv_dw(flow_prev, 4, 0, N, h / 2, w / 2, 2, L.upflow_w.p, L.flow_up.p, 4, 0, s));
-            DFVO_TRY(launch_warp(mf, Cm, 0, 1, L.flow_up.p, 4, 0, dbl, N, h, w, Cm, lin_x[l].p, lin_y[l].p, L.warped.p,
+            DFVO_TRY(launch_warp(mf, mcs, mco, 1, L.flow_up.p, 4, 0, dbl, N, h, w, Cm, lin_x[l].p, lin_y[l].p, L.warped.p,
                                  Cm, 0, 0, s));
-            DFVO_TRY(launch_correlation(mf, Cm, 0, L.warped.p, Cm, 0, 0, N, h, w, Cm, stride, L.corr.p, 52, 0.1f, s));
+            DFVO_TRY(launch_correlation(mf, mcs, mco, L.warped.p, Cm, 0, 0, N, h, w, Cm, stride, L.corr.p, 52, 0.1f, s));
         } else {
-            DFVO_TRY(launch_correlation(mf, Cm, 0, mf, Cm, 0, 1, N, h, w, Cm, stride, L.corr.p, 52, 0.1f, s));
+            DFVO_TRY(launch_correlation(mf, mcs, mco, mf, mcs, mco, 1, N, h, w, Cm, stride, L.corr.p, 52, 0.1f, s));
         }
         fl += 2.0 * N * cdiv(h, stride) * cdiv(w, stride) * 49.0 * Cm;
         const float* corr = L.corr.p;
@@ -679,9 +715,9 @@ int FlowNet::enqueue_levels(float* d_fwd, float* d_bwd, float* d_diff) {
         DFVO_TRY(run_conv(L.m_main[3], N, h, w, View{L.x32.p, 32, 0}, 0, none, flow_prev ? L.flow_up.p : nullptr, 4, 0,
                           L.flowM.p, 4, 0, 0, s, &fl, &splitk));
         // ------------------------------ Subpixel (lite_flow_net.py:182-190)
-        DFVO_TRY(launch_warp(sf, Cm, 0, 1, L.flowM.p, 4, 0, dbl, N, h, w, Cm, lin_x[l].p, lin_y[l].p, L.b1.p, Cm + 4, 0,
+        DFVO_TRY(launch_warp(sf, scs, sco, 1, L.flowM.p, 4, 0, dbl, N, h, w, Cm, lin_x[l].p, lin_y[l].p, L.b1.p, Cm + 4, 0,
                              1, s));
-        DFVO_TRY(run_conv(L.s_main[0], N, h, w, View{sf, Cm, 0}, 0, View{L.b1.p, Cm + 4, 0}, nullptr, 0, 0, L.x128b.p,
+        DFVO_TRY(run_conv(L.s_main[0], N, h, w, View{sf, scs, sco}, 0, View{L.b1.p, Cm + 4, 0}, nullptr, 0, 0, L.x128b.p,
                           128, 0, 0, s, &fl, &splitk));
         DFVO_TRY(run_conv(L.s_main[1], N, h, w, View{L.x128b.p, 128, 0}, 0, none, nullptr, 0, 0, L.x64b.p, 64, 0, 0, s,
                           &fl, &splitk));
@@ -692,13 +728,12 @@ int FlowNet::enqueue_levels(float* d_fwd, float* d_bwd, float* d_diff) {
         // ------------------------------ Regularization (lite_flow_net.py:243-264)
         DFVO_TRY(launch_flow_mean(L.flowS.p, 4, 0, N, h * w, nullptr, L.mean.p, s));
         DFVO_TRY(launch_reg_prep(img[l].p, L.flowS.p, 4, 0, dbl, L.mean.p, N, h, w, lin_x[l].p, lin_y[l].p, L.r0.p, s));
-        const float* rf = feat[l].p;
-        if (L.has_rfeat) {
+        if (L.has_rfeat && !L.has_feat3) {
             DFVO_TRY(run_conv(L.r_feat, N, h, w, View{feat[l].p, C, 0}, 0, none, nullptr, 0, 0, L.rfeat.p, 128, 0, 0, s,
                               &fl, &splitk));
             rf = L.rfeat.p;
         }
-        DFVO_TRY(run_conv(L.r_main[0], N, h, w, View{L.r0.p, 4, 0}, 0, View{rf, Cr, 0}, nullptr, 0, 0, L.x128.p, 128, 0,
+        DFVO_TRY(run_conv(L.r_main[0], N, h, w, View{L.r0.p, 4, 0}, 0, View{rf, rcs, rco}, nullptr, 0, 0, L.x128.p, 128, 0,
                           0, s, &fl, &splitk));
         DFVO_TRY(run_conv(L.r_main[1], N, h, w, View{L.x128.p, 128, 0}, 0, none, nullptr, 0, 0, L.x128b.p, 128, 0, 0, s,
                           &fl, &splitk));
@@ -839,6 +874,8 @@ void FlowNet::destroy() {
         free_conv(&L.m_feat);
         free_conv(&L.s_feat);
         free_conv(&L.r_feat);
+        free_conv(&L.feat3);
+        L.f3.release();
         for (auto& c : L.m_main) free_conv(&c);
         for (auto& c : L.s_main) free_conv(&c);
         for (auto& c : L.r_main) free_conv(&c);
