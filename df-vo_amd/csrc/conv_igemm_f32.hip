@@ -92,7 +92,8 @@ template <int NQ>
 struct ConvEpi {
     f32x4 b[NQ];
     int col0[NQ];
-    float slope;  // LeakyReLU a / ReLU 0 / none 1 as one formula: v > 0 ? v : v * slope
+    float slope;  // LeakyReLU a / none 1 as one formula: v > 0 ? v : v * slope; ReLU selects +0 (as apply_act does)
+    bool relu;
     bool fast;    // every quad of every lane of the wave takes the vector path
 };
 // col0_of(q): first cout of quad q for this lane
@@ -106,6 +107,7 @@ __device__ __forceinline__ void conv_epi_init(const ConvParams& p, ConvEpi<NQ>& 
     }
     c.fast = __all(ok ? 1 : 0) != 0;
     c.slope = p.act == ACT_LEAKY ? p.act_param : (p.act == ACT_RELU ? 0.f : 1.f);
+    c.relu = p.act == ACT_RELU;
     if (c.fast) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) c.b[q] = *reinterpret_cast<const f32x4*>(p.bias + c.col0[q]);
@@ -128,7 +130,7 @@ __device__ __forceinline__ void conv_epi_row_act(const ConvParams& p, const Conv
             f32x4 x = get(q0 + q) + c.b[q0 + q];
             if (p.res) x += r[q];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) x[e] = ELU ? (x[e] > 0.f ? x[e] : p.act_param * expm1f(x[e])) : (x[e] > 0.f ? x[e] : x[e] * c.slope);
+            for (int e = 0; e < 4; ++e) x[e] = ELU ? (x[e] > 0.f ? x[e] : p.act_param * expm1f(x[e])) : (x[e] > 0.f ? x[e] : (c.relu ? 0.f : x[e] * c.slope));
             *reinterpret_cast<f32x4*>(d + c.col0[q0 + q]) = x;
         }
     }
@@ -1396,7 +1398,7 @@ int launch_conv(const ConvParams& p, hipStream_t stream) {
     }
     if (p.wf16 && conv_f16s_ok(p)) {  // f16x3: the 3x3 / stride-1 layers whose map fills the chip
         const int rc2 = launch_f16s2(p, stream, 19);  // one-wave-per-SIMD skeleton where the grid is large enough
-        return rc2 >= 0 ? rc2 : launch_f16s(p, stream, 19);
+        return rc2 != F16S2_NOT_APPLICABLE ? rc2 : launch_f16s(p, stream, 19);  // errors (negative) propagate
     }
     if (conv_f16g_ok(p)) return launch_f16g(p, stream);  // f16x3: everything else (small maps, 1x1, k x 1, stride 2, 7x7)
     if (conv_use_window(p, bn) && p.kh == 7) return launch_win3<4, 1, 2, 1, 7>(p, stream, 16);

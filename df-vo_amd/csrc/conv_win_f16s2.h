@@ -311,32 +311,34 @@ static int launch_f16s2_cfg(const ConvParams& p, hipStream_t stream, int cfg_id)
 }
 
 // Tile choice for the one-wave-per-SIMD skeleton (one workgroup per CU): the rows per tile that minimise
-// rounds x rows for the layer's grid among the instantiated shapes.  Returns -1 when the layer should stay on the first
+// rounds x rows for the layer's grid among the instantiated shapes.  Returns F16S2_NOT_APPLICABLE (positive: every
+// DFVO_ERR_* code is negative) when the layer should stay on the first
 // skeleton (small grids: fewer than ~200 workgroups cannot fill the chip at one workgroup per CU).
+constexpr int F16S2_NOT_APPLICABLE = 1;
 static int launch_f16s2(const ConvParams& p, hipStream_t stream, int cfg_id) {
     // default on: per layer the two skeletons are within 2 % of each other (tools/bench_f16s_v2.py), inside the pipeline the
     // one-wave-per-SIMD one gives +3 % pairs/s (half the resident net waves next to the solver's kernels).
     // DFVO_F16S_V2=0 restores the first skeleton everywhere.
     static const int mode = getenv("DFVO_F16S_V2") ? atoi(getenv("DFVO_F16S_V2")) : 1;
-    if (!mode) return -1;
+    if (!mode) return F16S2_NOT_APPLICABLE;
     const int ncu = 256;
     auto cost = [&](long long blocks, int rows) { return blocks <= 0 ? (1LL << 60) : ((blocks + ncu - 1) / ncu) * rows; };
     if (p.wf16_cout_pad % 128 == 0) {
         // (an 8-row tile -- 256 accumulator registers -- does not fit: the allocator spills inside the tap loop)
         const long long b3 = f16s2_blocks<2, 2, 2, 3>(p), b2 = f16s2_blocks<2, 2, 2, 2>(p);
-        if (b2 < 200) return -1;
+        if (b2 < 200) return F16S2_NOT_APPLICABLE;
         const long long c3 = cost(b3, 6), c2 = cost(b2, 4) * 11 / 10;  // (small tiles: fewer MFMAs per load)
         if ((mode & 2) || c3 <= c2) return launch_f16s2_cfg<2, 2, 2, 3>(p, stream, cfg_id);
         return launch_f16s2_cfg<2, 2, 2, 2>(p, stream, cfg_id);
     }
     if (p.wf16_cout_pad % 64 == 0) {
         const long long b3 = f16s2_blocks<1, 4, 2, 3>(p), b2 = f16s2_blocks<1, 4, 2, 2>(p);
-        if (b2 < 200) return -1;
+        if (b2 < 200) return F16S2_NOT_APPLICABLE;
         if ((mode & 2) || cost(b3, 12) <= cost(b2, 8)) return launch_f16s2_cfg<1, 4, 2, 3>(p, stream, cfg_id);
         return launch_f16s2_cfg<1, 4, 2, 2>(p, stream, cfg_id);
     }
     const long long b3 = f16s2_blocks<1, 4, 1, 3>(p), b2 = f16s2_blocks<1, 4, 1, 2>(p);
-    if (b2 < 200) return -1;
+    if (b2 < 200) return F16S2_NOT_APPLICABLE;
     if ((mode & 2) || cost(b3, 12) <= cost(b2, 8)) return launch_f16s2_cfg<1, 4, 1, 3>(p, stream, cfg_id);
     return launch_f16s2_cfg<1, 4, 1, 2>(p, stream, cfg_id);
 }

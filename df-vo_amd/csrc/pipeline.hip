@@ -44,6 +44,10 @@ struct dfvo_pipeline {
     int pending_slot = -1;  // the one pair begun and not yet collected (the chains consume ONE RandomState, in pair order)
     hipStream_t s_flow = nullptr, s_depth = nullptr, s_trk = nullptr;
     hipEvent_t e_flow[DFVO_PIPELINE_SLOTS] = {}, e_depth[DFVO_PIPELINE_SLOTS] = {};
+    // the roll-over copy ref_depth <- proc_depth[slot] (s_trk) has read its source / written its target: the depth stream's
+    // next writers of either wait for it on the device (recorded by roll_ref_depth; null until the first roll-over)
+    hipEvent_t e_roll = nullptr;
+    bool roll_pending = false;
     // per-slot outputs of the nets
     float *fwd[DFVO_PIPELINE_SLOTS] = {}, *bwd[DFVO_PIPELINE_SLOTS] = {}, *diff[DFVO_PIPELINE_SLOTS] = {};
     float* raw_depth[DFVO_PIPELINE_SLOTS] = {};
@@ -246,6 +250,7 @@ void dfvo_pipeline_destroy(dfvo_pipeline* p) {
             if (q) (void)hipFree(q);
         if (p->e_flow[i]) (void)hipEventDestroy(p->e_flow[i]);
         if (p->e_depth[i]) (void)hipEventDestroy(p->e_depth[i]);
+        if (i == 0 && p->e_roll) (void)hipEventDestroy(p->e_roll);
     }
     if (p->depth_small) (void)hipFree(p->depth_small);
     p->feed_resize.release();
@@ -323,6 +328,9 @@ int dfvo_pipeline_enqueue_nets(dfvo_pipeline* p, int slot, const uint8_t* d_ref,
     const dfvo_pipeline_cfg& c = p->cfg;
     const int y0 = (int)(p->H * c.depth_crop[0]), y1 = (int)(p->H * c.depth_crop[1]);
     const int x0 = (int)(p->W * c.depth_crop[2]), x1 = (int)(p->W * c.depth_crop[3]);
+    // proc_depth[slot] may still be the source of the previous occupant's roll-over copy on s_trk (track_end does not
+    // wait for it on the host): order the overwrite behind it.  Placed after the net, so nothing stalls in practice.
+    if (p->roll_pending) DFVO_HIP_CHECK(hipStreamWaitEvent(p->s_depth, p->e_roll, 0));
     P_TRY(launch_depth_post(p->depth_small, p->feedH, p->feedW, p->H, p->W, y0, y1, x0, x1, (float)c.min_depth,
                             (float)c.max_depth, p->raw_depth[slot], p->proc_depth[slot], p->s_depth));
     DFVO_HIP_CHECK(hipEventRecord(p->e_depth[slot], p->s_depth));
@@ -364,6 +372,7 @@ int dfvo_pipeline_set_ref_depth(dfvo_pipeline* p, const uint8_t* d_feed, const d
         const dfvo_pipeline_cfg& c = p->cfg;
         const int y0 = (int)(p->H * c.depth_crop[0]), y1 = (int)(p->H * c.depth_crop[1]);
         const int x0 = (int)(p->W * c.depth_crop[2]), x1 = (int)(p->W * c.depth_crop[3]);
+        if (p->roll_pending) DFVO_HIP_CHECK(hipStreamWaitEvent(p->s_depth, p->e_roll, 0));  // WAW on ref_depth vs the roll-over
         P_TRY(launch_depth_post(p->depth_small, p->feedH, p->feedW, p->H, p->W, y0, y1, x0, x1, (float)c.min_depth,
                                 (float)c.max_depth, p->ref_raw, p->ref_depth, p->s_depth));
         // not waited for on the host: the solver stream (PnP fallback reads the reference depth, the roll-over writes it)
@@ -388,6 +397,9 @@ static int roll_ref_depth(dfvo_pipeline* p, int slot, const double* d_depth_over
     DFVO_HIP_CHECK(hipStreamWaitEvent(p->s_trk, p->e_depth[slot], 0));
     const double* depth = d_depth_override ? d_depth_override : p->proc_depth[slot];
     DFVO_HIP_CHECK(hipMemcpyAsync(p->ref_depth, depth, px * sizeof(double), hipMemcpyDeviceToDevice, p->s_trk));
+    if (!p->e_roll) DFVO_HIP_CHECK(hipEventCreateWithFlags(&p->e_roll, hipEventDisableTiming));
+    DFVO_HIP_CHECK(hipEventRecord(p->e_roll, p->s_trk));
+    p->roll_pending = true;
     p->has_ref_depth = true;
     return DFVO_OK;
 }

@@ -25,6 +25,7 @@
 #include "ransac_dev.h"
 #include "solver.h"
 #include "solver_math.h"
+#include "solver_poly_lanes.h"
 #include "tracker.h"
 
 namespace dfvo {
@@ -207,54 +208,53 @@ __global__ __launch_bounds__(64) void k_e_stage3(const EBatch B, int it0, int it
     if (active && root == 0) nmodels[it] = __popc(grp_mask);
 }
 
-// (Opt-in experiment, see enqueue_find_essential_batch.)  The three per-hypothesis stages in one launch (the
-// RandomState-ordered chain of the fused pipeline pays for every dependent launch): four hypotheses per 64-thread block.  Stage 1 and the polynomial are serial chains per hypothesis
-// and run on the first lane of each 16-lane group -- a wave with four active lanes has the latency of a full one, and
-// there are wave slots to spare -- stage 3 then uses all sixteen lanes of the group, one root per lane, exactly as
-// k_e_stage3 does.  Same device functions, same operands: bit-identical to the three-launch sequence.
-__global__ __launch_bounds__(64) void k_e_hyp(const EBatch B, int it0, int it1) {
-    __shared__ double s_ws[4 * E_STAGE1_STRIDE];
+// Polynomial + stage 3 in one launch, sixteen lanes (one DPP row) per hypothesis, one root per lane from the first sweep
+// of cv::solvePoly to the root's E (solver_poly_lanes.h: the Gauss-Seidel sweep with the updated roots handed over the
+// row by DPP broadcasts -- same operands in the same order as the sequential loop, a third of its instruction stream).
+// The roots never leave the registers; ws[86..105] is still written for the trace / tests that read it.
+__global__ __launch_bounds__(64) void k_e_poly_stage3(const EBatch B, int it0, int it1) {
     const ERep& R = B.r[blockIdx.y];
     const RansacState* st = R.state;
     double* ws = R.ws;
-    int* ok = R.ok;
+    const int* ok = R.ok;
     double* models = R.models;
     int* nmodels = R.nmodels;
     const int grp = threadIdx.x >> 4, root = threadIdx.x & 15;
     const int it = it0 + blockIdx.x * 4 + grp;
     if (st->done) return;  // uniform over the block
     const bool active = it < it1;
-    if (active && root == 0) {
-        const int* idx = B.idx;
-        const double *p1 = R.norm_a, *p2 = R.norm_b;
-        double q1[10], q2[10];
-        for (int i = 0; i < 5; i++) {
-            const int k = idx[it * 5 + i];
-            q1[i * 2] = p1[k * 2];
-            q1[i * 2 + 1] = p1[k * 2 + 1];
-            q2[i * 2] = p2[k * 2];
-            q2[i * 2 + 1] = p2[k * 2 + 1];
-        }
-        double* w = ws + (size_t)it * E_WS;  // [EE 36 | b 39 | c 11 | roots 20]
-        const int good = sm::five_point_stage1_ws(q1, q2, w, w + 36, w + 75, s_ws + grp * E_STAGE1_STRIDE) ? 1 : 0;
-        ok[it] = good;
-        if (good) {
-            double c[11], rre[10], rim[10];
-            for (int i = 0; i < 11; i++) c[i] = w[75 + i];
-            sm::solve_poly10(c, rre, rim);
+    const bool good = active && ok[it];
+    double* w = ws + (size_t)(active ? it : it0) * E_WS;
+    double c[11];
+#pragma unroll
+    for (int i = 0; i < 11; i++) c[i] = good ? w[75 + i] : 1.0;
+    int n = 10;
+    for (; n > 1; n--)
+        if (fabs(c[n]) + 0.0 > DBL_EPSILON) break;
+    double rre = 0, rim = 0;
+    sm::solve_poly10_row(c, root, good && n == 10, rre, rim);
+    if (good && n != 10) {  // leading coefficients ~ 0: the run-time-degree path, first lane of the row (rare)
+        if (root == 0) {
+            double r_re[10], r_im[10];
+            sm::solve_poly10(c, r_re, r_im);
             for (int i = 0; i < 10; i++) {
-                w[86 + i] = rre[i];
-                w[96 + i] = rim[i];
+                w[86 + i] = r_re[i];
+                w[96 + i] = r_im[i];
             }
         }
+        __threadfence_block();
+        __builtin_amdgcn_wave_barrier();
+        if (root < 10) {
+            rre = ((volatile double*)w)[86 + root];
+            rim = ((volatile double*)w)[96 + root];
+        }
+    } else if (good && root < 10) {
+        w[86 + root] = rre;
+        w[96 + root] = rim;
     }
-    __syncthreads();  // the group's lanes read what its first lane wrote (global memory, same workgroup)
     bool valid = false;
     double Ev[9];
-    if (active && root < 10 && ok[it]) {
-        const double* w = ws + (size_t)it * E_WS;
-        valid = sm::five_point_root_to_E(w, w + 36, w[86 + root], w[96 + root], Ev);
-    }
+    if (good && root < 10) valid = sm::five_point_root_to_E(w, w + 36, rre, rim, Ev);
     const unsigned long long m = __ballot(valid);
     const unsigned grp_mask = (unsigned)((m >> (grp * 16)) & 0xffffull);
     if (valid) {
@@ -264,97 +264,6 @@ __global__ __launch_bounds__(64) void k_e_hyp(const EBatch B, int it0, int it1) 
         for (int k = 0; k < 9; k++) dst[k] = Ev[k];
     }
     if (active && root == 0) nmodels[it] = __popc(grp_mask);
-}
-
-// Two launches instead of four for the hypothesis stages, without thinning the waves: stage 1 and the polynomial are both
-// one-lane-per-hypothesis chains and share k_e_stage1's 16-lane workgroups (k_e_stage1_poly); stage 3's output -- the
-// models of a hypothesis -- is exactly what the scoring wave of that hypothesis stages in LDS, so the first sixteen lanes
-// of the scoring wave compute it in place (k_e_stage3_score).  Same device functions, same operands, same results.
-__global__ __launch_bounds__(E_STAGE1_LANES) void k_e_stage1_poly(const EBatch B, int it0, int it1) {
-    __shared__ double s_ws[E_STAGE1_LANES * E_STAGE1_STRIDE];
-    const ERep& R = B.r[blockIdx.y];
-    const RansacState* st = R.state;
-    const int* idx = B.idx;
-    const double *p1 = R.norm_a, *p2 = R.norm_b;
-    double* ws = R.ws;
-    int* ok = R.ok;
-    const int it = it0 + blockIdx.x * E_STAGE1_LANES + threadIdx.x;
-    if (st->done || it >= it1) return;
-    double q1[10], q2[10];
-    for (int i = 0; i < 5; i++) {
-        const int k = idx[it * 5 + i];
-        q1[i * 2] = p1[k * 2];
-        q1[i * 2 + 1] = p1[k * 2 + 1];
-        q2[i * 2] = p2[k * 2];
-        q2[i * 2 + 1] = p2[k * 2 + 1];
-    }
-    double* w = ws + (size_t)it * E_WS;  // [EE 36 | b 39 | c 11 | roots 20]
-    const int good = sm::five_point_stage1_ws(q1, q2, w, w + 36, w + 75, s_ws + threadIdx.x * E_STAGE1_STRIDE) ? 1 : 0;
-    ok[it] = good;
-    if (!good) return;
-    double c[11], rre[10], rim[10];
-    for (int i = 0; i < 11; i++) c[i] = w[75 + i];
-    sm::solve_poly10(c, rre, rim);
-    for (int i = 0; i < 10; i++) {
-        w[86 + i] = rre[i];
-        w[96 + i] = rim[i];
-    }
-}
-
-__global__ __launch_bounds__(256) void k_e_stage3_score(const EBatch B, int it0, int it1, int n, float thr2) {
-    __shared__ double sE[4][90];
-    const ERep& R = B.r[blockIdx.y];
-    const RansacState* st = R.state;
-    const double* ws = R.ws;
-    const int* ok = R.ok;
-    double* models = R.models;
-    int* nmodels = R.nmodels;
-    const double *p1 = R.norm_a, *p2 = R.norm_b;
-    int* counts = R.counts;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int it = it0 + blockIdx.x * 4 + wave;
-    const bool active = !st->done && it < it1;
-    // stage 3: one root per lane on the wave's first sixteen lanes, survivors compacted in root order
-    bool valid = false;
-    double Ev[9];
-    if (active && lane < 10 && ok[it]) {
-        const double* w = ws + (size_t)it * E_WS;
-        valid = sm::five_point_root_to_E(w, w + 36, w[86 + lane], w[96 + lane], Ev);
-    }
-    const unsigned mask = (unsigned)(__ballot(valid) & 0xffffull);
-    const int nm = active ? __popc(mask) : 0;
-    if (valid) {
-        const int slot = __popc(mask & ((1u << lane) - 1u));
-        double* dst = models + (size_t)it * 90 + slot * 9;
-#pragma unroll
-        for (int k = 0; k < 9; k++) {
-            dst[k] = Ev[k];
-            sE[wave][slot * 9 + k] = Ev[k];
-        }
-    }
-    if (active && lane == 0) nmodels[it] = nm;
-    __syncthreads();
-    if (nm <= 0) return;
-    int cnt[10];
-#pragma unroll
-    for (int m = 0; m < 10; m++) cnt[m] = 0;
-    for (int i = lane; i < n; i += 64) {
-        const double x1 = p1[i * 2], y1 = p1[i * 2 + 1], x2 = p2[i * 2], y2 = p2[i * 2 + 1];
-#pragma unroll
-        for (int m = 0; m < 10; m++) {
-            if (m < nm) {
-                const float e = sm::essential_error(&sE[wave][m * 9], x1, y1, x2, y2);
-                cnt[m] += (e <= thr2) ? 1 : 0;
-            }
-        }
-    }
-#pragma unroll
-    for (int m = 0; m < 10; m++) {
-        if (m < nm) {
-            const int s = wave_sum(cnt[m]);
-            if (lane == 0) counts[it * 10 + m] = s;
-        }
-    }
 }
 
 // one wavefront per hypothesis: Sampson error of every correspondence under each of its models
@@ -501,31 +410,13 @@ int enqueue_find_essential_batch(RansacWorkspace* w, const double* const* d_pts1
             if (it1 <= it0) continue;
             const int nh = it1 - it0;
             hipLaunchKernelGGL(k_e_subsets, dim3(1), dim3(1), 0, s, B, n, it0, it1);
-            // DFVO_E_FUSED=1: k_e_hyp instead of the three launches.  Measured in the default bench: the five-point batch
-            // gets 0.14 ms shorter under load (2.46 vs 2.60 ms) but the pair rate drops, 223.8 vs 236.8 frames/s -- 800
-            // quarter-filled waves that live 1.3 ms each take more from the nets than two launches cost.  Off.
-            static const int fused = getenv("DFVO_E_FUSED") ? atoi(getenv("DFVO_E_FUSED")) : 0;
-            // 2: (stage 1 + polynomial), (stage 3 + scoring) -- the batch 0.21 ms shorter under load (2.37 vs 2.58 ms), the
-            // pair rate unchanged (235.9 vs 234.3 frames/s): the time reappears in the wait for the homography half, i.e.
-            // the pair rate is set by the nets under contention, not by this chain.  Off, like 1.
-            if (fused == 2) {
-                hipLaunchKernelGGL(k_e_stage1_poly, dim3(cdiv(nh, E_STAGE1_LANES), R), dim3(E_STAGE1_LANES), 0, s, B, it0, it1);
-                hipLaunchKernelGGL(k_e_stage3_score, dim3(cdiv(nh, 4), R), dim3(256), 0, s, B, it0, it1, n, thr2);
-                hipLaunchKernelGGL(k_e_replay, dim3(R), dim3(1), 0, s, B, it0, it1, n, prob);
-                continue;
-            }
-            if (fused == 1) {
-                hipLaunchKernelGGL(k_e_hyp, dim3(cdiv(nh, 4), R), dim3(64), 0, s, B, it0, it1);
+            hipLaunchKernelGGL(k_e_stage1, dim3(cdiv(nh, E_STAGE1_LANES), R), dim3(E_STAGE1_LANES), 0, s, B, it0, it1);
+            // A/B switch for the round-4 measurement (profiles/r4a_*): 0 = one lane per hypothesis (k_e_poly, 1.07 ms per pair)
+            static const int poly_lanes = getenv("DFVO_E_POLY_LANES") ? atoi(getenv("DFVO_E_POLY_LANES")) : 1;
+            if (poly_lanes) {
+                hipLaunchKernelGGL(k_e_poly_stage3, dim3(cdiv(nh, 4), R), dim3(64), 0, s, B, it0, it1);
             } else {
-                hipLaunchKernelGGL(k_e_stage1, dim3(cdiv(nh, E_STAGE1_LANES), R), dim3(E_STAGE1_LANES), 0, s, B, it0, it1);
-                // one lane per hypothesis, 0.5 ms per wave (cv::solvePoly's 300 sweeps).  DFVO_E_POLY_BLOCK = 128 / 256 packs two /
-                // four of those waves into one workgroup, i.e. onto the SIMDs of ONE compute unit instead of different ones (a
-                // resident foreign wave keeps the nets' one-wave-per-SIMD window workgroups off its whole compute unit):
-                // measured, 64 / 128 / 256 -> 276.8 / 277.4 / 277.0 pairs/s (profiles/r3t_poly_block_ab.txt): not what
-                // couples the solver stage to the nets.
-                static const int poly_block = getenv("DFVO_E_POLY_BLOCK") ? atoi(getenv("DFVO_E_POLY_BLOCK")) : 64;
-                const int pb = poly_block == 256 || poly_block == 128 ? poly_block : 64;
-                hipLaunchKernelGGL(k_e_poly, dim3(cdiv(nh, pb), R), dim3(pb), 0, s, B, it0, it1);
+                hipLaunchKernelGGL(k_e_poly, dim3(cdiv(nh, 64), R), dim3(64), 0, s, B, it0, it1);
                 hipLaunchKernelGGL(k_e_stage3, dim3(cdiv(nh, 4), R), dim3(64), 0, s, B, it0, it1);
             }
             hipLaunchKernelGGL(k_e_score, dim3(cdiv(nh, 4), R), dim3(256), 0, s, B, it0, it1, n, thr2);

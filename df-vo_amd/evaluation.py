@@ -6,7 +6,7 @@ kitti_odometry.py:120-299,445-497 (trajectory_distances, calc_sequence_errors ov
 frame, compute_overall_err, compute_ATE, compute_RPE) -- is done here on whole arrays: one cumulative sum for the path
 length, one searchsorted for all (first frame, length) segments, stacked 4x4 inverses / products for every pose error.
 Same definitions, same numbers (tests/test_evaluation_cpu.py: <= 1e-9 against the restatement in oracle/kitti_eval.py, which
-is pinned to the reference's own KittiEvalOdom methods)."""
+is pinned to the reference's own KittiEvalOdom methods and, for the alignment modes, to KittiEvalOdom.eval itself)."""
 import numpy as np
 
 LENGTHS = (100, 200, 300, 400, 500, 600, 700, 800)
@@ -65,9 +65,66 @@ def calc_sequence_errors(gt, res, lengths=LENGTHS, step_size=10):
     return np.stack([F.astype(np.float64), _rot_err(pe) / L, _trans_err(pe) / L, L, L / (0.1 * nf)], 1)
 
 
-def evaluate(gt, res):
+ALIGNMENTS = (None, "scale", "scale_7dof", "7dof", "6dof")
+
+
+def scale_lse_solver(X, Y):
+    """kitti_odometry.py:19-31: the s minimising ||s X - Y||"""
+    return float(np.sum(X * Y) / np.sum(X ** 2))
+
+
+def umeyama_alignment(x, y, with_scale=False):
+    """kitti_odometry.py:34-84 on stacked arrays: x, y [3, n] -> r [3,3], t [3], c.  The covariance is one matrix product
+    instead of n outer products (same sum, different association: agrees to rounding)."""
+    x, y = np.asarray(x, np.float64), np.asarray(y, np.float64)
+    m, n = x.shape
+    mean_x, mean_y = x.mean(axis=1), y.mean(axis=1)
+    xc, yc = x - mean_x[:, None], y - mean_y[:, None]
+    sigma_x = 1.0 / n * (np.linalg.norm(xc) ** 2)
+    cov_xy = (yc @ xc.T) * (1.0 / n)
+    u, d, v = np.linalg.svd(cov_xy)
+    s = np.eye(m)
+    if np.linalg.det(u) * np.linalg.det(v) < 0.0:
+        s[m - 1, m - 1] = -1
+    r = u @ s @ v
+    c = float(1 / sigma_x * np.trace(np.diag(d) @ s)) if with_scale else 1.0
+    t = mean_y - c * (r @ mean_x)
+    return r, t, c
+
+
+def align(gt, res, alignment=None):
+    """What KittiEvalOdom.eval does to the two trajectories before measuring (kitti_odometry.py:618-652): both are moved
+    into the frame of their first pose (only the frames the result holds, as the reference's loop does), then
+    alignment = None | "scale" (least-squares scale of the positions) | "scale_7dof" (Umeyama's scale only) | "7dof" |
+    "6dof" (Umeyama's similarity / rigid transform applied to every pose; "6dof" is the protocol of the README's table).
+    Returns (gt, res) as new [n,4,4] arrays."""
+    if alignment not in ALIGNMENTS:
+        raise ValueError("alignment: None, 'scale', 'scale_7dof', '7dof' or '6dof'")
+    gt, res = np.array(gt, np.float64), np.array(res, np.float64)
+    n = len(res)
+    res = np.linalg.inv(res[0]) @ res
+    gt[:n] = np.linalg.inv(gt[0]) @ gt[:n]
+    if alignment == "scale":
+        res[:, :3, 3] *= scale_lse_solver(res[:, :3, 3], gt[:n, :3, 3])
+    elif alignment is not None:
+        r, t, c = umeyama_alignment(res[:, :3, 3].T, gt[:n, :3, 3].T, alignment != "6dof")
+        res[:, :3, 3] *= c
+        if alignment != "scale_7dof":
+            T = np.eye(4)
+            T[:3, :3], T[:3, 3] = r, t
+            res = T @ res
+    return gt, res
+
+
+def evaluate(gt, res, alignment=None, first_frame=True):
     """dict(t_rel [%], r_rel [deg / 100 m], ate [m], rpe_t [m], rpe_r [deg]) of an estimated trajectory against the ground
-    truth, both [n,4,4] camera-to-world (kitti_odometry.py:274-299,445-497,627-628)"""
+    truth, both [n,4,4] camera-to-world: KittiEvalOdom.eval's numbers for one sequence (kitti_odometry.py:274-299,445-497,
+    618-683) under the chosen alignment.  first_frame=False skips eval()'s first-frame normalisation and the alignment
+    (the bare per-method definitions; t_rel / r_rel / RPE do not depend on it, ATE does)."""
+    if first_frame:
+        gt, res = align(gt, res, alignment)
+    elif alignment is not None:
+        raise ValueError("alignment needs first_frame=True (the reference aligns after the first-frame normalisation)")
     gt, res = np.asarray(gt, np.float64), np.asarray(res, np.float64)
     err = calc_sequence_errors(gt, res)
     t_rel = float(err[:, 2].mean() * 100.0) if len(err) else 0.0

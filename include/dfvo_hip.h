@@ -428,7 +428,12 @@ int dfvo_pipeline_track(dfvo_pipeline* p, int slot, const float* d_flow_override
  * _begin waits for the slot's keypoint stage and enqueues the RandomState-ordered chain + the copy of its results into
  * pinned host memory; _end waits for them, runs the PnP fallback where the reference takes it and rolls the reference
  * depth over.  Pairs must be begun and ended in order, and pair k + 1 must not be begun before pair k was ended (the PnP
- * fallback of pair k consumes the RandomState ahead of pair k + 1's shuffles).  dfvo_pipeline_track = _begin + _end. */
+ * fallback of pair k consumes the RandomState ahead of pair k + 1's shuffles).  dfvo_pipeline_track = _begin + _end.
+ * Lifetime of the overrides with the split calls: _end enqueues the roll-over copy of the reference depth (from
+ * d_depth_override when one was given to _begin) and returns WITHOUT waiting for it; a caller-owned d_depth_override must
+ * therefore stay unchanged and allocated until the next dfvo_pipeline_track_end / dfvo_pipeline_sync has returned (the
+ * flow / consistency overrides: until _end of their own pair has returned).  The pipeline's own buffers are ordered on
+ * the device (the depth stream's next write of the slot waits for the copy). */
 int dfvo_pipeline_track_begin(dfvo_pipeline* p, int slot, const float* d_flow_override, const float* d_diff_override,
                               const double* d_depth_override);
 int dfvo_pipeline_track_end(dfvo_pipeline* p, int slot, dfvo_track_out* out);

@@ -645,6 +645,100 @@ def golden_kitti_eval():
     np.savez_compressed(os.path.join(HERE, "kitti_eval.npz"), gt=gt, res=res, **r)
 
 
+EVAL_ALIGNMENTS = [None, "scale", "scale_7dof", "7dof", "6dof"]
+
+
+def eval_align_cases():
+    """Trajectories for the alignment modes: (a) the committed tunnel trajectory; (b) a 700-frame KITTI-like drive (~0.9 m
+    per frame, gentle turns) whose estimate drifts in scale and heading and whose FIRST poses are not the identity (so that
+    eval()'s first-frame normalisation matters); (c) the same estimate cut to 430 frames (result shorter than ground truth)."""
+    fx = np.load(os.path.join(HERE, "tunnel_traj.npz"))
+    cases = {"tunnel": (fx["gt"], fx["poses"])}
+    rng = np.random.Generator(np.random.PCG64(77))
+
+    def rot(ax, a):
+        c, s_ = np.cos(a), np.sin(a)
+        R = np.eye(3)
+        i, j = [(1, 2), (0, 2), (0, 1)][ax]
+        R[i, i], R[i, j], R[j, i], R[j, j] = c, -s_, s_, c
+        return R
+
+    def drive(n, yaw_rate, scale, noise):
+        T = np.eye(4)
+        T[:3, :3] = rot(1, 0.3) @ rot(0, -0.05)
+        T[:3, 3] = [12.0, -1.5, 40.0]
+        out = [T.copy()]
+        for k in range(1, n):
+            d = np.eye(4)
+            d[:3, :3] = rot(1, yaw_rate(k)) @ rot(0, noise * rng.normal()) @ rot(2, noise * rng.normal())
+            d[:3, 3] = np.array([0.01 * np.sin(k / 40.0), -0.004, 0.9]) * scale(k) + noise * rng.normal(size=3)
+            T = T @ d
+            out.append(T.copy())
+        return np.array(out)
+
+    gt = drive(700, lambda k: 0.004 * np.sin(k / 90.0), lambda k: 1.0, 0.0)
+    est = drive(700, lambda k: 0.004 * np.sin(k / 90.0) + 2e-5, lambda k: 0.93 + 1e-4 * k, 2e-3)
+    A = np.eye(4)  # the estimate lives in another world frame
+    A[:3, :3] = rot(1, -0.8) @ rot(2, 0.1)
+    A[:3, 3] = [-3.0, 0.7, 5.0]
+    est = A @ est
+    cases["drive"] = (gt, est)
+    cases["drive_short"] = (gt, est[:430])
+    return cases
+
+
+def kitti_eval_reference_eval(gt, res, alignment):
+    """KittiEvalOdom.eval itself (kitti_odometry.py:556-700) on one sequence written to a temporary directory; plotting and
+    the error files are switched off, write_result hands over the five numbers at full precision"""
+    import tempfile
+    _stub_matplotlib()
+    import matplotlib
+    matplotlib.use("Agg")
+    ko = load_by_path("ref_kitti_odometry", os.path.join(REF, "tools/evaluation/odometry/kitti_odometry.py"))
+    got = {}
+
+    class Ev(ko.KittiEvalOdom):
+        def plot_trajectory(self, *a, **k):
+            pass
+
+        def plot_error(self, *a, **k):
+            pass
+
+        def write_result(self, f, seq, errs):
+            got["errs"] = [float(e) for e in errs]
+
+    def write(path, poses):
+        with open(path, "w") as f:
+            for i, p in enumerate(poses):
+                f.write(str(i) + " " + " ".join(repr(float(v)) for v in np.asarray(p).flatten()[:12]) + "\n")
+
+    with tempfile.TemporaryDirectory() as d:
+        os.makedirs(os.path.join(d, "gt"))
+        os.makedirs(os.path.join(d, "res"))
+        write(os.path.join(d, "gt", "09.txt"), gt)
+        write(os.path.join(d, "res", "09.txt"), res)
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            Ev().eval(os.path.join(d, "gt"), os.path.join(d, "res"), alignment=alignment, seqs=["09"])
+    t, r, ate, rt, rr = got["errs"]
+    return {"t_rel": t * 100, "r_rel": r / np.pi * 180 * 100, "ate": ate, "rpe_t": rt, "rpe_r": rr * 180 / np.pi}
+
+
+def golden_kitti_eval_align():
+    """kitti_eval_align.npz: KittiEvalOdom.eval under every alignment mode -- pins oracle/kitti_eval.py's align() and,
+    through it, df-vo_amd/evaluation.py (tests/test_oracle_eval.py, tests/test_evaluation_cpu.py)"""
+    out = {}
+    for name, (gt, res) in eval_align_cases().items():
+        out[name + "_gt"], out[name + "_res"] = gt, res
+        for al in EVAL_ALIGNMENTS:
+            r = kitti_eval_reference_eval(gt, res, al)
+            out["%s_%s" % (name, al)] = np.array([r[k] for k in ("t_rel", "r_rel", "ate", "rpe_t", "rpe_r")])
+            print("  %-12s %-10s t_rel %.4f %%  r_rel %.4f  ATE %.4f  RPE %.5f m %.5f deg" % (
+                name, al, r["t_rel"], r["r_rel"], r["ate"], r["rpe_t"], r["rpe_r"]))
+    np.savez_compressed(os.path.join(HERE, "kitti_eval_align.npz"), **out)
+
+
 TARGET_SIZE_CASES = [(192, 640), (376, 1241), (370, 1226), (375, 1242), (384, 1248), (256, 640), (128, 416), (70, 100), (64, 96),
                      (960, 1280), (1280, 1920), (480, 640), (320, 1024), (256, 832), (200, 300), (97, 301), (1000, 1000)]
 
@@ -758,7 +852,7 @@ if __name__ == "__main__":
     todo = {"liteflownet": golden_liteflownet, "monodepth2": golden_monodepth2, "kp": golden_kp_selection,
             "gric": golden_gric, "tracker": golden_tracker, "lanczos": golden_lanczos, "sampled": golden_kp_sampled,
             "tracker_flow": golden_tracker_flow, "rigid": golden_rigid_flow, "bestn": golden_kp_bestn,
-            "kitti_eval": golden_kitti_eval, "dfvo_main": golden_dfvo_main,
+            "kitti_eval": golden_kitti_eval, "kitti_eval_align": golden_kitti_eval_align, "dfvo_main": golden_dfvo_main,
             "target_size": golden_target_size, "tracker_variants": golden_tracker_variants}
     for name, fn in todo.items():
         if not which or name in which:

@@ -369,3 +369,85 @@ void hh_rigid_flow(const float* mats, const float* depth, int H, int W, float* o
         sm::rigid_flow_px(mats, mats + 9, mats + 25, (float)(i % W), (float)(i / W), depth[i], out + i, out + (size_t)H * W + i);
 }
 }
+
+// ---- lock-step host emulation of df-vo_amd/csrc/solver_poly_lanes.h (one root per lane, sixteen lanes per row):
+// every statement of the device schedule is executed for all lanes before the next one, the DPP row broadcast is a copy
+// from lane S's value.  What it proves on the host: the lane-parallel Gauss-Seidel order yields the sequential bits.
+extern "C" void hh_solve_poly10_lockstep(const double* c, double* rre, double* rim) {
+    constexpr int L = 16;
+    struct Z {
+        double cr[11], xr[10], xi[10], pre, pim, nre, nim, dre, dim, md;
+    } z[L];
+    for (int l = 0; l < L; l++) {
+        for (int i = 0; i <= 10; i++) z[l].cr[i] = c[i];
+        double pre = 1, pim = 0;
+        for (int i = 0; i < 10; i++) {
+            z[l].xr[i] = pre;
+            z[l].xi[i] = pim;
+            const double tre = pre * 1.0 - pim * 1.0, tim = pre * 1.0 + pim * 1.0;
+            pre = tre;
+            pim = tim;
+        }
+        const int own = l < 10 ? l : 0;
+        z[l].pre = z[l].xr[own];
+        z[l].pim = z[l].xi[own];
+    }
+    bool active = true;
+    for (int iter = 0; iter < 300; iter++) {
+        if (!active) break;
+        for (int l = 0; l < L; l++) {
+            Z& q = z[l];
+            q.nre = q.cr[10];
+            q.nim = 0;
+            for (int j = 0; j < 10; j++) {
+                const double tre = q.nre * q.pre - q.nim * q.pim, tim = q.nre * q.pim + q.nim * q.pre;
+                q.nre = tre + q.cr[10 - j - 1];
+                q.nim = tim + 0.0;
+            }
+            q.dre = q.cr[10];
+            q.dim = 0;
+            q.md = 0;
+        }
+        for (int S = 0; S < 10; S++) {
+            {
+                Z& q = z[S];  // the lane with li == S
+                double dre = q.dre, dim = q.dim;
+                for (int j = S + 1; j < 10; j++) {
+                    const double qre = q.pre - q.xr[j], qim = q.pim - q.xi[j];
+                    const double tre = dre * qre - dim * qim, tim = dre * qim + dim * qre;
+                    dre = tre;
+                    dim = tim;
+                }
+                const double t = 1. / (dre * dre + dim * dim);
+                const double qre = (q.nre * dre + q.nim * dim) * t, qim = (-q.nre * dim + q.nim * dre) * t;
+                q.pre = q.pre - qre;
+                q.pim = q.pim - qim;
+                const double an = qre * qre + qim * qim;
+                q.md = q.md > an ? q.md : an;
+            }
+            const double bre = z[S].pre, bim = z[S].pim, bmd = z[S].md;
+            for (int l = 0; l < L; l++) {
+                z[l].xr[S] = bre;
+                z[l].xi[S] = bim;
+                z[l].md = bmd;
+            }
+            for (int l = S + 1; l < L; l++) {
+                Z& q = z[l];
+                const double qre = q.pre - q.xr[S], qim = q.pim - q.xi[S];
+                const double tre = q.dre * qre - q.dim * qim, tim = q.dre * qim + q.dim * qre;
+                q.dre = tre;
+                q.dim = tim;
+            }
+        }
+        if (z[0].md <= 0) active = false;
+    }
+    for (int l = 0; l < 10; l++) {
+        rre[l] = z[l].pre;
+        rim[l] = fabs(z[l].pim) < 1e-100 ? 0 : z[l].pim;
+    }
+}
+extern "C" int hh_five_point_poly(const double* q1, const double* q2, double* c) {
+    double EE[36], b[39];
+    return sm::five_point_stage1(q1, q2, EE, b, c) ? 1 : 0;
+}
+extern "C" void hh_solve_poly10(const double* c, double* rre, double* rim) { sm::solve_poly10(c, rre, rim); }

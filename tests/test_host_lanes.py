@@ -150,3 +150,38 @@ def test_rigid_flow_lane_matches_oracle(hh):
     hh.hh_rigid_flow(_p(mats, C.c_float), _p(depth, C.c_float), 120, 200, _p(out, C.c_float))
     want = T.rigid_flow(depth, c["T_ref_to_cur"], K)
     assert np.array_equal(out, want)
+
+
+def test_lane_parallel_durand_kerner_schedule_is_bit_exact(hh, cv3):
+    """df-vo_amd/csrc/solver_poly_lanes.h (one root per lane, updated roots handed over the row in Gauss-Seidel
+    order) restated in lock step on the host: same bits as the sequential cv::solvePoly restatement of the oracle and
+    as the one-lane device function, on five-point polynomials, random polynomials, repeated / clustered roots and
+    polynomials that end in NaN."""
+    rng = np.random.default_rng(5)
+    polys = []
+    for trial in range(3000):  # the polynomials findEssentialMat really solves
+        q1 = rng.normal(0, 0.3, (5, 2))
+        q2 = q1 + rng.normal(0, 0.05, (5, 2))
+        c = np.zeros(11)
+        if hh.hh_five_point_poly(_p(q1), _p(q2), _p(c)):
+            polys.append(c)
+    for trial in range(1000):
+        polys.append(rng.normal(0, 1, 11) * 10.0 ** rng.integers(-3, 4, 11))
+    for trial in range(200):  # repeated and clustered real roots, conjugate pairs
+        r = np.concatenate([np.repeat(rng.normal(0, 1, 3), 2), rng.normal(0, 1e-3, 2) + 0.5, rng.normal(0, 1, 2)])
+        polys.append(np.poly(r)[::-1].copy())
+    polys.append(np.array([0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1.0]))  # x^10: all denominators hit inf / NaN
+    polys.append(np.array([1.0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1.0]))
+    n10 = 0
+    for c in polys:
+        c = np.ascontiguousarray(c, np.float64)
+        if not abs(c[10]) > np.finfo(np.float64).eps:
+            continue
+        n10 += 1
+        a_re, a_im, b_re, b_im, o_re, o_im = (np.zeros(10) for _ in range(6))
+        hh.hh_solve_poly10_lockstep(_p(c), _p(a_re), _p(a_im))
+        hh.hh_solve_poly10(_p(c), _p(b_re), _p(b_im))
+        cv3.cv3_solve_poly(_p(c), 10, _p(o_re), _p(o_im), 300)
+        for x, y in ((a_re, b_re), (a_im, b_im), (a_re, o_re), (a_im, o_im)):
+            assert np.array_equal(x.view(np.uint64), y.view(np.uint64))
+    assert n10 > 4000
