@@ -75,19 +75,76 @@ CFG_NAMES = ["conv_igemm_f32<2,2,4,4> 128x128", "conv_igemm_f32<1,4,2,2> 32x128"
              "(unused)", "(unused)"]
 
 
-def cpu_baseline_nets(frames, fsd, dsd, K, H, W, n_pairs=3):
-    """the oracle's image-level frame loop (oracle/pipeline_np.py: torch-CPU nets + C/numpy solvers) over the same coded
-    frames, ping-pong like the timed region, on the host cores"""
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_nets(frames, fsd, dsd, K, H, W, n_pairs=3, warmup=None):
+    """the oracle's image-level frame loop (oracle/pipeline_np.py's stages: torch-CPU nets on all host cores + single-threaded
+    C/numpy solvers, as OpenCV's RANSAC is) over the same coded frames, ping-pong like the timed region.  BASELINE.md
+    section 4's protocol: warm-up pairs (3 when n_pairs >= 20, else 1), then the mean over n_pairs, per-stage ms under the
+    reference's Timer keys (libs/general/timer.py; dfvo.py:146-246,305-335), core count and CPU model stated."""
     import torch
+    from oracle import nets_torch as O
     from oracle import pipeline_np as P
+    from oracle import tracker_np as T
     cores = torch.get_num_threads()
-    seq = [frames[i % 2] for i in range(n_pairs + 1)]
-    t0 = time.time()
-    r = P.track_sequence(seq, fsd, dsd, K, seed=4869)
-    dt = time.time() - t0
-    return {"value": n_pairs / dt, "unit": "frames/s", "cores": int(cores), "kind": "port",
-            "sample": "%d frame pairs %dx%d through the oracle frame loop (torch-CPU fp32 monodepth2 + LiteFlowNet fwd+bwd, "
-                      "C/numpy solvers on their outputs; tracked %s), %.1f s" % (n_pairs, W, H, "/".join(r["status"]), dt)}
+    if warmup is None:
+        warmup = 3 if n_pairs >= 20 else 1
+    keys = ["depth_cnn", "flow_cnn", "kp_sel", "E-tracker", "scale_recovery", "pnp"]
+    acc = {k: 0.0 for k in keys}
+    status = []
+    np.random.seed(4869)  # apis/run.py:81-84
+    _, depth_ref = P.frame_depth(dsd, frames[0])
+    t_begin = None
+    for k in range(1, warmup + n_pairs + 1):
+        if k == warmup + 1:
+            acc = {kk: 0.0 for kk in keys}
+            status = []
+            t_begin = time.perf_counter()
+        ref, cur = frames[(k - 1) % 2], frames[k % 2]
+        t0 = time.perf_counter()
+        _, depth_cur = P.frame_depth(dsd, cur)
+        t1 = time.perf_counter()
+        fwd, bwd, diff = O.flow_inference(fsd, ref, cur)
+        t2 = time.perf_counter()
+        kp = T.local_bestN(fwd, diff[..., None] if diff.ndim == 2 else diff)
+        t3 = time.perf_counter()
+        acc["depth_cnn"] += t1 - t0
+        acc["flow_cnn"] += t2 - t1
+        acc["kp_sel"] += t3 - t2
+        mode = "constant_motion"
+        if kp["good_kp_found"]:
+            kp1, kp2 = kp["kp1_best"][0], kp["kp2_best"][0]
+            res = T.compute_pose_2d2d(kp1, kp2, K)
+            t4 = time.perf_counter()
+            acc["E-tracker"] += t4 - t3
+            scale = -1
+            if np.linalg.norm(res["t"]) != 0:
+                pose = np.eye(4)
+                pose[:3, :3], pose[:3, 3:] = res["R"], res["t"]
+                scale = T.find_scale_from_depth(kp1, kp2, np.linalg.inv(pose), depth_cur, K)
+            t5 = time.perf_counter()
+            acc["scale_recovery"] += t5 - t4
+            mode = "E"
+            if np.linalg.norm(res["t"]) == 0 or scale == -1:
+                T.compute_pose_3d2d(kp1, kp2, depth_ref, K)
+                acc["pnp"] += time.perf_counter() - t5
+                mode = "PnP"
+        status.append(mode)
+        depth_ref = depth_cur
+    dt = time.perf_counter() - t_begin
+    return {"value": n_pairs / dt, "unit": "frames/s", "cores": int(cores), "kind": "port", "cpu_model": cpu_model(),
+            "stage_ms_per_pair": {kk: round(v / n_pairs * 1e3, 1) for kk, v in acc.items()},
+            "sample": "%d frame pairs %dx%d after %d warm-up pair(s) through the oracle frame loop (torch-CPU fp32 monodepth2 + "
+                      "LiteFlowNet fwd+bwd on %d threads, single-threaded C/numpy solvers on their outputs; tracked %s), %.1f s" % (
+                          n_pairs, W, H, warmup, cores, "/".join(status), dt)}
 
 
 def cpu_baseline(syn, H, W, scenes, n_pairs=2):
@@ -296,6 +353,78 @@ def run_mirrors(args, syn, capi, h_frames, K, fsd, dsd, code_mode):
     print(json.dumps(line))
 
 
+KITTI_FRAMES = [4541, 1101, 4661, 801, 271, 2761, 1101, 1101, 4071, 1591, 1201]  # dataset/kitti_odom/gt_poses/00..10.txt
+
+
+def run_job(args, pipe, d_frames, dist, world, rank, local_rank, on_gpu, torch, syn, code_mode):
+    """--sequences kitti-lengths: BASELINE config 3.  Eleven sequences (frame counts of KITTI 00-10 x --scale, ping-pong coded
+    frames) as one job over `world` ranks: sequence.run_sequences -- balanced (sequence, chunk) work list, 1-frame halo per
+    item, ONE all-gather of pose rows (through the C ABI's RCCL communicator on GPUs), per-sequence composition, eleven
+    trajectories.  Timed: the whole job incl. gather and composition, max over ranks."""
+    smod = importlib.import_module("df-vo_amd.sequence")
+    dmod = importlib.import_module("df-vo_amd.dist")
+
+    class PingPong:
+        def __getitem__(self, i):
+            return d_frames[i % 2]
+
+    frames = PingPong()
+    seqs = [("%02d" % k, frames, max(2, int(round(n * args.scale)))) for k, n in enumerate(KITTI_FRAMES)]
+    n_pairs = sum(n - 1 for _, _, n in seqs)
+    comm = None
+    if dist is not None and dist.get_backend() == "nccl":
+        comm = dmod.RcclComm.from_torch(dist, world, rank)  # dfvo_comm_* / dfvo_allgather_poses: the C ABI's collective
+    rng_mode = "sequential" if world == 1 else "per_pair"
+    smod.track_chunk(pipe, frames, 0, 5, rng_mode="per_pair")  # warm-up (clocks, autotuned layer configurations)
+    if dist is not None:
+        dist.barrier()
+    device_sync()
+    t0 = time.perf_counter()
+    res = smod.run_sequences(pipe, seqs, world, rank, dist, comm, rng_mode=rng_mode)
+    device_sync()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    status = np.concatenate([v["gathered"][:, 16] for v in res.values()]).astype(np.int64)
+    check = None
+    if rank == 0 and world > 1 and on_gpu:  # outside the timed region: the same job on this rank alone, per-pair RandomState
+        one = smod.run_sequences(pipe, seqs, 1, 0, None, rng_mode="per_pair")
+        same = all(np.array_equal(one[k]["gathered"][:, 16], res[k]["gathered"][:, 16]) and
+                   np.array_equal(one[k]["gathered"][one[k]["gathered"][:, 16] != 1], res[k]["gathered"][one[k]["gathered"][:, 16] != 1])
+                   for k in res)
+        check = {"sequences": len(seqs), "pairs": int(n_pairs), "equal_to_single_rank_run": bool(same)}
+    seen = ranks_seen(dist, world, rank, local_rank, torch)
+    if comm is not None:
+        comm.close()
+    pipe.close()
+    if rank == 0:
+        net_h, net_w = syn._net_size(args.height, args.width)
+        items = dmod.job_items([n - 1 for _, _, n in seqs], world)
+        line = {
+            "metric": "KITTI-odom frames/sec (DF-VO per-pair tracking hot path: monodepth2 + LiteFlowNet fwd/bwd + "
+                      "kp selection + E/H RANSAC + scale)",
+            "value": round(n_pairs / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": int(n_pairs), "warmup": 5,
+            "ms_per_step": round(dt / n_pairs * 1e3 * world, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32 (%s)" % args.conv_precision, "data": "synthetic",
+            "config": {"workload": "BASELINE config 3: eleven sequences with the frame counts of KITTI 00-10 x %g = %s (%d pairs), %dx%d "
+                                   "coded frames (flow net %dx%d), tracked as one job frame-batched over %d rank(s)" % (
+                                       args.scale, [n for _, _, n in seqs], n_pairs, args.width, args.height, net_h, net_w, world),
+                       "parallelism": "balanced (sequence, chunk) work list, 1-frame halo per item, %s RandomState, ONE all-gather of pose rows%s, "
+                                      "per-sequence prefix composition" % (rng_mode, " (dfvo_allgather_poses: RCCL ncclAllGather)" if comm else ""),
+                       "items_per_rank": [len(it) for it in items], "pairs_per_rank": [sum(h - l for _, l, h in it) for it in items],
+                       "tracked_by_E": int((status == 0).sum()), "tracked_by_PnP": int((status == 3).sum()),
+                       "constant_motion": int((status == 1).sum()), "trajectories": len(res),
+                       "ranks_seen": len(set(r[0] for r in seen)), "devices_seen": len(set((r[1], r[2], r[3]) for r in seen))},
+            "sequence_check": check, "roofline": None, "cpu_baseline": None}
+        print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -323,6 +452,14 @@ def main(argv=None):
                     help="on: the flow net's image / feature pyramids of a pair's reference frame are the ones the previous pair "
                          "computed for it as its current frame (one Features pass per new frame); off: both frames of every pair "
                          "run through Features, as the reference's model call does")
+    ap.add_argument("--sequences", default=None, choices=["kitti-lengths"],
+                    help="BASELINE config 3: eleven synthetic sequences with the frame counts of KITTI 00-10 (x --scale) tracked as "
+                         "ONE job frame-batched over the ranks (df-vo_amd/sequence.py run_sequences): balanced work list, 1-frame "
+                         "halo per item, one all-gather, per-sequence composition; --steps / --warmup are ignored")
+    ap.add_argument("--scale", type=float, default=0.02, help="--sequences: fraction of the 23 201 KITTI frames (>= 2 frames per sequence)")
+    ap.add_argument("--cpu-pairs", type=int, default=3,
+                    help="pairs of the cpu_baseline leg (default 3: ~17 s on the GPU box's host cores; BASELINE.md section 4's protocol "
+                         "is >= 20 pairs after 3 warm-up pairs: --cpu-pairs 20 takes ~2.5 min)")
     args = ap.parse_args(argv)
     os.environ["DFVO_CONV_PRECISION"] = args.conv_precision  # read once by the library when the layers are packed
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -389,6 +526,10 @@ def main(argv=None):
     if not nets_mode:
         d_sc = [(dev(s["flow"]), dev(s["diff"]), dev(s["depth_cur"])) for s in scenes]
         d_ref_depth = dev(scenes[0]["depth_ref"])
+    if args.sequences:
+        if not nets_mode:
+            raise SystemExit("bench.py: --sequences runs the product data path (--solver-inputs nets)")
+        return run_job(args, pipe, d_frames, dist, world, rank, local_rank, on_gpu, torch, syn, code_mode)
     host_frames = args.frames == "host" and on_gpu
     if host_frames:
         # frames arrive in pinned host memory; the new frame of every pair is uploaded on a copy stream while the nets of
@@ -634,7 +775,7 @@ def main(argv=None):
         capi.check(capi.lib().dfvo_set_conv_precision(args.conv_precision.encode()))
     base = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        base = cpu_baseline_nets(seq["frames"], fsd, dsd, K, H, W) if nets_mode else cpu_baseline(syn, H, W, scenes)
+        base = cpu_baseline_nets(seq["frames"], fsd, dsd, K, H, W, n_pairs=args.cpu_pairs) if nets_mode else cpu_baseline(syn, H, W, scenes)
     seen = ranks_seen(dist, world, rank, local_rank, torch)
     if pipe is not None:
         pipe.close()
@@ -643,9 +784,13 @@ def main(argv=None):
         n_e = int((status == 0).sum())
         if roof is not None:
             roof["whole_pair_tflops"] = round(net_flops * n_total / dt / 1e12, 2)  # issued net FLOPs / timed wall time
-            roof["whole_pair_tflops_reference_work"] = round(net_flops_ref * n_total / dt / 1e12, 2)  # the reference's FLOPs per pair
+            roof["whole_pair_tflops_two_features_passes"] = round(net_flops_ref * n_total / dt / 1e12, 2)
             roof["algorithmic_gflop_per_pair"] = round(net_flops / 1e9, 1)
-            roof["algorithmic_gflop_per_pair_reference"] = round(net_flops_ref / 1e9, 1)
+            roof["algorithmic_gflop_per_pair_two_features_passes"] = round(net_flops_ref / 1e9, 1)  # both frames through Features once
+            # the reference's model call runs Features on FOUR images per pair (lite_flow_net.py:285-325 with batch 2 on both
+            # arguments: forward and backward samples each carry both frames): two more single-frame passes than the figure above
+            roof["algorithmic_gflop_per_pair_reference"] = (round((net_flops_ref + 2 * (net_flops_ref - net_flops)) / 1e9, 1)
+                                                            if recomputed is not None else None)
             roof["note"] = ("achieved/frac: the conv tile configuration with the largest time share, per-launch HIP-event "
                             "durations, graphs off, ONE pair in flight (conv_family_ms_per_pair sums those and exceeds "
                             "ms_per_step, whose timed region overlaps two flow-net instances and the solver stage); "

@@ -98,6 +98,12 @@ SIGNATURES = {
     "dfvo_conv2d": (_i, [C.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dfvo_compose_trajectory": (_i, [_vp, _i, _vp, _vp, C.POINTER(_i)]),
     "dfvo_compose_trajectory_device": (_i, [_vp, _i, _vp, _vp, C.POINTER(_i), _vp]),
+    "dfvo_tracker_stage_ms": (_i, [_vp, _vp]),
+    "dfvo_comm_unique_id": (_i, [_vp]),
+    "dfvo_comm_create": (_i, [_vp, _i, _i, C.POINTER(_vp)]),
+    "dfvo_comm_destroy": (_i, [_vp]),
+    "dfvo_allgather_poses": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "dfvo_allgather_poses_device": (_i, [_vp, _vp, _i, _vp, _vp]),
     "dfvo_set_conv_precision": (_i, [C.c_char_p]),
     "dfvo_set_sklearn_compat": (_i, [C.c_char_p]),
     "dfvo_f16s_overflow_count": (_i, [C.POINTER(C.c_ulonglong), _i]),

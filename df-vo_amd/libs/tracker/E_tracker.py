@@ -12,6 +12,29 @@ from ..geometry.camera_modules import SE3
 from . import _ctx, rigid_kp
 
 
+# dfvo_tracker_stage_ms slots -> the reference's Timer keys and groups (E_tracker.py:197-296,597-638)
+STAGE_KEYS = [("find H", "E-tracker"), ("GRIC-H", "E-tracker"), ("find-Ess", "E-tracker"), ("GRIC-E", "E-tracker"),
+              ("find-Ess (full)", "E-tracker"), ("recover pose", "E-tracker"), ("triangulation", "scale_recovery"),
+              ("scale ransac", "scale_recovery")]
+
+
+def feed_timers(timers, slots):
+    """append the device times of the last solver call to the reference's Timer under its own sub-keys: the stages run
+    as kernels behind one C call here, so their durations come from HIP events between them (dfvo_tracker_stage_ms), not
+    from host clocks around Python statements.  `timers` is the reference's libs.general.timer.Timer (or None)."""
+    if timers is None:
+        return
+    ms = np.zeros(8)
+    capi.check(capi.lib().dfvo_tracker_stage_ms(_ctx.tracker(), capi.as_ptr(ms)))
+    for i in slots:
+        if ms[i] < 0:
+            continue
+        key, group = STAGE_KEYS[i]
+        if timers.timers.get(key, -1) == -1:
+            timers.add(key, group)
+        timers.timers[key]['duration'].append(ms[i] * 1e-3)
+
+
 VALIDITY_METHODS = {"GRIC": 0, "flow": 1, "homo_ratio": 2}   # include/dfvo_hip.h DFVO_VALIDITY_*
 SCALE_METHODS = {"depth_ratio": 0, "abs_diff": 1}             # DFVO_SCALE_*
 
@@ -47,14 +70,11 @@ class EssTracker:
             cfg.Kinv[i] = Kinv.flat[i]
         out = capi.Pose2d2dOut()
         inl = np.zeros(max(n, 1), np.uint8)
-        if self.timers is not None:
-            self.timers.start('find-Ess (full)', 'E-tracker')
         _ctx.push_numpy_rng()
         capi.check(capi.lib().dfvo_compute_pose_2d2d(_ctx.tracker(), capi.as_ptr(kp_ref), capi.as_ptr(kp_cur), n,
                                                      C.byref(cfg), C.byref(out), capi.as_ptr(inl)))
         _ctx.pull_numpy_rng()
-        if self.timers is not None:
-            self.timers.end('find-Ess (full)')
+        feed_timers(self.timers, range(0, 6))
         pose = SE3()
         pose.R = np.array(out.R[:]).reshape(3, 3)
         pose.t = np.array(out.t[:]).reshape(3, 1)
@@ -129,15 +149,12 @@ class EssTracker:
                              stop_prob=float(rc.stop_prob), thre=float(rc.thre), method=SCALE_METHODS[rc.method])
         scale = C.c_double()
         info = np.zeros(4, np.int32)
-        if self.timers is not None:
-            self.timers.start('scale ransac', 'scale_recovery')
         _ctx.push_numpy_rng()
         capi.check(capi.lib().dfvo_find_scale_from_depth(_ctx.tracker(), capi.as_ptr(kp1), capi.as_ptr(kp2), kp1.shape[0],
                                                          capi.as_ptr(T_21), capi.as_ptr(depth2), h, w, C.byref(scfg),
                                                          C.byref(scale), capi.as_ptr(info)))
         _ctx.pull_numpy_rng()
-        if self.timers is not None:
-            self.timers.end('scale ransac')
+        feed_timers(self.timers, (6, 7))
         if info[3] < 0:
             raise ValueError("RANSAC could not find a valid consensus set (sklearn RANSACRegressor semantics)")
         return -1 if scale.value == -1.0 else scale.value

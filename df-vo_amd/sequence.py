@@ -64,7 +64,7 @@ def track_chunk(pipe, frames, lo, hi, seed=4869, rng_mode="sequential", ahead=3,
 
 
 def run_sequence(pipe, frames, n_frames, world=1, rank=0, dist=None, seed=4869, rng_mode=None, ahead=3, collect=None,
-                 compose="host", carry_features=True):
+                 compose="host", carry_features=True, comm=None):
     """data-parallel tracking of an n_frames sequence: contiguous chunk per rank (dist.chunk_bounds), ONE all-gather of
     the relative poses + status words (RCCL when `dist` runs the nccl backend), then the sequential prefix composition
     that reproduces DFVO.update_global_pose incl. the constant-motion rule (dfvo.py:109-119,157-161).
@@ -75,11 +75,59 @@ def run_sequence(pipe, frames, n_frames, world=1, rank=0, dist=None, seed=4869, 
         rng_mode = "sequential" if world == 1 else "per_pair"
     if world > 1 and rng_mode == "sequential":
         raise ValueError("the sequential numpy RandomState cannot be reproduced frame-parallel; use rng_mode='per_pair'")
-    lo, hi = dmod.chunk_bounds(n_frames - 1, world, rank)
+    bounds = [dmod.chunk_bounds(n_frames - 1, world, r) for r in range(world)]
+    lo, hi = bounds[rank]
     rel, status = track_chunk(pipe, frames, lo, hi, seed, rng_mode, ahead, collect=collect, carry_features=carry_features)
-    gathered = dmod.allgather_poses(rel, status, world, rank, dist)
+    gathered = dmod.allgather_poses(rel, status, world, rank, dist, counts=[b - a for a, b in bounds], comm=comm)
     traj = dmod.compose_trajectory_device(gathered) if compose == "device" else dmod.compose_trajectory(gathered)
     return traj, gathered
+
+
+def run_sequences(pipe, seqs, world=1, rank=0, dist=None, comm=None, seed=4869, rng_mode=None, ahead=3, compose="host",
+                  carry_features=True, out_dir=None, gts=None, alignment=None, collect=None):
+    """BASELINE config 3 (KITTI 00-10 frame-batched across the GPUs of one node): what the reference does as eleven
+    runs of apis/run.py, one `--seq` each (DFVO.main, /root/reference/libs/dfvo.py:347-425; trajectory written by
+    save_traj, libs/general/utils.py:329-355; evaluated by tools/evaluation/odometry/eval_odom.py).
+
+    seqs: list of (name, frames, n_frames) -- `frames` indexable by frame number -> device uint8 [H,W,3].
+    The pairs of all sequences form one work list balanced over the ranks by frame count (dist.job_items); every item
+    starts from its own 1-frame halo; ONE all-gather for the whole job (row counts are deterministic, nothing else is
+    exchanged); then every sequence is composed separately from the identity (a fresh DFVO per sequence), written to
+    out_dir/<name>.txt by rank 0 and, when gts[name] ([n,4,4]) is given, evaluated with evaluation.evaluate(alignment).
+    RandomState: world 1 -> "sequential", re-seeded at the start of every sequence as run.py does per run; world > 1 ->
+    "per_pair" keyed by the pair's index within its sequence (a pair's result does not depend on the job's composition).
+    Returns {name: {"poses": [n,4,4], "gathered": [n-1,17], "metrics": dict or None}} in the order of `seqs`."""
+    from . import evaluation as ev
+    if rng_mode is None:
+        rng_mode = "sequential" if world == 1 else "per_pair"
+    if world > 1 and rng_mode == "sequential":
+        raise ValueError("the sequential numpy RandomState cannot be reproduced frame-parallel; use rng_mode='per_pair'")
+    n_pairs = [max(0, int(n) - 1) for _, _, n in seqs]
+    items = dmod.job_items(n_pairs, world)
+    rows = []
+    for s, lo, hi in items[rank]:
+        name, frames, _ = seqs[s]
+        rel, status = track_chunk(pipe, frames, lo, hi, seed, rng_mode, ahead, carry_features=carry_features,
+                                  collect=None if collect is None else (lambda j, out, _n=name: collect(_n, j, out)))
+        rows.append(dmod.pack_rows(rel, status))
+    mine = np.concatenate(rows, 0) if rows else np.zeros((0, 17))
+    counts = [sum(hi - lo for _, lo, hi in it) for it in items]
+    gathered = dmod.allgather_rows(mine, counts, world, rank, dist, comm)
+    out = {}
+    off = 0
+    for (name, _, n), npair in zip(seqs, n_pairs):
+        g = gathered[off:off + npair]
+        off += npair
+        poses = dmod.compose_trajectory_device(g) if compose == "device" else dmod.compose_trajectory(g)
+        metrics = None
+        if gts is not None and gts.get(name) is not None:
+            metrics = ev.evaluate(np.asarray(gts[name])[:len(poses)], poses, alignment=alignment)
+        if out_dir is not None and rank == 0:
+            import os
+            os.makedirs(out_dir, exist_ok=True)
+            ev.save_traj(os.path.join(out_dir, "%s.txt" % name), poses)
+        out[name] = {"poses": poses, "gathered": g, "metrics": metrics}
+    return out
 
 
 def save_traj(path, poses):

@@ -190,6 +190,12 @@ int dfvo_depth_postprocess(const float* d_depth, int h, int w, int H, int W, int
 typedef struct dfvo_tracker dfvo_tracker;
 int dfvo_tracker_create(void* stream, dfvo_tracker** out);
 void dfvo_tracker_destroy(dfvo_tracker* trk);
+/* Device time [ms] of the stages of the LAST dfvo_compute_pose_2d2d / dfvo_find_scale_from_depth call on this tracker, under
+ * the reference's Timer sub-keys (E_tracker.py:197-296,597-638; libs/general/timer.py), from HIP events between the
+ * kernels of the chain.  h_ms8 = {find H, GRIC-H (incl. find H, nested as in the reference), find-Ess (shuffles + the
+ * `repeat` five-point RANSACs, one batched launch sequence here), GRIC-E, find-Ess (full) (shuffles .. best-model
+ * bookkeeping), recover pose, triangulation (+ depth ratios), scale ransac}; -1 for a stage the last call did not run. */
+int dfvo_tracker_stage_ms(dfvo_tracker* trk, double* h_ms8);
 
 /* cv2.findEssentialMat(points1, points2, focal, pp, RANSAC, prob, threshold)
  * (E_tracker.py:59-67,231-239).  h_pts [n][2] doubles.  h_E[9], h_mask[n] (0/1).
@@ -330,7 +336,7 @@ int dfvo_ransac_regressor(dfvo_tracker* trk, const double* h_x, const double* h_
  * out->R / tvec: the solvePnP pose (view-1 points -> view-2 camera); the caller inverts it like the reference
  * does (pose.pose = pose.inv_pose).  h_keep[n] (optional): 1 where the keypoint survived the masks.
  * Consumes the tracker's RandomState (one shuffle per repeat, drawn even when too few points remain).
- * Coplanar object points (planar initialisation of cvFindExtrinsicCameraParams2) -> DFVO_ERR_ARG. */
+ * Coplanar object points take cvFindExtrinsicCameraParams2's planar (homography) initialisation, as OpenCV does. */
 typedef struct dfvo_pose3d2d_cfg {
     double fx, fy, cx, cy;
     double Kinv[9];                 /* Intrinsics.inv_mat, row-major */
@@ -459,10 +465,28 @@ int dfvo_compose_trajectory(const double* h_rows, int n, const double* h_first, 
 int dfvo_compose_trajectory_device(const double* d_rows, int n, const double* d_first, double* d_poses, int* h_bad_row,
                                    void* stream);
 
-/* Not exported here: the per-sequence pose all-gather of SURVEY.md section 8e ("dfvo_allgather_poses").  It moves 136
- * bytes per frame once per chunk and runs through the process group the host already owns (torch.distributed: RCCL on
- * GPUs, gloo in the CPU tests) -- df-vo_amd/dist.py:allgather_poses, df-vo_amd/sequence.py:run_sequence.  A C caller
- * composes trajectories from dfvo_track_out exactly as dist.compose_trajectory does (dfvo.py:109-119,157-161). */
+/* ---- the data-parallel exchange step (SURVEY.md section 8e / 8b "dfvo_allgather_poses") ----
+ * Every rank tracks its chunks of frame pairs with no activation exchange; ONE RCCL ncclAllGather per job then hands every
+ * rank all relative poses (rows of DFVO_POSE_ROW = 17 doubles: 4x4 row-major cur -> ref pose | status), after which each
+ * rank (or rank 0) composes the trajectories with dfvo_compose_trajectory.  Replaces the sequential hand-over of
+ * update_global_pose between frames (dfvo.py:109-119,157-161) for chunks tracked on different GPUs.
+ * dfvo_comm wraps one RCCL communicator (bound with dlopen("librccl.so.1") at first use; its absence is an error, there is
+ * no fallback).  Bootstrap as with NCCL: rank 0 calls dfvo_comm_unique_id and ships the DFVO_COMM_ID_BYTES bytes to every
+ * rank by any out-of-band means (file, socket, MPI, torch's store); every rank calls dfvo_comm_create (collective; select
+ * the GPU with dfvo_set_device first).
+ * dfvo_allgather_poses: h_rows [n_local][17] of this rank, counts[world] = rows of every rank (deterministic: the chunking
+ * is a function of the job, so no count exchange precedes the collective), h_out [sum counts][17] in rank order.  Ranks
+ * pad to max(counts) rows for the fixed-size collective; the padding is trimmed here.  Synchronous.
+ * _device: the bare collective on caller-owned device buffers (d_send [rows_per_rank][17], d_recv [world][rows_per_rank]
+ * [17]) on `stream` (NULL: the communicator's own), asynchronous. */
+#define DFVO_COMM_ID_BYTES 128
+#define DFVO_POSE_ROW 17
+typedef struct dfvo_comm dfvo_comm;
+int dfvo_comm_unique_id(uint8_t* h_id128);
+int dfvo_comm_create(const uint8_t* h_id128, int world, int rank, dfvo_comm** out);
+int dfvo_comm_destroy(dfvo_comm* c);
+int dfvo_allgather_poses(dfvo_comm* c, const double* h_rows, int n_local, const int* counts, double* h_out);
+int dfvo_allgather_poses_device(dfvo_comm* c, const double* d_send, int rows_per_rank, double* d_recv, void* stream);
 
 #ifdef __cplusplus
 }

@@ -72,7 +72,7 @@ class StubPipeline:
         pass
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, extra=()):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port), DFVO_BENCH_BACKEND="gloo")
     sys.path.insert(0, ROOT)
@@ -86,7 +86,7 @@ def _worker(rank, world, port, q):
     buf = io.StringIO()
     with redirect_stdout(buf):
         bench.main(["--gpus", str(world), "--steps", "5", "--warmup", "1", "--height", "64", "--width", "96",
-                    "--no-roofline", "--no-cpu-baseline"])
+                    "--no-roofline", "--no-cpu-baseline"] + list(extra))
     q.put((rank, buf.getvalue()))
 
 
@@ -108,6 +108,28 @@ def test_bench_two_ranks_gloo():
     assert line["config"]["ranks_seen"] == 2 and line["config"]["gathered_poses"] == 10  # every rank composed all 10 pairs
     assert line["unit"] == "frames/s" and line["value"] > 0
     assert abs(line["value"] - 2 * 5 / (line["ms_per_step"] * 5e-3)) < 1e-2 * line["value"]  # whole-job aggregate
+
+
+def test_bench_sequences_mode_two_ranks_gloo():
+    """bench.py --sequences kitti-lengths (BASELINE config 3) under gloo: eleven sequences as one job over two ranks"""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, ("--sequences", "kitti-lengths", "--scale", "0.003")))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert outs[1].strip() == ""
+    line = json.loads(outs[0].strip().splitlines()[-1])
+    frames = [max(2, int(round(n * 0.003))) for n in (4541, 1101, 4661, 801, 271, 2761, 1101, 1101, 4071, 1591, 1201)]
+    assert line["n_gpus"] == 2 and line["steps"] == sum(frames) - 11 and line["config"]["trajectories"] == 11
+    assert sum(line["config"]["pairs_per_rank"]) == line["steps"] and abs(line["config"]["pairs_per_rank"][0] - line["config"]["pairs_per_rank"][1]) <= 1
+    assert line["config"]["ranks_seen"] == 2 and line["value"] > 0 and "config 3" in line["config"]["workload"]
 
 
 def test_bench_gpus_flag_self_launch(monkeypatch):

@@ -43,7 +43,8 @@ def _worker(rank, world, port, n, q):
     dmod = importlib.import_module("df-vo_amd.dist")
     rel, status = _poses(n)
     lo, hi = dmod.chunk_bounds(n, world, rank)
-    g = dmod.allgather_poses(rel[lo:hi], status[lo:hi], world, rank, dist)
+    counts = [b - a for a, b in (dmod.chunk_bounds(n, world, r) for r in range(world))]  # deterministic: no count exchange
+    g = dmod.allgather_poses(rel[lo:hi], status[lo:hi], world, rank, dist, counts=counts)
     if rank == 0:
         q.put(g)
     dist.barrier()
@@ -199,3 +200,113 @@ def test_run_sequence_chunks_equal_single_rank_per_pair_seed():
     bad[3, 16] = 2
     with pytest.raises(ValueError):
         dmod.compose_trajectory(bad)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# sequence.run_sequences: BASELINE config 3 (eleven sequences frame-batched over the ranks, one all-gather for the job)
+# ---------------------------------------------------------------------------------------------------------------
+KITTI_FRAMES = [4541, 1101, 4661, 801, 271, 2761, 1101, 1101, 4071, 1591, 1201]  # gt_poses/00..10.txt line counts
+
+
+def _job(scale=0.004):
+    """eleven stub sequences with KITTI's length ratios; frame ids are unique per sequence (1000 * k + i)"""
+    seqs = []
+    for k, n in enumerate(KITTI_FRAMES):
+        nf = max(2, int(round(n * scale)))
+        seqs.append(("%02d" % k, [1000 * k + i for i in range(nf)], nf))
+    return seqs
+
+
+class _CountingDist:
+    """wraps torch.distributed: counts the collectives run_sequences issues"""
+
+    def __init__(self, d):
+        self.d, self.calls = d, []
+
+    def get_backend(self):
+        return self.d.get_backend()
+
+    def all_gather(self, *a, **k):
+        self.calls.append("all_gather")
+        return self.d.all_gather(*a, **k)
+
+    def __getattr__(self, name):
+        def f(*a, **k):
+            self.calls.append(name)
+            return getattr(self.d, name)(*a, **k)
+        return f
+
+
+def _job_worker(rank, world, port, out_dir, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    smod = importlib.import_module("df-vo_amd.sequence")
+    cd = _CountingDist(dist)
+    pipe = _StubPipe()
+    res = smod.run_sequences(pipe, _job(), world, rank, cd, seed=4869, out_dir=out_dir)
+    if rank == 0:
+        q.put(({k: (v["poses"], v["gathered"]) for k, v in res.items()}, cd.calls, [e for e in pipe.log if e[0] == "ref"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_job_items_balance_and_cover_kitti_lengths():
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    dmod = importlib.import_module("df-vo_amd.dist")
+    pairs = [n - 1 for n in KITTI_FRAMES]
+    assert sum(KITTI_FRAMES) == 23201
+    for world in (1, 2, 3, 4, 8):
+        items = dmod.job_items(pairs, world)
+        loads = [sum(hi - lo for _, lo, hi in it) for it in items]
+        assert sum(loads) == sum(pairs) and max(loads) - min(loads) <= 1
+        cover = {s: [] for s in range(len(pairs))}
+        for it in items:
+            for s, lo, hi in it:
+                assert 0 <= lo < hi <= pairs[s]
+                cover[s].append((lo, hi))
+        for s, spans in cover.items():  # every sequence covered exactly once, in order
+            spans.sort()
+            assert spans[0][0] == 0 and spans[-1][1] == pairs[s]
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    assert dmod.job_items([0, 3], 2) == [[(1, 0, 2)], [(1, 2, 3)]]  # a one-frame sequence has no pair
+
+
+def test_run_sequences_world2_and_3_equal_single_rank(tmp_path):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    smod = importlib.import_module("df-vo_amd.sequence")
+    ev = importlib.import_module("df-vo_amd.evaluation")
+    seqs = _job()
+    want = smod.run_sequences(_StubPipe(), seqs, 1, 0, None, seed=4869, rng_mode="per_pair")
+    assert list(want) == ["%02d" % k for k in range(11)]
+    assert any((v["gathered"][:, 16] == 1).any() for v in want.values())
+    for world in (2, 3):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        out_dir = str(tmp_path / ("w%d" % world))
+        procs = [ctx.Process(target=_job_worker, args=(r, world, port, out_dir, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        got, calls, refs = q.get(timeout=120)
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+        assert calls.count("all_gather") == 1 and [c for c in calls if c not in ("all_gather", "get_backend")] == []  # ONE collective
+        for name, v in want.items():
+            assert np.array_equal(got[name][0], v["poses"]) and np.array_equal(got[name][1], v["gathered"])
+            assert np.array_equal(ev.load_traj(os.path.join(out_dir, name + ".txt")), v["poses"])  # eleven trajectory files
+        assert len(refs) >= 1  # every item of rank 0 started from its own halo frame
+    # sequential mode (one rank): every sequence re-seeds, i.e. equals that sequence tracked alone
+    seq_all = smod.run_sequences(_StubPipe(), seqs, 1, 0, None, seed=4869)
+    for name, frames, n in seqs[:3]:
+        alone, _ = smod.run_sequence(_StubPipe(), frames, n, 1, 0, None, seed=4869)
+        assert np.array_equal(seq_all[name]["poses"], alone)
+    # metrics per sequence when ground truth is given
+    gts = {name: want[name]["poses"] for name, _, _ in seqs}
+    ev_out = smod.run_sequences(_StubPipe(), seqs, 1, 0, None, seed=4869, rng_mode="per_pair", gts=gts, alignment="6dof")
+    assert all(abs(v["metrics"]["ate"]) < 1e-9 for v in ev_out.values())

@@ -291,3 +291,67 @@ def test_trajectory_composition_on_the_device(gpu):
     rows[50, 16] = 2
     with pytest.raises(ValueError, match="pair 50"):
         dmod.compose_trajectory_device(rows)
+
+
+class _RefTimer:
+    """the surface of the reference's libs/general/timer.py Timer that the trackers touch (timers dict, add / start / end)"""
+
+    def __init__(self):
+        self.timers = {}
+
+    def add(self, item, group=None):
+        self.timers[item] = {"name": item, "time": 0, "is_counting": False, "duration": [], "group": group}
+
+    def start(self, item, group=None):
+        if self.timers.get(item, -1) == -1:
+            self.add(item, group)
+        assert not self.timers[item]["is_counting"]
+        self.timers[item]["is_counting"] = True
+
+    def end(self, item):
+        assert self.timers[item]["is_counting"]
+        self.timers[item]["is_counting"] = False
+
+
+def test_timer_sub_keys_are_fed_from_device_stage_times(gpu):
+    """`timers` is part of EssTracker's signature.  The reference times GRIC-H / find H / find-Ess / GRIC-E /
+    find-Ess (full) / recover pose / triangulation / scale ransac around Python statements (E_tracker.py:197-296,597-638);
+    here the stages are kernels behind one C call and the mirror appends their HIP-event durations under the same keys and
+    groups (dfvo_tracker_stage_ms)."""
+    h, w = 192, 640
+    cfg = make_cfg(h, w)
+    fr = rigid_scene(h, w, seed=300, bad_frac=0.3)
+    K = fr["K"]
+    cam_mod = importlib.import_module("df-vo_amd.libs.geometry.camera_modules")
+    ks_mod = importlib.import_module("df-vo_amd.libs.matching.keypoint_sampler")
+    trk_mod = importlib.import_module("df-vo_amd.libs.tracker")
+    cam = cam_mod.Intrinsics([K[0, 2], K[1, 2], K[0, 0], K[1, 1]])
+    ref_timer = "/root/reference/libs/general/timer.py"
+    import os
+    if os.path.exists(ref_timer):  # build container with a GPU: the reference's own class
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("ref_timer", ref_timer)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        timers = mod.Timer()
+    else:
+        timers = _RefTimer()
+    np.random.seed(4869)
+    trk = trk_mod.EssTracker(cfg, cam, timers)
+    frames = [fr, rigid_scene(h, w, seed=301, bad_frac=0.4)]
+    got = track_sequence(frames, cfg, ks_mod.KeypointSampler(cfg), trk, trk_mod.PnpTracker(cfg, cam), cam_mod.SE3)
+    assert [m for m, _ in got] == ["Ess. Mat."] * 2
+    groups = {"find H": "E-tracker", "GRIC-H": "E-tracker", "find-Ess": "E-tracker", "GRIC-E": "E-tracker",
+              "find-Ess (full)": "E-tracker", "recover pose": "E-tracker", "triangulation": "scale_recovery",
+              "scale ransac": "scale_recovery"}
+    for key, grp in groups.items():
+        t = timers.timers[key]
+        assert t["group"] == grp and len(t["duration"]) == 2 and not t["is_counting"], key
+        assert all(1e-6 < d < 0.5 for d in t["duration"]), (key, t["duration"])
+    d = {k: timers.timers[k]["duration"][1] for k in groups}
+    assert d["GRIC-H"] >= d["find H"] and d["find-Ess (full)"] >= d["find-Ess"] + d["GRIC-E"] * 0.5
+    print("stage ms:", {k: round(v * 1e3, 3) for k, v in d.items()})
+    # a pair the E-tracker never reaches (fewer than 11 keypoints): the E keys get no new entry
+    small = np.ascontiguousarray(np.random.rand(8, 2) * 100)
+    trk.compute_pose_2d2d(small, small + 1.0, True)
+    assert len(timers.timers["find-Ess"]["duration"]) == 2 and len(timers.timers["find H"]["duration"]) == 3

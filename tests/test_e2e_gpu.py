@@ -244,3 +244,48 @@ def test_chunked_sequence_equals_single_chunk(gpu):
     for a, b in zip(seq_rel, whole):
         assert np.linalg.norm(a[:3, 3] - b[:3, 3]) < 0.05 * np.linalg.norm(b[:3, 3])
     pipe.close()
+
+
+def test_job_of_sequences_and_the_rccl_gather(gpu, tmp_path):
+    """BASELINE config 3 on one device: three sequences as one job (sequence.run_sequences) -- as 1 rank, and as the items
+    of a 2- and 3-rank work list tracked one after the other on this pipeline -- give bit-identical rows, trajectories
+    and files; the pose rows go through the C ABI's RCCL communicator (dfvo_comm_* / dfvo_allgather_poses, world size 1:
+    the only size a 1-GPU box can run) and come back unchanged; metrics under the README's 6dof protocol."""
+    pmod, smod = _mods()
+    dmod = importlib.import_module("df-vo_amd.dist")
+    ev = importlib.import_module("df-vo_amd.evaluation")
+    h, w = 256, 640
+    lens = [6, 3, 5]
+    seqs, gts = [], {}
+    pipe = None
+    for k, n in enumerate(lens):
+        seq = coded_tunnel_sequence(h, w, n, mode="mux", step=1.0, seed=21 + k)
+        if pipe is None:
+            pipe = pmod.TrackingPipeline(h, w, 192, 640, seq["K"], crafted_liteflownet_state_dict(h, w, "mux"),
+                                         crafted_monodepth2_state_dict(), seed=4869)
+        seqs.append(("%02d" % k, smod.frames_to_device(seq["frames"]), n))
+        gts["%02d" % k] = seq["poses"]
+    comm = dmod.RcclComm(1, 0, lambda raw: raw)
+    one = smod.run_sequences(pipe, seqs, 1, 0, None, comm, rng_mode="per_pair", out_dir=str(tmp_path), gts=gts, alignment="6dof",
+                             compose="device")
+    total = sum(n - 1 for n in lens)
+    rows = np.concatenate([one[k]["gathered"] for k in one], 0)
+    assert rows.shape == (total, 17) and (rows[:, 16] != 2).all()
+    back = comm.allgather_rows(rows, [total])  # ncclAllGather of the whole job's rows, world 1
+    assert np.array_equal(back, rows)
+    for world in (2, 3):
+        items = dmod.job_items([n - 1 for n in lens], world)
+        parts = []
+        for rank in range(world):
+            for s, lo, hi in items[rank]:
+                rel, st = smod.track_chunk(pipe, seqs[s][1], lo, hi, rng_mode="per_pair")
+                parts.append(dmod.pack_rows(rel, st))
+        assert np.array_equal(np.concatenate(parts, 0), rows)
+    for name, v in one.items():
+        assert np.array_equal(ev.load_traj(str(tmp_path / (name + ".txt"))), v["poses"])
+        assert np.abs(v["poses"] - dmod.compose_trajectory(v["gathered"])).max() <= 1e-12
+        m = v["metrics"]
+        assert m["ate"] < 0.1 and m["rpe_t"] < 0.1, (name, m)  # the coded world is tracked to a few cm
+        print("sequence %s: %d frames, ATE(6dof) %.4f m, RPE %.4f m / %.4f deg" % (name, len(v["poses"]), m["ate"], m["rpe_t"], m["rpe_r"]))
+    comm.close()
+    pipe.close()

@@ -22,7 +22,9 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tunne
 
 # Gates of the from-images accounting, set from the first measured run of round 3 (printed line "FROM-IMAGES ..."); a
 # regression of the nets' agreement with torch-CPU shows up here before it shows up in t_rel
-MIN_IDENTICAL_KP_PAIRS = {"fp32": 0, "f16x3": 0}
+# (the count of pairs with an identical keypoint list / inlier mask is REPORTED, not gated: it measured 0 of 129 in both
+# precisions -- the selection ranks rounding noise, DESIGN.md section 4 -- so a ">= 0" gate would be vacuous; what is gated
+# is the set overlap, the keypoint count and the pose distance below)
 MAX_MEDIAN_DT_F = 1e-2   # measured 5.3e-3 (fp32) / 6.1e-3 (f16x3): RANSAC sampling noise on a 1 m step
 MAX_DT_F = 6e-2          # measured max 3.5e-2 / 2.8e-2
 
@@ -62,7 +64,6 @@ def _from_images_accounting(fx, precision, n, rel, status, kps):
                   mode, precision, n - 1, same_kp, same_mask, same_kp_count, np.median(moved) if moved else -1,
                   max(moved) if moved else -1, 100 * np.median(overlap), 100 * min(overlap),
                   (dF <= 1e-4).sum(), (dF <= 1e-3).sum(), (dF <= 1e-2).sum(), np.median(dF), dF.max()))
-        assert same_kp >= MIN_IDENTICAL_KP_PAIRS[precision]
         assert same_kp_count == n - 1
         assert np.median(overlap) >= 0.95 and min(overlap) >= 0.6  # measured: median 98.1 / 98.9 %, min 88.0 / 74.2 %
         assert np.median(dF) <= MAX_MEDIAN_DT_F and dF.max() <= MAX_DT_F
