@@ -72,7 +72,8 @@ CFG_NAMES = ["conv_igemm_f32<2,2,4,4> 128x128", "conv_igemm_f32<1,4,2,2> 32x128"
              "conv_win_f16s (4|8 x 32) x 128|64|32 (f16 hi/lo planes, v_mfma_f32_32x32x16_f16)",
              "conv_gemm_f16s streaming (1x1, k x 1, stride 2, 7x7 layers; 32 px x 32|64 couts per wave, f16 hi/lo planes)",
              "conv_gemm_f16s K-sliced (small maps: pyramid levels 5-6, depth net inner layers; in-workgroup ordered reduction)",
-             "(unused)", "(unused)"]
+             "conv_gemm_f32g streaming (exact fp32 mode: 1x1, k x 1, stride 2, 7x7 layers; v_mfma_f32_32x32x2_f32, register ring)",
+             "conv_gemm_f32g K-sliced (exact fp32 mode: small maps; in-workgroup ordered reduction)"]
 
 
 def cpu_model():

@@ -174,8 +174,8 @@ __global__ __launch_bounds__(64 * WP * KSP) void conv_gemm_f16s_kernel(const Con
     // order by the wave that finishes the register quad
     if (KSP == 1) {
         ConvEpi<4 * TC> epi;
-        conv_epi_init(p, epi, [&](int q) { return n0 + (q >> 2) * 32 + 8 * (q & 3) + 4 * kb; });
-        conv_epi_row(p, epi, (size_t)(vm ? m : 0), vm, [&](int q) {
+        conv_epi_init_ragged(p, epi, [&](int q) { return n0 + (q >> 2) * 32 + 8 * (q & 3) + 4 * kb; });
+        conv_epi_row_ragged_ok(p, epi, (size_t)(vm ? m : 0), vm, [&](int q) {
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = am[q >> 2][4 * (q & 3) + e] + F16S_LO_UNSCALE * ax[q >> 2][4 * (q & 3) + e];

@@ -30,128 +30,7 @@
 
 namespace dfvo {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ float apply_act(float v, int act, float a) {
-    switch (act) {
-        case ACT_LEAKY: return v > 0.f ? v : v * a;
-        case ACT_RELU: return v > 0.f ? v : 0.f;
-        case ACT_ELU: return v > 0.f ? v : a * expm1f(v);
-        case ACT_SIGMOID: return 1.f / (1.f + expf(-v));
-        default: return v;
-    }
-}
-
-__device__ __forceinline__ int reflect_idx(int i, int n) {
-    i = i < 0 ? -i : i;
-    return i >= n ? 2 * n - 2 - i : i;
-}
-
-// Epilogue of four consecutive output channels [col0, col0+4) of one pixel (linear index m).  The MFMAs are issued
-// with the weight fragment as the A operand, so a lane's four accumulator registers are four consecutive couts of
-// ONE pixel: bias / residual / store move as 16-byte vectors (a quarter of the store instructions, whole 64-byte
-// runs per pixel) whenever the layer's strides allow it.
-__device__ __forceinline__ void conv_epilogue_quad(const ConvParams& p, size_t m, int col0, f32x4 a, bool vec_ok) {
-    float* d = p.dst + m * p.dst_cs + p.dst_co + col0;
-    if (vec_ok && col0 + 3 < p.cout) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + col0);
-        f32x4 v = a + b;
-        if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + m * p.res_cs + p.res_co + col0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = apply_act(v[q], p.act, p.act_param);
-        *reinterpret_cast<f32x4*>(d) = v;
-        return;
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int col = col0 + q;
-        if (col < p.cout) {
-            float v = a[q] + p.bias[col];
-            if (p.res) v += p.res[m * p.res_cs + p.res_co + col];
-            d[q] = apply_act(v, p.act, p.act_param);
-        } else if (col < p.dst_zero_to) {
-            d[q] = 0.f;
-        }
-    }
-}
-__device__ __forceinline__ bool conv_vec_ok(const ConvParams& p) {
-    return (((p.dst_cs | p.dst_co) & 3) == 0) && (!p.res || (((p.res_cs | p.res_co) & 3) == 0));
-}
-
-
-// ---- batched epilogue of the f16x3 kernels --------------------------------------------------------------------------
-// conv_epilogue_quad() interleaves, per quad, a bias (and residual) LOAD with the quad's STORE.  Stores count on vmcnt on
-// this architecture, so the wait for each bias value drains every store issued before it: 16-24 quads per wave become
-// 16-24 serialised store round trips (measured on the level-2 layers: 40 us of a 213 us launch at two workgroups per CU,
-// 111 us of 283 us at one -- the intercept of launch time over the number of channel chunks).  Here the bias quads of the
-// wave's couts are loaded ONCE before the first store, the residual quads of a group of four are loaded together, and the
-// stores go out back to back.  LeakyReLU / ReLU / none are one select-and-multiply with a per-layer slope; ELU is the
-// second instantiation.  Quads that are not fully inside [0, cout) or not 16-byte aligned, and sigmoid layers, fall back
-// to conv_epilogue_quad (wave-uniform decision).
-template <int NQ>
-struct ConvEpi {
-    f32x4 b[NQ];
-    int col0[NQ];
-    float slope;  // LeakyReLU a / none 1 as one formula: v > 0 ? v : v * slope; ReLU selects +0 (as apply_act does)
-    bool relu;
-    bool fast;    // every quad of every lane of the wave takes the vector path
-};
-// col0_of(q): first cout of quad q for this lane
-template <int NQ, class ColOf>
-__device__ __forceinline__ void conv_epi_init(const ConvParams& p, ConvEpi<NQ>& c, ColOf col0_of) {
-    bool ok = conv_vec_ok(p) && p.act != ACT_SIGMOID;  // (sigmoid: the one- / two-channel heads, never vector quads)
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        c.col0[q] = col0_of(q);
-        ok = ok && (c.col0[q] + 3 < p.cout);
-    }
-    c.fast = __all(ok ? 1 : 0) != 0;
-    c.slope = p.act == ACT_LEAKY ? p.act_param : (p.act == ACT_RELU ? 0.f : 1.f);
-    c.relu = p.act == ACT_RELU;
-    if (c.fast) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) c.b[q] = *reinterpret_cast<const f32x4*>(p.bias + c.col0[q]);
-    }
-}
-template <bool ELU, int NQ, class Get>
-__device__ __forceinline__ void conv_epi_row_act(const ConvParams& p, const ConvEpi<NQ>& c, size_t m, Get get) {
-    float* d = p.dst + m * p.dst_cs + p.dst_co;
-    constexpr int GQ = NQ < 4 ? NQ : 4;  // quads per group: a group's residual loads together, its stores back to back
-#pragma unroll
-    for (int q0 = 0; q0 < NQ; q0 += GQ) {
-        f32x4 r[GQ];
-        if (p.res) {
-            const float* rp = p.res + m * p.res_cs + p.res_co;
-#pragma unroll
-            for (int q = 0; q < GQ; ++q) r[q] = *reinterpret_cast<const f32x4*>(rp + c.col0[q0 + q]);
-        }
-#pragma unroll
-        for (int q = 0; q < GQ; ++q) {
-            f32x4 x = get(q0 + q) + c.b[q0 + q];
-            if (p.res) x += r[q];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) x[e] = ELU ? (x[e] > 0.f ? x[e] : p.act_param * expm1f(x[e])) : (x[e] > 0.f ? x[e] : (c.relu ? 0.f : x[e] * c.slope));
-            *reinterpret_cast<f32x4*>(d + c.col0[q0 + q]) = x;
-        }
-    }
-}
-// one output pixel (linear index m) x NQ quads; get(q) = the accumulated quad; `valid` false = the lane has no pixel here
-template <int NQ, class Get>
-__device__ __forceinline__ void conv_epi_row(const ConvParams& p, const ConvEpi<NQ>& c, size_t m, bool valid, Get get) {
-    if (!c.fast) {
-        if (valid) {
-            const bool vec_ok = conv_vec_ok(p);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) conv_epilogue_quad(p, m, c.col0[q], get(q), vec_ok);
-        }
-        return;
-    }
-    if (!valid) return;
-    if (p.act == ACT_ELU)  // wave-uniform
-        conv_epi_row_act<true, NQ>(p, c, m, get);
-    else
-        conv_epi_row_act<false, NQ>(p, c, m, get);
-}
+#include "conv_epi.h"
 
 // Split-K finish inside the contracting kernel.  After a workgroup has written its partial tile to the workspace it draws
 // a ticket for that tile; whoever draws the last one (all z-slices are then written) reduces the partials and runs the
@@ -1385,6 +1264,39 @@ void conv_effective_config(const ConvParams& p, int* bm_out, int* splits_out) {
     *splits_out = conv_pick_splits(p, ((M + bm - 1) / bm) * (p.cout_pad / bn));
 }
 
+// exact-fp32 mode: which layers leave conv_igemm_f32_kernel for the register-ring kernel (conv_gemm_f32g.hip).  Not the
+// 3x3 / stride-1 layers the LDS-window kernel takes, not the one- / two-channel heads.
+// DFVO_F32G: 0 off, 1 (default) the small maps whose igemm launch would split K across workgroups or leave the chip idle,
+// 2 every non-window layer
+static bool conv_f32g_takes(const ConvParams& p, int bn) {
+    static const int mode = getenv("DFVO_F32G") ? atoi(getenv("DFVO_F32G")) : 1;
+    if (conv_use_head(p)) return false;
+    if (conv_use_window(p, bn)) return false;
+    if (mode >= 2) return true;
+    const long long M = (long long)p.N * p.Ho * p.Wo;
+    return M <= 8192;  // pyramid levels 5 / 6 (2 x 11 x 38 .. 2 x 44 x 152) and the depth net's 6 x 20 .. 48 x 160 maps
+}
+static int launch_f32g_prof(const ConvParams& p, hipStream_t stream) {
+    ConvProfEntry pe;
+    if (g_prof) {
+        DFVO_HIP_CHECK(hipEventCreate(&pe.e0));
+        DFVO_HIP_CHECK(hipEventCreate(&pe.e1));
+        DFVO_HIP_CHECK(hipEventRecord(pe.e0, stream));
+    }
+    int ksp = 1, gx = 0;
+    const int rc = launch_f32g(p, stream, &ksp, &gx);
+    if (rc != DFVO_OK) return rc;
+    if (g_prof) {
+        pe.cfg = ksp == 1 ? 22 : 23;  // profile rows: 22 streaming (KSP = 1), 23 K-sliced small maps
+        DFVO_HIP_CHECK(hipEventRecord(pe.e1, stream));
+        pe.flops = p.useful_flops;
+        const int sh[12] = {p.N, p.H, p.W, p.Ho, p.Wo, (p.G0 + p.G1) * 4, p.cout, p.kh, p.stride, gx, 0, ksp * 100 + 1};
+        for (int i = 0; i < 12; ++i) pe.shape[i] = sh[i];
+        g_prof->push_back(pe);
+    }
+    return DFVO_OK;
+}
+
 int launch_conv(const ConvParams& p, hipStream_t stream) {
     const long long M = (long long)p.N * p.Ho * p.Wo;
     const int bn = conv_pick_bn(p.cout, M);
@@ -1401,6 +1313,7 @@ int launch_conv(const ConvParams& p, hipStream_t stream) {
         return rc2 != F16S2_NOT_APPLICABLE ? rc2 : launch_f16s(p, stream, 19);  // errors (negative) propagate
     }
     if (conv_f16g_ok(p)) return launch_f16g(p, stream);  // f16x3: everything else (small maps, 1x1, k x 1, stride 2, 7x7)
+    if (conv_f32g_ok(p) && conv_f32g_takes(p, bn)) return launch_f32g_prof(p, stream);  // exact fp32: the same skeleton on fp32 MFMAs
     if (conv_use_window(p, bn) && p.kh == 7) return launch_win3<4, 1, 2, 1, 7>(p, stream, 16);
     if (conv_use_window(p, bn) && p.kh == 5) return launch_win3<4, 1, 2, 1, 5>(p, stream, 17);
     if (conv_use_window(p, bn)) {

@@ -22,13 +22,7 @@
 #pragma once
 // (included inside namespace dfvo)
 
-typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr float F16S_LO_SCALE = 2048.0f;          // 2^11
-constexpr float F16S_LO_UNSCALE = 1.0f / 2048.0f;
-constexpr float F16S_MAX = 65504.0f;
+#include "conv_f16_split.h"
 
 // |x| > 65504 does not fit the hi plane.  It is neither clamped (a silently wrong product) nor ignored: the conversion
 // yields +-inf, which propagates as inf / NaN into the layer's output, and every kernel that splits activations keeps the
@@ -39,19 +33,6 @@ __device__ unsigned int g_f16s_clamped = 0;
 __device__ __forceinline__ void f16s_report_clamp(float amax) {
     if (amax > F16S_MAX) atomicAdd(&g_f16s_clamped, 1u);
 }
-__device__ __forceinline__ void split_f16_planes(f32x4 x, h16x4* hi, h16x4* lo, float& amax) {
-    // (spelled as instructions: fmaxf() drags a canonicalising v_max per operand along, 7 instructions instead of 2)
-    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(x[0]), "v"(x[1]));
-    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(x[2]), "v"(x[3]));
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float v = x[e];
-        const _Float16 h = (_Float16)v;  // round to nearest even
-        (*hi)[e] = h;
-        (*lo)[e] = (_Float16)((v - (float)h) * F16S_LO_SCALE);  // v - h is exact in fp32
-    }
-}
-
 template <int WC, int WR, int TC, int TR>
 __global__ __launch_bounds__(64 * WC * WR, 2) void conv_win_f16s_kernel(const ConvParams p) {
     constexpr int NT = 64 * WC * WR;  // 4 or 8 waves per workgroup

@@ -315,6 +315,56 @@ static int launch_f16s2_cfg(const ConvParams& p, hipStream_t stream, int cfg_id)
 // DFVO_ERR_* code is negative) when the layer should stay on the first
 // skeleton (small grids: fewer than ~200 workgroups cannot fill the chip at one workgroup per CU).
 constexpr int F16S2_NOT_APPLICABLE = 1;
+// third skeleton (conv_win_f16s3.hip, its own translation unit): the same tile loop, a run of p.tile_run tiles per workgroup
+int launch_f16s3_shape(const ConvParams& p, int shape, hipStream_t stream, int* grid_xy);
+bool f16s3_eligible(const ConvParams& p);
+static unsigned* f16s_clamp_counter() {
+    static unsigned* ptr = nullptr;
+    if (!ptr && hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(g_f16s_clamped)) != hipSuccess) ptr = nullptr;
+    return ptr;
+}
+// Run length of the third skeleton (DFVO_F16S_RUN: unset / 0 = second skeleton, N >= 1 = runs of N tiles, p = persistent:
+// one workgroup per CU walking ceil(tiles / 256) tiles, p<k> = the same on 256 - k CUs).  OFF by default -- measured
+// (profiles/r4c_*, r4g_*): the persistent form is 6-9 % faster one launch at a time (level-2 128 -> 128: 202 -> 188 us,
+// config-5 layer 1016 -> 929 us, roofline fraction 0.280 -> 0.296) and 5 % SLOWER in the pipeline (299 -> 283 pairs/s); runs
+// of two where they cost no extra round: -2 %.  A CU is handed back only when a workgroup ends, and the other streams of
+// the pipeline (the RandomState-ordered solver chain above all) wait for CUs; what a run saves per tile is ~3 us of 44.
+static int f16s3_run_for(int tiles) {
+    static const char* e = getenv("DFVO_F16S_RUN");
+    if (e && e[0] == 'p') {  // "p" / "p<reserve>": persistent on 256 - reserve CUs
+        const int cus = 256 - atoi(e + 1);
+        return (tiles + cus - 1) / cus;
+    }
+    return e ? atoi(e) : 0;
+}
+template <int WC, int WR, int TC, int TR>
+static int launch_f16s23(const ConvParams& p, hipStream_t stream, int cfg_id, int shape) {
+    constexpr int TH = WR * TR;
+    const int tiles = p.N * ((p.Ho + TH - 1) / TH) * ((p.Wo + 31) / 32);
+    const int run = f16s3_run_for(tiles);
+    if (run <= 0 || !f16s3_eligible(p)) return launch_f16s2_cfg<WC, WR, TC, TR>(p, stream, cfg_id);
+    ConvParams q = p;
+    q.tile_run = run;
+    q.f16s_clamp_ctr = f16s_clamp_counter();
+    ConvProfEntry pe;
+    if (g_prof) {
+        DFVO_HIP_CHECK(hipEventCreate(&pe.e0));
+        DFVO_HIP_CHECK(hipEventCreate(&pe.e1));
+        pe.cfg = cfg_id;
+        DFVO_HIP_CHECK(hipEventRecord(pe.e0, stream));
+    }
+    int gxy[2] = {0, 0};
+    const int rc = launch_f16s3_shape(q, shape, stream, gxy);
+    if (rc != DFVO_OK) return rc;
+    if (g_prof) {
+        DFVO_HIP_CHECK(hipEventRecord(pe.e1, stream));
+        pe.flops = p.useful_flops;
+        const int sh[12] = {p.N, p.H, p.W, p.Ho, p.Wo, (p.G0 + p.G1) * 4, p.cout, p.kh, p.stride, gxy[0], gxy[1], 3};
+        for (int i = 0; i < 12; ++i) pe.shape[i] = sh[i];
+        g_prof->push_back(pe);
+    }
+    return DFVO_OK;
+}
 static int launch_f16s2(const ConvParams& p, hipStream_t stream, int cfg_id) {
     // default on: per layer the two skeletons are within 2 % of each other (tools/bench_f16s_v2.py), inside the pipeline the
     // one-wave-per-SIMD one gives +3 % pairs/s (half the resident net waves next to the solver's kernels).
@@ -328,17 +378,17 @@ static int launch_f16s2(const ConvParams& p, hipStream_t stream, int cfg_id) {
         const long long b3 = f16s2_blocks<2, 2, 2, 3>(p), b2 = f16s2_blocks<2, 2, 2, 2>(p);
         if (b2 < 200) return F16S2_NOT_APPLICABLE;
         const long long c3 = cost(b3, 6), c2 = cost(b2, 4) * 11 / 10;  // (small tiles: fewer MFMAs per load)
-        if ((mode & 2) || c3 <= c2) return launch_f16s2_cfg<2, 2, 2, 3>(p, stream, cfg_id);
-        return launch_f16s2_cfg<2, 2, 2, 2>(p, stream, cfg_id);
+        if ((mode & 2) || c3 <= c2) return launch_f16s23<2, 2, 2, 3>(p, stream, cfg_id, 0);
+        return launch_f16s23<2, 2, 2, 2>(p, stream, cfg_id, 1);
     }
     if (p.wf16_cout_pad % 64 == 0) {
         const long long b3 = f16s2_blocks<1, 4, 2, 3>(p), b2 = f16s2_blocks<1, 4, 2, 2>(p);
         if (b2 < 200) return F16S2_NOT_APPLICABLE;
-        if ((mode & 2) || cost(b3, 12) <= cost(b2, 8)) return launch_f16s2_cfg<1, 4, 2, 3>(p, stream, cfg_id);
-        return launch_f16s2_cfg<1, 4, 2, 2>(p, stream, cfg_id);
+        if ((mode & 2) || cost(b3, 12) <= cost(b2, 8)) return launch_f16s23<1, 4, 2, 3>(p, stream, cfg_id, 2);
+        return launch_f16s23<1, 4, 2, 2>(p, stream, cfg_id, 3);
     }
     const long long b3 = f16s2_blocks<1, 4, 1, 3>(p), b2 = f16s2_blocks<1, 4, 1, 2>(p);
     if (b2 < 200) return F16S2_NOT_APPLICABLE;
-    if ((mode & 2) || cost(b3, 12) <= cost(b2, 8)) return launch_f16s2_cfg<1, 4, 1, 3>(p, stream, cfg_id);
-    return launch_f16s2_cfg<1, 4, 1, 2>(p, stream, cfg_id);
+    if ((mode & 2) || cost(b3, 12) <= cost(b2, 8)) return launch_f16s23<1, 4, 1, 3>(p, stream, cfg_id, 4);
+    return launch_f16s23<1, 4, 1, 2>(p, stream, cfg_id, 5);
 }

@@ -71,6 +71,9 @@ struct ConvParams {
     int wf16g_cout_pad;
     const uint32_t* f16g_tab;
     int f16g_steps;
+    // exact-fp32 twin of the above for conv_gemm_f32g_kernel (fp32 mode): [16-k step][cout_pad / 32][k / 8][32 couts][8]
+    // floats, same k-group table and cout padding (wf16g_cout_pad, f16g_tab, f16g_steps are set in both modes)
+    const float* wf32g;
     int cout, cout_pad, ksteps;
     // optional residual (added before activation)
     const float* res;
@@ -92,6 +95,10 @@ struct ConvParams {
     double useful_flops;
     // launch overrides chosen by the per-layer autotuner (0 = heuristic): M tile rows, split-K factor
     int force_bm, force_splits;
+    // conv_win_f16s3 (tile-run window kernel, its own translation unit): consecutive tiles per workgroup, and the device
+    // counter of activations beyond f16's range (g_f16s_clamped of conv_win_f16s.h; device symbols do not cross TUs)
+    int tile_run;
+    unsigned* f16s_clamp_ctr;
 };
 
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
@@ -185,6 +192,9 @@ int conv_f16s_overflow_count(unsigned long long* n, int reset);  // saturation r
 void conv_build_f16g_table(int c0, int c1, int kh, int kw, std::vector<uint32_t>* tab);
 size_t conv_pack_weights_f16g(const float* w_oihw, int cout, int c0, int c1, int kh, int kw, const float* fold_scale,
                               unsigned short* out);
+size_t conv_pack_weights_f32g(const float* w_oihw, int cout, int c0, int c1, int kh, int kw, const float* fold_scale, float* out);
+bool conv_f32g_ok(const ConvParams& p);
+int launch_f32g(const ConvParams& p, hipStream_t stream, int* ksp_out, int* grid_x);
 size_t conv_head_weight_floats(int cout, int c0, int c1, int k);
 void conv_pack_head_weights(const float* w_oihw, int cout, int c0, int c1, int k, const float* fold_scale, float* out);
 void conv_pack_weights(const float* w_oihw, const float* bias, int cout, int c0, int c1, int kh, int kw,

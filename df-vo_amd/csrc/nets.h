@@ -32,6 +32,7 @@ struct ConvLayer {
     int wf_cout_pad = 0;
     unsigned short* wg = nullptr;  // f16 hi/lo planes in k-group order for conv_gemm_f16s_kernel (f16x3 mode, every layer)
     uint32_t* gtab = nullptr;      // its k-group table
+    float* wg32 = nullptr;         // fp32 weights in the same k-group order for conv_gemm_f32g_kernel (fp32 mode, every layer)
     int wg_cout_pad = 0, g_steps = 0;
     float* wh = nullptr;  // head layout (cout <= 2, square 3/5/7 kernels), see conv_pack_head_weights
     int cout = 0, cout_pad = 0, c0 = 0, c1 = 0, kh = 0, kw = 0, ksteps = 0;

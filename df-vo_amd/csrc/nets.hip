@@ -113,6 +113,19 @@ int make_f16s_weights(const float* w_oihw, int cout, int c0, int c1, int kh, int
 }
 
 int make_f16g_weights(const float* w_oihw, int cout, int c0, int c1, int kh, int kw, const float* scale, ConvLayer* L) {
+    if (conv_split_mode() == 0 && kh <= 31 && kw <= 31) {  // exact fp32: the register-ring kernel's fp32 weights + the table
+        std::vector<float> wg(conv_pack_weights_f32g(w_oihw, cout, c0, c1, kh, kw, scale, nullptr));
+        conv_pack_weights_f32g(w_oihw, cout, c0, c1, kh, kw, scale, wg.data());
+        std::vector<uint32_t> tab;
+        conv_build_f16g_table(c0, c1, kh, kw, &tab);
+        DFVO_HIP_CHECK(hipMalloc((void**)&L->wg32, wg.size() * sizeof(float) + 256));
+        DFVO_HIP_CHECK(hipMemcpy(L->wg32, wg.data(), wg.size() * sizeof(float), hipMemcpyHostToDevice));
+        DFVO_HIP_CHECK(hipMalloc((void**)&L->gtab, tab.size() * sizeof(uint32_t) + 256));
+        DFVO_HIP_CHECK(hipMemcpy(L->gtab, tab.data(), tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        L->wg_cout_pad = round_up(cout, 32);
+        L->g_steps = (int)(tab.size() / 4);
+        return DFVO_OK;
+    }
     if (conv_split_mode() != 4 || kh > 31 || kw > 31) return DFVO_OK;
     std::vector<unsigned short> wg(conv_pack_weights_f16g(w_oihw, cout, c0, c1, kh, kw, scale, nullptr));
     conv_pack_weights_f16g(w_oihw, cout, c0, c1, kh, kw, scale, wg.data());
@@ -157,6 +170,8 @@ void free_conv(ConvLayer* l) {
     if (l->wsp) (void)hipFree(l->wsp);
     if (l->wf) (void)hipFree(l->wf);
     if (l->wg) (void)hipFree(l->wg);
+    if (l->wg32) (void)hipFree(l->wg32);
+    l->wg32 = nullptr;
     if (l->gtab) (void)hipFree(l->gtab);
     l->wf = nullptr;
     l->wg = nullptr;
@@ -276,6 +291,7 @@ int run_conv(const ConvLayer& L, int N, int H, int W, View s0, int up0, View s1,
     p.wf16 = L.wf;
     p.wf16_cout_pad = L.wf_cout_pad;
     p.wf16g = L.wg;
+    p.wf32g = L.wg32;
     p.wf16g_cout_pad = L.wg_cout_pad;
     p.f16g_tab = L.gtab;
     p.f16g_steps = L.g_steps;
