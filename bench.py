@@ -46,8 +46,8 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")  # before torch / HIP initialis
 SLOTS = 4  # DFVO_PIPELINE_SLOTS
 PREFETCH = os.environ.get("DFVO_BENCH_PREFETCH", "1") != "0"  # RNG-independent solver half enqueued behind the nets
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: FP32 matrix (f32 in / f32 acc)
-PEAK_BF16_MFMA_TFLOPS = 2500.0  # same table: BF16 MFMA dense (only used for the opt-in split-precision modes)
-PMC_FILE = "r3_pmc_bench.json"  # committed rocprofv3 --pmc passes over the default command (tools/r3_profile.sh)
+PEAK_F16_MFMA_TFLOPS = 2500.0  # same table: F16 / BF16 MFMA dense
+PMC_FILE = "r4_pmc_bench.json"  # committed rocprofv3 --pmc passes over the default command (tools/profile.sh)
 
 
 def kernel_source_digest():
@@ -435,10 +435,10 @@ def main(argv=None):
     ap.add_argument("--width", type=int, default=1241)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--conv-precision", default=os.environ.get("DFVO_CONV_PRECISION", "f16x3"), choices=["fp32", "f16x3", "bf16x6", "bf16x3"],
+    ap.add_argument("--conv-precision", default=os.environ.get("DFVO_CONV_PRECISION", "f16x3"), choices=["fp32", "f16x3"],
                     help="arithmetic of the 3x3 window layers: f16x3 (default: fp32-class split kernel, the whole -m gpu net / "
                          "pipeline parity suite runs green on it at the exact path's tolerances), fp32 (exact fp32 MFMA), "
-                         "bf16x6 / bf16x3 (round-1 experiments) -- reported in dtype and config.conv_precision")
+                         "-- reported in dtype and config.conv_precision")
     ap.add_argument("--solver-inputs", default="nets", choices=["nets", "synthetic"],
                     help="nets: the solver stage consumes the nets' own outputs (coded-world frames, the product data path); "
                          "synthetic: random-weight nets + a synthetic rigid-scene flow/consistency/depth triple (round-1 mode)")
@@ -717,13 +717,13 @@ def main(argv=None):
         dom = int(np.argmax(ms))
         ach = fl[dom] / (ms[dom] * 1e-3) / 1e12
         fam = fl.sum() / (ms.sum() * 1e-3) / 1e12
-        # exact fp32: the fp32-MFMA peak.  Split modes: 3 (f16x3) / 4 (bf16x3) / 6 (bf16x6) half-precision products per
-        # fp32 product, so the ceiling for USEFUL fp32-equivalent FLOPs is the dense f16 / bf16 peak divided by that
-        terms = {"fp32": 0, "f16x3": 3, "bf16x3": 4, "bf16x6": 6}[args.conv_precision]
+        # exact fp32: the fp32-MFMA peak.  f16x3: three f16 products per fp32 product, so the ceiling for USEFUL
+        # fp32-equivalent FLOPs is the dense f16 peak divided by three
+        terms = {"fp32": 0, "f16x3": 3}[args.conv_precision]
         if terms and dom < 19 and args.conv_precision == "f16x3":
             terms = 0  # a kernel of the exact fp32 family dominates although the window layers run split: price it as fp32
-        peak = PEAK_F32_MFMA_TFLOPS if not terms else PEAK_BF16_MFMA_TFLOPS / terms
-        roof = {"bound": "mfma", "kernel": CFG_NAMES[dom].replace("conv_win3_f32", "conv_win3_f32" if not terms else "conv_win3_bf16s"),
+        peak = PEAK_F32_MFMA_TFLOPS if not terms else PEAK_F16_MFMA_TFLOPS / terms
+        roof = {"bound": "mfma", "kernel": CFG_NAMES[dom],
                 "achieved": round(ach, 2), "peak": round(peak, 1),
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                 "avg_launch_us": round(ms[dom] * 1e3 / max(1, ln[dom]), 2), "launches_per_pair": int(ln[dom] // nprof),
@@ -735,7 +735,7 @@ def main(argv=None):
                                "tflops": round(float(fl[i] / (ms[i] * 1e-3) / 1e12), 1)}
                               for i in np.argsort(-ms) if ln[i] > 0]}
         # HBM-side bytes per launch of that kernel: hardware counters cannot be read from inside the process, so they come
-        # from the committed rocprofv3 --pmc passes over this same command (tools/r3_profile.sh -> tools/pmc_traffic.py:
+        # from the committed rocprofv3 --pmc passes over this same command (tools/profile.sh -> tools/pmc_traffic.py:
         # FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes); None when no committed profile holds the kernel.  The
         # profile records the library build it was taken on: a stale file is reported as such, not silently used.
         try:
@@ -812,7 +812,7 @@ def main(argv=None):
             "scaling": "weak", "vs_baseline": None,
             "dtype": {"fp32": "f32", "f16x3": "f32 (f16x3 split products: two f16 planes per operand = 22 mantissa bits, three exact "
                                                 "products per term, fp32 accumulate; direct one- / two-channel heads exact fp32)"
-                      }.get(args.conv_precision, "f32 accumulate, %s split-bf16 products in the 3x3 window layers (opt-in)" % args.conv_precision),
+                      }[args.conv_precision],
             "data": "synthetic",
             "config": {"workload": "%dx%d frame pairs%s (flow net %dx%d batch 2; device LANCZOS resize + depth net 192x640), "
                                    "local_bestN %d keypoints, findHomography + 5x findEssentialMat(%d-iteration budget) + GRIC + "

@@ -112,7 +112,6 @@ SIGNATURES = {
     "dfvo_correlation": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     "dfvo_backward_warp": (_i, [_vp, _vp, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "dfvo_deconv_dw4x4s2": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
-    "dfvo_split_bf16_planes": (_i, [_vp, _i, _i, _vp]),
     "dfvo_lanczos_coeffs": (_i, [_i, _i, _vp, _vp, _i, _ip]),
     "dfvo_resize_lanczos_u8": (_i, [_vp, _i, _i, _vp, _i, _i, _vp]),
     "dfvo_resize_linear_u8": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp]),

@@ -105,21 +105,14 @@ int dfvo_conv2d(const dfvo_conv_desc* d, const float* d_src0, const float* d_src
     DFVO_HIP_CHECK(hipMemcpy(db, pb.data(), pb.size() * sizeof(float), hipMemcpyHostToDevice));
     ConvLayer L;
     L.wp = dw;
-    if (make_split_weights(pw, d->kh, d->kw, &L) != DFVO_OK) {  // opt-in split-precision modes, as in make_conv
-        (void)hipFree(dw);
-        (void)hipFree(db);
-        return DFVO_ERR_HIP;
-    }
     if (make_f16s_weights(h_w, d->cout, d->c0, d->c1, d->kh, d->kw, nullptr, &L) != DFVO_OK) {
         (void)hipFree(dw);
         (void)hipFree(db);
-        if (L.wsp) (void)hipFree(L.wsp);
         return DFVO_ERR_HIP;
     }
     if (make_f16g_weights(h_w, d->cout, d->c0, d->c1, d->kh, d->kw, nullptr, &L) != DFVO_OK) {
         (void)hipFree(dw);
         (void)hipFree(db);
-        if (L.wsp) (void)hipFree(L.wsp);
         if (L.wf) (void)hipFree(L.wf);
         return DFVO_ERR_HIP;
     }
@@ -156,9 +149,9 @@ int dfvo_conv2d(const dfvo_conv_desc* d, const float* d_src0, const float* d_src
     (void)hipFree(dw);
     (void)hipFree(db);
     if (L.wh) (void)hipFree(L.wh);
-    if (L.wsp) (void)hipFree(L.wsp);
     if (L.wf) (void)hipFree(L.wf);
     if (L.wg) (void)hipFree(L.wg);
+    if (L.wg32) (void)hipFree(L.wg32);
     if (L.gtab) (void)hipFree(L.gtab);
     if (rc != DFVO_OK) return rc;
     DFVO_HIP_CHECK(e);
@@ -405,11 +398,6 @@ int dfvo_depthnet_forward_image_host(dfvo_depthnet* n, const uint8_t* h_img, int
     API_TRY(d.forward((const uint8_t*)d.u8_in.p, d.depth.p));
     DFVO_HIP_CHECK(hipMemcpyAsync(h_depth, d.depth.p, px * sizeof(float), hipMemcpyDeviceToHost, d.stream));
     DFVO_HIP_CHECK(hipStreamSynchronize(d.stream));
-    return DFVO_OK;
-}
-int dfvo_split_bf16_planes(const float* h_in, int n, int planes, uint16_t* h_out) {
-    DFVO_ARG_CHECK(h_in && h_out && n >= 0 && (planes == 2 || planes == 3), "dfvo_split_bf16_planes: bad argument");
-    conv_split_weights_bf16(h_in, (size_t)n, planes, h_out);
     return DFVO_OK;
 }
 int dfvo_lanczos_coeffs(int in_size, int out_size, int* h_bounds, int* h_coeffs, int coeff_cap, int* ksize) {

@@ -68,10 +68,6 @@ struct ConvEpi {
     float slope;  // LeakyReLU a / none 1 as one formula: v > 0 ? v : v * slope; ReLU selects +0 (as apply_act does)
     bool relu;
     bool fast;    // every quad of every lane of the wave takes the vector path
-    // ragged layers (cout not a multiple of the wave's cout tile: the 49- / 25-channel distance layers): bit q = quad q is
-    // inside [0, cout) for EVERY lane of the wave -> vector path with the preloaded bias; the other quads take
-    // conv_epilogue_quad after them.  Zero when the layer's views are unaligned or the activation is a sigmoid.
-    unsigned fastmask;
 };
 // col0_of(q): first cout of quad q for this lane
 template <int NQ, class ColOf>
@@ -83,44 +79,11 @@ __device__ __forceinline__ void conv_epi_init(const ConvParams& p, ConvEpi<NQ>& 
         ok = ok && (c.col0[q] + 3 < p.cout);
     }
     c.fast = __all(ok ? 1 : 0) != 0;
-    c.fastmask = 0;
     c.slope = p.act == ACT_LEAKY ? p.act_param : (p.act == ACT_RELU ? 0.f : 1.f);
     c.relu = p.act == ACT_RELU;
     if (c.fast) {
 #pragma unroll
         for (int q = 0; q < NQ; ++q) c.b[q] = *reinterpret_cast<const f32x4*>(p.bias + c.col0[q]);
-    }
-}
-// + the per-quad mask of a ragged layer (only the kernels that call conv_epi_row_ragged_ok need it)
-template <int NQ, class ColOf>
-__device__ __forceinline__ void conv_epi_init_ragged(const ConvParams& p, ConvEpi<NQ>& c, ColOf col0_of) {
-    conv_epi_init(p, c, col0_of);
-    const bool vec = conv_vec_ok(p) && p.act != ACT_SIGMOID;
-#pragma unroll
-    for (int q = 0; q < NQ; ++q)
-        if (__all((vec && c.col0[q] + 3 < p.cout) ? 1 : 0)) c.fastmask |= 1u << q;
-}
-// the vector quads of a ragged layer, stores back to back (no residual grouping: those layers have none; a residual is
-// loaded per quad), then the quads that cross cout one element at a time
-template <bool ELU, int NQ, class Get>
-__device__ __forceinline__ void conv_epi_row_ragged(const ConvParams& p, const ConvEpi<NQ>& c, size_t m, Get get) {
-    float* d = p.dst + m * p.dst_cs + p.dst_co;
-    f32x4 x[NQ];  // (every quad's bias from a valid address: nothing here is conditionally initialised or indexed at run time)
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) x[q] = *reinterpret_cast<const f32x4*>(p.bias + (c.col0[q] + 3 < p.cout ? c.col0[q] : 0));
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const f32x4 a = get(q);
-        x[q] = a + x[q];
-        if (p.res) x[q] += *reinterpret_cast<const f32x4*>(p.res + m * p.res_cs + p.res_co + (c.col0[q] + 3 < p.cout ? c.col0[q] : 0));
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-            x[q][e] = ELU ? (x[q][e] > 0.f ? x[q][e] : p.act_param * expm1f(x[q][e])) : (x[q][e] > 0.f ? x[q][e] : (c.relu ? 0.f : x[q][e] * c.slope));
-        if ((c.fastmask >> q) & 1u) *reinterpret_cast<f32x4*>(d + c.col0[q]) = x[q];  // wave-uniform
-    }
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        if (((c.fastmask >> q) & 1u) == 0u) conv_epilogue_quad(p, m, c.col0[q], get(q), true);
     }
 }
 template <bool ELU, int NQ, class Get>
@@ -164,19 +127,3 @@ __device__ __forceinline__ void conv_epi_row(const ConvParams& p, const ConvEpi<
 }
 
 
-// conv_epi_row for the kernels that run the ragged layers (the generic register-ring kernels: the 49- / 25-channel distance
-// layers of the flow net at levels 2-4): the quads inside [0, cout) take the vector path, only the crossing quad goes
-// element-wise.  Kept out of conv_epi_row itself: the LDS-window kernels, whose register budget is exhausted, must not
-// carry the extra path (it costs them their accumulator allocation).
-template <int NQ, class Get>
-__device__ __forceinline__ void conv_epi_row_ragged_ok(const ConvParams& p, const ConvEpi<NQ>& c, size_t m, bool valid, Get get) {
-    if (!c.fast && c.fastmask) {
-        if (!valid) return;
-        if (p.act == ACT_ELU)
-            conv_epi_row_ragged<true, NQ>(p, c, m, get);
-        else
-            conv_epi_row_ragged<false, NQ>(p, c, m, get);
-        return;
-    }
-    conv_epi_row(p, c, m, valid, get);
-}

@@ -28,7 +28,11 @@ static inline uint32_t f16g_entry(int ky, int kx, int valid, int src, int choff)
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(4))) const u32x4 cu32x4;
 
-template <int WP, int KSP, int TC, int PF = 3>  // PF: register ring, loads of step s + PF are issued when step s has been consumed
+// RAG (KSP = 1 shapes only): the layer's cout is not a multiple of the wave's cout tile (the 49- / 25-channel distance
+// layers).  The shared epilogue sends such a wave through conv_epilogue_quad quad by quad -- a bias load, a wait, a store,
+// and since stores count on vmcnt every wait drains the stores before it: 8-16 serialised round trips per wave, which is
+// most of those layers' launch time.  The RAG instantiation loads every quad's bias first and then only stores.
+template <int WP, int KSP, int TC, int PF = 3, bool RAG = false>  // PF: register ring, loads of step s + PF are issued when step s has been consumed
 __global__ __launch_bounds__(64 * WP * KSP) void conv_gemm_f16s_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float f16g_red[];  // [WP][KSP][TC][16][64] partial blocks (KSP > 1)
 
@@ -61,14 +65,10 @@ __global__ __launch_bounds__(64 * WP * KSP) void conv_gemm_f16s_kernel(const Con
         ix0 = ox * p.stride - p.pad_w;
     }
     const int n0 = ytile * (32 * TC);
-    // K slice of this wave.  gridDim.z > 1 (small maps that cannot fill the chip with their tiles x KSP waves): the K range
-    // is first divided over gridDim.z WORKGROUPS; their partial blocks meet in the split-K workspace and are added in
-    // workgroup order by the last one to arrive (tile tickets: splitk_last_arriver of conv_igemm_f32.hip) -- deterministic
-    // like the in-workgroup sum, and the launch streams its weights through gridDim.z times as many compute units.
+    // K slice of this wave
     const int S = p.f16g_steps;
-    const int nz = __builtin_amdgcn_readfirstlane((int)gridDim.z), zb = __builtin_amdgcn_readfirstlane((int)blockIdx.z);
-    const int per = (S + KSP * nz - 1) / (KSP * nz);
-    const int s0 = (zb * KSP + wk) * per < S ? (zb * KSP + wk) * per : S;
+    const int per = (S + KSP - 1) / KSP;
+    const int s0 = wk * per < S ? wk * per : S;
     const int s1 = s0 + per < S ? s0 + per : S;
 
     // Everything the gather needs from the parameter block lives in SGPRs for the whole kernel.  (Left to itself the
@@ -172,10 +172,43 @@ __global__ __launch_bounds__(64 * WP * KSP) void conv_gemm_f16s_kernel(const Con
 
     // combine the two accumulator sets; with KSP > 1 the partial blocks of a pixel block meet in LDS and are added in slice
     // order by the wave that finishes the register quad
+    if (KSP == 1 && RAG) {  // (host: 16-byte aligned views, no residual, none / leaky / relu)
+        if (!vm) return;
+        float* const drow = p.dst + (size_t)m * p.dst_cs + p.dst_co;
+        const float slope = p.act == ACT_LEAKY ? p.act_param : 1.f;
+        f32x4 bq[4 * TC];
+#pragma unroll
+        for (int q = 0; q < 4 * TC; ++q) {
+            const int col0 = n0 + (q >> 2) * 32 + 8 * (q & 3) + 4 * kb;
+            bq[q] = *reinterpret_cast<const f32x4*>(p.bias + (col0 + 3 < p.cout_pad ? col0 : p.cout_pad - 4));  // always a valid address
+        }
+#pragma unroll
+        for (int q = 0; q < 4 * TC; ++q) {
+            const int col0 = n0 + (q >> 2) * 32 + 8 * (q & 3) + 4 * kb;
+            f32x4 x;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = am[q >> 2][4 * (q & 3) + e] + F16S_LO_UNSCALE * ax[q >> 2][4 * (q & 3) + e] + bq[q][e];
+                x[e] = v > 0.f ? v : (p.act == ACT_RELU ? 0.f : v * slope);
+            }
+            if (col0 + 3 < p.cout) {
+                *reinterpret_cast<f32x4*>(drow + col0) = x;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (col0 + e < p.cout)
+                        drow[col0 + e] = x[e];
+                    else if (col0 + e < p.dst_zero_to)
+                        drow[col0 + e] = 0.f;
+                }
+            }
+        }
+        return;
+    }
     if (KSP == 1) {
         ConvEpi<4 * TC> epi;
-        conv_epi_init_ragged(p, epi, [&](int q) { return n0 + (q >> 2) * 32 + 8 * (q & 3) + 4 * kb; });
-        conv_epi_row_ragged_ok(p, epi, (size_t)(vm ? m : 0), vm, [&](int q) {
+        conv_epi_init(p, epi, [&](int q) { return n0 + (q >> 2) * 32 + 8 * (q & 3) + 4 * kb; });
+        conv_epi_row(p, epi, (size_t)(vm ? m : 0), vm, [&](int q) {
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = am[q >> 2][4 * (q & 3) + e] + F16S_LO_UNSCALE * ax[q >> 2][4 * (q & 3) + e];
@@ -190,23 +223,6 @@ __global__ __launch_bounds__(64 * WP * KSP) void conv_gemm_f16s_kernel(const Con
         for (int e = 0; e < 16; ++e) mine[(i * 16 + e) * 64 + lane] = am[i][e] + F16S_LO_UNSCALE * ax[i][e];
     __syncthreads();
     const bool vec_ok = conv_vec_ok(p);
-    const unsigned tile = blockIdx.x;
-    bool finish = true;
-    if (nz > 1) {  // hand the workgroup's partial block over, then only the last workgroup of the tile goes on
-        float* const wsb = p.ws + ((size_t)(tile * nz + zb) * (WP * 4 * TC)) * 256;
-        for (int q = wk; q < 4 * TC; q += KSP) {
-            const int i = q >> 2, g = q & 3;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            for (int z = 0; z < KSP; ++z) {
-                const float* src = f16g_red + (size_t)((wp * KSP + z) * TC + i) * 16 * 64 + (4 * g) * 64 + lane;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = z == 0 ? src[e * 64] : v[e] + src[e * 64];
-            }
-            splitk_store(wsb + ((size_t)(wp * 4 * TC + q) * 64 + lane) * 4, v);
-        }
-        finish = splitk_last_arriver(p, tile);
-    }
-    if (!finish) return;
     for (int q = wk; q < 4 * TC; q += KSP) {
         const int i = q >> 2, g = q & 3;
         const int col0 = n0 + i * 32 + 8 * g + 4 * kb;
@@ -218,17 +234,10 @@ __global__ __launch_bounds__(64 * WP * KSP) void conv_gemm_f16s_kernel(const Con
             if (p.res && vm) r = *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.res_cs + p.res_co + col0);
         }
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (nz > 1) {
-            for (int z = 0; z < nz; ++z) {
-                const f32x4 x = splitk_load(p.ws + ((size_t)(tile * nz + z) * (WP * 4 * TC) + (wp * 4 * TC + q)) * 256 + lane * 4);
-                v = z == 0 ? x : v + x;
-            }
-        } else {
-            for (int z = 0; z < KSP; ++z) {
-                const float* src = f16g_red + (size_t)((wp * KSP + z) * TC + i) * 16 * 64 + (4 * g) * 64 + lane;
+        for (int z = 0; z < KSP; ++z) {
+            const float* src = f16g_red + (size_t)((wp * KSP + z) * TC + i) * 16 * 64 + (4 * g) * 64 + lane;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = z == 0 ? src[e * 64] : v[e] + src[e * 64];
-            }
+            for (int e = 0; e < 4; ++e) v[e] = z == 0 ? src[e * 64] : v[e] + src[e * 64];
         }
         if (!vm) continue;
         if (fastq) {
@@ -291,24 +300,18 @@ void conv_build_f16g_table(int c0, int c1, int kh, int kw, std::vector<uint32_t>
 }
 
 static bool conv_f16g_ok(const ConvParams& p) {
-    static const int mode = getenv("DFVO_F16G") ? atoi(getenv("DFVO_F16G")) : 1;
-    if (!mode || !p.wf16g || !p.f16g_tab) return false;
+    if (!p.wf16g || !p.f16g_tab) return false;
     if (p.kh > 31 || p.kw > 31) return false;
     return true;
 }
 
-template <int WP, int KSP, int TC, int PF = 3>
-static int launch_f16g_cfg(const ConvParams& p, hipStream_t stream, int cfg_id, int nz = 1) {
+template <int WP, int KSP, int TC, int PF = 3, bool RAG = false>
+static int launch_f16g_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) {
     const long long M = (long long)p.N * p.Ho * p.Wo;
     dim3 grid((unsigned)(((M + 32 * WP - 1) / (32 * WP)) * (p.wf16g_cout_pad / (32 * TC))), 1, 1);
-    // cross-workgroup K split (KSP > 1 shapes only): needs the split-K workspace and tickets of the net
-    if (KSP == 1 || !p.tile_flags || !p.ws || (long long)grid.x > p.tile_flags_n ||
-        (size_t)grid.x * nz * (WP * 4 * TC) * 256 > p.ws_floats)
-        nz = 1;
-    grid.z = (unsigned)nz;
     const size_t lds = KSP > 1 ? (size_t)WP * KSP * TC * 16 * 64 * sizeof(float) : 0;
     if (lds > 48 * 1024)
-        if (int rc_lds = ensure_dyn_lds((const void*)conv_gemm_f16s_kernel<WP, KSP, TC, PF>, lds)) return rc_lds;
+        if (int rc_lds = ensure_dyn_lds((const void*)conv_gemm_f16s_kernel<WP, KSP, TC, PF, RAG>, lds)) return rc_lds;
     ConvProfEntry pe;
     if (g_prof) {
         DFVO_HIP_CHECK(hipEventCreate(&pe.e0));
@@ -316,12 +319,12 @@ static int launch_f16g_cfg(const ConvParams& p, hipStream_t stream, int cfg_id, 
         pe.cfg = cfg_id;
         DFVO_HIP_CHECK(hipEventRecord(pe.e0, stream));
     }
-    hipLaunchKernelGGL((conv_gemm_f16s_kernel<WP, KSP, TC, PF>), grid, dim3(64 * WP * KSP), lds, stream, p);
+    hipLaunchKernelGGL((conv_gemm_f16s_kernel<WP, KSP, TC, PF, RAG>), grid, dim3(64 * WP * KSP), lds, stream, p);
     DFVO_HIP_CHECK(hipGetLastError());
     if (g_prof) {
         DFVO_HIP_CHECK(hipEventRecord(pe.e1, stream));
         pe.flops = p.useful_flops;
-        const int sh[12] = {p.N, p.H, p.W, p.Ho, p.Wo, (p.G0 + p.G1) * 4, p.cout, p.kh, p.stride, (int)grid.x, TC, KSP * 100 + nz};
+        const int sh[12] = {p.N, p.H, p.W, p.Ho, p.Wo, (p.G0 + p.G1) * 4, p.cout, p.kh, p.stride, (int)grid.x, TC, KSP * 100 + 1};
         for (int i = 0; i < 12; ++i) pe.shape[i] = sh[i];
         g_prof->push_back(pe);
     }
@@ -335,54 +338,39 @@ static int launch_f16g(const ConvParams& p, hipStream_t stream) {
     const long long M = (long long)p.N * p.Ho * p.Wo;
     const long long mblocks = (M + 31) / 32;
     const int nblk = p.wf16g_cout_pad / 32;
-    static const int force_ksp = getenv("DFVO_F16G_KSP") ? atoi(getenv("DFVO_F16G_KSP")) : 0;
-    static const long long target = getenv("DFVO_F16G_WAVES") ? atoll(getenv("DFVO_F16G_WAVES")) : 2048;
-    // DFVO_F16G_PF=8 (A/B): eight-stage ring + one cout block per wave + twice the waves on the K-sliced shapes, so that a
-    // wave's whole K slice is in flight at once.  Measured: WORSE (K-sliced layers 1.24 vs 1.10 ms per pair, 225 vs 230
-    // pairs/s) -- more waves contending, not fewer round trips, is what the small layers feel.  Default: three stages.
-    static const int deep = getenv("DFVO_F16G_PF") ? atoi(getenv("DFVO_F16G_PF")) : 3;
-    // DFVO_F16G_STREAM_TC1=1 (A/B): streaming shapes with one cout block per wave (120 registers, four waves per SIMD)
-    static const int stream_tc1 = getenv("DFVO_F16G_STREAM_TC1") ? atoi(getenv("DFVO_F16G_STREAM_TC1")) : 0;
+    const long long target = 2048;  // waves on the chip: ~2 per SIMD
     // two cout blocks per wave (a pixel fragment, whose split costs the VALU work, feeds both) only while that still leaves
     // enough (pixel block, cout pair) tiles to fill the chip with at most eight K slices; tiny maps with many couts (the
     // depth net's 6 x 20 / 12 x 40 layers: the launch is one pass over megabytes of weights) take one block per wave and up
     // to 16 slices -- more waves, more loads in flight
     bool tc2 = (nblk % 2) == 0;
     if (tc2 && mblocks * (nblk / 2) * 8 * 2 < target && p.f16g_steps >= 64) tc2 = false;
-    if (deep == 8) tc2 = false;
-    long long tiles = mblocks * (tc2 ? nblk / 2 : nblk);
-    const long long tgt = deep == 8 ? 2 * target : target;
+    const long long tiles = mblocks * (tc2 ? nblk / 2 : nblk);
     int ksp = 1;
     // (16 slices only with one cout block per wave: a 1024-thread workgroup leaves 128 registers per lane)
-    while (ksp < (tc2 ? 8 : 16) && tiles * ksp * 2 <= tgt && p.f16g_steps >= 4 * ksp * 2) ksp *= 2;
-    if (force_ksp == 1 || force_ksp == 2 || force_ksp == 4 || force_ksp == 8) ksp = force_ksp;
-    if (ksp == 1 && stream_tc1) tc2 = false;
-    // K divided over workgroups as well while the tiles alone leave compute units idle (the depth net's 6 x 20 / 12 x 40
-    // layers, pyramid levels 5 / 6: 64 .. 120 tiles on 256 CUs) and every wave keeps at least three steps.
-    // DFVO_F16G_NZ: 0 = off (DEFAULT), -1 = this rule, 2 / 4 = forced.  Measured (profiles/r3af_nz_ab.txt): the K-sliced
-    // launches get 7 % shorter one pass at a time (1.20 -> 1.12 ms per pair) and the pair rate DROPS 1.3 % (280.5 -> 276.8,
-    // three alternations): these launches are latency chains, not bandwidth per compute unit, and twice the workgroups
-    // take slots from the window kernels of the other streams.
-    static const int force_nz = getenv("DFVO_F16G_NZ") ? atoi(getenv("DFVO_F16G_NZ")) : 0;
-    int nz = 1;
-    if (ksp > 1)
-        while (nz < 4 && tiles * nz * 2 <= 320 && p.f16g_steps >= ksp * nz * 2 * 3) nz *= 2;
-    if (force_nz == 0) nz = 1;
-    if ((force_nz == 2 || force_nz == 4) && ksp > 1) nz = force_nz;
+    while (ksp < (tc2 ? 8 : 16) && tiles * ksp * 2 <= target && p.f16g_steps >= 4 * ksp * 2) ksp *= 2;
+    // Measured and dropped (records under profiles/): an eight-stage ring with twice the waves (r3: K-sliced layers 1.24 vs
+    // 1.10 ms per pair), K divided over workgroups as well (r3af_nz_ab.txt: launches 7 % shorter one at a time, pair rate
+    // -1.3 %), one cout block per wave on the streaming shapes (r3j_stream_tc1_ab.txt: no gain).
     const int cfg = ksp == 1 ? 20 : 21;  // profile rows: 20 streaming (KSP = 1), 21 K-sliced small maps
+    // ragged cout on a streaming shape: the store-only epilogue (profiles/r4j_rag_ab.txt: the 7 x 1 / 1 x 7 distance layers
+    // 80 -> 68 / 104 -> 98 us, +0.8 % pairs/s, bit-identical)
+    const bool rag = ksp == 1 && (p.cout % (tc2 ? 64 : 32)) != 0 && !p.res && ((p.dst_cs | p.dst_co) & 3) == 0 &&
+                     p.cout_pad >= 4 && (p.act == ACT_NONE || p.act == ACT_LEAKY || p.act == ACT_RELU);
+    if (rag) return tc2 ? launch_f16g_cfg<4, 1, 2, 3, true>(p, stream, cfg) : launch_f16g_cfg<4, 1, 1, 3, true>(p, stream, cfg);
     if (tc2) {
         switch (ksp) {
             case 1: return launch_f16g_cfg<4, 1, 2>(p, stream, cfg);
-            case 2: return launch_f16g_cfg<2, 2, 2>(p, stream, cfg, nz);
-            case 4: return launch_f16g_cfg<1, 4, 2>(p, stream, cfg, nz);
-            default: return launch_f16g_cfg<1, 8, 2>(p, stream, cfg, nz);
+            case 2: return launch_f16g_cfg<2, 2, 2>(p, stream, cfg);
+            case 4: return launch_f16g_cfg<1, 4, 2>(p, stream, cfg);
+            default: return launch_f16g_cfg<1, 8, 2>(p, stream, cfg);
         }
     }
     switch (ksp) {
         case 1: return launch_f16g_cfg<4, 1, 1>(p, stream, cfg);
-        case 2: return launch_f16g_cfg<2, 2, 1>(p, stream, cfg, nz);
-        case 4: return deep == 8 ? launch_f16g_cfg<1, 4, 1, 8>(p, stream, cfg, nz) : launch_f16g_cfg<1, 4, 1>(p, stream, cfg, nz);
-        case 8: return deep == 8 ? launch_f16g_cfg<1, 8, 1, 8>(p, stream, cfg, nz) : launch_f16g_cfg<1, 8, 1>(p, stream, cfg, nz);
-        default: return deep == 8 ? launch_f16g_cfg<1, 16, 1, 4>(p, stream, cfg, nz) : launch_f16g_cfg<1, 16, 1>(p, stream, cfg, nz);
+        case 2: return launch_f16g_cfg<2, 2, 1>(p, stream, cfg);
+        case 4: return launch_f16g_cfg<1, 4, 1>(p, stream, cfg);
+        case 8: return launch_f16g_cfg<1, 8, 1>(p, stream, cfg);
+        default: return launch_f16g_cfg<1, 16, 1>(p, stream, cfg);
     }
 }

@@ -16,7 +16,6 @@
 // depth/monodepth2/resnet_encoder.py:87-98, depth_decoder.py:50-65.
 #include "dfvo_common.h"
 
-#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -156,8 +155,8 @@ __global__ __launch_bounds__(64 * WP * KSP) void conv_gemm_f32g_kernel(const Con
 
     if (KSP == 1) {
         ConvEpi<4 * TC> epi;
-        conv_epi_init_ragged(p, epi, [&](int q) { return n0 + (q >> 2) * 32 + 8 * (q & 3) + 4 * kb; });
-        conv_epi_row_ragged_ok(p, epi, (size_t)(vm ? m : 0), vm, [&](int q) {
+        conv_epi_init(p, epi, [&](int q) { return n0 + (q >> 2) * 32 + 8 * (q & 3) + 4 * kb; });
+        conv_epi_row(p, epi, (size_t)(vm ? m : 0), vm, [&](int q) {
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = am[q >> 2][4 * (q & 3) + e];
@@ -236,8 +235,7 @@ size_t conv_pack_weights_f32g(const float* w, int cout, int c0, int c1, int kh, 
 }
 
 bool conv_f32g_ok(const ConvParams& p) {
-    static const int mode = getenv("DFVO_F32G") ? atoi(getenv("DFVO_F32G")) : 1;
-    return mode && p.wf32g && p.f16g_tab && p.kh <= 31 && p.kw <= 31;
+    return p.wf32g && p.f16g_tab && p.kh <= 31 && p.kw <= 31;
 }
 
 template <int WP, int KSP, int TC>

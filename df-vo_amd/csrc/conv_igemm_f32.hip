@@ -510,246 +510,6 @@ __global__ __launch_bounds__(256) void conv_win_f32_kernel(const ConvParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Split-precision variants of the window kernel (opt-in: DFVO_CONV_PRECISION=bf16x3 | bf16x6).  Every fp32 operand is
-// split into NPL bf16 planes, x = x0 + x1 (+ x2) with x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1): 16 or 24
-// mantissa bits.  The product keeps the terms down to 2^-8 (NPL = 2: x0w0 + x1w0 + x0w1, error ~2^-16 relative) or 2^-16
-// (NPL = 3: + x1w1 + x2w0 + x0w2, the dropped terms are ~2^-24 like an fp32 rounding) and accumulates in fp32, smallest
-// terms first.  One v_mfma_f32_16x16x16_bf16 contracts a whole 16-channel chunk, so a tap costs 3 / 6 MFMAs of 8 passes
-// instead of 4 of 32 per accumulator (5.3x / 2.7x less matrix-pipe time than the exact fp32 path).  The activations are
-// split once, when the window is written to LDS (plane-major inside a pixel, pixel stride NPL * 8 + 4 dwords =
-// conflict-free ds_read_b64); the weights are split when the layer is packed (conv_split_weights_bf16: plane-major in
-// memory, and plane / k-group-major in the LDS stage with a 32-dword skew between k-groups).
-// NOT the default: the nets' parity gate is the exact fp32 path.
-// ------------------------------------------------------------------------------------------------
-constexpr bool SPLIT_SETPRIO = false;  // raising the wave priority around the short bf16 MFMA bursts costs ~4 % here
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-template <int NPL>
-__device__ __forceinline__ void split_bf16_planes(f32x4 x, s16x4* pl) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        float r = x[e];
-#pragma unroll
-        for (int q = 0; q < NPL; ++q) {
-            const __bf16 h = (__bf16)r;
-            pl[q][e] = __builtin_bit_cast(short, h);
-            r -= (float)h;  // exact: h is r rounded to 8 bits
-        }
-    }
-}
-template <int WM, int WN, int TM, int TN, int KS, int NPL>
-__global__ __launch_bounds__(256) void conv_win_bf16s_kernel(const ConvParams p) {
-    constexpr int TH = WM * TM, TW = 16, WH = TH + KS - 1, WW = TW + KS - 1, PS = NPL * 8 + 4;
-    constexpr int BN = WN * TN * 16;
-    constexpr int WIN = WH * WW * PS;          // dwords per window buffer
-    constexpr int BKQ = BN * 2 + 32;           // dwords per (plane, k-group) row of the weight stage (skewed)
-    constexpr int BT = NPL * 4 * BKQ;          // dwords per weight stage
-    constexpr int W_ITEMS = WH * WW * 4;
-    constexpr int W_CNT = (W_ITEMS + 255) / 256;
-    constexpr int B_CNT = (BN * 4 + 255) / 256;
-    static_assert(WM * WN == 4, "4 waves per block");
-    __shared__ __attribute__((aligned(16))) float lds[2 * WIN + 2 * BT];
-    float* const win = lds;
-    float* const bst = lds + 2 * WIN;
-
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int li = lane & 15, kq = lane >> 4;
-    const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
-    const int nb = gridDim.x;
-    int bid = blockIdx.x;
-    {  // XCD-aware order: each XCD walks a contiguous run of tiles (neighbours share halo rows in its L2)
-        const int q = nb >> 3, r = nb & 7, xcd = bid & 7, k = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-    }
-    const int n = bid / (tiles_y * tiles_x);
-    const int trem = bid - n * (tiles_y * tiles_x);
-    const int ty0 = (trem / tiles_x) * TH, tx0 = (trem % tiles_x) * TW;
-    const int n0 = blockIdx.y * BN;
-    const int G = p.G0 + p.G1;
-    const int nchunk0 = (p.G0 + 3) >> 2, nchunk1 = (p.G1 + 3) >> 2, nchunks = nchunk0 + nchunk1;
-    // split-K over the channel chunks: this workgroup contracts chunks [c_begin, c_end)
-    const int cper = (nchunks + (int)gridDim.z - 1) / (int)gridDim.z;
-    const int c_begin = (int)blockIdx.z * cper;
-    const int c_end = c_begin + cper < nchunks ? c_begin + cper : nchunks;
-
-    // window items of this thread: (pixel, channel group within the chunk)
-    int w_off0[W_CNT], w_off1[W_CNT], w_lds[W_CNT];
-    bool w_ok[W_CNT];
-#pragma unroll
-    for (int r = 0; r < W_CNT; ++r) {
-        const int id = t + 256 * r;
-        const int px = id >> 2, q = id & 3;
-        const int wy = px / WW, wx = px - wy * WW;
-        int iy = ty0 - p.pad_h + wy, ix = tx0 - p.pad_w + wx;
-        bool v = id < W_ITEMS;
-        if (p.pad_mode == PAD_REFLECT) {
-            iy = reflect_idx(iy, p.H);
-            ix = reflect_idx(ix, p.W);
-        }
-        v = v && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-        iy = iy < 0 ? 0 : (iy >= p.H ? p.H - 1 : iy);
-        ix = ix < 0 ? 0 : (ix >= p.W ? p.W - 1 : ix);
-        const int sh = p.up0;
-        w_off0[r] = (((n * (p.H >> sh) + (iy >> sh)) * (p.W >> sh) + (ix >> sh)) * p.cs0) + p.co0 + q * 4;
-        w_off1[r] = (((n * p.H + iy) * p.W + ix) * p.cs1) + p.co1 + q * 4;
-        w_ok[r] = v;
-        w_lds[r] = (px < WH * WW ? px : 0) * PS + q * 2;
-    }
-    f32x4 rw[W_CNT];
-    s16x4 rb[B_CNT][NPL];
-    bool rwv[W_CNT];
-    auto load_window = [&](int c) {
-        const bool s1 = c >= nchunk0;
-        const int cg0 = s1 ? (c - nchunk0) * 4 : c * 4;
-        const int Gs = s1 ? p.G1 : p.G0;
-        const float* base = s1 ? p.src1 : p.src0;
-#pragma unroll
-        for (int r = 0; r < W_CNT; ++r) {
-            const int q = (t + 256 * r) & 3;
-            const bool v = w_ok[r] && (cg0 + q) < Gs;
-            const int off = (s1 ? w_off1[r] : w_off0[r]) + (v ? cg0 * 4 : -(q * 4));  // masked lanes re-read channel 0
-            rw[r] = *reinterpret_cast<const f32x4*>(base + off);
-            rwv[r] = v;
-        }
-    };
-    auto store_window = [&](float* W) {  // per pixel: plane q of the 16 channels in dwords [8 q, 8 q + 8)
-#pragma unroll
-        for (int r = 0; r < W_CNT; ++r)
-            if (t + 256 * r < W_ITEMS) {
-                s16x4 pl[NPL];
-                split_bf16_planes<NPL>(rwv[r] ? rw[r] : f32x4{0.f, 0.f, 0.f, 0.f}, pl);
-#pragma unroll
-                for (int q = 0; q < NPL; ++q) *reinterpret_cast<s16x4*>(W + w_lds[r] + 8 * q) = pl[q];
-            }
-    };
-    auto wrow_of = [&](int c) { return c >= nchunk0 ? p.G0 + (c - nchunk0) * 4 : c * 4; };
-    auto load_b = [&](int c, int tap) {
-        const int g0 = tap * G + wrow_of(c);
-#pragma unroll
-        for (int r = 0; r < B_CNT; ++r) {
-            const int id = t + 256 * r;
-            if (id < BN * 4) {
-                const int gi = id / BN, j = id - gi * BN;
-#pragma unroll
-                for (int q = 0; q < NPL; ++q)
-                    rb[r][q] = *reinterpret_cast<const s16x4*>(p.wsp + (size_t)q * p.wsp_plane +
-                                                              ((size_t)(g0 + gi) * p.cout_pad + n0 + j) * 2);
-            }
-        }
-    };
-    auto store_b = [&](float* Bs) {
-#pragma unroll
-        for (int r = 0; r < B_CNT; ++r) {
-            const int id = t + 256 * r;
-            if (id < BN * 4) {
-                const int gi = id / BN, j = id - gi * BN;
-#pragma unroll
-                for (int q = 0; q < NPL; ++q) *reinterpret_cast<s16x4*>(Bs + (q * 4 + gi) * BKQ + j * 2) = rb[r][q];
-            }
-        }
-    };
-
-    f32x4 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    constexpr int TAPS = KS * KS;
-    if (c_begin < c_end) {
-        load_window(c_begin);
-        load_b(c_begin, 0);
-        store_window(win + (c_begin & 1) * WIN);
-        store_b(bst);
-    }
-    __syncthreads();
-    int stage = 0;
-    for (int c = c_begin; c < c_end; ++c) {
-        const float* Wc = win + (c & 1) * WIN;
-        float* Wn = win + ((c + 1) & 1) * WIN;
-        const bool next_chunk = c + 1 < c_end;
-        if (next_chunk) load_window(c + 1);
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int ky = tap / KS, kx = tap - ky * KS;
-            const float* Bs = bst + stage * BT;
-            const bool more = tap < TAPS - 1 || next_chunk;
-            if (more) load_b(tap < TAPS - 1 ? c : c + 1, tap < TAPS - 1 ? tap + 1 : 0);
-            s16x4 fa[TM][NPL], fb[TN][NPL];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = wm * TM + i;
-                const float* px = Wc + ((row + ky) * WW + (li + kx)) * PS + kq * 2;
-#pragma unroll
-                for (int q = 0; q < NPL; ++q) fa[i][q] = *reinterpret_cast<const s16x4*>(px + 8 * q);
-            }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = wn * TN * 16 + j * 16 + li;
-#pragma unroll
-                for (int q = 0; q < NPL; ++q) fb[j][q] = *reinterpret_cast<const s16x4*>(Bs + (q * 4 + kq) * BKQ + col * 2);
-            }
-            if (SPLIT_SETPRIO) __builtin_amdgcn_s_setprio(1);
-            // gfx950's double-rate v_mfma_f32_16x16x32_bf16 takes 8 bf16 per lane: two planes side by side contract two
-            // product terms per instruction.  NPL = 2: [w0|w1].[x1|x1] + [w0|w1].[x0|x0] (all four terms);
-            // NPL = 3: [w0|w2].[x2|x0] + [w0|w1].[x1|x1] + [w0|w1].[x0|x0] (the six terms down to 2^-16), small first.
-            s16x8 w01[TN], w02[TN], x00[TM], x11[TM], x20[TM];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                w01[j] = __builtin_shufflevector(fb[j][0], fb[j][1], 0, 1, 2, 3, 4, 5, 6, 7);
-                if (NPL == 3) w02[j] = __builtin_shufflevector(fb[j][0], fb[j][NPL - 1], 0, 1, 2, 3, 4, 5, 6, 7);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                x00[i] = __builtin_shufflevector(fa[i][0], fa[i][0], 0, 1, 2, 3, 4, 5, 6, 7);
-                x11[i] = __builtin_shufflevector(fa[i][1], fa[i][1], 0, 1, 2, 3, 4, 5, 6, 7);
-                if (NPL == 3) x20[i] = __builtin_shufflevector(fa[i][NPL - 1], fa[i][0], 0, 1, 2, 3, 4, 5, 6, 7);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if (NPL == 3)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w02[j]), __builtin_bit_cast(bf16x8, x20[i]), acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w01[j]), __builtin_bit_cast(bf16x8, x11[i]), acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w01[j]), __builtin_bit_cast(bf16x8, x00[i]), acc[i][j], 0, 0, 0);
-                }
-            if (SPLIT_SETPRIO) __builtin_amdgcn_s_setprio(0);
-            if (more) store_b(bst + (stage ^ 1) * BT);
-            if (tap == TAPS / 2 && next_chunk) store_window(Wn);
-            __syncthreads();
-            stage ^= 1;
-        }
-    }
-
-    // epilogue: lane (li, kq) holds couts kq*4 .. kq*4+3 of the pixel at x = tx0 + li of its tile rows
-    const int ox = tx0 + li;
-    if (gridDim.z > 1) {  // split-K partial: raw accumulators to the workspace [z][M][cout_pad]
-        const size_t Mtot = (size_t)p.N * p.Ho * p.Wo;
-        float* wsz = p.ws + (size_t)blockIdx.z * Mtot * p.cout_pad;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col0 = n0 + wn * TN * 16 + j * 16 + kq * 4;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int oy = ty0 + wm * TM + i;
-                if (oy < p.Ho && ox < p.Wo)
-                    *reinterpret_cast<f32x4*>(wsz + (((size_t)n * p.Ho + oy) * p.Wo + ox) * p.cout_pad + col0) = acc[i][j];
-            }
-        }
-        return;
-    }
-    ConvEpi<TN> epi;  // bias of the wave's couts loaded once, a pixel's stores back to back (see conv_epi_row)
-    conv_epi_init(p, epi, [&](int j) { return n0 + wn * TN * 16 + j * 16 + kq * 4; });
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int oy = ty0 + wm * TM + i;
-        const bool valid = oy < p.Ho && ox < p.Wo;
-        conv_epi_row(p, epi, valid ? ((size_t)n * p.Ho + oy) * p.Wo + ox : 0, valid, [&](int j) { return acc[i][j]; });
-    }
-}
 
 // split-K second pass: ordered sum of the partials + bias + residual + activation
 __global__ void conv_splitk_epilogue(const ConvParams p, int splits) {
@@ -821,29 +581,6 @@ void conv_pack_weights(const float* w, const float* bias, int cout, int c0, int 
     }
 }
 
-// packed weights [g][cout_pad][4] -> the same shape with every 4-float group replaced by 4 bf16 "hi" + 4 bf16 "lo"
-// (conv_win_bf16x3_kernel); round-to-nearest-even like v_cvt_pk_bf16_f32
-static inline unsigned short f32_to_bf16_rne(float f) {
-    unsigned u;
-    memcpy(&u, &f, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);  // NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
-void conv_split_weights_bf16(const float* packed, size_t n_floats, int planes, unsigned short* out) {
-    // out[q][i] = plane q of packed[i]; a plane is n_floats bf16 (= n_floats / 2 dwords)
-    for (size_t i = 0; i < n_floats; ++i) {
-        float r = packed[i];
-        for (int q = 0; q < planes; ++q) {
-            const unsigned short h = f32_to_bf16_rne(r);
-            out[(size_t)q * n_floats + i] = h;
-            const unsigned hu = (unsigned)h << 16;
-            float hf;
-            memcpy(&hf, &hu, 4);
-            r -= hf;
-        }
-    }
-}
 
 size_t conv_head_weight_floats(int cout, int c0, int c1, int k) {
     return (size_t)(cdiv(c0, 8) + cdiv(c1, 8)) * k * 2 * k * cout * 4;
@@ -1145,7 +882,7 @@ static int launch_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) {
 // workgroups (more resident workgroups hide the global -> LDS staging latency; the per-tap gather is served by
 // L2 either way); 128 x 128 keeps the largest maps.  Small grids additionally split K inside launch_cfg.
 // DFVO_CONV_FORCE_BM=<rows> overrides the M tile (tuning aid).
-template <int WM, int WN, int TM, int TN, int KS = 3, int NPL = 0>  // NPL: 0 exact fp32, 2 / 3 bf16 planes
+template <int WM, int WN, int TM, int TN, int KS = 3>
 static int launch_win3(const ConvParams& p, hipStream_t stream, int cfg_id) {
     constexpr int TH = WM * TM, BN = WN * TN * 16;
     const int tiles = p.N * ((p.Ho + TH - 1) / TH) * ((p.Wo + 15) / 16);
@@ -1172,12 +909,9 @@ static int launch_win3(const ConvParams& p, hipStream_t stream, int cfg_id) {
         DFVO_HIP_CHECK(hipEventRecord(pe.e0, stream));
     }
     ConvParams pk = p;  // in-kernel split-K finish (exact fp32 kernel) when the tiles have tickets
-    const bool fused = NPL == 0 && splits > 1 && pk.tile_flags && blocks <= pk.tile_flags_n;
+    const bool fused = splits > 1 && pk.tile_flags && blocks <= pk.tile_flags_n;
     if (!fused) pk.tile_flags = nullptr;
-    if constexpr (NPL == 0)
-        hipLaunchKernelGGL((conv_win_f32_kernel<WM, WN, TM, TN, KS>), grid, dim3(256), 0, stream, pk);
-    else
-        hipLaunchKernelGGL((conv_win_bf16s_kernel<WM, WN, TM, TN, KS, NPL>), grid, dim3(256), 0, stream, pk);
+    hipLaunchKernelGGL((conv_win_f32_kernel<WM, WN, TM, TN, KS>), grid, dim3(256), 0, stream, pk);
     DFVO_HIP_CHECK(hipGetLastError());
     if (splits > 1 && !fused) {
         const int cols = p.dst_zero_to > p.cout ? p.dst_zero_to : p.cout;
@@ -1220,8 +954,7 @@ static int launch_head(const ConvParams& p, hipStream_t stream, int cfg_id) {
 
 // the direct kernel serves the square, stride-1, "same"-padded heads with one or two output channels
 static bool conv_use_head(const ConvParams& p) {
-    static const int mode = getenv("DFVO_CONV_HEAD") ? atoi(getenv("DFVO_CONV_HEAD")) : 1;
-    if (!mode || p.cout > 2 || !p.wh) return false;
+    if (p.cout > 2 || !p.wh) return false;
     if (p.kh != p.kw || p.stride != 1 || p.pad_h != p.kh / 2 || p.pad_w != p.kw / 2) return false;
     if (p.kh != 3 && p.kh != 5 && p.kh != 7) return false;
     return (long long)p.N * p.Ho * p.Wo >= 1024;
@@ -1229,20 +962,16 @@ static bool conv_use_head(const ConvParams& p) {
 
 // the LDS-window kernel serves 3x3 / stride-1 layers on maps large enough to fill the chip with TH x 16 tiles
 static bool conv_use_window(const ConvParams& p, int bn) {
-    static const int mode = getenv("DFVO_CONV_WINDOW") ? atoi(getenv("DFVO_CONV_WINDOW")) : 1;
-    if (!mode) return false;
     if (p.kh != p.kw || p.stride != 1 || p.pad_h != p.kh / 2 || p.pad_w != p.kw / 2) return false;
     const long long M = (long long)p.N * p.Ho * p.Wo;
-    static const long long min_m = getenv("DFVO_CONV_WINDOW_MIN_M") ? atoll(getenv("DFVO_CONV_WINDOW_MIN_M")) : 30000;
-    if (p.kh == 3) return bn >= 32 && M >= min_m;
+    if (p.kh == 3) return bn >= 32 && M >= 30000;
     // 5x5 / 7x7 flow heads (32 -> 2 channels): the whole tap loop runs out of one window
     return (p.kh == 5 || p.kh == 7) && bn == 16 && (p.G0 + p.G1) >= 4 && M >= 8000;
 }
 
 static int conv_pick_bm(const ConvParams& p, int bn) {
     const long long M = (long long)p.N * p.Ho * p.Wo;
-    static const int env_bm = getenv("DFVO_CONV_FORCE_BM") ? atoi(getenv("DFVO_CONV_FORCE_BM")) : 0;
-    const int force_bm = p.force_bm ? p.force_bm : env_bm;
+    const int force_bm = p.force_bm;  // (0: the rule below)
     const long long ntiles_n = p.cout_pad / bn;
     auto blocks = [&](int bm) { return ((M + bm - 1) / bm) * ntiles_n; };
     if (bn == 128) {
@@ -1256,23 +985,13 @@ static int conv_pick_bm(const ConvParams& p, int bn) {
     return bm;
 }
 
-void conv_effective_config(const ConvParams& p, int* bm_out, int* splits_out) {
-    const long long M = (long long)p.N * p.Ho * p.Wo;
-    const int bn = conv_pick_bn(p.cout, M);
-    const int bm = conv_pick_bm(p, bn);
-    *bm_out = bm;
-    *splits_out = conv_pick_splits(p, ((M + bm - 1) / bm) * (p.cout_pad / bn));
-}
-
 // exact-fp32 mode: which layers leave conv_igemm_f32_kernel for the register-ring kernel (conv_gemm_f32g.hip).  Not the
 // 3x3 / stride-1 layers the LDS-window kernel takes, not the one- / two-channel heads.
-// DFVO_F32G: 0 off, 1 (default) the small maps whose igemm launch would split K across workgroups or leave the chip idle,
-// 2 every non-window layer
+// Measured (profiles/r4e_fp32_f32g_ab.txt): the small maps only 156.5 -> 160 pairs/s; every non-window layer 158 (the
+// streaming layers are no faster than on conv_igemm_f32_kernel).
 static bool conv_f32g_takes(const ConvParams& p, int bn) {
-    static const int mode = getenv("DFVO_F32G") ? atoi(getenv("DFVO_F32G")) : 1;
     if (conv_use_head(p)) return false;
     if (conv_use_window(p, bn)) return false;
-    if (mode >= 2) return true;
     const long long M = (long long)p.N * p.Ho * p.Wo;
     return M <= 8192;  // pyramid levels 5 / 6 (2 x 11 x 38 .. 2 x 44 x 152) and the depth net's 6 x 20 .. 48 x 160 maps
 }
@@ -1317,21 +1036,7 @@ int launch_conv(const ConvParams& p, hipStream_t stream) {
     if (conv_use_window(p, bn) && p.kh == 7) return launch_win3<4, 1, 2, 1, 7>(p, stream, 16);
     if (conv_use_window(p, bn) && p.kh == 5) return launch_win3<4, 1, 2, 1, 5>(p, stream, 17);
     if (conv_use_window(p, bn)) {
-        static const int force_cfg = getenv("DFVO_CONV_WIN_CFG") ? atoi(getenv("DFVO_CONV_WIN_CFG")) : 0;  // tuning aid
-        if (force_cfg == 13 && p.cout_pad % 64 == 0) return launch_win3<2, 2, 4, 2>(p, stream, 13);
-        if (force_cfg == 15 && bn == 128) return launch_win3<1, 4, 4, 2>(p, stream, 15);
-        if (force_cfg == 14 && p.cout_pad % 32 == 0) return launch_win3<4, 1, 2, 2>(p, stream, 14);
         const long long tiles8 = (long long)p.N * ((p.Ho + 7) / 8) * ((p.Wo + 15) / 16) * (p.cout_pad / bn);
-        if (p.wsp && p.wsp_planes == 2) {  // opt-in split-precision modes: same tiles, bf16 MFMAs
-            if (bn == 128) return launch_win3<2, 2, 4, 2, 3, 2>(p, stream, 13);
-            if (bn == 64) return launch_win3<2, 2, 4, 2, 3, 2>(p, stream, 13);
-            return launch_win3<4, 1, 2, 2, 3, 2>(p, stream, 14);
-        }
-        if (p.wsp && p.wsp_planes == 3) {
-            if (bn == 128) return launch_win3<2, 2, 4, 2, 3, 3>(p, stream, 13);
-            if (bn == 64) return launch_win3<2, 2, 4, 2, 3, 3>(p, stream, 13);
-            return launch_win3<4, 1, 2, 2, 3, 3>(p, stream, 14);
-        }
         if (bn == 128) {
             // 128-wide layers on the largest maps run as two 64-wide column blocks: 2x the workgroups at 4 (instead
             // of 3) per CU shortens the under-filled last round of the grid (+5 % measured at 2 x 192 x 624)

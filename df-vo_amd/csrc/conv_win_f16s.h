@@ -33,6 +33,12 @@ __device__ unsigned int g_f16s_clamped = 0;
 __device__ __forceinline__ void f16s_report_clamp(float amax) {
     if (amax > F16S_MAX) atomicAdd(&g_f16s_clamped, 1u);
 }
+// the counter's device address, for the f16x3 kernels that live in other translation units (device symbols do not cross TUs)
+static unsigned* f16s_clamp_counter() {
+    static unsigned* ptr = nullptr;
+    if (!ptr && hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(g_f16s_clamped)) != hipSuccess) ptr = nullptr;
+    return ptr;
+}
 template <int WC, int WR, int TC, int TR>
 __global__ __launch_bounds__(64 * WC * WR, 2) void conv_win_f16s_kernel(const ConvParams p) {
     constexpr int NT = 64 * WC * WR;  // 4 or 8 waves per workgroup
@@ -59,7 +65,6 @@ __global__ __launch_bounds__(64 * WC * WR, 2) void conv_win_f16s_kernel(const Co
     const int ty0 = (trem / tiles_x) * TH, tx0 = (trem % tiles_x) * TW;
     const int n0 = blockIdx.y * BN;
     const int nchunk0 = (p.G0 + 3) >> 2, nchunk1 = (p.G1 + 3) >> 2, nchunks = nchunk0 + nchunk1;
-    const bool nt = (p.force_splits & 1) != 0;  // (experiment switch, see launch_f16s)
 
     // window items of this thread: (pixel, 4-channel group within the chunk).  Their addresses are recomputed at every chunk
     // (a few dozen integer operations against 27 TC TR MFMAs) instead of living in 4 W_CNT registers for the whole kernel:
@@ -90,10 +95,8 @@ __global__ __launch_bounds__(64 * WC * WR, 2) void conv_win_f16s_kernel(const Co
         iy = iy < 0 ? 0 : (iy >= p.H ? p.H - 1 : iy);
         ix = ix < 0 ? 0 : (ix >= p.W ? p.W - 1 : ix);
         const int off = (((n * (p.H >> sh) + (iy >> sh)) * (p.W >> sh) + (ix >> sh)) * cs) + co + (v ? (cg0 + q) * 4 : 0);
-        // masked lanes re-read channel group 0 of a valid pixel.  Streaming (non-temporal) policy: the activations pass
-        // through once, the layer's weights are re-read by every workgroup and should keep the L2
-        rw[r] = nt ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(base + off))
-                   : *reinterpret_cast<const f32x4*>(base + off);
+        // masked lanes re-read channel group 0 of a valid pixel
+        rw[r] = *reinterpret_cast<const f32x4*>(base + off);
         rwv = (rwv & ~(1u << r)) | ((v ? 1u : 0u) << r);
     };
     auto store_window_item = [&](float* W, int r) {
@@ -237,9 +240,8 @@ static bool conv_f16s_ok(const ConvParams& p) {
     // small maps stay on the fp32 split-K kernels: with fewer than ~200 of the smallest (32 couts x 4 x 32 px) tiles the
     // grid cannot fill the chip and the un-split K loop makes the launch longer than the fp32 one (measured: pyramid
     // levels 5 / 6 and the depth net's inner layers 2-4x slower, level 4 1.5-2x faster)
-    static const long long min_blocks = getenv("DFVO_F16S_MIN_BLOCKS") ? atoll(getenv("DFVO_F16S_MIN_BLOCKS")) : 200;
     const long long e = (long long)p.N * ((p.Ho + 3) / 4) * ((p.Wo + 31) / 32) * (p.wf16_cout_pad / 32);
-    return e >= min_blocks;
+    return e >= 200;
 }
 
 template <int WC, int WR, int TC, int TR>
@@ -273,31 +275,11 @@ static int launch_f16s_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) 
     return DFVO_OK;
 }
 
-// Tile choice: the largest tile whose grid still fills the chip; small maps (pyramid level 4, the depth net's outer layers)
-// fall back to narrower cout blocks / fewer rows so that more CUs get work:
-//   A' 128 couts x (4 x 32) px, waves 4 x 1   A 128 x (4 x 32), waves 2 x 2   B 64 x (8 x 32)   C 64 x (4 x 32)
-//   D 32 x (8 x 32)   E 32 x (4 x 32)   (F / G: 8-wave tiles with twice the rows, opt-in)
-static int launch_f16s(const ConvParams& p_in, hipStream_t stream, int cfg_id) {
-    ConvParams p = p_in;
-    static const int nt_mode = getenv("DFVO_F16S_NT") ? atoi(getenv("DFVO_F16S_NT")) : 0;
-    p.force_splits = nt_mode ? 1 : 0;  // force_splits is unused by this kernel: carries the streaming-load experiment switch
-    static const long long fill = getenv("DFVO_F16S_FILL") ? atoll(getenv("DFVO_F16S_FILL")) : 400;
-    // 8-wave tiles (twice the pixels per workgroup = half the weight re-reads from L2): measured neutral, off by default
-    static const long long fill8 = getenv("DFVO_F16S_FILL8") ? atoll(getenv("DFVO_F16S_FILL8")) : (1LL << 40);
-    const long long f = f16s_blocks<2, 4, 2, 2>(p), g = f16s_blocks<1, 8, 2, 2>(p);
-    const long long a = f16s_blocks<2, 2, 2, 2>(p), b = f16s_blocks<1, 4, 2, 2>(p), c = f16s_blocks<2, 2, 1, 2>(p),
-                    d = f16s_blocks<1, 4, 1, 2>(p);
-    // 128-cout layers: one 32-cout block per wave x four rows (A').  Every weight fragment is then fetched by exactly one wave
-    // (the 2 x 2 arrangement loads each fragment twice); the pixel fragments, read from LDS, are the shared operand: +6 %.
-    // (DFVO_F16S_VARIANT=0 restores the 2 x 2 arrangement.)
-    static const int variant = getenv("DFVO_F16S_VARIANT") ? atoi(getenv("DFVO_F16S_VARIANT")) : 1;
-    if (variant == 1 && f16s_blocks<4, 1, 1, 4>(p) >= fill) return launch_f16s_cfg<4, 1, 1, 4>(p, stream, cfg_id);
-    if (f >= fill8) return launch_f16s_cfg<2, 4, 2, 2>(p, stream, cfg_id);
-    if (a >= fill) return launch_f16s_cfg<2, 2, 2, 2>(p, stream, cfg_id);
-    if (g >= fill8) return launch_f16s_cfg<1, 8, 2, 2>(p, stream, cfg_id);
-    if (b >= fill) return launch_f16s_cfg<1, 4, 2, 2>(p, stream, cfg_id);
-    if (c >= fill) return launch_f16s_cfg<2, 2, 1, 2>(p, stream, cfg_id);
-    if (d >= fill) return launch_f16s_cfg<1, 4, 1, 2>(p, stream, cfg_id);
+// The first skeleton (two waves per SIMD) takes what the one-wave-per-SIMD skeleton of conv_win_f16s2.h leaves: layers with
+// fewer than ~200 of its tiles (pyramid level 4, the depth net's outer layers), where one workgroup per CU cannot fill the
+// chip.  One shape: 32 couts x (4 x 32) pixels, four waves.  (Rounds 2-3 also instantiated 128- / 64-cout and 8-wave
+// tiles of this skeleton; since the second skeleton became the default none of them was reachable.)
+static int launch_f16s(const ConvParams& p, hipStream_t stream, int cfg_id) {
     return launch_f16s_cfg<1, 4, 1, 1>(p, stream, cfg_id);
 }
 

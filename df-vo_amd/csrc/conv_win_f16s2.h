@@ -15,10 +15,6 @@
 #pragma once
 // (included inside namespace dfvo, after conv_win_f16s.h)
 
-#ifndef F16S2_LATE
-#define F16S2_LATE 1
-#endif
-
 template <class F, int... T>
 __device__ __forceinline__ void f16s2_static_for_impl(F&& f, std::integer_sequence<int, T...>) {
     (f(std::integral_constant<int, T>{}), ...);
@@ -28,9 +24,7 @@ __device__ __forceinline__ void f16s2_static_for(F&& f) {  // f(integral_constan
     f16s2_static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-// SKIP: timing-only ablation (wrong results), compile-time so that the instructions really disappear: bit 0 no weight loads
-// inside the loop, bit 1 no pixel-fragment reads inside the loop, bit 2 no window loads / splits / stores inside the loop
-template <int WC, int WR, int TC, int TR, int SKIP = 0>
+template <int WC, int WR, int TC, int TR>
 __global__ __launch_bounds__(64 * WC * WR, 1) void conv_win_f16s2_kernel(const ConvParams p) {
     constexpr int NT = 64 * WC * WR;
     constexpr int TH = WR * TR, TW = 32, WH = TH + 2, WW = TW + 2, PS = 20;  // pixel stride in dwords (80 bytes)
@@ -168,14 +162,12 @@ __global__ __launch_bounds__(64 * WC * WR, 1) void conv_win_f16s2_kernel(const C
     // the hardware sees.  The last chunk prefetches itself again (window into the idle buffer, first two weight
     // fragments) instead of running a second, prefetch-free copy of the loop body: a second instantiation gets its own
     // register assignment and pays ~280 v_accvgpr moves to get there.
-    constexpr bool next_chunk = true;
     for (int c = 0; c < nchunks; ++c) {
         const float* Wc = lds + (c & 1) * WIN;
         float* Wn = lds + ((c + 1) & 1) * WIN;
         const int c_next = c + 1 < nchunks ? c + 1 : c;
         set_chunk(c_next);
-        if (!(SKIP & 2) || c == 0) read_x(Wc, 0, 0);
-        if ((SKIP & 2) && c == 0) read_x(Wc, 1, 1);
+        read_x(Wc, 0, 0);
         f16s2_static_for<9>([&](auto tap_c) {
             constexpr int tap = decltype(tap_c)::value;
             constexpr int cur = tap % 3, xs = tap & 1;
@@ -191,71 +183,45 @@ __global__ __launch_bounds__(64 * WC * WR, 1) void conv_win_f16s2_kernel(const C
                 else
                     am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][i][0], xb[xs][j][0], am[i][j], 0, 0, 0);
             };
-            if (F16S2_LATE) {
-                // One request per MFMA, each fenced into that MFMA's shadow (the compiler hoists free-standing loads to the
-                // top of the region whatever the group hints say): first the next tap's pixel fragments from LDS, then the
-                // weight fragments of tap + 2 and one window item of the next chunk from global memory -- they are
-                // consumed two taps / one chunk later -- so that nothing but the split of the window item is left between
-                // the taps' MFMA groups.
-                constexpr int NV = ((SKIP & 1) ? 0 : 2 * TC) + ((!(SKIP & 4) && tap < W_CNT) ? 1 : 0);
-                constexpr int NF = NR + NV < NM ? NR + NV : NM;  // fenced slots
-                f16s2_static_for<NF>([&](auto k_c) {
-                    constexpr int k = decltype(k_c)::value;
-                    mfma(k);
-                    constexpr int per = NF > 0 ? (NR + NV + NF - 1) / NF : 1;  // requests per slot (1 unless the tile has few MFMAs)
+            // One request per MFMA, each fenced into that MFMA's shadow (the compiler hoists free-standing loads to the
+            // top of the region whatever the group hints say): first the next tap's pixel fragments from LDS, then the
+            // weight fragments of tap + 2 and one window item of the next chunk from global memory -- they are
+            // consumed two taps / one chunk later -- so that nothing but the split of the window item is left between
+            // the taps' MFMA groups.
+            constexpr int NV = 2 * TC + (tap < W_CNT ? 1 : 0);
+            constexpr int NF = NR + NV < NM ? NR + NV : NM;  // fenced slots
+            f16s2_static_for<NF>([&](auto k_c) {
+                constexpr int k = decltype(k_c)::value;
+                mfma(k);
+                constexpr int per = NF > 0 ? (NR + NV + NF - 1) / NF : 1;  // requests per slot (1 unless the tile has few MFMAs)
 #pragma unroll
-                    for (int u = 0; u < per; ++u) {
-                        const int q = k * per + u;
-                        if (q < NR) {
-                            if (!(SKIP & 2)) read_x_piece(Wc, xs ^ 1, tap + 1, q);
-                        } else if (q < NR + NV) {
-                            const int v = q - NR;
-                            if (!(SKIP & 1) && v < 2 * TC) {
-                                if (tap < 7)
-                                    load_w_piece((tap + 2) % 3, tap + 2, c, v);
-                                else
-                                    load_w_piece((tap + 2) % 3, tap - 7, c_next, v);
-                            } else if (!(SKIP & 4) && tap < W_CNT) {
-                                load_window_item(tap);
-                            }
+                for (int u = 0; u < per; ++u) {
+                    const int q = k * per + u;
+                    if (q < NR) {
+                        read_x_piece(Wc, xs ^ 1, tap + 1, q);
+                    } else if (q < NR + NV) {
+                        const int v = q - NR;
+                        if (v < 2 * TC) {
+                            if (tap < 7)
+                                load_w_piece((tap + 2) % 3, tap + 2, c, v);
+                            else
+                                load_w_piece((tap + 2) % 3, tap - 7, c_next, v);
+                        } else if (tap < W_CNT) {
+                            load_window_item(tap);
                         }
                     }
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-                if (!(SKIP & 4) && tap >= ST0) store_window_item(Wn, tap - ST0);
-#pragma unroll
-                for (int k = NF; k < NM; ++k) mfma(k);
-#pragma unroll
-                for (int k = NF; k < NM; ++k) {  // the window item's split (about 30 VALU instructions), its two LDS writes last
-                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                    if (tap >= ST0) __builtin_amdgcn_sched_group_barrier(0x2, NM - NF >= 16 ? 2 : 4, 0);
                 }
-                if (tap >= ST0) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
-            } else {
-                if (!(SKIP & 1)) {
-                    if (tap < 7)
-                        load_w((tap + 2) % 3, tap + 2, c);
-                    else if (next_chunk)
-                        load_w((tap + 2) % 3, tap - 7, c_next);
-                }
-                if (!(SKIP & 4) && next_chunk && tap < W_CNT) load_window_item(tap);
-                __builtin_amdgcn_sched_barrier(0);  // the requests stay ahead of the tap's arithmetic
-                if (!(SKIP & 2) && tap < 8) read_x(Wc, xs ^ 1, tap + 1);
-                if (!(SKIP & 4) && next_chunk && tap >= ST0) store_window_item(Wn, tap - ST0);
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if (tap >= ST0) store_window_item(Wn, tap - ST0);
 #pragma unroll
-                for (int k = 0; k < NM; ++k) mfma(k);
-                // interleave: the next tap's pixel-fragment reads one per MFMA first, then the window item's split (about 30
-                // VALU instructions) two per MFMA, its two LDS writes last -- everything inside the shadow of the tap's MFMAs
+            for (int k = NF; k < NM; ++k) mfma(k);
 #pragma unroll
-                for (int k = 0; k < NM; ++k) {
-                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-                    if (k < NR)
-                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    else if (next_chunk && tap >= ST0)
-                        __builtin_amdgcn_sched_group_barrier(0x2, NM - NR >= 16 ? 2 : 4, 0);
-                }
-                if (next_chunk && tap >= ST0) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+            for (int k = NF; k < NM; ++k) {  // the window item's split (about 30 VALU instructions), its two LDS writes last
+                __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                if (tap >= ST0) __builtin_amdgcn_sched_group_barrier(0x2, NM - NF >= 16 ? 2 : 4, 0);
             }
+            if (tap >= ST0) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
             __builtin_amdgcn_sched_barrier(0);
         });
         __syncthreads();
@@ -286,7 +252,7 @@ static long long f16s2_blocks(const ConvParams& p) {
     return (long long)p.N * ((p.Ho + TH - 1) / TH) * ((p.Wo + 31) / 32) * (p.wf16_cout_pad / BN);
 }
 
-template <int WC, int WR, int TC, int TR, int SKIP = 0>
+template <int WC, int WR, int TC, int TR>
 static int launch_f16s2_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) {
     constexpr int TH = WR * TR, BN = WC * TC * 32;
     const int tiles = p.N * ((p.Ho + TH - 1) / TH) * ((p.Wo + 31) / 32);
@@ -298,7 +264,7 @@ static int launch_f16s2_cfg(const ConvParams& p, hipStream_t stream, int cfg_id)
         pe.cfg = cfg_id;
         DFVO_HIP_CHECK(hipEventRecord(pe.e0, stream));
     }
-    hipLaunchKernelGGL((conv_win_f16s2_kernel<WC, WR, TC, TR, SKIP>), grid, dim3(64 * WC * WR), 0, stream, p);
+    hipLaunchKernelGGL((conv_win_f16s2_kernel<WC, WR, TC, TR>), grid, dim3(64 * WC * WR), 0, stream, p);
     DFVO_HIP_CHECK(hipGetLastError());
     if (g_prof) {
         DFVO_HIP_CHECK(hipEventRecord(pe.e1, stream));
@@ -318,11 +284,6 @@ constexpr int F16S2_NOT_APPLICABLE = 1;
 // third skeleton (conv_win_f16s3.hip, its own translation unit): the same tile loop, a run of p.tile_run tiles per workgroup
 int launch_f16s3_shape(const ConvParams& p, int shape, hipStream_t stream, int* grid_xy);
 bool f16s3_eligible(const ConvParams& p);
-static unsigned* f16s_clamp_counter() {
-    static unsigned* ptr = nullptr;
-    if (!ptr && hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(g_f16s_clamped)) != hipSuccess) ptr = nullptr;
-    return ptr;
-}
 // Run length of the third skeleton (DFVO_F16S_RUN: unset / 0 = second skeleton, N >= 1 = runs of N tiles, p = persistent:
 // one workgroup per CU walking ceil(tiles / 256) tiles, p<k> = the same on 256 - k CUs).  OFF by default -- measured
 // (profiles/r4c_*, r4g_*): the persistent form is 6-9 % faster one launch at a time (level-2 128 -> 128: 202 -> 188 us,
@@ -366,11 +327,8 @@ static int launch_f16s23(const ConvParams& p, hipStream_t stream, int cfg_id, in
     return DFVO_OK;
 }
 static int launch_f16s2(const ConvParams& p, hipStream_t stream, int cfg_id) {
-    // default on: per layer the two skeletons are within 2 % of each other (tools/bench_f16s_v2.py), inside the pipeline the
-    // one-wave-per-SIMD one gives +3 % pairs/s (half the resident net waves next to the solver's kernels).
-    // DFVO_F16S_V2=0 restores the first skeleton everywhere.
-    static const int mode = getenv("DFVO_F16S_V2") ? atoi(getenv("DFVO_F16S_V2")) : 1;
-    if (!mode) return F16S2_NOT_APPLICABLE;
+    // (per layer the two skeletons are within 2 % of each other; inside the pipeline this one gives +3 % pairs/s: half the
+    // resident net waves next to the solver's kernels -- round 3)
     const int ncu = 256;
     auto cost = [&](long long blocks, int rows) { return blocks <= 0 ? (1LL << 60) : ((blocks + ncu - 1) / ncu) * rows; };
     if (p.wf16_cout_pad % 128 == 0) {
@@ -378,17 +336,17 @@ static int launch_f16s2(const ConvParams& p, hipStream_t stream, int cfg_id) {
         const long long b3 = f16s2_blocks<2, 2, 2, 3>(p), b2 = f16s2_blocks<2, 2, 2, 2>(p);
         if (b2 < 200) return F16S2_NOT_APPLICABLE;
         const long long c3 = cost(b3, 6), c2 = cost(b2, 4) * 11 / 10;  // (small tiles: fewer MFMAs per load)
-        if ((mode & 2) || c3 <= c2) return launch_f16s23<2, 2, 2, 3>(p, stream, cfg_id, 0);
+        if (c3 <= c2) return launch_f16s23<2, 2, 2, 3>(p, stream, cfg_id, 0);
         return launch_f16s23<2, 2, 2, 2>(p, stream, cfg_id, 1);
     }
     if (p.wf16_cout_pad % 64 == 0) {
         const long long b3 = f16s2_blocks<1, 4, 2, 3>(p), b2 = f16s2_blocks<1, 4, 2, 2>(p);
         if (b2 < 200) return F16S2_NOT_APPLICABLE;
-        if ((mode & 2) || cost(b3, 12) <= cost(b2, 8)) return launch_f16s23<1, 4, 2, 3>(p, stream, cfg_id, 2);
+        if (cost(b3, 12) <= cost(b2, 8)) return launch_f16s23<1, 4, 2, 3>(p, stream, cfg_id, 2);
         return launch_f16s23<1, 4, 2, 2>(p, stream, cfg_id, 3);
     }
     const long long b3 = f16s2_blocks<1, 4, 1, 3>(p), b2 = f16s2_blocks<1, 4, 1, 2>(p);
     if (b2 < 200) return F16S2_NOT_APPLICABLE;
-    if ((mode & 2) || cost(b3, 12) <= cost(b2, 8)) return launch_f16s23<1, 4, 1, 3>(p, stream, cfg_id, 4);
+    if (cost(b3, 12) <= cost(b2, 8)) return launch_f16s23<1, 4, 1, 3>(p, stream, cfg_id, 4);
     return launch_f16s23<1, 4, 1, 2>(p, stream, cfg_id, 5);
 }

@@ -57,10 +57,6 @@ struct ConvParams {
     const float* bias;
     // head layout of the same weights (one- / two-channel square layers only, else null): see conv_pack_head_weights
     const float* wh;
-    // bf16 planes of wp (plane-major, wsp_plane dwords each), only in the opt-in DFVO_CONV_PRECISION=bf16x3|bf16x6 modes
-    const float* wsp;
-    size_t wsp_plane;
-    int wsp_planes;
     // f16 hi/lo planes of the weights in the split window kernel's layout (DFVO_CONV_PRECISION=f16x3, 3x3 layers only):
     // [tap][16-channel chunk][wf16_cout_pad / 32][plane hi, lo][k / 8][32 couts][8] halves, see conv_pack_weights_f16s
     const unsigned short* wf16;
@@ -104,57 +100,11 @@ struct ConvParams {
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
-// Stream priorities (tuning aid, off by default).  The solver stage is a chain of ~40 dependent launches of one or a few
-// workgroups racing against net kernels that keep every CU full, so raising its streams' priority looked promising;
-// measured on MI355X (bench.py, 60 pairs) it is neutral for the chain's own stream and costs 3-9 % for the others:
-// DFVO_SOLVER_PRIORITY bit mask -> 0: 231.7 frames/s, 1: 231.7, 2: 225.4, 3: 222.8, 4: 214.2, 8 (nets lowest): 212.3.
-// Net streams with a few CUs left out (DFVO_NET_CU_RESERVE = CUs per 32-CU mask word, i.e. per XCD; default 0 = none), so
-// that the solver chain's small workgroups always find an idle CU (tuning aid).  Measured: 1 / 2 / 4 reserved CUs per
-// XCD -> 211.7 / 210.1 / 208.8 frames/s against 236.1 without; the chain's latency under load (3.75 ms, 2.1 ms with
-// the nets idle) did not move, so free CU slots are not what it waits for.
-static inline hipError_t create_net_stream(hipStream_t* s) {
-    static const int reserve = getenv("DFVO_NET_CU_RESERVE") ? atoi(getenv("DFVO_NET_CU_RESERVE")) : 0;
-    if (reserve <= 0 || reserve >= 32) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
-    hipDeviceProp_t prop;
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    e = hipGetDeviceProperties(&prop, dev);
-    if (e != hipSuccess) return e;
-    const int words = (prop.multiProcessorCount + 31) / 32;
-    uint32_t mask[16];
-    for (int i = 0; i < 16; ++i) mask[i] = i < words ? ~((1u << reserve) - 1u) : 0u;
-    return hipExtStreamCreateWithCUMask(s, (uint32_t)(words < 16 ? words : 16), mask);
-}
-
-static inline hipError_t create_solver_stream(hipStream_t* s, int which = 1) {
-    // which: 1 the RNG-ordered chain's stream, 2 its side streams, 4 the prefetch streams, 8 a net stream (lowest priority)
-    static const int mask = getenv("DFVO_SOLVER_PRIORITY") ? atoi(getenv("DFVO_SOLVER_PRIORITY")) : 0;
-    // DFVO_SOLVER_CU_ONLY (bit mask over `which`) together with DFVO_NET_CU_RESERVE = k: those solver streams may only use
-    // the k CUs per XCD that the nets leave out (measured: 211-213 frames/s, the chain's latency under load unchanged)
-    static const int cu_only = getenv("DFVO_SOLVER_CU_ONLY") ? atoi(getenv("DFVO_SOLVER_CU_ONLY")) : 0;
-    // (DFVO_SOLVER_CU_K = k confines them to k CUs per XCD while the nets keep all CUs)
-    static const int reserve = getenv("DFVO_SOLVER_CU_K")      ? atoi(getenv("DFVO_SOLVER_CU_K"))
-                               : getenv("DFVO_NET_CU_RESERVE") ? atoi(getenv("DFVO_NET_CU_RESERVE"))
-                                                               : 0;
-    if ((cu_only & which) && reserve > 0 && reserve < 32) {
-        hipDeviceProp_t prop;
-        int dev = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e != hipSuccess) return e;
-        e = hipGetDeviceProperties(&prop, dev);
-        if (e != hipSuccess) return e;
-        const int words = (prop.multiProcessorCount + 31) / 32;
-        uint32_t m[16];
-        for (int i = 0; i < 16; ++i) m[i] = i < words ? ((1u << reserve) - 1u) : 0u;
-        return hipExtStreamCreateWithCUMask(s, (uint32_t)(words < 16 ? words : 16), m);
-    }
-    if (!(mask & which)) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
-    int least = 0, greatest = 0;
-    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
-    if (e != hipSuccess) return e;
-    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, which == 8 ? least : greatest);
-}
+// Streams of the pipeline are plain non-blocking streams.  Measured dead ends, kept as records only:
+// stream priorities for the solver chain (neutral for the chain, -3 .. -9 % for the others: round 2), CU masks that keep a
+// few CUs per XCD free of net kernels or confine the solver to them (-10 %: round 2).
+static inline hipError_t create_net_stream(hipStream_t* s) { return hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
+static inline hipError_t create_solver_stream(hipStream_t* s, int = 1) { return hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
 
 // candidate streams classified by the dispatch pipe that serves them (stream_pool.hip)
 struct StreamPool {
@@ -183,8 +133,7 @@ static inline int conv_cout_pad(int cout, long long M) {
 // implement eval-mode BatchNorm folding: w' = w*scale, b' = b*scale + shift.
 // weights of a one- / two-channel k x k layer in the order the direct head kernel consumes them:
 // [8-channel chunk (source 0 first, each source rounded up)][kx][4-channel group of the chunk (2)][ky][cout][4]
-void conv_split_weights_bf16(const float* packed, size_t n_floats, int planes, unsigned short* out);
-int conv_split_mode();  // 0 exact fp32 (default), 2 = bf16x3, 3 = bf16x6, 4 = f16x3 (f16 hi/lo planes, fp32-class)
+int conv_split_mode();  // 0 exact fp32 (default), 4 = f16x3 (f16 hi/lo planes, fp32-class)
 // weights of a 3x3 layer as f16 hi / lo planes for conv_win_f16s_kernel; returns the number of halves written
 // (out may be null to query the size): [tap][chunk][cout_pad32][2][16], chunks = ceil(c0/16) + ceil(c1/16)
 size_t conv_pack_weights_f16s(const float* w_oihw, int cout, int c0, int c1, const float* fold_scale, unsigned short* out);
@@ -203,8 +152,6 @@ void conv_pack_weights(const float* w_oihw, const float* bias, int cout, int c0,
 
 constexpr int CONV_NUM_CFGS = 24;  // tile configurations of the implicit-GEMM kernel (profile arrays have this size)
 int launch_conv(const ConvParams& p, hipStream_t stream);
-// effective (bm, splits) the launcher would use for p (after clamping the overrides)
-void conv_effective_config(const ConvParams& p, int* bm, int* splits);
 void conv_profile_begin();
 int conv_profile_end(double* ms, double* flops, int* launches);
 

@@ -25,9 +25,6 @@ struct DevBuf {
 struct ConvLayer {
     float* wp = nullptr;
     float* bias = nullptr;
-    float* wsp = nullptr;  // bf16 planes of wp (opt-in split-precision modes, 3x3 layers only)
-    size_t wsp_plane = 0;  // dwords per plane
-    int wsp_planes = 0;
     unsigned short* wf = nullptr;  // f16 hi/lo planes for conv_win_f16s_kernel (DFVO_CONV_PRECISION=f16x3, 3x3 layers)
     int wf_cout_pad = 0;
     unsigned short* wg = nullptr;  // f16 hi/lo planes in k-group order for conv_gemm_f16s_kernel (f16x3 mode, every layer)
@@ -38,9 +35,6 @@ struct ConvLayer {
     int cout = 0, cout_pad = 0, c0 = 0, c1 = 0, kh = 0, kw = 0, ksteps = 0;
     int stride = 1, pad_h = 0, pad_w = 0, pad_mode = PAD_ZERO, act = ACT_NONE;
     float act_param = 0.f;
-    // per-layer launch configuration measured once on the device (conv autotuner, nets.hip); 0 = heuristic
-    mutable int tune_bm = 0, tune_splits = 0;
-    mutable bool tuned = false;
     double macs_per_pixel() const { return (double)cout * (c0 + c1) * kh * kw; }
 };
 
@@ -54,16 +48,11 @@ int make_conv(const ParamStore& ps, const std::string& wname, const std::string&
               long long M_hint, const float* scale, const float* shift, ConvLayer* out);
 void free_conv(ConvLayer* l);
 // uploads the head-layout copy of the weights when the layer qualifies for the direct head kernel (else leaves wh null)
-// uploads the bf16-plane copy of the packed weights when a split-precision mode is on and the layer is 3x3
-int make_split_weights(const std::vector<float>& packed, int kh, int kw, ConvLayer* L);
 int make_f16s_weights(const float* w_oihw, int cout, int c0, int c1, int kh, int kw, const float* scale, ConvLayer* L);
 int make_f16g_weights(const float* w_oihw, int cout, int c0, int c1, int kh, int kw, const float* scale, ConvLayer* L);
-int conv_set_precision(const char* name);  // fp32 | f16x3 | bf16x6 | bf16x3: applies to layers packed afterwards
+int conv_set_precision(const char* name);  // fp32 | f16x3: applies to layers packed afterwards
 int make_head_weights(const float* w_oihw, int cout, int c0, int c1, int kh, int kw, const float* scale, float** wh);
 
-// while set, run_conv times the candidate tile / split-K configurations of every not-yet-tuned layer on its
-// real shapes and keeps the fastest (set around the first eager forward of a net; never during graph capture)
-void conv_autotune_scope(bool on);
 
 struct View {
     const float* p;
@@ -93,9 +82,6 @@ struct FlowNet {
     std::vector<ConvLayer> feat_convs;  // 12 convs of Features
     struct Level {
         ConvLayer m_feat, m_main[4], s_feat, s_main[4], r_feat, r_main[6], r_dist[2];
-        ConvLayer feat3;  // level 2: m_feat | s_feat | r_feat as one 1x1 convolution (32 -> 256)
-        DevBuf f3;
-        bool has_feat3 = false;
         bool has_mfeat = false, has_upflow = false, has_upcorr = false, has_rfeat = false, dist_sep = false;
         DevBuf upflow_w, upcorr_w, scale_wx, scale_wy;
         float scale_bx = 0.f, scale_by = 0.f;

@@ -74,7 +74,6 @@ int make_conv(const ParamStore& ps, const std::string& wname, const std::string&
     DFVO_HIP_CHECK(hipMalloc((void**)&L->bias, pb.size() * sizeof(float)));
     DFVO_HIP_CHECK(hipMemcpy(L->wp, pw.data(), pw.size() * sizeof(float), hipMemcpyHostToDevice));
     DFVO_HIP_CHECK(hipMemcpy(L->bias, pb.data(), pb.size() * sizeof(float), hipMemcpyHostToDevice));
-    DFVO_TRY(make_split_weights(pw, L->kh, L->kw, L));
     DFVO_TRY(make_f16s_weights(w->data.data(), L->cout, c0, c1, L->kh, L->kw, scale, L));
     DFVO_TRY(make_f16g_weights(w->data.data(), L->cout, c0, c1, L->kh, L->kw, scale, L));
     return make_head_weights(w->data.data(), L->cout, c0, c1, L->kh, L->kw, scale, &L->wh);
@@ -82,8 +81,6 @@ int make_conv(const ParamStore& ps, const std::string& wname, const std::string&
 
 static int parse_conv_precision(const char* e) {
     if (!e || !strcmp(e, "fp32")) return 0;
-    if (!strcmp(e, "bf16x3")) return 2;
-    if (!strcmp(e, "bf16x6")) return 3;
     if (!strcmp(e, "f16x3")) return 4;
     return -1;
 }
@@ -97,7 +94,7 @@ int conv_split_mode() {
 }
 int conv_set_precision(const char* name) {
     const int m = parse_conv_precision(name);
-    DFVO_ARG_CHECK(m >= 0, "dfvo_set_conv_precision: expected fp32 | f16x3 | bf16x6 | bf16x3");
+    DFVO_ARG_CHECK(m >= 0, "dfvo_set_conv_precision: expected fp32 | f16x3");
     g_conv_precision = m;
     return DFVO_OK;
 }
@@ -140,18 +137,6 @@ int make_f16g_weights(const float* w_oihw, int cout, int c0, int c1, int kh, int
     return DFVO_OK;
 }
 
-int make_split_weights(const std::vector<float>& packed, int kh, int kw, ConvLayer* L) {
-    const int planes = conv_split_mode();
-    if (planes != 2 && planes != 3) return DFVO_OK;
-    if (kh != 3 || kw != 3) return DFVO_OK;
-    std::vector<unsigned short> ps(packed.size() * planes);
-    conv_split_weights_bf16(packed.data(), packed.size(), planes, ps.data());
-    DFVO_HIP_CHECK(hipMalloc((void**)&L->wsp, ps.size() * sizeof(unsigned short)));
-    DFVO_HIP_CHECK(hipMemcpy(L->wsp, ps.data(), ps.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
-    L->wsp_plane = packed.size() / 2;
-    L->wsp_planes = planes;
-    return DFVO_OK;
-}
 
 int make_head_weights(const float* w, int cout, int c0, int c1, int kh, int kw, const float* scale, float** wh) {
     *wh = nullptr;
@@ -167,7 +152,6 @@ void free_conv(ConvLayer* l) {
     if (l->wp) (void)hipFree(l->wp);
     if (l->bias) (void)hipFree(l->bias);
     if (l->wh) (void)hipFree(l->wh);
-    if (l->wsp) (void)hipFree(l->wsp);
     if (l->wf) (void)hipFree(l->wf);
     if (l->wg) (void)hipFree(l->wg);
     if (l->wg32) (void)hipFree(l->wg32);
@@ -176,85 +160,11 @@ void free_conv(ConvLayer* l) {
     l->wf = nullptr;
     l->wg = nullptr;
     l->gtab = nullptr;
-    l->wp = l->bias = l->wh = l->wsp = nullptr;
+    l->wp = l->bias = l->wh = nullptr;
 }
 
-// ---- per-layer autotuner: the candidates differ only in tiling / K splitting, the arithmetic is the same fp32 FMA
-// chain per output (split-K changes the summation order, within the nets' float tolerance)
-static bool g_conv_autotune = false;
-void conv_autotune_scope(bool on) {
-    // opt-in (DFVO_CONV_AUTOTUNE=1): measured gain over the sweep-derived rule in launch_conv is ~2 % on the KITTI
-    // shapes, and a timing-based choice makes the split-K summation order (last float bits) vary between runs
-    static const bool enabled = getenv("DFVO_CONV_AUTOTUNE") && atoi(getenv("DFVO_CONV_AUTOTUNE")) != 0;
-    g_conv_autotune = on && enabled;
-}
-
-// Tuning results are shared by every layer of the same shape in the process (the two flow-net instances of a pipeline, a
-// second pipeline): the choice is timing-based, and a different K-split changes the summation order -- the instances of
-// one net must not disagree about a layer, or a pair's flow would depend on which instance ran it.
-static std::mutex g_tune_mu;
-static std::map<std::array<int, 15>, std::pair<int, int>> g_tune_cache;
-
-static int autotune_conv(const ConvLayer& L, ConvParams p, hipStream_t s) {
-    const std::array<int, 15> key = {p.N, p.H, p.W, p.G0, p.G1, p.cout, p.kh, p.kw, p.stride, p.pad_h, p.pad_w, p.pad_mode, p.up0, p.act,
-                                       (L.wf ? 1 : 0) | (L.wg ? 2 : 0) | (L.wsp ? 4 : 0) | (L.wh ? 8 : 0)};  // (which kernel families the layer can use)
-    {
-        std::lock_guard<std::mutex> lk(g_tune_mu);
-        auto it = g_tune_cache.find(key);
-        if (it != g_tune_cache.end()) {
-            L.tune_bm = it->second.first;
-            L.tune_splits = it->second.second;
-            L.tuned = true;
-            return DFVO_OK;
-        }
-    }
-    const long long M = (long long)p.N * p.Ho * p.Wo;
-    const int bn = conv_pick_bn(p.cout, M);
-    const int bms128[3] = {128, 64, 32}, bms[3] = {256, 128, 64};
-    const int splits[6] = {1, 2, 4, 8, 16, 32};
-    hipEvent_t e0, e1;
-    DFVO_HIP_CHECK(hipEventCreate(&e0));
-    DFVO_HIP_CHECK(hipEventCreate(&e1));
-    float best = 1e30f;
-    int best_bm = 0, best_sp = 0;
-    std::vector<std::pair<int, int>> seen;
-    for (int bi = 0; bi < 3; ++bi)
-        for (int si = 0; si < 6; ++si) {
-            p.force_bm = bn == 128 ? bms128[bi] : bms[bi];
-            p.force_splits = splits[si];
-            int ebm, esp;
-            conv_effective_config(p, &ebm, &esp);
-            bool dup = false;
-            for (auto& q : seen) dup = dup || (q.first == ebm && q.second == esp);
-            if (dup) continue;
-            seen.push_back({ebm, esp});
-            const long long blocks = ((M + ebm - 1) / ebm) * (p.cout_pad / bn) * esp;
-            if (esp > 1 && blocks > 4096) continue;  // splitting an already full grid only adds traffic
-            int rc = launch_conv(p, s);  // warm-up
-            if (rc != DFVO_OK) return rc;
-            DFVO_HIP_CHECK(hipEventRecord(e0, s));
-            for (int r = 0; r < 3; ++r) launch_conv(p, s);
-            DFVO_HIP_CHECK(hipEventRecord(e1, s));
-            DFVO_HIP_CHECK(hipEventSynchronize(e1));
-            float ms = 0.f;
-            DFVO_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
-            if (ms < best) {
-                best = ms;
-                best_bm = ebm;
-                best_sp = esp;
-            }
-        }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    L.tune_bm = best_bm;
-    L.tune_splits = best_sp;
-    L.tuned = true;
-    {
-        std::lock_guard<std::mutex> lk(g_tune_mu);
-        g_tune_cache[key] = {best_bm, best_sp};
-    }
-    return DFVO_OK;
-}
+// (A per-layer timing-based autotuner of tile / split-K configurations existed in rounds 1-3, opt-in: ~2 % on the KITTI
+// shapes, at the price of a summation order that varies between runs.  Removed; launch_conv's rule decides.)
 
 constexpr int SPLITK_TICKETS = 4096;  // split-K never runs with 600 or more tiles (conv_pick_splits)
 
@@ -285,9 +195,6 @@ int run_conv(const ConvLayer& L, int N, int H, int W, View s0, int up0, View s1,
     p.co1 = s1.co;
     p.wp = L.wp;
     p.wh = L.wh;
-    p.wsp = L.wsp;
-    p.wsp_plane = L.wsp_plane;
-    p.wsp_planes = L.wsp_planes;
     p.wf16 = L.wf;
     p.wf16_cout_pad = L.wf_cout_pad;
     p.wf16g = L.wg;
@@ -313,6 +220,8 @@ int run_conv(const ConvLayer& L, int N, int H, int W, View s0, int up0, View s1,
     p.tile_flags = nullptr;
     p.tile_flags_n = 0;
     if (splitk_ws && splitk_ws->n > (size_t)(2 * SPLITK_TICKETS)) {  // the tail of the (zero-filled) workspace holds the tickets
+        // DFVO_SPLITK_FUSED=0 (test hook, tests/test_nets_gpu.py): the separate ordered-reduction launch instead of the
+        // in-kernel finish -- the reference form the fused one is compared with bit for bit
         static const bool fused = !(getenv("DFVO_SPLITK_FUSED") && atoi(getenv("DFVO_SPLITK_FUSED")) == 0);
         p.ws_floats = splitk_ws->n - SPLITK_TICKETS;
         if (fused) {
@@ -322,9 +231,6 @@ int run_conv(const ConvLayer& L, int N, int H, int W, View s0, int up0, View s1,
     }
     p.useful_flops = 2.0 * (double)N * p.Ho * p.Wo * L.macs_per_pixel();
     if (flops) *flops += p.useful_flops;
-    if (g_conv_autotune && !L.tuned) DFVO_TRY(autotune_conv(L, p, s));
-    p.force_bm = L.tune_bm;
-    p.force_splits = L.tune_splits;
     return launch_conv(p, s);
 }
 
@@ -519,34 +425,7 @@ int FlowNet::finalize() {
             leaky(L.r_feat, 0, 0);
             DFVO_TRY(L.rfeat.alloc(px * 128));
         }
-        // Level 2: the three 1x1 `moduleFeat` convolutions of Matching / Subpixel / Regularization (32 -> 64, 64, 128, all
-        // LeakyReLU 0.1) read the same feature map: one 32 -> 256 launch into one buffer, read back as channel views.  Every
-        // output channel keeps its own dot product over the same K order: bit-identical (tests/test_nets_gpu.py).  Opt-in
-        // (DFVO_FLOW_FUSE_FEAT=1): two launches and 13.6 MB of reads fewer per pass, pair rate 286.4 vs 288.0 without it over
-        // three alternations (profiles/r3am_fuse_feat_ab.txt) -- no gain to show for a second code path by default.
-        static const bool fuse_feat = getenv("DFVO_FLOW_FUSE_FEAT") && atoi(getenv("DFVO_FLOW_FUSE_FEAT")) != 0;
-        if (fuse_feat && L.has_mfeat && L.has_rfeat) {
-            const char* mods[3] = {"moduleMatching", "moduleSubpixel", "moduleRegularization"};
-            ParamStore cat;
-            HostTensor wt, bt;
-            for (int i = 0; i < 3; ++i) {
-                const HostTensor* w = params.get(lvl_name(mods[i], l, "moduleFeat.0.weight"));
-                const HostTensor* b = params.get(lvl_name(mods[i], l, "moduleFeat.0.bias"));
-                DFVO_ARG_CHECK(w && b && w->shape.size() == 4 && w->shape[1] == C && w->shape[2] == 1 && w->shape[3] == 1,
-                               "moduleFeat weights of level 2");
-                wt.data.insert(wt.data.end(), w->data.begin(), w->data.end());
-                bt.data.insert(bt.data.end(), b->data.begin(), b->data.end());
-            }
-            wt.shape = {(int)(wt.data.size() / C), C, 1, 1};
-            bt.shape = {(int)bt.data.size()};
-            DFVO_ARG_CHECK(wt.shape[0] == 256 && bt.shape[0] == 256, "moduleFeat weights of level 2: 64 + 64 + 128 outputs");
-            cat.t["w"] = wt;
-            cat.t["b"] = bt;
-            DFVO_TRY(make_conv(cat, "w", "b", C, 0, M, nullptr, nullptr, &L.feat3));
-            leaky(L.feat3, 0, 0);
-            DFVO_TRY(L.f3.alloc(px * 256));
-            L.has_feat3 = true;
-        }
+        // (the three level-2 moduleFeat convolutions as one 32 -> 256 launch: measured, no gain -- profiles/r3am_fuse_feat_ab.txt)
         const int rc0[6] = {3, 128, 128, 64, 64, 32}, rc1[6] = {Cr, 0, 0, 0, 0, 0};
         for (int i = 0; i < 6; ++i) {
             const std::string idx = std::to_string(2 * i);
@@ -652,10 +531,7 @@ int FlowNet::enqueue_carry(const FlowNet& src) {
             cnt[n++] = nf;
         }
     }
-    static const bool one_launch = !(getenv("DFVO_CARRY_ONE_LAUNCH") && atoi(getenv("DFVO_CARRY_ONE_LAUNCH")) == 0);
-    if (one_launch) return launch_copy_segments(from, to, cnt, n, stream);  // (eleven copy nodes cost eleven dispatches)
-    for (int i = 0; i < n; ++i) DFVO_HIP_CHECK(hipMemcpyAsync(to[i], from[i], cnt[i] * sizeof(float), hipMemcpyDeviceToDevice, stream));
-    return DFVO_OK;
+    return launch_copy_segments(from, to, cnt, n, stream);  // one launch (eleven copy nodes cost eleven dispatches)
 }
 
 int FlowNet::enqueue(float* d_fwd, float* d_bwd, float* d_diff) {
@@ -695,13 +571,7 @@ int FlowNet::enqueue_levels(float* d_fwd, float* d_bwd, float* d_diff) {
         const float* sf = feat[l].p;
         const float* rf = feat[l].p;
         int mcs = Cm, mco = 0, scs = Cm, sco = 0, rcs = Cr, rco = 0;  // channel stride / offset of the three views
-        if (L.has_feat3) {
-            DFVO_TRY(run_conv(L.feat3, N, h, w, View{feat[l].p, C, 0}, 0, none, nullptr, 0, 0, L.f3.p, 256, 0, 0, s, &fl, &splitk));
-            mf = sf = rf = L.f3.p;
-            mcs = scs = rcs = 256;
-            sco = 64;
-            rco = 128;
-        } else if (L.has_mfeat) {
+        if (L.has_mfeat) {
             DFVO_TRY(run_conv(L.m_feat, N, h, w, View{feat[l].p, C, 0}, 0, none, nullptr, 0, 0, L.mfeat.p, 64, 0, 0, s,
                               &fl, &splitk));
             DFVO_TRY(run_conv(L.s_feat, N, h, w, View{feat[l].p, C, 0}, 0, none, nullptr, 0, 0, L.sfeat.p, 64, 0, 0, s,
@@ -744,7 +614,7 @@ int FlowNet::enqueue_levels(float* d_fwd, float* d_bwd, float* d_diff) {
         // ------------------------------ Regularization (lite_flow_net.py:243-264)
         DFVO_TRY(launch_flow_mean(L.flowS.p, 4, 0, N, h * w, nullptr, L.mean.p, s));
         DFVO_TRY(launch_reg_prep(img[l].p, L.flowS.p, 4, 0, dbl, L.mean.p, N, h, w, lin_x[l].p, lin_y[l].p, L.r0.p, s));
-        if (L.has_rfeat && !L.has_feat3) {
+        if (L.has_rfeat) {
             DFVO_TRY(run_conv(L.r_feat, N, h, w, View{feat[l].p, C, 0}, 0, none, nullptr, 0, 0, L.rfeat.p, 128, 0, 0, s,
                               &fl, &splitk));
             rf = L.rfeat.p;
@@ -808,11 +678,9 @@ int FlowNet::forward(const uint8_t* d_ref, const uint8_t* d_cur, float* d_fwd, f
     }
     DFVO_ARG_CHECK(d_cur && (d_ref || carry_from), "FlowNet::forward: null frame");
     if (!e_feat) DFVO_HIP_CHECK(hipEventCreateWithFlags(&e_feat, hipEventDisableTiming));
-    if (!tuned_once) {  // first call: eager run with the conv autotuner on (sizes are final from here on)
-        DFVO_TRY(enqueue_input(d_ref, d_cur));  // (timing run: a carried first pass measures on a zero reference frame)
-        conv_autotune_scope(true);
+    if (!tuned_once) {  // first call: one eager run before any graph capture (lazy allocations, dynamic-LDS attributes)
+        DFVO_TRY(enqueue_input(d_ref, d_cur));
         int rc = enqueue(d_fwd, d_bwd, d_diff);
-        conv_autotune_scope(false);
         if (rc != DFVO_OK) return rc;
         DFVO_HIP_CHECK(hipStreamSynchronize(stream));
         tuned_once = true;
@@ -890,8 +758,6 @@ void FlowNet::destroy() {
         free_conv(&L.m_feat);
         free_conv(&L.s_feat);
         free_conv(&L.r_feat);
-        free_conv(&L.feat3);
-        L.f3.release();
         for (auto& c : L.m_main) free_conv(&c);
         for (auto& c : L.s_main) free_conv(&c);
         for (auto& c : L.r_main) free_conv(&c);
@@ -1099,10 +965,8 @@ int DepthNet::forward(const uint8_t* d_img, float* d_depth) {
         set_last_error("DepthNet::forward before finalize");
         return DFVO_ERR_STATE;
     }
-    if (!tuned_once) {
-        conv_autotune_scope(true);
+    if (!tuned_once) {  // one eager run before any graph capture
         int rc = enqueue(d_img, d_depth);
-        conv_autotune_scope(false);
         if (rc != DFVO_OK) return rc;
         DFVO_HIP_CHECK(hipStreamSynchronize(stream));
         tuned_once = true;

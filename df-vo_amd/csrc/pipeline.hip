@@ -88,33 +88,20 @@ int dfvo_pipeline_create(const dfvo_pipeline_cfg* cfg, dfvo_pipeline** out) {
     };
     // Streams by dispatch pipe (stream_pool.hip): twelve candidates, classified by measurement; pipe A / B: one flow-net
     // instance each, pipe C: the depth net + the two run-ahead homography chains, pipe D: the RandomState-ordered chain and
-    // its two side streams, alone.  Falls back to creation order when the probe is off (DFVO_STREAM_PROBE=0), when one of
-    // the stream experiments of dfvo_common.h is active, or when the probe does not find four groups of three.
+    // its two side streams, alone.  Falls back to creation order when the probe does not find four groups of three.
     hipStream_t pool_rep[2] = {nullptr, nullptr}, pool_pre[2] = {nullptr, nullptr}, pool_fx = nullptr;
     {
-        static const bool probe = !(getenv("DFVO_STREAM_PROBE") && atoi(getenv("DFVO_STREAM_PROBE")) == 0) &&
-                                  !getenv("DFVO_NET_CU_RESERVE") && !getenv("DFVO_SOLVER_PRIORITY") && !getenv("DFVO_SOLVER_CU_ONLY");
         StreamPool pool;
-        if (probe && pool.create(12) == DFVO_OK && pool.ngroups >= 4) {
+        if (pool.create(12) == DFVO_OK && pool.ngroups >= 4) {
             int g[4] = {-1, -1, -1, -1}, ng = 0;  // the four largest groups, largest first
             std::vector<int> order;
             for (int i = 0; i < pool.ngroups; ++i) order.push_back(i);
             std::sort(order.begin(), order.end(), [&](int a, int b) { return pool.count(a) > pool.count(b); });
             for (int i = 0; i < 4; ++i) g[ng++] = order[i];
-            // role -> pipe.  Layout 0 (default, measured best): the RandomState-ordered chain and its side streams alone on
-            // one pipe.  DFVO_STREAM_LAYOUT = 1 .. 3: other placements of the side / run-ahead streams (A/B).
-            static const int layout = getenv("DFVO_STREAM_LAYOUT") ? atoi(getenv("DFVO_STREAM_LAYOUT")) : 0;
-            //                         trk rep0 rep1 depth pre0 pre1 flow flow_x
-            // Measured (profiles/r3k_layouts.txt): 0 -> 266 pairs/s; 1 / 2 / 3 (a run-ahead homography chain on a flow net's
-            // pipe) -> 178-194: the long single-workgroup kernels of that chain hold up the dispatch of the flow net's
-            // hundred short launches per pass.
-            static const int L[6][8] = {{0, 0, 0, 1, 1, 1, 2, 3},
-                                        {0, 0, 0, 1, 2, 3, 2, 3},
-                                        {0, 1, 1, 1, 2, 3, 2, 3},
-                                        {0, 0, 1, 1, 2, 3, 2, 3},
-                                        {0, 0, 0, 2, 1, 1, 2, 3},
-                                        {0, 0, 0, 3, 1, 1, 2, 3}};
-            const int* R = L[layout >= 0 && layout < 6 ? layout : 0];
+            // role -> pipe: trk rep0 rep1 | depth pre0 pre1 | flow | flow_x.  Other placements were measured
+            // (profiles/r3k_layouts.txt): a run-ahead homography chain on a flow net's pipe 178-194 pairs/s against 266 -- its
+            // long single-workgroup kernels hold up the dispatch of the flow net's hundred short launches per pass.
+            static const int R[8] = {0, 0, 0, 1, 1, 1, 2, 3};
             if (pool.count(g[0]) >= 3 && pool.count(g[1]) >= 3 && pool.count(g[2]) >= 3 && pool.count(g[3]) >= 3) {
                 p->s_trk = pool.take(g[R[0]]);
                 pool_rep[0] = pool.take(g[R[1]]);
@@ -151,9 +138,7 @@ int dfvo_pipeline_create(const dfvo_pipeline_cfg* cfg, dfvo_pipeline** out) {
     }
     int rc = p->flow.init(p->H, p->W, p->s_flow);
     if (rc != DFVO_OK) return fail(rc);
-    p->flow_instances = getenv("DFVO_FLOW_INSTANCES") ? atoi(getenv("DFVO_FLOW_INSTANCES")) : 2;
-    if (p->flow_instances < 1) p->flow_instances = 1;
-    if (p->flow_instances > DFVO_PIPELINE_SLOTS) p->flow_instances = DFVO_PIPELINE_SLOTS;
+    p->flow_instances = 2;  // two LiteFlowNet instances on two pipes, alternating pairs
     for (int i = 0; i + 1 < p->flow_instances; ++i) {
         if (i == 0 && pool_fx) {
             p->s_flow_x[0] = pool_fx;
@@ -169,7 +154,7 @@ int dfvo_pipeline_create(const dfvo_pipeline_cfg* cfg, dfvo_pipeline** out) {
     p->depth.min_depth = cfg->net_min_depth;
     p->depth.max_depth = cfg->net_max_depth;
     p->depth.baseline_mult = cfg->baseline_mult;
-    if (pool_fx) (void)hipStreamDestroy(pool_fx);  // (DFVO_FLOW_INSTANCES=1)
+    if (pool_fx) (void)hipStreamDestroy(pool_fx);
     rc = p->tbs[0].init(pool_rep[0], pool_rep[1]);
     if (rc != DFVO_OK) return fail(rc);
     for (int i = 1; i < DFVO_PIPELINE_SLOTS; i++) {
@@ -345,16 +330,11 @@ int dfvo_pipeline_enqueue_nets(dfvo_pipeline* p, int slot, const uint8_t* d_ref,
     // stream is ordered behind that pass's feature stage.  A carried pass waits for the same event anyway; a full pass
     // enqueued right behind a carried one without a sync in between would otherwise race with that copy.
     if (p->last_flow && p->last_flow != &fn && p->last_flow->e_feat) DFVO_HIP_CHECK(hipStreamWaitEvent(sf, p->last_flow->e_feat, 0));
-    // DFVO_FLOW_DIRECT_OUT=1: the net writes the slot's buffers itself (one levels graph per slot, no copies behind the pass)
-    static const bool direct = getenv("DFVO_FLOW_DIRECT_OUT") && atoi(getenv("DFVO_FLOW_DIRECT_OUT")) != 0;
-    if (direct) {
-        P_TRY(fn.forward(d_ref, d_cur, p->fwd[slot], p->bwd[slot], p->diff[slot], d_ref ? nullptr : p->last_flow));
-    } else {
-        P_TRY(fn.forward(d_ref, d_cur, fn.out_fwd.p, fn.out_bwd.p, fn.out_diff.p, d_ref ? nullptr : p->last_flow));
-        DFVO_HIP_CHECK(hipMemcpyAsync(p->fwd[slot], fn.out_fwd.p, 2 * px * sizeof(float), hipMemcpyDeviceToDevice, sf));
-        DFVO_HIP_CHECK(hipMemcpyAsync(p->bwd[slot], fn.out_bwd.p, 2 * px * sizeof(float), hipMemcpyDeviceToDevice, sf));
-        DFVO_HIP_CHECK(hipMemcpyAsync(p->diff[slot], fn.out_diff.p, px * sizeof(float), hipMemcpyDeviceToDevice, sf));
-    }
+    // (the net writing the slot's buffers itself, one levels graph per slot, was measured: no gain -- profiles/r3x_copy_ab.txt)
+    P_TRY(fn.forward(d_ref, d_cur, fn.out_fwd.p, fn.out_bwd.p, fn.out_diff.p, d_ref ? nullptr : p->last_flow));
+    DFVO_HIP_CHECK(hipMemcpyAsync(p->fwd[slot], fn.out_fwd.p, 2 * px * sizeof(float), hipMemcpyDeviceToDevice, sf));
+    DFVO_HIP_CHECK(hipMemcpyAsync(p->bwd[slot], fn.out_bwd.p, 2 * px * sizeof(float), hipMemcpyDeviceToDevice, sf));
+    DFVO_HIP_CHECK(hipMemcpyAsync(p->diff[slot], fn.out_diff.p, px * sizeof(float), hipMemcpyDeviceToDevice, sf));
     p->last_flow = &fn;
     DFVO_HIP_CHECK(hipEventRecord(p->e_flow[slot], sf));
     return DFVO_OK;

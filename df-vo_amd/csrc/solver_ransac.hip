@@ -8,7 +8,8 @@
 //   1. the subset sequence comes from one sequential cv::RNG stream -> one lane generates the subsets
 //      of a chunk of iterations (kernels k_*_subsets);
 //   2. every hypothesis of the chunk is solved in parallel, ONE HYPOTHESIS PER LANE for the minimal
-//      solver (k_e_stage1/k_e_poly/k_e_stage3, k_h_solve: pure register/scratch f64 arithmetic), then
+//      solver (k_e_stage1, k_h_solve: pure register/scratch f64 arithmetic; the polynomial + root stage of the
+//      five-point solver, k_e_poly_stage3, runs one ROOT per lane, sixteen lanes per hypothesis), then
 //      ONE HYPOTHESIS PER WAVEFRONT for inlier scoring (k_e_score/k_h_score: 64 lanes stride over the
 //      correspondences, counts reduced across the wave with ds_swizzle/DPP butterflies);
 //   3. a single lane replays OpenCV's sequential "goodCount > max(best, modelPoints-1) -> update best,
@@ -157,55 +158,6 @@ __global__ __launch_bounds__(E_STAGE1_LANES) void k_e_stage1(const EBatch B, int
     }
     double* w = ws + (size_t)it * E_WS;  // [EE 36 | b 39 | c 11 | roots 20]
     ok[it] = sm::five_point_stage1_ws(q1, q2, w, w + 36, w + 75, s_ws + threadIdx.x * E_STAGE1_STRIDE) ? 1 : 0;
-}
-
-__global__ __launch_bounds__(256) void k_e_poly(const EBatch B, int it0, int it1) {
-    const ERep& R = B.r[blockIdx.y];
-    const RansacState* st = R.state;
-    double* ws = R.ws;
-    const int* ok = R.ok;
-    const int it = it0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (st->done || it >= it1) return;
-    if (!ok[it]) return;
-    double* w = ws + (size_t)it * E_WS;
-    double c[11], rre[10], rim[10];
-    for (int i = 0; i < 11; i++) c[i] = w[75 + i];
-    sm::solve_poly10(c, rre, rim);
-    for (int i = 0; i < 10; i++) {
-        w[86 + i] = rre[i];
-        w[96 + i] = rim[i];
-    }
-}
-
-// sixteen lanes per hypothesis, one root per lane (ten active): a root's 3x3 SVD and its E are independent of the
-// other roots; the survivors are stored compacted in root order (slot = number of surviving lower roots), which is
-// exactly the sequential loop's output
-__global__ __launch_bounds__(64) void k_e_stage3(const EBatch B, int it0, int it1) {
-    const ERep& R = B.r[blockIdx.y];
-    const RansacState* st = R.state;
-    const double* ws = R.ws;
-    const int* ok = R.ok;
-    double* models = R.models;
-    int* nmodels = R.nmodels;
-    const int grp = threadIdx.x >> 4, root = threadIdx.x & 15;
-    const int it = it0 + blockIdx.x * 4 + grp;
-    if (st->done) return;
-    const bool active = it < it1;
-    bool valid = false;
-    double Ev[9];
-    if (active && root < 10 && ok[it]) {
-        const double* w = ws + (size_t)it * E_WS;
-        valid = sm::five_point_root_to_E(w, w + 36, w[86 + root], w[96 + root], Ev);
-    }
-    const unsigned long long m = __ballot(valid);
-    const unsigned grp_mask = (unsigned)((m >> (grp * 16)) & 0xffffull);
-    if (valid) {
-        const int slot = __popc(grp_mask & ((1u << root) - 1u));
-        double* dst = models + (size_t)it * 90 + slot * 9;
-#pragma unroll
-        for (int k = 0; k < 9; k++) dst[k] = Ev[k];
-    }
-    if (active && root == 0) nmodels[it] = __popc(grp_mask);
 }
 
 // Polynomial + stage 3 in one launch, sixteen lanes (one DPP row) per hypothesis, one root per lane from the first sweep
@@ -411,14 +363,9 @@ int enqueue_find_essential_batch(RansacWorkspace* w, const double* const* d_pts1
             const int nh = it1 - it0;
             hipLaunchKernelGGL(k_e_subsets, dim3(1), dim3(1), 0, s, B, n, it0, it1);
             hipLaunchKernelGGL(k_e_stage1, dim3(cdiv(nh, E_STAGE1_LANES), R), dim3(E_STAGE1_LANES), 0, s, B, it0, it1);
-            // A/B switch for the round-4 measurement (profiles/r4a_*): 0 = one lane per hypothesis (k_e_poly, 1.07 ms per pair)
-            static const int poly_lanes = getenv("DFVO_E_POLY_LANES") ? atoi(getenv("DFVO_E_POLY_LANES")) : 1;
-            if (poly_lanes) {
-                hipLaunchKernelGGL(k_e_poly_stage3, dim3(cdiv(nh, 4), R), dim3(64), 0, s, B, it0, it1);
-            } else {
-                hipLaunchKernelGGL(k_e_poly, dim3(cdiv(nh, 64), R), dim3(64), 0, s, B, it0, it1);
-                hipLaunchKernelGGL(k_e_stage3, dim3(cdiv(nh, 4), R), dim3(64), 0, s, B, it0, it1);
-            }
+            // polynomial + stage 3: one root per lane (round 4; one lane per hypothesis + a separate stage-3 launch before:
+            // 1.10 -> 0.70 ms per pair, profiles/r4b_kernel_stats_poly_*.csv)
+            hipLaunchKernelGGL(k_e_poly_stage3, dim3(cdiv(nh, 4), R), dim3(64), 0, s, B, it0, it1);
             hipLaunchKernelGGL(k_e_score, dim3(cdiv(nh, 4), R), dim3(256), 0, s, B, it0, it1, n, thr2);
             hipLaunchKernelGGL(k_e_replay, dim3(R), dim3(1), 0, s, B, it0, it1, n, prob);
         }

@@ -53,15 +53,7 @@ struct ScaleConfig {
 
 constexpr int MAX_REP = 8;
 constexpr int NUM_REP_STREAMS = 4;  // side streams created per tracker; two are used (see TrackerBuffers::init)
-// DFVO_REP_STREAMS (tuning aid) overrides the count, clamped to [1, MAX_REP]
-static inline int rep_stream_count() {
-    static const int n = [] {
-        const char* e = getenv("DFVO_REP_STREAMS");
-        const int v = e ? atoi(e) : NUM_REP_STREAMS;
-        return v < 1 ? 1 : (v > MAX_REP ? MAX_REP : v);
-    }();
-    return n;
-}
+static inline int rep_stream_count() { return NUM_REP_STREAMS; }
 
 // PnpTracker.compute_pose_3d2d (solver_pnp.hip)
 struct PnpConfig {

@@ -76,7 +76,6 @@ int dfvo_conv2d(const dfvo_conv_desc* desc, const float* d_src0, const float* d_
  *   "fp32"   exact fp32 MFMA (v_mfma_f32_16x16x4_f32), the default
  *   "f16x3"  fp32-class: operands split into two f16 planes (22 mantissa bits), three exact products per term on
  *            v_mfma_f32_32x32x16_f16, fp32 accumulate (df-vo_amd/csrc/conv_win_f16s.h)
- *   "bf16x6" / "bf16x3"  bf16-plane variants (24 / 16 mantissa bits)
  * Also read once from the environment variable DFVO_CONV_PRECISION. */
 int dfvo_set_conv_precision(const char* name);
 /* Which scikit-learn the scale-recovery RANSAC (sklearn.linear_model.RANSACRegressor, E_tracker.py:618-636) reproduces
@@ -92,9 +91,6 @@ int dfvo_set_sklearn_compat(const char* version);
  * reset != 0 clears the counter. */
 int dfvo_f16s_overflow_count(unsigned long long* h_count, int reset);
 int dfvo_conv_profile_begin(void);
-/* host only: the bf16 planes the opt-in split-precision conv modes (DFVO_CONV_PRECISION=bf16x3 | bf16x6) give a weight:
- * h_out[q * n + i] = plane q of h_in[i], x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1), round to nearest even */
-int dfvo_split_bf16_planes(const float* h_in, int n, int planes, uint16_t* h_out);
 int dfvo_conv_profile_end(double* h_ms24, double* h_flops24, int* h_launches24);
 
 /* correlation.py:38-106,281-340 (_FunctionCorrelation.forward) followed by leaky_relu(slope)

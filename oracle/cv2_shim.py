@@ -154,6 +154,17 @@ def solvePnPRansac(objectPoints, imagePoints, cameraMatrix, distCoeffs, iteratio
     return True, r.reshape(3, 1), t.reshape(3, 1), inl[:cnt.value].reshape(-1, 1).copy()
 
 
+def solvePoly(coeffs, maxIters=300):
+    """cv2.solvePoly(coeffs[, roots[, maxIters]]) -> retval, roots [n,1,2] (re, im) for real coefficients c[0] + c[1] x + ...
+    (core/src/mathfuncs.cpp; the five-point solver calls it with its degree-10 polynomial, five-point.cpp).  retval (the
+    last sweep's maxDiff in OpenCV) is not restated: 0.0."""
+    c = np.ascontiguousarray(np.asarray(coeffs, np.float64).reshape(-1))
+    n = len(c) - 1
+    re, im = np.zeros(max(n, 1)), np.zeros(max(n, 1))
+    lib().cv3_solve_poly(c, n, re, im, int(maxIters))  # (_dp is an ndpointer: arrays are passed as they are)
+    return 0.0, np.stack([re[:n], im[:n]], 1).reshape(n, 1, 2)
+
+
 def Rodrigues(src):
     src = np.asarray(src, np.float64)
     if src.size == 3:

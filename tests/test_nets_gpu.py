@@ -127,11 +127,11 @@ def test_splitk_in_kernel_finish_equals_two_launch_reduction(gpu, tmp_path):
     assert np.abs(res["1"]["fwd0"]).max() > 0.1
 
 
-@pytest.mark.parametrize("knob", ["DFVO_REG_HEAD_V", "DFVO_CORR_RT", "DFVO_FLOW_FUSE_FEAT"])
+@pytest.mark.parametrize("knob", ["DFVO_REG_HEAD_V", "DFVO_CORR_RT"])
 def test_rewritten_kernels_leave_the_flow_bit_identical(gpu, tmp_path, knob):
-    """the register-tiled correlation kernel (DFVO_CORR_RT), the vectorised regularisation head (DFVO_REG_HEAD_V) and the
-    three 1x1 moduleFeat convolutions of level 2 as one launch (DFVO_FLOW_FUSE_FEAT) keep the operation order of what they
-    replace: the whole flow net's output with the knob off / on, bit for bit"""
+    """the register-tiled correlation kernel and the vectorised regularisation head keep the operation order of the plain
+    restatements they replaced (kept compiled as test references behind DFVO_CORR_RT=0 / DFVO_REG_HEAD_V=0): the whole flow
+    net's output with the knob off / on, bit for bit"""
     import os
     import subprocess
     import sys

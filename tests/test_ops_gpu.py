@@ -194,23 +194,22 @@ def test_resize_bilinear(gpu, ac, h, w, ho, wo):
 
 
 def test_split_precision_modes(gpu):
-    """opt-in conv modes (DFVO_CONV_PRECISION): exact fp32 (default), bf16x6 (three bf16 planes per operand, six product
-    terms: fp32-class accuracy) and bf16x3 (two planes, 16 mantissa bits).  The mode is per process, hence subprocesses."""
+    """conv modes (DFVO_CONV_PRECISION): exact fp32 (library default) and f16x3 (two f16 planes per operand, three exact
+    products per term: fp32-class accuracy) on the same 132 -> 64 window layer.  The mode is per process, hence
+    subprocesses.  (The bf16x3 / bf16x6 plane modes of rounds 1-2 were removed: slower than f16x3 at equal or lower accuracy.)"""
     import os
     import subprocess
     import sys
     probe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "split_mode_probe.py")
     err = {}
-    for mode in ("fp32", "bf16x6", "bf16x3"):
+    for mode in ("fp32", "f16x3"):
         env = dict(os.environ, DFVO_CONV_PRECISION=mode)
         out = subprocess.run([sys.executable, probe], env=env, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         err[mode] = float([l for l in out.stdout.splitlines() if l.startswith("relerr")][-1].split()[1])
     print("   window conv 132 -> 64, max relative error vs torch fp32:", err)
     assert err["fp32"] <= 2e-6       # exact fp32 products, summation order only
-    assert err["bf16x6"] <= 4e-6     # dropped terms ~2^-24 per product: the same class
-    assert err["bf16x3"] <= 2e-5     # 16 mantissa bits per operand, all four product terms
-    assert err["bf16x3"] > err["bf16x6"]
+    assert err["f16x3"] <= 4e-6      # 22-bit operands, dropped term ~2^-22 per product: the same class
 
 
 F16_CASES = [

@@ -65,6 +65,10 @@ def test_oracle_equals_opencv_343_on_the_dumped_cases():
             assert (E5 is None or E5.size == 0) == (want.size == 0), "five-tuple %d: model count" % ti
             if want.size:
                 assert np.abs(np.asarray(E5)[:3] - want[:3]).max() <= 1e-9, "five-tuple %d: first essential matrix" % ti
+    for qi in range(int(fx["n_poly"]) if "n_poly" in fx.files else 0):  # cv::solvePoly itself, incl. the coincident-root cases
+        _, roots = cv2.solvePoly(fx["poly_c_%d" % qi], maxIters=300)
+        got, want = np.asarray(roots).reshape(-1, 2), fx["poly_r_%d" % qi]
+        assert got.shape == want.shape and np.array_equal(got.view(np.uint64), want.view(np.uint64)), "solvePoly case %d" % qi
     for ri in range(int(fx["n_resize"]) if "n_resize" in fx.files else 0):
         seed, h, w, oh, ow = [int(v) for v in fx["r%d_spec" % ri]]
         img = fx["r%d_img" % ri]

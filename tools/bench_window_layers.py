@@ -1,6 +1,7 @@
 """per-layer timing of the f16x3 window layers at the KITTI pyramid sizes (level 2: 176x608, level 3: 88x304) for the
-skeleton selected by the environment (DFVO_F16S_V2 = 0 first skeleton, 1 one-wave-per-SIMD skeleton, 3 its largest tile
-forced); prints HIP-event durations and a CRC of the output (the two skeletons accumulate in the same order: equal CRCs)."""
+skeleton selected by the environment (DFVO_F16S_RUN unset: one-wave-per-SIMD skeleton; N / p: the tile-run skeleton with
+runs of N tiles / persistent); prints HIP-event durations and a CRC of the output (all skeletons accumulate in the same
+order: equal CRCs)."""
 import importlib
 import os
 import sys
@@ -52,4 +53,4 @@ for name, n, h, w, c0, c1, cout in LAYERS:
     if not name.startswith("c5"):
         tot += best
     print("%-16s %6.1f GF %8.1f us %6.1f TF/s-eq  crc %08x" % (name, gf, best * 1e3, gf / best, zlib.crc32(out.numpy().tobytes()) & 0xffffffff), flush=True)
-print("V2=%s operands %s: sum of the KITTI layers %.1f us" % (os.environ.get("DFVO_F16S_V2", "1"), os.environ.get("OPERANDS", "random"), tot * 1e3))
+print("DFVO_F16S_RUN=%s operands %s: sum of the KITTI layers %.1f us" % (os.environ.get("DFVO_F16S_RUN", "-"), os.environ.get("OPERANDS", "random"), tot * 1e3))

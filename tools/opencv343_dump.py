@@ -127,6 +127,24 @@ def main(out_path):
     for ti, idx in enumerate(tuples):
         E5, m5 = cv2.findEssentialMat(x2[idx], x1[idx], focal=K[0, 0], pp=(K[0, 2], K[1, 2]), method=cv2.RANSAC, prob=0.99, threshold=0.2)
         out["five_E_%d" % ti] = E5 if E5 is not None else np.zeros((0, 3))
+    # cv::solvePoly directly (it IS exposed in Python): the Durand-Kerner sweep behind every five-point hypothesis.  Random
+    # degree-10 polynomials, and polynomials built to hit `p - roots[j] == 0` exactly -- the 3.4 line is recalled to skip such
+    # factors and count `num_same_root` (then take square / cube roots of the correction), where the restatement and the
+    # device multiply by the zero factor: x^10, (x - 1)^10 expanded, products of exactly repeated integer roots, and
+    # polynomials whose roots sit ON the start spiral (1 + i)^k, so that a root equals its start value from the first sweep
+    rp = np.random.Generator(np.random.PCG64(91))
+    polys = [rp.normal(0, 1, 11) * 10.0 ** rp.integers(-3, 4, 11) for _ in range(20)]
+    polys.append(np.array([0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1.0]))
+    polys.append(np.poly(np.ones(10))[::-1].copy())
+    polys.append(np.poly([1, 1, 2, 2, 3, 3, -1, -1, 0.5, 0.5])[::-1].copy())
+    polys.append(np.poly([2, 2, 2, -3, -3, 4, 5, 6, 7, 8])[::-1].copy())
+    spiral = [(1 + 1j) ** k for k in range(10)]
+    polys.append(np.real(np.poly(spiral[:2] + [np.conj(spiral[1])] + [3.0, -2.0, 0.25, 7.0, -0.5, 1.5, 9.0]))[::-1].copy())
+    out["n_poly"] = len(polys)
+    for qi, c in enumerate(polys):
+        c = np.ascontiguousarray(c, np.float64)
+        _, roots = cv2.solvePoly(c, maxIters=300)
+        out["poly_c_%d" % qi], out["poly_r_%d" % qi] = c, np.asarray(roots, np.float64).reshape(-1, 2)
     # utils.py:51 (read_image): cv2.resize(img, (w, h)) of the uint8 frame, default INTER_LINEAR; dfvo.py:314-317 nearest
     out["n_resize"] = len(RESIZE_CASES)
     for ri, (seed, h, w, oh, ow) in enumerate(RESIZE_CASES):
