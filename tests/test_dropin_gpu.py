@@ -340,7 +340,18 @@ def test_timer_sub_keys_are_fed_from_device_stage_times(gpu):
     trk = trk_mod.EssTracker(cfg, cam, timers)
     frames = [fr, rigid_scene(h, w, seed=301, bad_frac=0.4)]
     got = track_sequence(frames, cfg, ks_mod.KeypointSampler(cfg), trk, trk_mod.PnpTracker(cfg, cam), cam_mod.SE3)
-    assert all(m in ("Ess. Mat.", "PnP") for m, _ in got)  # either way the E-tracker and the scale recovery ran
+    assert all(m in ("Ess. Mat.", "PnP") for m, _ in got)  # either way the E-tracker ran twice
+    # the scale recovery on its own (dfvo.py:198 runs it only behind a non-zero E translation): twice, on frame 0's keypoints
+    sampler = ks_mod.KeypointSampler(cfg)
+    ref = {"flow": fr["flow"], "flow_diff": fr["diff"][..., None], "depth": fr["depth_ref"], "raw_depth": fr["depth_ref"].astype(np.float32)}
+    cur = {"depth": fr["depth_cur"]}
+    sampler.update_kp_data(cur, ref, sampler.kp_selection(cur, ref))
+    pose = cam_mod.SE3()
+    pose.t = np.array([[0.02], [0.01], [0.8]])
+    for _ in range(2):
+        trk.scale_recovery(cur, ref, pose, False)
+    for key in ("triangulation", "scale ransac"):  # (the tracked pairs may have added entries of their own: keep the last two)
+        timers.timers[key]["duration"] = timers.timers[key]["duration"][-2:]
     groups = {"find H": "E-tracker", "GRIC-H": "E-tracker", "find-Ess": "E-tracker", "GRIC-E": "E-tracker",
               "find-Ess (full)": "E-tracker", "recover pose": "E-tracker", "triangulation": "scale_recovery",
               "scale ransac": "scale_recovery"}
