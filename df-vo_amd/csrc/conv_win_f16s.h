@@ -241,6 +241,8 @@ static bool conv_f16s_ok(const ConvParams& p) {
     // grid cannot fill the chip and the un-split K loop makes the launch longer than the fp32 one (measured: pyramid
     // levels 5 / 6 and the depth net's inner layers 2-4x slower, level 4 1.5-2x faster)
     const long long e = (long long)p.N * ((p.Ho + 3) / 4) * ((p.Wo + 31) / 32) * (p.wf16_cout_pad / 32);
+    // (round 4: raising the bound to 450 / 900 tiles sends pyramid level 4 / 3 to the generic kernel instead -- the window
+    // family's average TFLOP/s rises, 0.265 -> 0.30 / 0.31 of its roofline, and the pair rate FALLS, 287 -> 280 / 272: kept at 200)
     return e >= 200;
 }
 

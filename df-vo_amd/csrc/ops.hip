@@ -310,8 +310,55 @@ __global__ void k_deconv_dw(const float* __restrict__ src, int scs, int sco, int
     dst[pix * dcs + dco + c] = acc;
 }
 
+// the same, four channels per thread (16-byte loads / stores; views must be 16-byte aligned): a thread's four outputs are
+// four independent sums in the scalar kernel's tap order, so the values are bit-identical.  Channels c >= C of the last
+// quad are written as zeros (the consumers read the padded channel groups against zero weights: they must be finite).
+__global__ __launch_bounds__(256) void k_deconv_dw4(const float* __restrict__ src, int scs, int sco, int N, int H, int W, int C,
+                                                    const float* __restrict__ w, float* __restrict__ dst, int dcs, int dco) {
+    const int C4 = (C + 3) >> 2;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int Ho = 2 * H, Wo = 2 * W;
+    const long long total = (long long)N * Ho * Wo * C4;
+    if (idx >= total) return;
+    const int q = (int)(idx % C4);
+    const long long pix = idx / C4;
+    const int ox = (int)(pix % Wo);
+    const long long row = pix / Wo;
+    const int oy = (int)(row % Ho);
+    const int n = (int)(row / Ho);
+    const int c0 = q * 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 1; a >= 0; --a) {
+        const int ky = ((oy + 1) & 1) + 2 * a;
+        const int iy = (oy + 1 - ky) >> 1;
+        if ((oy + 1 - ky) < 0 || iy >= H) continue;
+#pragma unroll
+        for (int bq = 1; bq >= 0; --bq) {
+            const int kx = ((ox + 1) & 1) + 2 * bq;
+            const int ix = (ox + 1 - kx) >> 1;
+            if ((ox + 1 - kx) < 0 || ix >= W) continue;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + ((size_t)(n * H + iy) * W + ix) * scs + sco + c0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c0 + e < C) acc[e] += v[e] * w[(c0 + e) * 16 + ky * 4 + kx];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (c0 + e >= C) acc[e] = 0.f;
+    *reinterpret_cast<f32x4*>(dst + pix * dcs + dco + c0) = acc;
+}
+
 int launch_deconv_dw(const float* src, int scs, int sco, int N, int H, int W, int C, const float* w, float* dst,
                      int dcs, int dco, hipStream_t s) {
+    const int C4 = (C + 3) >> 2;
+    if (((scs | sco | dcs | dco) & 3) == 0 && C4 * 4 <= scs - sco && C4 * 4 <= dcs - dco) {  // 16-byte views with room for the quad
+        const long long total4 = (long long)N * 2 * H * 2 * W * C4;
+        hipLaunchKernelGGL(k_deconv_dw4, dim3(grid1d(total4, 256)), dim3(256), 0, s, src, scs, sco, N, H, W, C, w, dst, dcs, dco);
+        DFVO_HIP_CHECK(hipGetLastError());
+        return DFVO_OK;
+    }
     const long long total = (long long)N * 2 * H * 2 * W * C;
     hipLaunchKernelGGL(k_deconv_dw, dim3(grid1d(total, 256)), dim3(256), 0, s, src, scs, sco, N, H, W, C, w, dst,
                        dcs, dco);
