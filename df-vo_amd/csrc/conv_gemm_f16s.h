@@ -334,6 +334,32 @@ static int launch_f16g_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) 
 // Shape choice.  TC = 2 (a pixel fragment, whose split costs the VALU work, feeds two cout blocks) whenever the layer has
 // an even number of 32-cout blocks.  The K split fills the chip: ~2 waves per SIMD in total, at least 4 steps per wave.
 // Large maps (thousands of pixel blocks) run KSP = 1 with four pixel blocks per workgroup.
+// multi-tap streaming layers: conv_taps_f16s.hip (its own translation unit; bit-identical to the <4, 1, TC> shape here)
+bool conv_taps_f16s_ok(const ConvParams& p);
+int launch_taps_f16s(const ConvParams& p, hipStream_t stream, int* grid_x);
+static int launch_taps_prof(const ConvParams& p0, hipStream_t stream) {
+    ConvParams p = p0;
+    p.f16s_clamp_ctr = f16s_clamp_counter();
+    ConvProfEntry pe;
+    if (g_prof) {
+        DFVO_HIP_CHECK(hipEventCreate(&pe.e0));
+        DFVO_HIP_CHECK(hipEventCreate(&pe.e1));
+        pe.cfg = 20;
+        DFVO_HIP_CHECK(hipEventRecord(pe.e0, stream));
+    }
+    int gx = 0;
+    const int rc = launch_taps_f16s(p, stream, &gx);
+    if (rc != DFVO_OK) return rc;
+    if (g_prof) {
+        DFVO_HIP_CHECK(hipEventRecord(pe.e1, stream));
+        pe.flops = p.useful_flops;
+        const int sh[12] = {p.N, p.H, p.W, p.Ho, p.Wo, (p.G0 + p.G1) * 4, p.cout, p.kh, p.stride, gx, 0, 7};
+        for (int i = 0; i < 12; ++i) pe.shape[i] = sh[i];
+        g_prof->push_back(pe);
+    }
+    return DFVO_OK;
+}
+
 static int launch_f16g(const ConvParams& p, hipStream_t stream) {
     const long long M = (long long)p.N * p.Ho * p.Wo;
     const long long mblocks = (M + 31) / 32;
@@ -353,6 +379,11 @@ static int launch_f16g(const ConvParams& p, hipStream_t stream) {
     // 1.10 ms per pair), K divided over workgroups as well (r3af_nz_ab.txt: launches 7 % shorter one at a time, pair rate
     // -1.3 %), one cout block per wave on the streaming shapes (r3j_stream_tc1_ab.txt: no gain).
     const int cfg = ksp == 1 ? 20 : 21;  // profile rows: 20 streaming (KSP = 1), 21 K-sliced small maps
+    // multi-tap layers among the streaming shapes: the tap-window kernel (only where this kernel would not slice K: the two
+    // then sum in the same order).  DFVO_TAPS=0 (test hook, tests/test_nets_gpu.py): this file's <4, 1, TC> shape instead
+    // -- the form the tap-window kernel is compared with bit for bit
+    static const bool taps_on = !(getenv("DFVO_TAPS") && atoi(getenv("DFVO_TAPS")) == 0);
+    if (taps_on && ksp == 1 && conv_taps_f16s_ok(p)) return launch_taps_prof(p, stream);
     // ragged cout on a streaming shape: the store-only epilogue (profiles/r4j_rag_ab.txt: the 7 x 1 / 1 x 7 distance layers
     // 80 -> 68 / 104 -> 98 us, +0.8 % pairs/s, bit-identical)
     const bool rag = ksp == 1 && (p.cout % (tc2 ? 64 : 32)) != 0 && !p.res && ((p.dst_cs | p.dst_co) & 3) == 0 &&

@@ -150,6 +150,27 @@ def test_rewritten_kernels_leave_the_flow_bit_identical(gpu, tmp_path, knob):
     assert np.abs(res["1"]["fwd0"]).max() > 0.1
 
 
+def test_tap_window_kernel_leaves_the_f16x3_flow_bit_identical(gpu, tmp_path):
+    """f16x3 mode: the multi-tap streaming layers (7x7 first layer, 7x1 / 1x7 / 5x5 distance layers) on the tap-window
+    kernel (conv_taps_f16s.hip: window split once into LDS planes) against the generic register-ring kernel
+    (DFVO_TAPS=0): same weights, table, operand positions and step order -- the whole flow net's output bit for bit"""
+    import os
+    import subprocess
+    import sys
+    tests = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+    for on in ("0", "1"):
+        out = str(tmp_path / ("taps_%s.npz" % on))
+        env = dict(os.environ, DFVO_CONV_PRECISION="f16x3", DFVO_TAPS=on)
+        code = _SPLITK_AB % {"tests": tests, "root": os.path.dirname(tests), "out": out}
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[on] = np.load(out)
+    for k in ("fwd0", "bwd0", "diff0"):
+        assert np.array_equal(res["0"][k], res["1"][k]), "the tap-window kernel changes %s" % k
+    assert np.abs(res["1"]["fwd0"]).max() > 0.1
+
+
 _SPLITK_LOAD = """
 import importlib, sys, zlib
 import numpy as np, torch
