@@ -138,7 +138,9 @@ int dfvo_pipeline_create(const dfvo_pipeline_cfg* cfg, dfvo_pipeline** out) {
     }
     int rc = p->flow.init(p->H, p->W, p->s_flow);
     if (rc != DFVO_OK) return fail(rc);
-    p->flow_instances = 2;  // two LiteFlowNet instances on two pipes, alternating pairs
+    // two LiteFlowNet instances on two pipes, alternating pairs (measured 1 / 2 / 3: 217 / 287 / 272 pairs/s, profiles/
+    // r3ag_flow_instances_ab.txt).  DFVO_FLOW_INSTANCES=1 is a test hook: the carry-over from a pass of the SAME instance
+    p->flow_instances = getenv("DFVO_FLOW_INSTANCES") && atoi(getenv("DFVO_FLOW_INSTANCES")) == 1 ? 1 : 2;
     for (int i = 0; i + 1 < p->flow_instances; ++i) {
         if (i == 0 && pool_fx) {
             p->s_flow_x[0] = pool_fx;
