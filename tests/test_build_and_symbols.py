@@ -32,3 +32,25 @@ def test_no_gpu_is_loud(capi):
     import pytest
     with pytest.raises(capi.DfvoError):
         capi.require_gpu()
+
+
+def test_comm_entry_points_check_their_arguments():
+    """the data-parallel exchange of the C ABI (dfvo_comm_*, dfvo_allgather_poses): argument errors are reported through the
+    library's error channel before RCCL is touched (no GPU, no communicator needed)"""
+    import ctypes as C
+    import importlib
+    import numpy as np
+    capi = importlib.import_module("df-vo_amd.capi")
+    lib = capi.lib()
+    h = C.c_void_p()
+    idb = (C.c_uint8 * 128)()
+    assert lib.dfvo_comm_create(idb, 2, 2, C.byref(h)) == -2 and b"dfvo_comm_create" in lib.dfvo_last_error()  # rank >= world
+    assert lib.dfvo_comm_create(None, 1, 0, C.byref(h)) == -2
+    assert lib.dfvo_comm_unique_id(None) == -2
+    rows, out = np.zeros((3, 17)), np.zeros((3, 17))
+    cnt = (C.c_int * 1)(3)
+    assert lib.dfvo_allgather_poses(None, capi.as_ptr(rows), 3, cnt, capi.as_ptr(out)) == -2  # null communicator
+    assert lib.dfvo_allgather_poses_device(None, None, 0, None, None) == -2
+    assert lib.dfvo_comm_destroy(None) == 0  # destroying nothing is not an error
+    ms = np.zeros(8)
+    assert lib.dfvo_tracker_stage_ms(None, capi.as_ptr(ms)) == -2
