@@ -82,3 +82,29 @@ def test_alignment_modes_equal_the_reference_eval():
     import pytest
     with pytest.raises(ValueError):
         ev.evaluate(gt, res, alignment="5dof")
+
+
+def test_alignment_recovers_known_transforms():
+    """properties that do not go through the fixtures: an estimate that is the ground truth seen from another world frame
+    (rigid / similarity transform of the positions) aligns back onto it under 6dof / 7dof; a pure scale error under `scale`
+    and `scale_7dof`; and no alignment mode changes r_rel (7dof / 6dof left-multiply every pose by one transform, which
+    relative rotations do not see; arccos near 1 leaves ~1e-7 deg / 100 m of rounding)"""
+    ev = _ev()
+    fx = np.load(os.path.join(GOLD, "kitti_eval_align.npz"))
+    gt = fx["drive_gt"]
+    gt = np.linalg.inv(gt[0]) @ gt  # starts at the identity, as KITTI's ground truth does
+    ang = 0.4
+    R = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    # positions rotated / scaled about the first frame: eval()'s first-frame normalisation keeps res[0] = identity
+    def moved(scale, rot):
+        res = gt.copy()
+        res[:, :3, 3] = (scale * (rot @ gt[:, :3, 3].T)).T
+        return res
+    assert ev.evaluate(gt, moved(1.0, R), alignment="6dof")["ate"] < 1e-9
+    assert ev.evaluate(gt, moved(1.0, R), alignment=None)["ate"] > 10.0
+    assert ev.evaluate(gt, moved(0.7, R), alignment="7dof")["ate"] < 1e-9
+    assert ev.evaluate(gt, moved(0.7, R), alignment="6dof")["ate"] > 10.0
+    assert ev.evaluate(gt, moved(0.7, np.eye(3)), alignment="scale")["ate"] < 1e-9
+    assert ev.evaluate(gt, moved(0.7, np.eye(3)), alignment="scale_7dof")["ate"] < 1e-9
+    r = [ev.evaluate(gt, moved(0.7, R), alignment=a)["r_rel"] for a in ev.ALIGNMENTS]
+    assert max(r) - min(r) < 1e-5
