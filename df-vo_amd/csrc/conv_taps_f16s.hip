@@ -15,7 +15,6 @@
 // main sums), same step order: outputs are bit-identical to conv_gemm_f16s_kernel<4, 1, TC>.
 #include "dfvo_common.h"
 
-#include <cstdlib>
 
 namespace dfvo {
 
@@ -31,7 +30,7 @@ typedef __attribute__((address_space(4))) const u32x4t cu32x4t;
 // fetches per MFMA -- and a six-deep weight ring were both SLOWER per layer, 46 -> 58-62 us on the 7x7 layer.)
 template <int TH, int TC, int PF = 3>
 __global__ __launch_bounds__(64 * TH) void conv_taps_f16s_kernel(const ConvParams p, int G, int pxd, int wcols, int wrows) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char taps_lds[];  // [wrows * wcols pixels][pxd bytes] + 16 zero bytes
+    extern __shared__ __attribute__((aligned(16))) unsigned char taps_lds[];  // [wrows * wcols pixels][pxd bytes] | 16 zero bytes | [S][4] offsets
     constexpr int NT = 64 * TH;
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -88,32 +87,35 @@ __global__ __launch_bounds__(64 * TH) void conv_taps_f16s_kernel(const ConvParam
             }
         }
     }
+    // the byte offset of every k-group of the layer relative to a lane's pixel (-1: a group beyond the layer's K), once per
+    // workgroup into LDS: the K loop then costs one 8-byte LDS read per step instead of ~70 scalar + vector instructions
+    // of table decoding (counters, profiles/r4n_pmc_taps_layers_*.txt: the loop was instruction-issue bound, ~120
+    // instructions per 3-MFMA step)
+    const int S = p.f16g_steps;
+    const int rowb = wcols * pxd, lo_off = G * 8;
+    int* const otab = reinterpret_cast<int*>(taps_lds + zoff + 16);  // [S][4]
+    for (int i = t; i < S * 4; i += NT) {
+        const unsigned e = p.f16g_tab[i];
+        const int ky = e & 31, kx = (e >> 5) & 31, cg = (int)(e >> 16) >> 2;
+        otab[i] = ((e >> 10) & 1u) ? ky * rowb + kx * pxd + cg * 8 : -1;
+    }
     __syncthreads();
 
     // ---- K steps: the generic kernel's loop with the B fragments from LDS
-    const int S = p.f16g_steps;
-    const cu32x4t* const tab = (const cu32x4t*)p.f16g_tab;
     const unsigned short* const wbase = p.wf16g + (size_t)(kb * 32 + lp) * 8;
     const size_t w_step_stride = (size_t)p.wf16g_cout_pad * 32;  // halves per step
-    const int lane_base = (wave * wcols + lp) * pxd;  // this lane's output pixel in the window (stride 1)
-    const int rowb = wcols * pxd, lo_off = G * 8;
+    const int lane_base = (wave * p.stride * wcols + lp * p.stride) * pxd;  // this lane's output pixel in the window
 
     h16x8 rw[PF][TC][2];
     u32x2t rx[PF][2][2];  // [stage][k-group j of the lane][plane]
     int nl = 0;
-    u32x4t tq = tab[0];
+    u32x2t oo = *reinterpret_cast<const u32x2t*>(otab + 2 * kb);  // this lane's two k-group offsets of the next step to load
     auto load_step = [&](int st) {
-        const unsigned e0 = __builtin_amdgcn_readfirstlane(tq[0]), e1 = __builtin_amdgcn_readfirstlane(tq[1]),
-                       e2 = __builtin_amdgcn_readfirstlane(tq[2]), e3 = __builtin_amdgcn_readfirstlane(tq[3]);
-        tq = tab[nl + 1 < S ? nl + 1 : S - 1];
-        auto goff = [&](unsigned e) {  // byte offset of a k-group relative to the lane's pixel; invalid groups -> the zero slot
-            const int ky = e & 31, kx = (e >> 5) & 31, cg = (int)(e >> 16) >> 2;
-            return ((e >> 10) & 1u) ? ky * rowb + kx * pxd + cg * 8 : -1;
-        };
-        const int o0 = goff(e0), o1 = goff(e1), o2 = goff(e2), o3 = goff(e3);
+        const int o0 = (int)oo[0], o1 = (int)oo[1];
+        oo = *reinterpret_cast<const u32x2t*>(otab + (nl + 1 < S ? nl + 1 : S - 1) * 4 + 2 * kb);  // one step ahead of its use
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int o = kb ? (j ? o3 : o2) : (j ? o1 : o0);
+            const int o = j ? o1 : o0;
             const int a_hi = o < 0 ? zoff : lane_base + o;
             const int a_lo = o < 0 ? zoff + 8 : lane_base + o + lo_off;
             rx[st][j][0] = *reinterpret_cast<const u32x2t*>(taps_lds + a_hi);
@@ -207,7 +209,7 @@ bool taps_geom(const ConvParams& p, TapsGeom* g) {
         g->th = th;
         g->wrows = (th - 1) * p.stride + p.kh;
         g->wcols = 31 * p.stride + p.kw;
-        g->lds = (size_t)g->wrows * g->wcols * g->pxd + 16;
+        g->lds = (size_t)g->wrows * g->wcols * g->pxd + 16 + (size_t)p.f16g_steps * 16;
         if (g->lds <= 48 * 1024) return true;
     }
     return false;
@@ -216,7 +218,7 @@ bool taps_geom(const ConvParams& p, TapsGeom* g) {
 
 bool conv_taps_f16s_ok(const ConvParams& p) {
     if (!p.wf16g || !p.f16g_tab || p.G1 != 0 || p.up0 != 0 || p.pad_mode != PAD_ZERO) return false;
-    // stride 1 only: the stride-2 layers were measured slower here than on the generic kernel (3x3 / s2 32 -> 32: 61 vs 39 us --
+    // stride 1 only: the stride-2 layers were measured slower here than on the generic kernel (3x3 / s2 32 -> 32: 55-61 vs 39 us, before and after the offset table --
     // a window of 2 x the pixels for a quarter of the taps per element)
     if (p.kh * p.kw < 3 || p.stride != 1 || p.kh > 31 || p.kw > 31) return false;
     if (p.wf16g_cout_pad != 32 && p.wf16g_cout_pad != 64) return false;
