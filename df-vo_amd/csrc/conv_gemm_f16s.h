@@ -91,14 +91,53 @@ __global__ __launch_bounds__(64 * WP * KSP) void conv_gemm_f16s_kernel(const Con
     f32x4 ra[PF][2];
     unsigned rav = 0;  // bit (2 stage + j): the load holds real data
     h16x8 rw[PF][TC][2];
-    // table entries are fetched one load_step ahead (scalar cache latency off the address path); load_step is called for
-    // consecutive steps s0, s0 + 1, ...
+    // Address arithmetic of the gather.  Counters on the small-map layers (profiles/r4r_pmc_small_maps.txt) show a wave
+    // issuing ~150 vector instructions per 3-MFMA step, 40 % of its life -- most of them decoding the k-group table and
+    // clamping coordinates per lane.  Without reflection padding and x2 upsampling a k-group's address is LINEAR in the
+    // lane's pixel: base(pixel, source) + delta(group), delta = (ky W + kx) cs + channel offset.  The deltas are computed
+    // once per workgroup into an LDS table [S][4] x {delta, flags = ky | kx << 5 | valid << 10 | source << 11}; a step reads
+    // its two groups' entries with one 16-byte LDS load, one step ahead of their use.  The padded / upsampled layers (the
+    // depth decoder) keep the per-step decode of the scalar table.
+    const bool fast_addr = !refl && up0 == 0;  // wave-uniform
+    int* const gtab = reinterpret_cast<int*>(f16g_red + (KSP > 1 ? WP * KSP * TC * 16 * 64 : 0));
+    if (fast_addr) {
+        for (int i = t; i < S * 4; i += 64 * WP * KSP) {
+            const unsigned e = p.f16g_tab[i];
+            const int ky = e & 31, kx = (e >> 5) & 31;
+            const bool s1e = ((e >> 11) & 1u) != 0;
+            gtab[2 * i] = (ky * W + kx) * (s1e ? cs1 : cs0) + (int)(e >> 16);
+            gtab[2 * i + 1] = (int)(e & 0xfffu);
+        }
+        __syncthreads();
+    }
+    const int pbase0 = ((nimg * H + iy0) * W + ix0) * cs0 + co0, pbase1 = ((nimg * H + iy0) * W + ix0) * cs1 + co1;
+    // table entries are fetched one load_step ahead (scalar cache latency / LDS latency off the address path); load_step is
+    // called for consecutive steps s0, s0 + 1, ...
     int nl = s0;
     u32x4 tq = tab[nl < S ? nl : S - 1];
+    u32x4 gq = {0u, 0u, 0u, 0u};
+    if (fast_addr) gq = *reinterpret_cast<const u32x4*>(gtab + ((nl < S ? nl : S - 1) * 4 + 2 * kb) * 2);
     auto load_step = [&](int st) {
+        const int sN = nl + 1 < S ? nl + 1 : S - 1;
+        if (fast_addr) {
+            const u32x4 gc = gq;
+            gq = *reinterpret_cast<const u32x4*>(gtab + (sN * 4 + 2 * kb) * 2);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int d = (int)gc[2 * j];
+                const unsigned f = gc[2 * j + 1];
+                const int iy = iy0 + (int)(f & 31u), ix = ix0 + (int)((f >> 5) & 31u);
+                const bool s1v = ((f >> 11) & 1u) != 0;
+                const bool v = vm && ((f >> 10) & 1u) && (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                // (masked lanes read the first channels of the source: always inside the tensor)
+                const int off = v ? (s1v ? pbase1 : pbase0) + d : (s1v ? co1 : co0);
+                const unsigned long long base = s1v ? src1 : src0;
+                ra[st][j] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(base + (long long)off * 4);
+                rav = (rav & ~(1u << (2 * st + j))) | ((v ? 1u : 0u) << (2 * st + j));
+            }
+        } else {
         const unsigned e0 = __builtin_amdgcn_readfirstlane(tq[0]), e1 = __builtin_amdgcn_readfirstlane(tq[1]),
                        e2 = __builtin_amdgcn_readfirstlane(tq[2]), e3 = __builtin_amdgcn_readfirstlane(tq[3]);
-        const int sN = nl + 1 < S ? nl + 1 : S - 1;
         tq = tab[sN];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -123,6 +162,7 @@ __global__ __launch_bounds__(64 * WP * KSP) void conv_gemm_f16s_kernel(const Con
             // wait counters and force a full drain at every use)
             ra[st][j] = *reinterpret_cast<const __attribute__((address_space(1))) f32x4*>(base + (long long)off * 4);
             rav = (rav & ~(1u << (2 * st + j))) | ((v ? 1u : 0u) << (2 * st + j));
+        }
         }
         const unsigned short* g = wbase + (size_t)nl * w_step_stride;
 #pragma unroll
@@ -309,7 +349,7 @@ template <int WP, int KSP, int TC, int PF = 3, bool RAG = false>
 static int launch_f16g_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) {
     const long long M = (long long)p.N * p.Ho * p.Wo;
     dim3 grid((unsigned)(((M + 32 * WP - 1) / (32 * WP)) * (p.wf16g_cout_pad / (32 * TC))), 1, 1);
-    const size_t lds = KSP > 1 ? (size_t)WP * KSP * TC * 16 * 64 * sizeof(float) : 0;
+    const size_t lds = (KSP > 1 ? (size_t)WP * KSP * TC * 16 * 64 * sizeof(float) : 0) + (size_t)p.f16g_steps * 32;  // + the delta table
     if (lds > 48 * 1024)
         if (int rc_lds = ensure_dyn_lds((const void*)conv_gemm_f16s_kernel<WP, KSP, TC, PF, RAG>, lds)) return rc_lds;
     ConvProfEntry pe;
