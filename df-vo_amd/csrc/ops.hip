@@ -205,10 +205,10 @@ int launch_warp(const float* src, int scs, int sco, int swap, const float* flow,
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_flow_mean(const float* __restrict__ flow, int fcs, int fco, int HW,
                                                      float* __restrict__ mean) {
-    __shared__ float sx[1024], sy[1024];
+    __shared__ double sx[1024], sy[1024];
     const int n = blockIdx.x;
     const float* f = flow + (size_t)n * HW * fcs + fco;
-    float ax = 0.f, ay = 0.f;
+    double ax = 0., ay = 0.;  // exact sum of the floats, one rounding at the end
     for (int i = threadIdx.x; i < HW; i += 1024) {
         ax += f[(size_t)i * fcs];
         ay += f[(size_t)i * fcs + 1];
@@ -224,8 +224,8 @@ __global__ __launch_bounds__(1024) void k_flow_mean(const float* __restrict__ fl
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        mean[n * 2] = sx[0] / (float)HW;
-        mean[n * 2 + 1] = sy[0] / (float)HW;
+        mean[n * 2] = (float)(sx[0] / (double)HW);
+        mean[n * 2 + 1] = (float)(sy[0] / (double)HW);
     }
 }
 
@@ -592,7 +592,7 @@ __global__ void k_reg_head(const float* __restrict__ dist, int dist_cs, int k, c
         const float v = -(d[c] * d[c]);
         m = fmaxf(m, v);
     }
-    float se = 0.f, ax = 0.f, ay = 0.f;
+    double se = 0., ax = 0., ay = 0.;  // (see k_reg_head_v)
     for (int c = 0; c < kk; ++c) {
         const float v = -(d[c] * d[c]);
         const float e = expf(v - m);
@@ -605,12 +605,11 @@ __global__ void k_reg_head(const float* __restrict__ dist, int dist_cs, int k, c
             ux = f[0];
             uy = f[1];
         }
-        ax += wx[c] * (e * ux);
-        ay += wy[c] * (e * uy);
+        ax += (double)wx[c] * ((double)e * ux);
+        ay += (double)wy[c] * ((double)e * uy);
     }
-    const float div = 1.f / se;
-    dst[pix * dcs + dco] = (ax + bx) * div;
-    dst[pix * dcs + dco + 1] = (ay + by) * div;
+    dst[pix * dcs + dco] = (float)((ax + bx) / se);
+    dst[pix * dcs + dco + 1] = (float)((ay + by) / se);
 }
 
 // The same head with the pixel's distance vector read ONCE, as 16-byte loads into registers (a thread's k*k values are
@@ -639,7 +638,10 @@ __global__ __launch_bounds__(256) void k_reg_head_v(const float* __restrict__ di
     float m = -INFINITY;
 #pragma unroll
     for (int c = 0; c < KK; ++c) m = fmaxf(m, v[c]);
-    float se = 0.f, ax = 0.f, ay = 0.f;
+    // The weighted mean itself -- up to 49 terms of the size of the flow, the LAST arithmetic of a level -- is accumulated in
+    // double and rounded once: a float chain leaves 1-2 ulp of the flow here (3e-7 px on the level-2 map, x 20 on the output:
+    // measured against the float64 anchor, tools/flow_error_by_level.py), which is what the keypoint ranking then sees.
+    double se = 0., ax = 0., ay = 0.;
 #pragma unroll
     for (int c = 0; c < KK; ++c) {
         const float e = expf(v[c] - m);
@@ -652,11 +654,10 @@ __global__ __launch_bounds__(256) void k_reg_head_v(const float* __restrict__ di
             ux = f[0];
             uy = f[1];
         }
-        ax += wx[c] * (e * ux);
-        ay += wy[c] * (e * uy);
+        ax += (double)wx[c] * ((double)e * ux);
+        ay += (double)wy[c] * ((double)e * uy);
     }
-    const float div = 1.f / se;
-    *reinterpret_cast<f32x2*>(dst + pix * dcs + dco) = f32x2{(ax + bx) * div, (ay + by) * div};
+    *reinterpret_cast<f32x2*>(dst + pix * dcs + dco) = f32x2{(float)((ax + bx) / se), (float)((ay + by) / se)};
 }
 
 int launch_reg_head(const float* dist, int dist_cs, int k, const float* flow, int fcs, int fco, const float* wx,

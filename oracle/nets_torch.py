@@ -95,11 +95,11 @@ _grid_cache = {}
 
 def backward_warp(inp, flow):
     """lite_flow_net.py:10-28 (torch 1.1 grid_sample semantics = align_corners=True)"""
-    key = str(flow.size())
+    key = str(flow.size()) + str(flow.dtype)
     if key not in _grid_cache:
         hor = torch.linspace(-1.0, 1.0, flow.size(3)).view(1, 1, 1, flow.size(3)).expand(flow.size(0), -1, flow.size(2), -1)
         ver = torch.linspace(-1.0, 1.0, flow.size(2)).view(1, 1, flow.size(2), 1).expand(flow.size(0), -1, -1, flow.size(3))
-        _grid_cache[key] = torch.cat([hor, ver], 1)
+        _grid_cache[key] = torch.cat([hor, ver], 1).to(flow.dtype)  # (float64 anchor: the SAME fp32 grid values, widened)
     flow = torch.cat([flow[:, 0:1] / ((inp.size(3) - 1.0) / 2.0), flow[:, 1:2] / ((inp.size(2) - 1.0) / 2.0)], 1)
     return F.grid_sample(input=inp, grid=(_grid_cache[key] + flow).permute(0, 2, 3, 1), mode='bilinear',
                          padding_mode='zeros', align_corners=True)
@@ -236,7 +236,7 @@ def flow_to_pix(flow):
     """layers.py:193-229 (normalized=True)"""
     _, _, h, w = flow.shape
     mesh = np.meshgrid(range(w), range(h), indexing='xy')
-    ids = torch.from_numpy(np.stack(mesh, axis=0).astype(np.float32)).unsqueeze(0)
+    ids = torch.from_numpy(np.stack(mesh, axis=0).astype(np.float32)).unsqueeze(0).to(flow.dtype)
     pix = (ids + flow).permute(0, 2, 3, 1).clone()
     pix[..., 0] /= w - 1
     pix[..., 1] /= h - 1
@@ -250,11 +250,16 @@ def forward_backward_consistency(flow1, flow2, px1on2):
 
 
 @torch.no_grad()
-def flow_inference(sd, ref_img_u8, cur_img_u8, return_levels=False):
+def flow_inference(sd, ref_img_u8, cur_img_u8, return_levels=False, dtype=torch.float32):
     """DeepModel.forward_flow (deep_models.py:144-182) + LiteFlow.inference_flow (lite_flow.py:89-148),
-    forward_backward=True.  Images uint8 [H,W,3].  Returns numpy fwd [2,H,W], bwd [2,H,W], diff [H,W,1]."""
-    cur = torch.from_numpy(np.transpose(cur_img_u8 / 255, (2, 0, 1))).unsqueeze(0).float()
-    ref = torch.from_numpy(np.transpose(ref_img_u8 / 255, (2, 0, 1))).unsqueeze(0).float()
+    forward_backward=True.  Images uint8 [H,W,3].  Returns numpy fwd [2,H,W], bwd [2,H,W], diff [H,W,1].
+    dtype=torch.float64 is the ANCHOR of the accuracy tests, not the reference's arithmetic: the same fp32 inputs, weights
+    and grid constants, widened, every operation in double -- the exact value any fp32 execution of the net (oneDNN's,
+    the device's) approximates, so that "how far is an implementation from the function" is measurable for each."""
+    cur = torch.from_numpy(np.transpose(cur_img_u8 / 255, (2, 0, 1))).unsqueeze(0).float().to(dtype)
+    ref = torch.from_numpy(np.transpose(ref_img_u8 / 255, (2, 0, 1))).unsqueeze(0).float().to(dtype)
+    if dtype != torch.float32:
+        sd = {k: v.to(dtype) for k, v in sd.items()}
     img1 = torch.cat((ref, cur), 0)
     img2 = torch.cat((cur, ref), 0)
     _, _, h, w = img1.shape
@@ -327,10 +332,13 @@ def depth_decoder(sd, feats):
 
 
 @torch.no_grad()
-def depth_inference(sd, img_u8_feed, min_depth=0.1, max_depth=100, mult=5.4):
+def depth_inference(sd, img_u8_feed, min_depth=0.1, max_depth=100, mult=5.4, dtype=torch.float32):
     """DeepModel.forward_depth (deep_models.py:184-206) after the PIL resize, +
-    Monodepth2DepthNet.inference_depth (monodepth2.py:91-139).  img uint8 [feedH, feedW, 3]."""
-    x = torch.from_numpy(img_u8_feed).permute(2, 0, 1).contiguous().float().div(255).unsqueeze(0)
+    Monodepth2DepthNet.inference_depth (monodepth2.py:91-139).  img uint8 [feedH, feedW, 3].
+    (dtype=torch.float64: the accuracy anchor, see flow_inference)"""
+    x = torch.from_numpy(img_u8_feed).permute(2, 0, 1).contiguous().float().div(255).unsqueeze(0).to(dtype)
+    if dtype != torch.float32:
+        sd = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()}
     disp = depth_decoder(sd, resnet18_encoder(sd, x))[0]
     disp = F.interpolate(disp, (x.shape[2], x.shape[3]), mode='bilinear', align_corners=False)
     min_disp = 1 / max_depth

@@ -24,11 +24,12 @@ from . import tracker_np as T
 DEPTH_CROP = [[0.3, 1], [0, 1]]  # options/examples/default_configuration.yml crop.depth_crop
 
 
-def frame_depth(dsd, img_u8, feed_hw=(192, 640), depth_range=(0.0, 50.0)):
+def frame_depth(dsd, img_u8, feed_hw=(192, 640), depth_range=(0.0, 50.0), dtype=None):
     """dfvo.py:305-319: raw_depth (float32, image size) and depth (float64, cropped / range-masked) of one frame"""
     h, w = img_u8.shape[:2]
     feed = np.asarray(Image.fromarray(img_u8).resize((feed_hw[1], feed_hw[0]), Image.LANCZOS))  # deep_models.py:195-199
-    small = O.depth_inference(dsd, np.ascontiguousarray(feed))
+    small = O.depth_inference(dsd, np.ascontiguousarray(feed), **({"dtype": dtype} if dtype is not None else {}))
+    small = small.astype(np.float32)  # (float64 anchor runs: rounded once, where the reference's net output is float32)
     raw = cv2_shim.resize(small, (w, h), interpolation=cv2_shim.INTER_NEAREST)
     return raw, T.preprocess_depth(raw, DEPTH_CROP, list(depth_range))
 

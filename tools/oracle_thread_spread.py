@@ -9,6 +9,10 @@ fp32 convolutions -- one thread instead of all cores, and / or oneDNN off (torch
 with the committed fixture (all cores, oneDNN) exactly as tests/test_trajectory_gpu.py compares the device.
 
     python tools/oracle_thread_spread.py [--threads 1] [--no-mkldnn] [--frames 130] > profiles/r4_oracle_vs_oracle.txt
+
+--float64 runs both nets in DOUBLE on the same fp32 inputs / weights / grid constants (oracle/nets_torch.py, dtype=) and
+rounds their outputs to float32 once: the exact function the fp32 executions approximate.  Compared with the fp32 fixture
+it says how far the REFERENCE's own arithmetic is from its function -- the yardstick for the device's distance.
 """
 import argparse
 import importlib
@@ -30,6 +34,7 @@ def main():
     ap.add_argument("--threads", type=int, default=1)
     ap.add_argument("--no-mkldnn", action="store_true")
     ap.add_argument("--frames", type=int, default=130)
+    ap.add_argument("--float64", action="store_true")
     a = ap.parse_args()
     torch.set_num_threads(a.threads)
     if a.no_mkldnn:
@@ -45,11 +50,12 @@ def main():
     st_seq = np.random.get_state()
     res = {m: dict(same_kp=0, same_mask=0, same_cnt=0, dF=[], overlap=[], moved=[], flow_diff=[]) for m in ("seq", "pp")}
     mask_bits = {m: np.unpackbits(fx[m + "_mask"]) for m in ("seq", "pp")}
-    _, depth_ref = P.frame_depth(dsd, frames[0])
+    dt = torch.float64 if a.float64 else torch.float32
+    _, depth_ref = P.frame_depth(dsd, frames[0], dtype=dt)
     t0 = time.time()
     for k in range(1, n):
-        _, depth_cur = P.frame_depth(dsd, frames[k])
-        fwd, bwd, diff = O.flow_inference(fsd, frames[k - 1], frames[k])
+        _, depth_cur = P.frame_depth(dsd, frames[k], dtype=dt)
+        fwd, bwd, diff = (x.astype(np.float32) for x in O.flow_inference(fsd, frames[k - 1], frames[k], dtype=dt))
         j = k - 1
         xy0 = fx["kp_xy"][off[j]:off[j + 1]].astype(np.float64)
         cur0 = xy0 + fx["kp_flow"][off[j]:off[j + 1]].astype(np.float64)
@@ -83,8 +89,8 @@ def main():
         depth_ref = depth_cur
         if k % 10 == 0:
             sys.stderr.write("  frame %d (%.0f s)\n" % (k, time.time() - t0))
-    print("ORACLE vs ORACLE, from the same uint8 frames: this run = torch %s, %d thread(s), oneDNN %s; fixture = all cores, oneDNN on"
-          % (torch.__version__, a.threads, "off" if a.no_mkldnn else "on"))
+    print("ORACLE vs ORACLE, from the same uint8 frames: this run = torch %s, %d thread(s), oneDNN %s, nets in %s; fixture = all cores, oneDNN on, float32"
+          % (torch.__version__, a.threads, "off" if a.no_mkldnn else "on", "FLOAT64 (outputs rounded to float32)" if a.float64 else "float32"))
     for m, name in (("seq", "sequential"), ("pp", "per_pair")):
         d = res[m]
         dF = np.array(d["dF"])
