@@ -93,7 +93,8 @@ def _err_stats(x, exact):
 # gives shorter float chains than oneDNN's).  Coded tunnel world: the oracle sits at the REPRESENTATION floor there (median
 # 9e-7 px = half an ulp of a 10-27 px flow: its decode layers have at most three non-zero products, summed in one fixed order)
 # and the device's forward flow carries a uniform +7e-6 px offset -- one ulp of the constant 1.0 the crafted "later frame"
-# selector computes as 255 * (2/255 - 1/255), an exact tie between two floats that the two summation orders break differently
+# selector computes as 255 * (c2 - c1): 1 + 0.992 * 2^-24 for frame counters 1 and 2, next to the midpoint of two floats, where the
+# two summation orders land on different sides
 # (tools/flow_error_by_level.py; the oracle has the same offset against the anchor at other frame counters).  Absolute
 # gates there: (max, median) px.
 ANCHOR_FACTOR = {"fp32": (1.5, 1.5, 1.5), "f16x3": (1.5, 1.5, 1.5)}
