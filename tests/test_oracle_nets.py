@@ -63,3 +63,29 @@ def test_target_size():
         a, b = C.c_int(), C.c_int()
         capi.check(lib.dfvo_flow_target_size(int(h), int(w), C.byref(a), C.byref(b)))
         assert (a.value, b.value) == (th, tw)
+
+
+def test_float64_anchor_is_the_same_function():
+    """dtype=float64 (the accuracy anchor of tests/test_nets_gpu.py) evaluates the SAME function as the fp32 oracle: same
+    inputs, weights and grid constants widened, so the two agree to fp32 rounding noise, the double run reproduces itself,
+    and the fp32 run is bit-identical with and without the option (the pinned path is untouched)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from synth import image_pair
+    sd = O.liteflownet_state_dict(4869)
+    a, b = image_pair(70, 100, seed=1071)
+    O._grid_cache.clear()
+    f32 = O.flow_inference(sd, a, b)
+    f32b = O.flow_inference(sd, a, b, dtype=torch.float32)
+    f64 = O.flow_inference(sd, a, b, dtype=torch.float64)
+    f64b = O.flow_inference(sd, a, b, dtype=torch.float64)
+    for x, y, u, v in zip(f32, f32b, f64, f64b):
+        assert x.dtype == np.float32 and u.dtype == np.float64
+        assert np.array_equal(x, y) and np.array_equal(u, v)
+        e = np.abs(x.astype(np.float64) - u)
+        assert 0 < e.max() <= 2e-3 and np.median(e) <= 1e-4, (e.max(), np.median(e))
+    dsd = O.monodepth2_state_dict(4869)
+    img = image_pair(64, 96, seed=55)[0]
+    d32, d64 = O.depth_inference(dsd, img), O.depth_inference(dsd, img, dtype=torch.float64)
+    assert d32.dtype == np.float32 and d64.dtype == np.float64
+    assert np.abs(d32 - d64).max() <= 1e-3 * np.abs(d64).max()
