@@ -89,8 +89,8 @@ def _err_stats(x, exact):
 # Gates of the float64-anchor test, set from the measured runs (profiles/r4u_anchor.txt, printed lines "ANCHOR").
 # Random weights (every layer a dense sum, the realistic case): the device may be at most ANCHOR_FACTOR times further from
 # the exact function than the reference's own fp32 arithmetic (torch CPU) is -- (max, 99th percentile, median) of
-# |flow - anchor| over the map; measured 0.5-1.1 (fp32) and 0.75-1.03 (f16x3: one rounding per 16-term MFMA dot product
-# gives shorter float chains than oneDNN's).  Coded tunnel world: the oracle sits at the REPRESENTATION floor there (median
+# |flow - anchor| over the map; measured 0.5-1.1 (fp32) and 0.75-1.03 (f16x3: consistent with the f16 MFMA adding its 16 exact
+# products before one rounding into the accumulator -- shorter float chains than oneDNN's).  Coded tunnel world: the oracle sits at the REPRESENTATION floor there (median
 # 9e-7 px = half an ulp of a 10-27 px flow: its decode layers have at most three non-zero products, summed in one fixed order)
 # and the device's forward flow carries a uniform +7e-6 px offset -- one ulp of the constant 1.0 the crafted "later frame"
 # selector computes as 255 * (c2 - c1): 1 + 0.992 * 2^-24 for frame counters 1 and 2, next to the midpoint of two floats, where the
