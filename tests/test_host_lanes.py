@@ -57,6 +57,56 @@ def test_five_point_lane_matches_oracle(hh, cv3):
     assert checked > 200
 
 
+def _degenerate_five_tuples(rng, kind):
+    q1 = rng.normal(0, 0.3, (5, 2))
+    q2 = q1 + rng.normal(0, 0.05, (5, 2))
+    if kind == 0:  # no motion
+        q2 = q1.copy()
+    elif kind == 1:  # collinear image points
+        t = rng.normal(0, 1, (5, 1))
+        q1 = np.hstack([t, 2 * t + 0.1])
+        q2 = q1 + rng.normal(0, 0.01, (5, 2))
+    elif kind == 2:  # a duplicated correspondence
+        q1[1], q2[1] = q1[0], q2[0]
+    elif kind == 3:  # un-normalised magnitudes
+        q1 = q1 * 1e6
+        q2 = q1 + rng.normal(0, 1e4, (5, 2))
+    elif kind == 4:
+        q1 = q1 * 1e-9
+        q2 = q1 + rng.normal(0, 1e-10, (5, 2))
+    elif kind == 5:  # pure rotation
+        a = 0.05
+        R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        y = np.c_[q1, np.ones(5)] @ R.T
+        q2 = y[:, :2] / y[:, 2:]
+    elif kind == 6:  # planar scene
+        X = np.c_[rng.uniform(-1, 1, (5, 2)), np.full(5, 5.0)]
+        Y = X + np.array([0.3, 0.0, 0.1])
+        q1, q2 = X[:, :2] / X[:, 2:], Y[:, :2] / Y[:, 2:]
+    elif kind == 7:  # a non-finite coordinate
+        q2[rng.integers(5), rng.integers(2)] = [np.nan, np.inf, -np.inf][rng.integers(3)]
+    elif kind == 8:
+        q1, q2 = np.zeros((5, 2)), np.zeros((5, 2))
+    elif kind == 9:  # quantised coordinates: exact ties inside the elimination
+        q1, q2 = np.round(q1 * 4) / 4, np.round(q2 * 4) / 4
+    return np.ascontiguousarray(q1), np.ascontiguousarray(q2)
+
+
+def test_five_point_lane_on_degenerate_inputs(hh, cv3):
+    """the solver the RANSAC kernels run per hypothesis on the inputs a random 5-subset of real matches can be: no motion,
+    collinear / duplicated / planar points, pure rotation, huge and tiny magnitudes, NaN / inf, all zeros, quantised
+    coordinates -- solution count and every bit of every solution (NaN payloads included) equal to the C oracle's"""
+    rng = np.random.default_rng(123)
+    for kind in range(10):
+        for trial in range(250 if kind != 8 else 2):
+            q1, q2 = _degenerate_five_tuples(rng, kind)
+            e_h, e_o = np.zeros(90), np.zeros(90)
+            n_h = hh.hh_five_point(_p(q1), _p(q2), _p(e_h))
+            n_o = cv3.cv3_five_point(_p(q1), _p(q2), _p(e_o))
+            assert n_h == n_o, (kind, trial)
+            assert np.array_equal(e_h[:9 * n_h].view(np.uint64), e_o[:9 * n_o].view(np.uint64)), (kind, trial)
+
+
 def test_eig_solvers_match_oracle(hh, cv3):
     rng = np.random.default_rng(12)
     for trial in range(50):

@@ -148,6 +148,74 @@ def test_lane_refinement_flow_matches_oracle(hh, cv3):
         assert np.abs(r_o - rv).max() < 1e-4 and np.abs(t_o - t).max() < 1e-3
 
 
+def test_lane_functions_on_degenerate_inputs(hh, cv3):
+    """Rodrigues (angles near 0 and pi, huge angles, NaN, matrices that are not quite rotations), the EPnP kernel on
+    coplanar / duplicated / collinear / badly scaled / mismatched five-point sets, and the refinement flow on few points,
+    outliers and nearly coplanar objects: lane functions vs the C oracle, bit for bit"""
+    rng = np.random.default_rng(77)
+    beq = lambda a, b: np.array_equal(a.view(np.uint64), b.view(np.uint64))  # noqa: E731
+    for trial in range(3000):
+        k = trial % 6
+        r = rng.normal(0, 0.6, 3)
+        if k == 1:
+            r *= 1e-9
+        elif k == 2:
+            r = r / np.linalg.norm(r) * (np.pi - rng.uniform(0, 1e-7))
+        elif k == 3:
+            r = r / np.linalg.norm(r) * np.pi
+        elif k == 4:
+            r *= 50
+        elif k == 5:
+            r[rng.integers(3)] = np.nan
+        R_h, R_o, r_h, r_o = np.zeros(9), np.zeros(9), np.zeros(3), np.zeros(3)
+        hh.hh_rodrigues_v2m(_p(r), _p(R_h), None)
+        cv3.cv3_rodrigues_v2m(_p(r), _p(R_o))
+        assert beq(R_h, R_o), (k, r)
+        R_in = R_o + rng.normal(0, 1e-3, 9) if k == 4 else R_o.copy()
+        hh.hh_rodrigues_m2v(_p(R_in), _p(r_h))
+        cv3.cv3_rodrigues_m2v(_p(R_in), _p(r_o))
+        assert beq(r_h, r_o), (k, r)
+
+    def points(n):
+        X = np.c_[rng.uniform(-10, 10, (n, 2)), rng.uniform(4, 40, n)]
+        rv, t = rng.normal(0, 0.05, 3), rng.normal(0, 0.5, 3)
+        Xc = X @ cv2_shim.Rodrigues(rv)[0].T + t
+        return X, Xc[:, :2] / Xc[:, 2:] * [K[0, 0], K[1, 1]] + [K[0, 2], K[1, 2]]
+
+    for trial in range(900):
+        k = trial % 6
+        X, uv = points(5)
+        if k == 1:
+            X[:, 2] = 10.0
+        elif k == 2:
+            X[1], uv[1] = X[0], uv[0]
+        elif k == 3:
+            X[:, 1], X[:, 2] = 2 * X[:, 0], 3 * X[:, 0] + 20
+        elif k == 4:
+            X *= 1e4
+        elif k == 5:
+            uv += rng.normal(0, 50, (5, 2))
+        o, i = np.ascontiguousarray(X.astype(np.float32)), np.ascontiguousarray(uv.astype(np.float32))
+        r_h, t_h, r_o, t_o = np.zeros(3), np.zeros(3), np.zeros(3), np.zeros(3)
+        hh.hh_epnp_kernel(_p(K4), _p(o, C.c_float), _p(i, C.c_float), _p(r_h), _p(t_h))
+        cv3.cv3_solve_pnp_epnp_f32(_p(K), _p(o, C.c_float), _p(i, C.c_float), 5, _p(r_o), _p(t_o))
+        assert beq(r_h, r_o) and beq(t_h, t_o), k
+    for trial in range(40):
+        k = trial % 5
+        n = [6, 8, 30, 200, 50][k]
+        X, uv = points(n)
+        if k == 4:
+            X[:, 2] = 12.0 + 1e-4 * rng.normal(0, 1, n)
+        if k == 2:
+            uv[:3] += rng.normal(0, 80, (3, 2))
+        Xd = np.ascontiguousarray(X.astype(np.float32).astype(np.float64))
+        ud = np.ascontiguousarray(uv.astype(np.float32).astype(np.float64))
+        r_h, t_h, r_o, t_o = np.zeros(3), np.zeros(3), np.zeros(3), np.zeros(3)
+        rc_h = hh.hh_find_extrinsic(_p(Xd), _p(ud), n, _p(K4), _p(r_h), _p(t_h))
+        rc_o = cv3.cv3_find_extrinsic(_p(Xd), _p(ud), n, _p(K), _p(r_o), _p(t_o), None)
+        assert rc_h == rc_o and beq(r_h, r_o) and beq(t_h, t_o), k
+
+
 def test_oracle_solve_pnp_ransac_on_coplanar_points_reaches_the_reprojection_minimum():
     """object points on one plane: cvFindExtrinsicCameraParams2's planar branch (round 3: OpenCV's homography
     initialisation restated; rounds 1-2 started the LM from the RANSAC model).  The answer must be the reprojection-error
