@@ -50,6 +50,18 @@ def main(ref, gold, dst):
         out[tag + "_good"] = np.array(res["good_kp_found"])
         if res["good_kp_found"]:
             out[tag + "_kp1"], out[tag + "_kp2"] = res["kp1_best"], res["kp2_best"]
+    # libs/tracker/gric.py (pure numpy) on the inputs stored in tests/golden/gric.npz
+    gp = os.path.join(os.path.dirname(gold), "gric.npz")
+    if os.path.exists(gp):
+        spec = importlib.util.spec_from_file_location("ref_gric", os.path.join(ref, "libs/tracker/gric.py"))
+        gric = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(gric)
+        gg = np.load(gp)
+        f_res = gric.compute_fundamental_residual(gg["F"], gg["kp1"], gg["kp2"])
+        h_res = gric.compute_homography_residual(gg["H"], gg["kp1"], gg["kp2"])
+        n = gg["kp1"].shape[0]
+        out["f_res"], out["h_res"] = f_res, h_res
+        out["f_gric"], out["h_gric"] = np.array(gric.calc_GRIC(f_res, 0.8, n, "EMat")), np.array(gric.calc_GRIC(h_res, 0.8, n, "HMat"))
     np.savez(dst, **out)
 
 
