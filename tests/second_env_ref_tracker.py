@@ -1,0 +1,99 @@
+"""Runs under the SECOND python environment (numpy 1.x, scikit-learn < 1.2, no torch): the reference's own
+libs/tracker/E_tracker.py, imported from /root/reference unmodified, over the oracle's cv2 shim -- compute_pose_2d2d and
+scale_recovery on the seeded cases of tests/golden/e_tracker.npz.  Against make_golden.py's run (numpy 2.x, scikit-learn
+1.7 behind a `base_estimator=` -> `estimator=` adapter) this one needs NO adapter: `RANSACRegressor(base_estimator=...)` is
+still this scikit-learn's own spelling.  torch is absent here and unused on this path: a stub satisfies the imports of
+the RigidFlow layer classes.
+
+    <other python> tests/second_env_ref_tracker.py /root/reference <repo root> out.npz
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+
+def stub_torch():
+    t = types.ModuleType("torch")
+    nn = types.ModuleType("torch.nn")
+    fn = types.ModuleType("torch.nn.functional")
+
+    class Module:
+        def __init__(self, *a, **k):
+            pass
+    nn.Module = Module
+    nn.functional = fn
+    t.nn = nn
+    t.no_grad = lambda *a, **k: (lambda f: f)
+    sys.modules.update({"torch": t, "torch.nn": nn, "torch.nn.functional": fn})
+
+
+def main(ref, root, dst):
+    stub_torch()
+    if not hasattr(np, "int"):
+        np.int = int  # removed in numpy 1.24 (the reference's pin is 1.16.2): ops_3d.py:29
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "oracle", "ref_shims"))
+    sys.path.insert(0, os.path.join(root, "tests"))
+    sys.path.insert(0, ref)
+    from oracle import cv2_shim
+    sys.modules["cv2"] = cv2_shim
+    try:
+        import matplotlib.image  # noqa: F401  (libs/general/kitti_utils.py:5; unused on this path)
+        import matplotlib.pyplot  # noqa: F401
+    except Exception:
+        mpl = types.ModuleType("matplotlib")
+        mpl.__path__ = []
+        for sub in ("pyplot", "image"):
+            m = types.ModuleType("matplotlib." + sub)
+            setattr(mpl, sub, m)
+            sys.modules["matplotlib." + sub] = m
+        sys.modules["matplotlib"] = mpl
+    from easydict import EasyDict
+    from libs.tracker.E_tracker import EssTracker
+    from libs.general.timer import Timer
+    from libs.geometry.camera_modules import Intrinsics
+    from synth import two_view
+    import sklearn
+
+    def tracker_case(seed, n, out_frac, noise, h=376, w=1241):  # tests/golden/make_golden.py:tracker_case
+        x1, x2, R, t, K, o = two_view(n, out_frac, noise, seed, w=w, h=h)
+        rng = np.random.Generator(np.random.PCG64(seed + 77))
+        depth = np.zeros((h, w))
+        zs = rng.uniform(5, 60, n)
+        ix, iy = x2[:, 0].astype(int), x2[:, 1].astype(int)
+        ok = (ix >= 0) & (ix < w) & (iy >= 0) & (iy < h)
+        depth[iy[ok], ix[ok]] = zs[ok]
+        return dict(kp_ref=x1, kp_cur=x2, K=K, depth_cur=depth)
+
+    cfg = EasyDict({
+        "kp_selection": {"rigid_flow_kp": {"enable": False}},
+        "e_tracker": {"ransac": {"reproj_thre": 0.2, "repeat": 5}, "validity": {"method": "GRIC", "thre": None},
+                      "kp_src": "kp_best", "iterative_kp": {"enable": False}},
+        "scale_recovery": {"method": "simple", "kp_src": "kp_best", "iterative_kp": {"enable": False, "kp_src": "kp_depth"},
+                           "ransac": {"method": "depth_ratio", "min_samples": 3, "max_trials": 100, "stop_prob": 0.99,
+                                      "thre": 0.1}},
+        "image": {"height": 376, "width": 1241}})
+    out = {"versions": np.array([np.__version__, sklearn.__version__])}
+    for tag, (seed, n, of, noise) in {"a": (31, 2000, 0.3, 0.15), "b": (32, 2000, 0.6, 0.3), "c": (33, 600, 0.2, 0.1),
+                                      "d": (34, 2000, 0.97, 0.2)}.items():
+        c = tracker_case(seed, n, of, noise)
+        K = c["K"]
+        trk = EssTracker(cfg, Intrinsics([K[0, 2], K[1, 2], K[0, 0], K[1, 1]]), Timer())
+        np.random.seed(4869 + seed)
+        res = trk.compute_pose_2d2d(c["kp_ref"], c["kp_cur"], True)
+        pose = res["pose"]
+        out[tag + "_pose"] = pose.pose.copy()
+        out[tag + "_inliers"] = res["inliers"].copy()
+        scale = -2.0
+        if np.linalg.norm(pose.t) != 0:
+            scale = trk.scale_recovery({"kp_best": c["kp_cur"], "depth": c["depth_cur"]}, {"kp_best": c["kp_ref"]}, pose, False)["scale"]
+        out[tag + "_scale"] = np.array(float(scale))
+        st = np.random.get_state()
+        out[tag + "_rng_after"] = np.r_[st[1].astype(np.uint32), np.uint32(st[2])]
+    np.savez(dst, **out)
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])

@@ -169,3 +169,28 @@ def test_reference_kp_selection_under_numpy_1x_reproduces_the_fixture(tmp_path):
     # (the homography residual goes through np.linalg.inv and 3x3 matmuls: the two environments' BLAS / LAPACK builds differ
     # in the last bit on a quarter of the points -- 7e-15 absolute; the GRIC score above comes out identical)
     assert np.abs(gg["h_res"] - o["h_res"]).max() <= 1e-12 * np.abs(gg["h_res"]).max()
+
+
+def test_reference_e_tracker_under_the_older_libraries_reproduces_the_fixture(tmp_path):
+    """the reference's unmodified libs/tracker/E_tracker.py -- compute_pose_2d2d (shuffles, 5 x findEssentialMat over the
+    oracle's cv2, GRIC, recoverPose) and scale_recovery (triangulation + `RANSACRegressor(base_estimator=...)`, native to this
+    scikit-learn: no adapter) -- executed by the second environment (numpy 1.x RandomState / argpartition, scikit-learn 0.24)
+    gives tests/golden/e_tracker.npz, written under numpy 2.x / scikit-learn 1.7: poses, inlier masks and the RandomState
+    after each case identical, scale to 1e-12 (lstsq of two LAPACK builds)"""
+    py, vers = _second_python()
+    ref = "/root/reference"
+    if py is None or not os.path.isdir(ref):
+        pytest.skip("needs the second python environment and /root/reference (build container only)")
+    from oracle import cv2_shim
+    cv2_shim.lib()  # the C oracle the shim loads is built by the test interpreter
+    dst = str(tmp_path / "trk.npz")
+    r = subprocess.run([py, "-W", "ignore", os.path.join(HERE, "second_env_ref_tracker.py"), ref, os.path.dirname(HERE), dst],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    g, o = np.load(os.path.join(HERE, "golden", "e_tracker.npz")), np.load(dst)
+    print("second environment: numpy %s scikit-learn %s" % tuple(o["versions"]))
+    for tag in "abcd":
+        assert np.array_equal(g[tag + "_pose"], o[tag + "_pose"]), tag
+        assert np.array_equal(g[tag + "_inliers"], o[tag + "_inliers"]), tag
+        assert np.array_equal(g[tag + "_rng_after"], o[tag + "_rng_after"]), tag
+        assert abs(float(g[tag + "_scale"]) - float(o[tag + "_scale"])) <= 1e-12 * abs(float(g[tag + "_scale"])), tag
