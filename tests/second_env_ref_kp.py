@@ -50,6 +50,22 @@ def main(ref, gold, dst):
         out[tag + "_good"] = np.array(res["good_kp_found"])
         if res["good_kp_found"]:
             out[tag + "_kp1"], out[tag + "_kp2"] = res["kp1_best"], res["kp2_best"]
+    # bestN_flow_kp (ablation_correspondences_best_n.yml): ONE np.argpartition over the whole image, cases with heavy ties / NaNs
+    cases = {"a": (192, 640, 71, 0.6, 2000, 0), "b": (376, 1241, 72, 0.35, 2000, 0), "c": (60, 90, 73, 0.5, 300, 0),
+             "d": (120, 200, 74, 0.5, 1000, 1)}  # tests/golden/make_golden.py:BESTN_CASES
+    for tag, (h, w, seed, frac, N, hard) in cases.items():
+        diff, flow = kp_case(h, w, seed, frac)
+        if hard:
+            rng = np.random.Generator(np.random.PCG64(int(seed) + 1))
+            diff = (np.round(diff * 400) / 400).astype(np.float32)
+            diff[rng.random(diff.shape) < 0.002] = np.float32("nan")
+        cfg = Cfg({"kp_selection": {"bestN": {"enable": True, "num_bestN": N}}})
+        xv, yv = np.meshgrid(np.linspace(0, w - 1, w), np.linspace(0, h - 1, h))
+        kp1 = np.expand_dims(np.transpose(np.stack([xv, yv]), (1, 2, 0)), 0)
+        kp2 = kp1 + np.transpose(np.expand_dims(flow, 0), (0, 2, 3, 1))
+        with np.errstate(invalid="ignore"):
+            res = kps.bestN_flow_kp(kp1=kp1, kp2=kp2, ref_data={"flow_diff": diff}, cfg=cfg, outputs={})
+        out["bestN_" + tag + "_kp1"], out["bestN_" + tag + "_kp2"] = res["kp1_best"], res["kp2_best"]
     # libs/tracker/gric.py (pure numpy) on the inputs stored in tests/golden/gric.npz
     gp = os.path.join(os.path.dirname(gold), "gric.npz")
     if os.path.exists(gp):

@@ -163,6 +163,9 @@ def test_reference_kp_selection_under_numpy_1x_reproduces_the_fixture(tmp_path):
             assert np.array_equal(g[tag + "_kp1"], o[tag + "_kp1"]) and np.array_equal(g[tag + "_kp2"], o[tag + "_kp2"]), tag
             n += 1
     assert n >= 5
+    gb = np.load(os.path.join(HERE, "golden", "bestN.npz"))  # bestN_flow_kp: one argpartition over the whole map
+    for tag in "abcd":
+        assert np.array_equal(gb[tag + "_kp1"], o["bestN_" + tag + "_kp1"]) and np.array_equal(gb[tag + "_kp2"], o["bestN_" + tag + "_kp2"]), tag
     gg = np.load(os.path.join(HERE, "golden", "gric.npz"))  # the reference's gric.py under numpy 1.x: residuals and both scores
     for k in ("f_res", "f_gric", "h_gric"):
         assert np.array_equal(np.asarray(gg[k]), np.asarray(o[k])), k
