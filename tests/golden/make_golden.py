@@ -33,6 +33,7 @@ import torch.nn.functional as F  # noqa: E402
 
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle", "ref_shims"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, REF)
 
 from oracle import nets_torch as O  # noqa: E402
@@ -362,6 +363,35 @@ def golden_tracker():
         out[tag + "_rng_after"] = np.r_[st[1].astype(np.uint32), np.uint32(st[2])]
         print("  tracker", tag, "inliers", int(res["inliers"].sum()), "t", pose.t.ravel(), "scale", scale)
     np.savez_compressed(os.path.join(HERE, "e_tracker.npz"), **out)
+
+
+from golden.make_golden_cases import PNP_CASES, pnp_case  # noqa: E402,F401  (torch-free module: also imported by the second-environment run)
+
+
+def golden_pnp_tracker():
+    """the reference's own PnpTracker.compute_pose_3d2d (libs/tracker/pnp_tracker.py:45-125) over the oracle cv2 shim:
+    the image / depth-range filters, 3 or 5 shuffled solvePnPRansac calls, best by inlier count, Rodrigues, pose inversion"""
+    from oracle import cv2_shim
+    sys.modules["cv2"] = cv2_shim
+    from easydict import EasyDict
+    from libs.tracker.pnp_tracker import PnpTracker
+    from libs.geometry.camera_modules import Intrinsics
+    cfg = EasyDict({"kp_selection": {"rigid_flow_kp": {"enable": False}}, "depth": {"max_depth": 50.0, "min_depth": 0.0},
+                    "pnp_tracker": {"ransac": {"iter": 100, "reproj_thre": 1.0, "repeat": 5}},
+                    "image": {"height": 376, "width": 1241}})
+    out = {}
+    for tag, (seed, n, of, noise, it, cop) in PNP_CASES.items():
+        c = pnp_case(seed, n, of, noise, cop)
+        K = c["K"]
+        trk = PnpTracker(cfg, Intrinsics([K[0, 2], K[1, 2], K[0, 0], K[1, 1]]))
+        np.random.seed(4869 + seed)
+        res = trk.compute_pose_3d2d(c["kp1"], c["kp2"], c["depth_1"], it)
+        out[tag + "_pose"] = res["pose"].pose.copy()
+        out[tag + "_kp1"], out[tag + "_kp2"] = res["kp1"], res["kp2"]
+        st = np.random.get_state()
+        out[tag + "_rng_after"] = np.r_[st[1].astype(np.uint32), np.uint32(st[2])]
+        print("  pnp", tag, "survivors", len(res["kp1"]), "t", res["pose"].pose[:3, 3])
+    np.savez_compressed(os.path.join(HERE, "pnp_tracker.npz"), **out)
 
 
 def golden_tracker_flow():
@@ -853,7 +883,7 @@ if __name__ == "__main__":
             "gric": golden_gric, "tracker": golden_tracker, "lanczos": golden_lanczos, "sampled": golden_kp_sampled,
             "tracker_flow": golden_tracker_flow, "rigid": golden_rigid_flow, "bestn": golden_kp_bestn,
             "kitti_eval": golden_kitti_eval, "kitti_eval_align": golden_kitti_eval_align, "dfvo_main": golden_dfvo_main,
-            "target_size": golden_target_size, "tracker_variants": golden_tracker_variants}
+            "target_size": golden_target_size, "tracker_variants": golden_tracker_variants, "pnp_tracker": golden_pnp_tracker}
     for name, fn in todo.items():
         if not which or name in which:
             print("==", name)

@@ -92,6 +92,19 @@ def main(ref, root, dst):
         out[tag + "_scale"] = np.array(float(scale))
         st = np.random.get_state()
         out[tag + "_rng_after"] = np.r_[st[1].astype(np.uint32), np.uint32(st[2])]
+    # PnpTracker.compute_pose_3d2d (pnp_tracker.py:45-125) on the cases of tests/golden/pnp_tracker.npz
+    from golden.make_golden_cases import PNP_CASES, pnp_case
+    from libs.tracker.pnp_tracker import PnpTracker
+    pcfg = EasyDict({"kp_selection": {"rigid_flow_kp": {"enable": False}}, "depth": {"max_depth": 50.0, "min_depth": 0.0},
+                     "pnp_tracker": {"ransac": {"iter": 100, "reproj_thre": 1.0, "repeat": 5}}, "image": {"height": 376, "width": 1241}})
+    for tag, (seed, n, of, noise, it, cop) in PNP_CASES.items():
+        c = pnp_case(seed, n, of, noise, cop)
+        K = c["K"]
+        np.random.seed(4869 + seed)
+        res = PnpTracker(pcfg, Intrinsics([K[0, 2], K[1, 2], K[0, 0], K[1, 1]])).compute_pose_3d2d(c["kp1"], c["kp2"], c["depth_1"], it)
+        st = np.random.get_state()
+        out["pnp_" + tag + "_pose"], out["pnp_" + tag + "_kp1"] = res["pose"].pose.copy(), res["kp1"]
+        out["pnp_" + tag + "_rng_after"] = np.r_[st[1].astype(np.uint32), np.uint32(st[2])]
     np.savez(dst, **out)
 
 

@@ -197,3 +197,8 @@ def test_reference_e_tracker_under_the_older_libraries_reproduces_the_fixture(tm
         assert np.array_equal(g[tag + "_inliers"], o[tag + "_inliers"]), tag
         assert np.array_equal(g[tag + "_rng_after"], o[tag + "_rng_after"]), tag
         assert abs(float(g[tag + "_scale"]) - float(o[tag + "_scale"])) <= 1e-12 * abs(float(g[tag + "_scale"])), tag
+    gp = np.load(os.path.join(HERE, "golden", "pnp_tracker.npz"))  # the reference's PnpTracker under the same environment
+    for tag in "abcde":
+        assert np.array_equal(gp[tag + "_kp1"], o["pnp_" + tag + "_kp1"]), tag
+        assert np.array_equal(gp[tag + "_rng_after"], o["pnp_" + tag + "_rng_after"]), tag
+        assert np.abs(gp[tag + "_pose"] - o["pnp_" + tag + "_pose"]).max() <= 1e-12, tag  # (np.linalg.inv of the final inversion: two LAPACKs)

@@ -194,3 +194,21 @@ def test_bestN_flow_kp_matches_reference_fixture():
         diff, flow = bestn_case(h, w, seed, frac, hard)
         kp1, kp2 = T.bestN_flow_kp(flow, diff, N)
         assert np.array_equal(kp1, g[tag + "_kp1"]) and np.array_equal(kp2, g[tag + "_kp2"]), tag
+
+
+def test_compute_pose_3d2d_matches_reference_fixture():
+    """oracle/tracker_np.compute_pose_3d2d (the expected value of the device's PnP path) against the reference's own
+    PnpTracker.compute_pose_3d2d run over the oracle cv2 (tests/golden/pnp_tracker.npz): surviving keypoints, pose after the
+    final inversion and the RandomState after the shuffles bit for bit -- 5 repeats (is_iterative) and 3, few points, four
+    points (no solve: identity, the shuffles still drawn), a coplanar object"""
+    from golden.make_golden import PNP_CASES, pnp_case
+    g = np.load(os.path.join(G, "pnp_tracker.npz"))
+    for tag, (seed, n, of, noise, it, cop) in PNP_CASES.items():
+        c = pnp_case(seed, n, of, noise, cop)
+        np.random.seed(4869 + seed)
+        res = T.compute_pose_3d2d(c["kp1"], c["kp2"], c["depth_1"], c["K"], min_depth=0.0, max_depth=50.0,
+                                  repeat=5 if it else 3, iters=100, reproj_thre=1.0)
+        assert np.array_equal(res["kp1"], g[tag + "_kp1"]) and np.array_equal(res["kp2"], g[tag + "_kp2"]), tag
+        assert np.array_equal(res["pose"], g[tag + "_pose"]), (tag, np.abs(res["pose"] - g[tag + "_pose"]).max())
+        st = np.random.get_state()
+        assert np.array_equal(np.r_[st[1].astype(np.uint32), np.uint32(st[2])], g[tag + "_rng_after"]), tag
