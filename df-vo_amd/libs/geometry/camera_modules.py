@@ -50,7 +50,14 @@ class Intrinsics:
     def inv_mat(self):
         return np.linalg.inv(self._mat)
 
-    fx = property(lambda self: self._mat[0, 0])
-    fy = property(lambda self: self._mat[1, 1])
-    cx = property(lambda self: self._mat[0, 2])
-    cy = property(lambda self: self._mat[1, 2])
+    @inv_mat.setter
+    def inv_mat(self, v):
+        self._mat = np.linalg.inv(v)
+
+    @staticmethod
+    def _entry(r, c):  # a focal length / principal point component: reads and writes one entry of the matrix in place
+        return property(lambda self: self._mat[r, c], lambda self, v: self._mat.__setitem__((r, c), v))
+
+
+Intrinsics.fx, Intrinsics.fy = Intrinsics._entry(0, 0), Intrinsics._entry(1, 1)
+Intrinsics.cx, Intrinsics.cy = Intrinsics._entry(0, 2), Intrinsics._entry(1, 2)
