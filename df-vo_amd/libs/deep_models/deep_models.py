@@ -65,6 +65,9 @@ class DeepModel:
         the net; only the raw frame crosses PCIe"""
         return self.depth.inference_depth_image_u8(np.ascontiguousarray(imgs[0]))
 
+    def initialize_deep_pose_model(self):
+        raise NotImplementedError("deep_pose is 'Experiment Ver. only' in the reference; out of scope")
+
     def forward_pose(self, imgs):
         raise NotImplementedError("deep_pose is 'Experiment Ver. only' in the reference; out of scope")
 

@@ -78,7 +78,21 @@ class Monodepth2DepthNet:
         d = self.inference_depth_u8(np.ascontiguousarray(u.astype(np.uint8)))
         out = torch.from_numpy(d)[None, None]
         self.pred_depths = {0: out / self.stereo_baseline_multiplier}
+        self.pred_disps = {0: 1.0 / self.pred_depths[0]}
         return out
+
+    def inference(self, img):
+        """monodepth2.py:91-122: {'depth': {0: [1,1,h,w]}, 'disp': {0: [1,1,h,w]}} at the input size, depth WITHOUT the stereo
+        baseline multiplier (monodepth2's 0.1-unit baseline), disp = the scaled disparity min_disp + (max_disp - min_disp) sigma.
+        The device net returns the multiplied depth (what DF-VO consumes, inference_depth); both entries are derived from it
+        on the host: depth = that / multiplier, disp = 1 / depth -- equal to the reference's tensors to float32 rounding, not bit
+        for bit (the reference forms the disparity first and inverts it)."""
+        self.inference_depth(img)
+        return {'depth': dict(self.pred_depths), 'disp': dict(self.pred_disps)}
+
+    def inference_no_grad(self, img):
+        """deep_depth.py:74-85"""
+        return self.inference(img)
 
     def setup_train(self, deep_model, cfg):
         raise NotImplementedError("online finetuning is out of scope of the inference hot path")

@@ -23,6 +23,10 @@ class KeypointSampler:
         if ks.depth_consistency.enable:
             raise NotImplementedError("depth_consistency is experiment-only in the reference (out of scope)")
 
+    def get_feat_track_methods(self, method_idx):
+        """keypoint_sampler.py:38-50: the one feature-tracking method of the release"""
+        return {1: "deep_flow"}[method_idx]
+
     def generate_kp_samples(self, img_h, img_w, crop, N):
         """keypoint_sampler.py:51-74"""
         y0, y1 = int(crop[0][0] * img_h), int(crop[0][1] * img_h)
