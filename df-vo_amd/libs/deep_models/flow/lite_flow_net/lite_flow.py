@@ -33,6 +33,49 @@ class LiteFlow:
         capi.check(capi.lib().dfvo_flow_target_size(int(h), int(w), C.byref(th), C.byref(tw)))
         return th.value, tw.value
 
+    def resize_dense_flow(self, flow, des_height, des_width):
+        """deep_flow.py:107-129: [N,2,H,W] flow tensor -> [N,2,H',W'], bilinear with aligned corners (dfvo_resize_bilinear on the
+        device), x / y components scaled by the width / height ratio"""
+        n, c, h, w = flow.shape
+        assert c == 2
+        capi.require_gpu()
+        x = torch.zeros((n, h, w, 4), dtype=torch.float32, device="cuda")
+        x[..., :2] = flow.detach().float().permute(0, 2, 3, 1)
+        out = torch.empty((n, int(des_height), int(des_width), 4), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        capi.check(capi.lib().dfvo_resize_bilinear(C.c_void_p(x.data_ptr()), n, h, w, 4, C.c_void_p(out.data_ptr()),
+                                                   int(des_height), int(des_width), 1, None))
+        capi.check(capi.lib().dfvo_sync_device())
+        res = out[..., :2].permute(0, 3, 1, 2).cpu()
+        return torch.stack([res[:, 0] * float(des_width / w), res[:, 1] * float(des_height / h)], dim=1)
+
+    def forward_backward_consistency(self, flow1, flow2, px1on2):
+        """deep_flow.py:171-196: |flow1 - grid_sample(-flow2, px1on2)| -> [N,H,W,1].  Inside inference_flow the library
+        computes this map itself (k_flow_consistency); this stand-alone form samples through dfvo_backward_warp: the
+        normalised grid is handed over as a displacement from a zero base grid, so the sample positions agree with torch's
+        to one rounding of the grid coordinate, not bit for bit."""
+        n, c, h, w = flow2.shape
+        assert c == 2 and tuple(px1on2.shape) == (n, h, w, 2)
+        capi.require_gpu()
+        src = torch.zeros((n, h, w, 4), dtype=torch.float32, device="cuda")
+        src[..., :2] = (-flow2.detach().float()).permute(0, 2, 3, 1)
+        disp = px1on2.detach().float().clone()
+        disp[..., 0] *= (w - 1.0) / 2.0
+        disp[..., 1] *= (h - 1.0) / 2.0
+        disp = disp.contiguous().cuda()
+        dst = torch.empty_like(src)
+        zx, zy = np.zeros(w, np.float32), np.zeros(h, np.float32)
+        torch.cuda.synchronize()
+        capi.check(capi.lib().dfvo_backward_warp(C.c_void_p(src.data_ptr()), C.c_void_p(disp.data_ptr()), 1.0, n, h, w, 4,
+                                                 capi.as_ptr(zx), capi.as_ptr(zy), C.c_void_p(dst.data_ptr()), None))
+        capi.check(capi.lib().dfvo_sync_device())
+        warp = dst[..., :2].permute(0, 3, 1, 2).cpu()
+        return (flow1.detach().float().cpu() - warp).norm(dim=1, keepdim=True).permute(0, 2, 3, 1)
+
+    def load_flow_file(self, flow_path):
+        raise NotImplementedError("pre-computed flow files are a dataset-loader path of the reference (deep_flow.py:131-155); "
+                                  "out of scope of the tracking hot path")
+
     def initialize_network_model(self, weight_path, finetune):
         """lite_flow.py:32-53: `weight_path` is a torch state_dict file, or an in-memory state_dict"""
         if finetune:

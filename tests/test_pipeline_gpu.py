@@ -124,6 +124,16 @@ def test_pipeline_nets_equal_standalone_executors(gpu, conv_precision, pipe_mod)
     assert torch.equal(md.pred_depths[0], outs["depth"][0]) and torch.equal(md.pred_disps[0], outs["disp"][0])
     o_depth = O.depth_inference(dsd, feed)  # (the oracle's depth is the multiplied one too)
     assert np.abs(outs["depth"][0][0, 0].numpy() * 5.4 - o_depth).max() <= 1e-3 * np.abs(o_depth).max()
+    # DeepFlow helpers of the flow mirror (deep_flow.py:107-129,171-196) on the device, against the torch restatements
+    g = torch.Generator().manual_seed(3)
+    fl1, fl2 = torch.randn(2, 2, 24, 40, generator=g) * 3, torch.randn(2, 2, 24, 40, generator=g) * 3
+    got, want_t = lf.resize_dense_flow(fl1, 37, 53), O.resize_dense_flow(fl1, 37, 53)
+    assert got.shape == want_t.shape and (got - want_t).abs().max() <= 1e-5 * want_t.abs().max()
+    px = O.flow_to_pix(fl1)
+    got, want_t = lf.forward_backward_consistency(fl1, fl2, px), O.forward_backward_consistency(fl1, fl2, px)
+    assert got.shape == want_t.shape == (2, 24, 40, 1) and (got - want_t).abs().max() <= 1e-4 * max(1.0, float(want_t.abs().max()))
+    with pytest.raises(NotImplementedError):
+        lf.load_flow_file("x.npy")
     ks = importlib.import_module("df-vo_amd.libs.matching.keypoint_sampler").KeypointSampler
     assert ks.get_feat_track_methods(None, 1) == "deep_flow"
 
