@@ -92,6 +92,22 @@ def main(ref, root, dst):
         out[tag + "_scale"] = np.array(float(scale))
         st = np.random.get_state()
         out[tag + "_rng_after"] = np.r_[st[1].astype(np.uint32), np.uint32(st[2])]
+    # e_tracker.validity.method 'flow' (ablation_model_sel_flow.yml): the cases of tests/golden/e_tracker_flow.npz
+    import copy
+    cfg_f = copy.deepcopy(cfg)
+    cfg_f.e_tracker.validity = EasyDict({"method": "flow", "thre": 5})
+    for tag, (seed, n, of, noise, shrink) in {"a": (51, 2000, 0.3, 0.15, 1.0), "b": (52, 1200, 0.6, 0.3, 1.0),
+                                              "c": (53, 2000, 0.2, 0.1, 0.02), "d": (54, 2000, 0.97, 0.2, 1.0)}.items():
+        c = tracker_case(seed, n, of, noise)
+        kp_ref = c["kp_ref"]
+        kp_cur = kp_ref + (c["kp_cur"] - kp_ref) * shrink
+        K = c["K"]
+        trk = EssTracker(cfg_f, Intrinsics([K[0, 2], K[1, 2], K[0, 0], K[1, 1]]), Timer())
+        np.random.seed(4869 + seed)
+        res = trk.compute_pose_2d2d(kp_ref, kp_cur, True)
+        st = np.random.get_state()
+        out["flow_" + tag + "_pose"], out["flow_" + tag + "_inliers"] = res["pose"].pose.copy(), res["inliers"].copy()
+        out["flow_" + tag + "_rng_after"] = np.r_[st[1].astype(np.uint32), np.uint32(st[2])]
     # PnpTracker.compute_pose_3d2d (pnp_tracker.py:45-125) on the cases of tests/golden/pnp_tracker.npz
     from golden.make_golden_cases import PNP_CASES, pnp_case
     from libs.tracker.pnp_tracker import PnpTracker

@@ -197,6 +197,10 @@ def test_reference_e_tracker_under_the_older_libraries_reproduces_the_fixture(tm
         assert np.array_equal(g[tag + "_inliers"], o[tag + "_inliers"]), tag
         assert np.array_equal(g[tag + "_rng_after"], o[tag + "_rng_after"]), tag
         assert abs(float(g[tag + "_scale"]) - float(o[tag + "_scale"])) <= 1e-12 * abs(float(g[tag + "_scale"])), tag
+    gf = np.load(os.path.join(HERE, "golden", "e_tracker_flow.npz"))  # validity.method 'flow' (mean-displacement gate)
+    for tag in "abcd":
+        for k in ("_pose", "_inliers", "_rng_after"):
+            assert np.array_equal(gf[tag + k], o["flow_" + tag + k]), (tag, k)
     gp = np.load(os.path.join(HERE, "golden", "pnp_tracker.npz"))  # the reference's PnpTracker under the same environment
     for tag in "abcde":
         assert np.array_equal(gp[tag + "_kp1"], o["pnp_" + tag + "_kp1"]), tag
