@@ -54,18 +54,9 @@ def main(ref, root, dst):
     from libs.tracker.E_tracker import EssTracker
     from libs.general.timer import Timer
     from libs.geometry.camera_modules import Intrinsics
-    from synth import two_view
     import sklearn
 
-    def tracker_case(seed, n, out_frac, noise, h=376, w=1241):  # tests/golden/make_golden.py:tracker_case
-        x1, x2, R, t, K, o = two_view(n, out_frac, noise, seed, w=w, h=h)
-        rng = np.random.Generator(np.random.PCG64(seed + 77))
-        depth = np.zeros((h, w))
-        zs = rng.uniform(5, 60, n)
-        ix, iy = x2[:, 0].astype(int), x2[:, 1].astype(int)
-        ok = (ix >= 0) & (ix < w) & (iy >= 0) & (iy < h)
-        depth[iy[ok], ix[ok]] = zs[ok]
-        return dict(kp_ref=x1, kp_cur=x2, K=K, depth_cur=depth)
+    from golden.make_golden_cases import PNP_CASES, pnp_case, tracker_case, variant_case
 
     cfg = EasyDict({
         "kp_selection": {"rigid_flow_kp": {"enable": False}},
@@ -108,8 +99,25 @@ def main(ref, root, dst):
         st = np.random.get_state()
         out["flow_" + tag + "_pose"], out["flow_" + tag + "_inliers"] = res["pose"].pose.copy(), res["inliers"].copy()
         out["flow_" + tag + "_rng_after"] = np.r_[st[1].astype(np.uint32), np.uint32(st[2])]
+    # validity.method 'homo_ratio' + scale_recovery.ransac.method 'abs_diff': the cases of tests/golden/e_tracker_variants.npz
+    cfg_v = copy.deepcopy(cfg)
+    cfg_v.e_tracker.validity = EasyDict({"method": "homo_ratio", "thre": 0.4})
+    cfg_v.scale_recovery.ransac.method = "abs_diff"
+    for tag in "abpd":
+        c = variant_case(tag)
+        K = c["K"]
+        trk = EssTracker(cfg_v, Intrinsics([K[0, 2], K[1, 2], K[0, 0], K[1, 1]]), Timer())
+        np.random.seed(4869 + c["seed"])
+        res = trk.compute_pose_2d2d(c["kp_ref"], c["kp_cur"], True)
+        pose = res["pose"]
+        scale = -2.0
+        if np.linalg.norm(pose.t) != 0:
+            scale = trk.scale_recovery({"kp_best": c["kp_cur"], "depth": c["depth_cur"]}, {"kp_best": c["kp_ref"]}, pose, False)["scale"]
+        st = np.random.get_state()
+        out["var_" + tag + "_pose"], out["var_" + tag + "_inliers"] = pose.pose.copy(), res["inliers"].copy()
+        out["var_" + tag + "_scale"] = np.array(float(scale))
+        out["var_" + tag + "_rng_after"] = np.r_[st[1].astype(np.uint32), np.uint32(st[2])]
     # PnpTracker.compute_pose_3d2d (pnp_tracker.py:45-125) on the cases of tests/golden/pnp_tracker.npz
-    from golden.make_golden_cases import PNP_CASES, pnp_case
     from libs.tracker.pnp_tracker import PnpTracker
     pcfg = EasyDict({"kp_selection": {"rigid_flow_kp": {"enable": False}}, "depth": {"max_depth": 50.0, "min_depth": 0.0},
                      "pnp_tracker": {"ransac": {"iter": 100, "reproj_thre": 1.0, "repeat": 5}}, "image": {"height": 376, "width": 1241}})

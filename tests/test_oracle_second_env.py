@@ -201,6 +201,12 @@ def test_reference_e_tracker_under_the_older_libraries_reproduces_the_fixture(tm
     for tag in "abcd":
         for k in ("_pose", "_inliers", "_rng_after"):
             assert np.array_equal(gf[tag + k], o["flow_" + tag + k]), (tag, k)
+    gv = np.load(os.path.join(HERE, "golden", "e_tracker_variants.npz"))  # homo_ratio validity + abs_diff scale RANSAC
+    for tag in "abpd":
+        for k in ("_pose", "_inliers", "_rng_after"):
+            assert np.array_equal(gv[tag + k], o["var_" + tag + k]), (tag, k)
+        a, b = float(gv[tag + "_scale"]), float(o["var_" + tag + "_scale"])
+        assert abs(a - b) <= 1e-12 * max(1.0, abs(a)), (tag, a, b)
     gp = np.load(os.path.join(HERE, "golden", "pnp_tracker.npz"))  # the reference's PnpTracker under the same environment
     for tag in "abcde":
         assert np.array_equal(gp[tag + "_kp1"], o["pnp_" + tag + "_kp1"]), tag
