@@ -117,6 +117,24 @@ def main(ref, root, dst):
         out["var_" + tag + "_pose"], out["var_" + tag + "_inliers"] = pose.pose.copy(), res["inliers"].copy()
         out["var_" + tag + "_scale"] = np.array(float(scale))
         out["var_" + tag + "_rng_after"] = np.r_[st[1].astype(np.uint32), np.uint32(st[2])]
+    # KeypointSampler.generate_kp_samples + sampled_kp (ablation_correspondences_uniform.yml): the cases of sampled_kp.npz
+    import libs.matching.kp_selection as kps
+    import libs.matching.keypoint_sampler as sampler
+    for tag, (h, w, seed, crop, nkp) in {"a": (192, 640, 41, [[0, 1], [0, 1]], 2000), "b": (376, 1241, 42, [[0.1, 0.9], [0.05, 0.95]], 2000),
+                                          "c": (61, 83, 43, [[0.3, 1], [0, 0.7]], 37)}.items():
+        rng = np.random.Generator(np.random.PCG64(int(seed)))  # make_golden.py:kp_case(h, w, seed, 0.5), its flow output
+        rng.random((h, w, 1), dtype=np.float32)
+        rng.random((h, w, 1))
+        flow = (rng.standard_normal((2, h, w)) * 3).astype(np.float32)
+        cfg_s = EasyDict({"kp_selection": {"sampled_kp": {"enable": True, "num_kp": nkp}, "local_bestN": {"enable": False}, "bestN": {"enable": False}},
+                          "crop": {"flow_crop": crop}, "image": {"height": h, "width": w}})
+        ks = sampler.KeypointSampler(cfg_s)
+        xv, yv = np.meshgrid(np.linspace(0, w - 1, w), np.linspace(0, h - 1, h))
+        kp1 = np.expand_dims(np.transpose(np.stack([xv, yv]), (1, 2, 0)), 0)
+        kp2 = kp1 + np.transpose(np.expand_dims(flow, 0), (0, 2, 3, 1))
+        res = kps.sampled_kp(kp1=kp1, kp2=kp2, ref_data={"depth": np.zeros((h, w))}, kp_list=ks.kps["uniform"], cfg=cfg_s, outputs={})
+        out["smp_" + tag + "_idx"] = np.asarray(ks.kps["uniform"], np.int64)
+        out["smp_" + tag + "_kp1"], out["smp_" + tag + "_kp2"] = res["kp1_list"], res["kp2_list"]
     # PnpTracker.compute_pose_3d2d (pnp_tracker.py:45-125) on the cases of tests/golden/pnp_tracker.npz
     from libs.tracker.pnp_tracker import PnpTracker
     pcfg = EasyDict({"kp_selection": {"rigid_flow_kp": {"enable": False}}, "depth": {"max_depth": 50.0, "min_depth": 0.0},

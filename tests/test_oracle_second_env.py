@@ -207,6 +207,10 @@ def test_reference_e_tracker_under_the_older_libraries_reproduces_the_fixture(tm
             assert np.array_equal(gv[tag + k], o["var_" + tag + k]), (tag, k)
         a, b = float(gv[tag + "_scale"]), float(o["var_" + tag + "_scale"])
         assert abs(a - b) <= 1e-12 * max(1.0, abs(a)), (tag, a, b)
+    gs = np.load(os.path.join(HERE, "golden", "sampled_kp.npz"))  # KeypointSampler.generate_kp_samples + sampled_kp
+    for tag in "abc":
+        for k in ("_idx", "_kp1", "_kp2"):
+            assert np.array_equal(gs[tag + k], o["smp_" + tag + k]), (tag, k)
     gp = np.load(os.path.join(HERE, "golden", "pnp_tracker.npz"))  # the reference's PnpTracker under the same environment
     for tag in "abcde":
         assert np.array_equal(gp[tag + "_kp1"], o["pnp_" + tag + "_kp1"]), tag
