@@ -55,7 +55,7 @@ def kernel_source_digest():
     import hashlib
     h = hashlib.sha1()
     for f in ("conv_igemm_f32.hip", "conv_win_f16s.h", "conv_win_f16s2.h", "conv_gemm_f16s.h", "conv_epi.h", "conv_f16_split.h",
-              "conv_win_f16s3.hip", "conv_taps_f16s.hip", "conv_gemm_f32g.hip"):
+              "conv_taps_f16s.hip", "conv_gemm_f32g.hip"):
         try:
             h.update(open(os.path.join(ROOT, "df-vo_amd", "csrc", f), "rb").read())
         except OSError:
@@ -341,7 +341,7 @@ def run_mirrors(args, syn, capi, h_frames, K, fsd, dsd, code_mode):
                   "kp selection + E/H RANSAC + scale)",
         "value": round(args.steps / dt, 3), "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.conv_precision == "fp32" else "f32 (%s split products)" % args.conv_precision, "data": "synthetic",
+        "dtype": {"fp32": "f32", "f16x3": "f32 (f16x3 split products)", "f16": "f16 (one product per term, fp32 accumulate)"}[args.conv_precision], "data": "synthetic",
         "config": {"workload": "%dx%d frame pairs (flow net %dx%d batch 2; depth net 192x640) through the drop-in class surface: "
                                "DeepModel.forward_depth / forward_flow, KeypointSampler.kp_selection, EssTracker.compute_pose_2d2d / "
                                "scale_recovery, PnpTracker.compute_pose_3d2d built from weight files; host numpy arrays in and out of "
@@ -436,10 +436,11 @@ def main(argv=None):
     ap.add_argument("--width", type=int, default=1241)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--conv-precision", default=os.environ.get("DFVO_CONV_PRECISION", "f16x3"), choices=["fp32", "f16x3"],
-                    help="arithmetic of the 3x3 window layers: f16x3 (default: fp32-class split kernel, the whole -m gpu net / "
+    ap.add_argument("--conv-precision", default=os.environ.get("DFVO_CONV_PRECISION", "f16x3"), choices=["fp32", "f16x3", "f16"],
+                    help="arithmetic of the conv layers: f16x3 (default: fp32-class split kernels, the whole -m gpu net / "
                          "pipeline parity suite runs green on it at the exact path's tolerances), fp32 (exact fp32 MFMA), "
-                         "-- reported in dtype and config.conv_precision")
+                         "f16 (one f16 product per term, fp32 accumulate: BASELINE config 5's 'fp16 flow' -- NOT fp32-class, "
+                         "reported under its own dtype) -- reported in dtype and config.conv_precision")
     ap.add_argument("--solver-inputs", default="nets", choices=["nets", "synthetic"],
                     help="nets: the solver stage consumes the nets' own outputs (coded-world frames, the product data path); "
                          "synthetic: random-weight nets + a synthetic rigid-scene flow/consistency/depth triple (round-1 mode)")
@@ -719,8 +720,8 @@ def main(argv=None):
         fam = fl.sum() / (ms.sum() * 1e-3) / 1e12
         # exact fp32: the fp32-MFMA peak.  f16x3: three f16 products per fp32 product, so the ceiling for USEFUL
         # fp32-equivalent FLOPs is the dense f16 peak divided by three
-        terms = {"fp32": 0, "f16x3": 3}[args.conv_precision]
-        if terms and dom < 19 and args.conv_precision == "f16x3":
+        terms = {"fp32": 0, "f16x3": 3, "f16": 1}[args.conv_precision]
+        if terms and dom < 19:
             terms = 0  # a kernel of the exact fp32 family dominates although the window layers run split: price it as fp32
         peak = PEAK_F32_MFMA_TFLOPS if not terms else PEAK_F16_MFMA_TFLOPS / terms
         roof = {"bound": "mfma", "kernel": CFG_NAMES[dom],
@@ -811,7 +812,9 @@ def main(argv=None):
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": {"fp32": "f32", "f16x3": "f32 (f16x3 split products: two f16 planes per operand = 22 mantissa bits, three exact "
-                                                "products per term, fp32 accumulate; direct one- / two-channel heads exact fp32)"
+                                                "products per term, fp32 accumulate; direct one- / two-channel heads exact fp32)",
+                      "f16": "f16 (operands rounded to f16, ONE product per term on v_mfma_f32_32x32x16_f16, fp32 accumulate and fp32 "
+                             "activations between layers; direct one- / two-channel heads exact fp32) -- not fp32-class"
                       }[args.conv_precision],
             "data": "synthetic",
             "config": {"workload": "%dx%d frame pairs%s (flow net %dx%d batch 2; device LANCZOS resize + depth net 192x640), "

@@ -1,4 +1,4 @@
-// Epilogue helpers shared by every convolution kernel of the library (conv_igemm_f32.hip and conv_win_f16s3.hip):
+// Epilogue helpers shared by every convolution kernel of the library (conv_igemm_f32.hip, conv_taps_f16s.hip, conv_gemm_f32g.hip):
 // bias + residual + activation + store of accumulator quads.  See conv_igemm_f32.hip for the accumulator layout.
 #pragma once
 // (included inside namespace dfvo)

@@ -23,3 +23,11 @@ __device__ __forceinline__ void split_f16_planes(f32x4 x, h16x4* hi, h16x4* lo, 
     }
 }
 
+// "f16" mode (DFVO_CONV_PRECISION=f16: one product per term, BASELINE config 5's "fp16 flow"): the hi plane alone
+__device__ __forceinline__ void split_f16_hi(f32x4 x, h16x4* hi, float& amax) {
+    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(x[0]), "v"(x[1]));
+    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(x[2]), "v"(x[3]));
+#pragma unroll
+    for (int e = 0; e < 4; ++e) (*hi)[e] = (_Float16)x[e];
+}
+

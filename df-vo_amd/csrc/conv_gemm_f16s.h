@@ -32,7 +32,8 @@ typedef __attribute__((address_space(4))) const u32x4 cu32x4;
 // layers).  The shared epilogue sends such a wave through conv_epilogue_quad quad by quad -- a bias load, a wait, a store,
 // and since stores count on vmcnt every wait drains the stores before it: 8-16 serialised round trips per wave, which is
 // most of those layers' launch time.  The RAG instantiation loads every quad's bias first and then only stores.
-template <int WP, int KSP, int TC, int PF = 3, bool RAG = false>  // PF: register ring, loads of step s + PF are issued when step s has been consumed
+// NP: products per term (3 = f16x3; 1 = "f16" mode: hi planes only, no cross set)
+template <int WP, int KSP, int TC, int PF = 3, bool RAG = false, int NP = 3>  // PF: register ring, loads of step s + PF are issued when step s has been consumed
 __global__ __launch_bounds__(64 * WP * KSP) void conv_gemm_f16s_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) float f16g_red[];  // [WP][KSP][TC][16][64] partial blocks (KSP > 1)
 
@@ -168,12 +169,12 @@ __global__ __launch_bounds__(64 * WP * KSP) void conv_gemm_f16s_kernel(const Con
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
             rw[st][i][0] = *reinterpret_cast<const h16x8*>(g + (size_t)i * 1024);
-            rw[st][i][1] = *reinterpret_cast<const h16x8*>(g + (size_t)i * 1024 + 512);
+            if constexpr (NP == 3) rw[st][i][1] = *reinterpret_cast<const h16x8*>(g + (size_t)i * 1024 + 512);
         }
         ++nl;
     };
 
-    f32x16 am[TC], ax[TC];
+    f32x16 am[TC], ax[TC];  // (ax stays zero in the NP == 1 instantiation: the combination below adds an exact 0)
 #pragma unroll
     for (int i = 0; i < TC; ++i)
 #pragma unroll
@@ -187,22 +188,29 @@ __global__ __launch_bounds__(64 * WP * KSP) void conv_gemm_f16s_kernel(const Con
 #pragma unroll
         for (int u = 0; u < PF; ++u) {
             if (s + u < s1) {
-                h16x4 h0, l0, h1, l1;
-                split_f16_planes(((rav >> (2 * u)) & 1u) ? ra[u][0] : f32x4{0.f, 0.f, 0.f, 0.f}, &h0, &l0, amax);
-                split_f16_planes(((rav >> (2 * u + 1)) & 1u) ? ra[u][1] : f32x4{0.f, 0.f, 0.f, 0.f}, &h1, &l1, amax);
+                h16x4 h0, l0 = {}, h1, l1 = {};
+                if constexpr (NP == 3) {
+                    split_f16_planes(((rav >> (2 * u)) & 1u) ? ra[u][0] : f32x4{0.f, 0.f, 0.f, 0.f}, &h0, &l0, amax);
+                    split_f16_planes(((rav >> (2 * u + 1)) & 1u) ? ra[u][1] : f32x4{0.f, 0.f, 0.f, 0.f}, &h1, &l1, amax);
+                } else {
+                    split_f16_hi(((rav >> (2 * u)) & 1u) ? ra[u][0] : f32x4{0.f, 0.f, 0.f, 0.f}, &h0, amax);
+                    split_f16_hi(((rav >> (2 * u + 1)) & 1u) ? ra[u][1] : f32x4{0.f, 0.f, 0.f, 0.f}, &h1, amax);
+                }
                 const h16x8 xh = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
                 const h16x8 xl = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
                 h16x8 wh[TC], wl[TC];
 #pragma unroll
                 for (int i = 0; i < TC; ++i) {
                     wh[i] = rw[u][i][0];
-                    wl[i] = rw[u][i][1];
+                    if constexpr (NP == 3) wl[i] = rw[u][i][1];
                 }
                 if (s + u + PF < s1) load_step(u);
+                if constexpr (NP == 3) {
 #pragma unroll
-                for (int i = 0; i < TC; ++i) ax[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i], xl, ax[i], 0, 0, 0);
+                    for (int i = 0; i < TC; ++i) ax[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i], xl, ax[i], 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < TC; ++i) ax[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[i], xh, ax[i], 0, 0, 0);
+                    for (int i = 0; i < TC; ++i) ax[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[i], xh, ax[i], 0, 0, 0);
+                }
 #pragma unroll
                 for (int i = 0; i < TC; ++i) am[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i], xh, am[i], 0, 0, 0);
             }
@@ -351,7 +359,9 @@ static int launch_f16g_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) 
     dim3 grid((unsigned)(((M + 32 * WP - 1) / (32 * WP)) * (p.wf16g_cout_pad / (32 * TC))), 1, 1);
     const size_t lds = (KSP > 1 ? (size_t)WP * KSP * TC * 16 * 64 * sizeof(float) : 0) + (size_t)p.f16g_steps * 32;  // + the delta table
     if (lds > 48 * 1024)
-        if (int rc_lds = ensure_dyn_lds((const void*)conv_gemm_f16s_kernel<WP, KSP, TC, PF, RAG>, lds)) return rc_lds;
+        if (int rc_lds = ensure_dyn_lds(p.f16_terms == 1 ? (const void*)conv_gemm_f16s_kernel<WP, KSP, TC, PF, RAG, 1>
+                                                         : (const void*)conv_gemm_f16s_kernel<WP, KSP, TC, PF, RAG, 3>, lds))
+            return rc_lds;
     ConvProfEntry pe;
     if (g_prof) {
         DFVO_HIP_CHECK(hipEventCreate(&pe.e0));
@@ -359,7 +369,10 @@ static int launch_f16g_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) 
         pe.cfg = cfg_id;
         DFVO_HIP_CHECK(hipEventRecord(pe.e0, stream));
     }
-    hipLaunchKernelGGL((conv_gemm_f16s_kernel<WP, KSP, TC, PF, RAG>), grid, dim3(64 * WP * KSP), lds, stream, p);
+    if (p.f16_terms == 1)
+        hipLaunchKernelGGL((conv_gemm_f16s_kernel<WP, KSP, TC, PF, RAG, 1>), grid, dim3(64 * WP * KSP), lds, stream, p);
+    else
+        hipLaunchKernelGGL((conv_gemm_f16s_kernel<WP, KSP, TC, PF, RAG, 3>), grid, dim3(64 * WP * KSP), lds, stream, p);
     DFVO_HIP_CHECK(hipGetLastError());
     if (g_prof) {
         DFVO_HIP_CHECK(hipEventRecord(pe.e1, stream));

@@ -28,7 +28,8 @@ typedef __attribute__((address_space(4))) const u32x4t cu32x4t;
 // TH output rows x 32 columns per workgroup, one wave per row; a wave contracts all TC cout blocks (32 couts each) of the layer.
 // (Measured alternatives, profiles/r4l_taps_ab.txt: two rows per wave with one cout block each -- half the weight
 // fetches per MFMA -- and a six-deep weight ring were both SLOWER per layer, 46 -> 58-62 us on the 7x7 layer.)
-template <int TH, int TC, int PF = 3>
+// NP: products per term (3 = f16x3; 1 = "f16" mode: hi planes only)
+template <int TH, int TC, int NP = 3, int PF = 3>
 __global__ __launch_bounds__(64 * TH) void conv_taps_f16s_kernel(const ConvParams p, int G, int pxd, int wcols, int wrows) {
     extern __shared__ __attribute__((aligned(16))) unsigned char taps_lds[];  // [wrows * wcols pixels][pxd bytes] | 16 zero bytes | [S][4] offsets
     constexpr int NT = 64 * TH;
@@ -64,10 +65,15 @@ __global__ __launch_bounds__(64 * TH) void conv_taps_f16s_kernel(const ConvParam
             f32x4 x = {0.f, 0.f, 0.f, 0.f};
             if (v) x = *reinterpret_cast<const f32x4*>(p.src0 + ((size_t)(n * p.H + iy) * p.W + ix) * p.cs0 + p.co0 + cg * 4);
             h16x4 hi, lo;
-            split_f16_planes(x, &hi, &lo, amax);
             unsigned char* d = taps_lds + (size_t)px * pxd + cg * 8;
-            *reinterpret_cast<h16x4*>(d) = hi;
-            *reinterpret_cast<h16x4*>(d + G * 8) = lo;
+            if constexpr (NP == 3) {
+                split_f16_planes(x, &hi, &lo, amax);
+                *reinterpret_cast<h16x4*>(d) = hi;
+                *reinterpret_cast<h16x4*>(d + G * 8) = lo;
+            } else {
+                split_f16_hi(x, &hi, amax);
+                *reinterpret_cast<h16x4*>(d) = hi;
+            }
             cg += dcg;
             int cpx = dpx;
             if (cg >= G) {
@@ -119,13 +125,13 @@ __global__ __launch_bounds__(64 * TH) void conv_taps_f16s_kernel(const ConvParam
             const int a_hi = o < 0 ? zoff : lane_base + o;
             const int a_lo = o < 0 ? zoff + 8 : lane_base + o + lo_off;
             rx[st][j][0] = *reinterpret_cast<const u32x2t*>(taps_lds + a_hi);
-            rx[st][j][1] = *reinterpret_cast<const u32x2t*>(taps_lds + a_lo);
+            if constexpr (NP == 3) rx[st][j][1] = *reinterpret_cast<const u32x2t*>(taps_lds + a_lo);
         }
         const unsigned short* g = wbase + (size_t)nl * w_step_stride;
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
             rw[st][i][0] = *reinterpret_cast<const h16x8*>(g + (size_t)i * 1024);
-            rw[st][i][1] = *reinterpret_cast<const h16x8*>(g + (size_t)i * 1024 + 512);
+            if constexpr (NP == 3) rw[st][i][1] = *reinterpret_cast<const h16x8*>(g + (size_t)i * 1024 + 512);
         }
         ++nl;
     };
@@ -142,19 +148,22 @@ __global__ __launch_bounds__(64 * TH) void conv_taps_f16s_kernel(const ConvParam
         for (int u = 0; u < PF; ++u) {
             if (s + u < S) {
                 const u32x4t hq = {rx[u][0][0][0], rx[u][0][0][1], rx[u][1][0][0], rx[u][1][0][1]};
-                const u32x4t lq = {rx[u][0][1][0], rx[u][0][1][1], rx[u][1][1][0], rx[u][1][1][1]};
+                u32x4t lq = {0u, 0u, 0u, 0u};
+                if constexpr (NP == 3) lq = u32x4t{rx[u][0][1][0], rx[u][0][1][1], rx[u][1][1][0], rx[u][1][1][1]};
                 const h16x8 xh = __builtin_bit_cast(h16x8, hq), xl = __builtin_bit_cast(h16x8, lq);
                 h16x8 wh[TC], wl[TC];
 #pragma unroll
                 for (int i = 0; i < TC; ++i) {
                     wh[i] = rw[u][i][0];
-                    wl[i] = rw[u][i][1];
+                    if constexpr (NP == 3) wl[i] = rw[u][i][1];
                 }
                 if (s + u + PF < S) load_step(u);
+                if constexpr (NP == 3) {
 #pragma unroll
-                for (int i = 0; i < TC; ++i) ax[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i], xl, ax[i], 0, 0, 0);
+                    for (int i = 0; i < TC; ++i) ax[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i], xl, ax[i], 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < TC; ++i) ax[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[i], xh, ax[i], 0, 0, 0);
+                    for (int i = 0; i < TC; ++i) ax[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[i], xh, ax[i], 0, 0, 0);
+                }
 #pragma unroll
                 for (int i = 0; i < TC; ++i) am[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[i], xh, am[i], 0, 0, 0);
             }
@@ -235,17 +244,27 @@ int launch_taps_f16s(const ConvParams& p, hipStream_t stream, int* grid_x) {
     DFVO_ARG_CHECK(taps_geom(p, &g), "conv_taps_f16s: window does not fit");
     const int tiles = p.N * ((p.Ho + g.th - 1) / g.th) * ((p.Wo + 31) / 32);
     const bool tc2 = p.wf16g_cout_pad == 64;
+#define DFVO_TAPS_LAUNCH(TH_, TC_)                                                                                          \
+    do {                                                                                                                   \
+        if (p.f16_terms == 1)                                                                                              \
+            hipLaunchKernelGGL((conv_taps_f16s_kernel<TH_, TC_, 1>), dim3(tiles), dim3(64 * TH_), g.lds, stream, p, g.G,    \
+                               g.pxd, g.wcols, g.wrows);                                                                   \
+        else                                                                                                               \
+            hipLaunchKernelGGL((conv_taps_f16s_kernel<TH_, TC_, 3>), dim3(tiles), dim3(64 * TH_), g.lds, stream, p, g.G,    \
+                               g.pxd, g.wcols, g.wrows);                                                                   \
+    } while (0)
     if (g.th == 4) {
         if (tc2)
-            hipLaunchKernelGGL((conv_taps_f16s_kernel<4, 2>), dim3(tiles), dim3(256), g.lds, stream, p, g.G, g.pxd, g.wcols, g.wrows);
+            DFVO_TAPS_LAUNCH(4, 2);
         else
-            hipLaunchKernelGGL((conv_taps_f16s_kernel<4, 1>), dim3(tiles), dim3(256), g.lds, stream, p, g.G, g.pxd, g.wcols, g.wrows);
+            DFVO_TAPS_LAUNCH(4, 1);
     } else {
         if (tc2)
-            hipLaunchKernelGGL((conv_taps_f16s_kernel<2, 2>), dim3(tiles), dim3(128), g.lds, stream, p, g.G, g.pxd, g.wcols, g.wrows);
+            DFVO_TAPS_LAUNCH(2, 2);
         else
-            hipLaunchKernelGGL((conv_taps_f16s_kernel<2, 1>), dim3(tiles), dim3(128), g.lds, stream, p, g.G, g.pxd, g.wcols, g.wrows);
+            DFVO_TAPS_LAUNCH(2, 1);
     }
+#undef DFVO_TAPS_LAUNCH
     DFVO_HIP_CHECK(hipGetLastError());
     if (grid_x) *grid_x = tiles;
     return DFVO_OK;

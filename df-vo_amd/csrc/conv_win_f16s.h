@@ -39,7 +39,7 @@ static unsigned* f16s_clamp_counter() {
     if (!ptr && hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(g_f16s_clamped)) != hipSuccess) ptr = nullptr;
     return ptr;
 }
-template <int WC, int WR, int TC, int TR>
+template <int WC, int WR, int TC, int TR, int NP = 3>  // NP: products per term (3 = f16x3, 1 = "f16" mode: hi planes only)
 __global__ __launch_bounds__(64 * WC * WR, 2) void conv_win_f16s_kernel(const ConvParams p) {
     constexpr int NT = 64 * WC * WR;  // 4 or 8 waves per workgroup
     constexpr int TH = WR * TR, TW = 32, WH = TH + 2, WW = TW + 2, PS = 20;  // pixel stride in dwords (80 bytes)
@@ -103,10 +103,15 @@ __global__ __launch_bounds__(64 * WC * WR, 2) void conv_win_f16s_kernel(const Co
         const int id = t + NT * r;
         if (id < W_ITEMS) {
             h16x4 hi, lo;
-            split_f16_planes(((rwv >> r) & 1u) ? rw[r] : f32x4{0.f, 0.f, 0.f, 0.f}, &hi, &lo, amax);
             float* dst = W + (id >> 2) * PS + (id & 3) * 2;  // hi plane: dwords [0, 8), lo plane: [8, 16) of the pixel
-            *reinterpret_cast<h16x4*>(dst) = hi;
-            *reinterpret_cast<h16x4*>(dst + 8) = lo;
+            if constexpr (NP == 3) {
+                split_f16_planes(((rwv >> r) & 1u) ? rw[r] : f32x4{0.f, 0.f, 0.f, 0.f}, &hi, &lo, amax);
+                *reinterpret_cast<h16x4*>(dst) = hi;
+                *reinterpret_cast<h16x4*>(dst + 8) = lo;
+            } else {
+                split_f16_hi(((rwv >> r) & 1u) ? rw[r] : f32x4{0.f, 0.f, 0.f, 0.f}, &hi, amax);
+                *reinterpret_cast<h16x4*>(dst) = hi;
+            }
         }
     };
     auto load_window = [&](int c) {
@@ -135,17 +140,20 @@ __global__ __launch_bounds__(64 * WC * WR, 2) void conv_win_f16s_kernel(const Co
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
             wa[stage][i][0] = *reinterpret_cast<const h16x8*>(g + (size_t)i * 32 * 32);
-            wa[stage][i][1] = *reinterpret_cast<const h16x8*>(g + (size_t)i * 32 * 32 + 512);
+            if constexpr (NP == 3) wa[stage][i][1] = *reinterpret_cast<const h16x8*>(g + (size_t)i * 32 * 32 + 512);
         }
     };
 
-    f32x16 am[TC][TR], ax[TC][TR];
+    f32x16 am[TC][TR], ax[NP == 3 ? TC : 1][NP == 3 ? TR : 1];
 #pragma unroll
     for (int i = 0; i < TC; ++i)
 #pragma unroll
         for (int j = 0; j < TR; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) am[i][j][e] = ax[i][j][e] = 0.f;
+            for (int e = 0; e < 16; ++e) {
+                am[i][j][e] = 0.f;
+                if constexpr (NP == 3) ax[i][j][e] = 0.f;
+            }
 
     load_window(0);
     load_w(0, 0, 0);
@@ -181,19 +189,21 @@ __global__ __launch_bounds__(64 * WC * WR, 2) void conv_win_f16s_kernel(const Co
             for (int j = 0; j < TR; ++j) {
                 const float* px = Wc + ((wr * TR + j + ky) * WW + (lp + kx)) * PS + kb * 4;
                 xb[j][0] = *reinterpret_cast<const h16x8*>(px);
-                xb[j][1] = *reinterpret_cast<const h16x8*>(px + 8);
+                if constexpr (NP == 3) xb[j][1] = *reinterpret_cast<const h16x8*>(px + 8);
             }
             // the three product terms block by block per term: consecutive MFMAs never target the same accumulator
+            if constexpr (NP == 3) {
 #pragma unroll
-            for (int i = 0; i < TC; ++i)
+                for (int i = 0; i < TC; ++i)
 #pragma unroll
-                for (int j = 0; j < TR; ++j)
-                    ax[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][i][0], xb[j][1], ax[i][j], 0, 0, 0);
+                    for (int j = 0; j < TR; ++j)
+                        ax[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][i][0], xb[j][1], ax[i][j], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < TC; ++i)
+                for (int i = 0; i < TC; ++i)
 #pragma unroll
-                for (int j = 0; j < TR; ++j)
-                    ax[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][i][1], xb[j][0], ax[i][j], 0, 0, 0);
+                    for (int j = 0; j < TR; ++j)
+                        ax[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][i][1], xb[j][0], ax[i][j], 0, 0, 0);
+            }
 #pragma unroll
             for (int i = 0; i < TC; ++i)
 #pragma unroll
@@ -209,7 +219,7 @@ __global__ __launch_bounds__(64 * WC * WR, 2) void conv_win_f16s_kernel(const Co
 #pragma unroll
             for (int i = 0; i < TC; ++i) {  // ... and move to stage 0, where tap 0 expects them (2 TC register-quad copies per chunk)
                 wa[0][i][0] = wa[1][i][0];
-                wa[0][i][1] = wa[1][i][1];
+                if constexpr (NP == 3) wa[0][i][1] = wa[1][i][1];
             }
         __syncthreads();
     }
@@ -228,7 +238,10 @@ __global__ __launch_bounds__(64 * WC * WR, 2) void conv_win_f16s_kernel(const Co
         conv_epi_row(p, epi, m, valid, [&](int q) {
             f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = am[q >> 2][j][4 * (q & 3) + e] + F16S_LO_UNSCALE * ax[q >> 2][j][4 * (q & 3) + e];
+            for (int e = 0; e < 4; ++e) {
+                v[e] = am[q >> 2][j][4 * (q & 3) + e];
+                if constexpr (NP == 3) v[e] += F16S_LO_UNSCALE * ax[q >> 2][j][4 * (q & 3) + e];
+            }
             return v;
         });
     }
@@ -265,7 +278,10 @@ static int launch_f16s_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) 
         pe.cfg = cfg_id;
         DFVO_HIP_CHECK(hipEventRecord(pe.e0, stream));
     }
-    hipLaunchKernelGGL((conv_win_f16s_kernel<WC, WR, TC, TR>), grid, dim3(64 * WC * WR), 0, stream, p);
+    if (p.f16_terms == 1)
+        hipLaunchKernelGGL((conv_win_f16s_kernel<WC, WR, TC, TR, 1>), grid, dim3(64 * WC * WR), 0, stream, p);
+    else
+        hipLaunchKernelGGL((conv_win_f16s_kernel<WC, WR, TC, TR, 3>), grid, dim3(64 * WC * WR), 0, stream, p);
     DFVO_HIP_CHECK(hipGetLastError());
     if (g_prof) {
         DFVO_HIP_CHECK(hipEventRecord(pe.e1, stream));

@@ -24,9 +24,12 @@ __device__ __forceinline__ void f16s2_static_for(F&& f) {  // f(integral_constan
     f16s2_static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-template <int WC, int WR, int TC, int TR>
+// NP: products per term -- 3 = f16x3 (hi x lo, lo x hi into the cross sums, hi x hi into the main sums), 1 = the "f16"
+// mode (hi x hi only: the lo planes are neither written to LDS nor loaded, the cross set does not exist)
+template <int WC, int WR, int TC, int TR, int NP = 3>
 __global__ __launch_bounds__(64 * WC * WR, 1) void conv_win_f16s2_kernel(const ConvParams p) {
     constexpr int NT = 64 * WC * WR;
+    constexpr int NPL = NP == 3 ? 2 : 1;  // operand planes in use
     constexpr int TH = WR * TR, TW = 32, WH = TH + 2, WW = TW + 2, PS = 20;  // pixel stride in dwords (80 bytes)
     constexpr int BN = WC * TC * 32;
     constexpr int WIN = (WH * WW + 1) * PS;  // + one pixel slot that absorbs the stores of the items beyond the window
@@ -106,10 +109,15 @@ __global__ __launch_bounds__(64 * WC * WR, 1) void conv_win_f16s2_kernel(const C
         const int id = t + NT * r;
         const int px = (id >> 2) < WH * WW ? (id >> 2) : WH * WW;  // (no branch: out-of-window items land in the spare slot)
         h16x4 hi, lo;
-        split_f16_planes(((rwv >> r) & 1u) ? rw[r] : f32x4{0.f, 0.f, 0.f, 0.f}, &hi, &lo, amax);
         float* dst = W + px * PS + wq * 2;
-        *reinterpret_cast<h16x4*>(dst) = hi;
-        *reinterpret_cast<h16x4*>(dst + 8) = lo;
+        if constexpr (NP == 3) {
+            split_f16_planes(((rwv >> r) & 1u) ? rw[r] : f32x4{0.f, 0.f, 0.f, 0.f}, &hi, &lo, amax);
+            *reinterpret_cast<h16x4*>(dst) = hi;
+            *reinterpret_cast<h16x4*>(dst + 8) = lo;
+        } else {
+            split_f16_hi(((rwv >> r) & 1u) ? rw[r] : f32x4{0.f, 0.f, 0.f, 0.f}, &hi, amax);
+            *reinterpret_cast<h16x4*>(dst) = hi;
+        }
     };
     const unsigned short* wbase = p.wf16 + ((size_t)(n0 + wc * TC * 32) * 32 + (kb * 32 + lp) * 8);
     const size_t w_chunk_stride = (size_t)p.wf16_cout_pad * 32;  // halves per (tap, chunk)
@@ -119,18 +127,18 @@ __global__ __launch_bounds__(64 * WC * WR, 1) void conv_win_f16s2_kernel(const C
 #pragma unroll
         for (int i = 0; i < TC; ++i) {
             wa[stage][i][0] = *reinterpret_cast<const h16x8*>(g + (size_t)i * 32 * 32);
-            wa[stage][i][1] = *reinterpret_cast<const h16x8*>(g + (size_t)i * 32 * 32 + 512);
+            if constexpr (NP == 3) wa[stage][i][1] = *reinterpret_cast<const h16x8*>(g + (size_t)i * 32 * 32 + 512);
         }
     };
-    auto load_w_piece = [&](int stage, int tap, int c, int piece) {  // piece = cout tile * 2 + plane
+    auto load_w_piece = [&](int stage, int tap, int c, int piece) {  // piece = cout tile * NPL + plane
         const unsigned short* g = wbase + ((size_t)tap * nchunks + c) * w_chunk_stride;
-        wa[stage][piece >> 1][piece & 1] = *reinterpret_cast<const h16x8*>(g + (size_t)(piece >> 1) * 32 * 32 + (piece & 1) * 512);
+        wa[stage][piece / NPL][piece % NPL] = *reinterpret_cast<const h16x8*>(g + (size_t)(piece / NPL) * 32 * 32 + (piece % NPL) * 512);
     };
     h16x8 xb[2][TR][2];
-    auto read_x_piece = [&](const float* Wc, int set, int tap, int piece) {  // piece = row tile * 2 + plane
-        const int ky = tap / 3, kx = tap - ky * 3, j = piece >> 1;
+    auto read_x_piece = [&](const float* Wc, int set, int tap, int piece) {  // piece = row tile * NPL + plane
+        const int ky = tap / 3, kx = tap - ky * 3, j = piece / NPL;
         const float* px = Wc + ((wr * TR + j + ky) * WW + (lp + kx)) * PS + kb * 4;
-        xb[set][j][piece & 1] = *reinterpret_cast<const h16x8*>(px + (piece & 1) * 8);
+        xb[set][j][piece % NPL] = *reinterpret_cast<const h16x8*>(px + (piece % NPL) * 8);
     };
     auto read_x = [&](const float* Wc, int set, int tap) {
         const int ky = tap / 3, kx = tap - ky * 3;
@@ -138,17 +146,20 @@ __global__ __launch_bounds__(64 * WC * WR, 1) void conv_win_f16s2_kernel(const C
         for (int j = 0; j < TR; ++j) {
             const float* px = Wc + ((wr * TR + j + ky) * WW + (lp + kx)) * PS + kb * 4;
             xb[set][j][0] = *reinterpret_cast<const h16x8*>(px);
-            xb[set][j][1] = *reinterpret_cast<const h16x8*>(px + 8);
+            if constexpr (NP == 3) xb[set][j][1] = *reinterpret_cast<const h16x8*>(px + 8);
         }
     };
 
-    f32x16 am[TC][TR], ax[TC][TR];
+    f32x16 am[TC][TR], ax[NP == 3 ? TC : 1][NP == 3 ? TR : 1];
 #pragma unroll
     for (int i = 0; i < TC; ++i)
 #pragma unroll
         for (int j = 0; j < TR; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) am[i][j][e] = ax[i][j][e] = 0.f;
+            for (int e = 0; e < 16; ++e) {
+                am[i][j][e] = 0.f;
+                if constexpr (NP == 3) ax[i][j][e] = 0.f;
+            }
 
     set_chunk(0);
 #pragma unroll
@@ -172,23 +183,27 @@ __global__ __launch_bounds__(64 * WC * WR, 1) void conv_win_f16s2_kernel(const C
             constexpr int tap = decltype(tap_c)::value;
             constexpr int cur = tap % 3, xs = tap & 1;
             constexpr int ST0 = 9 - W_CNT;
-            constexpr int NM = 3 * TC * TR, NR = tap < 8 ? 2 * TR : 0;
+            constexpr int NM = NP * TC * TR, NR = tap < 8 ? NPL * TR : 0;
             // MFMA k of the tap: product set g = k / (TC * TR) (0: hi x lo, 1: lo x hi -> cross sums, 2: hi x hi -> main sums)
             auto mfma = [&](int k) {
                 const int g = k / (TC * TR), i = (k % (TC * TR)) / TR, j = k % TR;
-                if (g == 0)
-                    ax[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][i][0], xb[xs][j][1], ax[i][j], 0, 0, 0);
-                else if (g == 1)
-                    ax[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][i][1], xb[xs][j][0], ax[i][j], 0, 0, 0);
-                else
+                if constexpr (NP == 3) {
+                    if (g == 0)
+                        ax[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][i][0], xb[xs][j][1], ax[i][j], 0, 0, 0);
+                    else if (g == 1)
+                        ax[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][i][1], xb[xs][j][0], ax[i][j], 0, 0, 0);
+                    else
+                        am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][i][0], xb[xs][j][0], am[i][j], 0, 0, 0);
+                } else {
                     am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wa[cur][i][0], xb[xs][j][0], am[i][j], 0, 0, 0);
+                }
             };
             // One request per MFMA, each fenced into that MFMA's shadow (the compiler hoists free-standing loads to the
             // top of the region whatever the group hints say): first the next tap's pixel fragments from LDS, then the
             // weight fragments of tap + 2 and one window item of the next chunk from global memory -- they are
             // consumed two taps / one chunk later -- so that nothing but the split of the window item is left between
             // the taps' MFMA groups.
-            constexpr int NV = 2 * TC + (tap < W_CNT ? 1 : 0);
+            constexpr int NV = NPL * TC + (tap < W_CNT ? 1 : 0);
             constexpr int NF = NR + NV < NM ? NR + NV : NM;  // fenced slots
             f16s2_static_for<NF>([&](auto k_c) {
                 constexpr int k = decltype(k_c)::value;
@@ -201,7 +216,7 @@ __global__ __launch_bounds__(64 * WC * WR, 1) void conv_win_f16s2_kernel(const C
                         read_x_piece(Wc, xs ^ 1, tap + 1, q);
                     } else if (q < NR + NV) {
                         const int v = q - NR;
-                        if (v < 2 * TC) {
+                        if (v < NPL * TC) {
                             if (tap < 7)
                                 load_w_piece((tap + 2) % 3, tap + 2, c, v);
                             else
@@ -239,7 +254,10 @@ __global__ __launch_bounds__(64 * WC * WR, 1) void conv_win_f16s2_kernel(const C
         conv_epi_row(p, epi, m, valid, [&](int q) {
             f32x4 v;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = am[q >> 2][j][4 * (q & 3) + e] + F16S_LO_UNSCALE * ax[q >> 2][j][4 * (q & 3) + e];
+            for (int e = 0; e < 4; ++e) {
+                v[e] = am[q >> 2][j][4 * (q & 3) + e];
+                if constexpr (NP == 3) v[e] += F16S_LO_UNSCALE * ax[q >> 2][j][4 * (q & 3) + e];
+            }
             return v;
         });
     }
@@ -264,7 +282,10 @@ static int launch_f16s2_cfg(const ConvParams& p, hipStream_t stream, int cfg_id)
         pe.cfg = cfg_id;
         DFVO_HIP_CHECK(hipEventRecord(pe.e0, stream));
     }
-    hipLaunchKernelGGL((conv_win_f16s2_kernel<WC, WR, TC, TR>), grid, dim3(64 * WC * WR), 0, stream, p);
+    if (p.f16_terms == 1)
+        hipLaunchKernelGGL((conv_win_f16s2_kernel<WC, WR, TC, TR, 1>), grid, dim3(64 * WC * WR), 0, stream, p);
+    else
+        hipLaunchKernelGGL((conv_win_f16s2_kernel<WC, WR, TC, TR, 3>), grid, dim3(64 * WC * WR), 0, stream, p);
     DFVO_HIP_CHECK(hipGetLastError());
     if (g_prof) {
         DFVO_HIP_CHECK(hipEventRecord(pe.e1, stream));
@@ -281,51 +302,10 @@ static int launch_f16s2_cfg(const ConvParams& p, hipStream_t stream, int cfg_id)
 // DFVO_ERR_* code is negative) when the layer should stay on the first
 // skeleton (small grids: fewer than ~200 workgroups cannot fill the chip at one workgroup per CU).
 constexpr int F16S2_NOT_APPLICABLE = 1;
-// third skeleton (conv_win_f16s3.hip, its own translation unit): the same tile loop, a run of p.tile_run tiles per workgroup
-int launch_f16s3_shape(const ConvParams& p, int shape, hipStream_t stream, int* grid_xy);
-bool f16s3_eligible(const ConvParams& p);
-// Run length of the third skeleton (DFVO_F16S_RUN: unset / 0 = second skeleton, N >= 1 = runs of N tiles, p = persistent:
-// one workgroup per CU walking ceil(tiles / 256) tiles, p<k> = the same on 256 - k CUs).  OFF by default -- measured
-// (profiles/r4c_*, r4g_*): the persistent form is 6-9 % faster one launch at a time (level-2 128 -> 128: 202 -> 188 us,
-// config-5 layer 1016 -> 929 us, roofline fraction 0.280 -> 0.296) and 5 % SLOWER in the pipeline (299 -> 283 pairs/s); runs
-// of two where they cost no extra round: -2 %.  A CU is handed back only when a workgroup ends, and the other streams of
-// the pipeline (the RandomState-ordered solver chain above all) wait for CUs; what a run saves per tile is ~3 us of 44.
-static int f16s3_run_for(int tiles) {
-    static const char* e = getenv("DFVO_F16S_RUN");
-    if (e && e[0] == 'p') {  // "p" / "p<reserve>": persistent on 256 - reserve CUs
-        const int cus = 256 - atoi(e + 1);
-        return (tiles + cus - 1) / cus;
-    }
-    return e ? atoi(e) : 0;
-}
-template <int WC, int WR, int TC, int TR>
-static int launch_f16s23(const ConvParams& p, hipStream_t stream, int cfg_id, int shape) {
-    constexpr int TH = WR * TR;
-    const int tiles = p.N * ((p.Ho + TH - 1) / TH) * ((p.Wo + 31) / 32);
-    const int run = f16s3_run_for(tiles);
-    if (run <= 0 || !f16s3_eligible(p)) return launch_f16s2_cfg<WC, WR, TC, TR>(p, stream, cfg_id);
-    ConvParams q = p;
-    q.tile_run = run;
-    q.f16s_clamp_ctr = f16s_clamp_counter();
-    ConvProfEntry pe;
-    if (g_prof) {
-        DFVO_HIP_CHECK(hipEventCreate(&pe.e0));
-        DFVO_HIP_CHECK(hipEventCreate(&pe.e1));
-        pe.cfg = cfg_id;
-        DFVO_HIP_CHECK(hipEventRecord(pe.e0, stream));
-    }
-    int gxy[2] = {0, 0};
-    const int rc = launch_f16s3_shape(q, shape, stream, gxy);
-    if (rc != DFVO_OK) return rc;
-    if (g_prof) {
-        DFVO_HIP_CHECK(hipEventRecord(pe.e1, stream));
-        pe.flops = p.useful_flops;
-        const int sh[12] = {p.N, p.H, p.W, p.Ho, p.Wo, (p.G0 + p.G1) * 4, p.cout, p.kh, p.stride, gxy[0], gxy[1], 3};
-        for (int i = 0; i < 12; ++i) pe.shape[i] = sh[i];
-        g_prof->push_back(pe);
-    }
-    return DFVO_OK;
-}
+// (Round 4 also built a third skeleton -- the same tile loop walking a run of tiles per workgroup, persistent at the limit.
+// One launch at a time it was 6-9 % faster, in the pipeline 5 % SLOWER (a CU is handed back only when a workgroup ends and
+// the solver chain's kernels wait for CUs); it stayed opt-in for a round and was removed in round 5.  Records:
+// profiles/r4c_tile_run_*.txt, r4g_tile_run_policy_ab.txt, r4h_persistent_reserve_ab.txt)
 static int launch_f16s2(const ConvParams& p, hipStream_t stream, int cfg_id) {
     // (per layer the two skeletons are within 2 % of each other; inside the pipeline this one gives +3 % pairs/s: half the
     // resident net waves next to the solver's kernels -- round 3)
@@ -336,17 +316,17 @@ static int launch_f16s2(const ConvParams& p, hipStream_t stream, int cfg_id) {
         const long long b3 = f16s2_blocks<2, 2, 2, 3>(p), b2 = f16s2_blocks<2, 2, 2, 2>(p);
         if (b2 < 200) return F16S2_NOT_APPLICABLE;
         const long long c3 = cost(b3, 6), c2 = cost(b2, 4) * 11 / 10;  // (small tiles: fewer MFMAs per load)
-        if (c3 <= c2) return launch_f16s23<2, 2, 2, 3>(p, stream, cfg_id, 0);
-        return launch_f16s23<2, 2, 2, 2>(p, stream, cfg_id, 1);
+        if (c3 <= c2) return launch_f16s2_cfg<2, 2, 2, 3>(p, stream, cfg_id);
+        return launch_f16s2_cfg<2, 2, 2, 2>(p, stream, cfg_id);
     }
     if (p.wf16_cout_pad % 64 == 0) {
         const long long b3 = f16s2_blocks<1, 4, 2, 3>(p), b2 = f16s2_blocks<1, 4, 2, 2>(p);
         if (b2 < 200) return F16S2_NOT_APPLICABLE;
-        if (cost(b3, 12) <= cost(b2, 8)) return launch_f16s23<1, 4, 2, 3>(p, stream, cfg_id, 2);
-        return launch_f16s23<1, 4, 2, 2>(p, stream, cfg_id, 3);
+        if (cost(b3, 12) <= cost(b2, 8)) return launch_f16s2_cfg<1, 4, 2, 3>(p, stream, cfg_id);
+        return launch_f16s2_cfg<1, 4, 2, 2>(p, stream, cfg_id);
     }
     const long long b3 = f16s2_blocks<1, 4, 1, 3>(p), b2 = f16s2_blocks<1, 4, 1, 2>(p);
     if (b2 < 200) return F16S2_NOT_APPLICABLE;
-    if (cost(b3, 12) <= cost(b2, 8)) return launch_f16s23<1, 4, 1, 3>(p, stream, cfg_id, 4);
-    return launch_f16s23<1, 4, 1, 2>(p, stream, cfg_id, 5);
+    if (cost(b3, 12) <= cost(b2, 8)) return launch_f16s2_cfg<1, 4, 1, 3>(p, stream, cfg_id);
+    return launch_f16s2_cfg<1, 4, 1, 2>(p, stream, cfg_id);
 }

@@ -67,6 +67,9 @@ struct ConvParams {
     int wf16g_cout_pad;
     const uint32_t* f16g_tab;
     int f16g_steps;
+    // products per term of the f16 kernels: 3 (or 0) = f16x3 (hi x hi + the two cross products, fp32-class), 1 = "f16" mode
+    // (hi x hi only: plain f16 operands, fp32 accumulate -- BASELINE config 5's "fp16 flow"; the lo planes are never read)
+    int f16_terms;
     // exact-fp32 twin of the above for conv_gemm_f32g_kernel (fp32 mode): [16-k step][cout_pad / 32][k / 8][32 couts][8]
     // floats, same k-group table and cout padding (wf16g_cout_pad, f16g_tab, f16g_steps are set in both modes)
     const float* wf32g;
@@ -91,9 +94,8 @@ struct ConvParams {
     double useful_flops;
     // launch overrides chosen by the per-layer autotuner (0 = heuristic): M tile rows, split-K factor
     int force_bm, force_splits;
-    // conv_win_f16s3 (tile-run window kernel, its own translation unit): consecutive tiles per workgroup, and the device
-    // counter of activations beyond f16's range (g_f16s_clamped of conv_win_f16s.h; device symbols do not cross TUs)
-    int tile_run;
+    // the device counter of activations beyond f16's range (g_f16s_clamped of conv_win_f16s.h) for the f16 kernels that
+    // live in their own translation units (conv_taps_f16s.hip: device symbols do not cross TUs)
     unsigned* f16s_clamp_ctr;
 };
 
@@ -133,7 +135,7 @@ static inline int conv_cout_pad(int cout, long long M) {
 // implement eval-mode BatchNorm folding: w' = w*scale, b' = b*scale + shift.
 // weights of a one- / two-channel k x k layer in the order the direct head kernel consumes them:
 // [8-channel chunk (source 0 first, each source rounded up)][kx][4-channel group of the chunk (2)][ky][cout][4]
-int conv_split_mode();  // 0 exact fp32 (default), 4 = f16x3 (f16 hi/lo planes, fp32-class)
+int conv_split_mode();  // 0 exact fp32 (default), 4 = f16x3 (f16 hi/lo planes, fp32-class), 5 = f16 (hi plane only: one product per term)
 // weights of a 3x3 layer as f16 hi / lo planes for conv_win_f16s_kernel; returns the number of halves written
 // (out may be null to query the size): [tap][chunk][cout_pad32][2][16], chunks = ceil(c0/16) + ceil(c1/16)
 size_t conv_pack_weights_f16s(const float* w_oihw, int cout, int c0, int c1, const float* fold_scale, unsigned short* out);

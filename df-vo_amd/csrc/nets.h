@@ -31,6 +31,7 @@ struct ConvLayer {
     uint32_t* gtab = nullptr;      // its k-group table
     float* wg32 = nullptr;         // fp32 weights in the same k-group order for conv_gemm_f32g_kernel (fp32 mode, every layer)
     int wg_cout_pad = 0, g_steps = 0;
+    int f16_terms = 3;             // 1: packed in "f16" mode (one product per term; the kernels never read the lo planes)
     float* wh = nullptr;  // head layout (cout <= 2, square 3/5/7 kernels), see conv_pack_head_weights
     int cout = 0, cout_pad = 0, c0 = 0, c1 = 0, kh = 0, kw = 0, ksteps = 0;
     int stride = 1, pad_h = 0, pad_w = 0, pad_mode = PAD_ZERO, act = ACT_NONE;
@@ -50,7 +51,7 @@ void free_conv(ConvLayer* l);
 // uploads the head-layout copy of the weights when the layer qualifies for the direct head kernel (else leaves wh null)
 int make_f16s_weights(const float* w_oihw, int cout, int c0, int c1, int kh, int kw, const float* scale, ConvLayer* L);
 int make_f16g_weights(const float* w_oihw, int cout, int c0, int c1, int kh, int kw, const float* scale, ConvLayer* L);
-int conv_set_precision(const char* name);  // fp32 | f16x3: applies to layers packed afterwards
+int conv_set_precision(const char* name);  // fp32 | f16x3 | f16: applies to layers packed afterwards
 int make_head_weights(const float* w_oihw, int cout, int c0, int c1, int kh, int kw, const float* scale, float** wh);
 
 

@@ -82,6 +82,7 @@ int make_conv(const ParamStore& ps, const std::string& wname, const std::string&
 static int parse_conv_precision(const char* e) {
     if (!e || !strcmp(e, "fp32")) return 0;
     if (!strcmp(e, "f16x3")) return 4;
+    if (!strcmp(e, "f16")) return 5;  // one product per term (the hi planes only): BASELINE config 5's "fp16 flow", never the default
     return -1;
 }
 static int g_conv_precision = -2;  // -2: not yet read from DFVO_CONV_PRECISION
@@ -94,13 +95,14 @@ int conv_split_mode() {
 }
 int conv_set_precision(const char* name) {
     const int m = parse_conv_precision(name);
-    DFVO_ARG_CHECK(m >= 0, "dfvo_set_conv_precision: expected fp32 | f16x3");
+    DFVO_ARG_CHECK(m >= 0, "dfvo_set_conv_precision: expected fp32 | f16x3 | f16");
     g_conv_precision = m;
     return DFVO_OK;
 }
 
 int make_f16s_weights(const float* w_oihw, int cout, int c0, int c1, int kh, int kw, const float* scale, ConvLayer* L) {
-    if (conv_split_mode() != 4 || kh != 3 || kw != 3) return DFVO_OK;
+    L->f16_terms = conv_split_mode() == 5 ? 1 : 3;
+    if (conv_split_mode() < 4 || kh != 3 || kw != 3) return DFVO_OK;
     std::vector<unsigned short> wf(conv_pack_weights_f16s(w_oihw, cout, c0, c1, scale, nullptr));
     conv_pack_weights_f16s(w_oihw, cout, c0, c1, scale, wf.data());
     DFVO_HIP_CHECK(hipMalloc((void**)&L->wf, wf.size() * sizeof(unsigned short) + 256));
@@ -123,7 +125,7 @@ int make_f16g_weights(const float* w_oihw, int cout, int c0, int c1, int kh, int
         L->g_steps = (int)(tab.size() / 4);
         return DFVO_OK;
     }
-    if (conv_split_mode() != 4 || kh > 31 || kw > 31) return DFVO_OK;
+    if (conv_split_mode() < 4 || kh > 31 || kw > 31) return DFVO_OK;
     std::vector<unsigned short> wg(conv_pack_weights_f16g(w_oihw, cout, c0, c1, kh, kw, scale, nullptr));
     conv_pack_weights_f16g(w_oihw, cout, c0, c1, kh, kw, scale, wg.data());
     std::vector<uint32_t> tab;
@@ -202,6 +204,7 @@ int run_conv(const ConvLayer& L, int N, int H, int W, View s0, int up0, View s1,
     p.wf16g_cout_pad = L.wg_cout_pad;
     p.f16g_tab = L.gtab;
     p.f16g_steps = L.g_steps;
+    p.f16_terms = L.f16_terms;
     p.bias = L.bias;
     p.cout = L.cout;
     p.cout_pad = L.cout_pad;

@@ -72,10 +72,14 @@ int dfvo_conv2d(const dfvo_conv_desc* desc, const float* d_src0, const float* d_
  * heads (direct kernel; wider 5x5 / 7x7 layers use the window kernel under the same ids); arrays of 19), the
  * summed duration [ms], useful FLOPs and launch count.
  * Do not use while a hipGraph capture is active (disable graphs on the nets first). */
-/* arithmetic of the 3x3 / stride-1 window layers packed AFTER this call (nets are packed at *_finalize):
- *   "fp32"   exact fp32 MFMA (v_mfma_f32_16x16x4_f32), the default
+/* arithmetic of the convolution layers packed AFTER this call (nets are packed at *_finalize):
+ *   "fp32"   exact fp32 MFMA (v_mfma_f32_16x16x4_f32), the library default
  *   "f16x3"  fp32-class: operands split into two f16 planes (22 mantissa bits), three exact products per term on
- *            v_mfma_f32_32x32x16_f16, fp32 accumulate (df-vo_amd/csrc/conv_win_f16s.h)
+ *            v_mfma_f32_32x32x16_f16, fp32 accumulate (df-vo_amd/csrc/conv_win_f16s.h); what bench.py's headline and
+ *            the drop-in classes (DeepModel.initialize_models) select
+ *   "f16"    NOT fp32-class: operands rounded to f16 (the hi plane alone), one product per term, fp32 accumulate, fp32
+ *            activations between layers -- BASELINE config 5's "fp16 flow" (hard part 4: reported
+ *            separately, with its flow / keypoint / pose deltas); the one- and two-channel heads stay exact fp32
  * Also read once from the environment variable DFVO_CONV_PRECISION. */
 int dfvo_set_conv_precision(const char* name);
 /* Which scikit-learn the scale-recovery RANSAC (sklearn.linear_model.RANSACRegressor, E_tracker.py:618-636) reproduces

@@ -34,15 +34,32 @@ def gpu(capi):
     return capi
 
 
-@pytest.fixture(params=["fp32", "f16x3"])
-def conv_precision(request, gpu):
-    """arithmetic of the 3x3 window layers for every net packed inside the test (dfvo_set_conv_precision): the exact fp32
-    MFMA kernels, and the f16x3 split kernels that bench.py's headline uses -- same tolerances for both"""
-    gpu.check(gpu.lib().dfvo_set_conv_precision(request.param.encode()))
+def _with_precision(gpu, name):
+    gpu.check(gpu.lib().dfvo_set_conv_precision(name.encode()))
     gpu.f16s_overflow_count(reset=True)
-    yield request.param
+    yield name
     gpu.check(gpu.lib().dfvo_set_conv_precision(b"fp32"))
-    # the f16x3 split saturates at +-65504 (conv_win_f16s.h): never silently -- no activation or weight of any net in
+    # the f16 planes saturate at +-65504 (conv_win_f16s.h): never silently -- no activation or weight of any net in
     # the suite may have been clamped
     clamped = gpu.f16s_overflow_count(reset=True)
-    assert clamped == 0, "f16x3: %d activations / weights were clamped to +-65504" % clamped
+    assert clamped == 0, "%s: %d activations / weights were clamped to +-65504" % (name, clamped)
+
+
+@pytest.fixture(params=["fp32", "f16x3"])
+def conv_precision(request, gpu):
+    """arithmetic of the conv layers for every net packed inside the test (dfvo_set_conv_precision): the exact fp32
+    MFMA kernels, and the f16x3 split kernels that bench.py's headline uses -- same tolerances for both"""
+    yield from _with_precision(gpu, request.param)
+
+
+@pytest.fixture(params=["fp32", "f16x3", "f16"])
+def conv_precision_any(request, gpu):
+    """the two fp32-class modes plus the single-product "f16" mode (BASELINE config 5's "fp16 flow"): for tests whose
+    assertions hold in ANY net arithmetic -- the solver stage against the oracle chain on the device's own arrays"""
+    yield from _with_precision(gpu, request.param)
+
+
+@pytest.fixture
+def f16_mode(gpu):
+    """DFVO_CONV_PRECISION=f16 for the nets packed inside the test (tests/test_f16_mode_gpu.py)"""
+    yield from _with_precision(gpu, "f16")

@@ -168,12 +168,15 @@ def test_images_to_pose_no_overrides(gpu, conv_precision, h, w, mode, step):
         assert max(dts) <= 5e-2 * max(1.0, float(np.linalg.norm(seq["poses"][1][:3, 3] - seq["poses"][0][:3, 3])))
 
 
-def test_pipeline_config5_settings(gpu, conv_precision):
+def test_pipeline_config5_settings(gpu, conv_precision_any):
+    conv_precision = conv_precision_any
     """BASELINE config 5 through the FUSED pipeline object exactly as `bench.py --height 1280 --width 1920 --kp-bestn 20000
     --e-max-iters 8192` drives it: 1920x1280 coded pairs, local_bestN with num_bestN 20000 (200 per cell,
     kp_selection.py:74-200), findEssentialMat with an 8192-hypothesis budget.  The solver stage is compared with the oracle
     chain (same knobs) on the device's own arrays: keypoints (values and order), inlier mask, R, t, scale and the numpy
-    RandomState bit for bit, over two consecutive pairs."""
+    RandomState bit for bit, over two consecutive pairs.  Parametrised over all three net arithmetics: config 5 as BASELINE.json
+    names it is the "f16" one ("fp16 flow"); the solver-stage assertions are precision-independent (the oracle chain runs on
+    the device's own flow / depth arrays), the geometry gates at the end are what the f16 nets must still deliver."""
     pmod, smod = _mods()
     h, w, nb, iters = 1280, 1920, 20000, 8192
     seq = coded_tunnel_sequence(h, w, 3, mode="mux", step=1.0)

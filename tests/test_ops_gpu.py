@@ -263,6 +263,102 @@ def test_f16x3_window_conv(gpu, case):
     assert errs[b"f16x3"] <= 4e-6
 
 
+F16_MODE_CASES = [c for c in CASES if c[6] > 2]  # (the one- / two-channel heads stay exact fp32 in every mode)
+
+
+@pytest.mark.parametrize("case", F16_MODE_CASES, ids=[c[0] for c in F16_MODE_CASES])
+def test_conv_f16_mode(gpu, case):
+    """DFVO_CONV_PRECISION=f16 (BASELINE config 5's "fp16 flow"): every MFMA kernel family with the cross products compiled
+    out.  What the mode computes is DEFINED: both operands rounded to nearest f16, exact products, fp32 accumulation,
+    fp32 bias / residual / activation -- so it is checked against the float64 convolution of the ROUNDED operands at the
+    fp32 kernels' own tolerance (2e-5: summation order only), and its distance to the unrounded convolution is printed
+    (expected ~ 2^-11 relative per operand)."""
+    name, n, h, w, c0, c1, cout, kh, kw, stride, pad, pad_mode, act, up0, use_res = case
+    lib = gpu.lib()
+    g = torch.Generator().manual_seed(hash(name) % 10000)
+    x0 = torch.randn(n, c0, h, w, generator=g)
+    H, W = (2 * h, 2 * w) if up0 else (h, w)
+    x1 = torch.randn(n, c1, H, W, generator=g) if c1 else None
+    wt = torch.randn(cout, c0 + c1, kh, kw, generator=g) / np.sqrt((c0 + c1) * kh * kw)
+    b = torch.randn(cout, generator=g) * 0.1
+    xin = F.interpolate(x0, scale_factor=2, mode="nearest") if up0 else x0
+    if x1 is not None:
+        xin = torch.cat([xin, x1], 1)
+
+    def conv64(xx, ww):
+        if pad_mode == 1:
+            return F.conv2d(F.pad(xx, (pad[1], pad[1], pad[0], pad[0]), mode="reflect"), ww, b.double(), stride=stride)
+        return F.conv2d(xx, ww, b.double(), stride=stride, padding=pad)
+
+    res = torch.randn(conv64(xin.double(), wt.double()).shape, generator=g) if use_res else None
+    a = 0.1 if act == 1 else 1.0
+    ref_rounded = conv64(xin.half().double(), wt.half().double())
+    ref_exact = conv64(xin.double(), wt.double())
+    if res is not None:
+        ref_rounded, ref_exact = ref_rounded + res.double(), ref_exact + res.double()
+    ref_rounded, ref_exact = ref_act(ref_rounded, act, a), ref_act(ref_exact, act, a)
+    gpu.check(lib.dfvo_set_conv_precision(b"f16"))
+    gpu.f16s_overflow_count(reset=True)
+    try:
+        got = run_conv(gpu, x0, wt, b, stride, pad, pad_mode, act, a, x1, up0, res)
+    finally:
+        gpu.check(lib.dfvo_set_conv_precision(b"fp32"))
+    assert gpu.f16s_overflow_count(reset=True) == 0
+    err, scale = report("conv f16 " + name + " vs rounded operands", got, ref_rounded)
+    report("conv f16 " + name + " vs the exact convolution", got, ref_exact)
+    assert err <= 2e-5 * max(1.0, scale)
+
+
+@pytest.mark.parametrize("case", ["tiny_x", "tiny_w", "tiny_both", "mixed_12_decades"])
+@pytest.mark.parametrize("layer", ["win_128_128", "gen_L6_192+52_128", "taps_7x1_32_49"])
+def test_f16x3_dynamic_range(gpu, case, layer):
+    """The f16x3 split outside O(1) data (round-4 verdict).  x = hi + 2^-11 lo with hi = f16(x): for |x| < 2^-14 the hi
+    plane is subnormal (absolute spacing 2^-24) and the scaled residue lo = f16((x - hi) 2^11) has absolute spacing
+    2^-24 as well, so the split represents x to 2^-36 ABSOLUTE, not 2^-22 relative; below 2^-25 hi is zero and lo alone
+    carries the value (11 bits).  Stated bound, per output:  |err| <= 2^-22 sum|w x| (the normal-range term: 22-bit operands,
+    dropped lo x lo product) + 2^-35 (sum|w| max|x| [x tiny] + sum|x| max|w| [w tiny]) (the subnormal-plane term) + fp32
+    accumulation noise 2^-20 max|partial sum|.  Checked against float64 on a window layer, a K-sliced small-map layer and
+    a tap-window layer; the exact fp32 kernels' error on the same data is printed beside it."""
+    lib = gpu.lib()
+    n, h, w, c0, c1, cout, kh, kw, pad = {"win_128_128": (2, 96, 160, 128, 0, 128, 3, 3, (1, 1)),
+                                          "gen_L6_192+52_128": (2, 6, 19, 192, 52, 128, 3, 3, (1, 1)),
+                                          "taps_7x1_32_49": (2, 96, 160, 32, 0, 49, 7, 1, (3, 0))}[layer]
+    g = torch.Generator().manual_seed(len(case) * 7 + len(layer))
+    x = torch.randn(n, c0 + c1, h, w, generator=g)
+    wt = torch.randn(cout, c0 + c1, kh, kw, generator=g) / np.sqrt((c0 + c1) * kh * kw)
+    if case in ("tiny_x", "tiny_both"):
+        x = x * 1e-6
+    if case in ("tiny_w", "tiny_both"):
+        wt = wt * 1e-3
+    if case == "mixed_12_decades":  # magnitudes log-uniform over 1e-8 .. 1e4 in both operands
+        x = x * torch.pow(10.0, torch.rand(x.shape, generator=g) * 12 - 8)
+        wt = wt * torch.pow(10.0, torch.rand(wt.shape, generator=g) * 6 - 5)
+    x0, x1 = x[:, :c0].contiguous(), (x[:, c0:].contiguous() if c1 else None)
+    b = torch.zeros(cout)
+    ref = F.conv2d(x.double(), wt.double(), padding=pad)
+    sabs = F.conv2d(x.abs().double(), wt.abs().double(), padding=pad)            # sum |w x| per output
+    sw = F.conv2d(torch.ones_like(x).double(), wt.abs().double(), padding=pad)   # sum |w| over the taps inside the image
+    sx = F.conv2d(x.abs().double(), torch.ones_like(wt).double(), padding=pad)   # sum |x|
+    xt, wtiny = float(x.abs().min()) < 2.0 ** -14, float(wt.abs().min()) < 2.0 ** -14
+    bound = 2.0 ** -22 * sabs + 2.0 ** -20 * sabs \
+        + 2.0 ** -35 * ((sw * float(x.abs().max()) if xt else 0) + (sx * float(wt.abs().max()) if wtiny else 0))
+    out = {}
+    for mode in (b"fp32", b"f16x3"):
+        gpu.check(lib.dfvo_set_conv_precision(mode))
+        gpu.f16s_overflow_count(reset=True)
+        try:
+            out[mode] = run_conv(gpu, x0, wt, b, 1, pad, 0, 0, 0.0, x1=x1).double()
+        finally:
+            gpu.check(lib.dfvo_set_conv_precision(b"fp32"))
+        assert gpu.f16s_overflow_count(reset=True) == 0
+    e32, e16 = (out[b"fp32"] - ref).abs(), (out[b"f16x3"] - ref).abs()
+    scale = float(ref.abs().max())
+    print("   f16x3 range %-18s %-16s max|ref| %.2e  max err: fp32 %.2e (rel %.1e)  f16x3 %.2e (rel %.1e)  worst err / bound %.3f"
+          % (layer, case, scale, float(e32.max()), float(e32.max()) / scale, float(e16.max()), float(e16.max()) / scale,
+             float((e16 / bound).max())))
+    assert bool((e16 <= bound).all())
+
+
 @pytest.mark.gpu
 def test_conv_small_maps_with_k_divided_over_workgroups(gpu):
     """DFVO_F16G_NZ=-1 (off by default: slower inside the pipeline): the small-map cases again with the K range divided over

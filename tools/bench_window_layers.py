@@ -1,7 +1,6 @@
 """per-layer timing of the f16x3 window layers at the KITTI pyramid sizes (level 2: 176x608, level 3: 88x304) for the
-skeleton selected by the environment (DFVO_F16S_RUN unset: one-wave-per-SIMD skeleton; N / p: the tile-run skeleton with
-runs of N tiles / persistent); prints HIP-event durations and a CRC of the output (all skeletons accumulate in the same
-order: equal CRCs)."""
+precision mode in PREC (f16x3 default | f16 | fp32); prints HIP-event durations and a CRC of the output (skeletons that
+accumulate in the same order print equal CRCs)."""
 import importlib
 import os
 import sys
@@ -23,7 +22,7 @@ LAYERS = [("L2 128->128", 2, 176, 608, 128, 0, 128), ("L2 64+66->128", 2, 176, 6
           ("L2 32->32", 2, 176, 608, 32, 0, 32), ("L3 128->128", 2, 88, 304, 128, 0, 128), ("L3 128->64", 2, 88, 304, 128, 0, 64),
           ("L3 64->32", 2, 88, 304, 64, 0, 32), ("c5 128->128", 2, 640, 960, 128, 0, 128)]
 g = torch.Generator().manual_seed(1)
-capi.check(lib.dfvo_set_conv_precision(b"f16x3"))
+capi.check(lib.dfvo_set_conv_precision(os.environ.get("PREC", "f16x3").encode()))
 tot = 0.0
 for name, n, h, w, c0, c1, cout in LAYERS:
     x0 = torch.randn(n, c0, h, w, generator=g)
@@ -53,4 +52,4 @@ for name, n, h, w, c0, c1, cout in LAYERS:
     if not name.startswith("c5"):
         tot += best
     print("%-16s %6.1f GF %8.1f us %6.1f TF/s-eq  crc %08x" % (name, gf, best * 1e3, gf / best, zlib.crc32(out.numpy().tobytes()) & 0xffffffff), flush=True)
-print("DFVO_F16S_RUN=%s operands %s: sum of the KITTI layers %.1f us" % (os.environ.get("DFVO_F16S_RUN", "-"), os.environ.get("OPERANDS", "random"), tot * 1e3))
+print("PREC=%s DFVO_WIN=%s operands %s: sum of the KITTI layers %.1f us" % (os.environ.get("PREC", "f16x3"), os.environ.get("DFVO_WIN", "-"), os.environ.get("OPERANDS", "random"), tot * 1e3))
