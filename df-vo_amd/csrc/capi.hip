@@ -150,6 +150,8 @@ int dfvo_conv2d(const dfvo_conv_desc* d, const float* d_src0, const float* d_src
     (void)hipFree(db);
     if (L.wh) (void)hipFree(L.wh);
     if (L.wf) (void)hipFree(L.wf);
+    if (L.wfa) (void)hipFree(L.wfa);
+    if (L.wfa_inv) (void)hipFree(L.wfa_inv);
     if (L.wg) (void)hipFree(L.wg);
     if (L.wg32) (void)hipFree(L.wg32);
     if (L.gtab) (void)hipFree(L.gtab);

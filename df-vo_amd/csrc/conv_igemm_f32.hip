@@ -813,9 +813,11 @@ int conv_profile_end(double* ms, double* flops, int* launches) {
     return DFVO_OK;
 }
 
+constexpr int DFVO_WIN_DEFAULT = 0;  // 0: two-set window kernels (conv_win_f16s2.h), 1: single-accumulator (conv_win_f16a.h)
 #include "conv_win_f16s.h"
 #include "conv_gemm_f16s.h"
 #include "conv_win_f16s2.h"
+#include "conv_win_f16a.h"
 
 // split-K when the grid cannot fill the chip: partials to p.ws, ordered reduction in a second launch
 static int conv_pick_splits(const ConvParams& p, long long blocks) {
@@ -1016,6 +1018,17 @@ static int launch_f32g_prof(const ConvParams& p, hipStream_t stream) {
     return DFVO_OK;
 }
 
+// DFVO_WIN (read once; test / A-B hook): "a" = the single-accumulator window kernel (conv_win_f16a.h) packs its planes and
+// takes the chip-filling 3x3 layers; "2" = the two-set kernels of rounds 2-4.  Default: see the measurement in DESIGN.md 5a.
+int conv_window_variant() {
+    static const int v = [] {
+        const char* e = getenv("DFVO_WIN");
+        if (!e) return DFVO_WIN_DEFAULT;
+        return e[0] == 'a' ? 1 : 0;
+    }();
+    return v;
+}
+
 int launch_conv(const ConvParams& p, hipStream_t stream) {
     const long long M = (long long)p.N * p.Ho * p.Wo;
     const int bn = conv_pick_bn(p.cout, M);
@@ -1028,6 +1041,10 @@ int launch_conv(const ConvParams& p, hipStream_t stream) {
         return p.cout == 2 ? launch_head<3, 2>(p, stream, 18) : launch_head<3, 1>(p, stream, 18);
     }
     if (p.wf16 && conv_f16s_ok(p)) {  // f16x3: the 3x3 / stride-1 layers whose map fills the chip
+        if (p.wf16a && p.f16_terms != 1) {  // DFVO_WIN=a at pack time: the single-accumulator kernel, two workgroups per CU
+            const int rca = launch_f16a(p, stream, 19);
+            if (rca != F16S2_NOT_APPLICABLE) return rca;
+        }
         const int rc2 = launch_f16s2(p, stream, 19);  // one-wave-per-SIMD skeleton where the grid is large enough
         return rc2 != F16S2_NOT_APPLICABLE ? rc2 : launch_f16s(p, stream, 19);  // errors (negative) propagate
     }
