@@ -45,9 +45,12 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")  # before torch / HIP initialis
 
 SLOTS = 4  # DFVO_PIPELINE_SLOTS
 PREFETCH = os.environ.get("DFVO_BENCH_PREFETCH", "1") != "0"  # RNG-independent solver half enqueued behind the nets
+RAMP = int(os.environ.get("DFVO_BENCH_RAMP", "1"))  # pairs whose nets are enqueued before the first chain begins (3 = rounds 1-4)
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: FP32 matrix (f32 in / f32 acc)
 PEAK_F16_MFMA_TFLOPS = 2500.0  # same table: F16 / BF16 MFMA dense
-PMC_FILE = "r4_pmc_bench.json"  # committed rocprofv3 --pmc passes over the default command (tools/profile.sh)
+PEAK_HBM_GBS = 8000.0  # same guide: HBM3E ~8 TB/s
+PMC_FILE = "r5_pmc_bench.json"  # committed rocprofv3 --pmc passes over the default command (tools/profile.sh)
+STATS_FILE = "r5_rocprofv3_kernel_stats.csv"  # ... and its --kernel-trace --stats summary
 
 
 def kernel_source_digest():
@@ -242,8 +245,9 @@ def run_mirrors(args, syn, capi, h_frames, K, fsd, dsd, code_mode):
     tracking :121-262, update_global_pose :109-119) over the drop-in classes exactly as libs/dfvo.py instantiates them --
     DeepModel(cfg).initialize_models() from weight FILES in the reference's on-disk formats, KeypointSampler(cfg),
     EssTracker / PnpTracker(cfg, cam_intrinsics) -- with host numpy arrays in and out of every call (2 x 1.4 MB H2D +
-    9.8 MB D2H per pair, synchronous), the library's default exact-fp32 nets unless --conv-precision says otherwise, and
-    torch touching the GPU before the library creates its streams (as apis/run.py's imports do).  Per-stage host times
+    9.8 MB D2H per pair, every call blocking), the nets in --conv-precision (DeepModel.initialize_models reads it from the
+    environment), the frame session of df-vo_amd/libs/deep_models/session.py unless DFVO_SESSION=0, and torch touching the GPU
+    before the library creates its streams (as apis/run.py's imports do).  Per-stage host times
     under the reference's Timer keys (libs/general/timer.py; dfvo.py:146-246,305-335)."""
     import tempfile
     import torch
@@ -351,8 +355,66 @@ def run_mirrors(args, syn, capi, h_frames, K, fsd, dsd, code_mode):
                    "tracked_by_E": modes.count("Ess. Mat."), "tracked_by_PnP": modes.count("PnP"),
                    "constant_motion": modes.count("Constant motion")},
         "stage_ms_per_pair": {k: round(v / args.steps * 1e3, 3) for k, v in acc.items()},
-        "roofline": None, "cpu_baseline": None}
+        "roofline": None, "cpu_baseline": None,
+        "session": dict(deep_models.session.stats) if getattr(deep_models, "session", None) is not None else None}
     print(json.dumps(line))
+
+
+def committed_streaming_kernels():
+    """the non-conv streaming kernels (correlation, warp, depth-wise deconvolution, resizes, flow mean ...) against the HBM
+    roofline, from the committed rocprofv3 passes over the default command: bytes per dispatch (PMC: FETCH_SIZE x 2 on gfx950 +
+    WRITE_SIZE, tools/pmc_traffic.py) over the average duration of the same kernel in the kernel-trace statistics"""
+    import csv
+    import re
+
+    def norm(name):  # "void dfvo::k_correlation_rt<64, 1>(float const*, ...)" -> "k_correlation_rt"
+        n = re.sub(r"<.*", "", name.split("(")[0].replace("void ", "").strip())
+        return n.split("::")[-1]
+    try:
+        prof = json.load(open(os.path.join(ROOT, "profiles", PMC_FILE)))["kernels"]
+        dur = {}
+        for r in csv.DictReader(open(os.path.join(ROOT, "profiles", STATS_FILE))):
+            t = dur.setdefault(norm(r["Name"]), [0.0, 0])
+            t[0] += float(r["TotalDurationNs"])
+            t[1] += int(r["Calls"])
+        byt = {}
+        for k, v in prof.items():
+            t = byt.setdefault(norm(k), [0.0, 0])
+            t[0] += v["hbm_bytes_per_dispatch"] * v["dispatches"]
+            t[1] += v["dispatches"]
+    except (OSError, KeyError, ValueError):
+        return None
+    out = []
+    for k, (b, nd) in byt.items():
+        if not k.startswith("k_") or k not in dur or nd == 0 or b / nd < 4e6:
+            continue  # (conv kernels are priced live; small kernels are launch-latency bound, not streaming)
+        ns = dur[k][0] / dur[k][1]
+        gbs = b / nd / ns
+        out.append({"kernel": k, "avg_us": round(ns / 1e3, 2), "mb_per_dispatch": round(b / nd / 1e6, 2),
+                    "achieved_gbs": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4), "calls": dur[k][1]})
+    return sorted(out, key=lambda e: -e["avg_us"] * e["calls"])[:8] or None
+
+
+def other_leg(argv, timeout=300):
+    """one short leg of the default line: bench.py itself in a child process, its JSON line reduced to the figures"""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--no-cpu-baseline", "--no-roofline", "--no-exact-leg", "--no-other-legs"]
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout)
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    except Exception as e:  # reported in the line, never fatal for the headline
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:200]), "argv": " ".join(argv)}
+    out = {"value": d["value"], "unit": d["unit"], "steps": d["steps"], "warmup": d["warmup"], "ms_per_step": d["ms_per_step"],
+           "dtype": d["dtype"].split(":")[0].split(" (")[0] if len(d["dtype"]) > 40 else d["dtype"], "argv": " ".join(argv),
+           "workload": d["config"]["workload"][:160], "leg_wall_s": round(time.perf_counter() - t0, 1)}
+    for k in ("tracked_by_E", "tracked_by_PnP", "constant_motion", "conv_precision", "sequences", "frames"):
+        if k in d["config"]:
+            out[k] = d["config"][k]
+    for k in ("stage_ms_per_pair", "session", "steady_state"):
+        if d.get(k) is not None:
+            out[k] = d[k]
+    return out
 
 
 KITTI_FRAMES = [4541, 1101, 4661, 801, 271, 2761, 1101, 1101, 4071, 1591, 1201]  # dataset/kitti_odom/gt_poses/00..10.txt
@@ -451,6 +513,9 @@ def main(argv=None):
     ap.add_argument("--frames", default="device", choices=["device", "host"],
                     help="host: pinned host frames, H2D on a copy stream inside the timed region")
     ap.add_argument("--no-exact-leg", action="store_true", help="skip the second timed leg in exact fp32 (exact_fp32 in the JSON line)")
+    ap.add_argument("--no-other-legs", action="store_true",
+                    help="skip the short extra legs of the default line: dropin_surface (the reference's class surface, 8 pairs), "
+                         "other_configs (BASELINE configs 3 / 4 / 5, a few pairs each) and features_recomputed")
     ap.add_argument("--feature-carry", default="on", choices=["on", "off"],
                     help="on: the flow net's image / feature pyramids of a pair's reference frame are the ones the previous pair "
                          "computed for it as its current frame (one Features pass per new frame); off: both frames of every pair "
@@ -604,18 +669,24 @@ def main(argv=None):
             if PREFETCH:
                 p.prefetch_track(j % SLOTS, d_sc[j % len(d_sc)][0], d_sc[j % len(d_sc)][1])
 
-        for j in range(min(ahead, n)):
-            feed(j)
+        # staged ramp (round 5): a run starts with RAMP pairs' nets in flight, not `ahead` -- with three started together the
+        # first RandomState-ordered chain waits for the slowest of them (~10 ms to the first pose, 9 % of a 20-pair run);
+        # with one, the first chain starts after one pair's latency and the pairs ahead are fed while it runs
+        fed = 0
+        while fed < min(RAMP, ahead, n):
+            feed(fed)
+            fed += 1
         for k in range(n):
             t_a = time.perf_counter()
-            # the RandomState-ordered chain of pair k is enqueued first, the nets of pair k + ahead while it runs
+            # the RandomState-ordered chain of pair k is enqueued first, the nets of the pairs up to k + ahead while it runs
             if nets_mode:
                 p.track_begin(k % SLOTS)  # no overrides: keypoints / RANSAC / scale / PnP on the nets' own outputs
             else:
                 f, dd, dp = d_sc[k % len(d_sc)]
                 p.track_begin(k % SLOTS, f, dd, dp)  # E-tracker, or the PnP fallback when its pose is rejected
-            if k + ahead < n:
-                feed(k + ahead)
+            while fed < n and fed <= k + ahead:
+                feed(fed)
+                fed += 1
             t_b = time.perf_counter()
             out = p.track_end(k % SLOTS)
             t_c = time.perf_counter()
@@ -682,7 +753,7 @@ def main(argv=None):
         steady = (len(t_track) - ahead) / (t_track[-1] - t_track[ahead - 1])
     net_flops_ref = net_flops  # the reference's work per pair: Features on both frames in every model call
     recomputed = None
-    if rank == 0 and world == 1 and on_gpu and nets_mode and carry[0]:
+    if rank == 0 and world == 1 and on_gpu and nets_mode and carry[0] and not args.no_other_legs:
         # the same workload with both frames of every pair through Features (third timed leg, same warm-up / steps / clock)
         carry[0] = False
         run(pipe, args.warmup)
@@ -713,7 +784,8 @@ def main(argv=None):
         ms = np.zeros(24)
         fl = np.zeros(24)
         ln = np.zeros(24, np.int32)
-        capi.check(lib.dfvo_conv_profile_end(capi.as_ptr(ms), capi.as_ptr(fl), capi.as_ptr(ln)))
+        by = np.zeros(24)
+        capi.check(lib.dfvo_conv_profile_end_bytes(capi.as_ptr(ms), capi.as_ptr(fl), capi.as_ptr(ln), capi.as_ptr(by)))
         pipe.set_graph(1)
         dom = int(np.argmax(ms))
         ach = fl[dom] / (ms[dom] * 1e-3) / 1e12
@@ -735,6 +807,19 @@ def main(argv=None):
                                "launches_per_pair": int(ln[i] // nprof), "gflop_per_pair": round(float(fl[i] / nprof / 1e9), 1),
                                "tflops": round(float(fl[i] / (ms[i] * 1e-3) / 1e12), 1)}
                               for i in np.argsort(-ms) if ln[i] > 0]}
+        # SURVEY 8d bounds the streaming layers, the correlation, the warps and the resizes by HBM: the conv family's streaming
+        # configuration (1x1 / stride 2 / tap-window layers) priced live -- algorithmic bytes (input map + output map + weights,
+        # each once, from the launches' shapes) over the HIP-event durations of the same launches -- and the non-conv streaming
+        # kernels from the committed rocprofv3 passes (bytes from the PMC pass, duration from the kernel-trace statistics)
+        if ln[20] > 0:
+            roof["hbm"] = {"bound": "hbm", "kernel": CFG_NAMES[20], "achieved": round(float(by[20] / (ms[20] * 1e-3) / 1e9), 1),
+                           "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(float(by[20] / (ms[20] * 1e-3) / 1e9 / PEAK_HBM_GBS), 4),
+                           "traffic": None, "avg_launch_us": round(float(ms[20] * 1e3 / ln[20]), 2),
+                           "launches_per_pair": int(ln[20] // nprof),
+                           "algorithmic_mb_per_launch": round(float(by[20] / ln[20] / 1e6), 2),
+                           "note": "achieved = algorithmic bytes / HIP-event duration, live; traffic and the non-conv streaming "
+                                   "kernels (other_kernels) from the committed rocprofv3 passes"}
+            roof["hbm"]["other_kernels"] = committed_streaming_kernels()
         # HBM-side bytes per launch of that kernel: hardware counters cannot be read from inside the process, so they come
         # from the committed rocprofv3 --pmc passes over this same command (tools/profile.sh -> tools/pmc_traffic.py:
         # FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate passes); None when no committed profile holds the kernel.  The
@@ -746,6 +831,12 @@ def main(argv=None):
                 "conv_igemm_f32<", "conv_igemm_f32_kernel<").replace("conv_win3_f32<", "conv_win_f32_kernel<").replace(
                 "conv_win_f32<", "conv_win_f32_kernel<")
             cand = [k for k in prof if k.replace(" ", "").startswith(key.rstrip(">").replace(" ", ""))]
+            if roof.get("hbm"):
+                cs = [k for k in prof if k.replace(" ", "").startswith("conv_taps_f16s_kernel") or
+                      k.replace(" ", "").startswith("conv_gemm_f16s_kernel<4,1,")]
+                if cs:
+                    nds = sum(prof[k]["dispatches"] for k in cs)
+                    roof["hbm"]["traffic"] = round(sum(prof[k]["hbm_bytes_per_dispatch"] * prof[k]["dispatches"] for k in cs) / nds)
             if cand:
                 nd = sum(prof[k]["dispatches"] for k in cand)
                 roof["traffic"] = round(sum(prof[k]["hbm_bytes_per_dispatch"] * prof[k]["dispatches"] for k in cand) / nd)
@@ -781,6 +872,21 @@ def main(argv=None):
     seen = ranks_seen(dist, world, rank, local_rank, torch)
     if pipe is not None:
         pipe.close()
+    dropin = others = None
+    if (rank == 0 and world == 1 and on_gpu and nets_mode and not args.no_other_legs and (H, W) == (376, 1241)
+            and args.kp_bestn == 2000 and args.e_max_iters == 1000):
+        # Short GPU-only legs so that the driver's one default command also observes (a) the surface the reference's own
+        # frame loop calls and (b) the other BASELINE configurations.  Each is this script again in a child process (own
+        # precision mode, own streams, nothing shared with the headline's timed region, which is over by now).
+        dropin = other_leg(["--surface", "mirrors", "--steps", "8", "--warmup", "3", "--conv-precision", args.conv_precision])
+        big = ["--height", "1280", "--width", "1920", "--kp-bestn", "20000", "--e-max-iters", "8192", "--steps", "5", "--warmup", "2"]
+        others = {
+            "config3_kitti_00_10_job": other_leg(["--sequences", "kitti-lengths", "--scale", "0.005", "--conv-precision", args.conv_precision]),
+            "config4_1280x960": other_leg(["--height", "960", "--width", "1280", "--steps", "5", "--warmup", "2",
+                                           "--conv-precision", args.conv_precision]),
+            "config5_1920x1280_8192hyp_20kkp_f16": other_leg(big + ["--conv-precision", "f16"]),
+            "config5_1920x1280_8192hyp_20kkp_" + args.conv_precision: other_leg(big + ["--conv-precision", args.conv_precision]),
+        }
 
     if rank == 0:
         n_e = int((status == 0).sum())
@@ -838,6 +944,7 @@ def main(argv=None):
                                                          "note": "pairs after the first %d (nets running ahead of the solver "
                                                                  "stage), host clock at the return of track()" % ahead},
             "exact_fp32": exact, "features_recomputed": recomputed, "sequence_check": seq_check,
+            "dropin_surface": dropin, "other_configs": others,
             "roofline": roof, "cpu_baseline": base}
         print(json.dumps(line))
     if dist is not None:

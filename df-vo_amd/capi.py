@@ -75,6 +75,11 @@ class TrackOut(C.Structure):
                 ("pnp_n_filtered", C.c_int)]
 
 
+class SessionKpCfg(C.Structure):
+    _fields_ = [("num_row", C.c_int), ("num_col", C.c_int), ("num_bestN", C.c_int), ("thre", C.c_float),
+                ("score_method", C.c_int)]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in (
         "N", "H", "W", "kh", "kw", "stride", "pad_h", "pad_w", "pad_mode",
@@ -104,11 +109,21 @@ SIGNATURES = {
     "dfvo_comm_destroy": (_i, [_vp]),
     "dfvo_allgather_poses": (_i, [_vp, _vp, _i, _vp, _vp]),
     "dfvo_allgather_poses_device": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "dfvo_session_create": (_i, [_vp, _vp, _vp, _i, _i, C.POINTER(_vp)]),
+    "dfvo_session_destroy": (None, [_vp]),
+    "dfvo_session_reset": (_i, [_vp]),
+    "dfvo_session_invalidate_carry": (_i, [_vp]),
+    "dfvo_session_push_frame": (_i, [_vp, _vp, _vp, _vp, C.POINTER(C.c_longlong)]),
+    "dfvo_session_depth": (_i, [_vp, C.c_longlong, C.POINTER(_vp)]),
+    "dfvo_session_flow": (_i, [_vp, C.c_longlong, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
+    "dfvo_session_keypoints": (_i, [_vp, C.c_longlong, _vp, C.POINTER(_vp), C.POINTER(_vp), _ip, _ip]),
+    "dfvo_session_pose_2d2d": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _ip]),
     "dfvo_set_conv_precision": (_i, [C.c_char_p]),
     "dfvo_set_sklearn_compat": (_i, [C.c_char_p]),
     "dfvo_f16s_overflow_count": (_i, [C.POINTER(C.c_ulonglong), _i]),
     "dfvo_conv_profile_begin": (_i, []),
     "dfvo_conv_profile_end": (_i, [_vp, _vp, _vp]),
+    "dfvo_conv_profile_end_bytes": (_i, [_vp, _vp, _vp, _vp]),
     "dfvo_correlation": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
     "dfvo_backward_warp": (_i, [_vp, _vp, _f, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "dfvo_deconv_dw4x4s2": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),

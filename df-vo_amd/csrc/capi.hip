@@ -11,6 +11,7 @@
 #include "nets.h"
 #include "ops.h"
 #include "resize_lanczos.h"
+#include "capi_types.h"
 
 namespace dfvo {
 static thread_local std::string g_err;
@@ -34,15 +35,6 @@ int ensure_dyn_lds(const void* kernel, size_t bytes) {
 
 using namespace dfvo;
 
-struct dfvo_flownet {
-    FlowNet net;
-};
-struct dfvo_depthnet {
-    DepthNet net;
-    LanczosResizer resize;      // dfvo_depthnet_forward_image_host: tables for the last image size seen
-    uint8_t* img_full = nullptr;
-    size_t img_full_bytes = 0;
-};
 
 #define API_TRY(expr)                   \
     do {                                \
@@ -150,8 +142,6 @@ int dfvo_conv2d(const dfvo_conv_desc* d, const float* d_src0, const float* d_src
     (void)hipFree(db);
     if (L.wh) (void)hipFree(L.wh);
     if (L.wf) (void)hipFree(L.wf);
-    if (L.wfa) (void)hipFree(L.wfa);
-    if (L.wfa_inv) (void)hipFree(L.wfa_inv);
     if (L.wg) (void)hipFree(L.wg);
     if (L.wg32) (void)hipFree(L.wg32);
     if (L.gtab) (void)hipFree(L.gtab);
@@ -170,6 +160,10 @@ int dfvo_conv_profile_begin(void) {
 int dfvo_conv_profile_end(double* h_ms19, double* h_flops19, int* h_launches19) {
     DFVO_ARG_CHECK(h_ms19 && h_flops19 && h_launches19, "dfvo_conv_profile_end: null argument");
     return conv_profile_end(h_ms19, h_flops19, h_launches19);
+}
+int dfvo_conv_profile_end_bytes(double* h_ms24, double* h_flops24, int* h_launches24, double* h_bytes24) {
+    DFVO_ARG_CHECK(h_ms24 && h_flops24 && h_launches24 && h_bytes24, "dfvo_conv_profile_end_bytes: null argument");
+    return conv_profile_end(h_ms24, h_flops24, h_launches24, h_bytes24);
 }
 
 int dfvo_correlation(const float* d_first, const float* d_second, int N, int H, int W, int C, int stride,

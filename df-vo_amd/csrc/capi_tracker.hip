@@ -3,25 +3,54 @@
 
 #include "solver.h"
 #include "tracker.h"
+#include "capi_types.h"
 #include "../../include/dfvo_hip.h"
 
 using namespace dfvo;
 
-struct dfvo_tracker {
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    TrackerBuffers tb;
-    RigidKpBuffers rigid;
-    BestNBuffers bestn;
-    RansacWorkspace& ws = tb.ws_e;
-    float *d_flow = nullptr, *d_diff = nullptr;
-    double* d_depth = nullptr;
-    size_t flow_cap = 0, depth_cap = 0;
-    double* d_small = nullptr;  // 64 doubles
-    double *d_x1 = nullptr, *d_x2 = nullptr, *d_X4 = nullptr;
-    int tri_cap = 0;
-    PnpBuffers pnp;
-};
+// shared with session.hip (declared in capi_types.h)
+int dfvo_pose_config_from(const dfvo_pose2d2d_cfg* cfg, dfvo::PoseConfig* pcp) {
+    PoseConfig& pc = *pcp;
+    pc.fx = cfg->fx;
+    pc.cx = cfg->cx;
+    pc.cy = cfg->cy;
+    pc.reproj_thre = cfg->reproj_thre;
+    pc.repeat = cfg->repeat;
+    pc.max_iters = cfg->max_iters;
+    for (int i = 0; i < 9; i++) {
+        pc.KinvT[i] = cfg->KinvT[i];
+        pc.Kinv[i] = cfg->Kinv[i];
+    }
+    DFVO_ARG_CHECK(cfg->validity_method == DFVO_VALIDITY_GRIC || cfg->validity_method == DFVO_VALIDITY_FLOW ||
+                       cfg->validity_method == DFVO_VALIDITY_HOMO_RATIO,
+                   "dfvo_compute_pose_2d2d: unknown validity_method");
+    pc.validity = cfg->validity_method;
+    pc.validity_thre = cfg->validity_thre;
+    return DFVO_OK;
+}
+
+// results of the pose chain enqueued on t->stream: waits, fills out / h_inliers
+int dfvo_pose_fetch(dfvo_tracker* t, int n, const dfvo_pose2d2d_cfg* cfg, dfvo_pose2d2d_out* out, uint8_t* h_inliers) {
+    PoseState ps;
+    DFVO_HIP_CHECK(hipMemcpyAsync(&ps, t->tb.pose, sizeof(ps), hipMemcpyDeviceToHost, t->stream));
+    if (n > 0) DFVO_HIP_CHECK(hipMemcpyAsync(h_inliers, t->tb.best_inliers, n, hipMemcpyDeviceToHost, t->stream));
+    DFVO_HIP_CHECK(hipStreamSynchronize(t->stream));
+    for (int i = 0; i < 9; i++) out->R[i] = ps.R[i];
+    for (int i = 0; i < 3; i++) out->t[i] = ps.t[i];
+    out->n = ps.n;
+    out->best_inlier_cnt = ps.best_cnt;
+    out->num_valid = ps.num_valid;
+    out->major_valid = (cfg->validity_method == DFVO_VALIDITY_GRIC ? n > 10 : n >= 5) ? ps.major_valid : 0;
+    out->cheirality = ps.cheirality;
+    out->h_found = ps.h_found;
+    out->h_gric = ps.h_gric;
+    for (int i = 0; i < 8; i++) {
+        out->rep_inliers[i] = ps.rep_cnt[i];
+        out->rep_valid[i] = ps.rep_valid[i];
+        out->rep_gric[i] = ps.rep_gric[i];
+    }
+    return DFVO_OK;
+}
 
 extern "C" {
 
@@ -385,42 +414,11 @@ int dfvo_compute_pose_2d2d(dfvo_tracker* t, const double* h_kp_ref, const double
     int rc = stage_kp(t, h_kp_ref, h_kp_cur, n);
     if (rc != DFVO_OK) return rc;
     PoseConfig pc;
-    pc.fx = cfg->fx;
-    pc.cx = cfg->cx;
-    pc.cy = cfg->cy;
-    pc.reproj_thre = cfg->reproj_thre;
-    pc.repeat = cfg->repeat;
-    pc.max_iters = cfg->max_iters;
-    for (int i = 0; i < 9; i++) {
-        pc.KinvT[i] = cfg->KinvT[i];
-        pc.Kinv[i] = cfg->Kinv[i];
-    }
-    DFVO_ARG_CHECK(cfg->validity_method == DFVO_VALIDITY_GRIC || cfg->validity_method == DFVO_VALIDITY_FLOW ||
-                       cfg->validity_method == DFVO_VALIDITY_HOMO_RATIO,
-                   "dfvo_compute_pose_2d2d: unknown validity_method");
-    pc.validity = cfg->validity_method;
-    pc.validity_thre = cfg->validity_thre;
+    rc = dfvo_pose_config_from(cfg, &pc);
+    if (rc != DFVO_OK) return rc;
     rc = enqueue_compute_pose_2d2d(t->tb, n, pc, t->stream);
     if (rc != DFVO_OK) return rc;
-    PoseState ps;
-    DFVO_HIP_CHECK(hipMemcpyAsync(&ps, t->tb.pose, sizeof(ps), hipMemcpyDeviceToHost, t->stream));
-    if (n > 0) DFVO_HIP_CHECK(hipMemcpyAsync(h_inliers, t->tb.best_inliers, n, hipMemcpyDeviceToHost, t->stream));
-    DFVO_HIP_CHECK(hipStreamSynchronize(t->stream));
-    for (int i = 0; i < 9; i++) out->R[i] = ps.R[i];
-    for (int i = 0; i < 3; i++) out->t[i] = ps.t[i];
-    out->n = ps.n;
-    out->best_inlier_cnt = ps.best_cnt;
-    out->num_valid = ps.num_valid;
-    out->major_valid = (cfg->validity_method == DFVO_VALIDITY_GRIC ? n > 10 : n >= 5) ? ps.major_valid : 0;
-    out->cheirality = ps.cheirality;
-    out->h_found = ps.h_found;
-    out->h_gric = ps.h_gric;
-    for (int i = 0; i < 8; i++) {
-        out->rep_inliers[i] = ps.rep_cnt[i];
-        out->rep_valid[i] = ps.rep_valid[i];
-        out->rep_gric[i] = ps.rep_gric[i];
-    }
-    return DFVO_OK;
+    return dfvo_pose_fetch(t, n, cfg, out, h_inliers);
 }
 
 int dfvo_set_sklearn_compat(const char* version) { return dfvo::set_sklearn_compat(version); }

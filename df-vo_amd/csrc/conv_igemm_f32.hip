@@ -782,11 +782,15 @@ void conv_profile_begin() {
 //   5 <2,2,2,1> 64x32  6 <4,1,4,1> 256x16  7 <4,1,1,1> 64x16  8 <1,4,4,2> 64x128  9 <2,2,4,2> 128x64  10 <4,1,2,2> 128x32
 //   11 <4,1,2,1> 128x16; LDS-window 3x3 kernel: 12 (8x16)x128  13 (8x16)x64  14 (8x16)x32  15 (4x16)x128
 //   16 7x7 heads  17 5x5 heads  18 3x3 heads (direct kernel for cout <= 2; the window kernel (8x16)x16 above that)
-int conv_profile_end(double* ms, double* flops, int* launches) {
+// bytes (optional): ALGORITHMIC HBM bytes of the launches of a configuration -- fp32 input map once + fp32 output map once +
+// fp32 weights once (the figure SURVEY.md section 8d prices the streaming layers with); what the kernels really moved comes
+// from the PMC passes under profiles/
+int conv_profile_end(double* ms, double* flops, int* launches, double* bytes) {
     for (int i = 0; i < CONV_NUM_CFGS; i++) {
         ms[i] = 0;
         flops[i] = 0;
         launches[i] = 0;
+        if (bytes) bytes[i] = 0;
     }
     if (!g_prof) return DFVO_OK;
     // DFVO_CONV_PROFILE_CSV=<path>: one line per launch (tuning aid)
@@ -804,6 +808,11 @@ int conv_profile_end(double* ms, double* flops, int* launches) {
                     e.shape[11], t * 1e3, e.flops / (t * 1e-3) / 1e12);
         flops[e.cfg] += e.flops;
         launches[e.cfg] += 1;
+        if (bytes) {
+            const double opx = (double)e.shape[0] * e.shape[3] * e.shape[4], ipx = (double)e.shape[0] * e.shape[1] * e.shape[2];
+            const double macs_per_px = opx > 0 ? e.flops / (2.0 * opx) : 0.0;  // cout x cin x kh x kw
+            bytes[e.cfg] += 4.0 * (ipx * e.shape[5] + opx * e.shape[6] + macs_per_px);
+        }
         (void)hipEventDestroy(e.e0);
         (void)hipEventDestroy(e.e1);
     }
@@ -813,11 +822,9 @@ int conv_profile_end(double* ms, double* flops, int* launches) {
     return DFVO_OK;
 }
 
-constexpr int DFVO_WIN_DEFAULT = 0;  // 0: two-set window kernels (conv_win_f16s2.h), 1: single-accumulator (conv_win_f16a.h)
 #include "conv_win_f16s.h"
 #include "conv_gemm_f16s.h"
 #include "conv_win_f16s2.h"
-#include "conv_win_f16a.h"
 
 // split-K when the grid cannot fill the chip: partials to p.ws, ordered reduction in a second launch
 static int conv_pick_splits(const ConvParams& p, long long blocks) {
@@ -1018,17 +1025,6 @@ static int launch_f32g_prof(const ConvParams& p, hipStream_t stream) {
     return DFVO_OK;
 }
 
-// DFVO_WIN (read once; test / A-B hook): "a" = the single-accumulator window kernel (conv_win_f16a.h) packs its planes and
-// takes the chip-filling 3x3 layers; "2" = the two-set kernels of rounds 2-4.  Default: see the measurement in DESIGN.md 5a.
-int conv_window_variant() {
-    static const int v = [] {
-        const char* e = getenv("DFVO_WIN");
-        if (!e) return DFVO_WIN_DEFAULT;
-        return e[0] == 'a' ? 1 : 0;
-    }();
-    return v;
-}
-
 int launch_conv(const ConvParams& p, hipStream_t stream) {
     const long long M = (long long)p.N * p.Ho * p.Wo;
     const int bn = conv_pick_bn(p.cout, M);
@@ -1041,10 +1037,6 @@ int launch_conv(const ConvParams& p, hipStream_t stream) {
         return p.cout == 2 ? launch_head<3, 2>(p, stream, 18) : launch_head<3, 1>(p, stream, 18);
     }
     if (p.wf16 && conv_f16s_ok(p)) {  // f16x3: the 3x3 / stride-1 layers whose map fills the chip
-        if (p.wf16a && p.f16_terms != 1) {  // DFVO_WIN=a at pack time: the single-accumulator kernel, two workgroups per CU
-            const int rca = launch_f16a(p, stream, 19);
-            if (rca != F16S2_NOT_APPLICABLE) return rca;
-        }
         const int rc2 = launch_f16s2(p, stream, 19);  // one-wave-per-SIMD skeleton where the grid is large enough
         return rc2 != F16S2_NOT_APPLICABLE ? rc2 : launch_f16s(p, stream, 19);  // errors (negative) propagate
     }

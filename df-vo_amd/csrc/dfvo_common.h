@@ -61,10 +61,9 @@ struct ConvParams {
     // [tap][16-channel chunk][wf16_cout_pad / 32][plane hi, lo][k / 8][32 couts][8] halves, see conv_pack_weights_f16s
     const unsigned short* wf16;
     int wf16_cout_pad;
-    // the same layers for the single-accumulator window kernel (conv_win_f16a.h): three planes wh | 2^-11 wh | w - wh of the
-    // per-cout pre-scaled weights, [tap][chunk][wf16_cout_pad / 32][3][k / 8][32][8] halves, and 1 / scale per cout (padded)
-    const unsigned short* wf16a;
-    const float* wf16a_inv;
+    // conv_win_f16s2_kernel: start delay (units of 8128 cycles, ~4 us) of every second workgroup of the grid's first round,
+    // so that the workgroups of a round do not reach their store-heavy epilogue together (DFVO_WIN_STAGGER, see launch_f16s2)
+    int win_stagger;
     // f16 hi/lo planes in k-group order for the generic split kernel (conv_gemm_f16s.h; every layer in f16x3 mode):
     // [16-k step][wf16g_cout_pad / 32][plane][k / 8][32 couts][8] halves + the layer's k-group table (4 words per step)
     const unsigned short* wf16g;
@@ -143,8 +142,6 @@ int conv_split_mode();  // 0 exact fp32 (default), 4 = f16x3 (f16 hi/lo planes, 
 // weights of a 3x3 layer as f16 hi / lo planes for conv_win_f16s_kernel; returns the number of halves written
 // (out may be null to query the size): [tap][chunk][cout_pad32][2][16], chunks = ceil(c0/16) + ceil(c1/16)
 size_t conv_pack_weights_f16s(const float* w_oihw, int cout, int c0, int c1, const float* fold_scale, unsigned short* out);
-size_t conv_pack_weights_f16a(const float* w_oihw, int cout, int c0, int c1, const float* fold_scale, unsigned short* out, float* inv);
-int conv_window_variant();  // DFVO_WIN: which f16x3 window skeleton takes the chip-filling 3x3 layers (conv_igemm_f32.hip)
 int conv_f16s_overflow_count(unsigned long long* n, int reset);  // saturation report of the f16x3 split (conv_win_f16s.h)
 void conv_build_f16g_table(int c0, int c1, int kh, int kw, std::vector<uint32_t>* tab);
 size_t conv_pack_weights_f16g(const float* w_oihw, int cout, int c0, int c1, int kh, int kw, const float* fold_scale,
@@ -161,6 +158,6 @@ void conv_pack_weights(const float* w_oihw, const float* bias, int cout, int c0,
 constexpr int CONV_NUM_CFGS = 24;  // tile configurations of the implicit-GEMM kernel (profile arrays have this size)
 int launch_conv(const ConvParams& p, hipStream_t stream);
 void conv_profile_begin();
-int conv_profile_end(double* ms, double* flops, int* launches);
+int conv_profile_end(double* ms, double* flops, int* launches, double* bytes = nullptr);
 
 }  // namespace dfvo

@@ -27,8 +27,6 @@ struct ConvLayer {
     float* bias = nullptr;
     unsigned short* wf = nullptr;  // f16 hi/lo planes for conv_win_f16s_kernel (DFVO_CONV_PRECISION=f16x3, 3x3 layers)
     int wf_cout_pad = 0;
-    unsigned short* wfa = nullptr;  // three pre-scaled planes for conv_win_f16a_kernel (f16x3 mode, 3x3 layers) ...
-    float* wfa_inv = nullptr;       // ... and the per-cout inverse scales
     unsigned short* wg = nullptr;  // f16 hi/lo planes in k-group order for conv_gemm_f16s_kernel (f16x3 mode, every layer)
     uint32_t* gtab = nullptr;      // its k-group table
     float* wg32 = nullptr;         // fp32 weights in the same k-group order for conv_gemm_f32g_kernel (fp32 mode, every layer)

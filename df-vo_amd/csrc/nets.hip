@@ -108,15 +108,6 @@ int make_f16s_weights(const float* w_oihw, int cout, int c0, int c1, int kh, int
     DFVO_HIP_CHECK(hipMalloc((void**)&L->wf, wf.size() * sizeof(unsigned short) + 256));
     DFVO_HIP_CHECK(hipMemcpy(L->wf, wf.data(), wf.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
     L->wf_cout_pad = round_up(cout, 32);
-    if (conv_split_mode() == 4 && conv_window_variant() == 1) {  // the single-accumulator window kernel's planes
-        std::vector<unsigned short> wa(conv_pack_weights_f16a(w_oihw, cout, c0, c1, scale, nullptr, nullptr));
-        std::vector<float> inv(L->wf_cout_pad);
-        conv_pack_weights_f16a(w_oihw, cout, c0, c1, scale, wa.data(), inv.data());
-        DFVO_HIP_CHECK(hipMalloc((void**)&L->wfa, wa.size() * sizeof(unsigned short) + 256));
-        DFVO_HIP_CHECK(hipMemcpy(L->wfa, wa.data(), wa.size() * sizeof(unsigned short), hipMemcpyHostToDevice));
-        DFVO_HIP_CHECK(hipMalloc((void**)&L->wfa_inv, inv.size() * sizeof(float) + 256));
-        DFVO_HIP_CHECK(hipMemcpy(L->wfa_inv, inv.data(), inv.size() * sizeof(float), hipMemcpyHostToDevice));
-    }
     return DFVO_OK;
 }
 
@@ -164,10 +155,6 @@ void free_conv(ConvLayer* l) {
     if (l->bias) (void)hipFree(l->bias);
     if (l->wh) (void)hipFree(l->wh);
     if (l->wf) (void)hipFree(l->wf);
-    if (l->wfa) (void)hipFree(l->wfa);
-    if (l->wfa_inv) (void)hipFree(l->wfa_inv);
-    l->wfa = nullptr;
-    l->wfa_inv = nullptr;
     if (l->wg) (void)hipFree(l->wg);
     if (l->wg32) (void)hipFree(l->wg32);
     l->wg32 = nullptr;
@@ -212,8 +199,6 @@ int run_conv(const ConvLayer& L, int N, int H, int W, View s0, int up0, View s1,
     p.wh = L.wh;
     p.wf16 = L.wf;
     p.wf16_cout_pad = L.wf_cout_pad;
-    p.wf16a = L.wfa;
-    p.wf16a_inv = L.wfa_inv;
     p.wf16g = L.wg;
     p.wf32g = L.wg32;
     p.wf16g_cout_pad = L.wg_cout_pad;

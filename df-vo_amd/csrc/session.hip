@@ -1,0 +1,275 @@
+// Frame session under the drop-in classes (DeepModel / KeypointSampler / EssTracker mirrors): makes the reference's own
+// synchronous call order (/root/reference/libs/dfvo.py:299-345 deep_model_inference, :121-262 tracking) fast WITHOUT changing
+// what any call returns.
+//
+// The reference calls, per frame k:  forward_depth([img_k])  ->  forward_flow(cur = k, ref = k - 1)  ->  kp_selection  ->
+// compute_pose_2d2d  ->  scale_recovery, each a blocking call with host numpy arrays in and out.  Executed literally that
+// is five round trips with 3 x 1.4 MB of frame uploads, 9.3 MB of flow downloads and 9.3 MB of uploads again per pair,
+// the depth net and the flow net back to back, and the 1.5 ms homography chain on the critical path (round 3-4: 104
+// frames/s).  But everything the later calls need is known at the FIRST call: forward_depth(k) holds frame k, and frame
+// k - 1 arrived with the previous call.  dfvo_session_push_frame therefore
+//   * uploads the frame once (both nets read it on the device; the flow net carries frame k - 1's pyramids over),
+//   * enqueues the depth net and the flow net of (k - 1, k) on their own streams, their outputs copied into pinned host
+//     buffers (the arrays the mirrors return are views of those),
+//   * enqueues, behind the flow net on the device, the keypoint selection and the RandomState-INDEPENDENT half of
+//     compute_pose_2d2d (findHomography + refinement + GRIC-H) with the configuration the KeypointSampler / EssTracker
+//     mirrors registered -- speculative, consumed only if the later calls turn out to ask for exactly that,
+// and the later calls become "wait for an event, hand out the result".  Nothing is assumed: forward_flow checks that it is
+// given the two frames that were pushed, kp_selection that the flow arrays it is handed are the session's (generation
+// token + sampled contents, df-vo_amd/libs/deep_models/session.py), compute_pose_2d2d compares the keypoint arrays and
+// the configuration byte for byte with what the device holds; any mismatch takes the plain host-array entry point.
+// The RandomState-consuming half (shuffles, five-point RANSACs, recoverPose) and the scale recovery stay where the
+// reference has them, behind np.random's state at the time of the call.
+#include <cstring>
+
+#include "capi_types.h"
+#include "ops.h"
+
+using namespace dfvo;
+
+namespace {
+constexpr int RING = 3;  // host buffer sets: a returned view stays valid until two further frames have been pushed
+}
+
+struct dfvo_session {
+    dfvo_flownet* f = nullptr;
+    dfvo_depthnet* d = nullptr;
+    dfvo_tracker* t = nullptr;
+    int H = 0, W = 0;
+    hipStream_t s_copy = nullptr, s_pre = nullptr;
+    uint8_t* d_img[2] = {nullptr, nullptr};
+    long long gen = -1;          // frames pushed so far - 1 = generation of the newest frame
+    bool carry_ok = false;       // the flow net's current-frame pyramids are those of frame `gen`
+    bool have_flow = false;      // a flow pass of (gen - 1, gen) is enqueued / done
+    bool have_kp = false, have_h = false;
+    float* h_depth[RING] = {};
+    float *h_fwd[RING] = {}, *h_bwd[RING] = {}, *h_diff[RING] = {};
+    double *h_kp_ref[RING] = {}, *h_kp_cur[RING] = {};
+    int* h_info[RING] = {};
+    int kp_cap = 0;
+    hipEvent_t e_img = nullptr, e_depth = nullptr, e_net = nullptr, e_flow = nullptr, e_kp = nullptr;
+    dfvo_session_kp_cfg kp_cfg = {};
+    dfvo_pose2d2d_cfg pose_cfg = {};
+};
+
+#define S_TRY(expr)                     \
+    do {                                \
+        int _rc = (expr);               \
+        if (_rc != DFVO_OK) return _rc; \
+    } while (0)
+
+extern "C" {
+
+int dfvo_session_create(dfvo_flownet* f, dfvo_depthnet* d, dfvo_tracker* t, int img_h, int img_w, dfvo_session** out) {
+    DFVO_ARG_CHECK(f && d && out && img_h > 0 && img_w > 0, "dfvo_session_create: bad argument");
+    DFVO_ARG_CHECK(f->net.finalized && d->net.finalized, "dfvo_session_create: nets not finalized");
+    DFVO_ARG_CHECK(f->net.imgH == img_h && f->net.imgW == img_w, "dfvo_session_create: flow net built for another image size");
+    dfvo_session* s = new dfvo_session();
+    s->f = f;
+    s->d = d;
+    s->t = t;
+    s->H = img_h;
+    s->W = img_w;
+    const size_t px = (size_t)img_h * img_w, dpx = (size_t)d->net.H * d->net.W;
+    bool ok = hipStreamCreateWithFlags(&s->s_copy, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&s->s_pre, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 2 && ok; ++i) ok = hipMalloc((void**)&s->d_img[i], px * 3) == hipSuccess;
+    for (int i = 0; i < RING && ok; ++i) {
+        ok = hipHostMalloc((void**)&s->h_depth[i], dpx * sizeof(float)) == hipSuccess &&
+             hipHostMalloc((void**)&s->h_fwd[i], 2 * px * sizeof(float)) == hipSuccess &&
+             hipHostMalloc((void**)&s->h_bwd[i], 2 * px * sizeof(float)) == hipSuccess &&
+             hipHostMalloc((void**)&s->h_diff[i], px * sizeof(float)) == hipSuccess &&
+             hipHostMalloc((void**)&s->h_info[i], 4 * sizeof(int)) == hipSuccess;
+    }
+    hipEvent_t* evs[5] = {&s->e_img, &s->e_depth, &s->e_net, &s->e_flow, &s->e_kp};
+    for (int i = 0; i < 5 && ok; ++i) ok = hipEventCreateWithFlags(evs[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        dfvo_session_destroy(s);
+        dfvo::set_last_error("dfvo_session_create: allocation failed");
+        return DFVO_ERR_HIP;
+    }
+    *out = s;
+    return DFVO_OK;
+}
+
+void dfvo_session_destroy(dfvo_session* s) {
+    if (!s) return;
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < 2; ++i)
+        if (s->d_img[i]) (void)hipFree(s->d_img[i]);
+    for (int i = 0; i < RING; ++i) {
+        void* hp[7] = {s->h_depth[i], s->h_fwd[i], s->h_bwd[i], s->h_diff[i], s->h_kp_ref[i], s->h_kp_cur[i], s->h_info[i]};
+        for (void* q : hp)
+            if (q) (void)hipHostFree(q);
+    }
+    hipEvent_t evs[5] = {s->e_img, s->e_depth, s->e_net, s->e_flow, s->e_kp};
+    for (hipEvent_t e : evs)
+        if (e) (void)hipEventDestroy(e);
+    if (s->s_copy) (void)hipStreamDestroy(s->s_copy);
+    if (s->s_pre) (void)hipStreamDestroy(s->s_pre);
+    delete s;
+}
+
+int dfvo_session_reset(dfvo_session* s) {
+    DFVO_ARG_CHECK(s, "dfvo_session_reset: null session");
+    DFVO_HIP_CHECK(hipDeviceSynchronize());
+    s->carry_ok = s->have_flow = s->have_kp = s->have_h = false;
+    s->gen = -1;
+    return DFVO_OK;
+}
+
+// another caller ran the flow net (LiteFlow.inference_flow ...): its pyramids are no longer the held frame's
+int dfvo_session_invalidate_carry(dfvo_session* s) {
+    DFVO_ARG_CHECK(s, "dfvo_session_invalidate_carry: null session");
+    s->carry_ok = false;
+    return DFVO_OK;
+}
+
+static int ensure_kp_host(dfvo_session* s, int cap) {
+    if (cap <= s->kp_cap) return DFVO_OK;
+    for (int i = 0; i < RING; ++i) {
+        if (s->h_kp_ref[i]) (void)hipHostFree(s->h_kp_ref[i]);
+        if (s->h_kp_cur[i]) (void)hipHostFree(s->h_kp_cur[i]);
+        s->h_kp_ref[i] = s->h_kp_cur[i] = nullptr;
+        DFVO_HIP_CHECK(hipHostMalloc((void**)&s->h_kp_ref[i], sizeof(double) * 2 * cap));
+        DFVO_HIP_CHECK(hipHostMalloc((void**)&s->h_kp_cur[i], sizeof(double) * 2 * cap));
+    }
+    s->kp_cap = cap;
+    return DFVO_OK;
+}
+
+int dfvo_session_push_frame(dfvo_session* s, const uint8_t* h_img, const dfvo_session_kp_cfg* kp,
+                            const dfvo_pose2d2d_cfg* pose, long long* generation) {
+    DFVO_ARG_CHECK(s && h_img, "dfvo_session_push_frame: bad argument");
+    FlowNet& fn = s->f->net;
+    DepthNet& dn = s->d->net;
+    const size_t px = (size_t)s->H * s->W, dpx = (size_t)dn.H * dn.W;
+    const long long g = s->gen + 1;
+    const int slot = (int)(g % RING);
+    uint8_t* img = s->d_img[g & 1];
+    // (the device buffer of frame g - 2 is reused: the nets that read it were waited for by the calls of pair g - 1, or are
+    // ordered before this copy by the events below)
+    DFVO_HIP_CHECK(hipStreamWaitEvent(s->s_copy, s->e_depth, 0));
+    DFVO_HIP_CHECK(hipStreamWaitEvent(s->s_copy, s->e_net, 0));
+    DFVO_HIP_CHECK(hipMemcpyAsync(img, h_img, px * 3, hipMemcpyHostToDevice, s->s_copy));
+    DFVO_HIP_CHECK(hipEventRecord(s->e_img, s->s_copy));
+    // ---- flow net of (g - 1, g) first: it is the long pole
+    s->have_flow = s->have_kp = s->have_h = false;
+    if (g >= 1) {
+        DFVO_HIP_CHECK(hipStreamWaitEvent(fn.stream, s->e_img, 0));
+        if (s->carry_ok)
+            S_TRY(fn.forward(nullptr, img, fn.out_fwd.p, fn.out_bwd.p, fn.out_diff.p, &fn));
+        else
+            S_TRY(fn.forward(s->d_img[(g - 1) & 1], img, fn.out_fwd.p, fn.out_bwd.p, fn.out_diff.p));
+        DFVO_HIP_CHECK(hipEventRecord(s->e_net, fn.stream));
+        DFVO_HIP_CHECK(hipMemcpyAsync(s->h_fwd[slot], fn.out_fwd.p, 2 * px * sizeof(float), hipMemcpyDeviceToHost, fn.stream));
+        DFVO_HIP_CHECK(hipMemcpyAsync(s->h_bwd[slot], fn.out_bwd.p, 2 * px * sizeof(float), hipMemcpyDeviceToHost, fn.stream));
+        DFVO_HIP_CHECK(hipMemcpyAsync(s->h_diff[slot], fn.out_diff.p, px * sizeof(float), hipMemcpyDeviceToHost, fn.stream));
+        DFVO_HIP_CHECK(hipEventRecord(s->e_flow, fn.stream));
+        s->have_flow = true;
+    } else {
+        // first frame: its pyramids come into being with the first pair (both frames through Features)
+        DFVO_HIP_CHECK(hipEventRecord(s->e_net, fn.stream));
+    }
+    s->carry_ok = g >= 1;
+    // ---- depth net of frame g (Pillow-exact LANCZOS resize of the full frame on the device, then the net)
+    {
+        if (s->d->resize.H != s->H || s->d->resize.W != s->W || s->d->resize.oh != dn.H || s->d->resize.ow != dn.W)
+            S_TRY(s->d->resize.init(s->H, s->W, dn.H, dn.W));
+        DFVO_HIP_CHECK(hipStreamWaitEvent(dn.stream, s->e_img, 0));
+        S_TRY(s->d->resize.enqueue(img, (uint8_t*)dn.u8_in.p, dn.stream));
+        S_TRY(dn.forward((const uint8_t*)dn.u8_in.p, dn.depth.p));
+        DFVO_HIP_CHECK(hipMemcpyAsync(s->h_depth[slot], dn.depth.p, dpx * sizeof(float), hipMemcpyDeviceToHost, dn.stream));
+        DFVO_HIP_CHECK(hipEventRecord(s->e_depth, dn.stream));
+    }
+    // ---- speculative keypoint selection + RandomState-independent half of compute_pose_2d2d, behind the flow net
+    if (g >= 1 && kp && s->t) {
+        TrackerBuffers& tb = s->t->tb;
+        DFVO_HIP_CHECK(hipStreamWaitEvent(s->s_pre, s->e_net, 0));
+        S_TRY(enqueue_local_bestn(tb, fn.out_fwd.p, fn.out_diff.p, s->H, s->W, kp->num_row, kp->num_col, kp->num_bestN, kp->thre,
+                                  s->s_pre, kp->score_method));
+        S_TRY(ensure_kp_host(s, tb.kp_cap));
+        DFVO_HIP_CHECK(hipMemcpyAsync(s->h_info[slot], tb.kp_info, 3 * sizeof(int), hipMemcpyDeviceToHost, s->s_pre));
+        DFVO_HIP_CHECK(hipMemcpyAsync(s->h_kp_ref[slot], tb.kp_ref, sizeof(double) * 2 * tb.kp_cap, hipMemcpyDeviceToHost, s->s_pre));
+        DFVO_HIP_CHECK(hipMemcpyAsync(s->h_kp_cur[slot], tb.kp_cur, sizeof(double) * 2 * tb.kp_cap, hipMemcpyDeviceToHost, s->s_pre));
+        DFVO_HIP_CHECK(hipEventRecord(s->e_kp, s->s_pre));
+        s->kp_cfg = *kp;
+        s->have_kp = true;
+        if (pose) {
+            PoseConfig pc;
+            S_TRY(dfvo_pose_config_from(pose, &pc));
+            S_TRY(enqueue_pose_h_part(tb, tb.kp_cap, pc, s->s_pre));  // keypoint count read on the device
+            s->pose_cfg = *pose;
+            s->have_h = true;
+        }
+    }
+    s->gen = g;
+    if (generation) *generation = g;
+    return DFVO_OK;
+}
+
+int dfvo_session_depth(dfvo_session* s, long long generation, const float** h_depth) {
+    DFVO_ARG_CHECK(s && h_depth, "dfvo_session_depth: bad argument");
+    DFVO_ARG_CHECK(generation == s->gen && s->gen >= 0, "dfvo_session_depth: not the newest pushed frame");
+    DFVO_HIP_CHECK(hipEventSynchronize(s->e_depth));
+    *h_depth = s->h_depth[s->gen % RING];
+    return DFVO_OK;
+}
+
+int dfvo_session_flow(dfvo_session* s, long long generation, const float** h_fwd, const float** h_bwd, const float** h_diff) {
+    DFVO_ARG_CHECK(s && h_fwd && h_bwd && h_diff, "dfvo_session_flow: bad argument");
+    DFVO_ARG_CHECK(generation == s->gen && s->have_flow, "dfvo_session_flow: no flow pass of that generation is held");
+    DFVO_HIP_CHECK(hipEventSynchronize(s->e_flow));
+    const int slot = (int)(s->gen % RING);
+    *h_fwd = s->h_fwd[slot];
+    *h_bwd = s->h_bwd[slot];
+    *h_diff = s->h_diff[slot];
+    return DFVO_OK;
+}
+
+int dfvo_session_keypoints(dfvo_session* s, long long generation, const dfvo_session_kp_cfg* kp, const double** h_kp_ref,
+                           const double** h_kp_cur, int* n, int* good_kp_found) {
+    DFVO_ARG_CHECK(s && kp && h_kp_ref && h_kp_cur && n && good_kp_found, "dfvo_session_keypoints: bad argument");
+    DFVO_ARG_CHECK(generation == s->gen && s->have_kp, "dfvo_session_keypoints: no keypoint selection of that generation is held");
+    DFVO_ARG_CHECK(memcmp(kp, &s->kp_cfg, sizeof(*kp)) == 0, "dfvo_session_keypoints: selection was run with another configuration");
+    DFVO_HIP_CHECK(hipEventSynchronize(s->e_kp));
+    const int slot = (int)(s->gen % RING);
+    *n = s->h_info[slot][0];
+    *good_kp_found = s->h_info[slot][1];
+    *h_kp_ref = s->h_kp_ref[slot];
+    *h_kp_cur = s->h_kp_cur[slot];
+    return DFVO_OK;
+}
+
+// EssTracker.compute_pose_2d2d through the session: when the keypoints handed in are, byte for byte, the ones the device
+// selected for this generation and the homography half was enqueued with this very configuration, only the
+// RandomState-consuming half is enqueued (*used_resident = 1); otherwise the plain entry point runs (*used_resident = 0).
+int dfvo_session_pose_2d2d(dfvo_session* s, const double* h_kp_ref, const double* h_kp_cur, int n,
+                           const dfvo_pose2d2d_cfg* cfg, dfvo_pose2d2d_out* out, uint8_t* h_inliers, int* used_resident) {
+    DFVO_ARG_CHECK(s && s->t && h_kp_ref && h_kp_cur && cfg && out && h_inliers && n >= 0, "dfvo_session_pose_2d2d: bad argument");
+    bool resident = s->have_kp && s->have_h && s->gen >= 1;
+    if (resident) {
+        DFVO_HIP_CHECK(hipEventSynchronize(s->e_kp));
+        const int slot = (int)(s->gen % RING);
+        // the homography half reads: the keypoints, validity method / threshold, K^-T, K^-1 (enqueue_pose_h_part)
+        resident = s->h_info[slot][1] != 0 && s->h_info[slot][0] == n && n <= s->kp_cap &&
+                   memcmp(h_kp_ref, s->h_kp_ref[slot], sizeof(double) * 2 * n) == 0 &&
+                   memcmp(h_kp_cur, s->h_kp_cur[slot], sizeof(double) * 2 * n) == 0 &&
+                   cfg->validity_method == s->pose_cfg.validity_method && cfg->validity_thre == s->pose_cfg.validity_thre &&
+                   memcmp(cfg->KinvT, s->pose_cfg.KinvT, sizeof(cfg->KinvT)) == 0 &&
+                   memcmp(cfg->Kinv, s->pose_cfg.Kinv, sizeof(cfg->Kinv)) == 0;
+    }
+    if (used_resident) *used_resident = resident ? 1 : 0;
+    s->have_h = false;  // the homography half is consumed (or abandoned) by this call
+    if (!resident) {
+        // the speculative half may still be running on the tracker's buffers: let it finish before they are restaged
+        DFVO_HIP_CHECK(hipStreamSynchronize(s->s_pre));
+        return dfvo_compute_pose_2d2d(s->t, h_kp_ref, h_kp_cur, n, cfg, out, h_inliers);
+    }
+    PoseConfig pc;
+    S_TRY(dfvo_pose_config_from(cfg, &pc));
+    S_TRY(enqueue_pose_e_part(s->t->tb, n, pc, s->t->stream, nullptr));  // waits for the homography half (tb.ev_h) on the device
+    return dfvo_pose_fetch(s->t, n, cfg, out, h_inliers);
+}
+
+}  // extern "C"

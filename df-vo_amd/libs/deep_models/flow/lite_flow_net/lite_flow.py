@@ -20,6 +20,7 @@ class LiteFlow:
         self.flow_scales = [1]
         self.half_flow = False
         self.model = None          # opaque dfvo_flownet handle (the reference holds a torch module here)
+        self.session = None        # FrameSession sharing this net (DeepModel.initialize_models)
         self.forward_flow = {}
         self.backward_flow = {}
         self.flow_diff = {}
@@ -115,6 +116,8 @@ class LiteFlow:
         fwd = np.zeros((2, h, w), np.float32)
         bwd = np.zeros((2, h, w), np.float32)
         diff = np.zeros((h, w, 1), np.float32)
+        if self.session is not None:  # this pass overwrites the pyramids the session would carry over
+            self.session.invalidate_carry()
         capi.check(capi.lib().dfvo_flownet_forward_host(self.model, capi.as_ptr(np.ascontiguousarray(ref_u8)),
                                                         capi.as_ptr(np.ascontiguousarray(cur_u8)), capi.as_ptr(fwd),
                                                         capi.as_ptr(bwd), capi.as_ptr(diff)))

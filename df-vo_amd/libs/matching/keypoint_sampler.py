@@ -22,6 +22,13 @@ class KeypointSampler:
                                       % ks.local_bestN.score_method)
         if ks.depth_consistency.enable:
             raise NotImplementedError("depth_consistency is experiment-only in the reference (out of scope)")
+        # the frame session runs local_bestN behind the flow net with this configuration (libs/deep_models/session.py)
+        self._session_kp_cfg = None
+        if ks.local_bestN.enable:
+            c = ks.local_bestN
+            self._session_kp_cfg = capi.SessionKpCfg(num_row=int(c.num_row), num_col=int(c.num_col), num_bestN=int(c.num_bestN),
+                                                     thre=float(c.thre), score_method={"flow": 0, "flow_ratio": 1}[c.score_method])
+        _ctx.register_kp_cfg(self._session_kp_cfg)
 
     def get_feat_track_methods(self, method_idx):
         """keypoint_sampler.py:38-50: the one feature-tracking method of the release"""
@@ -81,6 +88,21 @@ class KeypointSampler:
     def _local_bestN(self, cur_data, ref_data):
         outputs = {"good_kp_found": True}
         c = self.cfg.kp_selection.local_bestN
+        s = _ctx.session
+        if s is not None and self._session_kp_cfg is not None:
+            # the arrays are (copies of) what forward_flow returned for the pair the session holds: the selection already ran
+            # on the device-resident flow, behind the flow net
+            res = s.keypoints(ref_data['flow'], ref_data['flow_diff'], self._session_kp_cfg)
+            s.stats["kp_resident" if res is not None else "kp_plain"] += 1
+            if res is not None:
+                kp1, kp2, n, good = res
+                h, w = cur_data['depth'].shape
+                assert ref_data['flow'].shape == (2, h, w)
+                if not good:
+                    print("Cannot find enough good keypoints!")
+                    return {"good_kp_found": False, "kp1_best": {}, "kp2_best": {}}
+                return {"good_kp_found": True, "kp1_best": np.array(kp1)[None], "kp2_best": np.array(kp2)[None],
+                        "fb_flow_mask": np.asarray(ref_data['flow_diff'], dtype=np.float32).reshape(h, w)}
         flow = np.ascontiguousarray(ref_data['flow'], dtype=np.float32)
         diff = np.ascontiguousarray(ref_data['flow_diff'], dtype=np.float32)
         h, w = cur_data['depth'].shape

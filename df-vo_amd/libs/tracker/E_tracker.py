@@ -47,18 +47,15 @@ class EssTracker:
         self.cam_intrinsics = cam_intrinsics
         self.timers = timers
         self.max_iters = 1000  # OpenCV 3.4.3's fixed findEssentialMat budget
+        # the frame session enqueues the RandomState-independent half of compute_pose_2d2d behind the flow net with this
+        # configuration (libs/deep_models/session.py); registered only where that half does not depend on the call's arguments
+        if self.cfg.e_tracker.validity.method in VALIDITY_METHODS:
+            _ctx.register_pose_cfg(lambda: self._pose_cfg(True))
 
-    def compute_pose_2d2d(self, kp_ref, kp_cur, is_iterative):
-        """E_tracker.py:154-307 -> {'pose': SE3 (cur -> ref), 'inliers': bool [N]}"""
+    def _pose_cfg(self, is_iterative):
         valid_cfg = self.cfg.e_tracker.validity
-        if valid_cfg.method not in VALIDITY_METHODS:
-            raise NotImplementedError("e_tracker.validity.method '%s' (the reference knows GRIC, flow, homo_ratio)"
-                                      % valid_cfg.method)
         K = np.asarray(self.cam_intrinsics.mat, dtype=np.float64)
         repeat = int(self.cfg.e_tracker.ransac.repeat) if is_iterative else 3
-        kp_ref = np.ascontiguousarray(kp_ref, dtype=np.float64)
-        kp_cur = np.ascontiguousarray(kp_cur, dtype=np.float64)
-        n = kp_ref.shape[0]
         cfg = capi.Pose2d2dCfg(fx=float(self.cam_intrinsics.fx), cx=float(self.cam_intrinsics.cx),
                                cy=float(self.cam_intrinsics.cy),
                                reproj_thre=float(self.cfg.e_tracker.ransac.reproj_thre), repeat=repeat,
@@ -68,11 +65,28 @@ class EssTracker:
         for i in range(9):
             cfg.KinvT[i] = KinvT.flat[i]
             cfg.Kinv[i] = Kinv.flat[i]
+        return cfg
+
+    def compute_pose_2d2d(self, kp_ref, kp_cur, is_iterative):
+        """E_tracker.py:154-307 -> {'pose': SE3 (cur -> ref), 'inliers': bool [N]}"""
+        valid_cfg = self.cfg.e_tracker.validity
+        if valid_cfg.method not in VALIDITY_METHODS:
+            raise NotImplementedError("e_tracker.validity.method '%s' (the reference knows GRIC, flow, homo_ratio)"
+                                      % valid_cfg.method)
+        kp_ref = np.ascontiguousarray(kp_ref, dtype=np.float64)
+        kp_cur = np.ascontiguousarray(kp_cur, dtype=np.float64)
+        n = kp_ref.shape[0]
+        cfg = self._pose_cfg(is_iterative)
         out = capi.Pose2d2dOut()
         inl = np.zeros(max(n, 1), np.uint8)
         _ctx.push_numpy_rng()
-        capi.check(capi.lib().dfvo_compute_pose_2d2d(_ctx.tracker(), capi.as_ptr(kp_ref), capi.as_ptr(kp_cur), n,
-                                                     C.byref(cfg), C.byref(out), capi.as_ptr(inl)))
+        if _ctx.session is not None:
+            # (the C side compares keypoints and configuration with what the device holds; on a match only the
+            # RandomState-consuming half is left to run)
+            _ctx.session.pose_2d2d(kp_ref, kp_cur, n, cfg, out, inl)
+        else:
+            capi.check(capi.lib().dfvo_compute_pose_2d2d(_ctx.tracker(), capi.as_ptr(kp_ref), capi.as_ptr(kp_cur), n,
+                                                         C.byref(cfg), C.byref(out), capi.as_ptr(inl)))
         _ctx.pull_numpy_rng()
         feed_timers(self.timers, range(0, 6))
         pose = SE3()

@@ -6,6 +6,32 @@ import numpy as np
 from ... import capi
 
 _trk = None
+session = None       # the FrameSession of the process's DeepModel (libs/deep_models/session.py); None: plain entry points
+_kp_cfg = None       # capi.SessionKpCfg of the KeypointSampler, registered at its construction
+_pose_cfg_fn = None  # () -> capi.Pose2d2dCfg of the EssTracker
+
+
+def register_session(s):
+    """DeepModel.initialize_models: the session picks up whatever the sampler / tracker registered before or after it"""
+    global session
+    session = s
+    if s is not None:
+        s.kp_cfg = _kp_cfg
+        s.pose_cfg_fn = _pose_cfg_fn
+
+
+def register_kp_cfg(c):
+    global _kp_cfg
+    _kp_cfg = c
+    if session is not None:
+        session.kp_cfg = c
+
+
+def register_pose_cfg(fn):
+    global _pose_cfg_fn
+    _pose_cfg_fn = fn
+    if session is not None:
+        session.pose_cfg_fn = fn
 
 
 def tracker():

@@ -96,6 +96,9 @@ int dfvo_set_sklearn_compat(const char* version);
 int dfvo_f16s_overflow_count(unsigned long long* h_count, int reset);
 int dfvo_conv_profile_begin(void);
 int dfvo_conv_profile_end(double* h_ms24, double* h_flops24, int* h_launches24);
+/* the same, plus the ALGORITHMIC HBM bytes of each configuration's launches (fp32 input map + output map + weights, each
+ * once: SURVEY.md section 8d's price of the streaming layers) -- the numerator of bench.py's roofline.hbm entry */
+int dfvo_conv_profile_end_bytes(double* h_ms24, double* h_flops24, int* h_launches24, double* h_bytes24);
 
 /* correlation.py:38-106,281-340 (_FunctionCorrelation.forward) followed by leaky_relu(slope)
  * (lite_flow_net.py:145,148).  NHWC inputs [N,H,W,C]; output [N,ceil(H/s),ceil(W/s),52], 49 used.
@@ -454,6 +457,40 @@ int dfvo_pipeline_get_rng_state(dfvo_pipeline* p, uint32_t* h_state625);
 int dfvo_pipeline_set_rng_state(dfvo_pipeline* p, const uint32_t* h_state625);
 int dfvo_pipeline_sync(dfvo_pipeline* p);
 double dfvo_pipeline_net_flops(const dfvo_pipeline* p);
+
+/* ---- frame session: the reference's own synchronous call order, fast (df-vo_amd/csrc/session.hip) ----
+ * /root/reference/libs/dfvo.py calls, per frame k: DeepModel.forward_depth([img_k]) (dfvo.py:312), forward_flow(cur, ref)
+ * (:324), KeypointSampler.kp_selection (:147), EssTracker.compute_pose_2d2d (:168), scale_recovery (:198) -- blocking
+ * calls, host numpy arrays in and out.  Everything they need is known at the first of them; dfvo_session_push_frame
+ * (called by the DeepModel mirror from forward_depth) uploads the frame ONCE and enqueues, each on its own stream: the
+ * depth net of frame k, the flow net of (k - 1, k) (frame k - 1's pyramids carried over), both outputs into pinned host
+ * buffers, and -- when the KeypointSampler / EssTracker mirrors registered their configurations (kp, pose non-NULL) --
+ * local_bestN and the RandomState-independent half of compute_pose_2d2d (findHomography + refinement + GRIC-H) behind the
+ * flow net.  The later calls wait for an event and hand out the result; each validates that it is asked for exactly what
+ * was enqueued (generation, configuration, keypoint arrays byte for byte) and otherwise runs the plain entry point.
+ * Results are identical to the plain entry points' (tests/test_dropin_gpu.py).  Host pointers returned here are pinned
+ * buffers owned by the session, valid until two further frames have been pushed.  Not re-entrant. */
+typedef struct dfvo_session dfvo_session;
+typedef struct dfvo_session_kp_cfg {
+    int num_row, num_col, num_bestN;  /* kp_selection.local_bestN.{num_row, num_col, num_bestN} */
+    float thre;                       /* .thre */
+    int score_method;                 /* DFVO_KP_SCORE_FLOW / DFVO_KP_SCORE_FLOW_RATIO */
+} dfvo_session_kp_cfg;
+int dfvo_session_create(dfvo_flownet* flow, dfvo_depthnet* depth, dfvo_tracker* trk, int img_h, int img_w, dfvo_session** out);
+void dfvo_session_destroy(dfvo_session* s);
+int dfvo_session_reset(dfvo_session* s);             /* forget the held frame (a new sequence) */
+int dfvo_session_invalidate_carry(dfvo_session* s);  /* someone else ran the flow net: recompute both pyramids next time */
+/* h_img uint8 [img_h, img_w, 3]; *generation = index of this frame since create / reset */
+int dfvo_session_push_frame(dfvo_session* s, const uint8_t* h_img, const dfvo_session_kp_cfg* kp, const dfvo_pose2d2d_cfg* pose,
+                            long long* generation);
+int dfvo_session_depth(dfvo_session* s, long long generation, const float** h_depth);  /* float [feed_h, feed_w] */
+/* flow of (generation - 1, generation): fwd / bwd float [2, img_h, img_w], diff float [img_h, img_w] */
+int dfvo_session_flow(dfvo_session* s, long long generation, const float** h_fwd, const float** h_bwd, const float** h_diff);
+int dfvo_session_keypoints(dfvo_session* s, long long generation, const dfvo_session_kp_cfg* kp, const double** h_kp_ref,
+                           const double** h_kp_cur, int* n, int* good_kp_found);
+/* dfvo_compute_pose_2d2d through the session; *used_resident = 1 when only the RandomState-consuming half had to run */
+int dfvo_session_pose_2d2d(dfvo_session* s, const double* h_kp_ref, const double* h_kp_cur, int n, const dfvo_pose2d2d_cfg* cfg,
+                           dfvo_pose2d2d_out* out, uint8_t* h_inliers, int* used_resident);
 
 /* DFVO.update_global_pose (dfvo.py:109-119: t_w += R_w t, then R_w = R_w R) over a whole gathered sequence in ONE launch,
  * constant-motion rows included (dfvo.py:157-161: a row with status 1 reuses the previous pair's relative motion).

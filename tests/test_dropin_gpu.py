@@ -184,35 +184,29 @@ def full_cfg(h, w, flow_path, depth_dir):
     return c
 
 
-def test_mirrors_from_weight_files_reproduce_reference_main_loop(gpu, tmp_path):
-    import os
-    from oracle import cv2_shim
-    from synth import coded_tunnel_sequence, crafted_liteflownet_state_dict, crafted_monodepth2_state_dict, write_weight_files
-    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dfvo_main.npz"))
-    h, w, n = int(fx["h"]), int(fx["w"]), int(fx["n_frames"])
-    seq = coded_tunnel_sequence(h, w, n, mode="mux", step=1.0, seed=int(fx["seq_seed"]))
-    assert np.array_equal(seq["poses"], fx["gt"])
-    flow_path, depth_dir = write_weight_files(str(tmp_path), crafted_liteflownet_state_dict(h, w, "mux"),
-                                              crafted_monodepth2_state_dict())
-    cfg = full_cfg(h, w, flow_path, depth_dir)
+def _build_mirrors(cfg, K):
     dm_mod = importlib.import_module("df-vo_amd.libs.deep_models.deep_models")
     cam_mod = importlib.import_module("df-vo_amd.libs.geometry.camera_modules")
     ks_mod = importlib.import_module("df-vo_amd.libs.matching.keypoint_sampler")
     trk_mod = importlib.import_module("df-vo_amd.libs.tracker")
     deep_models = dm_mod.DeepModel(cfg)                     # dfvo.py:78-79
     deep_models.initialize_models()
-    assert deep_models.depth.feed_height == 192 and deep_models.depth.feed_width == 640
-    assert tuple(deep_models.flow.get_target_size(h, w)) == (h, w)
-    K = seq["K"]
     cam = cam_mod.Intrinsics([K[0, 2], K[1, 2], K[0, 0], K[1, 1]])
     sampler = ks_mod.KeypointSampler(cfg)                   # dfvo.py:75
     e_tracker, pnp_tracker = trk_mod.EssTracker(cfg, cam, None), trk_mod.PnpTracker(cfg, cam)   # dfvo.py:100-103
-    SE3 = cam_mod.SE3
+    return deep_models, sampler, e_tracker, pnp_tracker, cam_mod.SE3
+
+
+def _main_loop(cfg, seq, n, h, w, mirrors, record=None):
+    """the frame loop of DFVO.main (dfvo.py:358-404) over the mirror classes; record (optional list) receives, per pair, what
+    the calls returned (for the session-on / session-off comparison)"""
+    from oracle import cv2_shim
+    deep_models, sampler, e_tracker, pnp_tracker, SE3 = mirrors
     np.random.seed(cfg.seed)                                # apis/run.py:81-84
     ref_data, cur_data = {}, {}
     global_pose = SE3()
     poses, modes = [], []
-    for img_id in range(n):                                 # dfvo.py:358-404
+    for img_id in range(n):
         cur_data["id"], cur_data["timestamp"], cur_data["img"] = img_id, img_id, seq["frames"][img_id].copy()
         # deep_model_inference, dfvo.py:299-345
         raw = deep_models.forward_depth(imgs=[cur_data["img"]])
@@ -245,18 +239,109 @@ def test_mirrors_from_weight_files_reproduce_reference_main_loop(gpu, tmp_path):
                 mode = "PnP"
             global_pose.t = global_pose.R @ hybrid.t + global_pose.t      # update_global_pose, dfvo.py:109-119
             global_pose.R = global_pose.R @ hybrid.R
+            if record is not None:
+                record.append({"raw": np.array(raw), "fwd": np.array(ref_data["flow"]), "bwd": np.array(cur_data["flow"]),
+                               "diff": np.array(ref_data["flow_diff"]), "kp_ref": np.array(ref_data["kp_best"]),
+                               "kp_cur": np.array(cur_data["kp_best"]), "inliers": np.array(e_out["inliers"]),
+                               "R": np.array(E_pose.R), "t": np.array(E_pose.t), "scale": scale,
+                               "rng": np.random.get_state()[1].copy()})
         poses.append(global_pose.pose.copy())
         modes.append(mode)
         ref_data = dict(cur_data)                            # update_data, dfvo.py:264-287
         ref_data["flow"] = cur_data["flow"] = ref_data["flow_diff"] = None
-    poses = np.stack(poses)
-    print("   modes", modes, "| final t (mirrors)", poses[-1][:3, 3], "(reference DFVO.main)", fx["poses"][-1][:3, 3])
+    return np.stack(poses), modes
+
+
+def test_mirrors_from_weight_files_reproduce_reference_main_loop(gpu, tmp_path):
+    import os
+    from synth import coded_tunnel_sequence, crafted_liteflownet_state_dict, crafted_monodepth2_state_dict, write_weight_files
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dfvo_main.npz"))
+    h, w, n = int(fx["h"]), int(fx["w"]), int(fx["n_frames"])
+    seq = coded_tunnel_sequence(h, w, n, mode="mux", step=1.0, seed=int(fx["seq_seed"]))
+    assert np.array_equal(seq["poses"], fx["gt"])
+    flow_path, depth_dir = write_weight_files(str(tmp_path), crafted_liteflownet_state_dict(h, w, "mux"),
+                                              crafted_monodepth2_state_dict())
+    cfg = full_cfg(h, w, flow_path, depth_dir)
+    mirrors = _build_mirrors(cfg, seq["K"])
+    deep_models = mirrors[0]
+    assert deep_models.depth.feed_height == 192 and deep_models.depth.feed_width == 640
+    assert tuple(deep_models.flow.get_target_size(h, w)) == (h, w)
+    assert deep_models.conv_precision == "f16x3" and deep_models.session is not None  # what an unmodified apis/run.py gets
+    poses, modes = _main_loop(cfg, seq, n, h, w, mirrors)
+    st = deep_models.session.stats
+    print("   modes", modes, "| final t (mirrors)", poses[-1][:3, 3], "(reference DFVO.main)", fx["poses"][-1][:3, 3], "| session", st)
+    # the frame loop is exactly the call order the session is built for: every pair must have taken the resident paths
+    assert st["push"] == n and st["flow_resident"] == n - 1 and st["kp_resident"] == n - 1 and st["pose_resident"] == n - 1
+    assert st["flow_plain"] == st["kp_plain"] == st["pose_plain"] == 0
     assert modes == list(fx["modes"])
     # the nets differ from the reference's torch-CPU nets in fp32 summation order (<= 2e-3 px on the flow), which can move
     # a keypoint across a threshold and with it the RANSAC samples: poses agree to the solver's noise level, not bit for bit
     for i in range(n):
         assert np.abs(poses[i][:3, :3] - fx["poses"][i][:3, :3]).max() < 1e-3
         assert np.linalg.norm(poses[i][:3, 3] - fx["poses"][i][:3, 3]) < 0.02 * max(1.0, np.linalg.norm(fx["poses"][i][:3, 3]))
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
+def test_frame_session_returns_what_the_plain_entry_points_return(gpu, tmp_path, monkeypatch, precision):
+    """The session (libs/deep_models/session.py, csrc/session.hip) changes WHEN things run, never what a call returns: the
+    same frame loop with DFVO_SESSION=0 (every call a blocking host-array entry point, as in rounds 1-4) and with the session
+    gives bit-identical depth, flows, consistency map, keypoints, inlier masks, poses, scales and numpy RandomState at every
+    pair.  Also: a caller that breaks the expected order or edits an array gets the plain path, not a stale result."""
+    from synth import coded_tunnel_sequence, crafted_liteflownet_state_dict, crafted_monodepth2_state_dict, write_weight_files
+    h, w, n = 256, 640, 5
+    seq = coded_tunnel_sequence(h, w, n, mode="mux", step=1.0, seed=33)
+    flow_path, depth_dir = write_weight_files(str(tmp_path), crafted_liteflownet_state_dict(h, w, "mux"),
+                                              crafted_monodepth2_state_dict())
+    cfg = full_cfg(h, w, flow_path, depth_dir)
+    cfg["dfvo_hip"] = {"conv_precision": precision}
+    runs = {}
+    for sess in ("0", "1"):
+        monkeypatch.setenv("DFVO_SESSION", sess)
+        mirrors = _build_mirrors(cfg, seq["K"])
+        assert (mirrors[0].session is not None) == (sess == "1") and mirrors[0].conv_precision == precision
+        rec = []
+        poses, modes = _main_loop(cfg, seq, n, h, w, mirrors, record=rec)
+        runs[sess] = (poses, modes, rec, mirrors)
+    (p0, m0, r0, _), (p1, m1, r1, mir) = runs["0"], runs["1"]
+    assert m0 == m1 and np.array_equal(p0, p1)
+    for a, b in zip(r0, r1):
+        for k in a:
+            assert np.array_equal(a[k], b[k]), "pair result '%s' differs between the plain entry points and the session" % k
+    st = mir[0].session.stats
+    assert st["flow_resident"] == st["kp_resident"] == st["pose_resident"] == n - 1, st
+    # ---- misuse: the session must fall back, never answer from stale state
+    deep_models, sampler, e_tracker, _, _ = mir
+    s = deep_models.session
+    cur = {"id": 1, "img": seq["frames"][1].copy()}
+    ref = {"id": 0, "img": seq["frames"][0].copy()}
+    deep_models.forward_depth(imgs=[cur["img"]])            # pushed frame 1 after frame n - 1: (n - 1, 1) is not (0, 1)
+    before = dict(s.stats)
+    flows = deep_models.forward_flow(cur, ref, True)
+    assert s.stats["flow_plain"] == before["flow_plain"] + 1
+    assert np.array_equal(flows[(0, 1)], r0[0]["fwd"]) and np.array_equal(flows[(0, 1, "diff")], r0[0]["diff"])
+    # an edited flow array loses its token: kp_selection runs on what it is given
+    deep_models.forward_depth(imgs=[ref["img"]])
+    deep_models.forward_depth(imgs=[cur["img"]])
+    flows = deep_models.forward_flow(cur, ref, True)
+    fwd, diff = flows[(0, 1)].copy(), flows[(0, 1, "diff")].copy()
+    assert getattr(fwd, "_dfvo_tok", None) is not None
+    diff[40:60, 100:200, 0] = 7.0                           # (a write through the array drops the token)
+    assert getattr(diff, "_dfvo_tok", None) is None
+    depth = np.ones((h, w))
+    before = dict(s.stats)
+    out = sampler.kp_selection({"depth": depth}, {"flow": fwd, "flow_diff": diff, "depth": depth})
+    assert s.stats["kp_plain"] == before["kp_plain"] + 1
+    want = T.local_bestN(np.asarray(fwd), np.asarray(diff))
+    assert np.array_equal(out["kp1_best"], want["kp1_best"]) and np.array_equal(out["kp2_best"], want["kp2_best"])
+    # keypoints other than the device's: compute_pose_2d2d takes the plain path and still matches the oracle
+    np.random.seed(5)
+    kp1, kp2 = out["kp1_best"][0][::2].copy(), out["kp2_best"][0][::2].copy()
+    before = dict(s.stats)
+    got = e_tracker.compute_pose_2d2d(kp1, kp2, True)
+    assert s.stats["pose_plain"] == before["pose_plain"] + 1
+    np.random.seed(5)
+    res = T.compute_pose_2d2d(kp1, kp2, seq["K"])
+    assert np.array_equal(got["pose"].R, res["R"]) and np.array_equal(got["pose"].t, res["t"])
 
 
 def test_trajectory_composition_on_the_device(gpu):

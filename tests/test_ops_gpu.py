@@ -313,12 +313,16 @@ def test_conv_f16_mode(gpu, case):
 @pytest.mark.parametrize("layer", ["win_128_128", "gen_L6_192+52_128", "taps_7x1_32_49"])
 def test_f16x3_dynamic_range(gpu, case, layer):
     """The f16x3 split outside O(1) data (round-4 verdict).  x = hi + 2^-11 lo with hi = f16(x): for |x| < 2^-14 the hi
-    plane is subnormal (absolute spacing 2^-24) and the scaled residue lo = f16((x - hi) 2^11) has absolute spacing
-    2^-24 as well, so the split represents x to 2^-36 ABSOLUTE, not 2^-22 relative; below 2^-25 hi is zero and lo alone
-    carries the value (11 bits).  Stated bound, per output:  |err| <= 2^-22 sum|w x| (the normal-range term: 22-bit operands,
-    dropped lo x lo product) + 2^-35 (sum|w| max|x| [x tiny] + sum|x| max|w| [w tiny]) (the subnormal-plane term) + fp32
-    accumulation noise 2^-20 max|partial sum|.  Checked against float64 on a window layer, a K-sliced small-map layer and
-    a tap-window layer; the exact fp32 kernels' error on the same data is printed beside it."""
+    plane is subnormal (absolute spacing 2^-24) and the scaled residue lo = f16((x - hi) 2^11) has absolute spacing 2^-24
+    as well, so the split represents such an x to 2^-36 ABSOLUTE, not to 2^-22 relative: an activation of 1e-6 keeps ~16
+    bits, below 2^-25 the hi plane is zero and lo alone carries the value (11 bits).  Stated bound, per output:
+        |err| <= 2^-22 sum|w x|                      (normal range: 22-bit operands, the dropped lo x lo product)
+               + 2^-36 (sum|w| [some |x| < 2^-14] + sum|x| [some |w| < 2^-14])     (subnormal planes: absolute per element)
+               + 2^-20 sum|w x|                      (fp32 accumulation of up to a few thousand terms)
+    Checked against float64 on a window layer, a K-sliced small-map layer and a tap-window layer; the exact fp32 kernels'
+    error on the same data is printed beside it (inputs scaled by 1e-6: fp32 stays at ~2e-6 of max|ref| where f16x3 falls to
+    ~1e-5 -- the one regime where the split is not fp32-class; no layer of either net runs there: activations are O(0.1-10),
+    asserted indirectly by the nets' parity tests and directly by the range counter for the upper end)."""
     lib = gpu.lib()
     n, h, w, c0, c1, cout, kh, kw, pad = {"win_128_128": (2, 96, 160, 128, 0, 128, 3, 3, (1, 1)),
                                           "gen_L6_192+52_128": (2, 6, 19, 192, 52, 128, 3, 3, (1, 1)),
@@ -340,8 +344,7 @@ def test_f16x3_dynamic_range(gpu, case, layer):
     sw = F.conv2d(torch.ones_like(x).double(), wt.abs().double(), padding=pad)   # sum |w| over the taps inside the image
     sx = F.conv2d(x.abs().double(), torch.ones_like(wt).double(), padding=pad)   # sum |x|
     xt, wtiny = float(x.abs().min()) < 2.0 ** -14, float(wt.abs().min()) < 2.0 ** -14
-    bound = 2.0 ** -22 * sabs + 2.0 ** -20 * sabs \
-        + 2.0 ** -35 * ((sw * float(x.abs().max()) if xt else 0) + (sx * float(wt.abs().max()) if wtiny else 0))
+    bound = 2.0 ** -22 * sabs + 2.0 ** -20 * sabs + 2.0 ** -36 * ((sw if xt else 0) + (sx if wtiny else 0))
     out = {}
     for mode in (b"fp32", b"f16x3"):
         gpu.check(lib.dfvo_set_conv_precision(mode))
@@ -369,7 +372,7 @@ def test_conv_small_maps_with_k_divided_over_workgroups(gpu):
     import sys
     env = dict(os.environ, DFVO_F16G_NZ="-1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-m", "gpu", "-x", "-k",
-                        "test_conv and (resnet_512_small or resnet_256_12x40 or flow_L5 or flow_L6 or 192_out or dec_refl_up_cat_elu)"],
+                        "test_conv and not f16_mode and (resnet_512_small or resnet_256_12x40 or flow_L5 or flow_L6 or 192_out or dec_refl_up_cat_elu)"],
                        env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:]
     assert "14 passed" in r.stdout, r.stdout[-500:]  # seven cases x two precisions
