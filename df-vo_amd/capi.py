@@ -113,6 +113,7 @@ SIGNATURES = {
     "dfvo_session_destroy": (None, [_vp]),
     "dfvo_session_reset": (_i, [_vp]),
     "dfvo_session_invalidate_carry": (_i, [_vp]),
+    "dfvo_session_quiesce": (_i, [_vp]),
     "dfvo_session_push_frame": (_i, [_vp, _vp, _vp, _vp, C.POINTER(C.c_longlong)]),
     "dfvo_session_depth": (_i, [_vp, C.c_longlong, C.POINTER(_vp)]),
     "dfvo_session_flow": (_i, [_vp, C.c_longlong, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),

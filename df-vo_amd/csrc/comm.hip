@@ -13,6 +13,7 @@
 #include <string>
 #include <vector>
 
+#include <cstdlib>
 #include <cstring>
 
 #include "dfvo_common.h"
@@ -32,13 +33,20 @@ Rccl* rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
+        // DFVO_RCCL_LIB (test hook, tests/test_dist_cpu.py): the one library name to try instead of the list below
+        const char* forced = getenv("DFVO_RCCL_LIB");
         const char* names[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+        std::string why;
         for (const char* n : names) {
-            r.h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            const char* name = forced ? forced : n;
+            r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
             if (r.h) break;
+            const char* e = dlerror();  // ONE call: dlerror() returns the message once and clears it
+            why = std::string("dlopen(") + name + "): " + (e ? e : "not found");
+            if (forced) break;
         }
         if (!r.h) {
-            r.err = std::string("dlopen(librccl.so.1): ") + (dlerror() ? dlerror() : "not found");
+            r.err = why;
             return;
         }
         auto sym = [&](const char* s) {
@@ -60,6 +68,7 @@ Rccl* rccl() {
 struct dfvo_comm {
     ncclComm_t comm = nullptr;
     int world = 1, rank = 0;
+    int device = -1;  // the HIP device that was current at dfvo_comm_create: every collective must be issued on it
     hipStream_t stream = nullptr;
     double *d_send = nullptr, *d_recv = nullptr;
     size_t cap_rows = 0;  // rows per rank the staging buffers hold
@@ -94,6 +103,11 @@ int dfvo_comm_create(const uint8_t* h_id128, int world, int rank, dfvo_comm** ou
     dfvo_comm* c = new dfvo_comm();
     c->world = world;
     c->rank = rank;
+    if (hipGetDevice(&c->device) != hipSuccess) {
+        dfvo::set_last_error("dfvo_comm_create: no current HIP device (dfvo_set_device first)");
+        delete c;
+        return DFVO_ERR_HIP;
+    }
     ncclUniqueId id;
     memcpy(&id, h_id128, sizeof(id));
     ncclResult_t r = R->CommInitRank(&c->comm, world, id, rank);
@@ -128,6 +142,10 @@ int dfvo_comm_destroy(dfvo_comm* c) {
 int dfvo_allgather_poses_device(dfvo_comm* c, const double* d_send, int rows_per_rank, double* d_recv, void* stream) {
     DFVO_ARG_CHECK(c && d_send && d_recv && rows_per_rank > 0, "dfvo_allgather_poses_device: bad argument");
     dfvo::Rccl* R = dfvo::rccl();
+    int dev = -1;
+    DFVO_HIP_CHECK(hipGetDevice(&dev));
+    DFVO_ARG_CHECK(dev == c->device, "dfvo_allgather_poses: the current device is not the one the communicator was created on "
+                                     "(a host thread that forgot dfvo_set_device would put two ranks on one GPU)");
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     DFVO_NCCL_CHECK(R->AllGather(d_send, d_recv, (size_t)rows_per_rank * DFVO_POSE_ROW, ncclDouble, c->comm, s));
     return DFVO_OK;

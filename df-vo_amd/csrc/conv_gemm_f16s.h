@@ -357,7 +357,11 @@ template <int WP, int KSP, int TC, int PF = 3, bool RAG = false>
 static int launch_f16g_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) {
     const long long M = (long long)p.N * p.Ho * p.Wo;
     dim3 grid((unsigned)(((M + 32 * WP - 1) / (32 * WP)) * (p.wf16g_cout_pad / (32 * TC))), 1, 1);
-    const size_t lds = (KSP > 1 ? (size_t)WP * KSP * TC * 16 * 64 * sizeof(float) : 0) + (size_t)p.f16g_steps * 32;  // + the delta table
+    // + the delta table, only for the layers whose kernel reads it (fast_addr: no reflection padding, no x2 upsampling).  With
+    // the 64 KB reduction buffer of the <1, 16, 1> / <1, 8, 2> shapes this exceeds 64 KB: fine on gfx950 (160 KB per
+    // workgroup, the only target of this library; ensure_dyn_lds reports anything the device refuses)
+    const bool fast_addr = p.pad_mode != PAD_REFLECT && p.up0 == 0;
+    const size_t lds = (KSP > 1 ? (size_t)WP * KSP * TC * 16 * 64 * sizeof(float) : 0) + (fast_addr ? (size_t)p.f16g_steps * 32 : 0);
     if (lds > 48 * 1024)
         if (int rc_lds = ensure_dyn_lds(p.f16_terms == 1 ? (const void*)conv_gemm_f16s_kernel<WP, KSP, TC, PF, RAG, 1>
                                                          : (const void*)conv_gemm_f16s_kernel<WP, KSP, TC, PF, RAG, 3>, lds))
@@ -432,6 +436,7 @@ static int launch_f16g(const ConvParams& p, hipStream_t stream) {
     // 1.10 ms per pair), K divided over workgroups as well (r3af_nz_ab.txt: launches 7 % shorter one at a time, pair rate
     // -1.3 %), one cout block per wave on the streaming shapes (r3j_stream_tc1_ab.txt: no gain).
     const int cfg = ksp == 1 ? 20 : 21;  // profile rows: 20 streaming (KSP = 1), 21 K-sliced small maps
+    if (strchr(conv_ablate(), ksp == 1 ? 's' : 'k')) return DFVO_OK;  // (measurement hook, see conv_ablate)
     // multi-tap layers among the streaming shapes: the tap-window kernel (only where this kernel would not slice K: the two
     // then sum in the same order).  DFVO_TAPS=0 (test hook, tests/test_nets_gpu.py): this file's <4, 1, TC> shape instead
     // -- the form the tap-window kernel is compared with bit for bit

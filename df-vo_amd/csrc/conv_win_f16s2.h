@@ -46,10 +46,6 @@ __global__ __launch_bounds__(64 * WC * WR, 1) void conv_win_f16s2_kernel(const C
     const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
     const int nb = gridDim.x;
     int bid = blockIdx.x;
-    // (experiment hook, DFVO_WIN_STAGGER: every second workgroup of the first round starts late, so that the workgroups of a
-    // round do not all reach their store-heavy epilogue -- 25 MB at once over the chip -- and their cold first window together)
-    if (p.win_stagger > 0 && blockIdx.y == 0 && bid < 256 && ((bid >> 3) & 1))
-        for (int i = 0; i < p.win_stagger; ++i) __builtin_amdgcn_s_sleep(127);
     {  // XCD-aware order: each XCD walks a contiguous run of tiles (neighbours share halo rows in its L2)
         const int q = nb >> 3, r = nb & 7, xcd = bid & 7, k = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
@@ -275,11 +271,8 @@ static long long f16s2_blocks(const ConvParams& p) {
 }
 
 template <int WC, int WR, int TC, int TR>
-static int launch_f16s2_cfg(const ConvParams& p0, hipStream_t stream, int cfg_id) {
+static int launch_f16s2_cfg(const ConvParams& p, hipStream_t stream, int cfg_id) {
     constexpr int TH = WR * TR, BN = WC * TC * 32;
-    static const int stagger = getenv("DFVO_WIN_STAGGER") ? atoi(getenv("DFVO_WIN_STAGGER")) : 0;
-    ConvParams p = p0;
-    p.win_stagger = stagger;
     const int tiles = p.N * ((p.Ho + TH - 1) / TH) * ((p.Wo + 31) / 32);
     dim3 grid((unsigned)tiles, (unsigned)(p.wf16_cout_pad / BN), 1);
     ConvProfEntry pe;

@@ -61,9 +61,6 @@ struct ConvParams {
     // [tap][16-channel chunk][wf16_cout_pad / 32][plane hi, lo][k / 8][32 couts][8] halves, see conv_pack_weights_f16s
     const unsigned short* wf16;
     int wf16_cout_pad;
-    // conv_win_f16s2_kernel: start delay (units of 8128 cycles, ~4 us) of every second workgroup of the grid's first round,
-    // so that the workgroups of a round do not reach their store-heavy epilogue together (DFVO_WIN_STAGGER, see launch_f16s2)
-    int win_stagger;
     // f16 hi/lo planes in k-group order for the generic split kernel (conv_gemm_f16s.h; every layer in f16x3 mode):
     // [16-k step][wf16g_cout_pad / 32][plane][k / 8][32 couts][8] halves + the layer's k-group table (4 words per step)
     const unsigned short* wf16g;

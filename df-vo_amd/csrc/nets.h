@@ -31,6 +31,7 @@ struct ConvLayer {
     uint32_t* gtab = nullptr;      // its k-group table
     float* wg32 = nullptr;         // fp32 weights in the same k-group order for conv_gemm_f32g_kernel (fp32 mode, every layer)
     int wg_cout_pad = 0, g_steps = 0;
+    long long m_hint = 0;          // output pixels the layer was built for (0: unknown, dfvo_conv2d) -- gates optional packings
     int f16_terms = 3;             // 1: packed in "f16" mode (one product per term; the kernels never read the lo planes)
     float* wh = nullptr;  // head layout (cout <= 2, square 3/5/7 kernels), see conv_pack_head_weights
     int cout = 0, cout_pad = 0, c0 = 0, c1 = 0, kh = 0, kw = 0, ksteps = 0;

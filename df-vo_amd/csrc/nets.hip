@@ -66,6 +66,7 @@ int make_conv(const ParamStore& ps, const std::string& wname, const std::string&
     L->kh = w->shape[2];
     L->kw = w->shape[3];
     L->cout_pad = conv_cout_pad(L->cout, M_hint);
+    L->m_hint = M_hint;
     L->ksteps = conv_ksteps(L->kh, L->kw, c0, c1);
     std::vector<float> pw((size_t)(L->ksteps * 4 + 8) * L->cout_pad * 4), pb(L->cout_pad);  // +8 k-groups: the window kernel rounds each source up to 4 groups
     conv_pack_weights(w->data.data(), b ? b->data.data() : nullptr, L->cout, c0, c1, L->kh, L->kw, L->cout_pad,
@@ -112,7 +113,10 @@ int make_f16s_weights(const float* w_oihw, int cout, int c0, int c1, int kh, int
 }
 
 int make_f16g_weights(const float* w_oihw, int cout, int c0, int c1, int kh, int kw, const float* scale, ConvLayer* L) {
-    if (conv_split_mode() == 0 && kh <= 31 && kw <= 31) {  // exact fp32: the register-ring kernel's fp32 weights + the table
+    // exact fp32: the register-ring kernel's fp32 weights + the table -- only for layers launch_conv can send there
+    // (conv_f32g_takes: maps of at most 8192 pixels, not the one- / two-channel heads); the large-map layers used to carry a
+    // second, never-read copy of their weights (round-4 advisor)
+    if (conv_split_mode() == 0 && kh <= 31 && kw <= 31 && (L->m_hint <= 0 || L->m_hint <= 8192) && cout > 2) {
         std::vector<float> wg(conv_pack_weights_f32g(w_oihw, cout, c0, c1, kh, kw, scale, nullptr));
         conv_pack_weights_f32g(w_oihw, cout, c0, c1, kh, kw, scale, wg.data());
         std::vector<uint32_t> tab;

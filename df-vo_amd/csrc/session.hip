@@ -20,7 +20,9 @@
 // the configuration byte for byte with what the device holds; any mismatch takes the plain host-array entry point.
 // The RandomState-consuming half (shuffles, five-point RANSACs, recoverPose) and the scale recovery stay where the
 // reference has them, behind np.random's state at the time of the call.
+#include <algorithm>
 #include <cstring>
+#include <vector>
 
 #include "capi_types.h"
 #include "ops.h"
@@ -58,6 +60,52 @@ struct dfvo_session {
         if (_rc != DFVO_OK) return _rc; \
     } while (0)
 
+// Streams by dispatch pipe (stream_pool.hip): two busy streams on one of the command processor's four pipes slow each
+// other's launches 2.5x, and which pipe a stream lands on follows the process's stream creation order -- with the nets'
+// and the tracker's own streams (created whenever the host built those objects) the first session measured the depth net
+// and the flow net SLOWER side by side than back to back (profiles/r5b_mirrors_first_run.txt: 7.2 vs 6.3 ms).  The session
+// therefore measures a pool of candidates and re-homes every stream it drives: flow net | depth net + the speculative
+// keypoint / homography stage | RandomState-ordered chain + its side streams | frame upload.  Streams the HOST handed to
+// the nets / the tracker (own_stream false) are left alone.
+static int place_streams(dfvo_session* s) {
+    StreamPool pool;
+    if (pool.create(12) != DFVO_OK || pool.ngroups < 3) {
+        pool.release();
+        return DFVO_OK;  // (no measurement: creation-order streams, as before)
+    }
+    std::vector<int> order;
+    for (int i = 0; i < pool.ngroups; ++i) order.push_back(i);
+    std::sort(order.begin(), order.end(), [&](int a, int b) { return pool.count(a) > pool.count(b); });
+    const int g_trk = order[0], g_dep = order[1], g_flow = order[2], g_copy = pool.ngroups >= 4 ? order[3] : order[2];
+    if (pool.count(g_trk) < 3 || pool.count(g_dep) < 2 || pool.count(g_flow) < (g_copy == g_flow ? 2 : 1) || pool.count(g_copy) < 1) {
+        pool.release();
+        return DFVO_OK;
+    }
+    DFVO_HIP_CHECK(hipDeviceSynchronize());
+    auto rehome = [&](hipStream_t* slot, bool owned, int g) {
+        if (!owned) return;
+        hipStream_t n = pool.take(g);
+        if (!n) return;
+        if (*slot) (void)hipStreamDestroy(*slot);
+        *slot = n;
+    };
+    rehome(&s->f->net.stream, s->f->net.own_stream, g_flow);
+    rehome(&s->d->net.stream, s->d->net.own_stream, g_dep);
+    rehome(&s->s_pre, true, g_dep);
+    rehome(&s->s_copy, true, g_copy);
+    if (s->t && s->t->own_stream && !s->t->tb.shared) {
+        hipStream_t r0 = pool.take(g_trk), r1 = pool.take(g_trk);
+        if (r0 && r1 && s->t->tb.rebind_streams(r0, r1) == DFVO_OK) {
+            rehome(&s->t->stream, true, g_trk);
+        } else {
+            if (r0) (void)hipStreamDestroy(r0);
+            if (r1) (void)hipStreamDestroy(r1);
+        }
+    }
+    pool.release();
+    return DFVO_OK;
+}
+
 extern "C" {
 
 int dfvo_session_create(dfvo_flownet* f, dfvo_depthnet* d, dfvo_tracker* t, int img_h, int img_w, dfvo_session** out) {
@@ -86,6 +134,10 @@ int dfvo_session_create(dfvo_flownet* f, dfvo_depthnet* d, dfvo_tracker* t, int 
     if (!ok) {
         dfvo_session_destroy(s);
         dfvo::set_last_error("dfvo_session_create: allocation failed");
+        return DFVO_ERR_HIP;
+    }
+    if (place_streams(s) != DFVO_OK) {
+        dfvo_session_destroy(s);
         return DFVO_ERR_HIP;
     }
     *out = s;
@@ -122,6 +174,14 @@ int dfvo_session_reset(dfvo_session* s) {
 int dfvo_session_invalidate_carry(dfvo_session* s) {
     DFVO_ARG_CHECK(s, "dfvo_session_invalidate_carry: null session");
     s->carry_ok = false;
+    return DFVO_OK;
+}
+
+// a plain solver entry point is about to use the tracker's buffers: the speculative stage must not be running on them
+int dfvo_session_quiesce(dfvo_session* s) {
+    DFVO_ARG_CHECK(s, "dfvo_session_quiesce: null session");
+    DFVO_HIP_CHECK(hipStreamSynchronize(s->s_pre));
+    s->have_h = false;  // its buffers are about to be overwritten: compute_pose_2d2d must restage
     return DFVO_OK;
 }
 

@@ -1641,6 +1641,16 @@ int TrackerBuffers::init(hipStream_t rep0, hipStream_t rep1) {
     return DFVO_OK;
 }
 
+int TrackerBuffers::rebind_streams(hipStream_t rep0, hipStream_t rep1) {
+    DFVO_ARG_CHECK(!shared && rep0 && rep1 && rep0 != rep1, "TrackerBuffers::rebind_streams: bad argument");
+    DFVO_HIP_CHECK(hipDeviceSynchronize());
+    for (int r = 0; r < n_rep_owned && r < MAX_REP; r++)
+        if (s_rep[r] && !(r == 1 && s_rep[1] == s_rep[0])) (void)hipStreamDestroy(s_rep[r]);
+    n_rep_owned = 2;
+    for (int r = 0; r < MAX_REP; r++) s_rep[r] = (r & 1) ? rep1 : rep0;
+    return DFVO_OK;
+}
+
 int TrackerBuffers::init_shared(const TrackerBuffers& first) {
     shared = true;
     mt_state = first.mt_state;

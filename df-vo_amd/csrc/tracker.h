@@ -140,6 +140,9 @@ struct TrackerBuffers {
     int kp_cap = 0, sel_cap = 0;
     // rep0 / rep1: side streams chosen by the caller (the fused pipeline hands out streams by dispatch pipe); null = create
     int init(hipStream_t rep0 = nullptr, hipStream_t rep1 = nullptr);
+    // replaces the side streams of an idle, non-shared buffer set by two streams the caller chose by dispatch pipe (the frame
+    // session, session.hip); this object owns and destroys them from then on
+    int rebind_streams(hipStream_t rep0, hipStream_t rep1);
     // second and further buffer sets of the fused pipeline: own keypoint / RANSAC workspaces, but the numpy
     // RandomState and the (serialised anyway) RNG-side streams and events of `first`
     int init_shared(const TrackerBuffers& first);

@@ -102,6 +102,8 @@ def align(gt, res, alignment=None):
         raise ValueError("alignment: None, 'scale', 'scale_7dof', '7dof' or '6dof'")
     gt, res = np.array(gt, np.float64), np.array(res, np.float64)
     n = len(res)
+    if len(gt) < n:  # (the reference indexes gt by the result's frame ids and raises KeyError on a missing frame)
+        raise ValueError("align: the ground truth holds %d poses, the result %d" % (len(gt), n))
     res = np.linalg.inv(res[0]) @ res
     gt[:n] = np.linalg.inv(gt[0]) @ gt[:n]
     if alignment == "scale":

@@ -76,6 +76,7 @@ class FrameSession:
         self.kp_cfg = None      # capi.SessionKpCfg registered by KeypointSampler (None: no speculative selection)
         self.pose_cfg_fn = None  # () -> capi.Pose2d2dCfg registered by EssTracker
         self.kp_spec = None     # the kp cfg the newest push ran with
+        self.spec_inflight = False  # a speculative keypoint / homography stage may be running on the tracker's buffers
         self._img_idx = _sample_idx(self.h * self.w * 3)
         self._flow_idx = {n: _sample_idx(sz) for n, sz in (("fwd", 2 * self.h * self.w), ("bwd", 2 * self.h * self.w),
                                                            ("diff", self.h * self.w))}
@@ -96,6 +97,13 @@ class FrameSession:
     def invalidate_carry(self):
         capi.check(self.lib.dfvo_session_invalidate_carry(self.handle))
 
+    def quiesce(self):
+        """a plain solver entry point is about to use the tracker's buffers: wait for the speculative stage and abandon its
+        homography half (the keypoints already copied to the host stay valid)"""
+        if self.spec_inflight:
+            capi.check(self.lib.dfvo_session_quiesce(self.handle))
+            self.spec_inflight = False
+
     # -- DeepModel.forward_depth ---------------------------------------------------------------------------------
     def accepts(self, img):
         return isinstance(img, np.ndarray) and img.dtype == np.uint8 and img.shape == (self.h, self.w, 3)
@@ -110,6 +118,7 @@ class FrameSession:
                                                     C.byref(pose) if pose is not None else None, C.byref(g)))
         self.gen = int(g.value)
         self.kp_spec = kp
+        self.spec_inflight = kp is not None and self.gen >= 1
         self.imgs[self.gen] = (img, a.reshape(-1)[self._img_idx].copy())
         self.imgs.pop(self.gen - 2, None)
         self.flow_views = None
@@ -173,6 +182,7 @@ class FrameSession:
     # -- EssTracker.compute_pose_2d2d ------------------------------------------------------------------------------
     def pose_2d2d(self, kp_ref, kp_cur, n, cfg, out, inliers):
         used = C.c_int()
+        self.spec_inflight = False  # (the C side waits for the stage -- or, on a mismatch, for its stream -- itself)
         capi.check(self.lib.dfvo_session_pose_2d2d(self.handle, capi.as_ptr(kp_ref), capi.as_ptr(kp_cur), n, C.byref(cfg),
                                                    C.byref(out), capi.as_ptr(inliers), C.byref(used)))
         self.stats["pose_resident" if used.value else "pose_plain"] += 1

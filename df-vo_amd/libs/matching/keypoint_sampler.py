@@ -62,7 +62,7 @@ class KeypointSampler:
         N = int(self.cfg.kp_selection.bestN.num_bestN)
         kp1, kp2 = np.zeros((N, 2)), np.zeros((N, 2))
         n = C.c_int()
-        capi.check(capi.lib().dfvo_kp_bestn(_ctx.tracker(), capi.as_ptr(flow), capi.as_ptr(diff.reshape(h, w)), h, w, N,
+        capi.check(capi.lib().dfvo_kp_bestn(_ctx.tracker_exclusive(), capi.as_ptr(flow), capi.as_ptr(diff.reshape(h, w)), h, w, N,
                                             capi.as_ptr(kp1), capi.as_ptr(kp2), C.byref(n)))
         if n.value != N:
             raise ValueError("kth(=%d) out of bounds (%d)" % (N, h * w))  # what np.argpartition raises in the reference
@@ -81,7 +81,7 @@ class KeypointSampler:
         idx = np.ascontiguousarray(self.kps['uniform'], dtype=np.int32)
         kp1 = np.zeros((len(idx), 2))
         kp2 = np.zeros((len(idx), 2))
-        capi.check(capi.lib().dfvo_kp_sampled(_ctx.tracker(), capi.as_ptr(flow), h, w, y0, y1, x0, x1, capi.as_ptr(idx),
+        capi.check(capi.lib().dfvo_kp_sampled(_ctx.tracker_exclusive(), capi.as_ptr(flow), h, w, y0, y1, x0, x1, capi.as_ptr(idx),
                                               len(idx), capi.as_ptr(kp1), capi.as_ptr(kp2)))
         return {"kp1_list": kp1[None], "kp2_list": kp2[None]}
 
@@ -112,7 +112,7 @@ class KeypointSampler:
         kp2 = np.zeros((nmax, 2))
         n, good = C.c_int(), C.c_int()
         score = {"flow": 0, "flow_ratio": 1}[c.score_method]
-        capi.check(capi.lib().dfvo_kp_local_bestn_ex(_ctx.tracker(), capi.as_ptr(flow), capi.as_ptr(diff.reshape(h, w)), h,
+        capi.check(capi.lib().dfvo_kp_local_bestn_ex(_ctx.tracker_exclusive(), capi.as_ptr(flow), capi.as_ptr(diff.reshape(h, w)), h,
                                                      w, int(c.num_row), int(c.num_col), nmax, float(c.thre), score,
                                                      capi.as_ptr(kp1), capi.as_ptr(kp2), C.byref(n), C.byref(good)))
         if not good.value:

@@ -85,7 +85,7 @@ class EssTracker:
             # RandomState-consuming half is left to run)
             _ctx.session.pose_2d2d(kp_ref, kp_cur, n, cfg, out, inl)
         else:
-            capi.check(capi.lib().dfvo_compute_pose_2d2d(_ctx.tracker(), capi.as_ptr(kp_ref), capi.as_ptr(kp_cur), n,
+            capi.check(capi.lib().dfvo_compute_pose_2d2d(_ctx.tracker_exclusive(), capi.as_ptr(kp_ref), capi.as_ptr(kp_cur), n,
                                                          C.byref(cfg), C.byref(out), capi.as_ptr(inl)))
         _ctx.pull_numpy_rng()
         feed_timers(self.timers, range(0, 6))
@@ -164,7 +164,7 @@ class EssTracker:
         scale = C.c_double()
         info = np.zeros(4, np.int32)
         _ctx.push_numpy_rng()
-        capi.check(capi.lib().dfvo_find_scale_from_depth(_ctx.tracker(), capi.as_ptr(kp1), capi.as_ptr(kp2), kp1.shape[0],
+        capi.check(capi.lib().dfvo_find_scale_from_depth(_ctx.tracker_exclusive(), capi.as_ptr(kp1), capi.as_ptr(kp2), kp1.shape[0],
                                                          capi.as_ptr(T_21), capi.as_ptr(depth2), h, w, C.byref(scfg),
                                                          C.byref(scale), capi.as_ptr(info)))
         _ctx.pull_numpy_rng()

@@ -44,6 +44,14 @@ def tracker():
     return _trk
 
 
+def tracker_exclusive():
+    """the tracker handle for a plain (host-array) solver entry point: the frame session may still have its speculative
+    keypoint / homography stage in flight on the tracker's buffers -- it is waited for and abandoned first"""
+    if session is not None:
+        session.quiesce()
+    return tracker()
+
+
 def push_numpy_rng():
     """upload np.random's global RandomState (the stream the reference consumes) to the device"""
     st = np.random.get_state()

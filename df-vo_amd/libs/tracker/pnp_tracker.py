@@ -35,7 +35,7 @@ class PnpTracker:
         out = capi.Pose3d2dOut()
         keep = np.zeros(max(n, 1), np.uint8)
         _ctx.push_numpy_rng()
-        capi.check(lib.dfvo_compute_pose_3d2d(_ctx.tracker(), capi.as_ptr(kp1), capi.as_ptr(kp2), n,
+        capi.check(lib.dfvo_compute_pose_3d2d(_ctx.tracker_exclusive(), capi.as_ptr(kp1), capi.as_ptr(kp2), n,
                                               capi.as_ptr(depth_1), h, w, C.byref(cfg), C.byref(out), capi.as_ptr(keep)))
         _ctx.pull_numpy_rng()
         # format pose (pnp_tracker.py:112-118): identity when no repeat produced a model, then inverted

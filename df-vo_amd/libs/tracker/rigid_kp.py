@@ -36,7 +36,7 @@ def kp_selection_good_depth(cfg_all, cam_intrinsics, cur_data, ref_data, rigid_k
     kps = [np.zeros((nmax, 2)) for _ in range(4)]
     n = C.c_int()
     rdiff = np.zeros((h, w), np.float32)
-    capi.check(capi.lib().dfvo_kp_rigid_flow(_ctx.tracker(), capi.as_ptr(flow), capi.as_ptr(diff), capi.as_ptr(raw_depth),
+    capi.check(capi.lib().dfvo_kp_rigid_flow(_ctx.tracker_exclusive(), capi.as_ptr(flow), capi.as_ptr(diff), capi.as_ptr(raw_depth),
                                              h, w, C.byref(cfg), None, capi.as_ptr(kps[0]), capi.as_ptr(kps[1]),
                                              capi.as_ptr(kps[2]), capi.as_ptr(kps[3]), C.byref(n), capi.as_ptr(rdiff)))
     assert n.value != 0, "sampling threshold is too small."

@@ -480,6 +480,7 @@ int dfvo_session_create(dfvo_flownet* flow, dfvo_depthnet* depth, dfvo_tracker* 
 void dfvo_session_destroy(dfvo_session* s);
 int dfvo_session_reset(dfvo_session* s);             /* forget the held frame (a new sequence) */
 int dfvo_session_invalidate_carry(dfvo_session* s);  /* someone else ran the flow net: recompute both pyramids next time */
+int dfvo_session_quiesce(dfvo_session* s);           /* a plain solver call is about to use the tracker: wait for the speculative stage */
 /* h_img uint8 [img_h, img_w, 3]; *generation = index of this frame since create / reset */
 int dfvo_session_push_frame(dfvo_session* s, const uint8_t* h_img, const dfvo_session_kp_cfg* kp, const dfvo_pose2d2d_cfg* pose,
                             long long* generation);
