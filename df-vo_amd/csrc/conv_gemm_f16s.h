@@ -436,7 +436,6 @@ static int launch_f16g(const ConvParams& p, hipStream_t stream) {
     // 1.10 ms per pair), K divided over workgroups as well (r3af_nz_ab.txt: launches 7 % shorter one at a time, pair rate
     // -1.3 %), one cout block per wave on the streaming shapes (r3j_stream_tc1_ab.txt: no gain).
     const int cfg = ksp == 1 ? 20 : 21;  // profile rows: 20 streaming (KSP = 1), 21 K-sliced small maps
-    if (strchr(conv_ablate(), ksp == 1 ? 's' : 'k')) return DFVO_OK;  // (measurement hook, see conv_ablate)
     // multi-tap layers among the streaming shapes: the tap-window kernel (only where this kernel would not slice K: the two
     // then sum in the same order).  DFVO_TAPS=0 (test hook, tests/test_nets_gpu.py): this file's <4, 1, TC> shape instead
     // -- the form the tap-window kernel is compared with bit for bit

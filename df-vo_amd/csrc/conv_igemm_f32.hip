@@ -822,14 +822,6 @@ int conv_profile_end(double* ms, double* flops, int* launches, double* bytes) {
     return DFVO_OK;
 }
 
-// DFVO_ABLATE (round-5 measurement hook, removed after the record was taken -- profiles/r5c_ablation.txt): families of
-// launches that are skipped altogether, to see what the pair rate owes to them: k = K-sliced small maps, s = streaming
-// layers, h = heads, w = window layers.  Results are garbage: only with bench.py --solver-inputs synthetic.
-static const char* conv_ablate() {
-    static const char* e = getenv("DFVO_ABLATE");
-    return e ? e : "";
-}
-
 #include "conv_win_f16s.h"
 #include "conv_gemm_f16s.h"
 #include "conv_win_f16s2.h"
@@ -1040,13 +1032,11 @@ int launch_conv(const ConvParams& p, hipStream_t stream) {
     DFVO_ARG_CHECK((p.cs0 % 4) == 0 && (p.co0 % 4) == 0, "launch_conv: src0 stride/offset must be multiples of 4");
     DFVO_ARG_CHECK(p.G1 == 0 || ((p.cs1 % 4) == 0 && (p.co1 % 4) == 0), "launch_conv: src1 stride/offset");
     if (conv_use_head(p)) {
-        if (strchr(conv_ablate(), 'h')) return DFVO_OK;
         if (p.kh == 7) return p.cout == 2 ? launch_head<7, 2>(p, stream, 16) : launch_head<7, 1>(p, stream, 16);
         if (p.kh == 5) return p.cout == 2 ? launch_head<5, 2>(p, stream, 17) : launch_head<5, 1>(p, stream, 17);
         return p.cout == 2 ? launch_head<3, 2>(p, stream, 18) : launch_head<3, 1>(p, stream, 18);
     }
     if (p.wf16 && conv_f16s_ok(p)) {  // f16x3: the 3x3 / stride-1 layers whose map fills the chip
-        if (strchr(conv_ablate(), 'w')) return DFVO_OK;
         const int rc2 = launch_f16s2(p, stream, 19);  // one-wave-per-SIMD skeleton where the grid is large enough
         return rc2 != F16S2_NOT_APPLICABLE ? rc2 : launch_f16s(p, stream, 19);  // errors (negative) propagate
     }

@@ -302,6 +302,7 @@ struct HRefineWork {
     double h[9], x[8], xd[8], d[8], v[8], A[64], D[8], norm[8], LtL[81];
     double S, Sd, rinf, lambda, lc;
     double Ap[64], eig[2 * 81 + 2 * 9];  // lane 0's dense 8x8 / 9x9 work (LDS, not scratch)
+    double At[64], vt[8], rinft;         // J^T J, J^T r, |r|_inf at the trial point x - d (see full_pass)
     int flag;
 };
 
@@ -446,7 +447,14 @@ __device__ __forceinline__ void h_refit_refine_block(HRefineShared& sh, HRefineW
         }
         aj = ai + rem;
     }
-    auto full_pass = [&](const double* h) {  // residuals + Jacobian at h -> s_A, s_v, s_S, s_rinf
+    // residuals + Jacobian at h -> (A, v, S, rinf) of the CURRENT point (s_A, s_v, s_S, s_rinf) or, trial = true, of the TRIAL
+    // point (w.At, w.vt, s_Sd, w.rinft).  The trial form replaces the reference loop's "residual norm at x - d first, then --
+    // if the step is accepted -- everything again at the new x": the norm is the same ordered sum either way (seq_acc_sq over
+    // the same residuals), and the Jacobian sums of an accepted step are exactly what the second evaluation would compute, so
+    // one pass per iteration yields the same bits as the two; a rejected step discards the trial set (its Jacobian sums were
+    // wasted: LM on RANSAC inliers rejects rarely).  Saves one ordered pass over the points -- ~13 us of dependent fp64 adds
+    // plus sixteen workgroup barriers -- per accepted iteration.
+    auto full_pass = [&](const double* h, bool trial) {
         double a = 0;
         for (int c0 = 0; c0 < np; c0 += 256) {
             const int cnt = np - c0 < 256 ? np - c0 : 256;
@@ -492,32 +500,27 @@ __device__ __forceinline__ void h_refit_refine_block(HRefineShared& sh, HRefineW
             }
             __syncthreads();
         }
+        double* const dA = trial ? w.At : s_A;
+        double* const dv = trial ? w.vt : s_v;
         if (t < 36) {
-            s_A[ai * 8 + aj] = a;
-            s_A[aj * 8 + ai] = a;
+            dA[ai * 8 + aj] = a;
+            dA[aj * 8 + ai] = a;
         } else if (t >= 64 && t < 72) {
-            s_v[t - 64] = a;
+            dv[t - 64] = a;
         } else if (t == 128) {
-            s_S = a;
+            if (trial)
+                s_Sd = a;
+            else
+                s_S = a;
         } else if (t == 192) {
-            s_rinf = a;
+            if (trial)
+                w.rinft = a;
+            else
+                s_rinf = a;
         }
         __syncthreads();
     };
-    auto residual_pass = [&](const double* h) {  // |r(h)|^2 -> s_Sd
-        double a = 0;
-        for (int c0 = 0; c0 < np; c0 += 256) {
-            const int cnt = np - c0 < 256 ? np - c0 : 256;
-            const float* cp = chunk_pts(c0);
-            h_chunk_lm(sh, cp, h, cnt, false);
-            __syncthreads();
-            if (t == 128) a = seq_acc_sq(sh.buf, cnt, a);
-            __syncthreads();
-        }
-        if (t == 128) s_Sd = a;
-        __syncthreads();
-    };
-    full_pass(s_x);
+    full_pass(s_x, false);
     if (t < 8) s_D[t] = s_A[t * 8 + t];
     if (t == 0) {
         s_lambda = 1;
@@ -540,7 +543,7 @@ __device__ __forceinline__ void h_refit_refine_block(HRefineShared& sh, HRefineW
             for (int i = 0; i < 8; i++) s_xd[i] = s_x[i] - s_d[i];
         }
         __syncthreads();
-        residual_pass(s_xd);
+        full_pass(s_xd, true);  // |r(x - d)|^2 -> s_Sd, and the Jacobian sums the step needs if it is accepted
         if (t == 0) {
             const double Sd = s_Sd;
             double temp_d[8], d[8], v[8];
@@ -586,8 +589,12 @@ __device__ __forceinline__ void h_refit_refine_block(HRefineShared& sh, HRefineW
                 s_x[t] = s_xd[t];
                 s_xd[t] = tx;
             }
+            // the trial set becomes the current one (what a second evaluation at the new x would have produced)
+            if (t < 64) s_A[t] = w.At[t];
+            if (t >= 64 && t < 72) s_v[t - 64] = w.vt[t - 64];
+            if (t == 128) s_S = s_Sd;
+            if (t == 192) s_rinf = w.rinft;
             __syncthreads();
-            full_pass(s_x);  // refreshes A, v, S (= Sd) and |r|_inf
         }
         iter++;
         double dinf = 0;
