@@ -114,9 +114,11 @@ int make_f16s_weights(const float* w_oihw, int cout, int c0, int c1, int kh, int
 
 int make_f16g_weights(const float* w_oihw, int cout, int c0, int c1, int kh, int kw, const float* scale, ConvLayer* L) {
     // exact fp32: the register-ring kernel's fp32 weights + the table -- only for layers launch_conv can send there
-    // (conv_f32g_takes: maps of at most 8192 pixels, not the one- / two-channel heads); the large-map layers used to carry a
-    // second, never-read copy of their weights (round-4 advisor)
-    if (conv_split_mode() == 0 && kh <= 31 && kw <= 31 && (L->m_hint <= 0 || L->m_hint <= 8192) && cout > 2) {
+    // (conv_f32g_takes: launches of at most 8192 output pixels, not the one- / two-channel heads).  m_hint is the builder's
+    // pixel count of the layer's INPUT map for the whole batch: a stride-2 Features layer launched one frame at a time has an
+    // eighth of it, hence the factor.  The large-map layers used to carry a second, never-read copy of their weights
+    // (round-4 advisor); dfvo_conv2d (no hint) packs always.
+    if (conv_split_mode() == 0 && kh <= 31 && kw <= 31 && (L->m_hint <= 0 || L->m_hint <= 8 * 8192) && cout > 2) {
         std::vector<float> wg(conv_pack_weights_f32g(w_oihw, cout, c0, c1, kh, kw, scale, nullptr));
         conv_pack_weights_f32g(w_oihw, cout, c0, c1, kh, kw, scale, wg.data());
         std::vector<uint32_t> tab;

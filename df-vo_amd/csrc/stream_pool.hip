@@ -34,6 +34,29 @@ static float chain_us(hipStream_t s, hipEvent_t e0, hipEvent_t e1, int n) {
     return ms * 1e3f;
 }
 
+// one classification pass over the already created streams; returns false when a measurement failed
+static bool classify(const std::vector<hipStream_t>& s, hipEvent_t e0, hipEvent_t e1, std::vector<int>* group, int* ngroups) {
+    const int n = (int)s.size(), CH = 40;
+    group->assign(n, -1);
+    std::vector<float> base(n);
+    for (int i = 0; i < n; ++i) base[i] = chain_us(s[i], e0, e1, CH);
+    *ngroups = 0;
+    for (int a = 0; a < n; ++a) {
+        if ((*group)[a] >= 0) continue;
+        (*group)[a] = *ngroups;
+        for (int b = a + 1; b < n; ++b) {
+            if ((*group)[b] >= 0) continue;
+            // stream a busy for ~0.6 ms (30 x 20 us, wall_clock64 ticks at 100 MHz), the chain on b inside that window
+            for (int k = 0; k < 30; ++k) hipLaunchKernelGGL(k_pool_spin, dim3(1), dim3(64), 0, s[a], 2000LL);
+            const float t = chain_us(s[b], e0, e1, CH);
+            if (hipStreamSynchronize(s[a]) != hipSuccess || t < 0.f || base[b] <= 0.f) return false;
+            if (t > 1.6f * base[b]) (*group)[b] = *ngroups;
+        }
+        ++*ngroups;
+    }
+    return true;
+}
+
 int StreamPool::create(int n) {
     release();
     s.resize(n, nullptr);
@@ -44,36 +67,37 @@ int StreamPool::create(int n) {
     DFVO_HIP_CHECK(hipEventCreate(&e1));
     for (int i = 0; i < n; ++i) hipLaunchKernelGGL(k_pool_empty, dim3(1), dim3(64), 0, s[i]);
     DFVO_HIP_CHECK(hipDeviceSynchronize());
-    const int CH = 40;
-    std::vector<float> base(n);
-    for (int i = 0; i < n; ++i) base[i] = chain_us(s[i], e0, e1, CH);
-    ngroups = 0;
-    bool ok = true;
-    for (int a = 0; a < n && ok; ++a) {
-        if (group[a] >= 0) continue;
-        group[a] = ngroups;
-        for (int b = a + 1; b < n; ++b) {
-            if (group[b] >= 0) continue;
-            // stream a busy for ~0.6 ms (30 x 20 us, wall_clock64 ticks at 100 MHz), the chain on b inside that window
-            for (int k = 0; k < 30; ++k) hipLaunchKernelGGL(k_pool_spin, dim3(1), dim3(64), 0, s[a], 2000LL);
-            const float t = chain_us(s[b], e0, e1, CH);
-            if (hipStreamSynchronize(s[a]) != hipSuccess || t < 0.f || base[b] <= 0.f) {
-                ok = false;
-                break;
-            }
-            if (t > 1.6f * base[b]) group[b] = ngroups;
+    // The hardware spreads consecutive queues over its four pipes, so n = 4 m streams created back to back must come out as
+    // four groups of m.  The probe is a timing measurement: on a device that has just been opened (clocks still ramping, the
+    // first process of a fresh box) it misclassifies -- round 5 saw the frame session fall back to creation-order streams
+    // exactly when it ran as the first GPU work of the driver's command, 99 instead of 135 frames/s.  So: warm the device
+    // up, classify, and re-measure (longer warm-up each time) until the result has the shape the hardware guarantees.
+    bool ok = false, measured = false;  // ok: the expected shape; measured: at least one complete classification (kept as is
+                                        // when no attempt has the expected shape: never worse than the single pass of round 3)
+    for (int attempt = 0; attempt < 4 && !ok; ++attempt) {
+        for (int k = 0; k < 50 * (attempt + 1); ++k)  // 1, 2, 3, 4 ms of spinning on one stream
+            hipLaunchKernelGGL(k_pool_spin, dim3(1), dim3(64), 0, s[0], 2000LL);
+        DFVO_HIP_CHECK(hipDeviceSynchronize());
+        std::vector<int> g2;
+        int ng2 = 0;
+        if (!classify(s, e0, e1, &g2, &ng2)) break;  // a failed measurement: keep what an earlier attempt found, if any
+        group = g2;
+        ngroups = ng2;
+        measured = ok = true;
+        if (n % 4 == 0) {
+            ok = ngroups == 4;
+            for (int g = 0; g < ngroups && ok; ++g) ok = count(g) == n / 4;
         }
-        ++ngroups;
+        if (getenv("DFVO_STREAM_PROBE_VERBOSE")) {
+            fprintf(stderr, "dfvo stream pool: attempt %d, %d streams, %d pipe groups (%s):", attempt, n, ngroups, ok ? "accepted" : "rejected");
+            for (int i = 0; i < n; ++i) fprintf(stderr, " %d", group[i]);
+            fprintf(stderr, "\n");
+        }
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     DFVO_HIP_CHECK(hipGetLastError());
-    if (!ok) ngroups = 0;
-    if (getenv("DFVO_STREAM_PROBE_VERBOSE")) {
-        fprintf(stderr, "dfvo stream pool: %d streams, %d pipe groups:", n, ngroups);
-        for (int i = 0; i < n; ++i) fprintf(stderr, " %d", group[i]);
-        fprintf(stderr, "\n");
-    }
+    if (!ok && !measured) ngroups = 0;
     return DFVO_OK;
 }
 

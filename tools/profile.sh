@@ -3,9 +3,9 @@
 # (one counter per run; counter collection is never combined with the sys/hip/hsa trace domains)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-TAG=${TAG:-r4}
+TAG=${TAG:-r5}
 mkdir -p $R/gpurun_out
-CMD="python $R/bench.py --no-cpu-baseline --no-roofline --no-exact-leg --steps 20 --warmup 5"
+CMD="python $R/bench.py --no-cpu-baseline --no-roofline --no-exact-leg --no-other-legs --steps 20 --warmup 5"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -o r -- $CMD > /tmp/b_stats.log 2>&1
 f=$(find /tmp/p_stats -name "*kernel_stats.csv" | head -1)
 [ -n "$f" ] && cp $f $R/gpurun_out/${TAG}_rocprofv3_kernel_stats.csv
@@ -24,7 +24,7 @@ for r in csv.DictReader(open('/tmp/SQ_VALU_MFMA_BUSY_CYCLES.csv')):
     m=re.search(r"(conv_\w+_kernel<[^>]*>)", r['Kernel_Name'])
     if not m: continue
     a=acc[m.group(1)]; a[0]+=1; a[1]+=float(r['Counter_Value'])
-with open(os.environ['GRAFT_REPO_ROOT']+'/gpurun_out/%s_mfma_busy.txt' % os.environ.get('TAG','r3'),'w') as f:
+with open(os.environ['GRAFT_REPO_ROOT']+'/gpurun_out/%s_mfma_busy.txt' % os.environ.get('TAG','r5'),'w') as f:
     for k,(n,s) in sorted(acc.items(), key=lambda kv:-kv[1][1]):
         line="%-45s dispatches %5d  SQ_VALU_MFMA_BUSY_CYCLES/dispatch %.4g"%(k,n,s/n)
         print(line); f.write(line+"\n")

@@ -6,12 +6,12 @@
 # cited into profiles/.  (tools/profile.sh takes the rocprofv3 records, tools/quick_check.sh is the 3-minute check of a
 # kernel change.)
 R=$GRAFT_REPO_ROOT
-TAG=${TAG:-r4}
+TAG=${TAG:-r5}
 mkdir -p $R/gpurun_out
 cd $R
-timeout 1500 python -m pytest tests -m gpu -q -s 2>&1 | grep -E "ANCHOR|FROM-IMAGES|passed|failed|FAILED|Error" > gpurun_out/${TAG}m_tests.txt
+timeout 1500 python -m pytest tests -m gpu -q -s 2>&1 | grep -E "ANCHOR|FROM-IMAGES|F16-MODE|f16x3 range|passed|failed|FAILED|Error" > gpurun_out/${TAG}m_tests.txt
 tail -3 gpurun_out/${TAG}m_tests.txt
-for prec in fp32 f16x3; do
+for prec in f16x3; do
   DFVO_CONV_PRECISION=$prec timeout 300 python tools/flow_error_by_level.py 2>&1 | grep -v amdgpu > gpurun_out/${TAG}m_flow_error_by_level_tunnel_$prec.txt
   DFVO_CONV_PRECISION=$prec timeout 300 python tools/flow_op_replay.py --world random 2>&1 | grep -v amdgpu > gpurun_out/${TAG}m_op_replay_random_$prec.txt
 done
@@ -19,11 +19,13 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 | 
 timeout 600 python bench.py 2>/dev/null | tail -1 > gpurun_out/${TAG}m_bench_default.json
 cut -c1-240 gpurun_out/${TAG}m_bench_default.json
 timeout 300 python bench.py --sequences kitti-lengths --scale 0.02 2>/dev/null | tail -1 > gpurun_out/${TAG}m_bench_config3_job_1gpu.json
-timeout 600 python bench.py --height 960 --width 1280 --steps 10 --warmup 3 2>/dev/null | tail -1 > gpurun_out/${TAG}m_bench_config4_1280x960.json
-timeout 900 python bench.py --height 1280 --width 1920 --kp-bestn 20000 --e-max-iters 8192 --steps 10 --warmup 3 2>/dev/null | tail -1 > gpurun_out/${TAG}m_bench_config5_1920x1280.json
-for f in config3_job_1gpu config4_1280x960 config5_1920x1280; do python -c "
+timeout 600 python bench.py --height 960 --width 1280 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${TAG}m_bench_config4_1280x960.json
+timeout 900 python bench.py --height 1280 --width 1920 --kp-bestn 20000 --e-max-iters 8192 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/${TAG}m_bench_config5_1920x1280.json
+timeout 900 python bench.py --height 1280 --width 1920 --kp-bestn 20000 --e-max-iters 8192 --steps 10 --warmup 3 --no-cpu-baseline --no-exact-leg --conv-precision f16 2>/dev/null | tail -1 > gpurun_out/${TAG}m_bench_config5_f16.json
+for s in 0 1; do DFVO_SESSION=$s timeout 300 python bench.py --surface mirrors --steps 30 --warmup 3 2>/dev/null | tail -1 > gpurun_out/${TAG}m_mirrors_session$s.json; done
+for f in config3_job_1gpu config4_1280x960 config5_1920x1280 config5_f16 mirrors_session0 mirrors_session1; do python -c "
 import json,sys
-d=json.loads(open('gpurun_out/${TAG}m_bench_$f.json').read())
+import glob; d=json.loads(open(glob.glob('gpurun_out/${TAG}m_*$f.json')[0]).read())
 print('$f', d['value'], d['ms_per_step'], (d.get('exact_fp32') or {}).get('value'), (d.get('roofline') or {}).get('frac'), (d.get('cpu_baseline') or {}).get('value'))"; done
 O=gpurun_out/${TAG}m_multirank_job_one_device.txt; : > $O
 for n in 2 3; do
