@@ -148,3 +148,44 @@ def test_bench_gpus_flag_self_launch(monkeypatch):
     assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "8"
     assert "--master-addr" in cmd and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert cmd[-4:] == ["--gpus", "8", "--steps", "3"] and cmd[-5].endswith("bench.py")
+
+
+def test_committed_profile_feeds_the_hbm_roofline_entry():
+    """roofline.hbm.other_kernels comes from the committed rocprofv3 passes (hardware counters cannot be read from inside the
+    process): the files bench.py names must exist, parse, and price the streaming kernels below the 8 TB/s peak"""
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert os.path.exists(os.path.join(root, "profiles", bench.PMC_FILE)) and os.path.exists(os.path.join(root, "profiles", bench.STATS_FILE))
+    ks = bench.committed_streaming_kernels()
+    assert ks and all(0.0 < k["frac"] < 1.0 and k["mb_per_dispatch"] >= 4.0 for k in ks)
+    names = {k["kernel"] for k in ks}
+    assert {"k_warp", "k_correlation_rt", "k_deconv_dw4"} <= names, names
+
+
+def test_other_legs_need_a_gpu_and_never_break_the_line(monkeypatch):
+    import bench
+    assert bench.gpu_visible() is False  # (this container; on the GPU box /dev/kfd exists)
+    r = bench.other_leg(["--definitely-not-an-option"], timeout=120)
+    assert "error" in r and "argv" in r  # a failed leg is reported inside the line, the headline still prints
+
+
+def test_mirror_options_precedence(monkeypatch):
+    """DeepModel.initialize_models: f16x3 and the frame session unless the optional cfg key `dfvo_hip` or the environment says
+    otherwise (environment first)"""
+    import importlib
+    import __graft_entry__ as g
+    g.dfvo_amd()
+    dm = importlib.import_module("df-vo_amd.libs.deep_models.deep_models")
+    monkeypatch.delenv("DFVO_CONV_PRECISION", raising=False)
+    monkeypatch.delenv("DFVO_SESSION", raising=False)
+    assert dm.hip_options({}) == {"conv_precision": "f16x3", "session": True}
+    assert dm.hip_options({"dfvo_hip": {"conv_precision": "fp32", "session": False}}) == {"conv_precision": "fp32", "session": False}
+    monkeypatch.setenv("DFVO_CONV_PRECISION", "f16")
+    monkeypatch.setenv("DFVO_SESSION", "0")
+    assert dm.hip_options({"dfvo_hip": {"conv_precision": "fp32"}}) == {"conv_precision": "f16", "session": False}
+
+    class Attr:  # an attribute-style config without the key (EasyDict raises AttributeError)
+        pass
+    monkeypatch.delenv("DFVO_CONV_PRECISION")
+    monkeypatch.delenv("DFVO_SESSION")
+    assert dm.hip_options(Attr()) == {"conv_precision": "f16x3", "session": True}
