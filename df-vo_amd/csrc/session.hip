@@ -187,6 +187,7 @@ int dfvo_session_quiesce(dfvo_session* s) {
 
 static int ensure_kp_host(dfvo_session* s, int cap) {
     if (cap <= s->kp_cap) return DFVO_OK;
+    DFVO_HIP_CHECK(hipDeviceSynchronize());  // (a copy into the old buffers may still be in flight)
     for (int i = 0; i < RING; ++i) {
         if (s->h_kp_ref[i]) (void)hipHostFree(s->h_kp_ref[i]);
         if (s->h_kp_cur[i]) (void)hipHostFree(s->h_kp_cur[i]);
@@ -263,6 +264,9 @@ int dfvo_session_push_frame(dfvo_session* s, const uint8_t* h_img, const dfvo_se
             s->have_h = true;
         }
     }
+    // the caller's (pageable) frame buffer is its own again when this returns: by now the copy has long been staged, the wait
+    // costs nothing and nothing above waited for it on the host
+    DFVO_HIP_CHECK(hipEventSynchronize(s->e_img));
     s->gen = g;
     if (generation) *generation = g;
     return DFVO_OK;
