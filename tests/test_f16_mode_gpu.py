@@ -60,12 +60,14 @@ def test_f16_flow_distance_to_the_exact_function(gpu, f16_mode, world):
         print("F16-MODE ANCHOR %s %s: |device f16 - exact| max %.2e p99 %.2e median %.2e px | |oracle fp32 - exact| max %.2e p99 %.2e "
               "median %.2e px | max |flow| %.1f px | ratio of medians %.0f" % ((world, name) + d + o + (mag, d[2] / max(o[2], 1e-12))))
         # one f16 rounding per operand is 2^-11 relative; through ~60 layers and the data-dependent warps of the coarse-to-fine
-        # scheme the flow moves by a small fraction of a pixel.  Gate (3x the first measured run, see profiles/r5_f16_mode.txt):
+        # scheme the flow moves by a small fraction of a pixel.  Gate: 2-3x the measured values (F16_ANCHOR_GATE below):
         assert d[2] <= F16_ANCHOR_GATE[world][0] and d[1] <= F16_ANCHOR_GATE[world][1], (world, name, d)
 
 
-# (median, p99) px of |flow - anchor|, see the test above
-F16_ANCHOR_GATE = {"random_weights_192x640": (0.05, 0.5), "coded_tunnel_256x640": (0.05, 0.5)}
+# (median, p99) px of |flow - anchor| over fwd / bwd / consistency map, see the test above.  Measured (profiles/r5c_f16_mode.txt):
+# random weights median <= 1.6e-2, p99 <= 1.6e-1; coded tunnel median <= 4.4e-2, p99 <= 1.1e-1 (deterministic: same kernels,
+# same inputs)
+F16_ANCHOR_GATE = {"random_weights_192x640": (0.05, 0.5), "coded_tunnel_256x640": (0.1, 0.4)}
 
 
 CHUNK = 4  # pairs per re-rendered chunk of the tunnel (frame counters 0 .. 4), see test_f16_trajectory_report
