@@ -4,12 +4,13 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=$1
-export DFVO_CONV_PRECISION=f16x3 ITERS=10
+export DFVO_CONV_PRECISION=${DFVO_CONV_PRECISION:-f16x3} ITERS=10
 for kv in $LAYER; do export $kv; done
 P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS"
 P2="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVES SQ_INSTS_SALU"
+P3="GRBM_GUI_ACTIVE"   # / the launch's wall time = the effective shader clock (MI355X_MICROARCH.md, DVFS give-back)
 i=0
-for P in "$P1" "$P2"; do
+for P in "$P1" "$P2" "$P3"; do
   i=$((i+1))
   rm -rf /tmp/pl_$i
   timeout 200 rocprofv3 --pmc $P --output-format csv -d /tmp/pl_$i -o r -- python $R/tools/bench_conv.py > /tmp/pl_$i.log 2>&1
