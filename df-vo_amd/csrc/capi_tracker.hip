@@ -93,6 +93,18 @@ int dfvo_tracker_stage_ms(dfvo_tracker* t, double* h_ms8) {
         const bool have = (t->tb.seg_mask >> a & 1u) && (t->tb.seg_mask >> b & 1u) && t->tb.ev_seg[a] && t->tb.ev_seg[b];
         h_ms8[k] = have && hipEventElapsedTime(&ms, t->tb.ev_seg[a], t->tb.ev_seg[b]) == hipSuccess ? (double)ms : -1.0;
     }
+    // DFVO_STAGE_OFFSETS=1 (diagnostics): every recorded mark relative to mark 0, across the streams the marks were recorded on
+    // -- shows which of the homography half and the five-point batch the bookkeeping kernel waited for
+    static const bool offsets = getenv("DFVO_STAGE_OFFSETS") != nullptr;
+    if (offsets && (t->tb.seg_mask & 1u) && t->tb.ev_seg[0]) {
+        fprintf(stderr, "dfvo stage offsets [ms from the start of the homography half]:");
+        for (int k = 1; k < TrackerBuffers::N_SEG; k++) {
+            float ms = 0.f;
+            if ((t->tb.seg_mask >> k & 1u) && t->tb.ev_seg[k] && hipEventElapsedTime(&ms, t->tb.ev_seg[0], t->tb.ev_seg[k]) == hipSuccess)
+                fprintf(stderr, " %d:%.3f", k, ms);
+        }
+        fprintf(stderr, "\n");
+    }
     return DFVO_OK;
 }
 

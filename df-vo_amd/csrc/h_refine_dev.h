@@ -22,102 +22,122 @@ namespace dfvo {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");   \
     } while (0)
 
+// 64-bit / 32-bit values through one DPP control (VALU moves inside a row of sixteen lanes, no LDS round trip)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false);
+}
+// one exchange of the pivot search: (key, scan order) maximum with the lower scan order winning ties; p = the signed element
+// and code = order << 16 | k << 8 | l travel with the key
+template <int CTRL>
+__device__ __forceinline__ void pivot_exchange(double& key, double& p, int& code) {
+    const double ok = dpp_f64<CTRL>(key), op = dpp_f64<CTRL>(p);
+    const int oc = dpp_i32<CTRL>(code);
+    if (ok > key || (ok == key && oc < code)) {
+        key = ok;
+        p = op;
+        code = oc;
+    }
+}
+__device__ __forceinline__ double uniform_f64(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+__device__ __forceinline__ double lane_f64(double v, int src_lane) {  // src_lane wave-uniform
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src_lane),
+                            __builtin_amdgcn_readlane(__double2loint(v), src_lane));
+}
+
+// Round 5 form (profiles/r5j_h_refine_trace.txt: the eigen problems were 1.0 of the 1.4 ms of k_h_refine at 2.1 - 2.6 us per
+// rotation).  What a rotation no longer does: the pivot tables and the diagonal live in REGISTERS of their owner lanes (lane r <
+// N - 1: row r's table entry, lane N - 2 + c: column c's, lane i < N: W[i]) instead of LDS; the pivot maximum is four DPP
+// exchanges (quad xor 1, xor 2, half mirror, row mirror -- an all-reduce over the sixteen candidate lanes) that carry the signed
+// element and its (k, l) along, instead of twelve ds_bpermute round trips plus three more for the winner's coordinates and an LDS
+// read of the element; W[k], W[l] come through v_readlane.  With nothing but A and V left in LDS, and every lane of the
+// rotation touching its own elements only, ONE wave-level LDS synchronisation per rotation remains (after the rotation, before
+// the owner lanes rescan rows / columns k and l) instead of three.  The rescans and the rotation are single code paths with
+// per-lane addresses (they were up to four / three divergent branches).  Same operations on the same operands in the same
+// order as sm::jacobi_eigen_ws -- the pivot search now also has the sequential scan's NaN behaviour (a NaN first candidate
+// sticks, any other NaN is never selected).
 template <int N>
-__device__ void jacobi_eigen_coop(double* A, double* W, double* V, int* ind, int lane) {
+__device__ int jacobi_eigen_coop(double* A, double* W, double* V, int* ind, int lane) {
+    static_assert(2 * N - 2 <= 16, "the pivot candidates must fit one DPP row");
+    (void)ind;
     const double eps = DBL_EPSILON;
-    int *indR = ind, *indC = ind + N;
-    auto scan_row = [&](int k) {  // first maximum of |A[k][i]|, i > k
-        int m = k + 1;
-        double mv = fabs(A[N * k + m]);
-        for (int i = k + 2; i < N; i++) {
-            const double val = fabs(A[N * k + i]);
-            if (mv < val) mv = val, m = i;
-        }
-        return m;
-    };
-    auto scan_col = [&](int k) {  // first maximum of |A[i][k]|, i < k
-        int m = 0;
-        double mv = fabs(A[k]);
-        for (int i = 1; i < k; i++) {
-            const double val = fabs(A[N * i + k]);
-            if (mv < val) mv = val, m = i;
+    // ---- ownership: lane r < N - 1 owns row r's pivot-table entry, lane N - 2 + c (c = 1 .. N - 1) column c's
+    const bool own_row = lane < N - 1, own_col = lane >= N - 1 && lane < 2 * N - 2;
+    const int oc = lane - (N - 2);
+    // the owner's scan as (first address, stride, count, index of the first element): row r: A[r][r + 1 ..], column c: A[0 .. c - 1][c]
+    const int sc_base = own_row ? N * lane + lane + 1 : oc, sc_stride = own_row ? 1 : N, sc_cnt = own_row ? N - 1 - lane : oc,
+              sc_m0 = own_row ? lane + 1 : 0;
+    auto rescan = [&]() {  // first maximum of |A| over the owner's row / column part
+        int m = sc_m0;
+        double mv = fabs(A[sc_base]);
+        for (int j = 1; j < sc_cnt; j++) {
+            const double val = fabs(A[sc_base + j * sc_stride]);
+            if (mv < val) mv = val, m = sc_m0 + j;
         }
         return m;
     };
     for (int idx = lane; idx < N * N; idx += 64) V[idx] = (idx / N == idx % N) ? 1. : 0.;
-    if (lane < N) {
-        W[lane] = A[(N + 1) * lane];
-        if (lane < N - 1) indR[lane] = scan_row(lane);
-        if (lane > 0) indC[lane] = scan_col(lane);
-    }
+    double myW = lane < N ? A[(N + 1) * lane] : 0.;
+    int myind = 0;
+    if (own_row || own_col) myind = rescan();
     WAVE_LDS_SYNC();
     const int maxIters = N * N * 30;
-    for (int iters = 0; iters < maxIters; iters++) {
-        // pivot candidates in the sequential scan order: rows 0..N-2 (via indR), then columns 1..N-1 (via indC)
-        double val = -1.;
-        int ck = 0, cl = 0, ord = lane;
-        if (lane < N - 1) {
-            ck = lane;
-            cl = indR[lane];
-            val = fabs(A[N * ck + cl]);
-        } else if (lane < 2 * N - 2) {
-            cl = lane - (N - 1) + 1;
-            ck = indC[cl];
-            val = fabs(A[N * ck + cl]);
+    int iters = 0;
+    for (; iters < maxIters; iters++) {
+        // pivot candidates in the sequential scan order: rows 0..N-2, then columns 1..N-1
+        double key = -1., p = 0.;
+        int code = 0x7fffffff;
+        if (own_row || own_col) {
+            const int ck = own_row ? lane : myind, cl = own_row ? myind : oc;
+            p = A[N * ck + cl];
+            key = fabs(p);
+            if (key != key) key = lane == 0 ? __builtin_inf() : -1.;
+            code = lane << 16 | ck << 8 | cl;
         }
-#pragma unroll
-        for (int sh = 8; sh >= 1; sh >>= 1) {
-            const double ov = __shfl_xor(val, sh, 64);
-            const int oo = __shfl_xor(ord, sh, 64);
-            if (ov > val || (ov == val && oo < ord)) {
-                val = ov;
-                ord = oo;
-            }
-        }
-        ord = __shfl(ord, 0, 64);  // lanes 0..15 agree; broadcast to the rest of the wave
-        const int k = __shfl(ck, ord, 64), l = __shfl(cl, ord, 64);
-        const double p = A[N * k + l];
+        pivot_exchange<0xB1>(key, p, code);   // quad_perm [1 0 3 2]
+        pivot_exchange<0x4E>(key, p, code);   // quad_perm [2 3 0 1]
+        pivot_exchange<0x141>(key, p, code);  // row_half_mirror
+        pivot_exchange<0x140>(key, p, code);  // row_mirror
+        code = __builtin_amdgcn_readfirstlane(code);
+        p = uniform_f64(p);
+        const int k = (code >> 8) & 0xff, l = code & 0xff;
         if (fabs(p) <= eps) break;
-        const double y = (W[l] - W[k]) * 0.5;
+        const double y = (lane_f64(myW, l) - lane_f64(myW, k)) * 0.5;
         double t = fabs(y) + sm::hypot_p(p, y);
         double sn = sm::hypot_p(p, t);
         const double c = t / sn;
         sn = p / sn;
         t = (p / t) * p;
         if (y < 0) sn = -sn, t = -t;
-        WAVE_LDS_SYNC();  // every lane has read W[k], W[l], A[k][l]
-        if (lane == 0) {
-            A[N * k + l] = 0;
-            W[k] -= t;
-            W[l] += t;
-        }
+        if (lane == k) myW -= t;
+        if (lane == l) myW += t;
+        if (lane == 0) A[N * k + l] = 0;
         if (lane < N) {
             const int i = lane;
-            double a0, b0;
-            if (i < k) {
-                a0 = A[N * i + k], b0 = A[N * i + l];
-                A[N * i + k] = a0 * c - b0 * sn;
-                A[N * i + l] = a0 * sn + b0 * c;
-            } else if (i > k && i < l) {
-                a0 = A[N * k + i], b0 = A[N * i + l];
-                A[N * k + i] = a0 * c - b0 * sn;
-                A[N * i + l] = a0 * sn + b0 * c;
-            } else if (i > l) {
-                a0 = A[N * k + i], b0 = A[N * l + i];
-                A[N * k + i] = a0 * c - b0 * sn;
-                A[N * l + i] = a0 * sn + b0 * c;
+            if (i != k && i != l) {  // the stored (upper-triangle) copies of A(i, k) and A(i, l)
+                const int ak = i < k ? N * i + k : N * k + i, al = i < l ? N * i + l : N * l + i;
+                const double a0 = A[ak], b0 = A[al];
+                A[ak] = a0 * c - b0 * sn;
+                A[al] = a0 * sn + b0 * c;
             }
-            a0 = V[N * k + i], b0 = V[N * l + i];
+            const double a0 = V[N * k + i], b0 = V[N * l + i];
             V[N * k + i] = a0 * c - b0 * sn;
             V[N * l + i] = a0 * sn + b0 * c;
         }
         WAVE_LDS_SYNC();
-        if (lane == 0 && k < N - 1) indR[k] = scan_row(k);
-        if (lane == 1 && k > 0) indC[k] = scan_col(k);
-        if (lane == 2 && l < N - 1) indR[l] = scan_row(l);
-        if (lane == 3 && l > 0) indC[l] = scan_col(l);
-        WAVE_LDS_SYNC();
+        if ((own_row && (lane == k || lane == l)) || (own_col && (oc == k || oc == l))) myind = rescan();
     }
+    if (lane < N) W[lane] = myW;
+    WAVE_LDS_SYNC();
     if (lane == 0) {  // descending selection sort of the eigenvalues with their vectors
         for (int k = 0; k < N - 1; k++) {
             int m = k;
@@ -136,6 +156,7 @@ __device__ void jacobi_eigen_coop(double* A, double* W, double* V, int* ind, int
         }
     }
     WAVE_LDS_SYNC();
+    return iters;  // rotations applied (diagnostics only)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -224,27 +245,6 @@ __device__ __forceinline__ double seq_acc_two(const double* buf, int cnt, int i0
     return a;
 }
 // a += o[i0]*o[i1] + o[i2]*o[i3]   per point
-// a += o[i0]*o[i1]   per point: the form used for accumulators one of whose two Jacobian rows is structurally zero
-// (the homography Jacobian rows are [* * * 0 0 0 * *] and [0 0 0 * * * * *]): the skipped term is an exact +-0
-// product, and x + (+-0) == x for every x the running sum can hold (it starts at +0 and can never become -0)
-__device__ __forceinline__ double seq_acc_one(const double* buf, int cnt, int i0, int i1, double a) {
-    int k = 0;
-    for (; k + H_UNROLL <= cnt; k += H_UNROLL) {
-        double p0[H_UNROLL];
-#pragma unroll
-        for (int u = 0; u < H_UNROLL; ++u) {
-            const double* o = buf + (k + u) * 18;
-            p0[u] = o[i0] * o[i1];
-        }
-#pragma unroll
-        for (int u = 0; u < H_UNROLL; ++u) a += p0[u];
-    }
-    for (; k < cnt; k++) {
-        const double* o = buf + k * 18;
-        a += o[i0] * o[i1];
-    }
-    return a;
-}
 __device__ __forceinline__ double seq_acc_pair(const double* buf, int cnt, int i0, int i1, int i2, int i3, double a) {
     int k = 0;
     for (; k + H_UNROLL <= cnt; k += H_UNROLL) {
@@ -313,10 +313,26 @@ struct HRefineWork {
 // refine_on_reject: run the LM from H_fallback even when the DLT rejected the points (findHomography's RANSAC tail calls
 // runKernel and the LM unconditionally); false = leave H_fallback as the answer (cv::findHomography method 0 returns
 // an empty matrix there, which cvFindHomography turns into zeros).
+// trace (optional, diagnostics: DFVO_HREFINE_TRACE): 24 long long in global memory, written by thread 0 -- wall_clock64 ticks
+// (100 MHz) at [1] entry [2] centroids + scales done [3] LtL sums done [4] 9 x 9 eigen + de-normalisation done [5] first
+// Jacobian pass done [6] end; sums over the LM loop [8] 8 x 8 eigen [9] back-substitution [10] trial passes [11] lane-0 step
+// logic; [12] LM iterations [13] rotations of the 9 x 9 problem [14] rotations of all 8 x 8 problems [15] point count.
 template <class ChunkPts>
 __device__ __forceinline__ void h_refit_refine_block(HRefineShared& sh, HRefineWork& w, int np, ChunkPts chunk_pts,
-                                                     const double* H_fallback, bool refine_on_reject = true) {
+                                                     const double* H_fallback, bool refine_on_reject = true,
+                                                     long long* trace = nullptr) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    auto mark = [&](int i) {
+        if (trace && t == 0) trace[i] = wall_clock64();
+    };
+    auto add_since = [&](int i, long long t0) {
+        if (trace && t == 0) trace[i] += wall_clock64() - t0;
+    };
+    if (trace && t == 0) {
+        for (int i = 8; i < 15; i++) trace[i] = 0;
+        trace[15] = np;
+    }
+    mark(1);
     double* const s_h = w.h;
     double* const s_x = w.x;
     double* const s_xd = w.xd;
@@ -377,6 +393,7 @@ __device__ __forceinline__ void h_refit_refine_block(HRefineShared& sh, HRefineW
     }
     if (t < 4) s_norm[4 + t] = acc;
     __syncthreads();
+    mark(2);
     sm::HNorm hn;
     hn.cmx = s_norm[0];
     hn.cmy = s_norm[1];
@@ -422,7 +439,11 @@ __device__ __forceinline__ void h_refit_refine_block(HRefineShared& sh, HRefineW
             if (k < j) s_LtL[t] = s_LtL[k * 9 + j];
         }
         __syncthreads();
-        if (wave == 0) jacobi_eigen_coop<9>(s_LtL, s_eig, s_eig + 9, reinterpret_cast<int*>(s_eig + 90), lane);
+        mark(3);
+        if (wave == 0) {
+            const int rot = jacobi_eigen_coop<9>(s_LtL, s_eig, s_eig + 9, reinterpret_cast<int*>(s_eig + 90), lane);
+            if (trace && t == 0) trace[13] = rot;
+        }
         __syncthreads();
         if (t == 0) sm::homography_denormalise(hn, s_eig + 9 + 72, s_h);
     } else if (t == 0) {
@@ -437,6 +458,7 @@ __device__ __forceinline__ void h_refit_refine_block(HRefineShared& sh, HRefineW
     // ---- Levenberg-Marquardt on the 8 free parameters
     if (t < 8) s_x[t] = s_h[t];
     __syncthreads();
+    mark(4);
     // accumulator roles: t < 36 -> JtJ(i,j); 64..71 -> Jtr(i); 128 -> |r|^2 (4-row groups); 192 -> |r|_inf
     int ai = 0, aj = 0;
     if (t < 36) {
@@ -462,22 +484,14 @@ __device__ __forceinline__ void h_refit_refine_block(HRefineShared& sh, HRefineW
             h_chunk_lm(sh, cp, h, cnt, true);
             __syncthreads();
             if (t < 36) {
-                // row a is non-zero in columns {0,1,2,6,7}, row b in {3,4,5,6,7}
-                const bool ua = (ai < 3 || ai > 5) && (aj < 3 || aj > 5), ub = ai >= 3 && aj >= 3;
-                if (ua && ub)
-                    a = seq_acc_two(sh.buf, cnt, ai, aj, 8 + ai, 8 + aj, a);
-                else if (ua)
-                    a = seq_acc_one(sh.buf, cnt, ai, aj, a);
-                else if (ub)
-                    a = seq_acc_one(sh.buf, cnt, 8 + ai, 8 + aj, a);
+                // One loop for all 36 lanes.  (Until round 5 the lanes whose row-a or row-b factor is structurally zero -- row a
+                // is non-zero in columns {0,1,2,6,7}, row b in {3,4,5,6,7} -- skipped that term in loops of their own: three
+                // divergent loops run one after the other by the same wavefront, 60 us per pass over 590 inliers instead of 20.)
+                // The extra term is an exact +-0 product, and x + (+-0) == x for every x the running sum can hold (it starts at
+                // +0 and can never become -0): the sums are the same bits, and the same operations the reference's GEMM performs.
+                a = seq_acc_two(sh.buf, cnt, ai, aj, 8 + ai, 8 + aj, a);
             } else if (t >= 64 && t < 72) {
-                const int i = t - 64;
-                if (i < 3)
-                    a = seq_acc_one(sh.buf, cnt, i, 16, a);
-                else if (i < 6)
-                    a = seq_acc_one(sh.buf, cnt, 8 + i, 17, a);
-                else
-                    a = seq_acc_two(sh.buf, cnt, i, 16, 8 + i, 17, a);
+                a = seq_acc_two(sh.buf, cnt, t - 64, 16, 8 + t - 64, 17, a);
             } else if (t == 128) {
                 a = seq_acc_sq(sh.buf, cnt, a);
             } else if (t == 192) {
@@ -521,6 +535,7 @@ __device__ __forceinline__ void h_refit_refine_block(HRefineShared& sh, HRefineW
         __syncthreads();
     };
     full_pass(s_x, false);
+    mark(5);
     if (t < 8) s_D[t] = s_A[t * 8 + t];
     if (t == 0) {
         s_lambda = 1;
@@ -536,14 +551,24 @@ __device__ __forceinline__ void h_refit_refine_block(HRefineShared& sh, HRefineW
         if (t < 8) s_Ap[t * 8 + t] += s_lambda * s_D[t];
         __syncthreads();
         // solve(Ap, v, d, DECOMP_EIG): eigen decomposition on wave 0 (in place), back-substitution on lane 0
-        if (wave == 0) jacobi_eigen_coop<8>(s_Ap, s_eig + 64, s_eig, reinterpret_cast<int*>(s_eig + 72), lane);
+        long long tr0 = trace ? wall_clock64() : 0;
+        if (wave == 0) {
+            const int rot = jacobi_eigen_coop<8>(s_Ap, s_eig + 64, s_eig, reinterpret_cast<int*>(s_eig + 72), lane);
+            if (trace && t == 0) trace[14] += rot;
+        }
         __syncthreads();
+        add_since(8, tr0);
+        tr0 = trace ? wall_clock64() : 0;
         if (t == 0) {
             sm::svbksb_eig_vec<8>(s_eig + 64, s_eig, s_v, s_d);
             for (int i = 0; i < 8; i++) s_xd[i] = s_x[i] - s_d[i];
         }
         __syncthreads();
+        add_since(9, tr0);
+        tr0 = trace ? wall_clock64() : 0;
         full_pass(s_xd, true);  // |r(x - d)|^2 -> s_Sd, and the Jacobian sums the step needs if it is accepted
+        add_since(10, tr0);
+        tr0 = trace ? wall_clock64() : 0;
         if (t == 0) {
             const double Sd = s_Sd;
             double temp_d[8], d[8], v[8];
@@ -583,6 +608,7 @@ __device__ __forceinline__ void h_refit_refine_block(HRefineShared& sh, HRefineW
             s_flag = Sd < S ? 1 : 0;
         }
         __syncthreads();
+        add_since(11, tr0);
         if (s_flag) {
             if (t < 8) {
                 const double tx = s_x[t];
@@ -603,6 +629,8 @@ __device__ __forceinline__ void h_refit_refine_block(HRefineShared& sh, HRefineW
         __syncthreads();
         if (!proceed) break;
     }
+    if (trace && t == 0) trace[12] = iter;
+    mark(6);
 }
 
 }  // namespace dfvo

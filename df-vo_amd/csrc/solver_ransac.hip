@@ -590,8 +590,9 @@ __global__ __launch_bounds__(256) void k_h_refine(const RansacState* st, const f
     __shared__ HRefineShared sh;
     extern __shared__ float s_allpts[];  // Mx My mx my of every inlier when they fit (pts_cap points)
     __shared__ HRefineWork w;
-    (void)lm;
+    long long* const trace = reinterpret_cast<long long*>(lm);  // null unless DFVO_HREFINE_TRACE (see h_refit_refine_block)
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (trace && t == 0) trace[0] = wall_clock64();
     const int n = d_n ? *d_n : n_arg;
     if (!st->found) {  // no model: all-zero mask (what k_h_mask writes in the stand-alone path)
         for (int i = t; i < n; i += 256) mask[i] = 0;
@@ -644,7 +645,7 @@ __global__ __launch_bounds__(256) void k_h_refine(const RansacState* st, const f
         __syncthreads();
         return sh.pts;
     };
-    h_refit_refine_block(sh, w, np, chunk_pts, H_io);
+    h_refit_refine_block(sh, w, np, chunk_pts, H_io, true, trace);
     if (t < 8) H_io[t] = w.x[t];
     if (t == 8) H_io[8] = w.h[8];
 }
@@ -684,9 +685,25 @@ int enqueue_find_homography(RansacWorkspace& w, const double* d_pts1, const doub
     if (pts_cap)
         if (int rc_lds = ensure_dyn_lds((const void*)k_h_refine, 6144 * 16)) return rc_lds;
     // inlier mask of the winner + refit + LM in one launch
+    // DFVO_HREFINE_TRACE=1 (diagnostics): phase timestamps of the launch, printed after a stream synchronisation
+    static const bool trace_on = getenv("DFVO_HREFINE_TRACE") != nullptr;
+    double* const d_trace = trace_on ? w.lm + (size_t)20 * w.cap_n + 256 : nullptr;
+    if (trace_on) DFVO_HIP_CHECK(hipMemsetAsync(d_trace, 0, 24 * sizeof(long long), s));
     hipLaunchKernelGGL(k_h_refine, dim3(1), dim3(256), (size_t)pts_cap * 16, s, w.state, w.f_a, w.f_b, n, d_n, w.mask, w.cidx,
-                       w.lm, w.out, pts_cap, w.models, thr2);
+                       d_trace, w.out, pts_cap, w.models, thr2);
     DFVO_HIP_CHECK(hipGetLastError());
+    if (trace_on) {
+        long long tr[24];
+        DFVO_HIP_CHECK(hipMemcpyAsync(tr, d_trace, sizeof(tr), hipMemcpyDeviceToHost, s));
+        DFVO_HIP_CHECK(hipStreamSynchronize(s));
+        auto us = [&](int a, int b) { return tr[b] && tr[a] ? (tr[b] - tr[a]) * 0.01 : -1.0; };
+        fprintf(stderr,
+                "k_h_refine trace: inliers %lld | mask+compaction+cache %.1f us | centroids+scales %.1f | LtL sums %.1f | eigen 9x9 %.1f "
+                "(%lld rotations) | first J pass %.1f | LM: %lld iterations, eigen 8x8 %.1f (%lld rotations), back-subst %.1f, trial "
+                "passes %.1f, step logic %.1f | total %.1f us\n",
+                tr[15], us(0, 1), us(1, 2), us(2, 3), us(3, 4), tr[13], us(4, 5), tr[12], tr[8] * 0.01, tr[14], tr[9] * 0.01,
+                tr[10] * 0.01, tr[11] * 0.01, us(0, 6));
+    }
     return DFVO_OK;
 }
 

@@ -4,6 +4,7 @@
 the global np.random stream through the device.  No CPU fallback."""
 import copy
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -22,10 +23,12 @@ def feed_timers(timers, slots):
     """append the device times of the last solver call to the reference's Timer under its own sub-keys: the stages run
     as kernels behind one C call here, so their durations come from HIP events between them (dfvo_tracker_stage_ms), not
     from host clocks around Python statements.  `timers` is the reference's libs.general.timer.Timer (or None)."""
-    if timers is None:
+    if timers is None and not os.environ.get("DFVO_STAGE_OFFSETS"):
         return
     ms = np.zeros(8)
-    capi.check(capi.lib().dfvo_tracker_stage_ms(_ctx.tracker(), capi.as_ptr(ms)))
+    capi.check(capi.lib().dfvo_tracker_stage_ms(_ctx.tracker(), capi.as_ptr(ms)))  # (DFVO_STAGE_OFFSETS: prints the marks)
+    if timers is None:
+        return
     for i in slots:
         if ms[i] < 0:
             continue
