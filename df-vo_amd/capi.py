@@ -118,7 +118,8 @@ SIGNATURES = {
     "dfvo_session_depth": (_i, [_vp, C.c_longlong, C.POINTER(_vp)]),
     "dfvo_session_flow": (_i, [_vp, C.c_longlong, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "dfvo_session_keypoints": (_i, [_vp, C.c_longlong, _vp, C.POINTER(_vp), C.POINTER(_vp), _ip, _ip]),
-    "dfvo_session_pose_2d2d": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _ip]),
+    "dfvo_session_pose_ahead": (_i, [_vp, C.c_longlong, _vp, _vp, _ip]),
+    "dfvo_session_pose_2d2d": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _ip]),
     "dfvo_set_conv_precision": (_i, [C.c_char_p]),
     "dfvo_set_sklearn_compat": (_i, [C.c_char_p]),
     "dfvo_f16s_overflow_count": (_i, [C.POINTER(C.c_ulonglong), _i]),

@@ -18,8 +18,12 @@
 // given the two frames that were pushed, kp_selection that the flow arrays it is handed are the session's (generation
 // token + sampled contents, df-vo_amd/libs/deep_models/session.py), compute_pose_2d2d compares the keypoint arrays and
 // the configuration byte for byte with what the device holds; any mismatch takes the plain host-array entry point.
-// The RandomState-consuming half (shuffles, five-point RANSACs, recoverPose) and the scale recovery stay where the
-// reference has them, behind np.random's state at the time of the call.
+// The RandomState-consuming half (shuffles, five-point RANSACs, recoverPose) needs np.random's state at the time of the
+// compute_pose_2d2d call.  dfvo_session_pose_ahead (called by the DeepModel mirror from forward_flow, the first moment the host
+// is back after the push) enqueues it under np.random's state AT THAT MOMENT; compute_pose_2d2d consumes the result only if
+// np.random's state at its own call is still that state, word for word (and keypoints and configuration match) -- the
+// reference's frame loop draws nothing in between (dfvo.py:324-333, 147-168) -- and otherwise waits for it, uploads the state
+// it was called under and runs the plain entry point.  The scale recovery stays where the reference has it.
 #include <algorithm>
 #include <cstring>
 #include <vector>
@@ -44,12 +48,15 @@ struct dfvo_session {
     bool carry_ok = false;       // the flow net's current-frame pyramids are those of frame `gen`
     bool have_flow = false;      // a flow pass of (gen - 1, gen) is enqueued / done
     bool have_kp = false, have_h = false;
+    bool have_e = false;         // the RandomState-consuming half of compute_pose_2d2d is enqueued (dfvo_session_pose_ahead)
+    uint32_t rng_ahead[625] = {};            // ... under this RandomState
+    unsigned char ahead_cfg[sizeof(dfvo_pose2d2d_cfg)] = {};  // ... and this configuration (bytes)
     float* h_depth[RING] = {};
     float *h_fwd[RING] = {}, *h_bwd[RING] = {}, *h_diff[RING] = {};
     double *h_kp_ref[RING] = {}, *h_kp_cur[RING] = {};
     int* h_info[RING] = {};
     int kp_cap = 0;
-    hipEvent_t e_img = nullptr, e_depth = nullptr, e_net = nullptr, e_flow = nullptr, e_kp = nullptr;
+    hipEvent_t e_img = nullptr, e_depth = nullptr, e_net = nullptr, e_flow = nullptr, e_kp = nullptr, e_pose = nullptr;
     dfvo_session_kp_cfg kp_cfg = {};
     dfvo_pose2d2d_cfg pose_cfg = {};
 };
@@ -129,8 +136,8 @@ int dfvo_session_create(dfvo_flownet* f, dfvo_depthnet* d, dfvo_tracker* t, int 
              hipHostMalloc((void**)&s->h_diff[i], px * sizeof(float)) == hipSuccess &&
              hipHostMalloc((void**)&s->h_info[i], 4 * sizeof(int)) == hipSuccess;
     }
-    hipEvent_t* evs[5] = {&s->e_img, &s->e_depth, &s->e_net, &s->e_flow, &s->e_kp};
-    for (int i = 0; i < 5 && ok; ++i) ok = hipEventCreateWithFlags(evs[i], hipEventDisableTiming) == hipSuccess;
+    hipEvent_t* evs[6] = {&s->e_img, &s->e_depth, &s->e_net, &s->e_flow, &s->e_kp, &s->e_pose};
+    for (int i = 0; i < 6 && ok; ++i) ok = hipEventCreateWithFlags(evs[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
         dfvo_session_destroy(s);
         dfvo::set_last_error("dfvo_session_create: allocation failed");
@@ -154,7 +161,7 @@ void dfvo_session_destroy(dfvo_session* s) {
         for (void* q : hp)
             if (q) (void)hipHostFree(q);
     }
-    hipEvent_t evs[5] = {s->e_img, s->e_depth, s->e_net, s->e_flow, s->e_kp};
+    hipEvent_t evs[6] = {s->e_img, s->e_depth, s->e_net, s->e_flow, s->e_kp, s->e_pose};
     for (hipEvent_t e : evs)
         if (e) (void)hipEventDestroy(e);
     if (s->s_copy) (void)hipStreamDestroy(s->s_copy);
@@ -165,7 +172,7 @@ void dfvo_session_destroy(dfvo_session* s) {
 int dfvo_session_reset(dfvo_session* s) {
     DFVO_ARG_CHECK(s, "dfvo_session_reset: null session");
     DFVO_HIP_CHECK(hipDeviceSynchronize());
-    s->carry_ok = s->have_flow = s->have_kp = s->have_h = false;
+    s->carry_ok = s->have_flow = s->have_kp = s->have_h = s->have_e = false;
     s->gen = -1;
     return DFVO_OK;
 }
@@ -181,7 +188,8 @@ int dfvo_session_invalidate_carry(dfvo_session* s) {
 int dfvo_session_quiesce(dfvo_session* s) {
     DFVO_ARG_CHECK(s, "dfvo_session_quiesce: null session");
     DFVO_HIP_CHECK(hipStreamSynchronize(s->s_pre));
-    s->have_h = false;  // its buffers are about to be overwritten: compute_pose_2d2d must restage
+    if (s->have_e && s->t) DFVO_HIP_CHECK(hipStreamSynchronize(s->t->stream));
+    s->have_h = s->have_e = false;  // their buffers are about to be overwritten: compute_pose_2d2d must restage
     return DFVO_OK;
 }
 
@@ -215,7 +223,7 @@ int dfvo_session_push_frame(dfvo_session* s, const uint8_t* h_img, const dfvo_se
     DFVO_HIP_CHECK(hipMemcpyAsync(img, h_img, px * 3, hipMemcpyHostToDevice, s->s_copy));
     DFVO_HIP_CHECK(hipEventRecord(s->e_img, s->s_copy));
     // ---- flow net of (g - 1, g) first: it is the long pole
-    s->have_flow = s->have_kp = s->have_h = false;
+    s->have_flow = s->have_kp = s->have_h = s->have_e = false;
     if (g >= 1) {
         DFVO_HIP_CHECK(hipStreamWaitEvent(fn.stream, s->e_img, 0));
         if (s->carry_ok)
@@ -247,6 +255,7 @@ int dfvo_session_push_frame(dfvo_session* s, const uint8_t* h_img, const dfvo_se
     if (g >= 1 && kp && s->t) {
         TrackerBuffers& tb = s->t->tb;
         DFVO_HIP_CHECK(hipStreamWaitEvent(s->s_pre, s->e_net, 0));
+        DFVO_HIP_CHECK(hipStreamWaitEvent(s->s_pre, s->e_pose, 0));  // (an early pose half nobody consumed may still be running)
         S_TRY(enqueue_local_bestn(tb, fn.out_fwd.p, fn.out_diff.p, s->H, s->W, kp->num_row, kp->num_col, kp->num_bestN, kp->thre,
                                   s->s_pre, kp->score_method));
         S_TRY(ensure_kp_host(s, tb.kp_cap));
@@ -305,26 +314,70 @@ int dfvo_session_keypoints(dfvo_session* s, long long generation, const dfvo_ses
     return DFVO_OK;
 }
 
-// EssTracker.compute_pose_2d2d through the session: when the keypoints handed in are, byte for byte, the ones the device
-// selected for this generation and the homography half was enqueued with this very configuration, only the
-// RandomState-consuming half is enqueued (*used_resident = 1); otherwise the plain entry point runs (*used_resident = 0).
+// does (kp arrays, configuration) ask for what the homography half of this generation was enqueued with?
+static bool h_half_matches(dfvo_session* s, const double* h_kp_ref, const double* h_kp_cur, int n, const dfvo_pose2d2d_cfg* cfg) {
+    const int slot = (int)(s->gen % RING);
+    // the homography half reads: the keypoints, validity method / threshold, K^-T, K^-1 (enqueue_pose_h_part)
+    return s->h_info[slot][1] != 0 && s->h_info[slot][0] == n && n <= s->kp_cap &&
+           memcmp(h_kp_ref, s->h_kp_ref[slot], sizeof(double) * 2 * n) == 0 &&
+           memcmp(h_kp_cur, s->h_kp_cur[slot], sizeof(double) * 2 * n) == 0 &&
+           cfg->validity_method == s->pose_cfg.validity_method && cfg->validity_thre == s->pose_cfg.validity_thre &&
+           memcmp(cfg->KinvT, s->pose_cfg.KinvT, sizeof(cfg->KinvT)) == 0 && memcmp(cfg->Kinv, s->pose_cfg.Kinv, sizeof(cfg->Kinv)) == 0;
+}
+
+// The RandomState-consuming half of compute_pose_2d2d, enqueued as soon as the keypoints of this generation exist, under the
+// RandomState the caller has NOW (h_rng625: numpy's 624 key words + position).  *enqueued = 1 when it was (the keypoint
+// selection found keypoints and the homography half runs with this configuration); dfvo_session_pose_2d2d hands its result
+// out if it is then called under the same RandomState, keypoints and configuration, and discards it otherwise.
+int dfvo_session_pose_ahead(dfvo_session* s, long long generation, const uint32_t* h_rng625, const dfvo_pose2d2d_cfg* cfg,
+                            int* enqueued) {
+    DFVO_ARG_CHECK(s && h_rng625 && cfg && enqueued, "dfvo_session_pose_ahead: bad argument");
+    *enqueued = 0;
+    if (!(s->t && generation == s->gen && s->gen >= 1 && s->have_kp && s->have_h && !s->have_e)) return DFVO_OK;
+    DFVO_HIP_CHECK(hipEventSynchronize(s->e_kp));
+    const int slot = (int)(s->gen % RING);
+    const int n = s->h_info[slot][0];
+    if (!h_half_matches(s, s->h_kp_ref[slot], s->h_kp_cur[slot], n, cfg)) return DFVO_OK;  // (no keypoints / another configuration)
+    PoseConfig pc;
+    S_TRY(dfvo_pose_config_from(cfg, &pc));
+    S_TRY(dfvo_tracker_set_rng_state(s->t, h_rng625));
+    S_TRY(enqueue_pose_e_part(s->t->tb, n, pc, s->t->stream, nullptr));  // waits for the homography half (tb.ev_h) on the device
+    DFVO_HIP_CHECK(hipEventRecord(s->e_pose, s->t->stream));
+    memcpy(s->rng_ahead, h_rng625, sizeof(s->rng_ahead));
+    memcpy(s->ahead_cfg, cfg, sizeof(s->ahead_cfg));
+    s->have_e = true;
+    *enqueued = 1;
+    return DFVO_OK;
+}
+
+// EssTracker.compute_pose_2d2d through the session, under the RandomState h_rng625 (np.random's state at the call).
+// *used_resident: 2 = the whole call had been enqueued ahead under exactly this RandomState, these keypoints and this
+// configuration (dfvo_session_pose_ahead): its result is handed out; 1 = the keypoints handed in are, byte for byte, the ones
+// the device selected for this generation and the homography half was enqueued with this very configuration: only the
+// RandomState-consuming half runs now; 0 = the plain entry point ran.
 int dfvo_session_pose_2d2d(dfvo_session* s, const double* h_kp_ref, const double* h_kp_cur, int n,
-                           const dfvo_pose2d2d_cfg* cfg, dfvo_pose2d2d_out* out, uint8_t* h_inliers, int* used_resident) {
-    DFVO_ARG_CHECK(s && s->t && h_kp_ref && h_kp_cur && cfg && out && h_inliers && n >= 0, "dfvo_session_pose_2d2d: bad argument");
+                           const dfvo_pose2d2d_cfg* cfg, dfvo_pose2d2d_out* out, uint8_t* h_inliers, const uint32_t* h_rng625,
+                           int* used_resident) {
+    DFVO_ARG_CHECK(s && s->t && h_kp_ref && h_kp_cur && cfg && out && h_inliers && h_rng625 && n >= 0,
+                   "dfvo_session_pose_2d2d: bad argument");
     bool resident = s->have_kp && s->have_h && s->gen >= 1;
     if (resident) {
         DFVO_HIP_CHECK(hipEventSynchronize(s->e_kp));
-        const int slot = (int)(s->gen % RING);
-        // the homography half reads: the keypoints, validity method / threshold, K^-T, K^-1 (enqueue_pose_h_part)
-        resident = s->h_info[slot][1] != 0 && s->h_info[slot][0] == n && n <= s->kp_cap &&
-                   memcmp(h_kp_ref, s->h_kp_ref[slot], sizeof(double) * 2 * n) == 0 &&
-                   memcmp(h_kp_cur, s->h_kp_cur[slot], sizeof(double) * 2 * n) == 0 &&
-                   cfg->validity_method == s->pose_cfg.validity_method && cfg->validity_thre == s->pose_cfg.validity_thre &&
-                   memcmp(cfg->KinvT, s->pose_cfg.KinvT, sizeof(cfg->KinvT)) == 0 &&
-                   memcmp(cfg->Kinv, s->pose_cfg.Kinv, sizeof(cfg->Kinv)) == 0;
+        resident = h_half_matches(s, h_kp_ref, h_kp_cur, n, cfg);
     }
-    if (used_resident) *used_resident = resident ? 1 : 0;
-    s->have_h = false;  // the homography half is consumed (or abandoned) by this call
+    const bool had_ahead = s->have_e;
+    const bool ahead = had_ahead && resident && memcmp(cfg, s->ahead_cfg, sizeof(s->ahead_cfg)) == 0 &&
+                       memcmp(h_rng625, s->rng_ahead, sizeof(s->rng_ahead)) == 0;
+    s->have_h = s->have_e = false;  // both halves are consumed (or abandoned) by this call
+    if (used_resident) *used_resident = ahead ? 2 : (resident && !had_ahead) ? 1 : 0;
+    if (ahead) return dfvo_pose_fetch(s->t, n, cfg, out, h_inliers);
+    if (had_ahead) {
+        // enqueued under another RandomState / configuration / keypoint set: let it finish, discard it; the plain entry point
+        // restages everything it needs
+        DFVO_HIP_CHECK(hipStreamSynchronize(s->t->stream));
+        resident = false;
+    }
+    S_TRY(dfvo_tracker_set_rng_state(s->t, h_rng625));
     if (!resident) {
         // the speculative half may still be running on the tracker's buffers: let it finish before they are restaged
         DFVO_HIP_CHECK(hipStreamSynchronize(s->s_pre));

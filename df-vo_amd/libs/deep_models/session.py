@@ -9,9 +9,12 @@ wait for an event and hand out the result, IF they are asked for what was enqueu
   * the flow / consistency arrays it returns are SessionArray views of pinned host buffers; a copy of one (dfvo.py:330-333
     copies them) keeps the generation token, any write through the array drops it, and kp_selection additionally compares a
     strided sample of the contents with the session's buffer before it trusts the device-resident copy,
-  * compute_pose_2d2d compares keypoints and configuration byte for byte on the C side.
+  * compute_pose_2d2d compares keypoints and configuration byte for byte on the C side; its RandomState-consuming half is
+    enqueued AHEAD, from forward_flow, under np.random's state at that moment, and its result is handed out only if
+    np.random's state at the compute_pose_2d2d call is still that state, word for word (DFVO_SESSION_POSE_AHEAD=0: never ahead).
 Anything else takes the plain host-array entry point -- same results, the round-3 speed."""
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -80,8 +83,10 @@ class FrameSession:
         self._img_idx = _sample_idx(self.h * self.w * 3)
         self._flow_idx = {n: _sample_idx(sz) for n, sz in (("fwd", 2 * self.h * self.w), ("bwd", 2 * self.h * self.w),
                                                            ("diff", self.h * self.w))}
+        self.pose_ahead = os.environ.get("DFVO_SESSION_POSE_AHEAD", "1") != "0"
+        self.rng_words = None   # () -> np.random's state as 625 uint32 words (libs/tracker/_ctx.numpy_rng_words)
         self.stats = {"push": 0, "flow_resident": 0, "flow_plain": 0, "kp_resident": 0, "kp_plain": 0, "pose_resident": 0,
-                      "pose_plain": 0}
+                      "pose_plain": 0, "pose_ahead": 0}
 
     def close(self):
         if self.handle is not None:
@@ -150,7 +155,18 @@ class FrameSession:
                 v._dfvo_tok = (self.sid, self.gen, name)
                 out.append(v)
             self.flow_views = (self.gen,) + tuple(out)
+            self._enqueue_pose_ahead()
         return self.flow_views[1:]
+
+    def _enqueue_pose_ahead(self):
+        """the host is back for the first time since the push and the flow exists: the rest of compute_pose_2d2d can run now,
+        under np.random's state as it is now (validated again when compute_pose_2d2d is called)"""
+        if not (self.pose_ahead and self.kp_spec is not None and self.pose_cfg_fn is not None and self.rng_words is not None):
+            return
+        cfg, words, enq = self.pose_cfg_fn(), self.rng_words(), C.c_int()
+        capi.check(self.lib.dfvo_session_pose_ahead(self.handle, self.gen, capi.as_ptr(words), C.byref(cfg), C.byref(enq)))
+        if enq.value:
+            self.spec_inflight = True
 
     # -- KeypointSampler.kp_selection ------------------------------------------------------------------------------
     def _is_buffer(self, arr, name):
@@ -180,10 +196,13 @@ class FrameSession:
         return _pinned(pr, C.c_double, (nn, 2)), _pinned(pc, C.c_double, (nn, 2)), nn, int(good.value)
 
     # -- EssTracker.compute_pose_2d2d ------------------------------------------------------------------------------
-    def pose_2d2d(self, kp_ref, kp_cur, n, cfg, out, inliers):
+    def pose_2d2d(self, kp_ref, kp_cur, n, cfg, out, inliers, rng_words):
+        """rng_words: np.random's state at this call (625 uint32); the advanced state is left on the device"""
         used = C.c_int()
         self.spec_inflight = False  # (the C side waits for the stage -- or, on a mismatch, for its stream -- itself)
         capi.check(self.lib.dfvo_session_pose_2d2d(self.handle, capi.as_ptr(kp_ref), capi.as_ptr(kp_cur), n, C.byref(cfg),
-                                                   C.byref(out), capi.as_ptr(inliers), C.byref(used)))
+                                                   C.byref(out), capi.as_ptr(inliers), capi.as_ptr(rng_words), C.byref(used)))
         self.stats["pose_resident" if used.value else "pose_plain"] += 1
+        if used.value == 2:
+            self.stats["pose_ahead"] += 1
         return bool(used.value)

@@ -82,12 +82,13 @@ class EssTracker:
         cfg = self._pose_cfg(is_iterative)
         out = capi.Pose2d2dOut()
         inl = np.zeros(max(n, 1), np.uint8)
-        _ctx.push_numpy_rng()
         if _ctx.session is not None:
-            # (the C side compares keypoints and configuration with what the device holds; on a match only the
-            # RandomState-consuming half is left to run)
-            _ctx.session.pose_2d2d(kp_ref, kp_cur, n, cfg, out, inl)
+            # (the C side compares keypoints, configuration and RandomState with what the device holds: on a full match the
+            # call was enqueued ahead and only its result is fetched; with matching keypoints only the RandomState-consuming
+            # half is left to run; else the plain entry point -- always under np.random's state as it is now)
+            _ctx.session.pose_2d2d(kp_ref, kp_cur, n, cfg, out, inl, _ctx.numpy_rng_words())
         else:
+            _ctx.push_numpy_rng()
             capi.check(capi.lib().dfvo_compute_pose_2d2d(_ctx.tracker_exclusive(), capi.as_ptr(kp_ref), capi.as_ptr(kp_cur), n,
                                                          C.byref(cfg), C.byref(out), capi.as_ptr(inl)))
         _ctx.pull_numpy_rng()

@@ -18,6 +18,7 @@ def register_session(s):
     if s is not None:
         s.kp_cfg = _kp_cfg
         s.pose_cfg_fn = _pose_cfg_fn
+        s.rng_words = numpy_rng_words
 
 
 def register_kp_cfg(c):
@@ -52,10 +53,18 @@ def tracker_exclusive():
     return tracker()
 
 
-def push_numpy_rng():
-    """upload np.random's global RandomState (the stream the reference consumes) to the device"""
+def numpy_rng_words():
+    """np.random's global RandomState (the stream the reference consumes) as the 625 words the C ABI takes: key | position"""
     st = np.random.get_state()
-    s = np.ascontiguousarray(np.r_[st[1].astype(np.uint32), np.uint32(st[2])])
+    s = np.empty(625, np.uint32)
+    s[:624] = st[1]
+    s[624] = st[2]
+    return s
+
+
+def push_numpy_rng():
+    """upload np.random's global RandomState to the device"""
+    s = numpy_rng_words()
     capi.check(capi.lib().dfvo_tracker_set_rng_state(tracker(), capi.as_ptr(s)))
 
 

@@ -467,7 +467,8 @@ double dfvo_pipeline_net_flops(const dfvo_pipeline* p);
  * buffers, and -- when the KeypointSampler / EssTracker mirrors registered their configurations (kp, pose non-NULL) --
  * local_bestN and the RandomState-independent half of compute_pose_2d2d (findHomography + refinement + GRIC-H) behind the
  * flow net.  The later calls wait for an event and hand out the result; each validates that it is asked for exactly what
- * was enqueued (generation, configuration, keypoint arrays byte for byte) and otherwise runs the plain entry point.
+ * was enqueued (generation, configuration, keypoint arrays byte for byte, RandomState word for word) and otherwise runs the
+ * plain entry point.
  * Results are identical to the plain entry points' (tests/test_dropin_gpu.py).  Host pointers returned here are pinned
  * buffers owned by the session, valid until two further frames have been pushed.  Not re-entrant. */
 typedef struct dfvo_session dfvo_session;
@@ -489,9 +490,17 @@ int dfvo_session_depth(dfvo_session* s, long long generation, const float** h_de
 int dfvo_session_flow(dfvo_session* s, long long generation, const float** h_fwd, const float** h_bwd, const float** h_diff);
 int dfvo_session_keypoints(dfvo_session* s, long long generation, const dfvo_session_kp_cfg* kp, const double** h_kp_ref,
                            const double** h_kp_cur, int* n, int* good_kp_found);
-/* dfvo_compute_pose_2d2d through the session; *used_resident = 1 when only the RandomState-consuming half had to run */
+/* The RandomState-consuming half of compute_pose_2d2d (shuffles, five-point RANSACs, GRIC-E, recoverPose) enqueued AHEAD of
+ * the call, as soon as the keypoints of `generation` exist, under the RandomState the caller has now (h_rng625: numpy's 624
+ * key words + position).  The DeepModel mirror calls it from forward_flow.  *enqueued = 1 when it was. */
+int dfvo_session_pose_ahead(dfvo_session* s, long long generation, const uint32_t* h_rng625, const dfvo_pose2d2d_cfg* cfg,
+                            int* enqueued);
+/* dfvo_compute_pose_2d2d through the session, under the RandomState h_rng625 (np.random's state at the call; the tracker's
+ * device copy is set from it unless the result enqueued ahead is handed out).  *used_resident = 2: the call had been enqueued
+ * ahead under exactly this RandomState, these keypoints and this configuration; 1: only the RandomState-consuming half had
+ * to run; 0: the plain entry point ran.  Read the advanced state back with dfvo_tracker_get_rng_state. */
 int dfvo_session_pose_2d2d(dfvo_session* s, const double* h_kp_ref, const double* h_kp_cur, int n, const dfvo_pose2d2d_cfg* cfg,
-                           dfvo_pose2d2d_out* out, uint8_t* h_inliers, int* used_resident);
+                           dfvo_pose2d2d_out* out, uint8_t* h_inliers, const uint32_t* h_rng625, int* used_resident);
 
 /* DFVO.update_global_pose (dfvo.py:109-119: t_w += R_w t, then R_w = R_w R) over a whole gathered sequence in ONE launch,
  * constant-motion rows included (dfvo.py:157-161: a row with status 1 reuses the previous pair's relative motion).

@@ -272,6 +272,7 @@ def test_mirrors_from_weight_files_reproduce_reference_main_loop(gpu, tmp_path):
     print("   modes", modes, "| final t (mirrors)", poses[-1][:3, 3], "(reference DFVO.main)", fx["poses"][-1][:3, 3], "| session", st)
     # the frame loop is exactly the call order the session is built for: every pair must have taken the resident paths
     assert st["push"] == n and st["flow_resident"] == n - 1 and st["kp_resident"] == n - 1 and st["pose_resident"] == n - 1
+    assert st["pose_ahead"] == n - 1  # ... and every compute_pose_2d2d had been enqueued from forward_flow
     assert st["flow_plain"] == st["kp_plain"] == st["pose_plain"] == 0
     assert modes == list(fx["modes"])
     # the nets differ from the reference's torch-CPU nets in fp32 summation order (<= 2e-3 px on the flow), which can move
@@ -308,7 +309,7 @@ def test_frame_session_returns_what_the_plain_entry_points_return(gpu, tmp_path,
         for k in a:
             assert np.array_equal(a[k], b[k]), "pair result '%s' differs between the plain entry points and the session" % k
     st = mir[0].session.stats
-    assert st["flow_resident"] == st["kp_resident"] == st["pose_resident"] == n - 1, st
+    assert st["flow_resident"] == st["kp_resident"] == st["pose_resident"] == st["pose_ahead"] == n - 1, st
     # ---- misuse: the session must fall back, never answer from stale state
     deep_models, sampler, e_tracker, _, _ = mir
     s = deep_models.session
@@ -333,6 +334,34 @@ def test_frame_session_returns_what_the_plain_entry_points_return(gpu, tmp_path,
     assert s.stats["kp_plain"] == before["kp_plain"] + 1
     want = T.local_bestN(np.asarray(fwd), np.asarray(diff))
     assert np.array_equal(out["kp1_best"], want["kp1_best"]) and np.array_equal(out["kp2_best"], want["kp2_best"])
+    # np.random consumed between forward_flow (where the RandomState-consuming half of compute_pose_2d2d was enqueued ahead)
+    # and compute_pose_2d2d: the result enqueued ahead is discarded, the call runs under the state it was made in
+    deep_models.forward_depth(imgs=[ref["img"]])
+    deep_models.forward_depth(imgs=[cur["img"]])
+    flows = deep_models.forward_flow(cur, ref, True)
+    sel = sampler.kp_selection({"depth": depth}, {"flow": flows[(0, 1)].copy(), "flow_diff": flows[(0, 1, "diff")].copy(), "depth": depth})
+    np.random.seed(9)
+    np.random.randint(0, 10, 3)
+    st_call = np.random.get_state()
+    before = dict(s.stats)
+    got = e_tracker.compute_pose_2d2d(sel["kp1_best"][0], sel["kp2_best"][0], True)
+    st_after = np.random.get_state()
+    assert s.stats["pose_plain"] == before["pose_plain"] + 1 and s.stats["pose_ahead"] == before["pose_ahead"]
+    np.random.set_state(st_call)
+    res = T.compute_pose_2d2d(np.array(sel["kp1_best"][0]), np.array(sel["kp2_best"][0]), seq["K"])
+    assert np.array_equal(got["pose"].R, res["R"]) and np.array_equal(got["pose"].t, res["t"])
+    assert np.array_equal(st_after[1], np.random.get_state()[1]) and st_after[2] == np.random.get_state()[2]
+    # ... and undisturbed, the same pair is answered from what was enqueued ahead, with the same bits as the plain path gives
+    deep_models.forward_depth(imgs=[ref["img"]])
+    deep_models.forward_depth(imgs=[cur["img"]])
+    np.random.set_state(st_call)
+    flows = deep_models.forward_flow(cur, ref, True)
+    sel2 = sampler.kp_selection({"depth": depth}, {"flow": flows[(0, 1)].copy(), "flow_diff": flows[(0, 1, "diff")].copy(), "depth": depth})
+    before = dict(s.stats)
+    got2 = e_tracker.compute_pose_2d2d(sel2["kp1_best"][0], sel2["kp2_best"][0], True)
+    assert s.stats["pose_ahead"] == before["pose_ahead"] + 1
+    assert np.array_equal(got2["pose"].R, res["R"]) and np.array_equal(got2["pose"].t, res["t"]) and np.array_equal(got2["inliers"], got["inliers"])
+    assert np.array_equal(st_after[1], np.random.get_state()[1]) and st_after[2] == np.random.get_state()[2]
     # keypoints other than the device's: compute_pose_2d2d takes the plain path and still matches the oracle
     np.random.seed(5)
     kp1, kp2 = out["kp1_best"][0][::2].copy(), out["kp2_best"][0][::2].copy()
