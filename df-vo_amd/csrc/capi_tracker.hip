@@ -435,15 +435,19 @@ int dfvo_compute_pose_2d2d(dfvo_tracker* t, const double* h_kp_ref, const double
 
 int dfvo_set_sklearn_compat(const char* version) { return dfvo::set_sklearn_compat(version); }
 
-int dfvo_find_scale_from_depth(dfvo_tracker* t, const double* h_kp1, const double* h_kp2, int n, const double* h_T21,
-                               const double* h_depth, int H, int W, const dfvo_scale_cfg* cfg, double* scale,
-                               int* h_info) {
+// h_depth: the H x W map, or (per_kp) its value at every keypoint's truncated kp2 pixel; h_rng625 (optional): RandomState to run
+// under, replaced by the advanced state
+static int find_scale_impl(dfvo_tracker* t, const double* h_kp1, const double* h_kp2, int n, const double* h_T21,
+                           const double* h_depth, bool per_kp, int H, int W, const dfvo_scale_cfg* cfg, uint32_t* h_rng625,
+                           double* scale, int* h_info) {
     DFVO_ARG_CHECK(t && h_kp1 && h_kp2 && h_T21 && h_depth && cfg && scale && n >= 0 && H > 0 && W > 0,
                    "dfvo_find_scale_from_depth: bad argument");
     DFVO_ARG_CHECK(cfg->min_samples >= 1 && cfg->min_samples <= 8, "dfvo_find_scale_from_depth: min_samples in [1,8]");
     int rc = stage_kp(t, h_kp1, h_kp2, n);
     if (rc != DFVO_OK) return rc;
-    const size_t px = (size_t)H * W;
+    if (h_rng625)
+        DFVO_HIP_CHECK(hipMemcpyAsync(t->tb.mt_state, h_rng625, 625 * sizeof(uint32_t), hipMemcpyHostToDevice, t->stream));
+    const size_t px = per_kp ? (size_t)(n > 0 ? n : 1) : (size_t)H * W;
     if (px > t->depth_cap) {
         if (t->d_depth) (void)hipFree(t->d_depth);
         t->depth_cap = px;
@@ -463,10 +467,12 @@ int dfvo_find_scale_from_depth(dfvo_tracker* t, const double* h_kp1, const doubl
     DFVO_ARG_CHECK(cfg->method == DFVO_SCALE_DEPTH_RATIO || cfg->method == DFVO_SCALE_ABS_DIFF,
                    "dfvo_find_scale_from_depth: unknown method");
     sc.method = cfg->method;
-    rc = enqueue_find_scale(t->tb, n, t->d_small, t->d_depth, H, W, sc, t->stream);
+    rc = enqueue_find_scale(t->tb, n, t->d_small, t->d_depth, H, W, sc, t->stream, nullptr, false, per_kp);
     if (rc != DFVO_OK) return rc;
     ScaleResult sr;
     DFVO_HIP_CHECK(hipMemcpyAsync(&sr, t->tb.scale_out, sizeof(sr), hipMemcpyDeviceToHost, t->stream));
+    if (h_rng625)
+        DFVO_HIP_CHECK(hipMemcpyAsync(h_rng625, t->tb.mt_state, 625 * sizeof(uint32_t), hipMemcpyDeviceToHost, t->stream));
     DFVO_HIP_CHECK(hipStreamSynchronize(t->stream));
     *scale = sr.scale;
     if (h_info) {
@@ -476,6 +482,18 @@ int dfvo_find_scale_from_depth(dfvo_tracker* t, const double* h_kp1, const doubl
         h_info[3] = sr.status;
     }
     return DFVO_OK;
+}
+
+int dfvo_find_scale_from_depth(dfvo_tracker* t, const double* h_kp1, const double* h_kp2, int n, const double* h_T21,
+                               const double* h_depth, int H, int W, const dfvo_scale_cfg* cfg, double* scale,
+                               int* h_info) {
+    return find_scale_impl(t, h_kp1, h_kp2, n, h_T21, h_depth, false, H, W, cfg, nullptr, scale, h_info);
+}
+
+int dfvo_find_scale_from_depth_at_kp(dfvo_tracker* t, const double* h_kp1, const double* h_kp2, int n, const double* h_T21,
+                                     const double* h_depth_at_kp2, int H, int W, const dfvo_scale_cfg* cfg,
+                                     uint32_t* h_rng625, double* scale, int* h_info) {
+    return find_scale_impl(t, h_kp1, h_kp2, n, h_T21, h_depth_at_kp2, true, H, W, cfg, h_rng625, scale, h_info);
 }
 
 int dfvo_ransac_regressor(dfvo_tracker* t, const double* h_x, const double* h_y, int n, const dfvo_scale_cfg* cfg,

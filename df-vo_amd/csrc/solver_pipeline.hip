@@ -1376,8 +1376,9 @@ __global__ __launch_bounds__(256) void k_scale_ratios(const int* __restrict__ n_
                                                        const int* __restrict__ pix, const int* __restrict__ winner,
                                                        const double* __restrict__ depth, double* __restrict__ ratios,
                                                        int* __restrict__ n_valid, double* __restrict__ tri_list,
-                                                       double* __restrict__ pred_list) {
+                                                       double* __restrict__ pred_list, int depth_per_kp) {
     // single block: n <= a few thousand.  rank = number of valid entries with a smaller pixel index.
+    // depth_per_kp: `depth` holds the depth map's value at keypoint i's pixel, [n], instead of the map (the only pixels read)
     extern __shared__ int s_pix[];
     const int n = *n_ptr;
     const int t = threadIdx.x;
@@ -1387,7 +1388,7 @@ __global__ __launch_bounds__(256) void k_scale_ratios(const int* __restrict__ n_
         if (ok) {
             double tri = z2[i];
             if (tri < 0) tri = 0;  // depth2_tri[depth2_tri < 0] = 0 (NaN stays NaN and fails > 0)
-            ok = (tri > 0) && (depth[p] > 0);
+            ok = (tri > 0) && (depth[depth_per_kp ? i : p] > 0);
         }
         s_pix[i] = ok ? p : -1;
     }
@@ -1398,10 +1399,11 @@ __global__ __launch_bounds__(256) void k_scale_ratios(const int* __restrict__ n_
         if (p < 0) continue;
         int rank = 0;
         for (int j = 0; j < n; j++) rank += (s_pix[j] >= 0 && s_pix[j] < p) ? 1 : 0;
-        ratios[rank] = z2[i] / depth[p];
+        const double dp = depth[depth_per_kp ? i : p];
+        ratios[rank] = z2[i] / dp;
         if (tri_list) {  // ransac.method 'abs_diff': the regression runs on the two depths themselves
             tri_list[rank] = z2[i];
-            pred_list[rank] = depth[p];
+            pred_list[rank] = dp;
         }
         local++;
     }
@@ -1935,7 +1937,7 @@ int enqueue_ransac_regressor(TrackerBuffers& tb, int n, bool y_is_ones, const Sc
 }
 
 int enqueue_find_scale(TrackerBuffers& tb, int n_host, const double* d_T21, const double* d_depth, int H, int W,
-                       const ScaleConfig& cfg, hipStream_t s, const PoseState* d_gate, bool prepared) {
+                       const ScaleConfig& cfg, hipStream_t s, const PoseState* d_gate, bool prepared, bool depth_per_kp) {
     DFVO_ARG_CHECK(n_host >= 0 && n_host <= tb.kp_cap, "find_scale: keypoint capacity");
     if (prepared) {
         DFVO_ARG_CHECK((size_t)H * W <= tb.winner_cap, "find_scale: enqueue_scale_prepare was not called for this size");
@@ -1957,7 +1959,7 @@ int enqueue_find_scale(TrackerBuffers& tb, int n_host, const double* d_T21, cons
                        cfg.cy, cfg.fx, cfg.fy, H, W, tb.z2, tb.pix, tb.winner);
     hipLaunchKernelGGL(k_scale_ratios, dim3(1), dim3(256), sizeof(int) * (size_t)(n_host > 0 ? n_host : 1), s, tb.kp_info,
                        tb.z2, tb.pix, tb.winner, d_depth, tb.ratios, tb.kp_total + 4, abs_diff ? tb.ratios + tb.kp_cap : nullptr,
-                       abs_diff ? tb.ratios + 2 * (size_t)tb.kp_cap : nullptr);
+                       abs_diff ? tb.ratios + 2 * (size_t)tb.kp_cap : nullptr, depth_per_kp ? 1 : 0);
     if (tb.mark(9, s) != DFVO_OK) return DFVO_ERR_HIP;
     hipLaunchKernelGGL(k_scale_ransac, dim3(1), dim3(256), 0, s, tb.mt_state, abs_diff ? tb.ratios + tb.kp_cap : tb.ratios,
                        abs_diff ? tb.ratios + 2 * (size_t)tb.kp_cap : (const double*)nullptr, tb.kp_total + 4, 10,

@@ -200,8 +200,11 @@ int enqueue_compute_pose_3d2d(PnpBuffers& pb, uint32_t* mt_state, const double* 
                               const int* d_n, int n_host, const double* d_depth, int H, int W, const PnpConfig& cfg,
                               hipStream_t s);
 // d_gate (optional): device PoseState whose zero translation suppresses the whole stage (no RandomState draws)
+// depth_per_kp: d_depth holds, per keypoint, the depth map's value at that keypoint's (truncated) kp2 pixel -- [n_host]
+// doubles instead of the H x W map (only those pixels are ever read)
 int enqueue_find_scale(TrackerBuffers& tb, int n_host, const double* d_T21, const double* d_depth, int H, int W,
-                       const ScaleConfig& cfg, hipStream_t s, const PoseState* d_gate = nullptr, bool prepared = false);
+                       const ScaleConfig& cfg, hipStream_t s, const PoseState* d_gate = nullptr, bool prepared = false,
+                       bool depth_per_kp = false);
 int enqueue_scale_prepare(TrackerBuffers& tb, int H, int W);
 int enqueue_ransac_regressor(TrackerBuffers& tb, int n, bool y_is_ones, const ScaleConfig& cfg, hipStream_t s);
 int set_sklearn_compat(const char* version);  // "0.20" (the reference's pin, default) | "0.22" and later

@@ -158,20 +158,27 @@ class EssTracker:
             raise NotImplementedError("scale_recovery.ransac.method '%s'" % rc.method)
         kp1 = np.ascontiguousarray(kp1, dtype=np.float64)
         kp2 = np.ascontiguousarray(kp2, dtype=np.float64)
-        depth2 = np.ascontiguousarray(depth2, dtype=np.float64)
         T_21 = np.ascontiguousarray(T_21, dtype=np.float64)
+        depth2 = np.asarray(depth2)
         h, w = depth2.shape[:2]
+        # depth2 is only read under the sparse triangulated map (E_tracker.py:604-612, ops_3d.py:29-40), i.e. at the truncated
+        # kp2 pixels: those n values travel instead of the H x W float64 map (3.7 MB per pair at KITTI size)
+        tx, ty = np.trunc(kp2[:, 0]), np.trunc(kp2[:, 1])
+        with np.errstate(invalid="ignore"):
+            inside = (tx >= 0) & (tx < w) & (ty >= 0) & (ty < h)  # (NaN / inf coordinates compare False)
+        depth_at_kp2 = np.zeros(kp2.shape[0], np.float64)
+        depth_at_kp2[inside] = depth2.reshape(h, w)[ty[inside].astype(np.int64), tx[inside].astype(np.int64)]
         cam = self.cam_intrinsics
         scfg = capi.ScaleCfg(cx=float(cam.cx), cy=float(cam.cy), fx=float(cam.fx), fy=float(cam.fy),
                              min_samples=int(rc.min_samples), max_trials=int(rc.max_trials),
                              stop_prob=float(rc.stop_prob), thre=float(rc.thre), method=SCALE_METHODS[rc.method])
         scale = C.c_double()
         info = np.zeros(4, np.int32)
-        _ctx.push_numpy_rng()
-        capi.check(capi.lib().dfvo_find_scale_from_depth(_ctx.tracker_exclusive(), capi.as_ptr(kp1), capi.as_ptr(kp2), kp1.shape[0],
-                                                         capi.as_ptr(T_21), capi.as_ptr(depth2), h, w, C.byref(scfg),
-                                                         C.byref(scale), capi.as_ptr(info)))
-        _ctx.pull_numpy_rng()
+        rng = _ctx.numpy_rng_words()  # in: np.random's state; out: the state after sklearn's draws
+        capi.check(capi.lib().dfvo_find_scale_from_depth_at_kp(_ctx.tracker_exclusive(), capi.as_ptr(kp1), capi.as_ptr(kp2),
+                                                               kp1.shape[0], capi.as_ptr(T_21), capi.as_ptr(depth_at_kp2), h, w,
+                                                               C.byref(scfg), capi.as_ptr(rng), C.byref(scale), capi.as_ptr(info)))
+        _ctx.set_numpy_rng(rng)
         feed_timers(self.timers, (6, 7))
         if info[3] < 0:
             raise ValueError("RANSAC could not find a valid consensus set (sklearn RANSACRegressor semantics)")

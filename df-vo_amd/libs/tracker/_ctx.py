@@ -68,9 +68,14 @@ def push_numpy_rng():
     capi.check(capi.lib().dfvo_tracker_set_rng_state(tracker(), capi.as_ptr(s)))
 
 
-def pull_numpy_rng():
-    """hand the advanced stream back to numpy (has_gauss / cached_gaussian are untouched by integer draws)"""
-    s = np.zeros(625, np.uint32)
-    capi.check(capi.lib().dfvo_tracker_get_rng_state(tracker(), capi.as_ptr(s)))
+def set_numpy_rng(s):
+    """hand an advanced stream (625 words) back to numpy (has_gauss / cached_gaussian are untouched by integer draws)"""
     st = np.random.get_state()
     np.random.set_state((st[0], s[:624].copy(), int(s[624]), st[3], st[4]))
+
+
+def pull_numpy_rng():
+    """read the tracker's advanced stream back and hand it to numpy"""
+    s = np.zeros(625, np.uint32)
+    capi.check(capi.lib().dfvo_tracker_get_rng_state(tracker(), capi.as_ptr(s)))
+    set_numpy_rng(s)

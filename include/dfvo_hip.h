@@ -324,6 +324,15 @@ typedef struct dfvo_scale_cfg {
 int dfvo_find_scale_from_depth(dfvo_tracker* trk, const double* h_kp1, const double* h_kp2, int n,
                                const double* h_T21, const double* h_depth, int H, int W, const dfvo_scale_cfg* cfg,
                                double* scale, int* h_info);
+/* The same call without the H x W upload (3.7 MB of float64 at KITTI size, from pageable memory, per pair): the reference reads
+ * depth2 only under the sparse triangulated map, i.e. at the pixels (int(kp2.x), int(kp2.y)) (E_tracker.py:604-612,
+ * ops_3d.py:29-40).  h_depth_at_kp2 [n] = depth2[int(kp2[i].y), int(kp2[i].x)] (truncation toward zero; any value where that
+ * pixel is outside the H x W map or the coordinate is not finite -- such keypoints are dropped before the value is read).
+ * h_rng625 (optional, in / out): numpy RandomState words to run under, replaced by the advanced state -- saves the two
+ * blocking dfvo_tracker_{set,get}_rng_state round trips of the mirror.  Same result as dfvo_find_scale_from_depth, bit for bit. */
+int dfvo_find_scale_from_depth_at_kp(dfvo_tracker* trk, const double* h_kp1, const double* h_kp2, int n, const double* h_T21,
+                                     const double* h_depth_at_kp2, int H, int W, const dfvo_scale_cfg* cfg,
+                                     uint32_t* h_rng625, double* scale, int* h_info);
 /* The regression stage on its own -- sklearn.linear_model.RANSACRegressor(LinearRegression(fit_intercept=False),
  * min_samples, max_trials, stop_probability, residual_threshold).fit(x[:, None], y) as E_tracker.py:618-636 builds it --
  * on raw host arrays: h_x [n], h_y [n] or NULL for y = 1 (the depth-ratio case).  Consumes the tracker's RandomState as

@@ -172,6 +172,51 @@ def test_compute_pose_2d2d_and_scale(gpu, trk, seed, n, of, noise):
     assert np.array_equal(pull_rng(gpu, trk), np_state()), "RandomState diverged after scale recovery"
 
 
+def test_scale_recovery_depth_at_keypoints_entry(gpu, trk):
+    """dfvo_find_scale_from_depth_at_kp (the depth map's values at the truncated kp2 pixels instead of the H x W map, RandomState in
+    and out of the same call -- what the EssTracker mirror uses) returns what dfvo_find_scale_from_depth returns, bit for bit,
+    keypoints outside the map / with non-finite coordinates / sharing a pixel included"""
+    lib = gpu.lib()
+    for seed, n in ((51, 600), (52, 2000), (53, 40)):
+        c = tracker_case(seed, n, 0.1, 0.05)
+        K = c["K"]
+        pose = np.eye(4)
+        pose[:3, :3] = c["R"]
+        pose[:3, 3] = c["t"]
+        T21 = np.ascontiguousarray(pose)
+        kp1, kp2 = c["kp_ref"].copy(), c["kp_cur"].copy()
+        h, w = c["depth_cur"].shape
+        kp2[3] = [-0.5, 10.2]            # truncates to pixel (0, 10): inside
+        kp2[5] = [-1.5, 10.2]            # outside
+        kp2[7] = [w + 0.25, 3.0]         # outside
+        kp2[9] = [np.nan, 5.0]
+        kp2[11] = [12.0, np.inf]
+        kp2[13] = kp2[12] + 0.25         # (most likely) the same pixel as its neighbour: the later one wins
+        depth = np.ascontiguousarray(c["depth_cur"], dtype=np.float64)
+        scfg = gpu.ScaleCfg(cx=K[0, 2], cy=K[1, 2], fx=K[0, 0], fy=K[1, 1], min_samples=3, max_trials=100, stop_prob=0.99, thre=0.1)
+        np.random.seed(seed)
+        push_rng(gpu, trk)
+        s0, i0 = C.c_double(), np.zeros(4, np.int32)
+        gpu.check(lib.dfvo_find_scale_from_depth(trk, gpu.as_ptr(kp1), gpu.as_ptr(kp2), n, gpu.as_ptr(T21), gpu.as_ptr(depth), h, w,
+                                                 C.byref(scfg), C.byref(s0), gpu.as_ptr(i0)))
+        rng0 = pull_rng(gpu, trk)
+        tx, ty = np.trunc(kp2[:, 0]), np.trunc(kp2[:, 1])
+        with np.errstate(invalid="ignore"):
+            inside = (tx >= 0) & (tx < w) & (ty >= 0) & (ty < h)
+        at_kp = np.full(n, -7.0)         # (values at dropped keypoints must not matter)
+        at_kp[inside] = depth[ty[inside].astype(int), tx[inside].astype(int)]
+        np.random.seed(seed)
+        st = np.random.get_state()
+        rng = np.r_[st[1].astype(np.uint32), np.uint32(st[2])]
+        s1, i1 = C.c_double(), np.zeros(4, np.int32)
+        gpu.check(lib.dfvo_find_scale_from_depth_at_kp(trk, gpu.as_ptr(kp1), gpu.as_ptr(kp2), n, gpu.as_ptr(T21), gpu.as_ptr(at_kp), h, w,
+                                                       C.byref(scfg), gpu.as_ptr(rng), C.byref(s1), gpu.as_ptr(i1)))
+        print("n=%d map entry %.15g %s | per-keypoint entry %.15g %s" % (n, s0.value, i0.tolist(), s1.value, i1.tolist()))
+        assert s0.value == s1.value and np.array_equal(i0, i1) and i0[0] > 10
+        assert np.array_equal(rng, rng0), "RandomState returned by the call differs from the tracker's"
+        assert np.array_equal(pull_rng(gpu, trk), rng0)
+
+
 def test_scale_recovery_small_populations(gpu, trk):
     """exercise sklearn's sample_without_replacement branches: permutation (n < 300) / tracking selection"""
     lib = gpu.lib()
