@@ -73,7 +73,9 @@ struct dfvo_session {
 // and the flow net SLOWER side by side than back to back (profiles/r5b_mirrors_first_run.txt: 7.2 vs 6.3 ms).  The session
 // therefore measures a pool of candidates and re-homes every stream it drives: flow net | depth net + the speculative
 // keypoint / homography stage | RandomState-ordered chain + its side streams | frame upload.  Streams the HOST handed to
-// the nets / the tracker (own_stream false) are left alone.
+// the nets / the tracker (own_stream false) are left alone.  Stream PRIORITIES were tried on top of the placement (round 5,
+// profiles/r5n_session_stream_priorities.txt: flow net highest, depth net lowest, both): the time at which both nets are done
+// does not move (4.7 ms either way, only which of the two finishes first), so every stream keeps the default priority.
 static int place_streams(dfvo_session* s) {
     StreamPool pool;
     if (pool.create(12) != DFVO_OK || pool.ngroups < 3) {
