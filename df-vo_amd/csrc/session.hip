@@ -75,7 +75,9 @@ struct dfvo_session {
 // keypoint / homography stage | RandomState-ordered chain + its side streams | frame upload.  Streams the HOST handed to
 // the nets / the tracker (own_stream false) are left alone.  Stream PRIORITIES were tried on top of the placement (round 5,
 // profiles/r5n_session_stream_priorities.txt: flow net highest, depth net lowest, both): the time at which both nets are done
-// does not move (4.7 ms either way, only which of the two finishes first), so every stream keeps the default priority.
+// does not move (4.7 ms either way, only which of the two finishes first), so every stream keeps the default priority; nor does
+// it move when the depth net is held back until the flow net's Features stage is done (r5o_session_depth_after_features.txt): 4.7
+// ms is the two nets' kernel time at one pair in flight (rocprofv3 timeline, r5p_mirrors_timeline.txt).
 static int place_streams(dfvo_session* s) {
     StreamPool pool;
     if (pool.create(12) != DFVO_OK || pool.ngroups < 3) {
