@@ -194,6 +194,7 @@ SIGNATURES = {
     "dfvo_find_scale_from_depth": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, C.POINTER(ScaleCfg), C.POINTER(_d), _vp]),
     "dfvo_find_scale_from_depth_at_kp": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _i, C.POINTER(ScaleCfg), _vp, C.POINTER(_d), _vp]),
     "dfvo_compute_pose_3d2d": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, C.POINTER(Pose3d2dCfg), C.POINTER(Pose3d2dOut), _vp]),
+    "dfvo_compute_pose_3d2d_at_kp": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, C.POINTER(Pose3d2dCfg), _vp, C.POINTER(Pose3d2dOut), _vp]),
     "dfvo_ransac_regressor": (_i, [_vp, _vp, _vp, _i, C.POINTER(ScaleCfg), C.POINTER(_d), _vp]),
 }
 

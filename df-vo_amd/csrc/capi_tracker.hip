@@ -527,14 +527,16 @@ int dfvo_ransac_regressor(dfvo_tracker* t, const double* h_x, const double* h_y,
     return DFVO_OK;
 }
 
-int dfvo_compute_pose_3d2d(dfvo_tracker* t, const double* h_kp1, const double* h_kp2, int n, const double* h_depth,
-                           int H, int W, const dfvo_pose3d2d_cfg* cfg, dfvo_pose3d2d_out* out, uint8_t* h_keep) {
+static int pose_3d2d_impl(dfvo_tracker* t, const double* h_kp1, const double* h_kp2, int n, const double* h_depth, bool per_kp,
+                          int H, int W, const dfvo_pose3d2d_cfg* cfg, uint32_t* h_rng625, dfvo_pose3d2d_out* out, uint8_t* h_keep) {
     DFVO_ARG_CHECK(t && h_kp1 && h_kp2 && h_depth && cfg && out && n >= 0 && H > 0 && W > 0,
                    "dfvo_compute_pose_3d2d: bad argument");
     DFVO_ARG_CHECK(cfg->repeat >= 1 && cfg->repeat <= MAX_REP && cfg->iters >= 1, "dfvo_compute_pose_3d2d: repeat/iters");
     int rc = stage_kp(t, h_kp1, h_kp2, n);  // kp1 -> tb.kp_ref, kp2 -> tb.kp_cur
     if (rc != DFVO_OK) return rc;
-    const size_t px = (size_t)H * W;
+    if (h_rng625)
+        DFVO_HIP_CHECK(hipMemcpyAsync(t->tb.mt_state, h_rng625, 625 * sizeof(uint32_t), hipMemcpyHostToDevice, t->stream));
+    const size_t px = per_kp ? (size_t)(n > 0 ? n : 1) : (size_t)H * W;
     if (px > t->depth_cap) {
         if (t->d_depth) (void)hipFree(t->d_depth);
         t->depth_cap = px;
@@ -553,11 +555,13 @@ int dfvo_compute_pose_3d2d(dfvo_tracker* t, const double* h_kp1, const double* h
     pc.iters = cfg->iters;
     pc.reproj_thre = cfg->reproj_thre;
     rc = enqueue_compute_pose_3d2d(t->pnp, t->tb.mt_state, t->tb.kp_ref, t->tb.kp_cur, nullptr, n, t->d_depth, H, W, pc,
-                                   t->stream);
+                                   t->stream, per_kp);
     if (rc != DFVO_OK) return rc;
     PnpResult res;
     DFVO_HIP_CHECK(hipMemcpyAsync(&res, t->pnp.result, sizeof(res), hipMemcpyDeviceToHost, t->stream));
     if (h_keep && n > 0) DFVO_HIP_CHECK(hipMemcpyAsync(h_keep, t->pnp.keep, (size_t)n, hipMemcpyDeviceToHost, t->stream));
+    if (h_rng625)
+        DFVO_HIP_CHECK(hipMemcpyAsync(h_rng625, t->tb.mt_state, 625 * sizeof(uint32_t), hipMemcpyDeviceToHost, t->stream));
     DFVO_HIP_CHECK(hipStreamSynchronize(t->stream));
     out->found = res.found;
     out->best_inliers = res.best_inliers;
@@ -569,6 +573,17 @@ int dfvo_compute_pose_3d2d(dfvo_tracker* t, const double* h_kp1, const double* h
     }
     for (int i = 0; i < 9; i++) out->R[i] = res.R[i];
     return DFVO_OK;
+}
+
+int dfvo_compute_pose_3d2d(dfvo_tracker* t, const double* h_kp1, const double* h_kp2, int n, const double* h_depth,
+                           int H, int W, const dfvo_pose3d2d_cfg* cfg, dfvo_pose3d2d_out* out, uint8_t* h_keep) {
+    return pose_3d2d_impl(t, h_kp1, h_kp2, n, h_depth, false, H, W, cfg, nullptr, out, h_keep);
+}
+
+int dfvo_compute_pose_3d2d_at_kp(dfvo_tracker* t, const double* h_kp1, const double* h_kp2, int n, const double* h_depth_at_kp1,
+                                 int H, int W, const dfvo_pose3d2d_cfg* cfg, uint32_t* h_rng625, dfvo_pose3d2d_out* out,
+                                 uint8_t* h_keep) {
+    return pose_3d2d_impl(t, h_kp1, h_kp2, n, h_depth_at_kp1, true, H, W, cfg, h_rng625, out, h_keep);
 }
 
 

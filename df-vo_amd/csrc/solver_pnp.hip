@@ -45,7 +45,8 @@ __global__ __launch_bounds__(256) void k_pnp_filter(const double* __restrict__ k
                                                      const double* __restrict__ depth, int H, int W, PnpConfig cfg,
                                                      double* __restrict__ fk1, double* __restrict__ fk2,
                                                      double* __restrict__ xyz, uint8_t* __restrict__ keep,
-                                                     int* __restrict__ info) {
+                                                     int* __restrict__ info, int depth_per_kp) {
+    // depth_per_kp: `depth` holds, per keypoint, the map's value at that keypoint's (truncated, wrapped) kp1 pixel -- [n]
     __shared__ int s_base, s_wave[4];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int n = n_in_ptr ? *n_in_ptr : n_in_host;
@@ -65,9 +66,10 @@ __global__ __launch_bounds__(256) void k_pnp_filter(const double* __restrict__ k
                 int xi = (int)x1, yi = (int)y1;  // astype(int): truncation; python wraps negative indices
                 if (xi < 0) xi += W;
                 if (yi < 0) yi += H;
-                f = xi >= 0 && xi < W && yi >= 0 && yi < H;
+                // (a NaN coordinate has no pixel: numpy's astype(int) makes it INT64_MIN and the reference's indexing raises; dropped)
+                f = xi >= 0 && xi < W && yi >= 0 && yi < H && x1 == x1 && y1 == y1;
                 if (f) {
-                    d = depth[(size_t)yi * W + xi];
+                    d = depth[depth_per_kp ? (size_t)i : (size_t)yi * W + xi];
                     f = (d != 0) && (d < cfg.max_depth) && (d > cfg.min_depth);
                 }
             }
@@ -281,7 +283,13 @@ __device__ __forceinline__ double pr_acc_two(const double* buf, int cnt, int i0,
     return a;
 }
 
-__global__ __launch_bounds__(256) void k_pnp_refine(const PBatch B) {
+// DFVO_PNP_TRACE (diagnostics): wall_clock64 ticks (100 MHz) of repeat 0's workgroup -- [0] start [1] inliers compacted [2] centroid +
+// covariance + 3 x 3 SVD [3] DLT sums (or the planar branch) [4] DLT solved (12 x 12 SVD on one lane) [5] end; sums over the LM loop:
+// [8] passes with Jacobian [9] passes without [10] lane-0 steps (6 x 6 SVD solve); [11] passes with J [12] passes without [13] steps
+// [14] inliers [15] planar
+__device__ long long g_pnp_trace[16];
+
+__global__ __launch_bounds__(256) void k_pnp_refine(const PBatch B, int trace_on) {
     __shared__ double s_buf[PR_CHUNK * PR_ROW];  // per-point rows (DLT: 2 x 12, LM: J 2 x 6 + err 2)
     __shared__ float s_pts[PR_CHUNK * 5];
     __shared__ double s_ws[sm::PNP_DLT_WS];
@@ -291,6 +299,13 @@ __global__ __launch_bounds__(256) void k_pnp_refine(const PBatch B) {
     const PRep& R = B.r[blockIdx.x];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     PnpRepOut* out = R.out;
+    const bool tr = trace_on && blockIdx.x == 0 && t == 0;
+    auto mark = [&](int i) {
+        if (tr) g_pnp_trace[i] = wall_clock64();
+    };
+    if (tr)
+        for (int i = 0; i < 16; i++) g_pnp_trace[i] = 0;
+    mark(0);
     if (t == 0) {
         out->flag = 0;
         out->n_inliers = 0;
@@ -324,6 +339,8 @@ __global__ __launch_bounds__(256) void k_pnp_refine(const PBatch B) {
     }
     const int np = s_base;
     __threadfence_block();
+    mark(1);
+    if (tr) g_pnp_trace[14] = np;
     auto load_chunk = [&](int c0) {  // points [c0, c0 + 256) -> s_pts
         const int cnt = np - c0 < PR_CHUNK ? np - c0 : PR_CHUNK;
         for (int k = t; k < cnt * 5; k += 256) s_pts[k] = R.pts5[(size_t)c0 * 5 + k];
@@ -369,6 +386,8 @@ __global__ __launch_bounds__(256) void k_pnp_refine(const PBatch B) {
     }
     __syncthreads();
     const bool planar = s_flag != 0;
+    mark(2);
+    if (tr) g_pnp_trace[15] = planar;
     if (planar) {
         // Coplanar object points: cvFindExtrinsicCameraParams2's planar initialisation (calibration.cpp; oracle:
         // cv3_find_extrinsic_guess).  The points are rotated into their principal plane (R_transform = V^T of the SVD above,
@@ -481,8 +500,10 @@ __global__ __launch_bounds__(256) void k_pnp_refine(const PBatch B) {
         s_LL[lb * 12 + la] = acc;
     }
     __syncthreads();
+    mark(3);
     if (t == 0 && !planar) sm::pnp_dlt_finish(s_LL, s_param, s_ws);
     __syncthreads();
+    mark(4);
     // ---- CvLevMarq(6 parameters, 2 np residuals, 20 iterations, FLT_EPSILON)
     int ja = 0, jb = 0;  // lane t < 21: JtJ entry (ja, jb)
     if (t < 21) {
@@ -550,11 +571,21 @@ __global__ __launch_bounds__(256) void k_pnp_refine(const PBatch B) {
     int lambdaLg10 = -3, iters = 0;
     bool calc_j = true;
     for (;;) {
+        long long tr0 = tr ? wall_clock64() : 0;
         pass(calc_j);
+        if (tr) {
+            g_pnp_trace[calc_j ? 8 : 9] += wall_clock64() - tr0;
+            g_pnp_trace[calc_j ? 11 : 12] += 1;
+            tr0 = wall_clock64();
+        }
         if (calc_j) {
             if (t == 0) {
                 for (int i = 0; i < 6; i++) s_prev[i] = s_param[i];
                 sm::pnp_lm_step(s_JtJ, s_JtErr, lambdaLg10, s_prev, s_param, s_ws);
+            }
+            if (tr) {
+                g_pnp_trace[10] += wall_clock64() - tr0;
+                g_pnp_trace[13] += 1;
             }
             if (iters == 0) prevErrNorm = sqrt(s_errnorm2);
             calc_j = false;
@@ -565,6 +596,10 @@ __global__ __launch_bounds__(256) void k_pnp_refine(const PBatch B) {
         if (errNorm > prevErrNorm) {
             if (++lambdaLg10 <= 16) {
                 if (t == 0) sm::pnp_lm_step(s_JtJ, s_JtErr, lambdaLg10, s_prev, s_param, s_ws);
+                if (tr) {
+                    g_pnp_trace[10] += wall_clock64() - tr0;
+                    g_pnp_trace[13] += 1;
+                }
                 __syncthreads();
                 continue;
             }
@@ -574,6 +609,7 @@ __global__ __launch_bounds__(256) void k_pnp_refine(const PBatch B) {
         prevErrNorm = errNorm;
         calc_j = true;
     }
+    mark(5);
     if (t == 0) {
         out->flag = 1;
         out->n_inliers = np;
@@ -659,13 +695,13 @@ void PnpBuffers::release() {
 // Results: pb.result (PnpResult), pb.fk1 / pb.fk2 (filtered keypoints, pb.info[0] of them)
 int enqueue_compute_pose_3d2d(PnpBuffers& pb, uint32_t* mt_state, const double* d_kp1, const double* d_kp2,
                               const int* d_n, int n_host, const double* d_depth, int H, int W, const PnpConfig& cfg,
-                              hipStream_t s) {
+                              hipStream_t s, bool depth_per_kp) {
     DFVO_ARG_CHECK(n_host >= 0 && cfg.repeat >= 1 && cfg.repeat <= MAX_REP && cfg.iters >= 1, "compute_pose_3d2d: bad sizes");
     int rc = pb.ensure(n_host > 8 ? n_host : 8, cfg.iters);
     if (rc != DFVO_OK) return rc;
     const int cap = pb.cap;
     hipLaunchKernelGGL(k_pnp_filter, dim3(1), dim3(256), 0, s, d_kp1, d_kp2, d_n, n_host, d_depth, H, W, cfg, pb.fk1,
-                       pb.fk2, pb.xyz, pb.keep, pb.info);
+                       pb.fk2, pb.xyz, pb.keep, pb.info, depth_per_kp ? 1 : 0);
     // the shuffles are drawn for every repeat, whatever the point count (pnp_tracker.py:90-92)
     rc = enqueue_mt_shuffle(mt_state, pb.info, n_host, cfg.repeat, cap + 8, pb.perm, s);
     if (rc != DFVO_OK) return rc;
@@ -708,9 +744,21 @@ int enqueue_compute_pose_3d2d(PnpBuffers& pb, uint32_t* mt_state, const double* 
         hipLaunchKernelGGL(k_pnp_replay, dim3(R), dim3(1), 0, s, B, it0, it1, 0.99);
     }
     hipLaunchKernelGGL(k_pnp_mask, dim3(nb, R), dim3(256), 0, s, B, thr2);
-    hipLaunchKernelGGL(k_pnp_refine, dim3(R), dim3(256), 0, s, B);
+    static const bool trace_on = getenv("DFVO_PNP_TRACE") != nullptr;
+    hipLaunchKernelGGL(k_pnp_refine, dim3(R), dim3(256), 0, s, B, trace_on ? 1 : 0);
     hipLaunchKernelGGL(k_pnp_select, dim3(1), dim3(1), 0, s, B, pb.result);
     DFVO_HIP_CHECK(hipGetLastError());
+    if (trace_on) {
+        long long tr[16];
+        DFVO_HIP_CHECK(hipStreamSynchronize(s));
+        DFVO_HIP_CHECK(hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_pnp_trace), sizeof(tr)));
+        auto us = [&](int a, int b) { return tr[a] && tr[b] ? (tr[b] - tr[a]) * 0.01 : -1.0; };
+        fprintf(stderr,
+                "k_pnp_refine trace (repeat 0): inliers %lld planar %lld | compaction %.1f us | centroid + covariance %.1f | DLT sums %.1f | "
+                "DLT solve %.1f | LM: %lld passes with J %.1f us, %lld passes without %.1f, %lld steps %.1f | total %.1f us\n",
+                tr[14], tr[15], us(0, 1), us(1, 2), us(2, 3), us(3, 4), tr[11], tr[8] * 0.01, tr[12], tr[9] * 0.01, tr[13], tr[10] * 0.01,
+                us(0, 5));
+    }
     return DFVO_OK;
 }
 

@@ -196,9 +196,11 @@ int enqueue_pose_h_part(TrackerBuffers& tb, int n_bound, const PoseConfig& cfg, 
 int enqueue_pose_e_part(TrackerBuffers& tb, int n_host, const PoseConfig& cfg, hipStream_t s, double* d_T21);
 int enqueue_mt_shuffle(uint32_t* mt_state, const int* d_n, int n_host, int repeat, int perm_stride, int* perm,
                        hipStream_t s);
+// depth_per_kp: d_depth holds, per keypoint, the depth map's value at that keypoint's kp1 pixel (truncated, negative indices
+// wrapped as numpy does) -- [n_host] doubles instead of the H x W map
 int enqueue_compute_pose_3d2d(PnpBuffers& pb, uint32_t* mt_state, const double* d_kp1, const double* d_kp2,
                               const int* d_n, int n_host, const double* d_depth, int H, int W, const PnpConfig& cfg,
-                              hipStream_t s);
+                              hipStream_t s, bool depth_per_kp = false);
 // d_gate (optional): device PoseState whose zero translation suppresses the whole stage (no RandomState draws)
 // depth_per_kp: d_depth holds, per keypoint, the depth map's value at that keypoint's (truncated) kp2 pixel -- [n_host]
 // doubles instead of the H x W map (only those pixels are ever read)

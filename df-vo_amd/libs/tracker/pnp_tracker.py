@@ -20,9 +20,17 @@ class PnpTracker:
         lib = capi.lib()
         kp1 = np.ascontiguousarray(kp1, dtype=np.float64)
         kp2 = np.ascontiguousarray(kp2, dtype=np.float64)
-        depth_1 = np.ascontiguousarray(depth_1, dtype=np.float64)
+        depth_1 = np.asarray(depth_1)
         h, w = depth_1.shape
         n = kp1.shape[0]
+        # depth_1 is only read at kp1's pixels (pnp_tracker.py:71-77: astype(int) truncation, negative indices wrap): those n
+        # values travel instead of the H x W float64 map
+        xi, yi = np.trunc(kp1[:, 0]), np.trunc(kp1[:, 1])
+        with np.errstate(invalid="ignore"):
+            xi, yi = np.where(xi < 0, xi + w, xi), np.where(yi < 0, yi + h, yi)
+            inside = (xi >= 0) & (xi < w) & (yi >= 0) & (yi < h)  # (NaN / inf compare False)
+        depth_at_kp1 = np.zeros(n, np.float64)
+        depth_at_kp1[inside] = depth_1[yi[inside].astype(np.int64), xi[inside].astype(np.int64)]
         cam = self.cam_intrinsics
         repeat = int(self.cfg.pnp_tracker.ransac.repeat) if is_iterative else 3
         cfg = capi.Pose3d2dCfg(fx=float(cam.fx), fy=float(cam.fy), cx=float(cam.cx), cy=float(cam.cy),
@@ -34,10 +42,11 @@ class PnpTracker:
             cfg.Kinv[i] = Kinv.flat[i]
         out = capi.Pose3d2dOut()
         keep = np.zeros(max(n, 1), np.uint8)
-        _ctx.push_numpy_rng()
-        capi.check(lib.dfvo_compute_pose_3d2d(_ctx.tracker_exclusive(), capi.as_ptr(kp1), capi.as_ptr(kp2), n,
-                                              capi.as_ptr(depth_1), h, w, C.byref(cfg), C.byref(out), capi.as_ptr(keep)))
-        _ctx.pull_numpy_rng()
+        rng = _ctx.numpy_rng_words()  # in: np.random's state; out: the state after the shuffles
+        capi.check(lib.dfvo_compute_pose_3d2d_at_kp(_ctx.tracker_exclusive(), capi.as_ptr(kp1), capi.as_ptr(kp2), n,
+                                                    capi.as_ptr(depth_at_kp1), h, w, C.byref(cfg), capi.as_ptr(rng), C.byref(out),
+                                                    capi.as_ptr(keep)))
+        _ctx.set_numpy_rng(rng)
         # format pose (pnp_tracker.py:112-118): identity when no repeat produced a model, then inverted
         pose = SE3()
         if out.found:

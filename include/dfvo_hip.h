@@ -363,6 +363,14 @@ typedef struct dfvo_pose3d2d_out {
 } dfvo_pose3d2d_out;
 int dfvo_compute_pose_3d2d(dfvo_tracker* trk, const double* h_kp1, const double* h_kp2, int n, const double* h_depth,
                            int H, int W, const dfvo_pose3d2d_cfg* cfg, dfvo_pose3d2d_out* out, uint8_t* h_keep);
+/* The same call without the H x W upload: the reference reads depth_1 only at kp1's pixels (pnp_tracker.py:71-77:
+ * depth_1[kp1[:, 1].astype(int), kp1[:, 0].astype(int)], truncation toward zero, negative indices wrapping as numpy's do).
+ * h_depth_at_kp1 [n] = that value per keypoint (any value where the wrapped index is still outside the map: the keypoint is
+ * dropped before the value is read).  h_rng625 (optional, in / out) as in dfvo_find_scale_from_depth_at_kp.  Same result as
+ * dfvo_compute_pose_3d2d, bit for bit. */
+int dfvo_compute_pose_3d2d_at_kp(dfvo_tracker* trk, const double* h_kp1, const double* h_kp2, int n, const double* h_depth_at_kp1,
+                                 int H, int W, const dfvo_pose3d2d_cfg* cfg, uint32_t* h_rng625, dfvo_pose3d2d_out* out,
+                                 uint8_t* h_keep);
 
 /* =====================================================================================
  * Fused per-pair pipeline: images in HBM -> relative pose, everything between on the device

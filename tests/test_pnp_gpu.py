@@ -189,6 +189,49 @@ def test_compute_pose_3d2d_coplanar_object_points(gpu, trk, seed):
     assert out.status != -2 and out.n_filtered == len(ref["kp1"]) and np.array_equal(state_after, np_state())
 
 
+def test_compute_pose_3d2d_depth_at_keypoints_entry(gpu, trk):
+    """dfvo_compute_pose_3d2d_at_kp (the depth map's values at kp1's pixels instead of the H x W map, RandomState in and out of the
+    same call -- what the PnpTracker mirror uses) returns what dfvo_compute_pose_3d2d returns, bit for bit; keypoints with
+    negative (wrapping) / out-of-map / non-finite kp1 coordinates and out-of-image kp2 included"""
+    capi = gpu
+    for seed, n in ((31, 1500), (32, 60)):
+        kp1, kp2, depth, _, _ = pnp_case(seed, n=n)
+        kp1, kp2 = kp1.copy(), kp2.copy()
+        h, w = depth.shape
+        kp1[2] = [-3.5, 20.0]            # wraps to column w - 3
+        kp1[4] = [30.0, -2.25]           # wraps to row h - 2
+        kp1[6] = [-(w + 5.0), 8.0]       # still negative after one wrap: dropped
+        kp1[8] = [w + 1.5, 8.0]          # outside: dropped
+        kp1[10] = [np.nan, 8.0]
+        kp2[12] = [-0.5, 10.0]           # kp2 outside the image: dropped before depth is looked at
+        np.random.seed(4869 + seed)
+        o0, keep0, st0 = run_hip(gpu, trk, kp1, kp2, depth)
+        xi, yi = np.trunc(kp1[:, 0]), np.trunc(kp1[:, 1])
+        with np.errstate(invalid="ignore"):
+            xi, yi = np.where(xi < 0, xi + w, xi), np.where(yi < 0, yi + h, yi)
+            inside = (xi >= 0) & (xi < w) & (yi >= 0) & (yi < h)
+        at_kp = np.full(len(kp1), 3.0)   # (a valid-looking depth at dropped keypoints must not matter)
+        at_kp[inside] = depth[yi[inside].astype(int), xi[inside].astype(int)]
+        cfg = capi.Pose3d2dCfg(fx=K[0, 0], fy=K[1, 1], cx=K[0, 2], cy=K[1, 2], min_depth=0.0, max_depth=50.0, repeat=5, iters=100,
+                               reproj_thre=1.0)
+        Kinv = np.linalg.inv(K)
+        for i in range(9):
+            cfg.Kinv[i] = Kinv.flat[i]
+        o1 = capi.Pose3d2dOut()
+        keep1 = np.zeros(len(kp1), np.uint8)
+        np.random.seed(4869 + seed)
+        rng = np_state()
+        capi.check(capi.lib().dfvo_compute_pose_3d2d_at_kp(trk, capi.as_ptr(kp1), capi.as_ptr(kp2), len(kp1), capi.as_ptr(at_kp), h, w,
+                                                           C.byref(cfg), capi.as_ptr(rng), C.byref(o1), capi.as_ptr(keep1)))
+        print("n=%d map entry: found %d inliers %d filtered %d | per-keypoint entry: found %d inliers %d filtered %d" % (
+            n, o0.found, o0.best_inliers, o0.n_filtered, o1.found, o1.best_inliers, o1.n_filtered))
+        assert (o0.found, o0.best_inliers, o0.n_filtered, o0.status) == (o1.found, o1.best_inliers, o1.n_filtered, o1.status)
+        assert o0.n_filtered < len(kp1) and not keep0[[6, 8, 10, 12]].any()
+        assert np.array_equal(keep0, keep1.astype(bool))
+        assert list(o0.rvec) == list(o1.rvec) and list(o0.tvec) == list(o1.tvec) and list(o0.R) == list(o1.R)
+        assert np.array_equal(rng, st0)
+
+
 def test_pnp_tracker_mirror_against_the_reference_class_fixture(gpu):
     """the PnpTracker mirror (libs/tracker/pnp_tracker.py of the package, dfvo_compute_pose_3d2d underneath) on the cases of
     tests/golden/pnp_tracker.npz -- written by the REFERENCE's own PnpTracker.compute_pose_3d2d over the oracle cv2

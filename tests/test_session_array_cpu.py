@@ -53,3 +53,29 @@ def test_arithmetic_on_session_arrays_gives_plain_arrays_with_the_right_values()
     assert float(a.sum()) == float(np.arange(24).sum())
     assert np.array_equal(a.transpose(1, 2, 0), np.asarray(a).transpose(1, 2, 0))
     assert np.array_equal(np.linalg.norm(a, axis=0), np.linalg.norm(np.asarray(a), axis=0))
+
+
+def test_randomstate_words_round_trip_and_detect_any_draw():
+    """what the session's early pose half is validated with (libs/tracker/_ctx.numpy_rng_words / set_numpy_rng): the 625 words
+    are np.random's whole integer stream state -- equal words <=> no draw in between, and handing words back reproduces the
+    stream; a pending Gaussian (has_gauss / cached_gaussian) is left alone"""
+    ctx = importlib.import_module("df-vo_amd.libs.tracker._ctx")
+    np.random.seed(4869)
+    np.random.randn()                       # leaves a cached Gaussian behind
+    w0 = ctx.numpy_rng_words()
+    assert w0.dtype == np.uint32 and w0.shape == (625,) and w0.flags.c_contiguous
+    assert np.array_equal(w0, ctx.numpy_rng_words())           # reading the state draws nothing
+    st0 = np.random.get_state()
+    a = np.random.randint(0, 1 << 30, 5)
+    assert not np.array_equal(w0, ctx.numpy_rng_words())       # any draw shows
+    np.random.permutation(7)
+    ctx.set_numpy_rng(w0)
+    st1 = np.random.get_state()
+    assert np.array_equal(st1[1], st0[1]) and st1[2] == st0[2] and st1[3] == st0[3] and st1[4] == st0[4]
+    assert np.array_equal(np.random.randint(0, 1 << 30, 5), a)
+    # a draw that leaves the position unchanged modulo nothing: even one word consumed moves the position
+    np.random.seed(1)
+    w1 = ctx.numpy_rng_words()
+    np.random.random_sample()
+    w2 = ctx.numpy_rng_words()
+    assert w1[624] != w2[624] or not np.array_equal(w1[:624], w2[:624])
