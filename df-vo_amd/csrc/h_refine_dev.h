@@ -66,9 +66,8 @@ __device__ __forceinline__ double lane_f64(double v, int src_lane) {  // src_lan
 // order as sm::jacobi_eigen_ws -- the pivot search now also has the sequential scan's NaN behaviour (a NaN first candidate
 // sticks, any other NaN is never selected).
 template <int N>
-__device__ int jacobi_eigen_coop(double* A, double* W, double* V, int* ind, int lane) {
+__device__ int jacobi_eigen_coop(double* A, double* W, double* V, int lane) {
     static_assert(2 * N - 2 <= 16, "the pivot candidates must fit one DPP row");
-    (void)ind;
     const double eps = DBL_EPSILON;
     // ---- ownership: lane r < N - 1 owns row r's pivot-table entry, lane N - 2 + c (c = 1 .. N - 1) column c's
     const bool own_row = lane < N - 1, own_col = lane >= N - 1 && lane < 2 * N - 2;
@@ -441,7 +440,7 @@ __device__ __forceinline__ void h_refit_refine_block(HRefineShared& sh, HRefineW
         __syncthreads();
         mark(3);
         if (wave == 0) {
-            const int rot = jacobi_eigen_coop<9>(s_LtL, s_eig, s_eig + 9, reinterpret_cast<int*>(s_eig + 90), lane);
+            const int rot = jacobi_eigen_coop<9>(s_LtL, s_eig, s_eig + 9, lane);
             if (trace && t == 0) trace[13] = rot;
         }
         __syncthreads();
@@ -553,7 +552,7 @@ __device__ __forceinline__ void h_refit_refine_block(HRefineShared& sh, HRefineW
         // solve(Ap, v, d, DECOMP_EIG): eigen decomposition on wave 0 (in place), back-substitution on lane 0
         long long tr0 = trace ? wall_clock64() : 0;
         if (wave == 0) {
-            const int rot = jacobi_eigen_coop<8>(s_Ap, s_eig + 64, s_eig, reinterpret_cast<int*>(s_eig + 72), lane);
+            const int rot = jacobi_eigen_coop<8>(s_Ap, s_eig + 64, s_eig, lane);
             if (trace && t == 0) trace[14] += rot;
         }
         __syncthreads();

@@ -461,7 +461,7 @@ __global__ __launch_bounds__(64) void k_h_solve(const RansacState* st, const int
                                                  const float* __restrict__ src, const float* __restrict__ dst, int it0,
                                                  int it1, double* __restrict__ models, int* __restrict__ nmodels) {
     __shared__ double s_LtL[81], s_W[9], s_V[81], s_norm[8];
-    __shared__ int s_ind[18], s_ok;
+    __shared__ int s_ok;
     const int it = it0 + blockIdx.x, lane = threadIdx.x;
     if (st->done || it >= it1) return;
     if (st->subset_fail_at >= 0 && it >= st->subset_fail_at) {
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(64) void k_h_solve(const RansacState* st, const int
         s_LtL[lk * 9 + lj] = acc;
     }
     __syncthreads();
-    jacobi_eigen_coop<9>(s_LtL, s_W, s_V, s_ind, lane);
+    jacobi_eigen_coop<9>(s_LtL, s_W, s_V, lane);
     __syncthreads();
     if (lane == 0) {
         double model[9];
