@@ -451,3 +451,131 @@ extern "C" int hh_five_point_poly(const double* q1, const double* q2, double* c)
     return sm::five_point_stage1(q1, q2, EE, b, c) ? 1 : 0;
 }
 extern "C" void hh_solve_poly10(const double* c, double* rre, double* rim) { sm::solve_poly10(c, rre, rim); }
+
+// ---- lock-step host emulation of jacobi_eigen_coop (df-vo_amd/csrc/h_refine_dev.h, round-5 form): sixteen candidate lanes with
+// the pivot-table entry and the eigenvalue they own in "registers" (per-lane variables), the pivot maximum as four pairwise
+// exchanges (lane ^ 1, lane ^ 2, mirror inside eight, mirror inside sixteen) in which every lane combines its OLD value with its
+// partner's OLD value, the winner read from lane 0, the rotation one element pair per lane, the rescans by the owner lanes.
+// What it proves on the host: that schedule visits the same pivots and produces the same bits as the sequential
+// sm::jacobi_eigen_ws, ties between equal magnitudes and NaN entries included.
+template <int N>
+static int jacobi_lockstep(double* A, double* W, double* V) {
+    constexpr int L = 16;
+    static_assert(2 * N - 2 <= L, "candidates fit one row");
+    const double eps = DBL_EPSILON;
+    bool own_row[L], own_col[L];
+    int oc[L], myind[L] = {};
+    double myW[L] = {};
+    auto rescan = [&](int lane) {
+        const bool r = own_row[lane];
+        const int base = r ? N * lane + lane + 1 : oc[lane], stride = r ? 1 : N, cnt = r ? N - 1 - lane : oc[lane], m0 = r ? lane + 1 : 0;
+        int m = m0;
+        double mv = fabs(A[base]);
+        for (int j = 1; j < cnt; j++) {
+            const double val = fabs(A[base + j * stride]);
+            if (mv < val) mv = val, m = m0 + j;
+        }
+        return m;
+    };
+    for (int i = 0; i < N * N; i++) V[i] = (i / N == i % N) ? 1. : 0.;
+    for (int lane = 0; lane < L; lane++) {
+        own_row[lane] = lane < N - 1;
+        own_col[lane] = lane >= N - 1 && lane < 2 * N - 2;
+        oc[lane] = lane - (N - 2);
+        if (lane < N) myW[lane] = A[(N + 1) * lane];
+    }
+    for (int lane = 0; lane < L; lane++)
+        if (own_row[lane] || own_col[lane]) myind[lane] = rescan(lane);
+    const int maxIters = N * N * 30;
+    int iters = 0;
+    for (; iters < maxIters; iters++) {
+        double key[L], p[L];
+        int code[L];
+        for (int lane = 0; lane < L; lane++) {
+            key[lane] = -1.;
+            p[lane] = 0.;
+            code[lane] = 0x7fffffff;
+            if (own_row[lane] || own_col[lane]) {
+                const int ck = own_row[lane] ? lane : myind[lane], cl = own_row[lane] ? myind[lane] : oc[lane];
+                p[lane] = A[N * ck + cl];
+                key[lane] = fabs(p[lane]);
+                if (key[lane] != key[lane]) key[lane] = lane == 0 ? INFINITY : -1.;
+                code[lane] = lane << 16 | ck << 8 | cl;
+            }
+        }
+        for (int step = 0; step < 4; step++) {
+            double ok[L], op[L];
+            int ocd[L];
+            for (int lane = 0; lane < L; lane++) {
+                const int q = step == 0 ? lane ^ 1 : step == 1 ? lane ^ 2 : step == 2 ? (lane & 8) | (7 - (lane & 7)) : 15 - lane;
+                ok[lane] = key[q];
+                op[lane] = p[q];
+                ocd[lane] = code[q];
+            }
+            for (int lane = 0; lane < L; lane++)
+                if (ok[lane] > key[lane] || (ok[lane] == key[lane] && ocd[lane] < code[lane])) {
+                    key[lane] = ok[lane];
+                    p[lane] = op[lane];
+                    code[lane] = ocd[lane];
+                }
+        }
+        const int cd = code[0];
+        const double pv = p[0];
+        const int k = (cd >> 8) & 0xff, l = cd & 0xff;
+        if (fabs(pv) <= eps) break;
+        const double y = (myW[l] - myW[k]) * 0.5;
+        double t = fabs(y) + sm::hypot_p(pv, y);
+        double sn = sm::hypot_p(pv, t);
+        const double c = t / sn;
+        sn = pv / sn;
+        t = (pv / t) * pv;
+        if (y < 0) sn = -sn, t = -t;
+        myW[k] -= t;
+        myW[l] += t;
+        A[N * k + l] = 0;
+        for (int i = 0; i < N; i++) {
+            if (i != k && i != l) {
+                const int ak = i < k ? N * i + k : N * k + i, al = i < l ? N * i + l : N * l + i;
+                const double a0 = A[ak], b0 = A[al];
+                A[ak] = a0 * c - b0 * sn;
+                A[al] = a0 * sn + b0 * c;
+            }
+            const double a0 = V[N * k + i], b0 = V[N * l + i];
+            V[N * k + i] = a0 * c - b0 * sn;
+            V[N * l + i] = a0 * sn + b0 * c;
+        }
+        for (int lane = 0; lane < L; lane++)
+            if ((own_row[lane] && (lane == k || lane == l)) || (own_col[lane] && (oc[lane] == k || oc[lane] == l))) myind[lane] = rescan(lane);
+    }
+    for (int i = 0; i < N; i++) W[i] = myW[i];
+    for (int k = 0; k < N - 1; k++) {
+        int m = k;
+        for (int i = k + 1; i < N; i++)
+            if (W[m] < W[i]) m = i;
+        if (k != m) {
+            double t = W[m];
+            W[m] = W[k];
+            W[k] = t;
+            for (int i = 0; i < N; i++) {
+                t = V[N * m + i];
+                V[N * m + i] = V[N * k + i];
+                V[N * k + i] = t;
+            }
+        }
+    }
+    return iters;
+}
+extern "C" int hh_jacobi_eigen_lockstep(int n, const double* A_in, double* A_out, double* W, double* V) {
+    for (int i = 0; i < n * n; i++) A_out[i] = A_in[i];
+    return n == 9 ? jacobi_lockstep<9>(A_out, W, V) : n == 8 ? jacobi_lockstep<8>(A_out, W, V) : -1;
+}
+extern "C" int hh_jacobi_eigen_sequential(int n, const double* A_in, double* A_out, double* W, double* V) {
+    for (int i = 0; i < n * n; i++) A_out[i] = A_in[i];
+    if (n == 9)
+        sm::jacobi_eigen<9>(A_out, W, V);
+    else if (n == 8)
+        sm::jacobi_eigen<8>(A_out, W, V);
+    else
+        return -1;
+    return 0;
+}

@@ -235,3 +235,52 @@ def test_lane_parallel_durand_kerner_schedule_is_bit_exact(hh, cv3):
         for x, y in ((a_re, b_re), (a_im, b_im), (a_re, o_re), (a_im, o_im)):
             assert np.array_equal(x.view(np.uint64), y.view(np.uint64))
     assert n10 > 4000
+
+
+def test_register_resident_jacobi_schedule_is_bit_exact(hh):
+    """df-vo_amd/csrc/h_refine_dev.h jacobi_eigen_coop (round 5: pivot tables and eigenvalues in the owner lanes' registers, the
+    pivot maximum as four pairwise exchanges over sixteen lanes with the lower scan order winning ties, one element pair of the
+    rotation per lane) restated in lock step on the host: same final matrix, eigenvalues and eigenvectors, bit for bit, as the
+    sequential sm::jacobi_eigen_ws (itself pinned to the C oracle by test_eig_solvers_match_oracle) -- on the normal
+    matrices of homography refits, random symmetric matrices over 12 decades, matrices full of TIES (equal magnitudes: the
+    first maximum in scan order must win), diagonal / zero / rank-one matrices and matrices with NaN or inf entries."""
+    rng = np.random.default_rng(17)
+    hh.hh_jacobi_eigen_lockstep.restype = C.c_int
+    mats = []
+    for n in (8, 9):
+        for trial in range(400):      # J^T J / L^T L of point sets
+            m = rng.integers(n, 40)
+            J = rng.normal(0, 1, (m, n)) * 10.0 ** rng.integers(-3, 4, n)
+            mats.append(J.T @ J)
+        for trial in range(300):      # random symmetric, wide range
+            B = rng.normal(0, 1, (n, n)) * 10.0 ** rng.integers(-6, 7)
+            mats.append(B + B.T)
+        for trial in range(200):      # ties everywhere: small integers, +-1 patterns, constant off-diagonals
+            B = rng.integers(-2, 3, (n, n)).astype(np.float64)
+            mats.append(B + B.T)
+        mats.append(np.ones((n, n)))
+        mats.append(np.ones((n, n)) - 2 * np.eye(n))
+        mats.append(np.diag(rng.normal(0, 1, n)))
+        mats.append(np.zeros((n, n)))
+        v = rng.normal(0, 1, n)
+        mats.append(np.outer(v, v))
+        for trial in range(60):       # NaN / inf somewhere (also in the first candidate's position)
+            B = rng.normal(0, 1, (n, n))
+            B = B + B.T
+            i, j = (0, 1) if trial % 3 == 0 else tuple(sorted(rng.choice(n, 2, replace=False)))
+            B[i, j] = B[j, i] = np.nan if trial % 2 == 0 else np.inf
+            mats.append(B)
+    checked = 0
+    for M in mats:
+        n = M.shape[0]
+        A = np.ascontiguousarray(M, np.float64)
+        outs = []
+        for fn in (hh.hh_jacobi_eigen_lockstep, hh.hh_jacobi_eigen_sequential):
+            Ao, W, V = np.zeros((n, n)), np.zeros(n), np.zeros((n, n))
+            with np.errstate(all="ignore"):
+                fn(n, _p(A), _p(Ao), _p(W), _p(V))
+            outs.append((Ao, W, V))
+        for x, y in zip(outs[0], outs[1]):
+            assert np.array_equal(x.view(np.uint64), y.view(np.uint64)), "lock-step schedule differs from the sequential Jacobi"
+        checked += 1
+    assert checked > 1900
