@@ -373,6 +373,32 @@ def test_frame_session_returns_what_the_plain_entry_points_return(gpu, tmp_path,
     assert np.array_equal(got["pose"].R, res["R"]) and np.array_equal(got["pose"].t, res["t"])
 
 
+def test_frame_session_over_a_long_sequence(gpu, tmp_path, monkeypatch):
+    """The same comparison over 48 pairs (the host buffer rings wrap sixteen times; the early pose half and the per-keypoint depth
+    entry of the scale recovery run on every pair -- this world never needs the PnP fallback): poses, tracking modes and the
+    numpy RandomState after the last pair bit-identical with and without the session, every pair through the resident paths."""
+    from synth import coded_tunnel_sequence, crafted_liteflownet_state_dict, crafted_monodepth2_state_dict, write_weight_files
+    h, w, n = 256, 640, 49
+    seq = coded_tunnel_sequence(h, w, n, mode="mux", step=1.0, seed=35)
+    flow_path, depth_dir = write_weight_files(str(tmp_path), crafted_liteflownet_state_dict(h, w, "mux"),
+                                              crafted_monodepth2_state_dict())
+    cfg = full_cfg(h, w, flow_path, depth_dir)
+    runs = {}
+    for sess in ("0", "1"):
+        monkeypatch.setenv("DFVO_SESSION", sess)
+        mirrors = _build_mirrors(cfg, seq["K"])
+        poses, modes = _main_loop(cfg, seq, n, h, w, mirrors)
+        runs[sess] = (poses, modes, np.random.get_state(), mirrors[0].session)
+    (p0, m0, st0, _), (p1, m1, st1, s) = runs["0"], runs["1"]
+    print("   modes E / PnP:", m1.count("Ess. Mat."), m1.count("PnP"), "| session", s.stats, "| final t", p1[-1][:3, 3])
+    assert m0 == m1 and np.array_equal(p0, p1)
+    assert np.array_equal(st0[1], st1[1]) and st0[2] == st1[2]
+    st = s.stats
+    assert st["push"] == n and st["flow_resident"] == st["kp_resident"] == st["pose_resident"] == st["pose_ahead"] == n - 1, st
+    assert st["flow_plain"] == st["kp_plain"] == st["pose_plain"] == 0
+    assert np.linalg.norm(p1[-1][:3, 3]) > 10.0  # the sequence really moved
+
+
 def test_trajectory_composition_on_the_device(gpu):
     """update_global_pose over a gathered sequence in one launch (dfvo_compose_trajectory) against the host
     loop of dist.compose_trajectory -- E / PnP rows, constant-motion rows (status 1: the previous motion is reused, also
