@@ -399,6 +399,32 @@ def test_frame_session_over_a_long_sequence(gpu, tmp_path, monkeypatch):
     assert np.linalg.norm(p1[-1][:3, 3]) > 10.0  # the sequence really moved
 
 
+def test_frame_session_with_pnp_fallbacks(gpu, tmp_path, monkeypatch):
+    """bench.py's class-surface workload (1241 x 376 'pot'-coded frames of a lateral motion, tracked ping-pong A -> B, B -> A: a few
+    pairs in ten reject the E-tracker's pose or its scale and take the PnP fallback, through dfvo_compute_pose_3d2d_at_kp and with
+    the early pose half discarded or consumed before it) -- session on and off: poses, modes and RandomState bit-identical"""
+    from synth import (coded_tunnel_sequence, crafted_liteflownet_state_dict, crafted_monodepth2_state_dict, tunnel_poses_lateral,
+                       write_weight_files)
+    h, w, n = 376, 1241, 31
+    two = coded_tunnel_sequence(h, w, 2, mode="pot", step=1.0, seed=7, poses=tunnel_poses_lateral(2, 0.4))
+    seq = {"frames": [two["frames"][i % 2] for i in range(n)], "K": two["K"]}
+    flow_path, depth_dir = write_weight_files(str(tmp_path), crafted_liteflownet_state_dict(h, w, "pot"),
+                                              crafted_monodepth2_state_dict())
+    cfg = full_cfg(h, w, flow_path, depth_dir)
+    runs = {}
+    for sess in ("0", "1"):
+        monkeypatch.setenv("DFVO_SESSION", sess)
+        mirrors = _build_mirrors(cfg, seq["K"])
+        poses, modes = _main_loop(cfg, seq, n, h, w, mirrors)
+        runs[sess] = (poses, modes, np.random.get_state(), mirrors[0].session)
+    (p0, m0, st0, _), (p1, m1, st1, s) = runs["0"], runs["1"]
+    print("   modes E / PnP:", m1.count("Ess. Mat.") - 1, m1.count("PnP"), "| session", s.stats)
+    assert m0 == m1 and np.array_equal(p0, p1)
+    assert np.array_equal(st0[1], st1[1]) and st0[2] == st1[2]
+    assert s.stats["pose_ahead"] == n - 1 and s.stats["pose_plain"] == 0
+    assert m1.count("PnP") >= 1, "this workload is expected to exercise the PnP fallback"
+
+
 def test_trajectory_composition_on_the_device(gpu):
     """update_global_pose over a gathered sequence in one launch (dfvo_compose_trajectory) against the host
     loop of dist.compose_trajectory -- E / PnP rows, constant-motion rows (status 1: the previous motion is reused, also
