@@ -558,7 +558,7 @@ def main(argv=None):
     if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and not args.no_other_legs and args.surface == "fused" and not args.sequences
             and args.solver_inputs == "nets" and (args.height, args.width) == (376, 1241) and args.kp_bestn == 2000
             and args.e_max_iters == 1000 and args.frames == "device" and gpu_visible()):
-        dropin = other_leg(["--surface", "mirrors", "--steps", "20", "--warmup", "3", "--conv-precision", args.conv_precision])
+        dropin = other_leg(["--surface", "mirrors", "--steps", "30", "--warmup", "5", "--conv-precision", args.conv_precision])
         big = ["--height", "1280", "--width", "1920", "--kp-bestn", "20000", "--e-max-iters", "8192", "--steps", "5", "--warmup", "2"]
         others = {
             "config3_kitti_00_10_job": other_leg(["--sequences", "kitti-lengths", "--scale", "0.005", "--conv-precision", args.conv_precision]),
