@@ -11,6 +11,10 @@ import numpy as np
 from . import LIB_PATH
 
 
+PUSH_NO_FLOW = 1   # dfvo_session_push_frame flags (include/dfvo_hip.h)
+ERR_RANGE = -4     # DFVO_ERR_RANGE: an activation left f16's range under an f16x3 / f16 packing
+
+
 class DfvoError(RuntimeError):
     pass
 
@@ -114,13 +118,17 @@ SIGNATURES = {
     "dfvo_session_reset": (_i, [_vp]),
     "dfvo_session_invalidate_carry": (_i, [_vp]),
     "dfvo_session_quiesce": (_i, [_vp]),
-    "dfvo_session_push_frame": (_i, [_vp, _vp, _vp, _vp, C.POINTER(C.c_longlong)]),
+    "dfvo_session_push_frame": (_i, [_vp, _vp, _vp, _vp, _i, C.POINTER(C.c_longlong)]),
+    "dfvo_session_frame": (_i, [_vp, C.c_longlong, C.POINTER(_vp)]),
+    "dfvo_session_detach_slot": (_i, [_vp, C.c_longlong, C.POINTER(_vp)]),
+    "dfvo_host_free": (_i, [_vp]),
     "dfvo_session_depth": (_i, [_vp, C.c_longlong, C.POINTER(_vp)]),
     "dfvo_session_flow": (_i, [_vp, C.c_longlong, C.POINTER(_vp), C.POINTER(_vp), C.POINTER(_vp)]),
     "dfvo_session_keypoints": (_i, [_vp, C.c_longlong, _vp, C.POINTER(_vp), C.POINTER(_vp), _ip, _ip]),
     "dfvo_session_pose_ahead": (_i, [_vp, C.c_longlong, _vp, _vp, _ip]),
     "dfvo_session_pose_2d2d": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _ip]),
     "dfvo_set_conv_precision": (_i, [C.c_char_p]),
+    "dfvo_get_conv_precision": (C.c_char_p, []),
     "dfvo_set_sklearn_compat": (_i, [C.c_char_p]),
     "dfvo_f16s_overflow_count": (_i, [C.POINTER(C.c_ulonglong), _i]),
     "dfvo_conv_profile_begin": (_i, []),
@@ -233,6 +241,16 @@ def check(rc):
     if rc != 0:
         msg = lib().dfvo_last_error()
         raise DfvoError("libdfvo_hip call failed (%d): %s" % (rc, msg.decode() if msg else "?"))
+
+
+def check_f16_range(seen, what):
+    """plain (non-session) net calls under an f16x3 / f16 packing: raise when the call drove an activation beyond +-65504
+    (its output then holds inf / NaN).  `seen`: the counter before the call; returns the counter now."""
+    now = f16s_overflow_count()
+    if now > seen:
+        raise DfvoError("f16 split out of range: %d activation group(s) beyond +-65504 in %s -- its output holds inf / NaN; pack "
+                        "the nets in exact fp32 (DFVO_CONV_PRECISION=fp32 or dfvo_hip.conv_precision: fp32)" % (now - seen, what))
+    return now
 
 
 def require_gpu():

@@ -151,6 +151,7 @@ int dfvo_conv2d(const dfvo_conv_desc* d, const float* d_src0, const float* d_src
 }
 
 int dfvo_set_conv_precision(const char* name) { return conv_set_precision(name); }
+const char* dfvo_get_conv_precision(void) { return conv_get_precision(); }
 int dfvo_f16s_overflow_count(unsigned long long* h_count, int reset) { return conv_f16s_overflow_count(h_count, reset); }
 
 int dfvo_conv_profile_begin(void) {

@@ -453,7 +453,8 @@ static int find_scale_impl(dfvo_tracker* t, const double* h_kp1, const double* h
         t->depth_cap = px;
         DFVO_HIP_CHECK(hipMalloc((void**)&t->d_depth, sizeof(double) * px));
     }
-    DFVO_HIP_CHECK(hipMemcpyAsync(t->d_depth, h_depth, sizeof(double) * px, hipMemcpyHostToDevice, t->stream));
+    if (!(per_kp && n == 0))  // (a zero-length per-keypoint array has no element to read)
+        DFVO_HIP_CHECK(hipMemcpyAsync(t->d_depth, h_depth, sizeof(double) * px, hipMemcpyHostToDevice, t->stream));
     DFVO_HIP_CHECK(hipMemcpyAsync(t->d_small, h_T21, 16 * sizeof(double), hipMemcpyHostToDevice, t->stream));
     ScaleConfig sc;
     sc.cx = cfg->cx;
@@ -542,7 +543,8 @@ static int pose_3d2d_impl(dfvo_tracker* t, const double* h_kp1, const double* h_
         t->depth_cap = px;
         DFVO_HIP_CHECK(hipMalloc((void**)&t->d_depth, sizeof(double) * px));
     }
-    DFVO_HIP_CHECK(hipMemcpyAsync(t->d_depth, h_depth, sizeof(double) * px, hipMemcpyHostToDevice, t->stream));
+    if (!(per_kp && n == 0))  // (a zero-length per-keypoint array has no element to read)
+        DFVO_HIP_CHECK(hipMemcpyAsync(t->d_depth, h_depth, sizeof(double) * px, hipMemcpyHostToDevice, t->stream));
     PnpConfig pc;
     pc.fx = cfg->fx;
     pc.fy = cfg->fy;

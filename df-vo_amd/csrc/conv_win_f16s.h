@@ -312,6 +312,8 @@ static inline void f16s_split_host(float x, unsigned short* hi, unsigned short* 
     memcpy(lo, &l, 2);
 }
 
+unsigned* conv_f16s_overflow_counter() { return f16s_clamp_counter(); }
+
 // number of threads (activations) + weights (pack time) that hit the +-65504 saturation of the hi plane since the last reset
 int conv_f16s_overflow_count(unsigned long long* n, int reset) {
     unsigned int dev = 0;

@@ -139,6 +139,7 @@ int conv_split_mode();  // 0 exact fp32 (default), 4 = f16x3 (f16 hi/lo planes, 
 // weights of a 3x3 layer as f16 hi / lo planes for conv_win_f16s_kernel; returns the number of halves written
 // (out may be null to query the size): [tap][chunk][cout_pad32][2][16], chunks = ceil(c0/16) + ceil(c1/16)
 size_t conv_pack_weights_f16s(const float* w_oihw, int cout, int c0, int c1, const float* fold_scale, unsigned short* out);
+unsigned* conv_f16s_overflow_counter();  // device address of the counter behind it (session.hip reads it behind each net)
 int conv_f16s_overflow_count(unsigned long long* n, int reset);  // saturation report of the f16x3 split (conv_win_f16s.h)
 void conv_build_f16g_table(int c0, int c1, int kh, int kw, std::vector<uint32_t>* tab);
 size_t conv_pack_weights_f16g(const float* w_oihw, int cout, int c0, int c1, int kh, int kw, const float* fold_scale,

@@ -53,6 +53,7 @@ void free_conv(ConvLayer* l);
 int make_f16s_weights(const float* w_oihw, int cout, int c0, int c1, int kh, int kw, const float* scale, ConvLayer* L);
 int make_f16g_weights(const float* w_oihw, int cout, int c0, int c1, int kh, int kw, const float* scale, ConvLayer* L);
 int conv_set_precision(const char* name);  // fp32 | f16x3 | f16: applies to layers packed afterwards
+const char* conv_get_precision();
 int make_head_weights(const float* w_oihw, int cout, int c0, int c1, int kh, int kw, const float* scale, float** wh);
 
 

@@ -101,6 +101,11 @@ int conv_set_precision(const char* name) {
     return DFVO_OK;
 }
 
+const char* conv_get_precision() {
+    const int m = conv_split_mode();
+    return m == 4 ? "f16x3" : m == 5 ? "f16" : "fp32";
+}
+
 int make_f16s_weights(const float* w_oihw, int cout, int c0, int c1, int kh, int kw, const float* scale, ConvLayer* L) {
     L->f16_terms = conv_split_mode() == 5 ? 1 : 3;
     if (conv_split_mode() < 4 || kh != 3 || kw != 3) return DFVO_OK;

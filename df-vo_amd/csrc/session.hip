@@ -25,7 +25,10 @@
 // reference's frame loop draws nothing in between (dfvo.py:324-333, 147-168) -- and otherwise waits for it, uploads the state
 // it was called under and runs the plain entry point.  The scale recovery stays where the reference has it.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "capi_types.h"
@@ -51,6 +54,10 @@ struct dfvo_session {
     bool have_e = false;         // the RandomState-consuming half of compute_pose_2d2d is enqueued (dfvo_session_pose_ahead)
     uint32_t rng_ahead[625] = {};            // ... under this RandomState
     unsigned char ahead_cfg[sizeof(dfvo_pose2d2d_cfg)] = {};  // ... and this configuration (bytes)
+    uint8_t* h_frame[RING] = {};  // pinned copies of the pushed frames: the upload's source, and what forward_flow's frames are compared with
+    unsigned* h_ovf[RING] = {};   // [0] f16x3 range counter behind the flow net of the generation, [1] behind its depth net
+    unsigned* d_ovf = nullptr;    // the device counter (conv_f16s_overflow_counter)
+    unsigned ovf_seen[2] = {0, 0};  // its value up to which each of the two readers (flow stream, depth stream) has reported
     float* h_depth[RING] = {};
     float *h_fwd[RING] = {}, *h_bwd[RING] = {}, *h_diff[RING] = {};
     double *h_kp_ref[RING] = {}, *h_kp_cur[RING] = {};
@@ -59,6 +66,11 @@ struct dfvo_session {
     hipEvent_t e_img = nullptr, e_depth = nullptr, e_net = nullptr, e_flow = nullptr, e_kp = nullptr, e_pose = nullptr;
     dfvo_session_kp_cfg kp_cfg = {};
     dfvo_pose2d2d_cfg pose_cfg = {};
+    // DFVO_SESSION_TRACE=1 (diagnostics): device times of the two nets of a push relative to the end of the frame upload
+    bool trace = false;
+    hipEvent_t t_img = nullptr, t_flow = nullptr, t_flow_copied = nullptr, t_depth = nullptr, t_kp = nullptr;
+    int order = 0;  // DFVO_SESSION_ORDER (experiments): 0 flow net enqueued first | 1 depth net first | 2 depth net ON the flow
+                    // net's stream, before it | 3 ... behind it
 };
 
 #define S_TRY(expr)                     \
@@ -138,7 +150,18 @@ int dfvo_session_create(dfvo_flownet* f, dfvo_depthnet* d, dfvo_tracker* t, int 
              hipHostMalloc((void**)&s->h_fwd[i], 2 * px * sizeof(float)) == hipSuccess &&
              hipHostMalloc((void**)&s->h_bwd[i], 2 * px * sizeof(float)) == hipSuccess &&
              hipHostMalloc((void**)&s->h_diff[i], px * sizeof(float)) == hipSuccess &&
-             hipHostMalloc((void**)&s->h_info[i], 4 * sizeof(int)) == hipSuccess;
+             hipHostMalloc((void**)&s->h_info[i], 4 * sizeof(int)) == hipSuccess &&
+             hipHostMalloc((void**)&s->h_frame[i], px * 3) == hipSuccess &&
+             hipHostMalloc((void**)&s->h_ovf[i], 2 * sizeof(unsigned)) == hipSuccess;
+        if (ok) s->h_ovf[i][0] = s->h_ovf[i][1] = 0;
+    }
+    if (ok) {
+        unsigned long long seen = 0;
+        s->d_ovf = conv_f16s_overflow_counter();
+        ok = s->d_ovf != nullptr && conv_f16s_overflow_count(&seen, 0) == DFVO_OK;
+        unsigned dev = 0;
+        ok = ok && hipMemcpy(&dev, s->d_ovf, sizeof(dev), hipMemcpyDeviceToHost) == hipSuccess;
+        s->ovf_seen[0] = s->ovf_seen[1] = dev;  // (events before the session -- other nets of the process -- are not this session's)
     }
     hipEvent_t* evs[6] = {&s->e_img, &s->e_depth, &s->e_net, &s->e_flow, &s->e_kp, &s->e_pose};
     for (int i = 0; i < 6 && ok; ++i) ok = hipEventCreateWithFlags(evs[i], hipEventDisableTiming) == hipSuccess;
@@ -146,6 +169,12 @@ int dfvo_session_create(dfvo_flownet* f, dfvo_depthnet* d, dfvo_tracker* t, int 
         dfvo_session_destroy(s);
         dfvo::set_last_error("dfvo_session_create: allocation failed");
         return DFVO_ERR_HIP;
+    }
+    s->trace = getenv("DFVO_SESSION_TRACE") != nullptr;
+    s->order = getenv("DFVO_SESSION_ORDER") ? atoi(getenv("DFVO_SESSION_ORDER")) : 0;
+    if (s->trace) {
+        hipEvent_t* tv[5] = {&s->t_img, &s->t_flow, &s->t_flow_copied, &s->t_depth, &s->t_kp};
+        for (hipEvent_t* e : tv) (void)hipEventCreate(e);
     }
     if (place_streams(s) != DFVO_OK) {
         dfvo_session_destroy(s);
@@ -161,7 +190,8 @@ void dfvo_session_destroy(dfvo_session* s) {
     for (int i = 0; i < 2; ++i)
         if (s->d_img[i]) (void)hipFree(s->d_img[i]);
     for (int i = 0; i < RING; ++i) {
-        void* hp[7] = {s->h_depth[i], s->h_fwd[i], s->h_bwd[i], s->h_diff[i], s->h_kp_ref[i], s->h_kp_cur[i], s->h_info[i]};
+        void* hp[9] = {s->h_depth[i], s->h_fwd[i], s->h_bwd[i], s->h_diff[i], s->h_kp_ref[i], s->h_kp_cur[i], s->h_info[i],
+                       s->h_frame[i], s->h_ovf[i]};
         for (void* q : hp)
             if (q) (void)hipHostFree(q);
     }
@@ -212,8 +242,9 @@ static int ensure_kp_host(dfvo_session* s, int cap) {
 }
 
 int dfvo_session_push_frame(dfvo_session* s, const uint8_t* h_img, const dfvo_session_kp_cfg* kp,
-                            const dfvo_pose2d2d_cfg* pose, long long* generation) {
+                            const dfvo_pose2d2d_cfg* pose, int flags, long long* generation) {
     DFVO_ARG_CHECK(s && h_img, "dfvo_session_push_frame: bad argument");
+    const bool want_flow = !(flags & DFVO_PUSH_NO_FLOW);
     FlowNet& fn = s->f->net;
     DepthNet& dn = s->d->net;
     const size_t px = (size_t)s->H * s->W, dpx = (size_t)dn.H * dn.W;
@@ -224,39 +255,70 @@ int dfvo_session_push_frame(dfvo_session* s, const uint8_t* h_img, const dfvo_se
     // ordered before this copy by the events below)
     DFVO_HIP_CHECK(hipStreamWaitEvent(s->s_copy, s->e_depth, 0));
     DFVO_HIP_CHECK(hipStreamWaitEvent(s->s_copy, s->e_net, 0));
-    DFVO_HIP_CHECK(hipMemcpyAsync(img, h_img, px * 3, hipMemcpyHostToDevice, s->s_copy));
+    // the frame goes through the session's own pinned copy (slot g % RING: the upload that read it last was that of frame
+    // g - RING, waited for long ago): the caller's buffer is its own again when this returns, the copy is asynchronous, and
+    // dfvo_session_frame hands the copy out for the byte-for-byte comparison forward_flow makes (no sampling)
+    memcpy(s->h_frame[slot], h_img, px * 3);
+    DFVO_HIP_CHECK(hipMemcpyAsync(img, s->h_frame[slot], px * 3, hipMemcpyHostToDevice, s->s_copy));
     DFVO_HIP_CHECK(hipEventRecord(s->e_img, s->s_copy));
-    // ---- flow net of (g - 1, g) first: it is the long pole
+    if (s->trace) DFVO_HIP_CHECK(hipEventRecord(s->t_img, s->s_copy));
     s->have_flow = s->have_kp = s->have_h = s->have_e = false;
-    if (g >= 1) {
-        DFVO_HIP_CHECK(hipStreamWaitEvent(fn.stream, s->e_img, 0));
-        if (s->carry_ok)
-            S_TRY(fn.forward(nullptr, img, fn.out_fwd.p, fn.out_bwd.p, fn.out_diff.p, &fn));
-        else
-            S_TRY(fn.forward(s->d_img[(g - 1) & 1], img, fn.out_fwd.p, fn.out_bwd.p, fn.out_diff.p));
-        DFVO_HIP_CHECK(hipEventRecord(s->e_net, fn.stream));
-        DFVO_HIP_CHECK(hipMemcpyAsync(s->h_fwd[slot], fn.out_fwd.p, 2 * px * sizeof(float), hipMemcpyDeviceToHost, fn.stream));
-        DFVO_HIP_CHECK(hipMemcpyAsync(s->h_bwd[slot], fn.out_bwd.p, 2 * px * sizeof(float), hipMemcpyDeviceToHost, fn.stream));
-        DFVO_HIP_CHECK(hipMemcpyAsync(s->h_diff[slot], fn.out_diff.p, px * sizeof(float), hipMemcpyDeviceToHost, fn.stream));
-        DFVO_HIP_CHECK(hipEventRecord(s->e_flow, fn.stream));
-        s->have_flow = true;
-    } else {
-        // first frame: its pyramids come into being with the first pair (both frames through Features)
-        DFVO_HIP_CHECK(hipEventRecord(s->e_net, fn.stream));
-    }
-    s->carry_ok = g >= 1;
+    // ---- flow net of (g - 1, g)
+    auto enqueue_flow = [&]() -> int {
+        if (g >= 1 && want_flow) {
+            DFVO_HIP_CHECK(hipStreamWaitEvent(fn.stream, s->e_img, 0));
+            if (s->carry_ok)
+                S_TRY(fn.forward(nullptr, img, fn.out_fwd.p, fn.out_bwd.p, fn.out_diff.p, &fn));
+            else
+                S_TRY(fn.forward(s->d_img[(g - 1) & 1], img, fn.out_fwd.p, fn.out_bwd.p, fn.out_diff.p));
+            DFVO_HIP_CHECK(hipEventRecord(s->e_net, fn.stream));
+            if (s->trace) DFVO_HIP_CHECK(hipEventRecord(s->t_flow, fn.stream));
+            DFVO_HIP_CHECK(hipMemcpyAsync(&s->h_ovf[slot][0], s->d_ovf, sizeof(unsigned), hipMemcpyDeviceToHost, fn.stream));
+            DFVO_HIP_CHECK(hipMemcpyAsync(s->h_fwd[slot], fn.out_fwd.p, 2 * px * sizeof(float), hipMemcpyDeviceToHost, fn.stream));
+            DFVO_HIP_CHECK(hipMemcpyAsync(s->h_bwd[slot], fn.out_bwd.p, 2 * px * sizeof(float), hipMemcpyDeviceToHost, fn.stream));
+            DFVO_HIP_CHECK(hipMemcpyAsync(s->h_diff[slot], fn.out_diff.p, px * sizeof(float), hipMemcpyDeviceToHost, fn.stream));
+            DFVO_HIP_CHECK(hipEventRecord(s->e_flow, fn.stream));
+            if (s->trace) DFVO_HIP_CHECK(hipEventRecord(s->t_flow_copied, fn.stream));
+            s->have_flow = true;
+        } else {
+            // first frame (or a push without the flow pass): its pyramids come into being with the next pair (both frames
+            // through Features)
+            DFVO_HIP_CHECK(hipEventRecord(s->e_net, fn.stream));
+        }
+        s->carry_ok = g >= 1 && want_flow;
+        return DFVO_OK;
+    };
     // ---- depth net of frame g (Pillow-exact LANCZOS resize of the full frame on the device, then the net)
-    {
+    auto enqueue_depth = [&]() -> int {
         if (s->d->resize.H != s->H || s->d->resize.W != s->W || s->d->resize.oh != dn.H || s->d->resize.ow != dn.W)
             S_TRY(s->d->resize.init(s->H, s->W, dn.H, dn.W));
         DFVO_HIP_CHECK(hipStreamWaitEvent(dn.stream, s->e_img, 0));
         S_TRY(s->d->resize.enqueue(img, (uint8_t*)dn.u8_in.p, dn.stream));
         S_TRY(dn.forward((const uint8_t*)dn.u8_in.p, dn.depth.p));
         DFVO_HIP_CHECK(hipMemcpyAsync(s->h_depth[slot], dn.depth.p, dpx * sizeof(float), hipMemcpyDeviceToHost, dn.stream));
+        DFVO_HIP_CHECK(hipMemcpyAsync(&s->h_ovf[slot][1], s->d_ovf, sizeof(unsigned), hipMemcpyDeviceToHost, dn.stream));
         DFVO_HIP_CHECK(hipEventRecord(s->e_depth, dn.stream));
+        if (s->trace) DFVO_HIP_CHECK(hipEventRecord(s->t_depth, dn.stream));
+        return DFVO_OK;
+    };
+    if (s->order == 1) {
+        S_TRY(enqueue_depth());
+        S_TRY(enqueue_flow());
+    } else if (s->order == 2 || s->order == 3) {
+        hipStream_t keep = dn.stream;
+        dn.stream = fn.stream;  // (a captured graph may be launched into any stream)
+        int rc = DFVO_OK;
+        if (s->order == 2) rc = enqueue_depth();
+        if (rc == DFVO_OK) rc = enqueue_flow();
+        if (rc == DFVO_OK && s->order == 3) rc = enqueue_depth();
+        dn.stream = keep;
+        S_TRY(rc);
+    } else {
+        S_TRY(enqueue_flow());
+        S_TRY(enqueue_depth());
     }
     // ---- speculative keypoint selection + RandomState-independent half of compute_pose_2d2d, behind the flow net
-    if (g >= 1 && kp && s->t) {
+    if (g >= 1 && want_flow && kp && s->t) {
         TrackerBuffers& tb = s->t->tb;
         DFVO_HIP_CHECK(hipStreamWaitEvent(s->s_pre, s->e_net, 0));
         DFVO_HIP_CHECK(hipStreamWaitEvent(s->s_pre, s->e_pose, 0));  // (an early pose half nobody consumed may still be running)
@@ -267,6 +329,7 @@ int dfvo_session_push_frame(dfvo_session* s, const uint8_t* h_img, const dfvo_se
         DFVO_HIP_CHECK(hipMemcpyAsync(s->h_kp_ref[slot], tb.kp_ref, sizeof(double) * 2 * tb.kp_cap, hipMemcpyDeviceToHost, s->s_pre));
         DFVO_HIP_CHECK(hipMemcpyAsync(s->h_kp_cur[slot], tb.kp_cur, sizeof(double) * 2 * tb.kp_cap, hipMemcpyDeviceToHost, s->s_pre));
         DFVO_HIP_CHECK(hipEventRecord(s->e_kp, s->s_pre));
+        if (s->trace) DFVO_HIP_CHECK(hipEventRecord(s->t_kp, s->s_pre));
         s->kp_cfg = *kp;
         s->have_kp = true;
         if (pose) {
@@ -277,12 +340,26 @@ int dfvo_session_push_frame(dfvo_session* s, const uint8_t* h_img, const dfvo_se
             s->have_h = true;
         }
     }
-    // the caller's (pageable) frame buffer is its own again when this returns: by now the copy has long been staged, the wait
-    // costs nothing and nothing above waited for it on the host
-    DFVO_HIP_CHECK(hipEventSynchronize(s->e_img));
     s->gen = g;
     if (generation) *generation = g;
     return DFVO_OK;
+}
+
+// The f16x3 / f16 split has f16's range: an activation beyond +-65504 becomes inf in the layer that splits it (conv_win_f16s.h).
+// The device counter of such events rides behind each net's output copy; a net that raised it fails its call here instead of
+// handing out inf / NaN silently (the exact-fp32 packing never counts).  The counter is process-wide: the two nets of a push run
+// side by side, so an event in either fails whichever of forward_depth / forward_flow reads the counter after it -- possibly
+// both; each reader keeps its own high-water mark (its reads are ordered on its stream).
+static int range_check(dfvo_session* s, int reader, unsigned now, const char* which) {
+    unsigned& seen = s->ovf_seen[reader];
+    if (now < seen) seen = 0;  // (someone reset the counter: dfvo_f16s_overflow_count(.., 1))
+    if (now == seen) return DFVO_OK;
+    const unsigned n = now - seen;
+    seen = now;
+    dfvo::set_last_error(std::string("f16 split out of range: ") + std::to_string(n) + " activation group(s) beyond +-65504 up to the " +
+                         which + " net of this frame -- its output holds inf / NaN; pack the nets in exact fp32 "
+                         "(DFVO_CONV_PRECISION=fp32 or dfvo_hip.conv_precision: fp32)");
+    return DFVO_ERR_RANGE;
 }
 
 int dfvo_session_depth(dfvo_session* s, long long generation, const float** h_depth) {
@@ -290,6 +367,48 @@ int dfvo_session_depth(dfvo_session* s, long long generation, const float** h_de
     DFVO_ARG_CHECK(generation == s->gen && s->gen >= 0, "dfvo_session_depth: not the newest pushed frame");
     DFVO_HIP_CHECK(hipEventSynchronize(s->e_depth));
     *h_depth = s->h_depth[s->gen % RING];
+    return range_check(s, 1, s->h_ovf[s->gen % RING][1], "depth");
+}
+
+// the session's pinned copy of frame `generation` (the newest or the one before): uint8 [img_h, img_w, 3]
+int dfvo_session_frame(dfvo_session* s, long long generation, const uint8_t** h_frame) {
+    DFVO_ARG_CHECK(s && h_frame, "dfvo_session_frame: bad argument");
+    DFVO_ARG_CHECK(generation >= 0 && generation <= s->gen && generation >= s->gen - 1, "dfvo_session_frame: frame no longer held");
+    *h_frame = s->h_frame[generation % RING];
+    return DFVO_OK;
+}
+
+// The host buffers of `generation`'s ring slot (depth, fwd, bwd, diff) are still referenced by the caller while the slot is
+// about to be reused (or the session destroyed): the session allocates itself fresh ones and hands the old ones over --
+// h_old4 = {depth, fwd, bwd, diff}, to be released with dfvo_host_free when the last reference is gone.
+int dfvo_session_detach_slot(dfvo_session* s, long long generation, void** h_old4) {
+    DFVO_ARG_CHECK(s && h_old4 && generation >= 0, "dfvo_session_detach_slot: bad argument");
+    const int i = (int)(generation % RING);
+    const size_t px = (size_t)s->H * s->W, dpx = (size_t)s->d->net.H * s->d->net.W;
+    DFVO_HIP_CHECK(hipDeviceSynchronize());  // (no copy into the old buffers is in flight any more)
+    float *nd = nullptr, *nf = nullptr, *nb = nullptr, *nx = nullptr;
+    const bool ok = hipHostMalloc((void**)&nd, dpx * sizeof(float)) == hipSuccess && hipHostMalloc((void**)&nf, 2 * px * sizeof(float)) == hipSuccess &&
+                    hipHostMalloc((void**)&nb, 2 * px * sizeof(float)) == hipSuccess && hipHostMalloc((void**)&nx, px * sizeof(float)) == hipSuccess;
+    if (!ok) {
+        void* fresh[4] = {nd, nf, nb, nx};
+        for (void* q : fresh)
+            if (q) (void)hipHostFree(q);
+        dfvo::set_last_error("dfvo_session_detach_slot: pinned allocation failed");
+        return DFVO_ERR_HIP;
+    }
+    h_old4[0] = s->h_depth[i];
+    h_old4[1] = s->h_fwd[i];
+    h_old4[2] = s->h_bwd[i];
+    h_old4[3] = s->h_diff[i];
+    s->h_depth[i] = nd;
+    s->h_fwd[i] = nf;
+    s->h_bwd[i] = nb;
+    s->h_diff[i] = nx;
+    return DFVO_OK;
+}
+
+int dfvo_host_free(void* h_pinned) {
+    if (h_pinned) DFVO_HIP_CHECK(hipHostFree(h_pinned));
     return DFVO_OK;
 }
 
@@ -297,11 +416,21 @@ int dfvo_session_flow(dfvo_session* s, long long generation, const float** h_fwd
     DFVO_ARG_CHECK(s && h_fwd && h_bwd && h_diff, "dfvo_session_flow: bad argument");
     DFVO_ARG_CHECK(generation == s->gen && s->have_flow, "dfvo_session_flow: no flow pass of that generation is held");
     DFVO_HIP_CHECK(hipEventSynchronize(s->e_flow));
+    if (s->trace) {
+        float a = 0, b = 0, c = 0, d = 0;
+        (void)hipEventSynchronize(s->t_depth);
+        (void)hipEventElapsedTime(&a, s->t_img, s->t_flow);
+        (void)hipEventElapsedTime(&b, s->t_img, s->t_flow_copied);
+        (void)hipEventElapsedTime(&c, s->t_img, s->t_depth);
+        if (s->have_kp && hipEventSynchronize(s->t_kp) == hipSuccess) (void)hipEventElapsedTime(&d, s->t_img, s->t_kp);
+        fprintf(stderr, "dfvo session trace gen %lld: after the upload (ms): flow net %.3f  + copies %.3f | depth net + copy %.3f | keypoints on the host %.3f\n",
+                s->gen, a, b, c, d);
+    }
     const int slot = (int)(s->gen % RING);
     *h_fwd = s->h_fwd[slot];
     *h_bwd = s->h_bwd[slot];
     *h_diff = s->h_diff[slot];
-    return DFVO_OK;
+    return range_check(s, 0, s->h_ovf[slot][0], "flow");
 }
 
 int dfvo_session_keypoints(dfvo_session* s, long long generation, const dfvo_session_kp_cfg* kp, const double** h_kp_ref,

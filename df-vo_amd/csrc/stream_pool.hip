@@ -11,10 +11,24 @@
 // its candidates, MEASURES which of them share a pipe (the same probe as the microbenchmark, ~10 ms once per pipeline),
 // and hands the roles out by pipe: the two flow-net instances a pipe each, the depth net and the run-ahead homography
 // chains a third, the RandomState-ordered chain and its side streams the fourth, alone.
+//
+// Robustness (round 6).  The probe is a wall-clock measurement, so it is (a) overridable, (b) accepted only when it repeats,
+// (c) never silently wrong:
+//   DFVO_STREAM_POOL=creation   no probe: every role gets a freshly created stream (the runtime's creation order decides)
+//   DFVO_STREAM_POOL=probe      (default) measure; a classification is ACCEPTED when it has the shape the hardware gives a
+//                               process whose queues are all its own (n = 4 m streams -> four groups of m), or when two
+//                               passes agree stream for stream (a process that already owns more streams than
+//                               GPU_MAX_HW_QUEUES -- torch, the nets' own -- shares hardware queues and legitimately shows
+//                               other shapes: bench.py --surface mirrors sees six groups, identically, on every pass)
+//   DFVO_STREAM_POOL_FORCE_FAIL=1   (test hook) every measurement reports failure
+// When no pass is accepted (or a measurement fails) the pool reports zero groups, its users fall back to creation-order
+// streams and a line on stderr says so (once per pool, i.e. per session / pipeline object).  DFVO_STREAM_PROBE_VERBOSE=1 prints every pass.
 #include "dfvo_common.h"
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
 #include <vector>
 
 namespace dfvo {
@@ -37,6 +51,7 @@ static float chain_us(hipStream_t s, hipEvent_t e0, hipEvent_t e1, int n) {
 // one classification pass over the already created streams; returns false when a measurement failed
 static bool classify(const std::vector<hipStream_t>& s, hipEvent_t e0, hipEvent_t e1, std::vector<int>* group, int* ngroups) {
     const int n = (int)s.size(), CH = 40;
+    if (getenv("DFVO_STREAM_POOL_FORCE_FAIL")) return false;
     group->assign(n, -1);
     std::vector<float> base(n);
     for (int i = 0; i < n; ++i) base[i] = chain_us(s[i], e0, e1, CH);
@@ -46,8 +61,9 @@ static bool classify(const std::vector<hipStream_t>& s, hipEvent_t e0, hipEvent_
         (*group)[a] = *ngroups;
         for (int b = a + 1; b < n; ++b) {
             if ((*group)[b] >= 0) continue;
-            // stream a busy for ~0.6 ms (30 x 20 us, wall_clock64 ticks at 100 MHz), the chain on b inside that window
-            for (int k = 0; k < 30; ++k) hipLaunchKernelGGL(k_pool_spin, dim3(1), dim3(64), 0, s[a], 2000LL);
+            // stream a busy for ~0.4 ms (20 x 20 us, wall_clock64 ticks at 100 MHz), the chain on b (0.07 ms alone, 0.17-0.19
+            // next to a busy stream on its pipe) inside that window
+            for (int k = 0; k < 20; ++k) hipLaunchKernelGGL(k_pool_spin, dim3(1), dim3(64), 0, s[a], 2000LL);
             const float t = chain_us(s[b], e0, e1, CH);
             if (hipStreamSynchronize(s[a]) != hipSuccess || t < 0.f || base[b] <= 0.f) return false;
             if (t > 1.6f * base[b]) (*group)[b] = *ngroups;
@@ -72,32 +88,52 @@ int StreamPool::create(int n) {
     // first process of a fresh box) it misclassifies -- round 5 saw the frame session fall back to creation-order streams
     // exactly when it ran as the first GPU work of the driver's command, 99 instead of 135 frames/s.  So: warm the device
     // up, classify, and re-measure (longer warm-up each time) until the result has the shape the hardware guarantees.
-    bool ok = false, measured = false;  // ok: the expected shape; measured: at least one complete classification (kept as is
-                                        // when no attempt has the expected shape: never worse than the single pass of round 3)
-    for (int attempt = 0; attempt < 4 && !ok; ++attempt) {
+    const char* mode = getenv("DFVO_STREAM_POOL");
+    bool ok = false;
+    if (mode && !strcmp(mode, "creation")) {
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        ngroups = 0;  // (the users' "no measurement" branch: creation-order streams)
+        return DFVO_OK;
+    }
+    std::vector<std::vector<int>> seen;
+    int attempts = 0;
+    for (int attempt = 0; attempt < 5 && !ok; ++attempt) {
         for (int k = 0; k < 50 * (attempt + 1); ++k)  // 1, 2, 3, 4 ms of spinning on one stream
             hipLaunchKernelGGL(k_pool_spin, dim3(1), dim3(64), 0, s[0], 2000LL);
         DFVO_HIP_CHECK(hipDeviceSynchronize());
         std::vector<int> g2;
         int ng2 = 0;
-        if (!classify(s, e0, e1, &g2, &ng2)) break;  // a failed measurement: keep what an earlier attempt found, if any
-        group = g2;
-        ngroups = ng2;
-        measured = ok = true;
-        if (n % 4 == 0) {
-            ok = ngroups == 4;
-            for (int g = 0; g < ngroups && ok; ++g) ok = count(g) == n / 4;
+        ++attempts;
+        if (!classify(s, e0, e1, &g2, &ng2)) break;  // a failed measurement: nothing is trusted
+        bool shape = n % 4 == 0 && ng2 == 4;
+        for (int g = 0; g < ng2 && shape; ++g) {
+            int c = 0;
+            for (int i = 0; i < n; ++i) c += g2[i] == g ? 1 : 0;
+            shape = c == n / 4;
         }
+        ok = shape || std::find(seen.begin(), seen.end(), g2) != seen.end();  // (group ids are canonical: first-seen order)
         if (getenv("DFVO_STREAM_PROBE_VERBOSE")) {
-            fprintf(stderr, "dfvo stream pool: attempt %d, %d streams, %d pipe groups (%s):", attempt, n, ngroups, ok ? "accepted" : "rejected");
-            for (int i = 0; i < n; ++i) fprintf(stderr, " %d", group[i]);
+            fprintf(stderr, "dfvo stream pool: attempt %d, %d streams, %d pipe groups (%s):", attempt, n, ng2,
+                    ok ? (shape ? "accepted: expected shape" : "accepted: repeated") : "not yet accepted");
+            for (int i = 0; i < n; ++i) fprintf(stderr, " %d", g2[i]);
             fprintf(stderr, "\n");
         }
+        seen.push_back(g2);
+        if (ok) {
+            group = g2;
+            ngroups = ng2;
+        }
+    }
+    if (!ok) {
+        fprintf(stderr, "dfvo stream pool: the pipe probe did not settle in %d pass(es); streams keep the runtime's creation order "
+                        "(set DFVO_STREAM_POOL=creation to skip the probe, DFVO_STREAM_PROBE_VERBOSE=1 to see its passes)\n", attempts);
+        group.assign(n, -1);
+        ngroups = 0;
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     DFVO_HIP_CHECK(hipGetLastError());
-    if (!ok && !measured) ngroups = 0;
     return DFVO_OK;
 }
 

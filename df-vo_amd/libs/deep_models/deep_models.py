@@ -46,14 +46,23 @@ class DeepModel:
         C library's exact-fp32 default -- and, when both nets exist, the frame session is created over them."""
         opts = hip_options(self.cfg)
         self.conv_precision = opts["conv_precision"]
-        capi.check(capi.lib().dfvo_set_conv_precision(self.conv_precision.encode()))
+        lib = capi.lib()
+        before = lib.dfvo_get_conv_precision()  # the process-wide setting is restored once these nets are packed
+        capi.check(lib.dfvo_set_conv_precision(self.conv_precision.encode()))
         self.session = None
-        self.flow = self.initialize_deep_flow_model()
-        if self.cfg.depth.depth_src is None:
-            if self.cfg.depth.deep_depth.pretrained_model is not None:
-                self.depth = self.initialize_deep_depth_model()
-            else:
-                assert False, "No precomputed depths nor pretrained depth model"
+        seen = capi.f16s_overflow_count() if self.conv_precision != "fp32" else 0
+        try:
+            self.flow = self.initialize_deep_flow_model()
+            if self.cfg.depth.depth_src is None:
+                if self.cfg.depth.deep_depth.pretrained_model is not None:
+                    self.depth = self.initialize_deep_depth_model()
+                else:
+                    assert False, "No precomputed depths nor pretrained depth model"
+        finally:
+            capi.check(lib.dfvo_set_conv_precision(before))
+        if self.conv_precision != "fp32":
+            # weights beyond f16's range are clamped (and counted) by the packer: refuse them here, loudly
+            self._f16_seen = capi.check_f16_range(seen, "the packed weights")
         if self.cfg.deep_pose.enable:
             raise NotImplementedError("deep_pose is 'Experiment Ver. only' in the reference; out of scope")
         if opts["session"] and getattr(self, "depth", None) is not None and isinstance(self.flow, LiteFlow):
@@ -97,6 +106,7 @@ class DeepModel:
                 s.stats["flow_plain"] += 1
             fwd, bwd, diff = self.flow.inference_flow_u8(np.ascontiguousarray(in_ref_data['img']),
                                                          np.ascontiguousarray(in_cur_data['img']))
+            self._check_range("the flow net")
         src_id, tgt_id = in_ref_data['id'], in_cur_data['id']
         flows = {(src_id, tgt_id): fwd}
         if forward_backward:
@@ -110,7 +120,15 @@ class DeepModel:
         flow net of (previous frame, this frame) and the keypoint / homography stage behind it are enqueued here as well."""
         if self.session is not None and self.session.accepts(imgs[0]):
             return self.session.push(imgs[0])
-        return self.depth.inference_depth_image_u8(np.ascontiguousarray(imgs[0]))
+        depth = self.depth.inference_depth_image_u8(np.ascontiguousarray(imgs[0]))
+        self._check_range("the depth net")
+        return depth
+
+    def _check_range(self, what):
+        """plain entry points under an f16x3 / f16 packing: fail instead of handing out inf / NaN (the session does the same
+        from the counter it reads behind each net, libs/deep_models/session.py)"""
+        if self.conv_precision != "fp32":
+            self._f16_seen = capi.check_f16_range(getattr(self, "_f16_seen", 0), what)
 
     def initialize_deep_pose_model(self):
         raise NotImplementedError("deep_pose is 'Experiment Ver. only' in the reference; out of scope")

@@ -14,6 +14,8 @@ _pose_cfg_fn = None  # () -> capi.Pose2d2dCfg of the EssTracker
 def register_session(s):
     """DeepModel.initialize_models: the session picks up whatever the sampler / tracker registered before or after it"""
     global session
+    if session is not None and session is not s:
+        session.retire()  # one speculating session per tracker: the older one's DeepModel continues on the plain entry points
     session = s
     if s is not None:
         s.kp_cfg = _kp_cfg

@@ -28,6 +28,7 @@ extern "C" {
 #define DFVO_ERR_HIP (-1)
 #define DFVO_ERR_ARG (-2)
 #define DFVO_ERR_STATE (-3)
+#define DFVO_ERR_RANGE (-4) /* f16x3 / f16 packing: an activation left f16's range in this call (see dfvo_f16s_overflow_count) */
 
 const char* dfvo_last_error(void);
 /* number of visible HIP devices (0 when there is none); never fails */
@@ -82,6 +83,8 @@ int dfvo_conv2d(const dfvo_conv_desc* desc, const float* d_src0, const float* d_
  *            separately, with its flow / keypoint / pose deltas); the one- and two-channel heads stay exact fp32
  * Also read once from the environment variable DFVO_CONV_PRECISION. */
 int dfvo_set_conv_precision(const char* name);
+/* the current setting ("fp32" | "f16x3" | "f16"): a caller that sets it for its own nets restores it afterwards */
+const char* dfvo_get_conv_precision(void);
 /* Which scikit-learn the scale-recovery RANSAC (sklearn.linear_model.RANSACRegressor, E_tracker.py:618-636) reproduces
  * where the versions differ: r2_score of a one-sample consensus set is nan from 0.22 on (every later trial with the same
  * inlier count then wins), 1.0 / 0.0 in 0.20.3 -- the version the reference pins (envs/requirement.yml:233) and the
@@ -499,12 +502,26 @@ void dfvo_session_destroy(dfvo_session* s);
 int dfvo_session_reset(dfvo_session* s);             /* forget the held frame (a new sequence) */
 int dfvo_session_invalidate_carry(dfvo_session* s);  /* someone else ran the flow net: recompute both pyramids next time */
 int dfvo_session_quiesce(dfvo_session* s);           /* a plain solver call is about to use the tracker: wait for the speculative stage */
-/* h_img uint8 [img_h, img_w, 3]; *generation = index of this frame since create / reset */
+/* h_img uint8 [img_h, img_w, 3] (copied into the session's pinned ring before the call returns); *generation = index of this
+ * frame since create / reset.  flags: DFVO_PUSH_NO_FLOW = depth net only -- no flow pass of (generation - 1, generation), no
+ * speculative stage (a caller that never asked for the flow of the last pushes; the next pair runs both frames through
+ * Features). */
+#define DFVO_PUSH_NO_FLOW 1
 int dfvo_session_push_frame(dfvo_session* s, const uint8_t* h_img, const dfvo_session_kp_cfg* kp, const dfvo_pose2d2d_cfg* pose,
-                            long long* generation);
-int dfvo_session_depth(dfvo_session* s, long long generation, const float** h_depth);  /* float [feed_h, feed_w] */
-/* flow of (generation - 1, generation): fwd / bwd float [2, img_h, img_w], diff float [img_h, img_w] */
+                            int flags, long long* generation);
+/* float [feed_h, feed_w].  DFVO_ERR_RANGE (pointer still set) when the depth net of this frame drove an activation out of
+ * f16's range under an f16x3 / f16 packing: the map holds inf / NaN. */
+int dfvo_session_depth(dfvo_session* s, long long generation, const float** h_depth);
+/* flow of (generation - 1, generation): fwd / bwd float [2, img_h, img_w], diff float [img_h, img_w]; DFVO_ERR_RANGE as above */
 int dfvo_session_flow(dfvo_session* s, long long generation, const float** h_fwd, const float** h_bwd, const float** h_diff);
+/* the session's pinned copy of frame `generation` (the newest or the one before), uint8 [img_h, img_w, 3]: what was uploaded --
+ * the mirror compares the frames handed to forward_flow with it byte for byte */
+int dfvo_session_frame(dfvo_session* s, long long generation, const uint8_t** h_frame);
+/* Buffer lifetime: the pointers dfvo_session_depth / _flow return belong to ring slot generation % 3 and are overwritten by
+ * the push of generation + 3.  A caller that still references them then (or at dfvo_session_destroy) takes them over:
+ * h_old4 = {depth, fwd, bwd, diff} of that slot, the session allocates itself fresh ones; release each with dfvo_host_free. */
+int dfvo_session_detach_slot(dfvo_session* s, long long generation, void** h_old4);
+int dfvo_host_free(void* h_pinned);
 int dfvo_session_keypoints(dfvo_session* s, long long generation, const dfvo_session_kp_cfg* kp, const double** h_kp_ref,
                            const double** h_kp_cur, int* n, int* good_kp_found);
 /* The RandomState-consuming half of compute_pose_2d2d (shuffles, five-point RANSACs, GRIC-E, recoverPose) enqueued AHEAD of

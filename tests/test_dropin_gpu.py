@@ -532,3 +532,176 @@ def test_timer_sub_keys_are_fed_from_device_stage_times(gpu):
     small = np.ascontiguousarray(np.random.rand(8, 2) * 100)
     trk.compute_pose_2d2d(small, small + 1.0, True)
     assert len(timers.timers["find-Ess"]["duration"]) == 2 and len(timers.timers["find H"]["duration"]) == 3
+
+
+# ---- round 6: guards of the frame session (VERDICT r5 tasks 5 / 8) ----------------------------------------------
+def _small_world(tmp_path, n=6, seed=41, tweak=None, precision=None):
+    from synth import coded_tunnel_sequence, crafted_liteflownet_state_dict, crafted_monodepth2_state_dict, write_weight_files
+    h, w = 256, 640
+    seq = coded_tunnel_sequence(h, w, n, mode="mux", step=1.0, seed=seed)
+    fsd, dsd = crafted_liteflownet_state_dict(h, w, "mux"), crafted_monodepth2_state_dict()
+    if tweak:
+        tweak(fsd, dsd)
+    flow_path, depth_dir = write_weight_files(str(tmp_path), fsd, dsd)
+    cfg = full_cfg(h, w, flow_path, depth_dir)
+    if precision:
+        cfg["dfvo_hip"] = {"conv_precision": precision}
+    return h, w, seq, cfg
+
+
+def test_f16_range_guard_raises_through_the_mirrors(gpu, tmp_path, monkeypatch):
+    """DeepModel packs the nets in f16x3 by default; an activation beyond +-65504 becomes inf in the layer that splits it.  The
+    mirrors must not hand such a map out: forward_depth / forward_flow raise DfvoError, with the session (counter read behind
+    each net) and without it (counter read after the call); the exact-fp32 packing of the same weights runs through."""
+    capi = importlib.import_module("df-vo_amd.capi")
+
+    def hot_depth(fsd, dsd):
+        dsd["encoder.bn1.bias"][:] = 1.0e5      # conv1 + BN + ReLU outputs ~1e5: the first residual block splits them
+
+    def hot_flow(fsd, dsd):
+        fsd["moduleFeatures.moduleOne.0.bias"][:] = 1.0e5
+
+    for sess in ("1", "0"):
+        monkeypatch.setenv("DFVO_SESSION", sess)
+        h, w, seq, cfg = _small_world(tmp_path, tweak=hot_depth)
+        dm = _build_mirrors(cfg, seq["K"])[0]
+        assert (dm.session is not None) == (sess == "1") and dm.conv_precision == "f16x3"
+        with pytest.raises(capi.DfvoError, match="out of range"):
+            dm.forward_depth(imgs=[seq["frames"][0].copy()])
+        h, w, seq, cfg = _small_world(tmp_path, tweak=hot_flow)
+        dm = _build_mirrors(cfg, seq["K"])[0]
+        f0, f1 = seq["frames"][0].copy(), seq["frames"][1].copy()
+        dm.forward_depth(imgs=[f0])             # (the depth net of these weights is in range)
+        with pytest.raises(capi.DfvoError, match="out of range"):
+            # with the session the flow net of (f0, f1) runs beside the depth net of f1 and the counter is process-wide: the
+            # event may already fail forward_depth(f1); without it, forward_flow is the call that runs the flow net
+            dm.forward_depth(imgs=[f1])
+            dm.forward_flow({"id": 1, "img": f1}, {"id": 0, "img": f0}, True)
+    # the same hot weights in exact fp32: no split, no guard, finite output
+    monkeypatch.setenv("DFVO_SESSION", "1")
+    h, w, seq, cfg = _small_world(tmp_path, tweak=hot_depth, precision="fp32")
+    dm = _build_mirrors(cfg, seq["K"])[0]
+    assert np.isfinite(np.asarray(dm.forward_depth(imgs=[seq["frames"][0].copy()]))).all()
+    capi.f16s_overflow_count(reset=True)        # (the suite asserts a zero counter after every test)
+
+
+def test_session_compares_whole_frames_and_whole_flow_arrays(gpu, tmp_path, monkeypatch):
+    """Round 5 validated the hand-over on a 1024-element sample: an edit elsewhere went unnoticed and the stale flow / the
+    keypoints of the unedited flow came back.  Now: (a) one byte of the current frame changed in place between forward_depth
+    and forward_flow -> forward_flow takes the plain path and returns the flow of the frames it was GIVEN; (b) a copy of the
+    returned flow edited through a child view (no __setitem__ on the array object, the token survives) -> kp_selection takes
+    the plain path and selects on what it was given."""
+    monkeypatch.setenv("DFVO_SESSION", "1")
+    h, w, seq, cfg = _small_world(tmp_path)
+    dm, sampler, _, _, _ = _build_mirrors(cfg, seq["K"])
+    s = dm.session
+    f0, f1 = seq["frames"][0].copy(), seq["frames"][1].copy()
+    dm.forward_depth(imgs=[f0])
+    dm.forward_depth(imgs=[f1])
+    f1.reshape(-1)[5] ^= 0x40                    # flat index 5: in no strided sample of round 5's check
+    before = dict(s.stats)
+    flows = dm.forward_flow({"id": 1, "img": f1}, {"id": 0, "img": f0}, True)
+    assert s.stats["flow_plain"] == before["flow_plain"] + 1 and s.stats["flow_resident"] == before["flow_resident"]
+    want = dm.flow.inference_flow_u8(f0, f1)
+    assert np.array_equal(flows[(0, 1)], want[0]) and np.array_equal(flows[(0, 1, "diff")], want[2])
+    # (b)
+    g0, g1 = seq["frames"][2].copy(), seq["frames"][3].copy()
+    dm.forward_depth(imgs=[g0])
+    dm.forward_depth(imgs=[g1])
+    flows = dm.forward_flow({"id": 3, "img": g1}, {"id": 2, "img": g0}, True)
+    assert s.stats["flow_resident"] == before["flow_resident"] + 1
+    fwd, diff = flows[(2, 3)].copy(), flows[(2, 3, "diff")].copy()
+    child = diff[100:140]                        # a view: writing through it leaves the parent's token alone
+    np.asarray(child)[...] = 9.0
+    assert getattr(diff, "_dfvo_tok", None) is not None, "the token is expected to survive a write through a child view"
+    depth = np.ones((h, w))
+    before = dict(s.stats)
+    out = sampler.kp_selection({"depth": depth}, {"flow": fwd, "flow_diff": diff, "depth": depth})
+    assert s.stats["kp_plain"] == before["kp_plain"] + 1 and s.stats["kp_resident"] == before["kp_resident"]
+    want = T.local_bestN(np.asarray(fwd), np.asarray(diff))
+    assert np.array_equal(out["kp1_best"], want["kp1_best"]) and np.array_equal(out["kp2_best"], want["kp2_best"])
+
+
+def test_session_views_keep_their_memory(gpu, tmp_path, monkeypatch):
+    """forward_depth / forward_flow return views of a three-slot pinned ring.  A view that is still referenced when
+    its slot comes up for reuse keeps the memory (the session takes fresh buffers); after close() it still reads what it read
+    before.  The arrays are read-only."""
+    monkeypatch.setenv("DFVO_SESSION", "1")
+    h, w, seq, cfg = _small_world(tmp_path, n=8)
+    dm = _build_mirrors(cfg, seq["K"])[0]
+    s = dm.session
+    frames = [f.copy() for f in seq["frames"]]
+    d0 = dm.forward_depth(imgs=[frames[0]])
+    d1 = dm.forward_depth(imgs=[frames[1]])
+    fl = dm.forward_flow({"id": 1, "img": frames[1]}, {"id": 0, "img": frames[0]}, True)
+    held = {"d0": d0, "d1": d1[10:20], "fwd": fl[(0, 1)][0], "diff": fl[(0, 1, "diff")]}
+    snap = {k: np.array(v) for k, v in held.items()}
+    with pytest.raises(ValueError):
+        d0[0, 0] = 1.0
+    del d0, d1, fl
+    for k in range(2, 8):                        # six more pushes: both slots are reused twice
+        dm.forward_depth(imgs=[frames[k]])
+        dm.forward_flow({"id": k, "img": frames[k]}, {"id": k - 1, "img": frames[k - 1]}, True)
+    assert s.stats["slots_detached"] == 2, s.stats
+    for k, v in held.items():
+        assert np.array_equal(np.asarray(v), snap[k]), "'%s' changed under its holder" % k
+    last = dm.forward_depth(imgs=[frames[0]])
+    last_snap = np.array(last)
+    s.close()
+    assert np.array_equal(np.asarray(last), last_snap)
+    for k, v in held.items():
+        assert np.array_equal(np.asarray(v), snap[k])
+    # a closed session no longer accepts frames: the DeepModel answers from the plain entry point
+    again = dm.forward_depth(imgs=[frames[0]])
+    assert np.array_equal(np.asarray(again), last_snap)
+
+
+def test_depth_only_caller_stops_paying_for_the_flow_net(gpu, tmp_path, monkeypatch):
+    """every push enqueued the flow net whether or not forward_flow followed.  After three pushes in a row whose
+    flow nobody asked for, a push runs the depth net alone; the first forward_flow is answered by the plain entry point (same
+    bits) and switches the speculation back on."""
+    monkeypatch.setenv("DFVO_SESSION", "1")
+    h, w, seq, cfg = _small_world(tmp_path, n=8)
+    dm = _build_mirrors(cfg, seq["K"])[0]
+    s = dm.session
+    frames = [f.copy() for f in seq["frames"]]
+    for k in range(6):
+        dm.forward_depth(imgs=[frames[k]])
+    assert s.stats["push"] == 6 and s.stats["push_no_flow"] == 3, s.stats
+    before = dict(s.stats)
+    flows = dm.forward_flow({"id": 5, "img": frames[5]}, {"id": 4, "img": frames[4]}, True)
+    assert s.stats["flow_plain"] == before["flow_plain"] + 1
+    want = dm.flow.inference_flow_u8(frames[4], frames[5])
+    assert np.array_equal(flows[(4, 5)], want[0])
+    dm.forward_depth(imgs=[frames[6]])           # speculating again; (5, 6) runs both frames through Features
+    flows = dm.forward_flow({"id": 6, "img": frames[6]}, {"id": 5, "img": frames[5]}, True)
+    assert s.stats["flow_resident"] == before["flow_resident"] + 1 and s.stats["push_no_flow"] == 3
+    want = dm.flow.inference_flow_u8(frames[5], frames[6])
+    assert np.array_equal(flows[(5, 6)], want[0]) and np.array_equal(flows[(5, 6, "diff")], want[2])
+
+
+@pytest.mark.parametrize("mode", ["force_fail", "creation"])
+def test_stream_pool_fallback_is_loud_and_harmless(gpu, tmp_path, monkeypatch, capfd, mode):
+    """VERDICT r5 task 8: the pipe probe is a timing measurement.  Forced to fail (DFVO_STREAM_POOL_FORCE_FAIL=1) the session
+    keeps creation-order streams and says so on stderr, once; DFVO_STREAM_POOL=creation skips the probe silently.  Either way
+    every call returns what the plain entry points return."""
+    if mode == "force_fail":
+        monkeypatch.setenv("DFVO_STREAM_POOL_FORCE_FAIL", "1")
+    else:
+        monkeypatch.setenv("DFVO_STREAM_POOL", "creation")
+    h, w, seq, cfg = _small_world(tmp_path, n=4)
+    runs = {}
+    for sess in ("0", "1"):
+        monkeypatch.setenv("DFVO_SESSION", sess)
+        mirrors = _build_mirrors(cfg, seq["K"])
+        rec = []
+        poses, modes = _main_loop(cfg, seq, 4, h, w, mirrors, record=rec)
+        runs[sess] = (poses, modes, rec, mirrors[0].session)
+    err = capfd.readouterr().err
+    assert ("pipe probe did not settle" in err) == (mode == "force_fail"), err[-400:]
+    (p0, m0, r0, _), (p1, m1, r1, s) = runs["0"], runs["1"]
+    assert m0 == m1 and np.array_equal(p0, p1)
+    for a, b in zip(r0, r1):
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
+    assert s.stats["flow_resident"] == s.stats["pose_ahead"] == 3, s.stats
