@@ -439,7 +439,11 @@ int FlowNet::finalize() {
             leaky(L.r_feat, 0, 0);
             DFVO_TRY(L.rfeat.alloc(px * 128));
         }
-        // (the three level-2 moduleFeat convolutions as one 32 -> 256 launch: measured, no gain -- profiles/r3am_fuse_feat_ab.txt)
+        // (the three level-2 moduleFeat convolutions as one 32 -> 256 launch: measured, no gain -- profiles/r3am_fuse_feat_ab.txt;
+        // the feature-only 1x1 convolutions of levels 4-2 on a side stream beside levels 6-5, round 6: as a fork inside the
+        // captured graph the pass took 6.0 ms instead of 3.7 -- hipGraph runs a forked graph through per-node cross-stream
+        // synchronisation --, as three linear graphs joined by events the flow net's time did not move (3.62 vs 3.64 ms) while
+        // the depth net beside it finished 0.5 ms later and the fused pipeline lost 5 %: profiles/r6e_*, r6f_*; removed)
         const int rc0[6] = {3, 128, 128, 64, 64, 32}, rc1[6] = {Cr, 0, 0, 0, 0, 0};
         for (int i = 0; i < 6; ++i) {
             const std::string idx = std::to_string(2 * i);
@@ -477,7 +481,7 @@ int FlowNet::finalize() {
         DFVO_TRY(L.dist_a.alloc(px * kkp));
         DFVO_TRY(L.dist_b.alloc(px * kkp));
         DFVO_TRY(L.flow.alloc(px * 4));
-        DFVO_TRY(L.mean.alloc(N * 2));
+        DFVO_TRY(L.mean.alloc(4 + flow_mean_scratch_floats(N)));  // [0, 2N): the means; from float 4 on: launch_flow_mean's scratch
     }
     DFVO_TRY(out_fwd.alloc((size_t)2 * imgH * imgW));
     DFVO_TRY(out_bwd.alloc((size_t)2 * imgH * imgW));
@@ -626,7 +630,7 @@ int FlowNet::enqueue_levels(float* d_fwd, float* d_bwd, float* d_diff) {
         DFVO_TRY(run_conv(L.s_main[3], N, h, w, View{L.x32b.p, 32, 0}, 0, none, L.flowM.p, 4, 0, L.flowS.p, 4, 0, 0, s,
                           &fl, &splitk));
         // ------------------------------ Regularization (lite_flow_net.py:243-264)
-        DFVO_TRY(launch_flow_mean(L.flowS.p, 4, 0, N, h * w, nullptr, L.mean.p, s));
+        DFVO_TRY(launch_flow_mean(L.flowS.p, 4, 0, N, h * w, L.mean.p + 4, L.mean.p, s));
         DFVO_TRY(launch_reg_prep(img[l].p, L.flowS.p, 4, 0, dbl, L.mean.p, N, h, w, lin_x[l].p, lin_y[l].p, L.r0.p, s));
         if (L.has_rfeat) {
             DFVO_TRY(run_conv(L.r_feat, N, h, w, View{feat[l].p, C, 0}, 0, none, nullptr, 0, 0, L.rfeat.p, 128, 0, 0, s,

@@ -21,7 +21,8 @@ int launch_warp(const float* src, int scs, int sco, int swap, const float* flow,
                 int N, int H, int W, int C, const float* lin_x, const float* lin_y, float* dst, int dcs, int dco,
                 int append_flow, hipStream_t s);
 // per-sample mean of a 2-channel flow over H*W -> mean[N][2]. lite_flow_net.py:255
-int launch_flow_mean(const float* flow, int fcs, int fco, int N, int HW, float* partial, float* mean,
+size_t flow_mean_scratch_floats(int N);  // zero-filled, 8-byte aligned scratch of launch_flow_mean (partials + tickets)
+int launch_flow_mean(const float* flow, int fcs, int fco, int N, int HW, float* scratch, float* mean,
                      hipStream_t s);
 // Regularization input head, lite_flow_net.py:244-255: dst[n,y,x] = [sqrt(sum_c (I1 - warp(I2))^2 + 1e-6),
 // fx - mean_x, fy - mean_y, 0].  I1 = img[n], I2 = img[N-1-n] (NHWC4, 3 used).

@@ -203,20 +203,29 @@ int launch_warp(const float* src, int scs, int sco, int swap, const float* flow,
 // ---------------------------------------------------------------------------------------------
 // flow mean (per sample, 2 channels)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_flow_mean(const float* __restrict__ flow, int fcs, int fco, int HW,
-                                                     float* __restrict__ mean) {
-    __shared__ double sx[1024], sy[1024];
-    const int n = blockIdx.x;
+// Round 6: the single 1024-thread workgroup per sample of rounds 1-5 read a level-2 map (3.4 MB) alone -- 35 us of a chain in
+// which every microsecond is latency.  Now FM_G workgroups per sample write double partial sums; the workgroup that takes the
+// last ticket adds the FM_G partials IN INDEX ORDER and rounds once: deterministic, and (the sums being sums of floats in
+// double, far from 53 bits) the same float as before.
+constexpr int FM_G = 64;
+__global__ __launch_bounds__(256) void k_flow_mean(const float* __restrict__ flow, int fcs, int fco, int HW,
+                                                    double* __restrict__ partial, unsigned* __restrict__ ticket,
+                                                    float* __restrict__ mean) {
+    __shared__ double sx[256], sy[256];
+    __shared__ bool last;
+    const int n = blockIdx.y, g = blockIdx.x;
     const float* f = flow + (size_t)n * HW * fcs + fco;
-    double ax = 0., ay = 0.;  // exact sum of the floats, one rounding at the end
-    for (int i = threadIdx.x; i < HW; i += 1024) {
-        ax += f[(size_t)i * fcs];
-        ay += f[(size_t)i * fcs + 1];
+    const int per = (HW + FM_G - 1) / FM_G, lo = g * per, hi = min(HW, lo + per);
+    double ax = 0., ay = 0.;
+    for (int i = lo + threadIdx.x; i < hi; i += 256) {
+        const f32x2 v = *reinterpret_cast<const f32x2*>(f + (size_t)i * fcs);
+        ax += v[0];
+        ay += v[1];
     }
     sx[threadIdx.x] = ax;
     sy[threadIdx.x] = ay;
     __syncthreads();
-    for (int o = 512; o > 0; o >>= 1) {
+    for (int o = 128; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) {
             sx[threadIdx.x] += sx[threadIdx.x + o];
             sy[threadIdx.x] += sy[threadIdx.x + o];
@@ -224,15 +233,34 @@ __global__ __launch_bounds__(1024) void k_flow_mean(const float* __restrict__ fl
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        mean[n * 2] = (float)(sx[0] / (double)HW);
-        mean[n * 2 + 1] = (float)(sy[0] / (double)HW);
+        double* pp = partial + ((size_t)n * FM_G + g) * 2;
+        __hip_atomic_store(pp, sx[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(pp + 1, sy[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned t = __hip_atomic_fetch_add(ticket + n, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last = t == FM_G - 1;
     }
+    __syncthreads();
+    if (!last || threadIdx.x != 0) return;
+    double tx = 0., ty = 0.;
+    for (int j = 0; j < FM_G; ++j) {
+        tx += __hip_atomic_load(partial + ((size_t)n * FM_G + j) * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ty += __hip_atomic_load(partial + ((size_t)n * FM_G + j) * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    mean[n * 2] = (float)(tx / (double)HW);
+    mean[n * 2 + 1] = (float)(ty / (double)HW);
+    __hip_atomic_store(ticket + n, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
 }
 
-int launch_flow_mean(const float* flow, int fcs, int fco, int N, int HW, float* partial, float* mean,
+size_t flow_mean_scratch_floats(int N) { return (size_t)N * FM_G * 2 * 2 + (size_t)N + 4; }  // doubles, then the tickets
+
+// scratch: flow_mean_scratch_floats(N) floats, 8-byte aligned, ZERO when first used (the kernel leaves the tickets at zero)
+int launch_flow_mean(const float* flow, int fcs, int fco, int N, int HW, float* scratch, float* mean,
                      hipStream_t s) {
-    (void)partial;
-    hipLaunchKernelGGL(k_flow_mean, dim3(N), dim3(1024), 0, s, flow, fcs, fco, HW, mean);
+    DFVO_ARG_CHECK(scratch && (fcs % 2) == 0 && (fco % 2) == 0 && ((uintptr_t)flow & 7) == 0 && ((uintptr_t)scratch & 7) == 0,
+                   "flow_mean: scratch / 8-byte aligned flow view required");
+    double* partial = reinterpret_cast<double*>(scratch);
+    unsigned* ticket = reinterpret_cast<unsigned*>(scratch + (size_t)N * FM_G * 2 * 2);
+    hipLaunchKernelGGL(k_flow_mean, dim3(FM_G, N), dim3(256), 0, s, flow, fcs, fco, HW, partial, ticket, mean);
     DFVO_HIP_CHECK(hipGetLastError());
     return DFVO_OK;
 }
@@ -350,10 +378,81 @@ __global__ __launch_bounds__(256) void k_deconv_dw4(const float* __restrict__ sr
     *reinterpret_cast<f32x4*>(dst + pix * dcs + dco + c0) = acc;
 }
 
+// Round 6: the same sums, one thread per INPUT pixel and channel quad = a 2 x 2 block of outputs.  The four outputs share
+// the 3 x 3 input neighbourhood (9 vector loads instead of 16) and the sixteen taps of the quad's channels, which the
+// workgroup first transposes into LDS ([tap][channel]: one 16-byte read per tap instead of four scattered 4-byte loads per
+// tap and output).  Per output the taps are added in k_deconv_dw4's order (ky high to low, kx high to low, one fma each):
+// bit-identical.  Level-2 correlation upsampling (49 channels, 176 x 608 x 2 outputs): 83 -> ~30 us.
+__global__ __launch_bounds__(256) void k_deconv_dw4_blk(const float* __restrict__ src, int scs, int sco, int N, int H, int W, int C,
+                                                        const float* __restrict__ w, float* __restrict__ dst, int dcs, int dco) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];  // [16][C4 * 4]
+    const int C4 = (C + 3) >> 2, CP = C4 * 4;
+    for (int i = threadIdx.x; i < 16 * CP; i += 256) {
+        const int tap = i / CP, c = i - tap * CP;
+        wl[i] = c < C ? w[c * 16 + tap] : 0.f;
+    }
+    __syncthreads();
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)N * H * W * C4;
+    if (idx >= total) return;
+    const int q = (int)(idx % C4);
+    const long long ipix = idx / C4;
+    const int j = (int)(ipix % W);
+    const long long row = ipix / W;
+    const int i = (int)(row % H);
+    const int n = (int)(row / H);
+    const int c0 = q * 4;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 in[3][3];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int iy = i + dy - 1, ix = j + dx - 1;
+            in[dy][dx] = (iy >= 0 && iy < H && ix >= 0 && ix < W)
+                             ? *reinterpret_cast<const f32x4*>(src + ((size_t)(n * H + iy) * W + ix) * scs + sco + c0) : z;
+        }
+    const int Wo = 2 * W;
+#pragma unroll
+    for (int py = 0; py < 2; ++py)
+#pragma unroll
+        for (int px = 0; px < 2; ++px) {
+            // output (2i + py, 2j + px): ky = (1 - py) + 2a reads input row i + py - a (a = 1 first), likewise in x
+            f32x4 acc = z;
+#pragma unroll
+            for (int a = 1; a >= 0; --a) {
+                const int ky = (1 - py) + 2 * a, dy = py - a + 1;  // row i + py - a  ->  in[dy]
+                if (i + py - a < 0 || i + py - a >= H) continue;
+#pragma unroll
+                for (int b = 1; b >= 0; --b) {
+                    const int kx = (1 - px) + 2 * b, dx = px - b + 1;
+                    if (j + px - b < 0 || j + px - b >= W) continue;
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + (ky * 4 + kx) * CP + c0);
+                    const f32x4 v = in[dy][dx];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] += v[e] * wv[e];
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c0 + e >= C) acc[e] = 0.f;
+            const size_t opix = ((size_t)n * 2 * H + 2 * i + py) * Wo + 2 * j + px;
+            *reinterpret_cast<f32x4*>(dst + opix * dcs + dco + c0) = acc;
+        }
+}
+
 int launch_deconv_dw(const float* src, int scs, int sco, int N, int H, int W, int C, const float* w, float* dst,
                      int dcs, int dco, hipStream_t s) {
     const int C4 = (C + 3) >> 2;
     if (((scs | sco | dcs | dco) & 3) == 0 && C4 * 4 <= scs - sco && C4 * 4 <= dcs - dco) {  // 16-byte views with room for the quad
+        static const bool blk = !(getenv("DFVO_DECONV_BLK") && atoi(getenv("DFVO_DECONV_BLK")) == 0);
+        if (blk && C4 * 4 * 16 * sizeof(float) <= 32 * 1024) {
+            const long long totalb = (long long)N * H * W * C4;
+            hipLaunchKernelGGL(k_deconv_dw4_blk, dim3(grid1d(totalb, 256)), dim3(256), (size_t)C4 * 4 * 16 * sizeof(float), s, src, scs, sco,
+                               N, H, W, C, w, dst, dcs, dco);
+            DFVO_HIP_CHECK(hipGetLastError());
+            return DFVO_OK;
+        }
         const long long total4 = (long long)N * 2 * H * 2 * W * C4;
         hipLaunchKernelGGL(k_deconv_dw4, dim3(grid1d(total4, 256)), dim3(256), 0, s, src, scs, sco, N, H, W, C, w, dst, dcs, dco);
         DFVO_HIP_CHECK(hipGetLastError());
