@@ -600,8 +600,9 @@ int FlowNet::enqueue_levels(float* d_fwd, float* d_bwd, float* d_diff) {
         const int stride = L.has_upcorr ? 2 : 1;
         if (flow_prev) {
             DFVO_TRY(launch_deconv_dw(flow_prev, 4, 0, N, h / 2, w / 2, 2, L.upflow_w.p, L.flow_up.p, 4, 0, s));
+            // (the correlation reads its second operand at the stride-subsampled positions only: the warp produces just those)
             DFVO_TRY(launch_warp(mf, mcs, mco, 1, L.flow_up.p, 4, 0, dbl, N, h, w, Cm, lin_x[l].p, lin_y[l].p, L.warped.p,
-                                 Cm, 0, 0, s));
+                                 Cm, 0, 0, s, stride));
             DFVO_TRY(launch_correlation(mf, mcs, mco, L.warped.p, Cm, 0, 0, N, h, w, Cm, stride, L.corr.p, 52, 0.1f, s));
         } else {
             DFVO_TRY(launch_correlation(mf, mcs, mco, mf, mcs, mco, 1, N, h, w, Cm, stride, L.corr.p, 52, 0.1f, s));

@@ -19,7 +19,7 @@ int launch_resize_bilinear(const float* src, int N, int H, int W, int C, float* 
 // lin_x/lin_y are torch.linspace(-1,1,W/H) tables (device).
 int launch_warp(const float* src, int scs, int sco, int swap, const float* flow, int fcs, int fco, float mult,
                 int N, int H, int W, int C, const float* lin_x, const float* lin_y, float* dst, int dcs, int dco,
-                int append_flow, hipStream_t s);
+                int append_flow, hipStream_t s, int step = 1);  // step > 1: only pixels (y % step == 0, x % step == 0)
 // per-sample mean of a 2-channel flow over H*W -> mean[N][2]. lite_flow_net.py:255
 size_t flow_mean_scratch_floats(int N);  // zero-filled, 8-byte aligned scratch of launch_flow_mean (partials + tickets)
 int launch_flow_mean(const float* flow, int fcs, int fco, int N, int HW, float* scratch, float* mean,

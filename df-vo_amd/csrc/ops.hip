@@ -157,17 +157,21 @@ __device__ __forceinline__ Bilin bilin_setup(float gx, float gy, int W, int H) {
 
 __global__ void k_warp(const float* __restrict__ src, int scs, int sco, int swap, const float* __restrict__ flow,
                        int fcs, int fco, float mult, int N, int H, int W, int C4, const float* __restrict__ lin_x,
-                       const float* __restrict__ lin_y, float* __restrict__ dst, int dcs, int dco, int append_flow) {
+                       const float* __restrict__ lin_y, float* __restrict__ dst, int dcs, int dco, int append_flow, int step) {
+    // step > 1: only the pixels (y % step == 0, x % step == 0) are produced -- all a stride-`step` correlation reads of its
+    // second operand (levels 3 and 2: a quarter of the map)
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int per_pix = C4 + (append_flow ? 1 : 0);
-    const long long total = (long long)N * H * W * per_pix;
+    const int Hs = (H + step - 1) / step, Ws = (W + step - 1) / step;
+    const long long total = (long long)N * Hs * Ws * per_pix;
     if (idx >= total) return;
     const int c = (int)(idx % per_pix);
-    long long pix = idx / per_pix;
-    const int x = (int)(pix % W);
-    const long long row = pix / W;
-    const int y = (int)(row % H);
-    const int n = (int)(row / H);
+    const long long spix = idx / per_pix;
+    const int x = (int)(spix % Ws) * step;
+    const long long row = spix / Ws;
+    const int y = (int)(row % Hs) * step;
+    const int n = (int)(row / Hs);
+    const long long pix = ((long long)n * H + y) * W + x;
     const float fx = flow[pix * fcs + fco], fy = flow[pix * fcs + fco + 1];
     if (c == C4) {
         *reinterpret_cast<f32x4*>(dst + pix * dcs + dco + C4 * 4) = f32x4{fx, fy, 0.f, 0.f};
@@ -191,11 +195,11 @@ __global__ void k_warp(const float* __restrict__ src, int scs, int sco, int swap
 
 int launch_warp(const float* src, int scs, int sco, int swap, const float* flow, int fcs, int fco, float mult,
                 int N, int H, int W, int C, const float* lin_x, const float* lin_y, float* dst, int dcs, int dco,
-                int append_flow, hipStream_t s) {
-    DFVO_ARG_CHECK(C % 4 == 0 && scs % 4 == 0 && sco % 4 == 0 && dcs % 4 == 0 && dco % 4 == 0, "warp: alignment");
-    const long long total = (long long)N * H * W * (C / 4 + (append_flow ? 1 : 0));
+                int append_flow, hipStream_t s, int step) {
+    DFVO_ARG_CHECK(C % 4 == 0 && scs % 4 == 0 && sco % 4 == 0 && dcs % 4 == 0 && dco % 4 == 0 && step >= 1, "warp: alignment");
+    const long long total = (long long)N * cdiv(H, step) * cdiv(W, step) * (C / 4 + (append_flow ? 1 : 0));
     hipLaunchKernelGGL(k_warp, dim3(grid1d(total, 256)), dim3(256), 0, s, src, scs, sco, swap, flow, fcs, fco, mult,
-                       N, H, W, C / 4, lin_x, lin_y, dst, dcs, dco, append_flow);
+                       N, H, W, C / 4, lin_x, lin_y, dst, dcs, dco, append_flow, step);
     DFVO_HIP_CHECK(hipGetLastError());
     return DFVO_OK;
 }
@@ -759,6 +763,9 @@ __global__ __launch_bounds__(256) void k_reg_head_v(const float* __restrict__ di
     *reinterpret_cast<f32x2*>(dst + pix * dcs + dco) = f32x2{(float)((ax + bx) / se), (float)((ay + by) / se)};
 }
 
+// (Round 6: the distance vectors of a workgroup's 256 consecutive pixels staged through LDS -- one contiguous, fully coalesced
+// run instead of 16-byte loads at a 208-byte lane stride -- measured SLOWER: 49.1 vs 45.9 us on the level-2 map, 11.4 vs 10.1
+// on level 3, profiles/r6i_mirrors_kernel_stats_lds{0,1}.csv.  The kernel is not bound by its load pattern; removed.)
 int launch_reg_head(const float* dist, int dist_cs, int k, const float* flow, int fcs, int fco, const float* wx,
                     float bx, const float* wy, float by, int N, int H, int W, float* dst, int dcs, int dco,
                     hipStream_t s) {

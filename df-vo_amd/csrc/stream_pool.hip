@@ -50,7 +50,7 @@ static float chain_us(hipStream_t s, hipEvent_t e0, hipEvent_t e1, int n) {
 
 // one classification pass over the already created streams; returns false when a measurement failed
 static bool classify(const std::vector<hipStream_t>& s, hipEvent_t e0, hipEvent_t e1, std::vector<int>* group, int* ngroups) {
-    const int n = (int)s.size(), CH = 40;
+    const int n = (int)s.size(), CH = 16;  // 16 dependent empty launches: ~30 us alone, ~75 us next to a busy stream on their pipe
     if (getenv("DFVO_STREAM_POOL_FORCE_FAIL")) return false;
     group->assign(n, -1);
     std::vector<float> base(n);
@@ -61,9 +61,10 @@ static bool classify(const std::vector<hipStream_t>& s, hipEvent_t e0, hipEvent_
         (*group)[a] = *ngroups;
         for (int b = a + 1; b < n; ++b) {
             if ((*group)[b] >= 0) continue;
-            // stream a busy for ~0.4 ms (20 x 20 us, wall_clock64 ticks at 100 MHz), the chain on b (0.07 ms alone, 0.17-0.19
-            // next to a busy stream on its pipe) inside that window
-            for (int k = 0; k < 20; ++k) hipLaunchKernelGGL(k_pool_spin, dim3(1), dim3(64), 0, s[a], 2000LL);
+            // stream a busy for ~0.1 ms (5 x 20 us, wall_clock64 ticks at 100 MHz), the chain on b inside that window.  (Round 5's
+            // 40-launch chain under a 0.6 ms window, up to four passes, was 27 % of the kernel time of a 33-pair class-surface run:
+            // profiles/r6g_mirrors_kernel_stats_before_probe_trim.csv.)
+            for (int k = 0; k < 5; ++k) hipLaunchKernelGGL(k_pool_spin, dim3(1), dim3(64), 0, s[a], 2000LL);
             const float t = chain_us(s[b], e0, e1, CH);
             if (hipStreamSynchronize(s[a]) != hipSuccess || t < 0.f || base[b] <= 0.f) return false;
             if (t > 1.6f * base[b]) (*group)[b] = *ngroups;
@@ -99,7 +100,7 @@ int StreamPool::create(int n) {
     std::vector<std::vector<int>> seen;
     int attempts = 0;
     for (int attempt = 0; attempt < 5 && !ok; ++attempt) {
-        for (int k = 0; k < 50 * (attempt + 1); ++k)  // 1, 2, 3, 4 ms of spinning on one stream
+        for (int k = 0; k < 25 * (attempt + 1); ++k)  // 0.5, 1, 1.5 ... ms of spinning on one stream
             hipLaunchKernelGGL(k_pool_spin, dim3(1), dim3(64), 0, s[0], 2000LL);
         DFVO_HIP_CHECK(hipDeviceSynchronize());
         std::vector<int> g2;
