@@ -59,37 +59,54 @@ __global__ __launch_bounds__(64 * TH) void conv_taps_f16s_kernel(const ConvParam
         const int dwy = dpx / wcols, dwx = dpx - dwy * wcols;    // pixel step dpx = dwy rows + dwx columns
         int px = t / G, cg = t - px * G;
         int wy = px / wcols, wx = px - wy * wcols;
-        for (int it = t; it < npix * G; it += NT) {
-            const int iy = iy0 + wy, ix = ix0 + wx;
-            const bool v = iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            f32x4 x = {0.f, 0.f, 0.f, 0.f};
-            if (v) x = *reinterpret_cast<const f32x4*>(p.src0 + ((size_t)(n * p.H + iy) * p.W + ix) * p.cs0 + p.co0 + cg * 4);
-            h16x4 hi, lo;
-            unsigned char* d = taps_lds + (size_t)px * pxd + cg * 8;
-            if constexpr (NP == 3) {
-                split_f16_planes(x, &hi, &lo, amax);
-                *reinterpret_cast<h16x4*>(d) = hi;
-                *reinterpret_cast<h16x4*>(d + G * 8) = lo;
-            } else {
-                split_f16_hi(x, &hi, amax);
-                *reinterpret_cast<h16x4*>(d) = hi;
+        // Items in batches of LB: the batch's addresses first, then its loads back to back, then the splits.  (Round 6: one load
+        // per loop iteration left every load's HBM latency exposed -- ten dependent round trips on the 7 x 1 distance layer of
+        // level 2, whose launch took 64 us for 72 MB: 1.1 TB/s with the matrix pipe 85 % idle.)
+        constexpr int LB = 4;
+        const int nitems = npix * G;
+        for (int it = t; it < nitems; it += NT * LB) {
+            f32x4 xb[LB];
+            int pxb[LB], cgb[LB];
+#pragma unroll
+            for (int u = 0; u < LB; ++u) {
+                const bool live = it + u * NT < nitems;
+                const int iy = iy0 + wy, ix = ix0 + wx;
+                const bool v = live && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+                pxb[u] = live ? px : -1;
+                cgb[u] = cg;
+                xb[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (v) xb[u] = *reinterpret_cast<const f32x4*>(p.src0 + ((size_t)(n * p.H + iy) * p.W + ix) * p.cs0 + p.co0 + cg * 4);
+                cg += dcg;
+                int cpx = dpx;
+                if (cg >= G) {
+                    cg -= G;
+                    cpx += 1;
+                }
+                px += cpx;
+                wx += dwx + (cpx - dpx);
+                wy += dwy;
+                if (wx >= wcols) {
+                    wx -= wcols;
+                    wy += 1;
+                }
+                if (wx >= wcols) {  // (dwx + 1 can exceed wcols once more only when dwx = wcols - 1 and both carries hit)
+                    wx -= wcols;
+                    wy += 1;
+                }
             }
-            cg += dcg;
-            int cpx = dpx;
-            if (cg >= G) {
-                cg -= G;
-                cpx += 1;
-            }
-            px += cpx;
-            wx += dwx + (cpx - dpx);
-            wy += dwy;
-            if (wx >= wcols) {
-                wx -= wcols;
-                wy += 1;
-            }
-            if (wx >= wcols) {  // (dwx + 1 can exceed wcols once more only when dwx = wcols - 1 and both carries hit)
-                wx -= wcols;
-                wy += 1;
+#pragma unroll
+            for (int u = 0; u < LB; ++u) {
+                if (pxb[u] < 0) continue;
+                h16x4 hi, lo;
+                unsigned char* d = taps_lds + (size_t)pxb[u] * pxd + cgb[u] * 8;
+                if constexpr (NP == 3) {
+                    split_f16_planes(xb[u], &hi, &lo, amax);
+                    *reinterpret_cast<h16x4*>(d) = hi;
+                    *reinterpret_cast<h16x4*>(d + G * 8) = lo;
+                } else {
+                    split_f16_hi(xb[u], &hi, amax);
+                    *reinterpret_cast<h16x4*>(d) = hi;
+                }
             }
         }
     }

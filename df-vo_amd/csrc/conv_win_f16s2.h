@@ -26,7 +26,13 @@ __device__ __forceinline__ void f16s2_static_for(F&& f) {  // f(integral_constan
 
 // NP: products per term -- 3 = f16x3 (hi x lo, lo x hi into the cross sums, hi x hi into the main sums), 1 = the "f16"
 // mode (hi x hi only: the lo planes are neither written to LDS nor loaded, the cross set does not exist)
-template <int WC, int WR, int TC, int TR, int NP = 3>
+// PRE (round 6, TIMING EXPERIMENT ONLY -- DFVO_WIN_PRESPLIT_TIMING=1, tools/bench_window_layers.py): the window item is taken to
+// be ALREADY split by its producer -- 16 bytes = [4 hi halves | 4 lo halves] of a pixel's 4-channel group, the same 4 bytes per
+// element as fp32 -- and goes to LDS as it is: no v_cvt / v_sub / v_mul / v_max3, nothing but the two LDS writes between the
+// taps' MFMA groups.  The bytes it reinterprets are the fp32 activations, so the OUTPUT IS MEANINGLESS; the instruction stream
+// is what a consumer of pre-split activations would run with register-staged loads (VERDICT r5 task 4's upper bound short
+// of global_load_lds).
+template <int WC, int WR, int TC, int TR, int NP = 3, bool PRE = false>
 __global__ __launch_bounds__(64 * WC * WR, 1) void conv_win_f16s2_kernel(const ConvParams p) {
     constexpr int NT = 64 * WC * WR;
     constexpr int NPL = NP == 3 ? 2 : 1;  // operand planes in use
@@ -110,7 +116,11 @@ __global__ __launch_bounds__(64 * WC * WR, 1) void conv_win_f16s2_kernel(const C
         const int px = (id >> 2) < WH * WW ? (id >> 2) : WH * WW;  // (no branch: out-of-window items land in the spare slot)
         h16x4 hi, lo;
         float* dst = W + px * PS + wq * 2;
-        if constexpr (NP == 3) {
+        if constexpr (NP == 3 && PRE) {
+            const f32x4 x = ((rwv >> r) & 1u) ? rw[r] : f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x2*>(dst) = f32x2{x[0], x[1]};
+            *reinterpret_cast<f32x2*>(dst + 8) = f32x2{x[2], x[3]};
+        } else if constexpr (NP == 3) {
             split_f16_planes(((rwv >> r) & 1u) ? rw[r] : f32x4{0.f, 0.f, 0.f, 0.f}, &hi, &lo, amax);
             *reinterpret_cast<h16x4*>(dst) = hi;
             *reinterpret_cast<h16x4*>(dst + 8) = lo;
@@ -282,8 +292,11 @@ static int launch_f16s2_cfg(const ConvParams& p, hipStream_t stream, int cfg_id)
         pe.cfg = cfg_id;
         DFVO_HIP_CHECK(hipEventRecord(pe.e0, stream));
     }
+    static const bool presplit_timing = getenv("DFVO_WIN_PRESPLIT_TIMING") && atoi(getenv("DFVO_WIN_PRESPLIT_TIMING")) != 0;
     if (p.f16_terms == 1)
         hipLaunchKernelGGL((conv_win_f16s2_kernel<WC, WR, TC, TR, 1>), grid, dim3(64 * WC * WR), 0, stream, p);
+    else if (presplit_timing && WC == 2 && TC == 2)  // (the 128-cout shapes only: one extra instantiation pair)
+        hipLaunchKernelGGL((conv_win_f16s2_kernel<WC, WR, TC, TR, 3, (WC == 2 && TC == 2)>), grid, dim3(64 * WC * WR), 0, stream, p);
     else
         hipLaunchKernelGGL((conv_win_f16s2_kernel<WC, WR, TC, TR, 3>), grid, dim3(64 * WC * WR), 0, stream, p);
     DFVO_HIP_CHECK(hipGetLastError());

@@ -554,23 +554,44 @@ __global__ __launch_bounds__(256) void k_correlation_rt(const float* __restrict_
     const int n = blockIdx.z;
     const int oy0 = blockIdx.y * TH, ox0 = blockIdx.x * TW;
     const int n2 = swap2 ? (N - 1 - n) : n;
-    for (int it = threadIdx.x; it < TH * TW * C4; it += 256) {
-        const int c = it % C4, pp = it / C4;
-        const int py = pp / TW, px = pp - py * TW;
-        const int oy = oy0 + py, ox = ox0 + px;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (oy < Ho && ox < Wo)
-            v = *reinterpret_cast<const f32x4*>(f1 + ((size_t)(n * H + oy * stride) * W + ox * stride) * cs1 + co1 + c * 4);
-        *reinterpret_cast<f32x4*>(s1 + pp * P + c * 4) = v;
+    // staging in batches of four items: addresses, then the four loads back to back, then the LDS stores (round 6: one load
+    // per iteration left every round trip exposed -- twelve in a row for the halo tile of a 64-channel level)
+    constexpr int LB = 4;
+    for (int it0 = threadIdx.x; it0 < TH * TW * C4; it0 += 256 * LB) {
+        f32x4 v[LB];
+        int dsto[LB];
+#pragma unroll
+        for (int u = 0; u < LB; ++u) {
+            const int it = it0 + 256 * u;
+            const int c = it % C4, pp = it / C4;
+            const int py = pp / TW, px = pp - py * TW;
+            const int oy = oy0 + py, ox = ox0 + px;
+            dsto[u] = it < TH * TW * C4 ? pp * P + c * 4 : -1;
+            v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (dsto[u] >= 0 && oy < Ho && ox < Wo)
+                v[u] = *reinterpret_cast<const f32x4*>(f1 + ((size_t)(n * H + oy * stride) * W + ox * stride) * cs1 + co1 + c * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < LB; ++u)
+            if (dsto[u] >= 0) *reinterpret_cast<f32x4*>(s1 + dsto[u]) = v[u];
     }
-    for (int it = threadIdx.x; it < HH2 * HW2 * C4; it += 256) {
-        const int c = it % C4, pp = it / C4;
-        const int py = pp / HW2, px = pp - py * HW2;
-        const int sy = oy0 + py - 3, sx = ox0 + px - 3;  // coordinates on the stride-subsampled grid
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (sy >= 0 && sy < Ho && sx >= 0 && sx < Wo)
-            v = *reinterpret_cast<const f32x4*>(f2 + ((size_t)(n2 * H + sy * stride) * W + sx * stride) * cs2 + co2 + c * 4);
-        *reinterpret_cast<f32x4*>(s2 + pp * P + c * 4) = v;
+    for (int it0 = threadIdx.x; it0 < HH2 * HW2 * C4; it0 += 256 * LB) {
+        f32x4 v[LB];
+        int dsto[LB];
+#pragma unroll
+        for (int u = 0; u < LB; ++u) {
+            const int it = it0 + 256 * u;
+            const int c = it % C4, pp = it / C4;
+            const int py = pp / HW2, px = pp - py * HW2;
+            const int sy = oy0 + py - 3, sx = ox0 + px - 3;  // coordinates on the stride-subsampled grid
+            dsto[u] = it < HH2 * HW2 * C4 ? pp * P + c * 4 : -1;
+            v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (dsto[u] >= 0 && sy >= 0 && sy < Ho && sx >= 0 && sx < Wo)
+                v[u] = *reinterpret_cast<const f32x4*>(f2 + ((size_t)(n2 * H + sy * stride) * W + sx * stride) * cs2 + co2 + c * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < LB; ++u)
+            if (dsto[u] >= 0) *reinterpret_cast<f32x4*>(s2 + dsto[u]) = v[u];
     }
     __syncthreads();
     const int units = TW * 7 * (TH / 2);
