@@ -26,13 +26,13 @@ __device__ __forceinline__ void f16s2_static_for(F&& f) {  // f(integral_constan
 
 // NP: products per term -- 3 = f16x3 (hi x lo, lo x hi into the cross sums, hi x hi into the main sums), 1 = the "f16"
 // mode (hi x hi only: the lo planes are neither written to LDS nor loaded, the cross set does not exist)
-// PRE (round 6, TIMING EXPERIMENT ONLY -- DFVO_WIN_PRESPLIT_TIMING=1, tools/bench_window_layers.py): the window item is taken to
-// be ALREADY split by its producer -- 16 bytes = [4 hi halves | 4 lo halves] of a pixel's 4-channel group, the same 4 bytes per
-// element as fp32 -- and goes to LDS as it is: no v_cvt / v_sub / v_mul / v_max3, nothing but the two LDS writes between the
-// taps' MFMA groups.  The bytes it reinterprets are the fp32 activations, so the OUTPUT IS MEANINGLESS; the instruction stream
-// is what a consumer of pre-split activations would run with register-staged loads (VERDICT r5 task 4's upper bound short
-// of global_load_lds).
-template <int WC, int WR, int TC, int TR, int NP = 3, bool PRE = false>
+// (Round 6, VERDICT r5 task 4's experiment: a TIMING-ONLY instantiation that took the window item as already split by its producer
+// -- 16 bytes = [4 hi halves | 4 lo halves], stored to LDS as they come, no v_cvt / v_sub / v_mul / v_max3 between the taps' MFMA
+// groups -- ran the level-2 128 -> 128 layer in 189-193 us instead of 202-211, 64+66 -> 128 in 204 instead of 218, the 1920 x 1280
+// layer in 972 instead of 1048 (-7 %): above the kill criterion of 175 us, and the price is a second activation format through
+// every producer and consumer of both nets.  Not built; commit "Batched window / halo loads ..." holds the instantiation,
+// profiles/r6k_window_presplit_timing.txt the numbers.)
+template <int WC, int WR, int TC, int TR, int NP = 3>
 __global__ __launch_bounds__(64 * WC * WR, 1) void conv_win_f16s2_kernel(const ConvParams p) {
     constexpr int NT = 64 * WC * WR;
     constexpr int NPL = NP == 3 ? 2 : 1;  // operand planes in use
@@ -116,11 +116,7 @@ __global__ __launch_bounds__(64 * WC * WR, 1) void conv_win_f16s2_kernel(const C
         const int px = (id >> 2) < WH * WW ? (id >> 2) : WH * WW;  // (no branch: out-of-window items land in the spare slot)
         h16x4 hi, lo;
         float* dst = W + px * PS + wq * 2;
-        if constexpr (NP == 3 && PRE) {
-            const f32x4 x = ((rwv >> r) & 1u) ? rw[r] : f32x4{0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x2*>(dst) = f32x2{x[0], x[1]};
-            *reinterpret_cast<f32x2*>(dst + 8) = f32x2{x[2], x[3]};
-        } else if constexpr (NP == 3) {
+        if constexpr (NP == 3) {
             split_f16_planes(((rwv >> r) & 1u) ? rw[r] : f32x4{0.f, 0.f, 0.f, 0.f}, &hi, &lo, amax);
             *reinterpret_cast<h16x4*>(dst) = hi;
             *reinterpret_cast<h16x4*>(dst + 8) = lo;
@@ -292,11 +288,8 @@ static int launch_f16s2_cfg(const ConvParams& p, hipStream_t stream, int cfg_id)
         pe.cfg = cfg_id;
         DFVO_HIP_CHECK(hipEventRecord(pe.e0, stream));
     }
-    static const bool presplit_timing = getenv("DFVO_WIN_PRESPLIT_TIMING") && atoi(getenv("DFVO_WIN_PRESPLIT_TIMING")) != 0;
     if (p.f16_terms == 1)
         hipLaunchKernelGGL((conv_win_f16s2_kernel<WC, WR, TC, TR, 1>), grid, dim3(64 * WC * WR), 0, stream, p);
-    else if (presplit_timing && WC == 2 && TC == 2)  // (the 128-cout shapes only: one extra instantiation pair)
-        hipLaunchKernelGGL((conv_win_f16s2_kernel<WC, WR, TC, TR, 3, (WC == 2 && TC == 2)>), grid, dim3(64 * WC * WR), 0, stream, p);
     else
         hipLaunchKernelGGL((conv_win_f16s2_kernel<WC, WR, TC, TR, 3>), grid, dim3(64 * WC * WR), 0, stream, p);
     DFVO_HIP_CHECK(hipGetLastError());
@@ -324,6 +317,11 @@ static int launch_f16s2(const ConvParams& p, hipStream_t stream, int cfg_id) {
     // resident net waves next to the solver's kernels -- round 3)
     const int ncu = 256;
     auto cost = [&](long long blocks, int rows) { return blocks <= 0 ? (1LL << 60) : ((blocks + ncu - 1) / ncu) * rows; };
+    // (Round 6: the maps too small for the wide tiles -- pyramid level 4, the depth decoder's middle layers: 105-212 tiles -- on
+    // this skeleton's 8- / 12-row x 32-cout tiles instead of the first skeleton's 4-row tile: 27.3-29.5 vs 29.4 us on the level-4
+    // 128 -> 128 layer, 37.4-38.0 vs 42.0 on 96+98 -> 128, every other shape equal -- profiles/r6l_small_map_tiles.txt.  These
+    // launches are chains of 72 taps at ~0.35 us, the L2 latency of a tap's weight fragments with 3-6 MFMAs to cover it; the
+    // tile shape does not change that.  Not adopted.)
     if (p.wf16_cout_pad % 128 == 0) {
         // (an 8-row tile -- 256 accumulator registers -- does not fit: the allocator spills inside the tap loop)
         const long long b3 = f16s2_blocks<2, 2, 2, 3>(p), b2 = f16s2_blocks<2, 2, 2, 2>(p);
