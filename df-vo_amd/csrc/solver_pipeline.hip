@@ -40,13 +40,6 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // ================================================================================================
 // keypoint selection
 // ================================================================================================
-__global__ void k_kp_count(const float* __restrict__ diff, int n, float thre, int* __restrict__ total) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int f = (i < n && diff[i] < thre) ? 1 : 0;
-    const int s = wave_sum_i(f);
-    if ((threadIdx.x & 63) == 0 && s) atomicAdd(total, s);
-}
-
 
 // ------------------------------------------------------------------------------------------------
 // numpy's introselect with the long partition passes run by the whole 256-thread workgroup.
@@ -399,11 +392,27 @@ int enqueue_bestn_flow_kp(BestNBuffers& bb, const float* d_flow, const float* d_
 // one 256-thread block per grid cell: ordered (row-major) compaction of the candidates into LDS, then
 // lane 0 runs numpy's introselect on them (keys carried along with the indices, see kp_select.h); writes
 // the picked local indices in argpartition order.
+// Blocks [cells, cells + KP_CNT_BLOCKS) do not select: they count the pixels of the whole consistency map `mask_map` under the
+// threshold (kp_selection.py:158: mask.sum() < N * 0.1 -> "not enough keypoints") into count_partial[], which k_kp_gather adds up
+// (round 6: was a memset + k_kp_count in front of this launch, two more dependent launches on the path to the first pose).
+constexpr int KP_CNT_BLOCKS = 64;
 __global__ __launch_bounds__(256) void k_kp_cell(const float* __restrict__ diff, int H, int W, int num_row, int num_col,
                                                   float thre, int n_best, int cap, int* __restrict__ cell_count,
                                                   int* __restrict__ cell_sel /*[cells][n_best] (y<<16|x)*/,
-                                                  unsigned short* __restrict__ lidx_all /*[cells][cap]*/, int par) {
+                                                  unsigned short* __restrict__ lidx_all /*[cells][cap]*/, int par,
+                                                  const float* __restrict__ mask_map, int* __restrict__ count_partial) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    if ((int)blockIdx.x >= num_row * num_col) {
+        __shared__ int s_cnt[4];
+        const int b = blockIdx.x - num_row * num_col, n = H * W;
+        int c = 0;
+        for (int i = b * 256 + threadIdx.x; i < n; i += KP_CNT_BLOCKS * 256) c += mask_map[i] < thre ? 1 : 0;
+        c = wave_sum_i(c);
+        if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) count_partial[b] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        return;
+    }
     float* vals = reinterpret_cast<float*>(smem_raw) + 4;  // 4 floats of slack on either side: the 4-wide scans over-read
     unsigned short* tosort = reinterpret_cast<unsigned short*>(vals + cap + 4);
     unsigned short* Lpos = tosort + cap + 2;  // stopper lists of the workgroup-parallel partition (par != 0)
@@ -420,13 +429,30 @@ __global__ __launch_bounds__(256) void k_kp_cell(const float* __restrict__ diff,
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     if (t == 0) s_base = 0;
     __syncthreads();
+    // the cell's values in batches of eight loads per thread (round 6: one load per compaction step left eighteen dependent
+    // round trips to memory in front of the selection of a KITTI-sized cell)
+    constexpr int KB = 8;
+    float vb[KB];
     for (int c0 = 0; c0 < total; c0 += 256) {
         const int e = c0 + t;
+        const int slot = (c0 / 256) % KB;
+        if (slot == 0) {
+#pragma unroll
+            for (int u = 0; u < KB; ++u) {
+                const int eu = c0 + u * 256 + t;
+                vb[u] = 0.f;
+                if (eu < total) {
+                    const int ly = eu / tw, lx = eu - ly * tw;
+                    vb[u] = diff[(size_t)(y0 + ly) * W + x0 + lx];
+                }
+            }
+        }
         bool f = false;
         float v = 0.f;
         if (e < total) {
-            const int ly = e / tw, lx = e - ly * tw;
-            v = diff[(size_t)(y0 + ly) * W + x0 + lx];
+            v = vb[0];
+#pragma unroll
+            for (int u = 1; u < KB; ++u) v = slot == u ? vb[u] : v;
             f = v < thre;
         }
         const unsigned long long b = __ballot(f);
@@ -463,36 +489,48 @@ __global__ __launch_bounds__(256) void k_kp_cell(const float* __restrict__ diff,
     }
 }
 
-// concatenate the cells (row-major cell order), build kp1 (pixel grid) and kp2 = kp1 + flow
+// concatenate the cells (row-major cell order), build kp1 (pixel grid) and kp2 = kp1 + flow.  count_partial (optional): the
+// KP_CNT_BLOCKS partial counts of k_kp_cell's counting blocks, else *total_good is the count.  (Round 6: the cell counts go to
+// LDS in one parallel read and the (cell, k) items are spread over the threads -- the loop over the cells with a dependent
+// global read each was 45 us of one workgroup.)
 __global__ __launch_bounds__(256) void k_kp_gather(const int* __restrict__ cell_count, const int* __restrict__ cell_sel,
                                                     int cells, int n_best, const float* __restrict__ flow, int H, int W,
-                                                    const int* __restrict__ total_good, int min_total, int min_regions,
+                                                    const int* __restrict__ total_good, const int* __restrict__ count_partial,
+                                                    int min_total, int min_regions,
                                                     double* __restrict__ kp1, double* __restrict__ kp2,
                                                     int* __restrict__ info /*[n, good_kp_found, regions]*/) {
-    __shared__ int s_off[1025];
+    __shared__ int s_off[1025], s_cnt[1024], s_good;
     const int t = threadIdx.x;
+    for (int c = t; c < cells; c += 256) s_cnt[c] = cell_count[c];
+    __syncthreads();
     if (t == 0) {
         int acc = 0, regions = 0;
         for (int c = 0; c < cells; c++) {
             s_off[c] = acc;
-            acc += cell_count[c];
-            regions += cell_count[c] != 0;
+            acc += s_cnt[c];
+            regions += s_cnt[c] != 0;
         }
         s_off[cells] = acc;
-        const bool enough = !(*total_good < min_total);     // (mask.sum() < N*0.1) -> fail
+        int good = 0;
+        if (count_partial)
+            for (int b = 0; b < KP_CNT_BLOCKS; ++b) good += count_partial[b];
+        else
+            good = *total_good;
+        const bool enough = !(good < min_total);            // (mask.sum() < N*0.1) -> fail
         const bool diverse = !(regions < min_regions);      // good_region_cnt < rows*cols*0.1 -> fail
         info[0] = (enough && diverse) ? acc : 0;
         info[1] = (enough && diverse) ? 1 : 0;
         info[2] = regions;
+        s_good = (enough && diverse) ? 1 : 0;
     }
     __syncthreads();
-    if (!info[1]) return;
-    for (int c = 0; c < cells; c++) {
-        const int cnt = cell_count[c];
-        if (t < cnt) {
-            const int code = cell_sel[c * n_best + t];
+    if (!s_good) return;
+    for (int i = t; i < cells * n_best; i += 256) {
+        const int c = i / n_best, k = i - c * n_best;
+        if (k < s_cnt[c]) {
+            const int code = cell_sel[i];
             const int y = code >> 16, x = code & 0xffff;
-            const int o = s_off[c] + t;
+            const int o = s_off[c] + k;
             kp1[o * 2] = (double)x;
             kp1[o * 2 + 1] = (double)y;
             kp2[o * 2] = (double)x + (double)flow[(size_t)y * W + x];
@@ -681,10 +719,10 @@ int enqueue_rigid_flow_kp(RigidKpBuffers& rb, const float* d_flow, const float* 
                        rb.cell_sel_uni, rb.lidx, par);
     // both sets in cell order; no "enough keypoints" rules here (the reference asserts a non-empty selection)
     const size_t sc = (size_t)rb.sel_cap * 2;
-    hipLaunchKernelGGL(k_kp_gather, dim3(1), dim3(256), 0, s, rb.cell_count, rb.cell_sel, cells, n_best, d_flow, H, W, rb.zero, 0,
-                       0, rb.kp, rb.kp + sc, rb.info);
+    hipLaunchKernelGGL(k_kp_gather, dim3(1), dim3(256), 0, s, rb.cell_count, rb.cell_sel, cells, n_best, d_flow, H, W, rb.zero,
+                       (const int*)nullptr, 0, 0, rb.kp, rb.kp + sc, rb.info);
     hipLaunchKernelGGL(k_kp_gather, dim3(1), dim3(256), 0, s, rb.cell_count, rb.cell_sel_uni, cells, n_best, d_flow, H, W,
-                       rb.zero, 0, 0, rb.kp + 2 * sc, rb.kp + 3 * sc, rb.info + 4);
+                       rb.zero, (const int*)nullptr, 0, 0, rb.kp + 2 * sc, rb.kp + 3 * sc, rb.info + 4);
     DFVO_HIP_CHECK(hipGetLastError());
     return DFVO_OK;
 }
@@ -744,8 +782,6 @@ int enqueue_local_bestn(TrackerBuffers& tb, const float* d_flow, const float* d_
         DFVO_HIP_CHECK(hipMalloc((void**)&tb.lidx, sizeof(unsigned short) * tb.lidx_cap));
     }
     if (int rc_lds = ensure_dyn_lds((const void*)k_kp_cell, lds)) return rc_lds;
-    DFVO_HIP_CHECK(hipMemsetAsync(tb.kp_total, 0, sizeof(int), s));
-    hipLaunchKernelGGL(k_kp_count, dim3(cdiv(H * W, 256)), dim3(256), 0, s, d_diff, H * W, thre, tb.kp_total);
     const float* d_key = d_diff;  // what the cells threshold and rank: the consistency map, or its ratio to the flow magnitude
     if (score_method == 1) {
         if ((size_t)H * W > tb.ratio_cap) {
@@ -756,13 +792,14 @@ int enqueue_local_bestn(TrackerBuffers& tb, const float* d_flow, const float* d_
         hipLaunchKernelGGL(k_flow_ratio, dim3(cdiv(H * W, 256)), dim3(256), 0, s, d_flow, d_diff, H * W, tb.ratio_map);
         d_key = tb.ratio_map;
     }
-    hipLaunchKernelGGL(k_kp_cell, dim3(cells), dim3(256), lds, s, d_key, H, W, num_row, num_col, thre, n_best, cap,
-                       tb.cell_count, tb.cell_sel, tb.lidx, par);
+    // (the counting blocks read the consistency map itself, whatever the cells rank: kp_selection.py:158)
+    hipLaunchKernelGGL(k_kp_cell, dim3(cells + KP_CNT_BLOCKS), dim3(256), lds, s, d_key, H, W, num_row, num_col, thre, n_best, cap,
+                       tb.cell_count, tb.cell_sel, tb.lidx, par, d_diff, tb.kp_total + 8);
     // thresholds exactly as the python float comparisons: count < N*0.1 ; regions < rows*cols*0.1
     const int min_total = (int)ceil((double)num_bestN * 0.1);
     const int min_regions = (int)ceil((double)cells * 0.1);
     hipLaunchKernelGGL(k_kp_gather, dim3(1), dim3(256), 0, s, tb.cell_count, tb.cell_sel, cells, n_best, d_flow, H, W,
-                       tb.kp_total, min_total, min_regions, tb.kp_ref, tb.kp_cur, tb.kp_info);
+                       tb.kp_total, tb.kp_total + 8, min_total, min_regions, tb.kp_ref, tb.kp_cur, tb.kp_info);
     DFVO_HIP_CHECK(hipGetLastError());
     return DFVO_OK;
 }
@@ -1612,7 +1649,7 @@ void TrackerBuffers::release_kp() {
 int TrackerBuffers::init(hipStream_t rep0, hipStream_t rep1) {
     DFVO_HIP_CHECK(hipMalloc((void**)&mt_state, sizeof(uint32_t) * 640));
     DFVO_HIP_CHECK(hipMalloc((void**)&kp_info, sizeof(int) * 8));
-    DFVO_HIP_CHECK(hipMalloc((void**)&kp_total, sizeof(int) * 8));
+    DFVO_HIP_CHECK(hipMalloc((void**)&kp_total, sizeof(int) * (8 + 64)));  // [0..7] counters, [8..71] k_kp_cell's partial counts
     DFVO_HIP_CHECK(hipMalloc((void**)&pose, sizeof(PoseState)));
     DFVO_HIP_CHECK(hipMalloc((void**)&small, sizeof(double) * 128));
     DFVO_HIP_CHECK(hipMalloc((void**)&scale_out, sizeof(ScaleResult)));
@@ -1662,7 +1699,7 @@ int TrackerBuffers::init_shared(const TrackerBuffers& first) {
     }
     ev_fork = first.ev_fork;
     DFVO_HIP_CHECK(hipMalloc((void**)&kp_info, sizeof(int) * 8));
-    DFVO_HIP_CHECK(hipMalloc((void**)&kp_total, sizeof(int) * 8));
+    DFVO_HIP_CHECK(hipMalloc((void**)&kp_total, sizeof(int) * (8 + 64)));  // [0..7] counters, [8..71] k_kp_cell's partial counts
     DFVO_HIP_CHECK(hipMalloc((void**)&pose, sizeof(PoseState)));
     DFVO_HIP_CHECK(hipMalloc((void**)&small, sizeof(double) * 128));
     DFVO_HIP_CHECK(hipMalloc((void**)&scale_out, sizeof(ScaleResult)));

@@ -167,7 +167,11 @@ def test_reference_kp_selection_under_numpy_1x_reproduces_the_fixture(tmp_path):
     for tag in "abcd":
         assert np.array_equal(gb[tag + "_kp1"], o["bestN_" + tag + "_kp1"]) and np.array_equal(gb[tag + "_kp2"], o["bestN_" + tag + "_kp2"]), tag
     gg = np.load(os.path.join(HERE, "golden", "gric.npz"))  # the reference's gric.py under numpy 1.x: residuals and both scores
-    for k in ("f_res", "f_gric", "h_gric"):
+    # the two GRIC scores bit for bit; the 500 epipolar residuals to a few ulp: they come out of BLAS matmuls, whose summation
+    # order follows the kernel OpenBLAS dispatches for the HOST CPU (this container has run on hosts where all 500 were equal
+    # and on a Xeon where 158 differ by <= 7e-15 relative -- with both scores still equal)
+    assert np.allclose(np.asarray(gg["f_res"]), np.asarray(o["f_res"]), rtol=1e-12, atol=0.0)
+    for k in ("f_gric", "h_gric"):
         assert np.array_equal(np.asarray(gg[k]), np.asarray(o[k])), k
     # (the homography residual goes through np.linalg.inv and 3x3 matmuls: the two environments' BLAS / LAPACK builds differ
     # in the last bit on a quarter of the points -- 7e-15 absolute; the GRIC score above comes out identical)
@@ -192,21 +196,28 @@ def test_reference_e_tracker_under_the_older_libraries_reproduces_the_fixture(tm
     assert r.returncode == 0, r.stderr[-2000:]
     g, o = np.load(os.path.join(HERE, "golden", "e_tracker.npz")), np.load(dst)
     print("second environment: numpy %s scikit-learn %s" % tuple(o["versions"]))
+    # Inlier masks and RandomState bit for bit.  Poses and scales to 1e-9: they pass through the second environment's BLAS / LAPACK
+    # (np.linalg.inv / svd / lstsq, matmuls), whose kernels are picked per HOST CPU -- on the hosts of rounds 3-5 every pose was
+    # bit-equal, on a round-6 Xeon they differ by up to 3e-12 (poses) / 2e-11 (scales) with masks and RandomState still equal
+    # (round 6: tests/test_oracle_second_env.py was the one CPU test that depended on the machine under the container).
+    TOL = 1e-9
     for tag in "abcd":
-        assert np.array_equal(g[tag + "_pose"], o[tag + "_pose"]), tag
+        assert np.abs(g[tag + "_pose"] - o[tag + "_pose"]).max() <= TOL, tag
         assert np.array_equal(g[tag + "_inliers"], o[tag + "_inliers"]), tag
         assert np.array_equal(g[tag + "_rng_after"], o[tag + "_rng_after"]), tag
-        assert abs(float(g[tag + "_scale"]) - float(o[tag + "_scale"])) <= 1e-12 * abs(float(g[tag + "_scale"])), tag
+        assert abs(float(g[tag + "_scale"]) - float(o[tag + "_scale"])) <= TOL * abs(float(g[tag + "_scale"])), tag
     gf = np.load(os.path.join(HERE, "golden", "e_tracker_flow.npz"))  # validity.method 'flow' (mean-displacement gate)
     for tag in "abcd":
-        for k in ("_pose", "_inliers", "_rng_after"):
+        assert np.abs(gf[tag + "_pose"] - o["flow_" + tag + "_pose"]).max() <= TOL, tag
+        for k in ("_inliers", "_rng_after"):
             assert np.array_equal(gf[tag + k], o["flow_" + tag + k]), (tag, k)
     gv = np.load(os.path.join(HERE, "golden", "e_tracker_variants.npz"))  # homo_ratio validity + abs_diff scale RANSAC
     for tag in "abpd":
-        for k in ("_pose", "_inliers", "_rng_after"):
+        assert np.abs(gv[tag + "_pose"] - o["var_" + tag + "_pose"]).max() <= TOL, tag
+        for k in ("_inliers", "_rng_after"):
             assert np.array_equal(gv[tag + k], o["var_" + tag + k]), (tag, k)
         a, b = float(gv[tag + "_scale"]), float(o["var_" + tag + "_scale"])
-        assert abs(a - b) <= 1e-12 * max(1.0, abs(a)), (tag, a, b)
+        assert abs(a - b) <= TOL * max(1.0, abs(a)), (tag, a, b)
     gs = np.load(os.path.join(HERE, "golden", "sampled_kp.npz"))  # KeypointSampler.generate_kp_samples + sampled_kp
     for tag in "abc":
         for k in ("_idx", "_kp1", "_kp2"):
