@@ -140,6 +140,7 @@ SIGNATURES = {
     "dfvo_lanczos_coeffs": (_i, [_i, _i, _vp, _vp, _i, _ip]),
     "dfvo_resize_lanczos_u8": (_i, [_vp, _i, _i, _vp, _i, _i, _vp]),
     "dfvo_resize_linear_u8": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp]),
+    "dfvo_read_image_tail_u8": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "dfvo_resize_bilinear": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _i, _i, _vp]),
     "dfvo_flownet_create": (_i, [_i, _i, _vp, C.POINTER(_vp)]),
     "dfvo_flownet_destroy": (None, [_vp]),

@@ -414,6 +414,13 @@ int dfvo_resize_lanczos_u8(const uint8_t* d_src, int H, int W, uint8_t* d_dst, i
 int dfvo_resize_linear_u8(const uint8_t* d_src, int H, int W, int C, uint8_t* d_dst, int out_h, int out_w, void* stream) {
     return enqueue_resize_linear_u8(d_src, H, W, C, d_dst, out_h, out_w, (hipStream_t)stream);
 }
+int dfvo_read_image_tail_u8(const uint8_t* d_decoded, int img_h, int img_w, int bgr, int y0, int y1, int x0, int x1, uint8_t* d_dst,
+                            int out_h, int out_w, void* stream) {
+    DFVO_ARG_CHECK(d_decoded && d_dst && img_h > 0 && img_w > 0 && 0 <= y0 && y0 < y1 && y1 <= img_h && 0 <= x0 && x0 < x1 && x1 <= img_w,
+                   "dfvo_read_image_tail_u8: crop outside the frame");
+    return enqueue_resize_linear_u8(d_decoded + ((size_t)y0 * img_w + x0) * 3, y1 - y0, x1 - x0, 3, d_dst, out_h, out_w,
+                                    (hipStream_t)stream, img_w, bgr);
+}
 double dfvo_depthnet_last_flops(const dfvo_depthnet* n) { return n ? n->net.flops_last : 0.0; }
 int dfvo_depthnet_sync(dfvo_depthnet* n) {
     DFVO_ARG_CHECK(n, "null net");

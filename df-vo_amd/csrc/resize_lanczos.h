@@ -20,7 +20,8 @@ struct LanczosResizer {
 };
 
 // cv2.resize(img, (ow, oh)) for uint8 [H, W, C] (INTER_LINEAR, OpenCV 3.4.3's 11-bit fixed point), utils.py:51
-int enqueue_resize_linear_u8(const uint8_t* d_src, int H, int W, int C, uint8_t* d_dst, int oh, int ow, hipStream_t s);
+int enqueue_resize_linear_u8(const uint8_t* d_src, int H, int W, int C, uint8_t* d_dst, int oh, int ow, hipStream_t s, int pitch = 0,
+                             int rev = 0);  // pitch: pixels per source row (0 = W); rev: reverse the channel order (BGR -> RGB)
 
 int lanczos_coeffs_host(int in_size, int out_size, int* bounds, int* coeffs, int coeff_cap, int* ksize);
 

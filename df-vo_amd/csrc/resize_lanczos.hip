@@ -184,16 +184,21 @@ __device__ __forceinline__ void linear_coef_u8(int d, double scale, int* s_out, 
     *c1 = (int)rintf(__fmul_rn(f, 2048.f));
 }
 
-__global__ __launch_bounds__(256) void k_resize_linear_u8(const uint8_t* __restrict__ src, int H, int W, int C,
+// pitch: pixels per source row (a crop window of a wider frame reads with the frame's pitch); rev: output channel c is source
+// channel C - 1 - c (cv2.cvtColor(img, COLOR_BGR2RGB) of read_image, utils.py:45, folded into the read)
+__global__ __launch_bounds__(256) void k_resize_linear_u8(const uint8_t* __restrict__ src, int H, int W, int C, int pitch, int rev,
                                                            uint8_t* __restrict__ dst, int oh, int ow, double scale_x,
                                                            double scale_y, int area2) {
     const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y * blockDim.y + threadIdx.y;
     if (dx >= ow || dy >= oh) return;
     uint8_t* o = dst + ((size_t)dy * ow + dx) * C;
     if (area2) {
-        const uint8_t* p = src + ((size_t)(2 * dy) * W + 2 * dx) * C;
-        const size_t row = (size_t)W * C;
-        for (int c = 0; c < C; ++c) o[c] = (uint8_t)((p[c] + p[C + c] + p[row + c] + p[row + C + c] + 2) >> 2);
+        const uint8_t* p = src + ((size_t)(2 * dy) * pitch + 2 * dx) * C;
+        const size_t row = (size_t)pitch * C;
+        for (int c = 0; c < C; ++c) {
+            const int sc = rev ? C - 1 - c : c;
+            o[c] = (uint8_t)((p[sc] + p[C + sc] + p[row + sc] + p[row + C + sc] + 2) >> 2);
+        }
         return;
     }
     int sx, a0, a1, sy, b0, b1;
@@ -204,21 +209,24 @@ __global__ __launch_bounds__(256) void k_resize_linear_u8(const uint8_t* __restr
     linear_coef_u8(dy, scale_y, &sy, &b0, &b1, &f);
     const int y0 = sy < 0 ? 0 : (sy < H ? sy : H - 1), y1 = sy + 1 < 0 ? 0 : (sy + 1 < H ? sy + 1 : H - 1);
     const int sx1 = sx + 1 < W ? sx + 1 : sx;
-    const uint8_t *r0 = src + (size_t)y0 * W * C, *r1 = src + (size_t)y1 * W * C;
+    const uint8_t *r0 = src + (size_t)y0 * pitch * C, *r1 = src + (size_t)y1 * pitch * C;
     for (int c = 0; c < C; ++c) {
-        const int h0 = r0[sx * C + c] * a0 + r0[sx1 * C + c] * a1;
-        const int h1 = r1[sx * C + c] * a0 + r1[sx1 * C + c] * a1;
+        const int sc = rev ? C - 1 - c : c;
+        const int h0 = r0[sx * C + sc] * a0 + r0[sx1 * C + sc] * a1;
+        const int h1 = r1[sx * C + sc] * a0 + r1[sx1 * C + sc] * a1;
         o[c] = (uint8_t)((((b0 * (h0 >> 4)) >> 16) + ((b1 * (h1 >> 4)) >> 16) + 2) >> 2);
     }
 }
 
-int enqueue_resize_linear_u8(const uint8_t* d_src, int H, int W, int C, uint8_t* d_dst, int oh, int ow, hipStream_t s) {
-    DFVO_ARG_CHECK(d_src && d_dst && H > 0 && W > 0 && oh > 0 && ow > 0 && C >= 1 && C <= 4, "resize_linear_u8: bad argument");
+int enqueue_resize_linear_u8(const uint8_t* d_src, int H, int W, int C, uint8_t* d_dst, int oh, int ow, hipStream_t s, int pitch,
+                             int rev) {
+    if (pitch <= 0) pitch = W;
+    DFVO_ARG_CHECK(d_src && d_dst && H > 0 && W > 0 && oh > 0 && ow > 0 && C >= 1 && C <= 4 && pitch >= W, "resize_linear_u8: bad argument");
     volatile double inv_x = (double)ow / (double)W, inv_y = (double)oh / (double)H;  // cv::resize: inv_scale = dsize / ssize
     const double scale_x = 1.0 / inv_x, scale_y = 1.0 / inv_y;                       // hal::resize: scale = 1 / inv_scale
     const int area2 = (std::fabs(scale_x - 2.0) < 2.220446049250313e-16 && std::fabs(scale_y - 2.0) < 2.220446049250313e-16) ? 1 : 0;
-    hipLaunchKernelGGL(k_resize_linear_u8, dim3(cdiv(ow, 64), cdiv(oh, 4)), dim3(64, 4), 0, s, d_src, H, W, C, d_dst, oh, ow,
-                       scale_x, scale_y, area2);
+    hipLaunchKernelGGL(k_resize_linear_u8, dim3(cdiv(ow, 64), cdiv(oh, 4)), dim3(64, 4), 0, s, d_src, H, W, C, pitch, rev ? 1 : 0, d_dst,
+                       oh, ow, scale_x, scale_y, area2);
     DFVO_HIP_CHECK(hipGetLastError());
     return DFVO_OK;
 }

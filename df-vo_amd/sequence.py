@@ -141,21 +141,23 @@ def frames_to_device(frames_u8):
     return [torch.from_numpy(np.ascontiguousarray(f)).cuda() for f in frames_u8]
 
 
-def image_to_device(img_u8, h, w, crop=None):
-    """the tail of read_image (/root/reference/libs/general/utils.py:46-51) on the device: the decoded RGB frame is uploaded
-    as it is, optionally cropped ([[y0, y1], [x0, x1]] fractions) and resized to the configured (h, w) with cv2.resize's
-    default 8-bit INTER_LINEAR arithmetic (dfvo_resize_linear_u8).  Returns a device uint8 tensor [h, w, 3]."""
+def image_to_device(img_u8, h, w, crop=None, bgr=False):
+    """read_image (/root/reference/libs/general/utils.py:44-51) behind the decoder, on the device: the decoded frame is uploaded
+    as it is -- bgr=True: as cv2.imread returns it, the BGR -> RGB conversion of utils.py:45 is folded into the read --,
+    cropped ([[y0, y1], [x0, x1]] fractions, utils.py:46-50) and resized to the configured (h, w) with cv2.resize's default
+    8-bit INTER_LINEAR arithmetic, in ONE launch (dfvo_read_image_tail_u8).  Returns a device uint8 tensor [h, w, 3] (RGB)."""
     img = np.ascontiguousarray(img_u8)
+    assert img.ndim == 3 and img.shape[2] == 3 and img.dtype == np.uint8
+    ih, iw = img.shape[:2]
+    y0, y1, x0, x1 = 0, ih, 0, iw
     if crop is not None:
-        ih, iw = img.shape[:2]
         y0, y1 = int(ih * crop[0][0]), int(ih * crop[0][1])
         x0, x1 = int(iw * crop[1][0]), int(iw * crop[1][1])
-        img = np.ascontiguousarray(img[y0:y1, x0:x1])
     src = torch.from_numpy(img).cuda()
-    dst = torch.empty((h, w, img.shape[2]), dtype=torch.uint8, device="cuda")
+    dst = torch.empty((h, w, 3), dtype=torch.uint8, device="cuda")
     stream = torch.cuda.current_stream()
-    capi.check(capi.lib().dfvo_resize_linear_u8(src.data_ptr(), img.shape[0], img.shape[1], img.shape[2], dst.data_ptr(), h, w,
-                                                stream.cuda_stream))
+    capi.check(capi.lib().dfvo_read_image_tail_u8(src.data_ptr(), ih, iw, 1 if bgr else 0, y0, y1, x0, x1, dst.data_ptr(), h, w,
+                                                  stream.cuda_stream))
     # Ordering contract for device frames handed to TrackingPipeline.enqueue_nets / set_ref_image: the pipeline reads them
     # on its OWN non-blocking streams, which are not ordered behind torch's current stream -- a frame must be complete
     # before it is handed over.  The upload + resize are therefore drained here (frames_to_device's .cuda() copy is

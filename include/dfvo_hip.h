@@ -132,6 +132,13 @@ int dfvo_lanczos_coeffs(int in_size, int out_size, int* h_bounds, int* h_coeffs,
  * fixed-point bilinear arithmetic (exact 2 x 2 decimation: its (a + b + c + d + 2) >> 2 area path).  Asynchronous on
  * `stream`. */
 int dfvo_resize_linear_u8(const uint8_t* d_src, int H, int W, int C, uint8_t* d_dst, int out_h, int out_w, void* stream);
+/* Everything of read_image (libs/general/utils.py:44-51) behind the decoder, in one launch on the decoded frame as cv2.imread
+ * left it: cv2.cvtColor(img, COLOR_BGR2RGB) (bgr != 0: channel order reversed while reading), the crop img[y0:y1, x0:x1]
+ * (pass 0, img_h, 0, img_w for none; the caller evaluates int(img_h * crop[0][0]) ... as utils.py:47-49 does) and
+ * cv2.resize(img, (out_w, out_h)) with dfvo_resize_linear_u8's arithmetic.  d_decoded uint8 [img_h, img_w, 3], d_dst uint8
+ * [out_h, out_w, 3].  PNG / JPEG entropy decoding stays on the host (bit-serial). */
+int dfvo_read_image_tail_u8(const uint8_t* d_decoded, int img_h, int img_w, int bgr, int y0, int y1, int x0, int x1, uint8_t* d_dst,
+                            int out_h, int out_w, void* stream);
 int dfvo_resize_bilinear(const float* d_src, int N, int H, int W, int C, float* d_dst, int Ho, int Wo,
                          int align_corners, void* stream);
 

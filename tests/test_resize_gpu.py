@@ -50,3 +50,11 @@ def test_image_to_device_is_read_image_after_decoding(gpu):
     y0, y1, x0, x1 = int(370 * 0.2), int(370 * 1.0), int(1226 * 0.05), int(1226 * 0.95)
     assert np.array_equal(got, cv2.resize(np.ascontiguousarray(img[y0:y1, x0:x1]), (640, 192)))
     assert np.array_equal(smod.image_to_device(img, 192, 640).cpu().numpy(), cv2.resize(img, (640, 192)))
+    # the frame as cv2.imread leaves it (BGR): cvtColor + crop + resize in the one launch, crop read with the frame's pitch
+    bgr = np.ascontiguousarray(img[..., ::-1])
+    got = smod.image_to_device(bgr, 192, 640, crop, bgr=True).cpu().numpy()
+    assert np.array_equal(got, cv2.resize(np.ascontiguousarray(img[y0:y1, x0:x1]), (640, 192)))
+    assert np.array_equal(smod.image_to_device(bgr, 370, 1226, bgr=True).cpu().numpy(), img)     # same size: cv2.resize is the identity
+    half = resize_case(3, 376, 1240)
+    assert np.array_equal(smod.image_to_device(np.ascontiguousarray(half[..., ::-1]), 188, 620, bgr=True).cpu().numpy(),
+                          cv2.resize(half, (620, 188)))                                                   # INTER_AREA's 2 x 2 fast path

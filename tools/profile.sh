@@ -3,7 +3,7 @@
 # (one counter per run; counter collection is never combined with the sys/hip/hsa trace domains)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-TAG=${TAG:-r5}
+TAG=${TAG:-r6}
 mkdir -p $R/gpurun_out
 CMD="python $R/bench.py --no-cpu-baseline --no-roofline --no-exact-leg --no-other-legs --steps 20 --warmup 5"
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -o r -- $CMD > /tmp/b_stats.log 2>&1

@@ -1,12 +1,12 @@
 #!/bin/bash
-# End-of-round records on the GPU box (TAG=r5 bash tools/round_records.sh; ~20 GPU-minutes): full -m gpu suite with the
+# End-of-round records on the GPU box (TAG=r6 bash tools/round_records.sh; ~20 GPU-minutes): full -m gpu suite with the
 # ANCHOR / FROM-IMAGES accounting lines, smoke, default bench, BASELINE configs 3 / 4 / 5, the CPU-baseline protocol of
 # BASELINE.md section 4 (20 pairs after 3 warm-up), the config-3 job on 2 / 3 ranks sharing this box's one device, the flow
 # net's error against the float64 anchor per level and per operator.  Outputs under gpurun_out/${TAG}m_*: copy what is
 # cited into profiles/.  (tools/profile.sh takes the rocprofv3 records, tools/quick_check.sh is the 3-minute check of a
 # kernel change.)
 R=$GRAFT_REPO_ROOT
-TAG=${TAG:-r5}
+TAG=${TAG:-r6}
 mkdir -p $R/gpurun_out
 cd $R
 timeout 1500 python -m pytest tests -m gpu -q -s 2>&1 | grep -E "ANCHOR|FROM-IMAGES|F16-MODE|f16x3 range|passed|failed|FAILED|Error" > gpurun_out/${TAG}m_tests.txt
