@@ -159,7 +159,7 @@ def test_committed_profile_feeds_the_hbm_roofline_entry():
     ks = bench.committed_streaming_kernels()
     assert ks and all(0.0 < k["frac"] < 1.0 and k["mb_per_dispatch"] >= 4.0 for k in ks)
     names = {k["kernel"] for k in ks}
-    assert {"k_warp", "k_correlation_rt", "k_deconv_dw4"} <= names, names
+    assert {"k_warp", "k_correlation_rt", "k_deconv_dw4_blk"} <= names, names
 
 
 def test_other_legs_need_a_gpu_and_never_break_the_line(monkeypatch):
