@@ -296,10 +296,14 @@ def test_frame_session_returns_what_the_plain_entry_points_return(gpu, tmp_path,
     cfg = full_cfg(h, w, flow_path, depth_dir)
     cfg["dfvo_hip"] = {"conv_precision": precision}
     runs = {}
+    capi = importlib.import_module("df-vo_amd.capi")
     for sess in ("0", "1"):
         monkeypatch.setenv("DFVO_SESSION", sess)
+        before = capi.lib().dfvo_get_conv_precision()
         mirrors = _build_mirrors(cfg, seq["K"])
         assert (mirrors[0].session is not None) == (sess == "1") and mirrors[0].conv_precision == precision
+        # (initialize_models sets the process-wide packing precision for ITS nets and puts it back)
+        assert capi.lib().dfvo_get_conv_precision() == before
         rec = []
         poses, modes = _main_loop(cfg, seq, n, h, w, mirrors, record=rec)
         runs[sess] = (poses, modes, rec, mirrors)
