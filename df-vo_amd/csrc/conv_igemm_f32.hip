@@ -615,9 +615,12 @@ void conv_pack_head_weights(const float* w, int cout, int c0, int c1, int k, con
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(4))) const f32x4 cf32x4;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-template <int KS, int CO>
+// PY: output rows per thread (tile = 16 PY rows x 16 columns).  2 on the large maps; 1 (round 6) where the 32-row tiles leave most
+// of the chip idle -- level 3: 105 workgroups, level 4: 26, levels 5 / 6: 7 / 2 --: twice the workgroups, half the tap chain per
+// thread.  A pixel's sum runs over (chunk, kx, channel group, ky) in the same order either way: bit-identical.
+template <int KS, int CO, int PY = 2>
 __global__ __launch_bounds__(256) void conv_head_f32_kernel(const ConvParams p) {
-    constexpr int PY = 2, TW = 16, TH = 16 * PY, WH = TH + KS - 1, WW = TW + KS - 1, PS = 12;
+    constexpr int TW = 16, TH = 16 * PY, WH = TH + KS - 1, WW = TW + KS - 1, PS = 12;
     constexpr int WIN = WH * WW * PS;
     constexpr int W_ITEMS = WH * WW * 2;  // (pixel, half of the 8-channel chunk)
     constexpr int W_CNT = (W_ITEMS + 255) / 256;
@@ -940,7 +943,10 @@ static int launch_win3(const ConvParams& p, hipStream_t stream, int cfg_id) {
 
 template <int KS, int CO>
 static int launch_head(const ConvParams& p, hipStream_t stream, int cfg_id) {
-    const int tiles = p.N * ((p.Ho + 31) / 32) * ((p.Wo + 15) / 16);
+    static const bool py1_ok = !(getenv("DFVO_HEAD_PY1") && atoi(getenv("DFVO_HEAD_PY1")) == 0);
+    const int tiles2 = p.N * ((p.Ho + 31) / 32) * ((p.Wo + 15) / 16);
+    const bool py1 = py1_ok && tiles2 < 256;  // (one workgroup per CU is the first round; below that the chain per thread is the launch)
+    const int tiles = py1 ? p.N * ((p.Ho + 15) / 16) * ((p.Wo + 15) / 16) : tiles2;
     dim3 grid((unsigned)tiles, 1, 1);
     ConvProfEntry pe;
     if (g_prof) {
@@ -949,7 +955,10 @@ static int launch_head(const ConvParams& p, hipStream_t stream, int cfg_id) {
         pe.cfg = cfg_id;
         DFVO_HIP_CHECK(hipEventRecord(pe.e0, stream));
     }
-    hipLaunchKernelGGL((conv_head_f32_kernel<KS, CO>), grid, dim3(256), 0, stream, p);
+    if (py1)
+        hipLaunchKernelGGL((conv_head_f32_kernel<KS, CO, 1>), grid, dim3(256), 0, stream, p);
+    else
+        hipLaunchKernelGGL((conv_head_f32_kernel<KS, CO, 2>), grid, dim3(256), 0, stream, p);
     DFVO_HIP_CHECK(hipGetLastError());
     if (g_prof) {
         DFVO_HIP_CHECK(hipEventRecord(pe.e1, stream));

@@ -133,6 +133,10 @@ __global__ __launch_bounds__(64 * WC * WR, 2) void conv_win_f16s_kernel(const Co
     // (9 taps = 3 turns of the ring: the stage of a tap is a compile-time constant and nothing is copied at the chunk end);
     // TC == 2 keeps two stages, one tap ahead (a third would spill: 128 accumulator + 48 ring + 16 pixel-fragment +
     // window staging registers)
+    // (Round 6: a ring of NINE for the one shape left on this skeleton -- a whole chunk of fragments in registers, tap t of chunk
+    // c + 1 requested behind the MFMAs of tap t of chunk c; 183 VGPRs, no scratch -- measured SLOWER on every small-map layer it
+    // serves: level-4 128 -> 128 29.4 -> 33.6 us, 96+98 -> 128 42.0 -> 48.1, 128 -> 64 25.4 -> 29.1 (profiles/r6q_heads_ring.txt
+    // against r6l_small_map_tiles.txt).  Those launches are not waiting for their weight fragments; reverted.)
     constexpr int R = TC == 1 ? 3 : 2;
     h16x8 wa[R][TC][2];
     auto load_w = [&](int stage, int tap, int c) {
