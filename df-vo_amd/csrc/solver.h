@@ -43,7 +43,11 @@ int enqueue_find_essential(RansacWorkspace& w, const double* d_pts1, const doubl
                            double ppx, double ppy, double prob, double threshold, int max_iters, hipStream_t s);
 int enqueue_find_essential_batch(RansacWorkspace* w, const double* const* d_pts1, const double* const* d_pts2, int nrep,
                                  int n, double focal, double ppx, double ppy, double prob, double threshold,
-                                 int max_iters, hipStream_t s);
+                                 int max_iters, hipStream_t s, const unsigned long long* rng_pre = nullptr);
+// the first chunk's five-point subsets ahead of the call (a function of the point count alone): into w0.idx, the sampler's state
+// behind them into *d_rng_pre; hand d_rng_pre to enqueue_find_essential_batch
+int enqueue_e_subsets_prefetch(RansacWorkspace& w0, const int* d_n, int n_bound, int max_iters, unsigned long long* d_rng_pre,
+                               hipStream_t s);
 int enqueue_find_homography(RansacWorkspace& w, const double* d_pts1, const double* d_pts2, int n, double thr,
                             int max_iters, double confidence, hipStream_t s, const int* d_n = nullptr);
 struct PoseState;

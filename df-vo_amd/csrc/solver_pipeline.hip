@@ -1649,7 +1649,7 @@ void TrackerBuffers::release_kp() {
 int TrackerBuffers::init(hipStream_t rep0, hipStream_t rep1) {
     DFVO_HIP_CHECK(hipMalloc((void**)&mt_state, sizeof(uint32_t) * 640));
     DFVO_HIP_CHECK(hipMalloc((void**)&kp_info, sizeof(int) * 8));
-    DFVO_HIP_CHECK(hipMalloc((void**)&kp_total, sizeof(int) * (8 + 64)));  // [0..7] counters, [8..71] k_kp_cell's partial counts
+    DFVO_HIP_CHECK(hipMalloc((void**)&kp_total, sizeof(int) * (8 + 64 + 2)));  // [0..7] counters (5, 6: the flow gate), [8..71] k_kp_cell's partial counts, [72..73] the five-point sampler's state behind its prefetched subsets
     DFVO_HIP_CHECK(hipMalloc((void**)&pose, sizeof(PoseState)));
     DFVO_HIP_CHECK(hipMalloc((void**)&small, sizeof(double) * 128));
     DFVO_HIP_CHECK(hipMalloc((void**)&scale_out, sizeof(ScaleResult)));
@@ -1699,7 +1699,7 @@ int TrackerBuffers::init_shared(const TrackerBuffers& first) {
     }
     ev_fork = first.ev_fork;
     DFVO_HIP_CHECK(hipMalloc((void**)&kp_info, sizeof(int) * 8));
-    DFVO_HIP_CHECK(hipMalloc((void**)&kp_total, sizeof(int) * (8 + 64)));  // [0..7] counters, [8..71] k_kp_cell's partial counts
+    DFVO_HIP_CHECK(hipMalloc((void**)&kp_total, sizeof(int) * (8 + 64 + 2)));  // [0..7] counters (5, 6: the flow gate), [8..71] k_kp_cell's partial counts, [72..73] the five-point sampler's state behind its prefetched subsets
     DFVO_HIP_CHECK(hipMalloc((void**)&pose, sizeof(PoseState)));
     DFVO_HIP_CHECK(hipMalloc((void**)&small, sizeof(double) * 128));
     DFVO_HIP_CHECK(hipMalloc((void**)&scale_out, sizeof(ScaleResult)));
@@ -1811,6 +1811,16 @@ int enqueue_pose_h_part(TrackerBuffers& tb, int n_bound, const PoseConfig& cfg, 
     }
     hipLaunchKernelGGL(k_pose_state_init, dim3(cdiv(tb.kp_cap, 256)), dim3(256), 0, sh, tb.pose, tb.kp_info,
                        tb.best_inliers, tb.kp_cap);
+    // the five-point sampler's first chunk of subsets depends on the keypoint COUNT only: drawn here, beside the homography
+    // chain, instead of inside the RandomState-ordered chain (round 6; consumed by enqueue_pose_e_part through tb.e_pre_*)
+    tb.e_pre_iters = 0;
+    static const bool subsets_ahead = !(getenv("DFVO_E_SUBSETS_AHEAD") && atoi(getenv("DFVO_E_SUBSETS_AHEAD")) == 0);  // (0: A/B hook)
+    if (subsets_ahead && cfg.max_iters >= 1) {
+        int rc_pre = enqueue_e_subsets_prefetch(tb.ws_rep[0], tb.kp_info, n_bound, cfg.max_iters,
+                                                reinterpret_cast<unsigned long long*>(tb.kp_total + 72), sh);
+        if (rc_pre != DFVO_OK) return rc_pre;
+        tb.e_pre_iters = cfg.max_iters;
+    }
     DFVO_HIP_CHECK(hipEventRecord(tb.ev_start, sh));
     if (tb.mark(0, sh) != DFVO_OK) return DFVO_ERR_HIP;
     if (cfg.validity == 1) {  // "flow": no homography; the mean displacement decides whether the pair is tracked
@@ -1868,8 +1878,11 @@ int enqueue_pose_e_part(TrackerBuffers& tb, int n_host, const PoseConfig& cfg, h
             pas[rep] = tb.pa + (size_t)rep * 2 * cap;
             pbs[rep] = tb.pb + (size_t)rep * 2 * cap;
         }
+        // (the first chunk's subsets were drawn by the homography half for this keypoint count, if it ran with this budget)
+        const unsigned long long* rng_pre = tb.e_pre_iters == cfg.max_iters ? reinterpret_cast<const unsigned long long*>(tb.kp_total + 72) : nullptr;
+        tb.e_pre_iters = 0;
         rc = enqueue_find_essential_batch(tb.ws_rep, pas, pbs, cfg.repeat, n_host, cfg.fx, cfg.cx, cfg.cy, 0.99,
-                                          cfg.reproj_thre, cfg.max_iters, sr);
+                                          cfg.reproj_thre, cfg.max_iters, sr, rng_pre);
         if (rc != DFVO_OK) return rc;
         if (tb.mark(4, sr) != DFVO_OK) return DFVO_ERR_HIP;
         if (by_flow) {

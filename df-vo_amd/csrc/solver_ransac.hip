@@ -87,12 +87,14 @@ struct EBatch {
     ERep r[MAX_E_BATCH];
 };
 
-__global__ void k_e_init_normalise(const EBatch B, int n, int max_iters, double a, double bx, double by) {
+// rng_pre (optional): the subsets of the first chunk were drawn ahead (k_e_subsets_pre): the stream continues behind them
+__global__ void k_e_init_normalise(const EBatch B, int n, int max_iters, double a, double bx, double by,
+                                   const unsigned long long* __restrict__ rng_pre) {
     const ERep& R = B.r[blockIdx.y];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
         RansacState* st = R.state;
-        st->rng_state = 0xffffffffffffffffULL;
+        st->rng_state = rng_pre ? *rng_pre : 0xffffffffffffffffULL;
         st->niters = max_iters > 1 ? max_iters : 1;
         st->iter = 0;
         st->max_good = 0;
@@ -107,6 +109,34 @@ __global__ void k_e_init_normalise(const EBatch B, int n, int max_iters, double 
     R.norm_a[i * 2 + 1] = R.pts1[i * 2 + 1] * a + by;
     R.norm_b[i * 2] = R.pts2[i * 2] * a + bx;
     R.norm_b[i * 2 + 1] = R.pts2[i * 2 + 1] * a + by;
+}
+
+// The FIRST chunk's subsets ahead of the call (round 6).  cv::RANSAC seeds its RNG with the same constant in every call and the
+// five-point sampler has no data-dependent subset check: the indices are a function of the point COUNT alone.  So they are drawn
+// as soon as the keypoint count exists -- on the stream of the RandomState-independent half, beside the homography chain --
+// instead of as the fourth dependent launch of the RandomState-ordered chain (50 us of one lane on the path to every pose).
+// idx [it1][5]; *rng_out = the stream's state behind them (k_e_init_normalise hands it to every problem of the batch).
+__global__ void k_e_subsets_pre(int* __restrict__ idx, unsigned long long* __restrict__ rng_out, const int* __restrict__ d_n, int n_arg,
+                                int it1) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int count = d_n ? *d_n : n_arg;
+    sm::CvRng rng;
+    rng.state = 0xffffffffffffffffULL;
+    if (count >= 5)
+        for (int it = 0; it < it1; ++it) {
+            int* id = idx + it * 5;
+            for (int i = 0; i < 5;) {
+                int v, j;
+                for (;;) {
+                    v = id[i] = sm::cvrng_uniform(rng, 0, count);
+                    for (j = 0; j < i; j++)
+                        if (v == id[j]) break;
+                    if (j == i) break;
+                }
+                i++;
+            }
+        }
+    *rng_out = rng.state;
 }
 
 // one lane: subsets of iterations [it0, it1) from the sequential cv::RNG stream, shared by the batch
@@ -322,9 +352,11 @@ void RansacWorkspace::release() {
 
 // batch of `nrep` problems (workspaces w[r], inputs d_pts1[r]/d_pts2[r], all with n correspondences).
 // Results per problem: w[r].state (RansacState), w[r].out[0..8] = E, w[r].mask[n]
+// rng_pre (optional): enqueue_e_subsets_prefetch(w[0], ...) ran for this call's point count: the first chunk's subsets are in
+// w[0].idx already, *rng_pre is the sampler's state behind them.
 int enqueue_find_essential_batch(RansacWorkspace* w, const double* const* d_pts1, const double* const* d_pts2, int nrep,
                                  int n, double focal, double ppx, double ppy, double prob, double threshold,
-                                 int max_iters, hipStream_t s) {
+                                 int max_iters, hipStream_t s, const unsigned long long* rng_pre) {
     DFVO_ARG_CHECK(n >= 0 && max_iters >= 1 && nrep >= 1 && nrep <= MAX_E_BATCH, "find_essential: bad sizes");
     EBatch B;
     memset(&B, 0, sizeof(B));
@@ -351,7 +383,7 @@ int enqueue_find_essential_batch(RansacWorkspace* w, const double* const* d_pts1
     threshold /= (focal + focal) / 2;
     const float thr2 = (float)(threshold * threshold);
     const unsigned R = (unsigned)nrep;
-    hipLaunchKernelGGL(k_e_init_normalise, dim3(cdiv(n > 0 ? n : 1, 256), R), dim3(256), 0, s, B, n, max_iters, a, bx, by);
+    hipLaunchKernelGGL(k_e_init_normalise, dim3(cdiv(n > 0 ? n : 1, 256), R), dim3(256), 0, s, B, n, max_iters, a, bx, by, rng_pre);
     if (n >= 5) {  // count < modelPoints: no model (state->found stays 0)
         // count == modelPoints would run the kernel once on all points; DF-VO never gets there (N >= 10
         // is required upstream), treat it through the generic loop with the single possible subset order.
@@ -361,7 +393,7 @@ int enqueue_find_essential_batch(RansacWorkspace* w, const double* const* d_pts1
             const int it0 = cb[c], it1 = cb[c + 1];
             if (it1 <= it0) continue;
             const int nh = it1 - it0;
-            hipLaunchKernelGGL(k_e_subsets, dim3(1), dim3(1), 0, s, B, n, it0, it1);
+            if (!(c == 0 && rng_pre)) hipLaunchKernelGGL(k_e_subsets, dim3(1), dim3(1), 0, s, B, n, it0, it1);
             hipLaunchKernelGGL(k_e_stage1, dim3(cdiv(nh, E_STAGE1_LANES), R), dim3(E_STAGE1_LANES), 0, s, B, it0, it1);
             // polynomial + stage 3: one root per lane (round 4; one lane per hypothesis + a separate stage-3 launch before:
             // 1.10 -> 0.70 ms per pair, profiles/r4b_kernel_stats_poly_*.csv)
@@ -377,7 +409,19 @@ int enqueue_find_essential_batch(RansacWorkspace* w, const double* const* d_pts1
 
 int enqueue_find_essential(RansacWorkspace& w, const double* d_pts1, const double* d_pts2, int n, double focal,
                            double ppx, double ppy, double prob, double threshold, int max_iters, hipStream_t s) {
-    return enqueue_find_essential_batch(&w, &d_pts1, &d_pts2, 1, n, focal, ppx, ppy, prob, threshold, max_iters, s);
+    return enqueue_find_essential_batch(&w, &d_pts1, &d_pts2, 1, n, focal, ppx, ppy, prob, threshold, max_iters, s, nullptr);
+}
+
+int enqueue_e_subsets_prefetch(RansacWorkspace& w0, const int* d_n, int n_bound, int max_iters, unsigned long long* d_rng_pre,
+                               hipStream_t s) {
+    DFVO_ARG_CHECK(d_rng_pre && max_iters >= 1 && n_bound >= 0, "e_subsets_prefetch: bad argument");
+    int rc = w0.ensure(n_bound > 8 ? n_bound : 8, max_iters);
+    if (rc != DFVO_OK) return rc;
+    int cb[4];
+    chunk_bounds(max_iters, cb);
+    hipLaunchKernelGGL(k_e_subsets_pre, dim3(1), dim3(1), 0, s, w0.idx, d_rng_pre, d_n, n_bound, cb[1]);
+    DFVO_HIP_CHECK(hipGetLastError());
+    return DFVO_OK;
 }
 
 // ================================================================================================

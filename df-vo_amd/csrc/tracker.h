@@ -121,6 +121,7 @@ struct TrackerBuffers {
     uint32_t* mt_state = nullptr;  // numpy RandomState: key[624], pos
     int* kp_info = nullptr;        // [n, good_kp_found, regions]
     int* kp_total = nullptr;
+    int e_pre_iters = 0;  // > 0: enqueue_pose_h_part drew the five-point sampler's first chunk ahead, for this iteration budget
     PoseState* pose = nullptr;
     double* small = nullptr;
     double h_small[18] = {};       // host copy of the 18 intrinsics doubles held in `small` (uploaded only when they change)
