@@ -418,6 +418,16 @@ typedef struct dfvo_track_out {
     int scale_n_valid, scale_n_trials, scale_n_inliers;
     int pnp_found, pnp_inliers, pnp_n_filtered;
 } dfvo_track_out;
+/* Stream placement (dfvo_pipeline_create and dfvo_session_create; df-vo_amd/csrc/stream_pool.hip).  Both objects drive several
+ * HIP streams whose hardware queues should sit on different dispatch pipes of the command processor (two busy streams on one
+ * pipe slow each other's launches 2.5 x).  Which pipe a stream lands on follows the PROCESS's stream creation order, so the
+ * objects create twelve candidates and classify them by a ~10 ms timing probe.  The probe is a measurement:
+ *   - a classification is accepted when it has the shape of a process whose queues are all its own (four groups of three)
+ *     or when two passes agree stream for stream; a positive ("these two share a pipe") has to show twice in a row;
+ *   - when no pass is accepted, or a measurement fails, ONE line goes to stderr and every role keeps a stream in the
+ *     runtime's creation order (slower by up to a third, never wrong);
+ *   - environment: DFVO_STREAM_POOL=creation skips the probe; DFVO_STREAM_PROBE_VERBOSE=1 prints every pass;
+ *     DFVO_STREAM_POOL_FORCE_FAIL=1 (test hook) makes every measurement fail. */
 int dfvo_pipeline_create(const dfvo_pipeline_cfg* cfg, dfvo_pipeline** out);
 void dfvo_pipeline_destroy(dfvo_pipeline* p);
 int dfvo_pipeline_set_flow_param(dfvo_pipeline* p, const char* name, const float* h_data, int ndim, const int* shape);
