@@ -459,6 +459,10 @@ __global__ void k_h_init_to_float(RansacState* st, int max_iters, const double* 
 }
 
 // one lane: subsets with HomographyEstimatorCallback::checkSubset, up to 10000 attempts each
+// (Round 6: the two point sets copied into LDS by 256 threads before lane 0 walks the sampler -- no dependent global reads per
+// draw -- measured no faster: 167 vs 150 us for the first chunk of 128 subsets, profiles/r6t_h_subsets_lds.txt.  The ~1.2 us per
+// subset are the sampler's own dependent arithmetic: four 64-bit modulo draws and checkSubset's collinearity / orientation tests
+// in double.  Reverted.)
 __global__ void k_h_subsets(RansacState* st, int* __restrict__ idx, const float* __restrict__ src,
                             const float* __restrict__ dst, int count_arg, const int* __restrict__ d_n, int it0, int it1) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
