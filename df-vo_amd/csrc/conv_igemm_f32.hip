@@ -24,6 +24,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <tuple>
 #include <type_traits>
 #include <utility>
 #include <vector>

@@ -32,34 +32,32 @@ __device__ __forceinline__ void f16s2_static_for(F&& f) {  // f(integral_constan
 // layer in 972 instead of 1048 (-7 %): above the kill criterion of 175 us, and the price is a second activation format through
 // every producer and consumer of both nets.  Not built; commit "Batched window / halo loads ..." holds the instantiation,
 // profiles/r6k_window_presplit_timing.txt the numbers.)
-template <int WC, int WR, int TC, int TR, int NP = 3>
-__global__ __launch_bounds__(64 * WC * WR, 1) void conv_win_f16s2_kernel(const ConvParams p) {
+// LDS floats of one tile shape (two window buffers)
+template <int WR, int TR>
+constexpr int f16s2_lds_floats() {
+    return 2 * (((WR * TR + 2) * 34 + 1) * 20);
+}
+
+// ONE tile: (32 WC TC) couts from n0 x (WR TR) rows from ty0 x 32 columns from tx0 of sample n.  lds: f16s2_lds_floats<WR, TR>()
+// floats.  (Round 6: the kernel body as a device function, so that a launch can hold tiles of two heights -- see
+// conv_win_f16s2_mix_kernel.)
+template <int WC, int WR, int TC, int TR, int NP>
+__device__ __forceinline__ void conv_win_f16s2_tile(const ConvParams& p, float* __restrict__ lds, const int n, const int ty0,
+                                                    const int tx0, const int n0) {
     constexpr int NT = 64 * WC * WR;
     constexpr int NPL = NP == 3 ? 2 : 1;  // operand planes in use
     constexpr int TH = WR * TR, TW = 32, WH = TH + 2, WW = TW + 2, PS = 20;  // pixel stride in dwords (80 bytes)
-    constexpr int BN = WC * TC * 32;
     constexpr int WIN = (WH * WW + 1) * PS;  // + one pixel slot that absorbs the stores of the items beyond the window
     constexpr int W_ITEMS = WH * WW * 4;
     constexpr int W_CNT = (W_ITEMS + NT - 1) / NT;
     static_assert(W_CNT <= 9, "one window item per tap");
     static_assert(WC * WR == 4, "4 waves per block");
-    __shared__ __attribute__((aligned(16))) float lds[2 * WIN];
+    static_assert(2 * WIN == f16s2_lds_floats<WR, TR>(), "LDS size helper out of step");
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wc = wave / WR, wr = wave % WR;
     const int lp = lane & 31, kb = lane >> 5;
-    const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
-    const int nb = gridDim.x;
-    int bid = blockIdx.x;
-    {  // XCD-aware order: each XCD walks a contiguous run of tiles (neighbours share halo rows in its L2)
-        const int q = nb >> 3, r = nb & 7, xcd = bid & 7, k = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-    }
-    const int n = bid / (tiles_y * tiles_x);
-    const int trem = bid - n * (tiles_y * tiles_x);
-    const int ty0 = (trem / tiles_x) * TH, tx0 = (trem % tiles_x) * TW;
-    const int n0 = blockIdx.y * BN;
     const int nchunk0 = (p.G0 + 3) >> 2, nchunk1 = (p.G1 + 3) >> 2, nchunks = nchunk0 + nchunk1;
 
     // window items of this thread: (pixel, 4-channel group q = t & 3 of the chunk).  Their pixel offsets inside both sources
@@ -269,6 +267,55 @@ __global__ __launch_bounds__(64 * WC * WR, 1) void conv_win_f16s2_kernel(const C
     }
 }
 
+// XCD-aware order of `count` tiles: the hardware hands workgroup b to XCD b & 7; each XCD walks a contiguous run of tiles
+// (neighbours share halo rows in its L2)
+__device__ __forceinline__ int f16s2_xcd_order(int b, int count) {
+    const int q = count >> 3, r = count & 7, xcd = b & 7, k = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+template <int WC, int WR, int TC, int TR, int NP = 3>
+__global__ __launch_bounds__(64 * WC * WR, 1) void conv_win_f16s2_kernel(const ConvParams p) {
+    constexpr int TH = WR * TR, TW = 32, BN = WC * TC * 32;
+    __shared__ __attribute__((aligned(16))) float lds[f16s2_lds_floats<WR, TR>()];
+    const int tiles_x = (p.Wo + TW - 1) / TW, tiles_y = (p.Ho + TH - 1) / TH;
+    const int bid = f16s2_xcd_order(blockIdx.x, gridDim.x);
+    const int n = bid / (tiles_y * tiles_x);
+    const int trem = bid - n * (tiles_y * tiles_x);
+    conv_win_f16s2_tile<WC, WR, TC, TR, NP>(p, lds, n, (trem / tiles_x) * TH, (trem % tiles_x) * TW, blockIdx.y * BN);
+}
+
+// Tiles of TWO heights in one launch (round 6).  One workgroup per CU, 256 CUs: a launch of T equal tiles takes ceil(T / 256)
+// rounds, and at KITTI size the last round is mostly empty -- level-2 64- / 32-cout layers: 836 tiles = 3.27 rounds run as 4,
+// 128-cout: 1140 tiles = 4.45 rounds run as 5.  Here the first rows_a rows of every sample are cut into TRA-row tiles (workgroups
+// [0, na), dispatched first), the rest into TRB-row tiles that fill the CUs as the tall ones finish; launch_f16s2 picks the
+// split by simulating the dispatch.  na_pad = na rounded up to 8 (the pad workgroups exit), so that the XCD of a workgroup is
+// b & 7 in both regions.  Every output pixel is computed by the same instruction sequence whatever tile it falls into:
+// bit-identical to the single-height launches.
+template <int WC, int WR, int TC, int TRA, int TRB, int NP = 3>
+__global__ __launch_bounds__(64 * WC * WR, 1) void conv_win_f16s2_mix_kernel(const ConvParams p, int rows_a, int na, int na_pad,
+                                                                             int nb) {
+    constexpr int THA = WR * TRA, THB = WR * TRB, TW = 32, BN = WC * TC * 32;
+    constexpr int LDSF = f16s2_lds_floats<WR, TRA>() > f16s2_lds_floats<WR, TRB>() ? f16s2_lds_floats<WR, TRA>() : f16s2_lds_floats<WR, TRB>();
+    __shared__ __attribute__((aligned(16))) float lds[LDSF];
+    const int tiles_x = (p.Wo + TW - 1) / TW;
+    const int b = blockIdx.x;
+    if (b < na_pad) {
+        const int tiles_y = rows_a / THA;
+        const int bid = f16s2_xcd_order(b, na_pad);
+        if (bid >= na) return;
+        const int n = bid / (tiles_y * tiles_x);
+        const int trem = bid - n * (tiles_y * tiles_x);
+        conv_win_f16s2_tile<WC, WR, TC, TRA, NP>(p, lds, n, (trem / tiles_x) * THA, (trem % tiles_x) * TW, blockIdx.y * BN);
+    } else {
+        const int tiles_y = (p.Ho - rows_a + THB - 1) / THB;
+        const int bid = f16s2_xcd_order(b - na_pad, nb);
+        const int n = bid / (tiles_y * tiles_x);
+        const int trem = bid - n * (tiles_y * tiles_x);
+        conv_win_f16s2_tile<WC, WR, TC, TRB, NP>(p, lds, n, rows_a + (trem / tiles_x) * THB, (trem % tiles_x) * TW, blockIdx.y * BN);
+    }
+}
+
 template <int WC, int WR, int TC, int TR>
 static long long f16s2_blocks(const ConvParams& p) {
     constexpr int TH = WR * TR, BN = WC * TC * 32;
@@ -303,6 +350,85 @@ static int launch_f16s2_cfg(const ConvParams& p, hipStream_t stream, int cfg_id)
     return DFVO_OK;
 }
 
+template <int WC, int WR, int TC, int TRA, int TRB>
+static int launch_f16s2_mix(const ConvParams& p, hipStream_t stream, int cfg_id, int rows_a) {
+    constexpr int THA = WR * TRA, THB = WR * TRB, BN = WC * TC * 32;
+    const int tiles_x = (p.Wo + 31) / 32;
+    const int na = p.N * (rows_a / THA) * tiles_x, na_pad = (na + 7) & ~7;
+    const int nb = p.N * ((p.Ho - rows_a + THB - 1) / THB) * tiles_x;
+    dim3 grid((unsigned)(na_pad + nb), (unsigned)(p.wf16_cout_pad / BN), 1);
+    ConvProfEntry pe;
+    if (g_prof) {
+        DFVO_HIP_CHECK(hipEventCreate(&pe.e0));
+        DFVO_HIP_CHECK(hipEventCreate(&pe.e1));
+        pe.cfg = cfg_id;
+        DFVO_HIP_CHECK(hipEventRecord(pe.e0, stream));
+    }
+    if (p.f16_terms == 1)
+        hipLaunchKernelGGL((conv_win_f16s2_mix_kernel<WC, WR, TC, TRA, TRB, 1>), grid, dim3(64 * WC * WR), 0, stream, p, rows_a, na, na_pad, nb);
+    else
+        hipLaunchKernelGGL((conv_win_f16s2_mix_kernel<WC, WR, TC, TRA, TRB, 3>), grid, dim3(64 * WC * WR), 0, stream, p, rows_a, na, na_pad, nb);
+    DFVO_HIP_CHECK(hipGetLastError());
+    if (g_prof) {
+        DFVO_HIP_CHECK(hipEventRecord(pe.e1, stream));
+        pe.flops = p.useful_flops;
+        const int sh[12] = {p.N, p.H, p.W, p.Ho, p.Wo, (p.G0 + p.G1) * 4, p.cout, p.kh, p.stride, (int)grid.x, (int)grid.y, 2};
+        for (int i = 0; i < 12; ++i) pe.shape[i] = sh[i];
+        g_prof->push_back(pe);
+    }
+    return DFVO_OK;
+}
+
+// Greedy dispatch of `ca` tiles of cost `wa` followed by `cb` tiles of cost `wb` onto 256 CUs (one workgroup per CU): the time
+// the last CU finishes.  What the hardware does with a launch of this skeleton, to the accuracy of "a tile costs its rows".
+static double f16s2_makespan(long long ca, double wa, long long cb, double wb) {
+    const int ncu = 256;
+    std::vector<double> h(ncu, 0.0);  // min-heap on finish times
+    auto cmp = [](double x, double y) { return x > y; };
+    for (long long i = 0; i < ca + cb; ++i) {
+        std::pop_heap(h.begin(), h.end(), cmp);
+        h.back() += i < ca ? wa : wb;
+        std::push_heap(h.begin(), h.end(), cmp);
+    }
+    return *std::max_element(h.begin(), h.end());
+}
+
+// rows_a of the best launch for tiles of th3 (TR = 3) and th2 (TR = 2) rows: 0 = all th2, >= Ho = all th3, else the mixed launch
+// (taken only where the simulation promises more than 3 % over the better single height).  Cached per shape: the eager
+// (graph-less) path asks at every launch.
+static int f16s2_pick_rows_a(const ConvParams& p, int th3, int th2, int ny, bool allow_mix) {
+    if (ny != 1) allow_mix = false;  // (several cout blocks: blockIdx.y advances last, the two heights would alternate per block)
+    struct Key { int ho, per_row, th3, mix; bool operator<(const Key& o) const { return std::tie(ho, per_row, th3, mix) < std::tie(o.ho, o.per_row, o.th3, o.mix); } };
+    static std::map<Key, int> cache;
+    static std::mutex mu;
+    const int per_row = p.N * ((p.Wo + 31) / 32) * ny;
+    const Key key{p.Ho, per_row, th3, allow_mix ? 1 : 0};
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = cache.find(key);
+        if (it != cache.end()) return it->second;
+    }
+    const double w3 = th3, w2 = th2 * 1.1;  // (small tiles: fewer MFMAs per load)
+    const double pure3 = f16s2_makespan((long long)((p.Ho + th3 - 1) / th3) * per_row, w3, 0, w2);
+    const double pure2 = f16s2_makespan(0, w3, (long long)((p.Ho + th2 - 1) / th2) * per_row, w2);
+    int best_rows = pure3 <= pure2 ? p.Ho : 0;
+    double best = pure3 <= pure2 ? pure3 : pure2;
+    if (allow_mix) {
+        const double need = best * 0.97;
+        for (int a = 1; a * th3 < p.Ho; ++a) {
+            const int rest = p.Ho - a * th3;
+            const double m = f16s2_makespan((long long)a * per_row, w3, (long long)((rest + th2 - 1) / th2) * per_row, w2);
+            if (m < need && m < best) {
+                best = m;
+                best_rows = a * th3;
+            }
+        }
+    }
+    std::lock_guard<std::mutex> g(mu);
+    cache[key] = best_rows;
+    return best_rows;
+}
+
 // Tile choice for the one-wave-per-SIMD skeleton (one workgroup per CU): the rows per tile that minimise
 // rounds x rows for the layer's grid among the instantiated shapes.  Returns F16S2_NOT_APPLICABLE (positive: every
 // DFVO_ERR_* code is negative) when the layer should stay on the first
@@ -315,29 +441,31 @@ constexpr int F16S2_NOT_APPLICABLE = 1;
 static int launch_f16s2(const ConvParams& p, hipStream_t stream, int cfg_id) {
     // (per layer the two skeletons are within 2 % of each other; inside the pipeline this one gives +3 % pairs/s: half the
     // resident net waves next to the solver's kernels -- round 3)
-    const int ncu = 256;
-    auto cost = [&](long long blocks, int rows) { return blocks <= 0 ? (1LL << 60) : ((blocks + ncu - 1) / ncu) * rows; };
-    // (Round 6: the maps too small for the wide tiles -- pyramid level 4, the depth decoder's middle layers: 105-212 tiles -- on
-    // this skeleton's 8- / 12-row x 32-cout tiles instead of the first skeleton's 4-row tile: 27.3-29.5 vs 29.4 us on the level-4
-    // 128 -> 128 layer, 37.4-38.0 vs 42.0 on 96+98 -> 128, every other shape equal -- profiles/r6l_small_map_tiles.txt.  These
-    // launches are chains of 72 taps at ~0.35 us, the L2 latency of a tap's weight fragments with 3-6 MFMAs to cover it; the
-    // tile shape does not change that.  Not adopted.)
+    // DFVO_WIN_MIX=0: single-height launches only (the round 3-5 rule: the height that minimises rounds x rows)
+    static const bool mix_env = !(getenv("DFVO_WIN_MIX") && atoi(getenv("DFVO_WIN_MIX")) == 0);
+    // (the f16 mode's two-row shapes run two workgroups per CU: like the 32-cout layers below they keep single heights)
+    const bool mix_ok = mix_env && p.f16_terms != 1;
     if (p.wf16_cout_pad % 128 == 0) {
         // (an 8-row tile -- 256 accumulator registers -- does not fit: the allocator spills inside the tap loop)
-        const long long b3 = f16s2_blocks<2, 2, 2, 3>(p), b2 = f16s2_blocks<2, 2, 2, 2>(p);
-        if (b2 < 200) return F16S2_NOT_APPLICABLE;
-        const long long c3 = cost(b3, 6), c2 = cost(b2, 4) * 11 / 10;  // (small tiles: fewer MFMAs per load)
-        if (c3 <= c2) return launch_f16s2_cfg<2, 2, 2, 3>(p, stream, cfg_id);
-        return launch_f16s2_cfg<2, 2, 2, 2>(p, stream, cfg_id);
+        if (f16s2_blocks<2, 2, 2, 2>(p) < 200) return F16S2_NOT_APPLICABLE;
+        const int ra = f16s2_pick_rows_a(p, 6, 4, p.wf16_cout_pad / 128, mix_ok);
+        if (ra >= p.Ho) return launch_f16s2_cfg<2, 2, 2, 3>(p, stream, cfg_id);
+        if (ra <= 0) return launch_f16s2_cfg<2, 2, 2, 2>(p, stream, cfg_id);
+        return launch_f16s2_mix<2, 2, 2, 3, 2>(p, stream, cfg_id, ra);
     }
     if (p.wf16_cout_pad % 64 == 0) {
-        const long long b3 = f16s2_blocks<1, 4, 2, 3>(p), b2 = f16s2_blocks<1, 4, 2, 2>(p);
-        if (b2 < 200) return F16S2_NOT_APPLICABLE;
-        if (cost(b3, 12) <= cost(b2, 8)) return launch_f16s2_cfg<1, 4, 2, 3>(p, stream, cfg_id);
-        return launch_f16s2_cfg<1, 4, 2, 2>(p, stream, cfg_id);
+        if (f16s2_blocks<1, 4, 2, 2>(p) < 200) return F16S2_NOT_APPLICABLE;
+        const int ra = f16s2_pick_rows_a(p, 12, 8, p.wf16_cout_pad / 64, mix_ok);
+        if (ra >= p.Ho) return launch_f16s2_cfg<1, 4, 2, 3>(p, stream, cfg_id);
+        if (ra <= 0) return launch_f16s2_cfg<1, 4, 2, 2>(p, stream, cfg_id);
+        return launch_f16s2_mix<1, 4, 2, 3, 2>(p, stream, cfg_id, ra);
     }
+    // 32-cout layers: single heights only.  Their 8-row shape needs 198 registers and runs TWO workgroups per CU; inside a mixed
+    // launch it would carry the 12-row shape's 262 and run one (measured: 64 -> 32 44 -> 52 us, 32 -> 32 31 -> 34,
+    // profiles/r6u_window_mixed_tiles.txt).
     const long long b3 = f16s2_blocks<1, 4, 1, 3>(p), b2 = f16s2_blocks<1, 4, 1, 2>(p);
     if (b2 < 200) return F16S2_NOT_APPLICABLE;
+    auto cost = [&](long long blocks, int rows) { return blocks <= 0 ? (1LL << 60) : ((blocks + 255) / 256) * rows; };
     if (cost(b3, 12) <= cost(b2, 8)) return launch_f16s2_cfg<1, 4, 1, 3>(p, stream, cfg_id);
     return launch_f16s2_cfg<1, 4, 1, 2>(p, stream, cfg_id);
 }
