@@ -443,6 +443,12 @@ static int launch_f16s2(const ConvParams& p, hipStream_t stream, int cfg_id) {
     // resident net waves next to the solver's kernels -- round 3)
     // DFVO_WIN_MIX=0: single-height launches only (the round 3-5 rule: the height that minimises rounds x rows)
     static const bool mix_env = !(getenv("DFVO_WIN_MIX") && atoi(getenv("DFVO_WIN_MIX")) == 0);
+    static const int force_tr = getenv("DFVO_WIN_FORCE_TR") ? atoi(getenv("DFVO_WIN_FORCE_TR")) : 0;  // (calibration hook: 2 / 3)
+    if (force_tr == 2 || force_tr == 3) {
+        if (p.wf16_cout_pad % 128 == 0) return force_tr == 3 ? launch_f16s2_cfg<2, 2, 2, 3>(p, stream, cfg_id) : launch_f16s2_cfg<2, 2, 2, 2>(p, stream, cfg_id);
+        if (p.wf16_cout_pad % 64 == 0) return force_tr == 3 ? launch_f16s2_cfg<1, 4, 2, 3>(p, stream, cfg_id) : launch_f16s2_cfg<1, 4, 2, 2>(p, stream, cfg_id);
+        return force_tr == 3 ? launch_f16s2_cfg<1, 4, 1, 3>(p, stream, cfg_id) : launch_f16s2_cfg<1, 4, 1, 2>(p, stream, cfg_id);
+    }
     // (the f16 mode's two-row shapes run two workgroups per CU: like the 32-cout layers below they keep single heights)
     const bool mix_ok = mix_env && p.f16_terms != 1;
     if (p.wf16_cout_pad % 128 == 0) {
