@@ -376,3 +376,48 @@ def test_conv_small_maps_with_k_divided_over_workgroups(gpu):
                        env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stdout[-3000:]
     assert "14 passed" in r.stdout, r.stdout[-500:]  # seven cases x two precisions
+
+
+# ---- round 6: window launches with tiles of two heights are bit-identical to single-height launches ---------------------
+_MIX_WORKER = r'''
+import importlib, os, sys, zlib
+import numpy as np, torch
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+importlib.import_module("df-vo_amd")
+capi = importlib.import_module("df-vo_amd.capi")
+from test_ops_gpu import run_conv
+capi.check(capi.lib().dfvo_set_conv_precision(b"f16x3"))
+g = torch.Generator().manual_seed(11)
+# shapes whose single-height launch leaves a mostly empty last round (so that the mixed rule fires), odd heights, 1-3 samples,
+# one- and two-source layers, 64 and 128 couts, reflection padding + nearest-x2 upsampled first source (the depth decoder's form)
+for name, n, h, w, c0, c1, cout, pad_mode, up0 in [("a", 2, 176, 608, 128, 0, 64, 0, 0), ("b", 2, 176, 608, 64, 66, 128, 0, 0), ("c", 1, 203, 640, 64, 0, 64, 0, 0),
+                                                 ("d", 3, 131, 333, 32, 16, 128, 0, 0), ("e", 1, 96, 320, 64, 64, 64, 1, 1), ("f", 2, 181, 500, 49, 0, 128, 0, 0)]:
+    hs, ws = (h // 2, w // 2) if up0 else (h, w)
+    x0 = torch.randn(n, c0, hs, ws, generator=g)
+    x1 = torch.randn(n, c1, h, w, generator=g) if c1 else None
+    wt = torch.randn(cout, c0 + c1, 3, 3, generator=g) * 0.05
+    out = run_conv(capi, x0, wt, torch.randn(cout, generator=g), 1, (1, 1), pad_mode, 1, 0.1, x1=x1, up0=up0)
+    print("CRC", name, "%%08x" %% (zlib.crc32(out.numpy().tobytes()) & 0xffffffff), flush=True)
+assert capi.f16s_overflow_count() == 0
+'''
+
+
+def test_mixed_height_window_launches_are_bit_identical(gpu, tmp_path):
+    """conv_win_f16s2_mix_kernel (csrc/conv_win_f16s2.h, round 6): tall tiles for the first rows of every sample, short ones for
+    the rest, in ONE launch.  Every output pixel runs the same instruction sequence whatever tile it falls into, so the layer's
+    output must equal the single-height launch's bit for bit: the same six layers with DFVO_WIN_MIX=1 (default) and =0, and on
+    three-row / two-row tiles only (DFVO_WIN_FORCE_TR), in separate processes (the switches are read once)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "mix_worker.py"
+    script.write_text(_MIX_WORKER % {"root": root})
+    crcs = {}
+    for tag, env in (("mix", {"DFVO_WIN_MIX": "1"}), ("single", {"DFVO_WIN_MIX": "0"}), ("tr3", {"DFVO_WIN_FORCE_TR": "3"}), ("tr2", {"DFVO_WIN_FORCE_TR": "2"})):
+        r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+        crcs[tag] = [ln.split()[1:] for ln in r.stdout.splitlines() if ln.startswith("CRC")]
+        assert len(crcs[tag]) == 6, r.stdout
+    print("   ", crcs["mix"])
+    assert crcs["mix"] == crcs["single"] == crcs["tr3"] == crcs["tr2"]
